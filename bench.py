@@ -1,0 +1,230 @@
+#!/usr/bin/env python
+"""bench.py -- rendered Mpixels/s (forward + backward) of the MI355X rasteriser.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is one forward + backward pass of the drop-in operator over one synthetic frame with the
+inputs already resident in HBM.  Default workload = the configuration BASELINE.json's metric is
+quoted on: 1e6 random-init Gaussians, 1920x1080 -> rendered at 1920x1072 (the reference asserts
+H % 16 == 0 and its data path crops, RAS:1193-1194, ImagePoseDataset.py:86-88), SH degree 3.
+N > 1: the same frame is sharded over interleaved 16-pixel tile rows (one process per GPU,
+RCCL all-gather of the rendered rows + all-reduce of the per-Gaussian gradient accumulators), so the
+scaling is STRONG: total work is fixed, value = frame pixels / max-over-ranks step time.
+
+Rank 0 prints ONE JSON line.  Besides the contract fields it carries
+  roofline     : achieved algorithmic HBM GB/s of the dominant kernel vs the 8 TB/s peak, measured
+                 live with HIP events on the launch stream (plus all stage times and the whole-path figure)
+  cpu_baseline : the CPU oracle (a from-source port of the reference kernels; the reference itself
+                 cannot run here -- taichi is absent and its kernels are CUDA-only) timed on this
+                 box's host cores on one full frame of the same workload.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def algorithmic_bytes(n, m, k, p):
+    """Compulsory HBM bytes per launch of each stage: every
+    stage input read once, every output written once; N points, M visible, K (tile,Gaussian) pairs,
+    P pixels."""
+    return {
+        "filter_compact": 18 * n + 4 * m,
+        "preprocess": 244 * m + 16 * m + 48 * m + 8 * m + 4 * m,   # row+xyz+ids+obj, q write, attrs, counts
+        "scan_block_sums": 8 * (m // 256 + 1),
+        "make_keys": 32 * m + 12 * k,
+        "sort_pairs": 24 * k,
+        "tile_ranges": 8 * k,
+        "blend_forward": 48 * k + 28 * p,
+        "blend_backward": 44 * k + 28 * p + 48 * m,
+        "point_backward": 244 * m + 48 * m + 248 * n,
+    }
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="headline_1m_1080p")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-stage-profile", action="store_true")
+    args = ap.parse_args()
+
+    import torch.distributed as dist
+    from taichi_3d_gaussian_splatting_amd import CameraInfo, GaussianPointCloudRasterisation as Op
+    from taichi_3d_gaussian_splatting_amd import hip_ops
+    from taichi_3d_gaussian_splatting_amd.distributed import shard_rasteriser_across_tile_rows
+    from taichi_3d_gaussian_splatting_amd.synthetic import make_config_scene, make_grad_image
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    assert torch.cuda.is_available(), "bench.py needs HIP devices"
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=device)  # nccl == RCCL on ROCm
+
+    host_scene = make_config_scene(args.workload)
+    s = host_scene.to(device)
+    grad_image = make_grad_image(s.height, s.width).to(device)
+    cfg = Op.GaussianPointCloudRasterisationConfig(near_plane=s.near_plane, far_plane=s.far_plane,
+                                                   depth_to_sort_key_scale=s.depth_to_sort_key_scale)
+    op = Op(cfg)
+    if world > 1:
+        shard_rasteriser_across_tile_rows(op)
+    xyz = s.point_cloud.clone().requires_grad_(True)
+    feat = s.point_cloud_features.clone().requires_grad_(True)
+    cam = CameraInfo(camera_intrinsics=s.camera_intrinsics, camera_height=s.height, camera_width=s.width, camera_id=0)
+    inp = Op.GaussianPointCloudRasterisationInput(
+        point_cloud=xyz, point_cloud_features=feat, point_object_id=s.point_object_id,
+        point_invalid_mask=s.point_invalid_mask, camera_info=cam, q_pointcloud_camera=s.q_pointcloud_camera,
+        t_pointcloud_camera=s.t_pointcloud_camera, color_max_sh_band=3)
+
+    def step():
+        xyz.grad = None
+        feat.grad = None
+        image, depth, count = op(inp)
+        image.backward(grad_image)
+        return image
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ms_per_step = 1e3 * elapsed / args.steps
+    pixels = s.height * s.width
+    value = pixels / 1e6 / (ms_per_step / 1e3)
+
+    # ---------------------------------------------------------------- per-stage timing (rank-local)
+    n = s.point_cloud.shape[0]
+    roofline, stages_ms, sizes = None, {}, {}
+    if not args.no_stage_profile:
+        rb, rs = op.tile_row_begin, op.tile_row_step
+        ev = lambda: torch.cuda.Event(enable_timing=True)  # noqa: E731  (events on torch's current stream,
+        reps = max(3, min(args.steps, 10))                 #  the stream every kernel is launched on)
+        acc_ms = {}
+
+        def timed(name, fn):
+            a, b = ev(), ev()
+            a.record()
+            out = fn()
+            b.record()
+            acc_ms.setdefault(name, []).append((a, b))
+            return out
+
+        num_tiles = (s.width // 16) * (s.height // 16)
+        db, tb = hip_ops.sort_key_bits(s.near_plane, s.far_plane, s.depth_to_sort_key_scale, num_tiles)
+        q_cp, t_cp = hip_ops.pose_inverse(s.q_pointcloud_camera, s.t_pointcloud_camera)
+        for _ in range(reps):
+            f = feat.detach()
+            _, ids, counters = timed("filter_compact", lambda: hip_ops.filter_compact(
+                s.point_cloud, s.point_invalid_mask, s.point_object_id, s.camera_intrinsics, q_cp, t_cp,
+                s.near_plane, s.far_plane, s.width, s.height))
+            attrs, ntiles, nowned, bsums = timed("preprocess", lambda: hip_ops.preprocess(
+                s.point_cloud, f, s.point_object_id, s.camera_intrinsics, q_cp, t_cp, ids, s.width, s.height, rb, rs))
+            k = timed("scan_block_sums", lambda: hip_ops.scan_block_sums(bsums, counters))
+            keys, payload = timed("make_keys", lambda: hip_ops.make_keys(
+                attrs, nowned, bsums, k, s.width, s.height, s.depth_to_sort_key_scale, rb, rs))
+            timed("sort_pairs", lambda: hip_ops.sort_pairs(keys, payload, db, tb))
+            start, end = timed("tile_ranges", lambda: hip_ops.tile_ranges(keys, num_tiles))
+            image, depth, acc_alpha, last_eff, count = timed("blend_forward", lambda: hip_ops.blend_forward(
+                start, end, payload, attrs, s.width, s.height, rb, rs))
+            acc, mag = timed("blend_backward", lambda: hip_ops.blend_backward(
+                start, end, payload, attrs, grad_image, acc_alpha, last_eff, s.width, s.height, rb, rs))
+            timed("point_backward", lambda: hip_ops.point_backward(
+                s.point_cloud, f, s.point_object_id, s.camera_intrinsics, q_cp, t_cp, s.t_pointcloud_camera, ids,
+                acc, 3, cfg.grad_q_factor, cfg.grad_s_factor, cfg.grad_alpha_factor, cfg.grad_color_factor,
+                cfg.grad_high_order_color_factor, False))
+        torch.cuda.synchronize()
+        m = int(ids.shape[0])
+        sizes = {"N": n, "M": m, "K": int(k), "P": pixels, "tiles": num_tiles}
+        stages_ms = {name: sum(a.elapsed_time(b) for a, b in pairs[1:]) / max(len(pairs) - 1, 1)
+                     for name, pairs in acc_ms.items()}
+        p_owned = pixels if world == 1 else pixels * len(range(rb, s.height // 16, rs)) / (s.height // 16)
+        bytes_per = algorithmic_bytes(n, m, int(k), p_owned)
+        dominant = max(stages_ms, key=stages_ms.get)
+        achieved = bytes_per[dominant] / (stages_ms[dominant] * 1e-3) / 1e9
+        path_bytes = sum(bytes_per.values())
+        roofline = {
+            "bound": "hbm", "kernel": dominant, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+            "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+            "kernel_ms": round(stages_ms[dominant], 4),
+            "algorithmic_bytes": int(bytes_per[dominant]),
+            "path": {"algorithmic_bytes": int(path_bytes),
+                     "achieved": round(path_bytes / (ms_per_step * 1e-3) / 1e9, 2),
+                     "frac": round(path_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)},
+            "stages_ms": {k_: round(v, 4) for k_, v in stages_ms.items()},
+            "note": "blend kernels are VALU/LDS/atomic-bound by construction (DESIGN.md section 5)",
+        }
+
+    # ---------------------------------------------------------------- CPU baseline (rank 0, N == 1)
+    cpu_baseline = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import gs_oracle as O
+        O.build()
+        hs = host_scene
+        t0 = time.perf_counter()
+        f = O.forward(hs.point_cloud.numpy(), hs.point_cloud_features.numpy(), hs.point_invalid_mask.numpy(),
+                      hs.point_object_id.numpy(), hs.camera_intrinsics.numpy(), hs.q_pointcloud_camera.numpy(),
+                      hs.t_pointcloud_camera.numpy(), hs.height, hs.width, near_plane=hs.near_plane,
+                      far_plane=hs.far_plane, depth_to_sort_key_scale=hs.depth_to_sort_key_scale)
+        t1 = time.perf_counter()
+        O.backward(f, grad_image.cpu().numpy(), 3)
+        t2 = time.perf_counter()
+        cpu_baseline = {
+            "value": round(pixels / 1e6 / (t2 - t0), 4), "unit": "Mpixels/s", "cores": O.num_threads(),
+            "kind": "port",
+            "sample": f"1 full frame of the same workload ({args.workload}): forward {t1 - t0:.2f} s + "
+                      f"backward {t2 - t1:.2f} s, OpenMP fp32 C oracle",
+            "host_cpus": os.cpu_count(),
+        }
+
+    if rank == 0:
+        out = {
+            "metric": "rendered Mpixels/s (fwd+bwd), 1e6 Gaussians @1920x1080",
+            "value": round(value, 3), "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": args.workload, "gaussians": n, "image": f"{s.width}x{s.height}",
+                       "sh_degree": 3, "sharding": "none" if world == 1 else f"tile-rows/{world}",
+                       **sizes},
+            "roofline": roofline, "cpu_baseline": cpu_baseline,
+        }
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

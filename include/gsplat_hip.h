@@ -1,0 +1,145 @@
+/*
+ * gsplat_hip.h -- C ABI of the MI355X (gfx950) differentiable 3D-Gaussian-splatting rasteriser.
+ *
+ * This is the drop-in boundary for the hot path of wanmeihuali/taichi_3d_gaussian_splatting:
+ * each entry point replaces one stage of the reference operator
+ *   RAS = taichi_3d_gaussian_splatting/GaussianPointCloudRasterisation.py
+ * (kernel or torch glue, cited per function).  The reference has no FFI of its own (its kernels
+ * are Taichi JIT functions called with torch tensors, RAS:848-997,1069-1100); a host binds these
+ * symbols with ctypes/cffi and passes raw device pointers -- see INTEGRATION.md.
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer unless the parameter name starts with `host_`;
+ *  - the caller owns every buffer (the library never allocates device memory and keeps no
+ *    global mutable state); scratch buffers are sized with the *_workspace_bytes queries;
+ *  - `stream` is a hipStream_t passed as void*; work is enqueued, never synchronised, except in
+ *    gs_read_counters (the two size read-backs the reference also performs, RAS:870,916);
+ *  - return value: 0 on success, negative on error; gs_last_error() gives the (thread-local)
+ *    message.  Nothing throws across the boundary;
+ *  - fp32 everywhere, quaternions (x,y,z,w), row-major matrices, image memory [v,u,c].
+ *
+ * Packed per-visible-point record `attrs` (float[M][12], 48 B, 16-B aligned), produced by
+ * gs_preprocess and gathered by the blend kernels:
+ *   [0] u  [1] v  [2] z (camera depth)  [3] opacity sigmoid(logit)
+ *   [4] conic A  [5] conic B  [6] conic C  [7] rescale          (UTL:257-272)
+ *   [8] r  [9] g  [10] b  [11] 3-sigma radius                   (RAS:302-315)
+ * Backward accumulators `acc` (float[M][12]):
+ *   [0..1] dL/duv  [2..4] dL/dcov(00,01,11)  [5..7] dL/drgb  [8] dL/dlogit
+ *   [9] sum of |dL/duv| norms  [10] number of affected pixels (int32 bits)  [11] unused
+ */
+#ifndef GSPLAT_HIP_H
+#define GSPLAT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GS_TILE_WIDTH 16      /* RAS:27 */
+#define GS_TILE_HEIGHT 16     /* RAS:28 */
+#define GS_BOUNDARY_TILES 3   /* RAS:26 */
+#define GS_ATTR_STRIDE 12
+#define GS_ACC_STRIDE 12
+#define GS_FEATURE_DIM 56     /* RAS:214-226 */
+
+/* counters[] slots written by the library (int32, device) */
+#define GS_COUNTER_NUM_VISIBLE 0   /* M */
+#define GS_COUNTER_NUM_KEYS 1      /* K (saturates at INT32_MAX) */
+#define GS_NUM_COUNTERS 8
+
+const char *gs_last_error(void);
+int gs_abi_version(void);
+
+/* Camera<-pointcloud pose from pointcloud<-camera pose.  Replaces inverse_SE3_qt_torch,
+ * UTL:426-432 as called at RAS:845-846.  n_obj rows. */
+int gs_pose_inverse(const float *q_pointcloud_camera, const float *t_pointcloud_camera,
+                    float *q_camera_pointcloud, float *t_camera_pointcloud, int n_obj, void *stream);
+
+/* Frustum test + order-preserving stream compaction.  Replaces filter_point_in_camera
+ * (RAS:31-78) and the mask -> index torch glue (RAS:841-870).
+ * out: mask int8[N], ids int32[N] (first M valid, ascending), counters[GS_COUNTER_NUM_VISIBLE]=M. */
+size_t gs_filter_workspace_bytes(int n_points);
+int gs_filter_compact(const float *xyz, const int8_t *invalid_mask, const int32_t *object_id,
+                      const float *intrinsics, const float *q_camera_pointcloud,
+                      const float *t_camera_pointcloud, int n_points, float near_plane,
+                      float far_plane, int width, int height, int8_t *mask, int32_t *ids,
+                      int32_t *counters, void *workspace, void *stream);
+
+/* Blocking read of the device counters into host memory (host sync, as RAS:870,916). */
+int gs_read_counters(const int32_t *counters, int32_t *host_counters, int n, void *stream);
+
+/* Per-visible-point projection.  Replaces generate_point_attributes_in_camera_plane
+ * (RAS:239-315, incl. the in-place quaternion normalisation RAS:196-205) and
+ * generate_num_overlap_tiles (RAS:106-128).  Also emits per-256-point partial sums of the
+ * tile counts (block_sums int32[ceil(M/256)]) for the scan.  tile_row_begin/tile_row_step
+ * restrict the tile box to the tile rows  r = begin + k*step  owned by this GPU (1 GPU: 0,1);
+ * num_overlap_tiles (hook output, RAS:1136) is always the full box count and
+ * num_owned_tiles the count restricted to owned rows (the one that is scanned). */
+int gs_preprocess(const float *xyz, float *features, const int32_t *object_id,
+                  const float *intrinsics, const float *q_camera_pointcloud,
+                  const float *t_camera_pointcloud, const int32_t *ids, int n_visible,
+                  int width, int height, int tile_row_begin, int tile_row_step,
+                  float *attrs, int32_t *num_overlap_tiles, int32_t *num_owned_tiles,
+                  int32_t *block_sums, void *stream);
+
+/* Exclusive scan of the per-block sums (in place) and total -> counters[GS_COUNTER_NUM_KEYS].
+ * Replaces torch.cumsum/cat, RAS:913-922. */
+int gs_scan_block_sums(int32_t *block_sums, int n_blocks, int32_t *counters, void *stream);
+
+/* Sort-key generation.  Replaces generate_point_sort_key_by_num_overlap_tiles (RAS:131-172).
+ * keys[k] = (tile_id << 32) + int32(z * depth_scale), payload[k] = offset into the visible list. */
+int gs_make_keys(const float *attrs, const int32_t *num_owned_tiles, const int32_t *block_offsets,
+                 int n_visible, int width, int height, int tile_row_begin, int tile_row_step,
+                 float depth_scale, uint64_t *keys, int32_t *payload, void *stream);
+
+/* Stable LSD radix sort of (key, payload) pairs on the bit ranges [0,depth_bits) and
+ * [32,32+tile_bits) of the key; depth_bits = 64 sorts the whole key as a signed int64.
+ * Replaces torch.sort + gather (RAS:947-950) with the stable tie rule.  Result is left in
+ * keys/payload (keys_alt/payload_alt are scratch of the same size). */
+size_t gs_sort_workspace_bytes(int64_t n_keys);
+int gs_sort_pairs(uint64_t *keys, int32_t *payload, uint64_t *keys_alt, int32_t *payload_alt,
+                  int64_t n_keys, int depth_bits, int tile_bits, void *workspace, void *stream);
+
+/* Per-tile [start,end) ranges.  Replaces find_tile_start_and_end (RAS:175-193) including the
+ * zero-initialisation of RAS:954-957. */
+int gs_tile_ranges(const uint64_t *keys_sorted, int64_t n_keys, int32_t *tile_start,
+                   int32_t *tile_end, int n_tiles, void *stream);
+
+/* Front-to-back alpha blending.  Replaces gaussian_point_rasterisation (RAS:318-485).
+ * Tiles with tile row not in {begin + k*step} are skipped (their pixels are left untouched).
+ * All five outputs are always written for owned tiles (also when n_keys == 0: zeros). */
+int gs_blend_forward(const int32_t *tile_start, const int32_t *tile_end, const int32_t *payload,
+                     const float *attrs, int width, int height, int tile_row_begin,
+                     int tile_row_step, float *image, float *depth, float *acc_alpha,
+                     int32_t *last_effective, int32_t *valid_count, void *stream);
+
+/* Backward per-pixel pass.  Replaces the pixel loop of gaussian_point_rasterisation_backward
+ * (RAS:531-705).  acc (float[M][12]) is zeroed by the library, then accumulated. */
+int gs_blend_backward(const int32_t *tile_start, const int32_t *tile_end, const int32_t *payload,
+                      const float *attrs, const float *grad_image, const float *acc_alpha,
+                      const int32_t *last_effective, int n_visible, int width, int height,
+                      int tile_row_begin, int tile_row_step, float *acc, float *magnitude_image,
+                      void *stream);
+
+/* Backward per-point pass + gradient post-processing.  Replaces the per-point loop of
+ * gaussian_point_rasterisation_backward (RAS:707-772), the dense zero-initialisation
+ * (RAS:1051-1053), _clear_grad_by_color_max_sh_band (RAS:1167-1182) and the factor scaling
+ * (RAS:1105-1125; factors are the frozen class attributes RAS:782-786, passed explicitly).
+ * grad_xyz float[N][3] and grad_features float[N][56] are fully written (zeros for rows that
+ * are not visible).  The optional compact outputs (may be NULL) are the hook gathers of
+ * RAS:1130-1134: grad_xyz_visible float[M][3], grad_features_visible float[M][56]. */
+int gs_point_backward(const float *xyz, const float *features, const int32_t *object_id,
+                      const float *intrinsics, const float *q_camera_pointcloud,
+                      const float *t_camera_pointcloud, const float *t_pointcloud_camera,
+                      const int32_t *ids, int n_visible, int n_points, const float *acc,
+                      int color_max_sh_band, float grad_q_factor, float grad_s_factor,
+                      float grad_alpha_factor, float grad_color_factor,
+                      float grad_high_order_color_factor, float *grad_xyz, float *grad_features,
+                      float *grad_xyz_visible, float *grad_features_visible, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GSPLAT_HIP_H */

@@ -1,0 +1,199 @@
+"""Drop-in mirror of the reference operator ``GaussianPointCloudRasterisation``.
+
+Reference: ``taichi_3d_gaussian_splatting/GaussianPointCloudRasterisation.py`` (RAS):
+``nn.Module`` + inner ``torch.autograd.Function`` RAS:775-1204, nested dataclasses
+``GaussianPointCloudRasterisationConfig`` RAS:776-786, ``...Input`` RAS:788-804,
+``BackwardValidPointHookInput`` RAS:806-817.  Same names, argument meaning, outputs
+(image[H,W,3] f32, depth[H,W] f32, pixel_valid_point_count[H,W] i32), gradients (dense [N,3] and
+[N,56], ``None`` for the other inputs), hook payload, assertion on the image size, and the same
+side effect (in-place quaternion normalisation of visible rows, RAS:196-205,264).
+
+Every stage runs in the hand-written HIP library behind the C ABI of ``include/gsplat_hip.h``
+(no Taichi, no eager-PyTorch arithmetic, no CPU path).  Where the reference leaves outputs
+uninitialised (no Gaussian on screen, RAS:967-980) this operator returns zeros.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Callable, Optional
+
+import torch
+
+from . import hip_ops
+from .Camera import CameraInfo
+
+BOUNDARY_TILES = 3   # RAS:26
+TILE_WIDTH = 16      # RAS:27
+TILE_HEIGHT = 16     # RAS:28
+
+
+def find_tile_start_and_end(point_in_camera_sort_key: torch.Tensor, tile_points_start: torch.Tensor,
+                            tile_points_end: torch.Tensor) -> None:
+    """Same call shape as the reference kernel RAS:175-193: fills the (pre-zeroed) ranges in place."""
+    start, end = hip_ops.tile_ranges(point_in_camera_sort_key.contiguous(), tile_points_start.shape[0])
+    tile_points_start.copy_(start)
+    tile_points_end.copy_(end)
+
+
+class GaussianPointCloudRasterisation(torch.nn.Module):
+    @dataclass
+    class GaussianPointCloudRasterisationConfig:
+        near_plane: float = 0.8
+        far_plane: float = 1000.
+        depth_to_sort_key_scale: float = 100.
+        rgb_only: bool = False
+        # un-annotated => class attributes, not dataclass fields, exactly as RAS:782-786:
+        # YAML/ctor values for these are ignored by the reference as well.
+        grad_color_factor = 5.
+        grad_high_order_color_factor = 1.
+        grad_s_factor = 0.5
+        grad_q_factor = 1.
+        grad_alpha_factor = 20.
+
+    @dataclass
+    class GaussianPointCloudRasterisationInput:
+        point_cloud: torch.Tensor  # Nx3
+        point_cloud_features: torch.Tensor  # Nx56
+        point_object_id: torch.Tensor  # N, int32, in [0, K-1]
+        point_invalid_mask: torch.Tensor  # N, int8
+        camera_info: CameraInfo
+        q_pointcloud_camera: torch.Tensor  # Kx4 (x,y,z,w), camera -> pointcloud
+        t_pointcloud_camera: torch.Tensor  # Kx3
+        color_max_sh_band: int = 2
+
+    @dataclass
+    class BackwardValidPointHookInput:
+        point_id_in_camera_list: torch.Tensor  # M
+        grad_point_in_camera: torch.Tensor  # Mx3
+        grad_pointfeatures_in_camera: torch.Tensor  # Mx56
+        grad_viewspace: torch.Tensor  # Mx2
+        magnitude_grad_viewspace: torch.Tensor  # M
+        magnitude_grad_viewspace_on_image: torch.Tensor  # HxWx2
+        num_overlap_tiles: torch.Tensor  # M
+        num_affected_pixels: torch.Tensor  # M
+        point_depth: torch.Tensor  # M
+        point_uv_in_camera: torch.Tensor  # Mx2
+
+    def __init__(
+        self,
+        config: "GaussianPointCloudRasterisation.GaussianPointCloudRasterisationConfig",
+        backward_valid_point_hook: Optional[Callable[
+            ["GaussianPointCloudRasterisation.BackwardValidPointHookInput"], None]] = None,
+    ):
+        super().__init__()
+        self.config = config
+        # image-space sharding (multi-GPU): this instance renders tile rows begin, begin+step, ...
+        self.tile_row_begin = 0
+        self.tile_row_step = 1
+        outer = self
+
+        class _module_function(torch.autograd.Function):
+
+            @staticmethod
+            def forward(ctx, pointcloud, pointcloud_features, point_invalid_mask, point_object_id,
+                        q_pointcloud_camera, t_pointcloud_camera, camera_info, color_max_sh_band):
+                cfg = outer.config
+                width, height = camera_info.camera_width, camera_info.camera_height
+                row_begin, row_step = outer.tile_row_begin, outer.tile_row_step
+                if not pointcloud_features.is_contiguous():
+                    raise ValueError("point_cloud_features must be contiguous (it is normalised in place)")
+                if pointcloud_features.dtype != torch.float32 or pointcloud_features.shape[1] != 56:
+                    raise TypeError("point_cloud_features must be float32 [N,56]")
+                xyz = pointcloud.contiguous()
+                invalid = point_invalid_mask.to(torch.int8).contiguous()
+                obj = point_object_id.to(torch.int32).contiguous()
+                intrinsics = camera_info.camera_intrinsics.to(device=xyz.device, dtype=torch.float32).contiguous()
+                q_pc = q_pointcloud_camera.to(torch.float32).contiguous()
+                t_pc = t_pointcloud_camera.to(torch.float32).contiguous()
+
+                # RAS:845  (q,t)_camera<-pointcloud
+                q_cp, t_cp = hip_ops.pose_inverse(q_pc, t_pc)
+                # RAS:848-870  frustum filter + compaction (host sync #1: M)
+                _, ids, counters = hip_ops.filter_compact(
+                    xyz, invalid, obj, intrinsics, q_cp, t_cp, cfg.near_plane, cfg.far_plane, width, height)
+                # RAS:887-911  per-point projection + tile counts
+                attrs, num_overlap_tiles, num_owned_tiles, block_sums = hip_ops.preprocess(
+                    xyz, pointcloud_features, obj, intrinsics, q_cp, t_cp, ids, width, height, row_begin, row_step)
+                # RAS:913-922  scan (host sync #2: K)
+                n_keys = hip_ops.scan_block_sums(block_sums, counters)
+                # RAS:927-945  keys
+                keys, payload = hip_ops.make_keys(attrs, num_owned_tiles, block_sums, n_keys, width, height,
+                                                  cfg.depth_to_sort_key_scale, row_begin, row_step)
+                # RAS:947-950  sort (stable)
+                num_tiles = (width // TILE_WIDTH) * (height // TILE_HEIGHT)
+                depth_bits, tile_bits = hip_ops.sort_key_bits(cfg.near_plane, cfg.far_plane,
+                                                              cfg.depth_to_sort_key_scale, num_tiles)
+                hip_ops.sort_pairs(keys, payload, depth_bits, tile_bits)
+                # RAS:952-964  tile ranges
+                tile_start, tile_end = hip_ops.tile_ranges(keys, num_tiles)
+                del keys
+                # RAS:967-997  blend
+                image, depth, acc_alpha, last_eff, count = hip_ops.blend_forward(
+                    tile_start, tile_end, payload, attrs, width, height, row_begin, row_step)
+                if outer.image_gather is not None:  # multi-GPU: all-gather the tile rows of the other ranks
+                    outer.image_gather([image, depth, count])
+
+                ctx.save_for_backward(xyz, pointcloud_features, payload, ids, tile_start, tile_end, acc_alpha,
+                                      last_eff, num_overlap_tiles, obj, q_cp, t_cp, t_pc, attrs, intrinsics)
+                ctx.camera_info = camera_info
+                ctx.color_max_sh_band = color_max_sh_band
+                ctx.tile_rows = (row_begin, row_step)
+                ctx.mark_non_differentiable(count)
+                return image, depth, count
+
+            @staticmethod
+            def backward(ctx, grad_rasterized_image, grad_rasterized_depth, grad_pixel_valid_point_count):
+                grad_pointcloud = grad_pointcloud_features = None
+                if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:  # RAS:1028
+                    (xyz, features, payload, ids, tile_start, tile_end, acc_alpha, last_eff, num_overlap_tiles,
+                     obj, q_cp, t_cp, t_pc, attrs, intrinsics) = ctx.saved_tensors
+                    cfg = outer.config
+                    camera_info = ctx.camera_info
+                    width, height = camera_info.camera_width, camera_info.camera_height
+                    row_begin, row_step = ctx.tile_rows
+                    hook = backward_valid_point_hook
+                    # RAS:531-705  per-pixel pass
+                    acc, magnitude_image = hip_ops.blend_backward(
+                        tile_start, tile_end, payload, attrs, grad_rasterized_image, acc_alpha, last_eff, width,
+                        height, row_begin, row_step)
+                    if outer.grad_accumulator_reduce is not None:  # multi-GPU: sum partial tile gradients
+                        outer.grad_accumulator_reduce(acc)
+                    # RAS:707-772 + 1102-1125  per-point pass, band clearing and factors fused
+                    grad_pointcloud, grad_pointcloud_features, gx_vis, gf_vis = hip_ops.point_backward(
+                        xyz, features, obj, intrinsics, q_cp, t_cp, t_pc, ids, acc, ctx.color_max_sh_band,
+                        cfg.grad_q_factor, cfg.grad_s_factor, cfg.grad_alpha_factor, cfg.grad_color_factor,
+                        cfg.grad_high_order_color_factor, want_visible=hook is not None)
+                    if hook is not None:  # RAS:1127-1142
+                        hook(GaussianPointCloudRasterisation.BackwardValidPointHookInput(
+                            point_id_in_camera_list=ids,
+                            grad_point_in_camera=gx_vis,
+                            grad_pointfeatures_in_camera=gf_vis,
+                            grad_viewspace=acc[:, 0:2].contiguous(),
+                            magnitude_grad_viewspace=acc[:, 9].contiguous(),
+                            magnitude_grad_viewspace_on_image=magnitude_image,
+                            num_overlap_tiles=num_overlap_tiles,
+                            num_affected_pixels=acc[:, 10].contiguous().view(torch.int32),
+                            point_depth=attrs[:, 2].contiguous(),
+                            point_uv_in_camera=attrs[:, 0:2].contiguous(),
+                        ))
+                return grad_pointcloud, grad_pointcloud_features, None, None, None, None, None, None
+
+        self._module_function = _module_function
+        # multi-GPU hooks installed by distributed.shard_rasteriser_across_tile_rows (None on 1 GPU)
+        self.grad_accumulator_reduce: Optional[Callable[[torch.Tensor], None]] = None
+        self.image_gather: Optional[Callable[[list], None]] = None
+
+    def forward(self, input_data: "GaussianPointCloudRasterisation.GaussianPointCloudRasterisationInput"):
+        camera_info = input_data.camera_info
+        assert camera_info.camera_width % TILE_WIDTH == 0    # RAS:1193
+        assert camera_info.camera_height % TILE_HEIGHT == 0  # RAS:1194
+        return self._module_function.apply(
+            input_data.point_cloud,
+            input_data.point_cloud_features,
+            input_data.point_invalid_mask,
+            input_data.point_object_id,
+            input_data.q_pointcloud_camera,
+            input_data.t_pointcloud_camera,
+            camera_info,
+            input_data.color_max_sh_band,
+        )

@@ -1,0 +1,96 @@
+"""ctypes binding of the gfx950 rasteriser library (C ABI: include/gsplat_hip.h).
+
+The shared library is built in-tree (``csrc/Makefile`` -> ``libgsplat_hip.so`` next to this
+file).  There is NO fallback: if the library is missing or a call fails, a RuntimeError is
+raised -- the product path never routes through PyTorch eager code or the CPU oracle.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+from typing import Optional
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgsplat_hip.so")
+ABI_VERSION = 1
+
+_c = ctypes
+_P = _c.c_void_p
+_I = _c.c_int
+_F = _c.c_float
+_I64 = _c.c_int64
+
+# name -> (restype, argtypes); mirrors include/gsplat_hip.h one to one
+_SIGNATURES = {
+    "gs_last_error": (_c.c_char_p, []),
+    "gs_abi_version": (_I, []),
+    "gs_pose_inverse": (_I, [_P, _P, _P, _P, _I, _P]),
+    "gs_filter_workspace_bytes": (_c.c_size_t, [_I]),
+    "gs_filter_compact": (_I, [_P, _P, _P, _P, _P, _P, _I, _F, _F, _I, _I, _P, _P, _P, _P, _P]),
+    "gs_read_counters": (_I, [_P, _P, _I, _P]),
+    "gs_preprocess": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P]),
+    "gs_scan_block_sums": (_I, [_P, _I, _P, _P]),
+    "gs_make_keys": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _F, _P, _P, _P]),
+    "gs_sort_workspace_bytes": (_c.c_size_t, [_I64]),
+    "gs_sort_pairs": (_I, [_P, _P, _P, _P, _I64, _I, _I, _P, _P]),
+    "gs_tile_ranges": (_I, [_P, _I64, _P, _P, _I, _P]),
+    "gs_blend_forward": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P]),
+    "gs_blend_backward": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P]),
+    "gs_point_backward": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _I, _F, _F, _F, _F, _F,
+                               _P, _P, _P, _P, _P]),
+}
+
+EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+
+_lib: Optional[ctypes.CDLL] = None
+
+
+def build(verbose: bool = False) -> str:
+    """Compile the HIP sources for gfx950 with the in-tree Makefile; returns the .so path."""
+    cmd = ["make", "-C", os.path.join(_HERE, "csrc"), "-j8"]
+    subprocess.run(cmd, check=True, stdout=None if verbose else subprocess.DEVNULL)
+    return LIB_PATH
+
+
+def load() -> ctypes.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: build it with `make -C {os.path.join(_HERE, 'csrc')}` "
+                "(or __graft_entry__.build()).  There is no fallback path.")
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(lib, name)  # AttributeError if the library does not export the symbol
+            fn.restype = res
+            fn.argtypes = args
+        if lib.gs_abi_version() != ABI_VERSION:
+            raise RuntimeError(f"libgsplat_hip.so ABI {lib.gs_abi_version()} != expected {ABI_VERSION}")
+        _lib = lib
+    return _lib
+
+
+def ptr(t: Optional[torch.Tensor]):
+    """Raw device pointer of a contiguous tensor (None -> NULL)."""
+    if t is None:
+        return None
+    if not t.is_contiguous():
+        raise ValueError("the C ABI takes contiguous buffers")
+    return t.data_ptr()
+
+
+def current_stream(device: torch.device) -> int:
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def check(status: int, what: str) -> None:
+    if status != 0:
+        msg = load().gs_last_error().decode("utf-8", "replace")
+        raise RuntimeError(f"{what} failed with status {status}: {msg}")
+
+
+def call(name: str, *args) -> None:
+    check(getattr(load(), name)(*args), name)

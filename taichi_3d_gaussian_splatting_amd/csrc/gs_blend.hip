@@ -1,0 +1,233 @@
+// gs_blend.hip -- per-tile alpha blending, forward and backward, for gfx950 (wave64).
+//
+// Workgroup = one 16x16 tile = 4 wavefronts; lane = pixel (a wave covers 4 rows x 16 columns).
+// The tile's depth-sorted Gaussian list is staged through LDS in batches of 256 packed 48-B
+// records (3 x float4 per Gaussian, gathered with 16-B loads).
+//  forward : front-to-back blend (RAS:318-485, weight UTL:275-284); whole-tile early exit with a
+//            workgroup vote (the reference could not express it, RAS:387-394).
+//  backward: back-to-front traversal (RAS:531-705, gradients UTL:331-348) starting at the
+//            tile's last effective entry; the 10 per-Gaussian partial sums are reduced across
+//            the 64 lanes with DPP row shifts/broadcasts and ONE lane issues the hardware fp32
+//            atomics -- one atomic set per (wave, Gaussian) instead of one per (pixel, Gaussian).
+#include "gs_common.h"
+
+namespace {
+
+constexpr float EPS_ALPHA = (float)(1.0 / 255.0);  // RAS:451
+constexpr float CLAMP_ALPHA = 0.99f;               // RAS:453
+constexpr float STOP_T = 0.0001f;                  // RAS:458
+
+struct TileCoord { int tile_u, tile_v, tile_id; };
+
+// blockIdx -> owned tile.  Consecutive workgroups are dispatched round-robin over the 8 XCDs
+// (block b -> XCD b%8); the remap gives every XCD a contiguous run of tiles so that neighbouring
+// tiles (which share Gaussians) hit the same 4-MiB L2.  Speed only, never correctness.
+__device__ __forceinline__ TileCoord owned_tile(int tw, int row_begin, int row_step) {
+    const int nb = gridDim.x;
+    int b = blockIdx.x;
+    const int chunk = nb / 8;
+    if (b < chunk * 8) b = (b % 8) * chunk + b / 8;
+    TileCoord t;
+    t.tile_u = b % tw;
+    t.tile_v = row_begin + (b / tw) * row_step;
+    t.tile_id = t.tile_u + t.tile_v * tw;
+    return t;
+}
+
+// ------------------------------------------------------------------------------- forward
+__global__ __launch_bounds__(GS_BLOCK) void blend_forward_kernel(
+    const int32_t *__restrict__ tile_start, const int32_t *__restrict__ tile_end,
+    const int32_t *__restrict__ payload, const float4 *__restrict__ attrs, int width, int height, int row_begin,
+    int row_step, float *__restrict__ image, float *__restrict__ depth, float *__restrict__ acc_alpha,
+    int32_t *__restrict__ last_effective, int32_t *__restrict__ valid_count) {
+    __shared__ float4 s_a[GS_BLOCK], s_b[GS_BLOCK], s_c[GS_BLOCK];
+    const int tw = width / GS_TILE_WIDTH;
+    const TileCoord tc = owned_tile(tw, row_begin, row_step);
+    const int tid = threadIdx.x;
+    const int pu = tc.tile_u * GS_TILE_WIDTH + (tid & 15);
+    const int pv = tc.tile_v * GS_TILE_HEIGHT + (tid >> 4);
+    const int start = tile_start[tc.tile_id], end = tile_end[tc.tile_id];
+    const float px = (float)pu + 0.5f, py = (float)pv + 0.5f;
+
+    float T = 1.0f, Cr = 0.f, Cg = 0.f, Cb = 0.f, D = 0.f, Wd = 0.f;
+    int last = start, cnt = 0;
+    bool done = false;
+
+    for (int base = start; base < end; base += GS_BLOCK) {
+        // barrier (protects the LDS batch) + whole-tile early exit vote
+        if (__syncthreads_and(done ? 1 : 0)) break;
+        const int j = base + tid;
+        if (j < end) {
+            const float4 *g = attrs + 3 * (size_t)payload[j];
+            s_a[tid] = g[0];
+            s_b[tid] = g[1];
+            s_c[tid] = g[2];
+        }
+        __syncthreads();
+        const int n = min(GS_BLOCK, end - base);
+        for (int k = 0; k < n && !done; ++k) {
+            const float4 a = s_a[k], b = s_b[k];
+            const float dx = px - a.x, dy = py - a.y;
+            // UTL:275-284
+            const float e = -0.5f * (dx * dx * b.x + dy * dy * b.z) - dx * dy * b.y;
+            float alpha = __expf(e) * b.w * a.w;
+            if (alpha < EPS_ALPHA) continue;
+            alpha = fminf(alpha, CLAMP_ALPHA);
+            const float Tn = T * (1.f - alpha);
+            if (Tn < STOP_T) {  // RAS:458-460: saturated, this Gaussian is not blended
+                done = true;
+                break;
+            }
+            const float4 c = s_c[k];
+            const float wgt = alpha * T;
+            last = base + k + 1;
+            Cr += c.x * wgt; Cg += c.y * wgt; Cb += c.z * wgt;
+            D += a.z * wgt;
+            Wd += wgt;
+            cnt += 1;
+            T = Tn;
+        }
+    }
+    const size_t p = (size_t)pv * width + pu;
+    image[3 * p] = Cr; image[3 * p + 1] = Cg; image[3 * p + 2] = Cb;
+    depth[p] = D / fmaxf(Wd, 1e-6f);  // RAS:479-480
+    acc_alpha[p] = 1.f - T;
+    last_effective[p] = last;
+    valid_count[p] = cnt;
+}
+
+// ------------------------------------------------------------------------------- backward
+__global__ __launch_bounds__(GS_BLOCK) void blend_backward_kernel(
+    const int32_t *__restrict__ tile_start, const int32_t *__restrict__ tile_end,
+    const int32_t *__restrict__ payload, const float4 *__restrict__ attrs, const float *__restrict__ grad_image,
+    const float *__restrict__ acc_alpha, const int32_t *__restrict__ last_effective, int width, int height,
+    int row_begin, int row_step, float *__restrict__ acc, float *__restrict__ magnitude_image) {
+    __shared__ float4 s_a[GS_BLOCK], s_b[GS_BLOCK], s_c[GS_BLOCK];
+    __shared__ int s_o[GS_BLOCK];
+    __shared__ int s_max[GS_BLOCK / GS_WAVE];
+    const int tw = width / GS_TILE_WIDTH;
+    const TileCoord tc = owned_tile(tw, row_begin, row_step);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int pu = tc.tile_u * GS_TILE_WIDTH + (tid & 15);
+    const int pv = tc.tile_v * GS_TILE_HEIGHT + (tid >> 4);
+    const size_t p = (size_t)pv * width + pu;
+    const int start = tile_start[tc.tile_id];
+    const float px = (float)pu + 0.5f, py = (float)pv + 0.5f;
+
+    const int last = last_effective[p];
+    float T = 1.0f - acc_alpha[p];
+    float wr = 0.f, wg = 0.f, wb = 0.f;
+    const float Gr = grad_image[3 * p], Gg = grad_image[3 * p + 1], Gb = grad_image[3 * p + 2];
+    float mag_u = 0.f, mag_v = 0.f;
+
+    // no pixel of the tile touches an entry at or beyond the tile-wide max of `last`
+    int mx = last;
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) mx = max(mx, __shfl_xor(mx, d, GS_WAVE));
+    if (lane == 0) s_max[tid >> 6] = mx;
+    __syncthreads();
+    const int end = max(max(s_max[0], s_max[1]), max(s_max[2], s_max[3]));
+
+    for (int top = end; top > start; top -= GS_BLOCK) {
+        __syncthreads();
+        const int j = top - 1 - tid;
+        if (j >= start) {
+            const int o = payload[j];
+            const float4 *g = attrs + 3 * (size_t)o;
+            s_a[tid] = g[0];
+            s_b[tid] = g[1];
+            s_c[tid] = g[2];
+            s_o[tid] = o;
+        }
+        __syncthreads();
+        const int n = min(GS_BLOCK, top - start);
+        for (int k = 0; k < n; ++k) {
+            const int jj = top - 1 - k;
+            const float4 a = s_a[k], b = s_b[k];
+            const float dx = px - a.x, dy = py - a.y;
+            // UTL:331-348: m = conic @ d, exponent = -0.5 d.m
+            const float m0 = b.x * dx + b.y * dy, m1 = b.y * dx + b.z * dy;
+            const float g = __expf(-0.5f * (dx * m0 + dy * m1)) * b.w;
+            const float pa = g * a.w;
+            const bool hit = (jj < last) && (pa >= EPS_ALPHA);
+            const unsigned long long hits = __ballot(hit);
+            if (hits == 0ull) continue;  // wave-uniform skip: nobody in this wave touches the Gaussian
+            float v0 = 0.f, v1 = 0.f, c00 = 0.f, c01 = 0.f, c11 = 0.f, gr = 0.f, gg = 0.f, gb = 0.f, gl = 0.f,
+                  nv = 0.f;
+            if (hit) {
+                const float4 c = s_c[k];
+                const float alpha = fminf(pa, CLAMP_ALPHA);
+                const float inv1m = __builtin_amdgcn_rcpf(1.f - alpha);
+                T = T * inv1m;  // RAS:643, T_i = T_{i+1} / (1 - alpha_i)
+                const float aT = alpha * T;
+                gr = aT * Gr; gg = aT * Gg; gb = aT * Gb;
+                const float dLda = (c.x * T - wr * inv1m) * Gr + (c.y * T - wg * inv1m) * Gg +
+                                   (c.z * T - wb * inv1m) * Gb;
+                wr += c.x * aT; wg += c.y * aT; wb += c.z * aT;
+                gl = dLda * g * (1.f - a.w) * a.w;
+                const float dLdg = dLda * a.w;
+                const float gm0 = g * m0, gm1 = g * m1;
+                v0 = dLdg * gm0; v1 = dLdg * gm1;
+                mag_u += fabsf(v0); mag_v += fabsf(v1);
+                const float h = 0.5f * dLdg;
+                c00 = h * gm0 * m0; c01 = h * gm0 * m1; c11 = h * gm1 * m1;
+                nv = sqrtf(v0 * v0 + v1 * v1);
+            }
+            v0 = gs_wave_sum_to_lane63(v0); v1 = gs_wave_sum_to_lane63(v1);
+            c00 = gs_wave_sum_to_lane63(c00); c01 = gs_wave_sum_to_lane63(c01); c11 = gs_wave_sum_to_lane63(c11);
+            gr = gs_wave_sum_to_lane63(gr); gg = gs_wave_sum_to_lane63(gg); gb = gs_wave_sum_to_lane63(gb);
+            gl = gs_wave_sum_to_lane63(gl); nv = gs_wave_sum_to_lane63(nv);
+            if (lane == 63) {
+                float *A = acc + (size_t)GS_ACC_STRIDE * s_o[k];
+                atomicAdd(A + 0, v0); atomicAdd(A + 1, v1);
+                atomicAdd(A + 2, c00); atomicAdd(A + 3, c01); atomicAdd(A + 4, c11);
+                atomicAdd(A + 5, gr); atomicAdd(A + 6, gg); atomicAdd(A + 7, gb);
+                atomicAdd(A + 8, gl); atomicAdd(A + 9, nv);
+                atomicAdd(reinterpret_cast<int *>(A + 10), (int)__popcll(hits));
+            }
+        }
+    }
+    magnitude_image[2 * p] = mag_u;
+    magnitude_image[2 * p + 1] = mag_v;
+}
+
+}  // namespace
+
+extern "C" {
+
+static int owned_row_count(int th, int begin, int step) { return begin < th ? (th - 1 - begin) / step + 1 : 0; }
+
+int gs_blend_forward(const int32_t *tile_start, const int32_t *tile_end, const int32_t *payload, const float *attrs,
+                     int width, int height, int tile_row_begin, int tile_row_step, float *image, float *depth,
+                     float *acc_alpha, int32_t *last_effective, int32_t *valid_count, void *stream) {
+    GS_REQUIRE(width % GS_TILE_WIDTH == 0 && height % GS_TILE_HEIGHT == 0, "image size must be a multiple of 16");
+    GS_REQUIRE(tile_row_step >= 1 && tile_row_begin >= 0, "tile row ownership");
+    const int tw = width / GS_TILE_WIDTH, rows = owned_row_count(height / GS_TILE_HEIGHT, tile_row_begin, tile_row_step);
+    if (rows == 0 || tw == 0) return 0;
+    hipLaunchKernelGGL(blend_forward_kernel, dim3(tw * rows), dim3(GS_BLOCK), 0, (hipStream_t)stream, tile_start,
+                       tile_end, payload, reinterpret_cast<const float4 *>(attrs), width, height, tile_row_begin,
+                       tile_row_step, image, depth, acc_alpha, last_effective, valid_count);
+    GS_CHECK_LAUNCH();
+    return 0;
+}
+
+int gs_blend_backward(const int32_t *tile_start, const int32_t *tile_end, const int32_t *payload, const float *attrs,
+                      const float *grad_image, const float *acc_alpha, const int32_t *last_effective, int n_visible,
+                      int width, int height, int tile_row_begin, int tile_row_step, float *acc, float *magnitude_image,
+                      void *stream) {
+    GS_REQUIRE(width % GS_TILE_WIDTH == 0 && height % GS_TILE_HEIGHT == 0, "image size must be a multiple of 16");
+    GS_REQUIRE(tile_row_step >= 1 && tile_row_begin >= 0, "tile row ownership");
+    GS_REQUIRE(n_visible >= 0, "n_visible");
+    hipStream_t s = (hipStream_t)stream;
+    if (n_visible > 0)
+        GS_CHECK_HIP(hipMemsetAsync(acc, 0, sizeof(float) * GS_ACC_STRIDE * (size_t)n_visible, s));
+    const int tw = width / GS_TILE_WIDTH, rows = owned_row_count(height / GS_TILE_HEIGHT, tile_row_begin, tile_row_step);
+    if (rows == 0 || tw == 0) return 0;
+    hipLaunchKernelGGL(blend_backward_kernel, dim3(tw * rows), dim3(GS_BLOCK), 0, s, tile_start, tile_end, payload,
+                       reinterpret_cast<const float4 *>(attrs), grad_image, acc_alpha, last_effective, width, height,
+                       tile_row_begin, tile_row_step, acc, magnitude_image);
+    GS_CHECK_LAUNCH();
+    return 0;
+}
+
+}  // extern "C"

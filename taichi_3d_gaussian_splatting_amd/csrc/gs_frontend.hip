@@ -1,0 +1,481 @@
+// gs_frontend.hip -- per-point front end of the gfx950 rasteriser:
+//   pose inverse, frustum filter + ordered compaction, EWA projection (+ tile counting),
+//   block-sum scan, sort-key generation, tile ranges.
+// Hand-written HIP for CDNA4 (wave64).  The arithmetic follows the reference formulas
+// (cited per function; RAS/GP3/SPH/UTL as in include/gsplat_hip.h) and is evaluated in the
+// same left-to-right order as the CPU oracle with FMA contraction disabled, so that the
+// discrete decisions derived from it (frustum test, depth quantisation, tile boxes) agree
+// bit-for-bit with the oracle.
+#include "gs_common.h"
+
+#pragma clang fp contract(off)
+
+namespace {
+
+// ------------------------------------------------------------------ small math (device)
+struct Mat3 { float m[9]; };
+
+// GP3:31-48 rotation_matrix_from_quaternion (q = x,y,z,w; not normalised here)
+__device__ __forceinline__ Mat3 rotmat_from_q(float x, float y, float z, float w) {
+    float xx = x * x, yy = y * y, zz = z * z, xy = x * y, xz = x * z, yz = y * z;
+    float wx = w * x, wy = w * y, wz = w * z;
+    Mat3 R;
+    R.m[0] = 1.f - 2.f * (yy + zz); R.m[1] = 2.f * (xy - wz); R.m[2] = 2.f * (xz + wy);
+    R.m[3] = 2.f * (xy + wz); R.m[4] = 1.f - 2.f * (xx + zz); R.m[5] = 2.f * (yz - wx);
+    R.m[6] = 2.f * (xz - wy); R.m[7] = 2.f * (yz + wx); R.m[8] = 1.f - 2.f * (xx + yy);
+    return R;
+}
+
+// GP3:14-27 project_point_to_camera
+__device__ __forceinline__ void project_point(const Mat3 &R, const float t[3], const float K[9],
+                                              const float p[3], float uv[2], float c[3]) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+        c[i] = ((R.m[3 * i] * p[0] + R.m[3 * i + 1] * p[1]) + R.m[3 * i + 2] * p[2]) + t[i] * 1.f;
+    float u1 = (K[0] * c[0] + K[1] * c[1]) + K[2] * c[2];
+    float v1 = (K[3] * c[0] + K[4] * c[1]) + K[5] * c[2];
+    uv[0] = u1 / c[2];
+    uv[1] = v1 / c[2];
+}
+
+// C(m x n) = A(m x k) @ B(k x n), left-to-right sums (Taichi's unrolled matmul order)
+template <int M, int Kd, int N>
+__device__ __forceinline__ void matmul(const float *A, const float *B, float *C) {
+#pragma unroll
+    for (int i = 0; i < M; ++i)
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            float s = A[i * Kd] * B[j];
+#pragma unroll
+            for (int l = 1; l < Kd; ++l) s = s + A[i * Kd + l] * B[l * N + j];
+            C[i * N + j] = s;
+        }
+}
+
+// SPH:10-32 get_spherical_harmonic_from_xyz
+__device__ __forceinline__ void sh_basis(const float d[3], float Y[16]) {
+    float n = sqrtf((d[0] * d[0] + d[1] * d[1]) + d[2] * d[2]);
+    float x = d[0] / n, y = d[1] / n, z = d[2] / n;
+    Y[0] = 0.28209479177387814f;
+    Y[1] = -0.48860251190291987f * y;
+    Y[2] = 0.48860251190291987f * z;
+    Y[3] = -0.48860251190291987f * x;
+    Y[4] = 1.0925484305920792f * x * y;
+    Y[5] = -1.0925484305920792f * y * z;
+    Y[6] = 0.94617469575755997f * z * z - 0.31539156525251999f;
+    Y[7] = -1.0925484305920792f * x * z;
+    Y[8] = 0.54627421529603959f * x * x - 0.54627421529603959f * y * y;
+    Y[9] = 0.59004358992664352f * y * (-3.0f * x * x + y * y);
+    Y[10] = 2.8906114426405538f * x * y * z;
+    Y[11] = 0.45704579946446572f * y * (1.0f - 5.0f * z * z);
+    Y[12] = 0.3731763325901154f * z * (5.0f * z * z - 3.0f);
+    Y[13] = 0.45704579946446572f * x * (1.0f - 5.0f * z * z);
+    Y[14] = 1.4453057213202769f * z * (x * x - y * y);
+    Y[15] = 0.59004358992664352f * x * (-x * x + 3.0f * y * y);
+}
+
+__device__ __forceinline__ float sigmoidf(float x) { return 1.f / (1.f + expf(-x)); }
+
+// RAS:81-103 get_bounding_box_by_point_and_radii
+__device__ __forceinline__ void tile_box(float u, float v, float r, int tw, int th, int &t0u, int &t1u,
+                                         int &t0v, int &t1v) {
+    r = fmaxf(r, 1.0f);
+    float min_u = fmaxf(0.0f, u - r), max_u = u + r;
+    float min_v = fmaxf(0.0f, v - r), max_v = v + r;
+    t0u = min((int)floorf(min_u / (float)GS_TILE_WIDTH), tw);
+    t1u = min(max((int)floorf(max_u / (float)GS_TILE_WIDTH) + 1, t0u + 1), tw);
+    t0v = min((int)floorf(min_v / (float)GS_TILE_HEIGHT), th);
+    t1v = min(max((int)floorf(max_v / (float)GS_TILE_HEIGHT) + 1, t0v + 1), th);
+}
+
+// number of tile rows r in [t0v, t1v) with r = begin + k*step, k >= 0; first such row in *first
+__device__ __forceinline__ int owned_rows(int t0v, int t1v, int begin, int step, int *first) {
+    int f = begin;
+    if (t0v > begin) f = begin + ((t0v - begin + step - 1) / step) * step;
+    *first = f;
+    return f < t1v ? (t1v - 1 - f) / step + 1 : 0;
+}
+
+// ------------------------------------------------------------------ pose inverse
+// UTL:396-432 inverse_SE3_qt_torch: q_inv = conj(q) (not renormalised),
+// t_inv = -rot(normalise(q_inv), t) with the Hamilton products of UTL:402-412.
+__device__ __forceinline__ void quat_mul(const float a[4], const float b[4], float o[4]) {
+    float x0 = a[0], y0 = a[1], z0 = a[2], w0 = a[3];
+    float x1 = b[0], y1 = b[1], z1 = b[2], w1 = b[3];
+    o[0] = w0 * x1 + x0 * w1 + y0 * z1 - z0 * y1;
+    o[1] = w0 * y1 - x0 * z1 + y0 * w1 + z0 * x1;
+    o[2] = w0 * z1 + x0 * y1 - y0 * x1 + z0 * w1;
+    o[3] = w0 * w1 - x0 * x1 - y0 * y1 - z0 * z1;
+}
+
+__global__ void pose_inverse_kernel(const float *__restrict__ q, const float *__restrict__ t,
+                                    float *__restrict__ q_inv, float *__restrict__ t_inv, int n) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float qi[4] = {-q[4 * i], -q[4 * i + 1], -q[4 * i + 2], q[4 * i + 3]};
+    float nrm = sqrtf(((qi[0] * qi[0] + qi[1] * qi[1]) + qi[2] * qi[2]) + qi[3] * qi[3]);
+    float qn[4] = {qi[0] / nrm, qi[1] / nrm, qi[2] / nrm, qi[3] / nrm};
+    float v[4] = {t[3 * i], t[3 * i + 1], t[3 * i + 2], 0.f};
+    float qc[4] = {-qn[0], -qn[1], -qn[2], qn[3]};
+    float tmp[4], out[4];
+    quat_mul(qn, v, tmp);
+    quat_mul(tmp, qc, out);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) q_inv[4 * i + k] = qi[k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) t_inv[3 * i + k] = -out[k];
+}
+
+// ------------------------------------------------------------------ filter + ordered compaction
+// One 256-thread workgroup handles FILTER_ITEMS consecutive points in rounds of 256 so that
+// the xyz reads are coalesced and the output order is the input order.
+constexpr int FILTER_ROUNDS = 4;
+constexpr int FILTER_ITEMS = GS_BLOCK * FILTER_ROUNDS;
+
+// RAS:31-78 filter_point_in_camera
+__global__ __launch_bounds__(GS_BLOCK) void filter_kernel(
+    const float *__restrict__ xyz, const int8_t *__restrict__ invalid, const int32_t *__restrict__ obj,
+    const float *__restrict__ Kmat, const float *__restrict__ q_cp, const float *__restrict__ t_cp, int n,
+    float near_plane, float far_plane, int width, int height, int8_t *__restrict__ mask,
+    int32_t *__restrict__ block_counts) {
+    __shared__ int s_count;
+    if (threadIdx.x == 0) s_count = 0;
+    __syncthreads();
+    float K[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) K[k] = Kmat[k];
+    int local = 0;
+#pragma unroll
+    for (int r = 0; r < FILTER_ROUNDS; ++r) {
+        int i = blockIdx.x * FILTER_ITEMS + r * GS_BLOCK + threadIdx.x;
+        bool vis = false;
+        if (i < n) {
+            if (invalid[i] != 1) {
+                int o = obj[i];
+                Mat3 R = rotmat_from_q(q_cp[4 * o], q_cp[4 * o + 1], q_cp[4 * o + 2], q_cp[4 * o + 3]);
+                float t[3] = {t_cp[3 * o], t_cp[3 * o + 1], t_cp[3 * o + 2]};
+                float p[3] = {xyz[3 * (size_t)i], xyz[3 * (size_t)i + 1], xyz[3 * (size_t)i + 2]};
+                float uv[2], c[3];
+                project_point(R, t, K, p, uv, c);
+                vis = c[2] > near_plane && c[2] < far_plane &&
+                      uv[0] >= (float)(-GS_TILE_WIDTH * GS_BOUNDARY_TILES) &&
+                      uv[0] < (float)(width + GS_TILE_WIDTH * GS_BOUNDARY_TILES) &&
+                      uv[1] >= (float)(-GS_TILE_HEIGHT * GS_BOUNDARY_TILES) &&
+                      uv[1] < (float)(height + GS_TILE_HEIGHT * GS_BOUNDARY_TILES);
+            }
+            mask[i] = vis ? 1 : 0;
+        }
+        unsigned long long b = __ballot(vis);
+        if (gs_lane() == 0) local += __popcll(b);
+    }
+    if (gs_lane() == 0) atomicAdd(&s_count, local);
+    __syncthreads();
+    if (threadIdx.x == 0) block_counts[blockIdx.x] = s_count;
+}
+
+// single-workgroup exclusive scan over n ints (in place); total -> *total_out (saturating)
+__global__ __launch_bounds__(GS_BLOCK) void scan_single_block_kernel(int32_t *__restrict__ data, int n,
+                                                                    int32_t *__restrict__ total_out) {
+    __shared__ int lds[4];
+    long long carry = 0;
+    for (int base = 0; base < n; base += GS_BLOCK) {
+        int i = base + threadIdx.x;
+        int v = i < n ? data[i] : 0;
+        int total;
+        int ex = gs_block_excl_scan(v, &total, lds);
+        long long out = carry + ex;
+        if (i < n) data[i] = out > 0x7fffffffLL ? 0x7fffffff : (int)out;
+        carry += total;
+    }
+    if (threadIdx.x == 0) *total_out = carry > 0x7fffffffLL ? 0x7fffffff : (int)carry;
+}
+
+// RAS:861-870: point_id[mask] -- order-preserving compaction with wave ballots
+__global__ __launch_bounds__(GS_BLOCK) void compact_kernel(const int8_t *__restrict__ mask, int n,
+                                                          const int32_t *__restrict__ block_offsets,
+                                                          int32_t *__restrict__ ids) {
+    __shared__ int s_wave[GS_BLOCK / GS_WAVE];
+    int running = block_offsets[blockIdx.x];
+    const int w = threadIdx.x >> 6;
+#pragma unroll
+    for (int r = 0; r < FILTER_ROUNDS; ++r) {
+        int i = blockIdx.x * FILTER_ITEMS + r * GS_BLOCK + threadIdx.x;
+        bool vis = i < n && mask[i] != 0;
+        unsigned long long b = __ballot(vis);
+        int rank = gs_mbcnt(b);
+        if (gs_lane() == 0) s_wave[w] = __popcll(b);
+        __syncthreads();
+        int before = 0, total = 0;
+#pragma unroll
+        for (int k = 0; k < GS_BLOCK / GS_WAVE; ++k) {
+            int c = s_wave[k];
+            if (k < w) before += c;
+            total += c;
+        }
+        if (vis) ids[running + before + rank] = i;
+        running += total;
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------ per-visible-point projection
+// RAS:239-315 generate_point_attributes_in_camera_plane + RAS:106-128 generate_num_overlap_tiles.
+// One lane per visible point; the 224-B feature row is read as 14 x 16-B loads.
+__global__ __launch_bounds__(GS_BLOCK) void preprocess_kernel(
+    const float *__restrict__ xyz, float *__restrict__ feat, const int32_t *__restrict__ obj,
+    const float *__restrict__ Kmat, const float *__restrict__ q_cp, const float *__restrict__ t_cp,
+    const int32_t *__restrict__ ids, int m, int width, int height, int row_begin, int row_step,
+    float *__restrict__ attrs, int32_t *__restrict__ ntiles_full, int32_t *__restrict__ ntiles_owned,
+    int32_t *__restrict__ block_sums) {
+    __shared__ int s_sum;
+    if (threadIdx.x == 0) s_sum = 0;
+    __syncthreads();
+    const int i = blockIdx.x * GS_BLOCK + threadIdx.x;
+    int owned = 0;
+    if (i < m) {
+        const int id = ids[i];
+        float4 *row4 = reinterpret_cast<float4 *>(feat + (size_t)GS_FEATURE_DIM * id);
+        float f[GS_FEATURE_DIM];
+#pragma unroll
+        for (int k = 0; k < GS_FEATURE_DIM / 4; ++k) {
+            float4 v = row4[k];
+            f[4 * k] = v.x; f[4 * k + 1] = v.y; f[4 * k + 2] = v.z; f[4 * k + 3] = v.w;
+        }
+        // RAS:196-205: q <- q/|q|, written back in place
+        float nrm = sqrtf(((f[0] * f[0] + f[1] * f[1]) + f[2] * f[2]) + f[3] * f[3]);
+        f[0] = f[0] / nrm; f[1] = f[1] / nrm; f[2] = f[2] / nrm; f[3] = f[3] / nrm;
+        row4[0] = make_float4(f[0], f[1], f[2], f[3]);
+
+        float K[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) K[k] = Kmat[k];
+        const int o = obj[id];
+        const Mat3 W = rotmat_from_q(q_cp[4 * o], q_cp[4 * o + 1], q_cp[4 * o + 2], q_cp[4 * o + 3]);
+        const float t[3] = {t_cp[3 * o], t_cp[3 * o + 1], t_cp[3 * o + 2]};
+        const float p[3] = {xyz[3 * (size_t)id], xyz[3 * (size_t)id + 1], xyz[3 * (size_t)id + 2]};
+        float uv[2], c[3];
+        project_point(W, t, K, p, uv, c);
+
+        // GP3:161-191 project_to_camera_covariance: cov = J W Sigma W^T J^T, left to right
+        float J[6] = {K[0] / c[2], 0.f, -(K[0] * c[0]) / (c[2] * c[2]),
+                      0.f, K[4] / c[2], -(K[4] * c[1]) / (c[2] * c[2])};
+        const Mat3 R = rotmat_from_q(f[0], f[1], f[2], f[3]);
+        float S[9] = {expf(f[4]), 0.f, 0.f, 0.f, expf(f[5]), 0.f, 0.f, 0.f, expf(f[6])};
+        float RS[9], RSS[9], Rt[9], Sigma[9];
+        matmul<3, 3, 3>(R.m, S, RS);
+        matmul<3, 3, 3>(RS, S, RSS);
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int b = 0; b < 3; ++b) Rt[b * 3 + a] = R.m[a * 3 + b];
+        matmul<3, 3, 3>(RSS, Rt, Sigma);
+        float JW[6], JWS[6], Wt[9], JWSW[6], Jt[6], cov[4];
+        matmul<2, 3, 3>(J, W.m, JW);
+        matmul<2, 3, 3>(JW, Sigma, JWS);
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int b = 0; b < 3; ++b) Wt[b * 3 + a] = W.m[a * 3 + b];
+        matmul<2, 3, 3>(JWS, Wt, JWSW);
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 3; ++b) Jt[b * 2 + a] = J[a * 3 + b];
+        matmul<2, 3, 2>(JWSW, Jt, cov);
+
+        // UTL:257-272 get_point_conic_and_rescale (+0.3 low-pass only inside the conic)
+        float det0 = cov[0] * cov[3] - cov[1] * cov[2];
+        float ca = cov[0] + 0.3f, cd = cov[3] + 0.3f;
+        float det = ca * cd - cov[1] * cov[2];
+        float rescale = sqrtf(fmaxf(0.0f, det0 / det));
+        float inv = 1.0f / det;
+
+        // colour: RAS:280-282,302-310; ray origin = (-R^T) t (UTL:495-510)
+        float ro[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+            ro[k] = ((-W.m[k]) * t[0] + (-W.m[3 + k]) * t[1]) + (-W.m[6 + k]) * t[2];
+        float dir[3] = {p[0] - ro[0], p[1] - ro[1], p[2] - ro[2]}, Y[16];
+        sh_basis(dir, Y);
+        float rgb[3];
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) {
+            float s = f[8 + 16 * ch] * Y[0];
+#pragma unroll
+            for (int k = 1; k < 16; ++k) s = s + f[8 + 16 * ch + k] * Y[k];
+            rgb[ch] = sigmoidf(s);
+        }
+        // RAS:311-315 radius from the un-filtered covariance
+        float dd = cov[0] - cov[3];
+        float lam = (cov[0] + cov[3] + sqrtf(dd * dd + 4.0f * cov[1] * cov[2])) / 2.0f;
+        float radius = sqrtf(lam) * 3.0f;
+
+        float4 *out = reinterpret_cast<float4 *>(attrs + (size_t)GS_ATTR_STRIDE * i);
+        out[0] = make_float4(uv[0], uv[1], c[2], 1.f / (1.f + expf(-f[7])));
+        out[1] = make_float4(inv * cd, inv * (-cov[1]), inv * ca, rescale);
+        out[2] = make_float4(rgb[0], rgb[1], rgb[2], radius);
+
+        int t0u, t1u, t0v, t1v, first;
+        tile_box(uv[0], uv[1], radius, width / GS_TILE_WIDTH, height / GS_TILE_HEIGHT, t0u, t1u, t0v, t1v);
+        ntiles_full[i] = (t1u - t0u) * (t1v - t0v);
+        owned = (t1u - t0u) * owned_rows(t0v, t1v, row_begin, row_step, &first);
+        ntiles_owned[i] = owned;
+    }
+    // per-block partial sum for the scan (wave reduce, then one LDS atomic per wave)
+    int s = owned;
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) s += __shfl_xor(s, d, GS_WAVE);
+    if (gs_lane() == 0 && s != 0) atomicAdd(&s_sum, s);
+    __syncthreads();
+    if (threadIdx.x == 0) block_sums[blockIdx.x] = s_sum;
+}
+
+// ------------------------------------------------------------------ key generation
+// RAS:131-172 generate_point_sort_key_by_num_overlap_tiles
+__global__ __launch_bounds__(GS_BLOCK) void make_keys_kernel(
+    const float *__restrict__ attrs, const int32_t *__restrict__ ntiles_owned,
+    const int32_t *__restrict__ block_offsets, int m, int width, int height, int row_begin, int row_step,
+    float depth_scale, uint64_t *__restrict__ keys, int32_t *__restrict__ payload) {
+    __shared__ int lds[4];
+    const int i = blockIdx.x * GS_BLOCK + threadIdx.x;
+    int cnt = i < m ? ntiles_owned[i] : 0;
+    int total;
+    int offset = block_offsets[blockIdx.x] + gs_block_excl_scan(cnt, &total, lds);
+    if (i >= m || cnt == 0) return;
+    const float4 a0 = reinterpret_cast<const float4 *>(attrs + (size_t)GS_ATTR_STRIDE * i)[0];
+    const float radius = attrs[(size_t)GS_ATTR_STRIDE * i + 11];
+    const int tw = width / GS_TILE_WIDTH;
+    int t0u, t1u, t0v, t1v, first;
+    tile_box(a0.x, a0.y, radius, tw, height / GS_TILE_HEIGHT, t0u, t1u, t0v, t1v);
+    owned_rows(t0v, t1v, row_begin, row_step, &first);
+    const int32_t dq = (int32_t)(a0.z * depth_scale);  // truncation toward zero, RAS:159-160
+    int k = offset;
+    for (int tu = t0u; tu < t1u; ++tu)
+        for (int tv = first; tv < t1v; tv += row_step) {
+            const int32_t tile = tu + tv * tw;
+            keys[k] = (uint64_t)((int64_t)dq + ((int64_t)tile << 32));
+            payload[k] = i;
+            ++k;
+        }
+}
+
+// RAS:175-193 find_tile_start_and_end (arrays pre-zeroed by the caller entry point)
+__global__ void tile_ranges_kernel(const uint64_t *__restrict__ keys, long long n,
+                                   int32_t *__restrict__ tile_start, int32_t *__restrict__ tile_end) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int32_t t = (int32_t)((int64_t)keys[i] >> 32);
+    if (i + 1 < n) {
+        int32_t tn = (int32_t)((int64_t)keys[i + 1] >> 32);
+        if (t != tn) {
+            tile_start[tn] = (int32_t)(i + 1);
+            tile_end[t] = (int32_t)(i + 1);
+        }
+    } else {
+        tile_end[t] = (int32_t)n;
+    }
+}
+
+}  // namespace
+
+// =================================================================== C ABI
+extern "C" {
+
+int gs_pose_inverse(const float *q_pc, const float *t_pc, float *q_cp, float *t_cp, int n_obj, void *stream) {
+    GS_REQUIRE(n_obj > 0, "n_obj must be positive");
+    hipLaunchKernelGGL(pose_inverse_kernel, dim3(gs_div_up(n_obj, 64)), dim3(64), 0, (hipStream_t)stream,
+                       q_pc, t_pc, q_cp, t_cp, n_obj);
+    GS_CHECK_LAUNCH();
+    return 0;
+}
+
+size_t gs_filter_workspace_bytes(int n_points) {
+    return sizeof(int32_t) * ((size_t)gs_div_up(n_points > 0 ? n_points : 1, FILTER_ITEMS) + 64);
+}
+
+int gs_filter_compact(const float *xyz, const int8_t *invalid_mask, const int32_t *object_id,
+                      const float *intrinsics, const float *q_cp, const float *t_cp, int n_points,
+                      float near_plane, float far_plane, int width, int height, int8_t *mask, int32_t *ids,
+                      int32_t *counters, void *workspace, void *stream) {
+    GS_REQUIRE(n_points >= 0, "n_points");
+    GS_REQUIRE(width % GS_TILE_WIDTH == 0 && height % GS_TILE_HEIGHT == 0, "image size must be a multiple of 16");
+    hipStream_t s = (hipStream_t)stream;
+    int32_t *block_counts = (int32_t *)workspace;
+    if (n_points == 0) {
+        GS_CHECK_HIP(hipMemsetAsync(counters + GS_COUNTER_NUM_VISIBLE, 0, sizeof(int32_t), s));
+        return 0;
+    }
+    const int nblk = gs_div_up(n_points, FILTER_ITEMS);
+    hipLaunchKernelGGL(filter_kernel, dim3(nblk), dim3(GS_BLOCK), 0, s, xyz, invalid_mask, object_id, intrinsics,
+                       q_cp, t_cp, n_points, near_plane, far_plane, width, height, mask, block_counts);
+    GS_CHECK_LAUNCH();
+    hipLaunchKernelGGL(scan_single_block_kernel, dim3(1), dim3(GS_BLOCK), 0, s, block_counts, nblk,
+                       counters + GS_COUNTER_NUM_VISIBLE);
+    GS_CHECK_LAUNCH();
+    hipLaunchKernelGGL(compact_kernel, dim3(nblk), dim3(GS_BLOCK), 0, s, mask, n_points, block_counts, ids);
+    GS_CHECK_LAUNCH();
+    return 0;
+}
+
+int gs_read_counters(const int32_t *counters, int32_t *host_counters, int n, void *stream) {
+    GS_REQUIRE(n > 0 && n <= GS_NUM_COUNTERS, "n");
+    GS_CHECK_HIP(hipMemcpyAsync(host_counters, counters, sizeof(int32_t) * n, hipMemcpyDeviceToHost,
+                                (hipStream_t)stream));
+    GS_CHECK_HIP(hipStreamSynchronize((hipStream_t)stream));
+    return 0;
+}
+
+int gs_preprocess(const float *xyz, float *features, const int32_t *object_id, const float *intrinsics,
+                  const float *q_cp, const float *t_cp, const int32_t *ids, int n_visible, int width, int height,
+                  int tile_row_begin, int tile_row_step, float *attrs, int32_t *num_overlap_tiles,
+                  int32_t *num_owned_tiles, int32_t *block_sums, void *stream) {
+    GS_REQUIRE(n_visible >= 0, "n_visible");
+    GS_REQUIRE(tile_row_step >= 1 && tile_row_begin >= 0, "tile row ownership");
+    GS_REQUIRE(width % GS_TILE_WIDTH == 0 && height % GS_TILE_HEIGHT == 0, "image size must be a multiple of 16");
+    if (n_visible == 0) return 0;
+    hipLaunchKernelGGL(preprocess_kernel, dim3(gs_div_up(n_visible, GS_BLOCK)), dim3(GS_BLOCK), 0,
+                       (hipStream_t)stream, xyz, features, object_id, intrinsics, q_cp, t_cp, ids, n_visible, width,
+                       height, tile_row_begin, tile_row_step, attrs, num_overlap_tiles, num_owned_tiles, block_sums);
+    GS_CHECK_LAUNCH();
+    return 0;
+}
+
+int gs_scan_block_sums(int32_t *block_sums, int n_blocks, int32_t *counters, void *stream) {
+    GS_REQUIRE(n_blocks >= 0, "n_blocks");
+    if (n_blocks == 0) {
+        GS_CHECK_HIP(hipMemsetAsync(counters + GS_COUNTER_NUM_KEYS, 0, sizeof(int32_t), (hipStream_t)stream));
+        return 0;
+    }
+    hipLaunchKernelGGL(scan_single_block_kernel, dim3(1), dim3(GS_BLOCK), 0, (hipStream_t)stream, block_sums,
+                       n_blocks, counters + GS_COUNTER_NUM_KEYS);
+    GS_CHECK_LAUNCH();
+    return 0;
+}
+
+int gs_make_keys(const float *attrs, const int32_t *num_owned_tiles, const int32_t *block_offsets, int n_visible,
+                 int width, int height, int tile_row_begin, int tile_row_step, float depth_scale, uint64_t *keys,
+                 int32_t *payload, void *stream) {
+    GS_REQUIRE(n_visible >= 0, "n_visible");
+    GS_REQUIRE(tile_row_step >= 1 && tile_row_begin >= 0, "tile row ownership");
+    if (n_visible == 0) return 0;
+    hipLaunchKernelGGL(make_keys_kernel, dim3(gs_div_up(n_visible, GS_BLOCK)), dim3(GS_BLOCK), 0,
+                       (hipStream_t)stream, attrs, num_owned_tiles, block_offsets, n_visible, width, height,
+                       tile_row_begin, tile_row_step, depth_scale, keys, payload);
+    GS_CHECK_LAUNCH();
+    return 0;
+}
+
+int gs_tile_ranges(const uint64_t *keys_sorted, int64_t n_keys, int32_t *tile_start, int32_t *tile_end, int n_tiles,
+                   void *stream) {
+    GS_REQUIRE(n_keys >= 0 && n_tiles > 0, "sizes");
+    hipStream_t s = (hipStream_t)stream;
+    GS_CHECK_HIP(hipMemsetAsync(tile_start, 0, sizeof(int32_t) * n_tiles, s));
+    GS_CHECK_HIP(hipMemsetAsync(tile_end, 0, sizeof(int32_t) * n_tiles, s));
+    if (n_keys == 0) return 0;
+    hipLaunchKernelGGL(tile_ranges_kernel, dim3(gs_div_up(n_keys, GS_BLOCK)), dim3(GS_BLOCK), 0, s, keys_sorted,
+                       (long long)n_keys, tile_start, tile_end);
+    GS_CHECK_LAUNCH();
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,209 @@
+// gs_point_backward.hip -- per-visible-point chain rule of the backward pass (gfx950).
+// Replaces the per-point loop of gaussian_point_rasterisation_backward (RAS:707-772) and fuses
+// the torch post-processing that follows it in the reference: SH band clearing
+// (RAS:1167-1182) and the gradient factors (RAS:1105-1125).
+//
+// Jacobians (GP3:132-159 position, GP3:237-331 covariance, GP3:351-373 colour) are contracted
+// with the upstream gradient FIRST instead of being materialised as 4x9 / 9x9 matrices:
+//   Sigma' = U Sigma U^T, Sigma = M M^T, M = R(q) diag(exp s), U = J W
+//   dL/dSigma = U^T g U,   dL/dM = (dL/dSigma + dL/dSigma^T) M = 2 (U^T g U) M   (g symmetric)
+//   dL/ds_c = (sum_a dL/dM[a][c] R[a][c]) exp(s_c),   dL/dq = sum_ab dL/dM[a][b] dM[a][b]/dq
+// which is the same linear map as GP3:270-330 evaluated in a cheaper association order.
+#include "gs_common.h"
+
+namespace {
+
+__device__ __forceinline__ void rotmat_from_q(const float q[4], float R[9]) {  // GP3:31-48
+    float x = q[0], y = q[1], z = q[2], w = q[3];
+    float xx = x * x, yy = y * y, zz = z * z, xy = x * y, xz = x * z, yz = y * z;
+    float wx = w * x, wy = w * y, wz = w * z;
+    R[0] = 1.f - 2.f * (yy + zz); R[1] = 2.f * (xy - wz); R[2] = 2.f * (xz + wy);
+    R[3] = 2.f * (xy + wz); R[4] = 1.f - 2.f * (xx + zz); R[5] = 2.f * (yz - wx);
+    R[6] = 2.f * (xz - wy); R[7] = 2.f * (yz + wx); R[8] = 1.f - 2.f * (xx + yy);
+}
+
+__device__ __forceinline__ void sh_basis(const float d[3], float Y[16]) {  // SPH:10-32
+    float n = sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+    float x = d[0] / n, y = d[1] / n, z = d[2] / n;
+    Y[0] = 0.28209479177387814f;
+    Y[1] = -0.48860251190291987f * y;
+    Y[2] = 0.48860251190291987f * z;
+    Y[3] = -0.48860251190291987f * x;
+    Y[4] = 1.0925484305920792f * x * y;
+    Y[5] = -1.0925484305920792f * y * z;
+    Y[6] = 0.94617469575755997f * z * z - 0.31539156525251999f;
+    Y[7] = -1.0925484305920792f * x * z;
+    Y[8] = 0.54627421529603959f * x * x - 0.54627421529603959f * y * y;
+    Y[9] = 0.59004358992664352f * y * (-3.0f * x * x + y * y);
+    Y[10] = 2.8906114426405538f * x * y * z;
+    Y[11] = 0.45704579946446572f * y * (1.0f - 5.0f * z * z);
+    Y[12] = 0.3731763325901154f * z * (5.0f * z * z - 3.0f);
+    Y[13] = 0.45704579946446572f * x * (1.0f - 5.0f * z * z);
+    Y[14] = 1.4453057213202769f * z * (x * x - y * y);
+    Y[15] = 0.59004358992664352f * x * (-x * x + 3.0f * y * y);
+}
+
+struct Factors { float q, s, alpha, color, color_hi; int keep; /* SH coefficients kept per channel */ };
+
+__global__ __launch_bounds__(GS_BLOCK) void point_backward_kernel(
+    const float *__restrict__ xyz, const float *__restrict__ feat, const int32_t *__restrict__ obj,
+    const float *__restrict__ Kmat, const float *__restrict__ q_cp, const float *__restrict__ t_cp,
+    const float *__restrict__ t_pc, const int32_t *__restrict__ ids, int m, const float4 *__restrict__ acc,
+    Factors fac, float *__restrict__ grad_xyz, float *__restrict__ grad_feat, float *__restrict__ grad_xyz_vis,
+    float *__restrict__ grad_feat_vis) {
+    const int i = blockIdx.x * GS_BLOCK + threadIdx.x;
+    if (i >= m) return;
+    const int id = ids[i];
+    const float4 *row4 = reinterpret_cast<const float4 *>(feat + (size_t)GS_FEATURE_DIM * id);
+    float f[GS_FEATURE_DIM];
+#pragma unroll
+    for (int k = 0; k < GS_FEATURE_DIM / 4; ++k) {
+        float4 v = row4[k];
+        f[4 * k] = v.x; f[4 * k + 1] = v.y; f[4 * k + 2] = v.z; f[4 * k + 3] = v.w;
+    }
+    const float4 A0 = acc[3 * (size_t)i], A1 = acc[3 * (size_t)i + 1], A2 = acc[3 * (size_t)i + 2];
+    const float g_uv[2] = {A0.x, A0.y};
+    const float g00 = A0.z, g01 = A0.w, g11 = A1.x;
+    const float g_rgb[3] = {A1.y, A1.z, A1.w};
+    const float g_logit = A2.x;
+
+    float K[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) K[k] = Kmat[k];
+    const int o = obj[id];
+    float W[9];
+    rotmat_from_q(q_cp + 4 * o, W);
+    const float t[3] = {t_cp[3 * o], t_cp[3 * o + 1], t_cp[3 * o + 2]};
+    const float p[3] = {xyz[3 * (size_t)id], xyz[3 * (size_t)id + 1], xyz[3 * (size_t)id + 2]};
+    float c[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) c[r] = ((W[3 * r] * p[0] + W[3 * r + 1] * p[1]) + W[3 * r + 2] * p[2]) + t[r];
+    const float iz = 1.f / c[2], iz2 = iz * iz;
+
+    // position: GP3:132-159 (full K rows 0,1), grad_xyz = g_uv @ (d_uv_d_camera @ W)
+    const float dc[6] = {K[0] * iz, K[1] * iz, (-K[0] * c[0] - K[1] * c[1]) * iz2,
+                         K[3] * iz, K[4] * iz, (-K[3] * c[0] - K[4] * c[1]) * iz2};
+    float gc[3];  // dL/d camera-space position
+#pragma unroll
+    for (int k = 0; k < 3; ++k) gc[k] = g_uv[0] * dc[k] + g_uv[1] * dc[3 + k];
+    float gx[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) gx[k] = gc[0] * W[k] + gc[1] * W[3 + k] + gc[2] * W[6 + k];
+
+    // covariance: U = J W with J of GP3:84-87
+    const float J[6] = {K[0] * iz, 0.f, -(K[0] * c[0]) * iz2, 0.f, K[4] * iz, -(K[4] * c[1]) * iz2};
+    float U[6];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b) U[a * 3 + b] = J[a * 3] * W[b] + J[a * 3 + 1] * W[3 + b] + J[a * 3 + 2] * W[6 + b];
+    // dL/dSigma = U^T g U  (3x3, symmetric)
+    float gU[6];  // g @ U (2x3)
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+        gU[b] = g00 * U[b] + g01 * U[3 + b];
+        gU[3 + b] = g01 * U[b] + g11 * U[3 + b];
+    }
+    float dS[9];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b) dS[a * 3 + b] = U[a] * gU[b] + U[3 + a] * gU[3 + b];
+    float R[9];
+    rotmat_from_q(f, R);
+    const float es[3] = {expf(f[4]), expf(f[5]), expf(f[6])};
+    float M[9];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b) M[a * 3 + b] = R[a * 3 + b] * es[b];
+    float dM[9];  // dL/dM = 2 dS M
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b)
+            dM[a * 3 + b] = 2.f * (dS[a * 3] * M[b] + dS[a * 3 + 1] * M[3 + b] + dS[a * 3 + 2] * M[6 + b]);
+    float gs[3];
+#pragma unroll
+    for (int b = 0; b < 3; ++b) gs[b] = (dM[b] * R[b] + dM[3 + b] * R[3 + b] + dM[6 + b] * R[6 + b]) * es[b];
+    // dM/dq rows of GP3:319-329 (M[a][b] = R[a][b] s_b), contracted with dM
+    const float qx = f[0], qy = f[1], qz = f[2], qw = f[3], sx = es[0], sy = es[1], sz = es[2];
+    float gq[4];
+    gq[0] = dM[1] * (2 * sy * qy) + dM[2] * (2 * sz * qz) + dM[3] * (2 * sx * qy) + dM[4] * (-4 * sy * qx) +
+            dM[5] * (-2 * sz * qw) + dM[6] * (2 * sx * qz) + dM[7] * (2 * sy * qw) + dM[8] * (-4 * sz * qx);
+    gq[1] = dM[0] * (-4 * sx * qy) + dM[1] * (2 * sy * qx) + dM[2] * (2 * sz * qw) + dM[3] * (2 * sx * qx) +
+            dM[5] * (2 * sz * qz) + dM[6] * (-2 * sx * qw) + dM[7] * (2 * sy * qz) + dM[8] * (-4 * sz * qy);
+    gq[2] = dM[0] * (-4 * sx * qz) + dM[1] * (-2 * sy * qw) + dM[2] * (2 * sz * qx) + dM[3] * (2 * sx * qw) +
+            dM[4] * (-4 * sy * qz) + dM[5] * (2 * sz * qy) + dM[6] * (2 * sx * qx) + dM[7] * (2 * sy * qy);
+    gq[3] = dM[1] * (-2 * sy * qz) + dM[2] * (2 * sz * qy) + dM[3] * (2 * sx * qz) + dM[5] * (-2 * sz * qx) +
+            dM[6] * (-2 * sx * qy) + dM[7] * (2 * sy * qx);
+
+    // colour: RAS:749-756; ray origin = t_pointcloud_camera of the object (RAS:731)
+    const float dir[3] = {p[0] - t_pc[3 * o], p[1] - t_pc[3 * o + 1], p[2] - t_pc[3 * o + 2]};
+    float Y[16];
+    sh_basis(dir, Y);
+
+    float out[GS_FEATURE_DIM];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) out[k] = gq[k] * fac.q;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) out[4 + k] = gs[k] * fac.s;
+    out[7] = g_logit * fac.alpha;
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) {
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) s += f[8 + 16 * ch + k] * Y[k];
+        const float sg = 1.f / (1.f + expf(-s));
+        const float scale = g_rgb[ch] * (sg * (1.f - sg));  // UTL:356-359
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            float v = scale * Y[k] * (k == 0 ? fac.color : fac.color_hi);
+            out[8 + 16 * ch + k] = k < fac.keep ? v : 0.f;  // RAS:1167-1182
+        }
+    }
+    float4 *dst = reinterpret_cast<float4 *>(grad_feat + (size_t)GS_FEATURE_DIM * id);
+#pragma unroll
+    for (int k = 0; k < GS_FEATURE_DIM / 4; ++k)
+        dst[k] = make_float4(out[4 * k], out[4 * k + 1], out[4 * k + 2], out[4 * k + 3]);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) grad_xyz[3 * (size_t)id + k] = gx[k];
+    if (grad_feat_vis) {
+        float4 *dv = reinterpret_cast<float4 *>(grad_feat_vis + (size_t)GS_FEATURE_DIM * i);
+#pragma unroll
+        for (int k = 0; k < GS_FEATURE_DIM / 4; ++k)
+            dv[k] = make_float4(out[4 * k], out[4 * k + 1], out[4 * k + 2], out[4 * k + 3]);
+    }
+    if (grad_xyz_vis) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) grad_xyz_vis[3 * (size_t)i + k] = gx[k];
+    }
+}
+
+}  // namespace
+
+extern "C" int gs_point_backward(const float *xyz, const float *features, const int32_t *object_id,
+                                 const float *intrinsics, const float *q_cp, const float *t_cp, const float *t_pc,
+                                 const int32_t *ids, int n_visible, int n_points, const float *acc,
+                                 int color_max_sh_band, float grad_q_factor, float grad_s_factor,
+                                 float grad_alpha_factor, float grad_color_factor,
+                                 float grad_high_order_color_factor, float *grad_xyz, float *grad_features,
+                                 float *grad_xyz_visible, float *grad_features_visible, void *stream) {
+    GS_REQUIRE(n_visible >= 0 && n_points >= n_visible, "sizes");
+    hipStream_t s = (hipStream_t)stream;
+    if (n_points > 0) {
+        GS_CHECK_HIP(hipMemsetAsync(grad_xyz, 0, sizeof(float) * 3 * (size_t)n_points, s));
+        GS_CHECK_HIP(hipMemsetAsync(grad_features, 0, sizeof(float) * GS_FEATURE_DIM * (size_t)n_points, s));
+    }
+    if (n_visible == 0) return 0;
+    Factors fac;
+    fac.q = grad_q_factor; fac.s = grad_s_factor; fac.alpha = grad_alpha_factor;
+    fac.color = grad_color_factor; fac.color_hi = grad_high_order_color_factor;
+    fac.keep = color_max_sh_band <= 0 ? 1 : color_max_sh_band == 1 ? 4 : color_max_sh_band == 2 ? 9 : 16;
+    hipLaunchKernelGGL(point_backward_kernel, dim3(gs_div_up(n_visible, GS_BLOCK)), dim3(GS_BLOCK), 0, s, xyz,
+                       features, object_id, intrinsics, q_cp, t_cp, t_pc, ids, n_visible,
+                       reinterpret_cast<const float4 *>(acc), fac, grad_xyz, grad_features, grad_xyz_visible,
+                       grad_features_visible);
+    GS_CHECK_LAUNCH();
+    return 0;
+}

@@ -1,0 +1,171 @@
+// gs_sort.hip -- stable LSD radix sort of (64-bit key, 32-bit payload) pairs for gfx950.
+// Replaces torch.sort + gather of the reference (RAS:947-950) with the STABLE tie rule
+// (ties keep key-generation order = ascending offset into the visible list).
+//
+// Only the bits that can differ are sorted: the quantised-depth field [0, depth_bits) and the
+// tile field [32, 32+tile_bits); 8-bit digits.  Per pass:
+//   1. digit histogram per workgroup (SORT_ITEMS keys each)       -> counts[digit][block]
+//   2. exclusive scan of every digit row + digit totals            (256 workgroups)
+//   3. stable scatter: wave-level digit matching with ballots (64-lane match-any), per-wave
+//      digit counters in LDS, running per-digit bases across rounds.
+// All hand-written; no rocPRIM/hipCUB.
+#include "gs_common.h"
+
+namespace {
+
+constexpr int RADIX_BITS = 8;
+constexpr int RADIX = 1 << RADIX_BITS;
+constexpr int SORT_ROUNDS = 8;
+constexpr int SORT_ITEMS = GS_BLOCK * SORT_ROUNDS;  // keys per workgroup
+constexpr int WAVES = GS_BLOCK / GS_WAVE;
+
+__device__ __forceinline__ unsigned digit_of(uint64_t key, int shift, uint64_t flip) {
+    return (unsigned)(((key ^ flip) >> shift) & (RADIX - 1));
+}
+
+__global__ __launch_bounds__(GS_BLOCK) void sort_hist_kernel(const uint64_t *__restrict__ keys, long long n,
+                                                            int shift, uint64_t flip, int nblk,
+                                                            int32_t *__restrict__ counts) {
+    __shared__ int hist[RADIX];
+    hist[threadIdx.x] = 0;
+    __syncthreads();
+    const long long base = (long long)blockIdx.x * SORT_ITEMS;
+#pragma unroll
+    for (int r = 0; r < SORT_ROUNDS; ++r) {
+        long long i = base + r * GS_BLOCK + threadIdx.x;
+        if (i < n) atomicAdd(&hist[digit_of(keys[i], shift, flip)], 1);
+    }
+    __syncthreads();
+    counts[(size_t)threadIdx.x * nblk + blockIdx.x] = hist[threadIdx.x];
+}
+
+// workgroup d: exclusive scan of row d (nblk entries) in place, row total -> totals[d]
+__global__ __launch_bounds__(GS_BLOCK) void sort_scan_rows_kernel(int32_t *__restrict__ counts, int nblk,
+                                                                 int32_t *__restrict__ totals) {
+    __shared__ int lds[4];
+    int32_t *row = counts + (size_t)blockIdx.x * nblk;
+    int carry = 0;
+    for (int base = 0; base < nblk; base += GS_BLOCK) {
+        int i = base + threadIdx.x;
+        int v = i < nblk ? row[i] : 0;
+        int total;
+        int ex = gs_block_excl_scan(v, &total, lds);
+        if (i < nblk) row[i] = carry + ex;
+        carry += total;
+    }
+    if (threadIdx.x == 0) totals[blockIdx.x] = carry;
+}
+
+__global__ __launch_bounds__(GS_BLOCK) void sort_scatter_kernel(
+    const uint64_t *__restrict__ keys_in, const int32_t *__restrict__ payload_in, long long n, int shift,
+    uint64_t flip, int nblk, const int32_t *__restrict__ row_offsets, const int32_t *__restrict__ totals,
+    uint64_t *__restrict__ keys_out, int32_t *__restrict__ payload_out) {
+    __shared__ int s_base[RADIX];         // global destination of the next key of each digit
+    __shared__ int s_wave[WAVES][RADIX];  // per-round, per-wave digit counts
+    __shared__ int lds[4];
+    // digit base = exclusive scan of the 256 digit totals, plus this block's row offset
+    {
+        int total;
+        int ex = gs_block_excl_scan(totals[threadIdx.x], &total, lds);
+        s_base[threadIdx.x] = ex + row_offsets[(size_t)threadIdx.x * nblk + blockIdx.x];
+    }
+#pragma unroll
+    for (int w = 0; w < WAVES; ++w) s_wave[w][threadIdx.x] = 0;
+    __syncthreads();
+    const int w = threadIdx.x >> 6;
+    const long long base = (long long)blockIdx.x * SORT_ITEMS;
+    for (int r = 0; r < SORT_ROUNDS; ++r) {
+        const long long i = base + r * GS_BLOCK + threadIdx.x;
+        const bool valid = i < n;
+        uint64_t key = 0;
+        int32_t pay = 0;
+        unsigned d = 0;
+        if (valid) {
+            key = keys_in[i];
+            pay = payload_in[i];
+            d = digit_of(key, shift, flip);
+        }
+        // 64-lane match-any on the 8-bit digit: peers = lanes holding the same digit
+        unsigned long long peers = __ballot(valid);
+#pragma unroll
+        for (int b = 0; b < RADIX_BITS; ++b) {
+            const bool bit = (d >> b) & 1u;
+            const unsigned long long m = __ballot(bit);
+            peers &= bit ? m : ~m;
+        }
+        const int rank = gs_mbcnt(peers);  // same-digit lanes below me (stable order)
+        if (valid && rank == 0) s_wave[w][d] = __popcll(peers);
+        __syncthreads();
+        if (valid) {
+            int before = 0;
+#pragma unroll
+            for (int k = 0; k < WAVES; ++k)
+                if (k < w) before += s_wave[k][d];
+            const int dst = s_base[d] + before + rank;
+            keys_out[dst] = key;
+            payload_out[dst] = pay;
+        }
+        __syncthreads();
+        {
+            int add = 0;
+#pragma unroll
+            for (int k = 0; k < WAVES; ++k) {
+                add += s_wave[k][threadIdx.x];
+                s_wave[k][threadIdx.x] = 0;
+            }
+            s_base[threadIdx.x] += add;
+        }
+        __syncthreads();
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t gs_sort_workspace_bytes(int64_t n_keys) {
+    const size_t nblk = (size_t)gs_div_up(n_keys > 0 ? n_keys : 1, SORT_ITEMS);
+    return sizeof(int32_t) * (RADIX * nblk + RADIX + 64);
+}
+
+int gs_sort_pairs(uint64_t *keys, int32_t *payload, uint64_t *keys_alt, int32_t *payload_alt, int64_t n_keys,
+                  int depth_bits, int tile_bits, void *workspace, void *stream) {
+    GS_REQUIRE(n_keys >= 0 && n_keys < 0x7fffffffLL, "n_keys must fit int32");
+    GS_REQUIRE(depth_bits >= 0 && depth_bits <= 64 && tile_bits >= 0 && tile_bits <= 31, "bit ranges");
+    if (n_keys <= 1) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    const int nblk = gs_div_up(n_keys, SORT_ITEMS);
+    int32_t *counts = (int32_t *)workspace;
+    int32_t *totals = counts + (size_t)RADIX * nblk;
+
+    int shifts[16], n_pass = 0;
+    uint64_t flip = 0;
+    if (depth_bits >= 64) {  // full signed 64-bit order
+        for (int sh = 0; sh < 64; sh += RADIX_BITS) shifts[n_pass++] = sh;
+        flip = 0x8000000000000000ull;
+    } else {
+        for (int sh = 0; sh < depth_bits && sh < 32; sh += RADIX_BITS) shifts[n_pass++] = sh;
+        for (int sh = 32; sh < 32 + tile_bits; sh += RADIX_BITS) shifts[n_pass++] = sh;
+    }
+    uint64_t *kin = keys, *kout = keys_alt;
+    int32_t *pin = payload, *pout = payload_alt;
+    for (int p = 0; p < n_pass; ++p) {
+        hipLaunchKernelGGL(sort_hist_kernel, dim3(nblk), dim3(GS_BLOCK), 0, s, kin, (long long)n_keys, shifts[p],
+                           flip, nblk, counts);
+        GS_CHECK_LAUNCH();
+        hipLaunchKernelGGL(sort_scan_rows_kernel, dim3(RADIX), dim3(GS_BLOCK), 0, s, counts, nblk, totals);
+        GS_CHECK_LAUNCH();
+        hipLaunchKernelGGL(sort_scatter_kernel, dim3(nblk), dim3(GS_BLOCK), 0, s, kin, pin, (long long)n_keys,
+                           shifts[p], flip, nblk, counts, totals, kout, pout);
+        GS_CHECK_LAUNCH();
+        uint64_t *tk = kin; kin = kout; kout = tk;
+        int32_t *tp = pin; pin = pout; pout = tp;
+    }
+    if (kin != keys) {  // odd number of passes: result sits in the alt buffers
+        GS_CHECK_HIP(hipMemcpyAsync(keys, kin, sizeof(uint64_t) * n_keys, hipMemcpyDeviceToDevice, s));
+        GS_CHECK_HIP(hipMemcpyAsync(payload, pin, sizeof(int32_t) * n_keys, hipMemcpyDeviceToDevice, s));
+    }
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,81 @@
+"""Image-space (tile-row) sharding of the rasteriser across the GPUs of one node.
+
+The reference is single-GPU (no collective anywhere); this is the
+multi-GPU path BASELINE.json's north_star defines: the point cloud is replicated, GPU ``g`` of ``G``
+owns the interleaved 16-pixel tile rows ``g, g+G, g+2G, ...`` (interleaving balances the load), runs
+binning/sort/blend only for its rows, and ONE all-gather (RCCL over xGMI; ``backend="nccl"`` is
+RCCL on ROCm) assembles the full image on every rank.  In the backward pass every rank
+back-propagates its own tiles and the per-Gaussian accumulators (48 B x M, not the 236 B x N dense
+gradients) are summed with one all-reduce before the per-point chain rule, so every rank ends up
+with the full gradient of its replicated parameters.
+
+One process per GPU (``torch.distributed``); works unchanged on ``gloo`` for the CPU tests of the
+collective logic (tests/test_distributed_cpu.py).
+"""
+from __future__ import annotations
+
+from typing import Optional, Sequence
+
+import torch
+import torch.distributed as dist
+
+TILE_HEIGHT = 16
+
+
+def owned_tile_rows(num_tile_rows: int, rank: int, world: int) -> range:
+    return range(rank, num_tile_rows, world)
+
+
+def all_gather_tile_rows(tensors: Sequence[torch.Tensor], rank: int, world: int,
+                         group: Optional[dist.ProcessGroup] = None) -> None:
+    """In place: every tensor is [H, W, ...] with only this rank's tile rows valid; after the call all
+    rows are valid on every rank.  One collective per call: the per-rank blocks of all tensors are
+    packed into one byte buffer (fewer, larger collectives)."""
+    if world == 1:
+        return
+    height = tensors[0].shape[0]
+    th = height // TILE_HEIGHT
+    max_rows = (th + world - 1) // world
+    views, chunks = [], []
+    for t in tensors:
+        assert t.shape[0] == height and t.is_contiguous()
+        v = t.view(th, -1)  # one row of tiles = 16 image rows, contiguous
+        views.append(v)
+        mine = v[rank::world]
+        pad = torch.zeros((max_rows, v.shape[1]), dtype=v.dtype, device=v.device)
+        pad[: mine.shape[0]] = mine
+        chunks.append(pad.view(torch.uint8).reshape(-1))
+    send = torch.cat(chunks)
+    recv_flat = torch.empty(world * send.numel(), dtype=torch.uint8, device=send.device)
+    dist.all_gather_into_tensor(recv_flat, send, group=group)
+    recv = recv_flat.view(world, send.numel())
+    offset = 0
+    for v in views:
+        nbytes = max_rows * v.shape[1] * v.element_size()
+        block = recv[:, offset: offset + nbytes].reshape(world, -1).view(v.dtype).reshape(world, max_rows, v.shape[1])
+        for r in range(world):
+            if r == rank:
+                continue
+            rows = len(owned_tile_rows(th, r, world))
+            v[r::world] = block[r, :rows]
+        offset += nbytes
+
+
+def all_reduce_accumulators(acc: torch.Tensor, group: Optional[dist.ProcessGroup] = None) -> None:
+    """Sum the [M,12] backward accumulators over ranks.  Column 10 holds an int32 pixel count in the
+    float's bits (include/gsplat_hip.h) and is reduced as integers."""
+    npix = acc[:, 10].contiguous().view(torch.int32)
+    dist.all_reduce(npix, op=dist.ReduceOp.SUM, group=group)
+    acc[:, 10] = 0.0
+    dist.all_reduce(acc, op=dist.ReduceOp.SUM, group=group)
+    acc[:, 10] = npix.view(torch.float32)
+
+
+def shard_rasteriser_across_tile_rows(rasteriser, group: Optional[dist.ProcessGroup] = None):
+    """Configure a ``GaussianPointCloudRasterisation`` instance for tile-row sharding over ``group``."""
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    rasteriser.tile_row_begin, rasteriser.tile_row_step = rank, world
+    if world > 1:
+        rasteriser.image_gather = lambda tensors: all_gather_tile_rows(tensors, rank, world, group)
+        rasteriser.grad_accumulator_reduce = lambda acc: all_reduce_accumulators(acc, group)
+    return rasteriser

@@ -1,0 +1,189 @@
+"""Stage-level Python wrappers over the C ABI (include/gsplat_hip.h).
+
+Each function allocates its outputs with torch (the caller owns every buffer, the library
+allocates nothing), passes raw device pointers + the current HIP stream, and returns torch
+tensors.  One function per reference stage; the stage it replaces is cited in the C header.
+PyTorch is plumbing here (device memory + streams); all arithmetic runs in the HIP kernels.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import call, current_stream, ptr
+
+TILE_WIDTH = 16
+TILE_HEIGHT = 16
+ATTR_STRIDE = 12
+ACC_STRIDE = 12
+FEATURE_DIM = 56
+COUNTER_NUM_VISIBLE = 0
+COUNTER_NUM_KEYS = 1
+NUM_COUNTERS = 8
+_PRE_BLOCK = 256  # points per workgroup of gs_preprocess / gs_make_keys
+
+
+def _require_device(t: torch.Tensor, name: str) -> None:
+    if not t.is_cuda:
+        raise RuntimeError(
+            f"{name} is on {t.device}: the rasteriser runs on an AMD GPU (HIP) only; there is no CPU path")
+
+
+def _f32(t: torch.Tensor, name: str) -> torch.Tensor:
+    _require_device(t, name)
+    if t.dtype != torch.float32:
+        raise TypeError(f"{name} must be float32, got {t.dtype}")
+    return t.contiguous()
+
+
+def read_counters(counters: torch.Tensor) -> Tuple[int, ...]:
+    host = (ctypes.c_int32 * NUM_COUNTERS)()
+    call("gs_read_counters", ptr(counters), ctypes.cast(host, ctypes.c_void_p), NUM_COUNTERS,
+         current_stream(counters.device))
+    return tuple(host)
+
+
+def pose_inverse(q_pointcloud_camera: torch.Tensor, t_pointcloud_camera: torch.Tensor):
+    q = _f32(q_pointcloud_camera, "q_pointcloud_camera").reshape(-1, 4)
+    t = _f32(t_pointcloud_camera, "t_pointcloud_camera").reshape(-1, 3)
+    if q.shape[0] != t.shape[0] or q.shape[0] == 0:
+        raise ValueError("q_pointcloud_camera / t_pointcloud_camera must be (K,4)/(K,3) with K >= 1")
+    q_inv, t_inv = torch.empty_like(q), torch.empty_like(t)
+    call("gs_pose_inverse", ptr(q), ptr(t), ptr(q_inv), ptr(t_inv), q.shape[0], current_stream(q.device))
+    return q_inv, t_inv
+
+
+def filter_compact(xyz, invalid_mask, object_id, intrinsics, q_cp, t_cp, near_plane, far_plane, width, height,
+                   counters: Optional[torch.Tensor] = None):
+    """-> (mask int8[N], ids int32[M], counters).  Blocks on the size read-back (RAS:870)."""
+    xyz = _f32(xyz, "point_cloud")
+    n = xyz.shape[0]
+    dev = xyz.device
+    mask = torch.empty(n, dtype=torch.int8, device=dev)
+    ids = torch.empty(n, dtype=torch.int32, device=dev)
+    if counters is None:
+        counters = torch.zeros(NUM_COUNTERS, dtype=torch.int32, device=dev)
+    ws = torch.empty(_lib.load().gs_filter_workspace_bytes(n), dtype=torch.uint8, device=dev)
+    call("gs_filter_compact", ptr(xyz), ptr(invalid_mask), ptr(object_id), ptr(intrinsics), ptr(q_cp), ptr(t_cp),
+         n, float(near_plane), float(far_plane), int(width), int(height), ptr(mask), ptr(ids), ptr(counters),
+         ptr(ws), current_stream(dev))
+    m = read_counters(counters)[COUNTER_NUM_VISIBLE]
+    return mask, ids[:m], counters
+
+
+def preprocess(xyz, features, object_id, intrinsics, q_cp, t_cp, ids, width, height, tile_row_begin=0,
+               tile_row_step=1):
+    """-> (attrs f32[M,12], num_overlap_tiles i32[M], num_owned_tiles i32[M], block_sums i32[ceil(M/256)]).
+    Normalises features[ids, 0:4] IN PLACE (RAS:196-205)."""
+    m = ids.shape[0]
+    dev = xyz.device
+    attrs = torch.empty((m, ATTR_STRIDE), dtype=torch.float32, device=dev)
+    ntiles = torch.empty(m, dtype=torch.int32, device=dev)
+    nowned = torch.empty(m, dtype=torch.int32, device=dev)
+    block_sums = torch.empty((m + _PRE_BLOCK - 1) // _PRE_BLOCK, dtype=torch.int32, device=dev)
+    call("gs_preprocess", ptr(xyz), ptr(features), ptr(object_id), ptr(intrinsics), ptr(q_cp), ptr(t_cp), ptr(ids),
+         m, int(width), int(height), int(tile_row_begin), int(tile_row_step), ptr(attrs), ptr(ntiles), ptr(nowned),
+         ptr(block_sums), current_stream(dev))
+    return attrs, ntiles, nowned, block_sums
+
+
+def scan_block_sums(block_sums: torch.Tensor, counters: torch.Tensor) -> int:
+    """In-place exclusive scan; returns K.  Blocks on the size read-back (RAS:916)."""
+    call("gs_scan_block_sums", ptr(block_sums), block_sums.shape[0], ptr(counters), current_stream(counters.device))
+    k = read_counters(counters)[COUNTER_NUM_KEYS]
+    if k >= 0x7fffffff:
+        raise RuntimeError("more than 2^31-1 (tile, Gaussian) pairs: key offsets are int32 as in the reference")
+    return k
+
+
+def make_keys(attrs, num_owned_tiles, block_offsets, n_keys, width, height, depth_to_sort_key_scale,
+              tile_row_begin=0, tile_row_step=1):
+    dev = attrs.device
+    keys = torch.empty(n_keys, dtype=torch.int64, device=dev)
+    payload = torch.empty(n_keys, dtype=torch.int32, device=dev)
+    if n_keys > 0:
+        call("gs_make_keys", ptr(attrs), ptr(num_owned_tiles), ptr(block_offsets), attrs.shape[0], int(width),
+             int(height), int(tile_row_begin), int(tile_row_step), float(depth_to_sort_key_scale), ptr(keys),
+             ptr(payload), current_stream(dev))
+    return keys, payload
+
+
+def sort_key_bits(near_plane: float, far_plane: float, depth_to_sort_key_scale: float, num_tiles: int):
+    """Bit ranges that can differ between keys: quantised depth [0,depth_bits), tile [32,32+tile_bits)."""
+    tile_bits = max(int(num_tiles) - 1, 0).bit_length()
+    max_dq = far_plane * depth_to_sort_key_scale
+    if near_plane >= 0 and depth_to_sort_key_scale >= 0 and 0 <= max_dq < 2 ** 31 - 1:
+        return max(int(max_dq), 1).bit_length(), tile_bits
+    return 64, tile_bits  # negative depths borrow from the tile field: sort the whole signed key
+
+
+def sort_pairs(keys: torch.Tensor, payload: torch.Tensor, depth_bits: int, tile_bits: int) -> None:
+    """Stable sort of (keys, payload) in place."""
+    n = keys.shape[0]
+    if n <= 1:
+        return
+    dev = keys.device
+    keys_alt, payload_alt = torch.empty_like(keys), torch.empty_like(payload)
+    ws = torch.empty(_lib.load().gs_sort_workspace_bytes(n), dtype=torch.uint8, device=dev)
+    call("gs_sort_pairs", ptr(keys), ptr(payload), ptr(keys_alt), ptr(payload_alt), n, int(depth_bits),
+         int(tile_bits), ptr(ws), current_stream(dev))
+
+
+def tile_ranges(keys_sorted: torch.Tensor, num_tiles: int):
+    dev = keys_sorted.device
+    start = torch.empty(num_tiles, dtype=torch.int32, device=dev)
+    end = torch.empty(num_tiles, dtype=torch.int32, device=dev)
+    call("gs_tile_ranges", ptr(keys_sorted), keys_sorted.shape[0], ptr(start), ptr(end), int(num_tiles),
+         current_stream(dev))
+    return start, end
+
+
+def blend_forward(tile_start, tile_end, payload, attrs, width, height, tile_row_begin=0, tile_row_step=1,
+                  out=None):
+    dev = tile_start.device
+    if out is None:
+        alloc = torch.empty if tile_row_step == 1 else torch.zeros  # un-owned tiles are left untouched
+        out = (alloc((height, width, 3), dtype=torch.float32, device=dev),
+               alloc((height, width), dtype=torch.float32, device=dev),
+               alloc((height, width), dtype=torch.float32, device=dev),
+               alloc((height, width), dtype=torch.int32, device=dev),
+               alloc((height, width), dtype=torch.int32, device=dev))
+    image, depth, acc_alpha, last_eff, count = out
+    call("gs_blend_forward", ptr(tile_start), ptr(tile_end), ptr(payload), ptr(attrs), int(width), int(height),
+         int(tile_row_begin), int(tile_row_step), ptr(image), ptr(depth), ptr(acc_alpha), ptr(last_eff), ptr(count),
+         current_stream(dev))
+    return out
+
+
+def blend_backward(tile_start, tile_end, payload, attrs, grad_image, acc_alpha, last_eff, width, height,
+                   tile_row_begin=0, tile_row_step=1):
+    """-> (acc f32[M,12], magnitude_grad_viewspace_on_image f32[H,W,2])."""
+    dev = attrs.device
+    m = attrs.shape[0]
+    grad_image = _f32(grad_image, "grad_rasterized_image")
+    acc = torch.empty((m, ACC_STRIDE), dtype=torch.float32, device=dev)
+    alloc = torch.empty if tile_row_step == 1 else torch.zeros
+    mag = alloc((height, width, 2), dtype=torch.float32, device=dev)
+    call("gs_blend_backward", ptr(tile_start), ptr(tile_end), ptr(payload), ptr(attrs), ptr(grad_image),
+         ptr(acc_alpha), ptr(last_eff), m, int(width), int(height), int(tile_row_begin), int(tile_row_step),
+         ptr(acc), ptr(mag), current_stream(dev))
+    return acc, mag
+
+
+def point_backward(xyz, features, object_id, intrinsics, q_cp, t_cp, t_pc, ids, acc, color_max_sh_band,
+                   grad_q_factor, grad_s_factor, grad_alpha_factor, grad_color_factor,
+                   grad_high_order_color_factor, want_visible: bool):
+    dev = xyz.device
+    n, m = xyz.shape[0], ids.shape[0]
+    grad_xyz = torch.empty((n, 3), dtype=torch.float32, device=dev)
+    grad_feat = torch.empty((n, FEATURE_DIM), dtype=torch.float32, device=dev)
+    gx_vis = torch.empty((m, 3), dtype=torch.float32, device=dev) if want_visible else None
+    gf_vis = torch.empty((m, FEATURE_DIM), dtype=torch.float32, device=dev) if want_visible else None
+    call("gs_point_backward", ptr(xyz), ptr(features), ptr(object_id), ptr(intrinsics), ptr(q_cp), ptr(t_cp),
+         ptr(t_pc), ptr(ids), m, n, ptr(acc), int(color_max_sh_band), float(grad_q_factor), float(grad_s_factor),
+         float(grad_alpha_factor), float(grad_color_factor), float(grad_high_order_color_factor), ptr(grad_xyz),
+         ptr(grad_feat), ptr(gx_vis), ptr(gf_vis), current_stream(dev))
+    return grad_xyz, grad_feat, gx_vis, gf_vis

@@ -1,0 +1,64 @@
+"""Shared helpers of the parity tests (oracle <-> HIP path)."""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from oracle import gs_oracle as O
+from taichi_3d_gaussian_splatting_amd.synthetic import SyntheticScene, make_scene
+
+# pixels whose blend decisions sit this close to a discontinuity (alpha = 1/255 skip, RAS:451;
+# T' = 1e-4 stop, RAS:458) may legitimately flip between two correct fp32 implementations
+FRAGILE_MARGIN = 5e-7
+PIXEL_TOL = 1e-4  # BASELINE.json north_star: pixel L-inf <= 1e-4
+
+
+def scene_numpy(s: SyntheticScene):
+    return (s.point_cloud.numpy(), s.point_cloud_features.numpy(), s.point_invalid_mask.numpy(),
+            s.point_object_id.numpy(), s.camera_intrinsics.numpy(), s.q_pointcloud_camera.numpy(),
+            s.t_pointcloud_camera.numpy(), s.height, s.width)
+
+
+def oracle_forward(s: SyntheticScene, precision="f32", want_margin=True):
+    return O.forward(*scene_numpy(s), near_plane=s.near_plane, far_plane=s.far_plane,
+                     depth_to_sort_key_scale=s.depth_to_sort_key_scale, precision=precision,
+                     want_margin=want_margin)
+
+
+def pack_attrs(f: dict) -> np.ndarray:
+    """Oracle SoA intermediates -> the packed [M,12] record of include/gsplat_hip.h."""
+    m = f["ids"].shape[0]
+    a = np.empty((m, 12), np.float32)
+    a[:, 0:2] = f["uv"]; a[:, 2] = f["xyz_cam"][:, 2]; a[:, 3] = f["alpha"]
+    a[:, 4:8] = f["conic"]; a[:, 8:11] = f["rgb"]; a[:, 11] = f["radii"]
+    return a
+
+
+def pack_acc(acc10: np.ndarray, npix: np.ndarray) -> np.ndarray:
+    a = np.zeros((acc10.shape[0], 12), np.float32)
+    a[:, :10] = acc10
+    a[:, 10] = npix.astype(np.int32).view(np.float32)
+    return a
+
+
+def dev(x, device="cuda"):
+    return torch.as_tensor(np.ascontiguousarray(x)).to(device)
+
+
+def small_scene(n=10_000, size=256, seed=0, sh_degree=3, **kw) -> SyntheticScene:
+    return make_scene(n=n, height=size, width=size, s_min=0.01, s_max=0.08, sh_degree=sh_degree, seed=seed, **kw)
+
+
+def close_fraction(a: np.ndarray, b: np.ndarray, rtol: float, atol: float) -> float:
+    """Fraction of elements with |a-b| <= atol + rtol*|b|."""
+    a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
+    return float(np.mean(np.abs(a - b) <= atol + rtol * np.abs(b)))
+
+
+def rel_l2(a: np.ndarray, b: np.ndarray) -> float:
+    a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
+    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
+
+
+def report(name: str, **kv) -> None:
+    print(f"[parity] {name}: " + ", ".join(f"{k}={v}" for k, v in kv.items()))

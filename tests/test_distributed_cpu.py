@@ -1,0 +1,70 @@
+"""world_size-2 gloo tests (CPU) of the collective logic of the tile-row sharded path."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, height, width):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from taichi_3d_gaussian_splatting_amd.distributed import (all_gather_tile_rows, all_reduce_accumulators,
+                                                              owned_tile_rows)
+    th = height // 16
+    g = torch.Generator().manual_seed(7)
+    full_image = torch.rand(height, width, 3, generator=g)
+    full_depth = torch.rand(height, width, generator=g)
+    full_count = torch.randint(0, 1000, (height, width), generator=g, dtype=torch.int32)
+    # each rank holds only its own tile rows (others are zero, as hip_ops.blend_forward leaves them)
+    rows = torch.arange(height) // 16
+    own = torch.zeros(height, dtype=torch.bool)
+    for r in owned_tile_rows(th, rank, world):
+        own |= rows == r
+    image = torch.where(own[:, None, None], full_image, torch.zeros_like(full_image)).contiguous()
+    depth = torch.where(own[:, None], full_depth, torch.zeros_like(full_depth)).contiguous()
+    count = torch.where(own[:, None], full_count, torch.zeros_like(full_count)).contiguous()
+    all_gather_tile_rows([image, depth, count], rank, world)
+    assert torch.equal(image, full_image) and torch.equal(depth, full_depth) and torch.equal(count, full_count)
+
+    # gradient accumulators: float columns summed, column 10 summed as int32 bits
+    m = 1000
+    gens = [torch.Generator().manual_seed(100 + r) for r in range(world)]
+    accs = [torch.rand(m, 12, generator=gg) for gg in gens]
+    npix = [torch.randint(0, 5000, (m,), generator=gg, dtype=torch.int32) for gg in gens]
+    acc = accs[rank].clone()
+    acc[:, 10] = npix[rank].view(torch.float32)
+    all_reduce_accumulators(acc)
+    expect = sum(accs)
+    assert torch.allclose(acc[:, :10], expect[:, :10]) and torch.allclose(acc[:, 11], expect[:, 11])
+    assert torch.equal(acc[:, 10].contiguous().view(torch.int32), sum(npix))
+    dist.destroy_process_group()
+
+
+def _run(world, height, width):
+    mp.spawn(_worker, args=(world, _free_port(), height, width), nprocs=world, join=True)
+
+
+def test_all_gather_tile_rows_and_grad_reduce_world2():
+    _run(2, 1072 // 4 // 16 * 16 + 16, 64)   # 17 tile rows: uneven split (9 + 8)
+
+
+def test_all_gather_tile_rows_world3_uneven():
+    _run(3, 80, 32)   # 5 tile rows over 3 ranks: 2 + 2 + 1
+
+
+def test_owned_rows_partition():
+    from taichi_3d_gaussian_splatting_amd.distributed import owned_tile_rows
+    for th in (1, 5, 67):
+        for world in (1, 2, 4, 8):
+            got = sorted(r for g in range(world) for r in owned_tile_rows(th, g, world))
+            assert got == list(range(th))

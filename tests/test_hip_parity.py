@@ -1,0 +1,406 @@
+"""GPU parity tests: every HIP stage (through the C ABI) against the CPU oracle on the same
+seeded inputs, then the whole operator.  Integer/index work must be bit-exact; floating point is
+held to the tolerance written next to each assertion (north_star: pixel L-inf <= 1e-4).
+
+Each stage test feeds the ORACLE's intermediates to the stage under test, so one faulty kernel
+cannot mask (or be masked by) another.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import gs_oracle as O
+from tests.helpers import (FRAGILE_MARGIN, PIXEL_TOL, close_fraction, dev, oracle_forward, pack_acc, pack_attrs,
+                           rel_l2, report, scene_numpy, small_scene)
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    from taichi_3d_gaussian_splatting_amd import hip_ops
+    return hip_ops
+
+
+@pytest.fixture(scope="module")
+def scene():
+    return small_scene(n=10_000, size=256, seed=0, sh_degree=3, invalid_fraction=0.05)
+
+
+@pytest.fixture(scope="module")
+def ofwd(scene):
+    return oracle_forward(scene)
+
+
+@pytest.fixture(scope="module")
+def obwd(scene, ofwd):
+    from taichi_3d_gaussian_splatting_amd.synthetic import make_grad_image
+    g = make_grad_image(scene.height, scene.width).numpy()
+    return g, O.backward(ofwd, g, color_max_sh_band=3)
+
+
+def test_pose_inverse(ops):
+    rng = np.random.default_rng(0)
+    q = rng.normal(size=(7, 4)).astype(np.float32)
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    q[3] *= 1.5  # the conjugate is returned un-normalised (UTL:426-432)
+    t = rng.normal(size=(7, 3)).astype(np.float32)
+    qi, ti = ops.pose_inverse(dev(q), dev(t))
+    qo, to = O.inverse_se3_qt(q, t)
+    assert np.array_equal(qi.cpu().numpy(), qo)
+    assert np.allclose(ti.cpu().numpy(), to, rtol=0, atol=1e-6)
+
+
+def test_filter_compact_bit_exact(ops, scene, ofwd):
+    s = scene
+    q_cp, t_cp = dev(ofwd["q_cp"]), dev(ofwd["t_cp"])
+    mask, ids, _ = ops.filter_compact(dev(s.point_cloud), dev(s.point_invalid_mask), dev(s.point_object_id),
+                                      dev(s.camera_intrinsics), q_cp, t_cp, s.near_plane, s.far_plane, s.width,
+                                      s.height)
+    assert np.array_equal(mask.cpu().numpy(), ofwd["mask"])
+    assert np.array_equal(ids.cpu().numpy(), ofwd["ids"])  # ascending ids: order-preserving compaction
+
+
+def test_preprocess(ops, scene, ofwd):
+    s = scene
+    feat = dev(s.point_cloud_features).clone()
+    attrs, ntiles, nowned, block_sums = ops.preprocess(
+        dev(s.point_cloud), feat, dev(s.point_object_id), dev(s.camera_intrinsics), dev(ofwd["q_cp"]),
+        dev(ofwd["t_cp"]), dev(ofwd["ids"]), s.width, s.height)
+    a, ref = attrs.cpu().numpy(), pack_attrs(ofwd)
+    # projection is evaluated in the oracle's operation order with contraction off: bit-exact
+    assert np.array_equal(a[:, 0:3], ref[:, 0:3]), "uv / depth must be bit-exact"
+    for name, sl, rtol in (("opacity", slice(3, 4), 1e-6), ("conic", slice(4, 7), 2e-5), ("rescale", slice(7, 8), 2e-5),
+                           ("rgb", slice(8, 11), 2e-6), ("radius", slice(11, 12), 1e-5)):
+        frac = close_fraction(a[:, sl], ref[:, sl], rtol=rtol, atol=1e-7)
+        report(f"preprocess.{name}", close=frac, max_abs=float(np.abs(a[:, sl] - ref[:, sl]).max()))
+        assert frac == 1.0, name
+    # in-place quaternion normalisation of visible rows only (RAS:196-205)
+    f_hip, f_ref = feat.cpu().numpy(), ofwd["feat"]
+    assert np.allclose(f_hip[:, :4], f_ref[:, :4], rtol=0, atol=1e-7)
+    assert np.array_equal(f_hip[:, 4:], s.point_cloud_features.numpy()[:, 4:])
+    invisible = np.setdiff1d(np.arange(f_hip.shape[0]), ofwd["ids"])
+    assert np.array_equal(f_hip[invisible], s.point_cloud_features.numpy()[invisible])
+    mism = int((ntiles.cpu().numpy() != ofwd["num_overlap_tiles"]).sum())
+    report("preprocess.num_overlap_tiles", mismatches=mism, m=len(ofwd["ids"]))
+    assert mism <= max(1, len(ofwd["ids"]) // 10_000)
+    assert np.array_equal(nowned.cpu().numpy(), ntiles.cpu().numpy())  # 1 GPU owns every row
+    sums = np.add.reduceat(ntiles.cpu().numpy(), np.arange(0, len(ofwd["ids"]), 256))
+    assert np.array_equal(block_sums.cpu().numpy(), sums)
+
+
+def test_keys_sort_ranges_bit_exact(ops, scene, ofwd):
+    s = scene
+    attrs = dev(pack_attrs(ofwd))
+    nt = dev(ofwd["num_overlap_tiles"])
+    m = nt.shape[0]
+    block_sums = dev(np.add.reduceat(ofwd["num_overlap_tiles"], np.arange(0, m, 256)).astype(np.int32))
+    counters = torch.zeros(ops.NUM_COUNTERS, dtype=torch.int32, device="cuda")
+    k = ops.scan_block_sums(block_sums, counters)
+    assert k == ofwd["keys"].shape[0]
+    keys, payload = ops.make_keys(attrs, nt, block_sums, k, s.width, s.height, s.depth_to_sort_key_scale)
+    # unsorted keys: same generation order as RAS:161-172
+    uk = np.empty(k, np.int64); up = np.empty(k, np.int32)
+    import ctypes
+    O._lib("f32").gs_oracle_make_keys(O._p(ofwd["uv"]), O._p(ofwd["xyz_cam"]), O._p(ofwd["radii"]),
+                                      O._p(ofwd["offsets"]), ctypes.c_int(m), ctypes.c_int(s.width),
+                                      ctypes.c_int(s.height), ctypes.c_float(s.depth_to_sort_key_scale),
+                                      O._p(uk), O._p(up))
+    assert np.array_equal(keys.cpu().numpy(), uk)
+    assert np.array_equal(payload.cpu().numpy(), up)
+    num_tiles = (s.width // 16) * (s.height // 16)
+    db, tb = ops.sort_key_bits(s.near_plane, s.far_plane, s.depth_to_sort_key_scale, num_tiles)
+    ops.sort_pairs(keys, payload, db, tb)
+    assert np.array_equal(keys.cpu().numpy(), ofwd["keys"])
+    assert np.array_equal(payload.cpu().numpy(), ofwd["payload"]), "stable tie order"
+    start, end = ops.tile_ranges(keys, num_tiles)
+    assert np.array_equal(start.cpu().numpy(), ofwd["tile_start"])
+    assert np.array_equal(end.cpu().numpy(), ofwd["tile_end"])
+
+
+@pytest.mark.parametrize("n,depth_bits,tile_bits", [(1, 17, 13), (2, 17, 13), (257, 8, 3), (5000, 17, 13),
+                                                     (70_000, 9, 5), (300_001, 64, 13)])
+def test_radix_sort_stable_vs_numpy(ops, n, depth_bits, tile_bits):
+    rng = np.random.default_rng(n)
+    if depth_bits == 64:  # negative depths: the full signed key is sorted
+        dq = rng.integers(-50, 50, size=n).astype(np.int64)
+    else:
+        dq = rng.integers(0, 1 << min(depth_bits, 6), size=n).astype(np.int64)  # few values: many ties
+    tile = rng.integers(0, 1 << tile_bits, size=n).astype(np.int64)
+    keys = dq + (tile << 32)
+    payload = np.arange(n, dtype=np.int32)
+    k, p = dev(keys), dev(payload)
+    ops.sort_pairs(k, p, depth_bits, tile_bits)
+    order = np.argsort(keys, kind="stable")
+    assert np.array_equal(k.cpu().numpy(), keys[order])
+    assert np.array_equal(p.cpu().numpy(), payload[order])
+
+
+def test_find_tile_start_and_end_known_answer(ops):
+    # the reference's own known-answer vector, T_RAS:18-51, through the drop-in symbol
+    from taichi_3d_gaussian_splatting_amd.GaussianPointCloudRasterisation import find_tile_start_and_end
+    keys = torch.tensor([0x100000000, 0x100000001, 0x200000000, 0x200000001, 0x200000002, 0x300000000,
+                         0x300000001], dtype=torch.int64, device="cuda")
+    start = torch.zeros(4, dtype=torch.int32, device="cuda")
+    end = torch.zeros(4, dtype=torch.int32, device="cuda")
+    find_tile_start_and_end(keys, start, end)
+    assert start.tolist() == [0, 0, 2, 5] and end.tolist() == [0, 2, 5, 7]
+
+
+def _check_image(name, hip, ref, fragile):
+    diff = np.abs(hip.astype(np.float64) - ref.astype(np.float64))
+    if diff.ndim == 3:
+        diff = diff.max(axis=2)
+    ok = ~fragile
+    report(name, linf_nonfragile=float(diff[ok].max()), linf_all=float(diff.max()),
+           fragile_fraction=float(fragile.mean()), over_tol_all=int((diff > PIXEL_TOL).sum()))
+    assert diff[ok].max() <= PIXEL_TOL
+    assert fragile.mean() < 0.02
+
+
+def test_blend_forward(ops, scene, ofwd):
+    s = scene
+    out = ops.blend_forward(dev(ofwd["tile_start"]), dev(ofwd["tile_end"]), dev(ofwd["payload"]),
+                            dev(pack_attrs(ofwd)), s.width, s.height)
+    image, depth, acc_alpha, last_eff, count = [t.cpu().numpy() for t in out]
+    fragile = ofwd["margin"] < FRAGILE_MARGIN
+    _check_image("blend_forward.image", image, ofwd["image"], fragile)
+    _check_image("blend_forward.acc_alpha", acc_alpha, ofwd["acc_alpha"], fragile)
+    ok = ~fragile
+    assert np.allclose(depth[ok], ofwd["depth"][ok], rtol=1e-4, atol=1e-4)
+    assert np.array_equal(last_eff[ok], ofwd["last_eff"][ok])
+    assert np.array_equal(count[ok], ofwd["count"][ok])
+
+
+def _check_acc(name, hip, ref, frac_needed=0.999):
+    scale = float(np.abs(ref).max()) + 1e-30
+    frac = close_fraction(hip, ref, rtol=2e-3, atol=2e-6 * scale)
+    r = rel_l2(hip, ref)
+    report(name, close_fraction=frac, rel_l2=r, scale=scale)
+    assert frac >= frac_needed, name
+    assert r < 2e-3, name
+
+
+def test_blend_backward(ops, scene, ofwd, obwd):
+    s = scene
+    g, ob = obwd
+    acc, mag = ops.blend_backward(dev(ofwd["tile_start"]), dev(ofwd["tile_end"]), dev(ofwd["payload"]),
+                                  dev(pack_attrs(ofwd)), dev(g), dev(ofwd["acc_alpha"]), dev(ofwd["last_eff"]),
+                                  s.width, s.height)
+    acc = acc.cpu().numpy()
+    names = ["duv_u", "duv_v", "dcov00", "dcov01", "dcov11", "dr", "dg", "db", "dlogit", "magnitude"]
+    for c, nme in enumerate(names):
+        _check_acc(f"blend_backward.{nme}", acc[:, c], ob["acc"][:, c])
+    npix = acc[:, 10].copy().view(np.int32)
+    ref_npix = ob["hook"]["num_affected_pixels"]
+    mism = int((npix != ref_npix).sum())
+    report("blend_backward.num_affected_pixels", mismatched_points=mism,
+           max_abs=int(np.abs(npix - ref_npix).max()))
+    assert mism <= 0.01 * len(npix) and np.abs(npix - ref_npix).max() <= 2
+    _check_acc("blend_backward.magnitude_image", mag.cpu().numpy(), ob["hook"]["magnitude_grad_viewspace_on_image"],
+               frac_needed=0.995)
+
+
+def test_point_backward(ops, scene, ofwd, obwd):
+    s = scene
+    g, ob = obwd
+    acc = pack_acc(ob["acc"], ob["hook"]["num_affected_pixels"])
+    gx, gf, gxv, gfv = ops.point_backward(
+        dev(s.point_cloud), dev(ofwd["feat"]), dev(s.point_object_id), dev(s.camera_intrinsics), dev(ofwd["q_cp"]),
+        dev(ofwd["t_cp"]), dev(ofwd["t_pc"]), dev(ofwd["ids"]), dev(acc), 3, O.GRAD_Q_FACTOR, O.GRAD_S_FACTOR,
+        O.GRAD_ALPHA_FACTOR, O.GRAD_COLOR_FACTOR, O.GRAD_HIGH_ORDER_COLOR_FACTOR, want_visible=True)
+    gx, gf = gx.cpu().numpy(), gf.cpu().numpy()
+    for name, hip, ref in (("xyz", gx, ob["grad_xyz"]), ("q", gf[:, :4], ob["grad_feat"][:, :4]),
+                           ("s", gf[:, 4:7], ob["grad_feat"][:, 4:7]), ("logit", gf[:, 7], ob["grad_feat"][:, 7]),
+                           ("sh", gf[:, 8:], ob["grad_feat"][:, 8:])):
+        scale = float(np.abs(ref).max()) + 1e-30
+        frac = close_fraction(hip, ref, rtol=1e-4, atol=1e-6 * scale)
+        report(f"point_backward.{name}", close_fraction=frac, rel_l2=rel_l2(hip, ref))
+        assert frac >= 0.9999 and rel_l2(hip, ref) < 1e-5
+    # rows of points that are not visible are exactly zero; compact hook copies match the dense rows
+    invisible = np.setdiff1d(np.arange(gx.shape[0]), ofwd["ids"])
+    assert not gx[invisible].any() and not gf[invisible].any()
+    assert np.array_equal(gxv.cpu().numpy(), gx[ofwd["ids"]])
+    assert np.array_equal(gfv.cpu().numpy(), gf[ofwd["ids"]])
+
+
+@pytest.mark.parametrize("band,keep", [(0, 1), (1, 4), (2, 9), (3, 16)])
+def test_point_backward_sh_band_clearing(ops, scene, ofwd, obwd, band, keep):
+    s = scene
+    g, ob = obwd
+    acc = pack_acc(ob["acc"], ob["hook"]["num_affected_pixels"])
+    _, gf, _, _ = ops.point_backward(
+        dev(s.point_cloud), dev(ofwd["feat"]), dev(s.point_object_id), dev(s.camera_intrinsics), dev(ofwd["q_cp"]),
+        dev(ofwd["t_cp"]), dev(ofwd["t_pc"]), dev(ofwd["ids"]), dev(acc), band, O.GRAD_Q_FACTOR, O.GRAD_S_FACTOR,
+        O.GRAD_ALPHA_FACTOR, O.GRAD_COLOR_FACTOR, O.GRAD_HIGH_ORDER_COLOR_FACTOR, want_visible=False)
+    gf = gf.cpu().numpy()
+    ref = ob["grad_feat"].copy()  # computed with band 3
+    O.clear_grad_by_color_max_sh_band(ref, band)
+    for base in (8, 24, 40):
+        assert not gf[:, base + keep: base + 16].any()
+    assert rel_l2(gf, ref) < 1e-5
+
+
+# ------------------------------------------------------------------------------- whole operator
+def _run_operator(scene, grad_image, band=3, hook=None, row=(0, 1)):
+    from taichi_3d_gaussian_splatting_amd import CameraInfo, GaussianPointCloudRasterisation as Op
+    s = scene.to("cuda")
+    xyz = s.point_cloud.clone().requires_grad_(True)
+    feat = s.point_cloud_features.clone().requires_grad_(True)
+    op = Op(Op.GaussianPointCloudRasterisationConfig(near_plane=s.near_plane, far_plane=s.far_plane,
+                                                     depth_to_sort_key_scale=s.depth_to_sort_key_scale),
+            backward_valid_point_hook=hook)
+    op.tile_row_begin, op.tile_row_step = row
+    inp = Op.GaussianPointCloudRasterisationInput(
+        point_cloud=xyz, point_cloud_features=feat, point_object_id=s.point_object_id,
+        point_invalid_mask=s.point_invalid_mask,
+        camera_info=CameraInfo(camera_intrinsics=s.camera_intrinsics, camera_height=s.height,
+                               camera_width=s.width, camera_id=0),
+        q_pointcloud_camera=s.q_pointcloud_camera, t_pointcloud_camera=s.t_pointcloud_camera,
+        color_max_sh_band=band)
+    image, depth, count = op(inp)
+    if grad_image is not None:
+        (image * grad_image.to("cuda")).sum().backward()
+    return image, depth, count, xyz, feat
+
+
+def test_operator_end_to_end(scene, ofwd, obwd):
+    from taichi_3d_gaussian_splatting_amd.synthetic import make_grad_image
+    g, ob = obwd
+    got = {}
+    image, depth, count, xyz, feat = _run_operator(scene, make_grad_image(scene.height, scene.width), 3,
+                                                   hook=lambda h: got.setdefault("h", h))
+    assert image.shape == (scene.height, scene.width, 3) and image.dtype == torch.float32
+    assert depth.shape == (scene.height, scene.width) and count.dtype == torch.int32
+    fragile = ofwd["margin"] < FRAGILE_MARGIN
+    _check_image("operator.image", image.detach().cpu().numpy(), ofwd["image"], fragile)
+    ok = ~fragile
+    assert np.allclose(depth.cpu().numpy()[ok], ofwd["depth"][ok], rtol=1e-4, atol=1e-4)
+    assert np.array_equal(count.cpu().numpy()[ok], ofwd["count"][ok])
+    # side effect: visible quaternions normalised in place in the caller's tensor
+    assert np.allclose(feat.detach().cpu().numpy()[:, :4], ofwd["feat"][:, :4], atol=1e-7)
+    # gradients (fp32 tolerance: 99.9 % of entries within rel 2e-3, global rel-L2 < 2e-3)
+    _check_acc("operator.grad_xyz", xyz.grad.cpu().numpy(), ob["grad_xyz"])
+    _check_acc("operator.grad_feat", feat.grad.cpu().numpy(), ob["grad_feat"])
+    h, ho = got["h"], ob["hook"]
+    m = len(ofwd["ids"])
+    assert np.array_equal(h.point_id_in_camera_list.cpu().numpy(), ho["point_id_in_camera_list"])
+    assert h.grad_point_in_camera.shape == (m, 3) and h.grad_pointfeatures_in_camera.shape == (m, 56)
+    assert h.grad_viewspace.shape == (m, 2) and h.magnitude_grad_viewspace.shape == (m,)
+    assert h.magnitude_grad_viewspace_on_image.shape == (scene.height, scene.width, 2)
+    assert h.num_affected_pixels.dtype == torch.int32 and h.num_overlap_tiles.dtype == torch.int32
+    assert np.array_equal(h.num_overlap_tiles.cpu().numpy(), ho["num_overlap_tiles"])
+    assert np.array_equal(h.point_depth.cpu().numpy(), ho["point_depth"])
+    assert np.array_equal(h.point_uv_in_camera.cpu().numpy(), ho["point_uv_in_camera"])
+    _check_acc("operator.hook.grad_viewspace", h.grad_viewspace.cpu().numpy(), ho["grad_viewspace"])
+    _check_acc("operator.hook.grad_pointfeatures", h.grad_pointfeatures_in_camera.cpu().numpy(),
+               ho["grad_pointfeatures_in_camera"])
+
+
+def test_operator_tile_row_sharding_matches_single(scene):
+    """Image-space sharding: rendering tile rows {0,2,4,..} and {1,3,5,..} separately and merging
+    equals the un-sharded render bit-for-bit; partial gradients add up."""
+    from taichi_3d_gaussian_splatting_amd.synthetic import make_grad_image
+    g = make_grad_image(scene.height, scene.width)
+    image, depth, count, xyz, feat = _run_operator(scene, g)
+    parts = [_run_operator(scene, g, row=(r, 2)) for r in range(2)]
+    rows = torch.arange(scene.height, device="cuda") // 16
+    merged = torch.where((rows % 2 == 0)[:, None, None], parts[0][0], parts[1][0])
+    assert torch.equal(merged, image)
+    merged_count = torch.where((rows % 2 == 0)[:, None], parts[0][2], parts[1][2])
+    assert torch.equal(merged_count, count)
+    gsum = parts[0][4].grad + parts[1][4].grad
+    assert rel_l2(gsum.cpu().numpy(), feat.grad.cpu().numpy()) < 1e-4
+
+
+def test_operator_edge_cases():
+    from taichi_3d_gaussian_splatting_amd.synthetic import make_grad_image
+    # (a) every point invalid -> M = 0: zero image, zero grads, no crash (RAS:915-918,934,959,980)
+    s = small_scene(n=300, size=64, seed=1, invalid_fraction=1.1)
+    image, depth, count, xyz, feat = _run_operator(s, make_grad_image(64, 64))
+    assert not image.any() and not count.any() and not xyz.grad.any() and not feat.grad.any()
+    # (b) a single Gaussian
+    s1 = small_scene(n=1, size=64, seed=2)
+    s1.point_cloud[:] = torch.tensor([[0.05, -0.02, 0.0]])
+    f = oracle_forward(s1)
+    image, *_ = _run_operator(s1, None)
+    assert np.abs(image.detach().cpu().numpy() - f["image"])[f["margin"] >= FRAGILE_MARGIN].max() <= PIXEL_TOL
+    assert image.max() > 0.01
+    # (c) ragged sizes: N not a multiple of any block size, non-square image
+    from taichi_3d_gaussian_splatting_amd.synthetic import make_scene
+    s2 = make_scene(n=1237, height=48, width=112, s_min=0.02, s_max=0.1, seed=3)
+    f2 = oracle_forward(s2)
+    image, depth, count, *_ = _run_operator(s2, None)
+    assert np.abs(image.detach().cpu().numpy() - f2["image"])[f2["margin"] >= FRAGILE_MARGIN].max() <= PIXEL_TOL
+
+
+def test_operator_multi_object_poses():
+    """Kobj = 2: per-point object ids select the camera pose (RAS:56-59,272-275,727-732)."""
+    from taichi_3d_gaussian_splatting_amd.synthetic import make_grad_image
+    s = small_scene(n=4000, size=128, seed=5)
+    s.point_object_id = (torch.arange(4000) % 2).to(torch.int32)
+    q2 = torch.tensor([[0.0, 0.0, 0.0, 1.0], [0.02, -0.03, 0.01, 1.0]])
+    s.q_pointcloud_camera = q2 / q2.norm(dim=1, keepdim=True)
+    s.t_pointcloud_camera = torch.tensor([[0.0, 0.0, -3.0], [0.1, -0.05, -3.2]])
+    f = oracle_forward(s)
+    g = make_grad_image(128, 128)
+    ob = O.backward(f, g.numpy(), 3)
+    image, depth, count, xyz, feat = _run_operator(s, g)
+    _check_image("multi_object.image", image.detach().cpu().numpy(), f["image"], f["margin"] < FRAGILE_MARGIN)
+    _check_acc("multi_object.grad_feat", feat.grad.cpu().numpy(), ob["grad_feat"])
+    _check_acc("multi_object.grad_xyz", xyz.grad.cpu().numpy(), ob["grad_xyz"])
+
+
+def test_operator_cfg2_size_forward_backward():
+    """BASELINE config 2: 1e5 Gaussians, 800x800, SH degree 3, forward + backward vs the oracle."""
+    from taichi_3d_gaussian_splatting_amd.synthetic import make_config_scene, make_grad_image
+    s = make_config_scene("cfg2_100k_800")
+    f = oracle_forward(s)
+    g = make_grad_image(s.height, s.width)
+    ob = O.backward(f, g.numpy(), 3)
+    image, depth, count, xyz, feat = _run_operator(s, g)
+    report("cfg2.sizes", M=len(f["ids"]), K=len(f["keys"]))
+    _check_image("cfg2.image", image.detach().cpu().numpy(), f["image"], f["margin"] < FRAGILE_MARGIN)
+    _check_acc("cfg2.grad_feat", feat.grad.cpu().numpy(), ob["grad_feat"])
+    _check_acc("cfg2.grad_xyz", xyz.grad.cpu().numpy(), ob["grad_xyz"])
+
+
+def test_headline_size_properties(ops):
+    """Full size (1e6 Gaussians @1920x1072): size-independent properties instead of the oracle."""
+    from taichi_3d_gaussian_splatting_amd.synthetic import make_config_scene
+    s = make_config_scene("headline_1m_1080p").to("cuda")
+    q_cp, t_cp = ops.pose_inverse(s.q_pointcloud_camera, s.t_pointcloud_camera)
+    mask, ids, counters = ops.filter_compact(s.point_cloud, s.point_invalid_mask, s.point_object_id,
+                                             s.camera_intrinsics, q_cp, t_cp, s.near_plane, s.far_plane, s.width,
+                                             s.height)
+    assert torch.equal(ids.long(), torch.nonzero(mask).flatten())  # ordered compaction
+    feat = s.point_cloud_features.clone()
+    attrs, ntiles, nowned, block_sums = ops.preprocess(s.point_cloud, feat, s.point_object_id, s.camera_intrinsics,
+                                                       q_cp, t_cp, ids, s.width, s.height)
+    assert torch.allclose(feat[ids.long(), :4].norm(dim=1), torch.ones(ids.shape[0], device="cuda"), atol=1e-6)
+    total = int(ntiles.sum().item())
+    k = ops.scan_block_sums(block_sums, counters)
+    assert k == total
+    keys, payload = ops.make_keys(attrs, nowned, block_sums, k, s.width, s.height, s.depth_to_sort_key_scale)
+    # histogram of payload = tile counts (every point emits exactly its count)
+    assert torch.equal(torch.bincount(payload.long(), minlength=ids.shape[0]).int(), ntiles)
+    num_tiles = (s.width // 16) * (s.height // 16)
+    db, tb = ops.sort_key_bits(s.near_plane, s.far_plane, s.depth_to_sort_key_scale, num_tiles)
+    k0, p0 = keys.clone(), payload.clone()
+    ops.sort_pairs(keys, payload, db, tb)
+    ref_keys, perm = torch.sort(k0, stable=True)
+    assert torch.equal(keys, ref_keys) and torch.equal(payload, p0[perm])  # sortedness + stability
+    start, end = ops.tile_ranges(keys, num_tiles)
+    tile_of = (keys >> 32).int()
+    cnt = torch.bincount(tile_of.long(), minlength=num_tiles).int()
+    assert torch.equal(end - start, cnt)
+    image, depth, acc_alpha, last_eff, count = ops.blend_forward(start, end, payload, attrs, s.width, s.height)
+    assert torch.isfinite(image).all() and image.min() >= 0 and image.max() <= 1.0 + 1e-5
+    assert acc_alpha.min() >= 0 and acc_alpha.max() <= 1.0 - 1e-4 + 1e-6  # T never drops below 1e-4
+    tiles_v = torch.arange(s.height, device="cuda") // 16
+    tiles_u = torch.arange(s.width, device="cuda") // 16
+    tid = tiles_v[:, None] * (s.width // 16) + tiles_u[None, :]
+    assert (last_eff >= start[tid]).all() and (last_eff <= end[tid]).all()
+    assert (count <= last_eff - start[tid]).all()
+    report("headline.sizes", M=ids.shape[0], K=k)
