@@ -9,7 +9,7 @@ from taichi_3d_gaussian_splatting_amd.synthetic import SyntheticScene, make_scen
 
 # pixels whose blend decisions sit this close to a discontinuity (alpha = 1/255 skip, RAS:451;
 # T' = 1e-4 stop, RAS:458) may legitimately flip between two correct fp32 implementations
-FRAGILE_MARGIN = 5e-7
+FRAGILE_MARGIN = 5e-8  # ~50x the observed fp32 alpha disagreement between two implementations
 PIXEL_TOL = 1e-4  # BASELINE.json north_star: pixel L-inf <= 1e-4
 
 

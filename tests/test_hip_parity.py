@@ -276,7 +276,7 @@ def test_operator_end_to_end(scene, ofwd, obwd):
     fragile = ofwd["margin"] < FRAGILE_MARGIN
     _check_image("operator.image", image.detach().cpu().numpy(), ofwd["image"], fragile)
     ok = ~fragile
-    assert np.allclose(depth.cpu().numpy()[ok], ofwd["depth"][ok], rtol=1e-4, atol=1e-4)
+    assert np.allclose(depth.detach().cpu().numpy()[ok], ofwd["depth"][ok], rtol=1e-4, atol=1e-4)
     assert np.array_equal(count.cpu().numpy()[ok], ofwd["count"][ok])
     # side effect: visible quaternions normalised in place in the caller's tensor
     assert np.allclose(feat.detach().cpu().numpy()[:, :4], ofwd["feat"][:, :4], atol=1e-7)

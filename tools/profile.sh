@@ -1,0 +1,16 @@
+#!/bin/bash
+# Profiling recipe run on the GPU box through gpurun (see profiles/README.md).
+# usage: tools_profile.sh <tag>   -> gpurun_out/prof_<tag>/{trace,fetch,write}
+set -u
+TAG=${1:-r1}
+ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+OUT=$ROOT/gpurun_out/prof_$TAG
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+CMD="python $ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline"
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- $CMD > $OUT/trace.log 2>&1
+timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch -o fetch -- $CMD > $OUT/fetch.log 2>&1
+timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/write -o write -- $CMD > $OUT/write.log 2>&1
+# keep only the small summaries (kernel trace CSVs can be large)
+find $OUT -name "*.db" -delete 2>/dev/null
+ls -laR $OUT | head -50

@@ -1,0 +1,61 @@
+#!/usr/bin/env python
+"""Per-stage timing of the HIP path on one workload (development tool; run through gpurun).
+usage: python tools/stage_bench.py [workload] [reps]"""
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from taichi_3d_gaussian_splatting_amd import hip_ops  # noqa: E402
+from taichi_3d_gaussian_splatting_amd.synthetic import make_config_scene, make_grad_image  # noqa: E402
+
+workload = sys.argv[1] if len(sys.argv) > 1 else "headline_1m_1080p"
+reps = int(sys.argv[2]) if len(sys.argv) > 2 else 10
+s = make_config_scene(workload).to("cuda")
+g = make_grad_image(s.height, s.width).to("cuda")
+times = {}
+
+
+def timed(name, fn):
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record(); out = fn(); b.record()
+    times.setdefault(name, []).append((a, b))
+    return out
+
+
+num_tiles = (s.width // 16) * (s.height // 16)
+db, tb = hip_ops.sort_key_bits(s.near_plane, s.far_plane, s.depth_to_sort_key_scale, num_tiles)
+q_cp, t_cp = hip_ops.pose_inverse(s.q_pointcloud_camera, s.t_pointcloud_camera)
+feat = s.point_cloud_features.clone()
+for _ in range(reps + 2):
+    _, ids, counters = timed("filter_compact", lambda: hip_ops.filter_compact(
+        s.point_cloud, s.point_invalid_mask, s.point_object_id, s.camera_intrinsics, q_cp, t_cp, s.near_plane,
+        s.far_plane, s.width, s.height))
+    attrs, ntiles, nowned, bsums = timed("preprocess", lambda: hip_ops.preprocess(
+        s.point_cloud, feat, s.point_object_id, s.camera_intrinsics, q_cp, t_cp, ids, s.width, s.height))
+    k = timed("scan_block_sums", lambda: hip_ops.scan_block_sums(bsums, counters))
+    keys, payload = timed("make_keys", lambda: hip_ops.make_keys(attrs, nowned, bsums, k, s.width, s.height,
+                                                                 s.depth_to_sort_key_scale))
+    timed("sort_pairs", lambda: hip_ops.sort_pairs(keys, payload, db, tb))
+    start, end = timed("tile_ranges", lambda: hip_ops.tile_ranges(keys, num_tiles))
+    image, depth, acc_alpha, last_eff, count = timed("blend_forward", lambda: hip_ops.blend_forward(
+        start, end, payload, attrs, s.width, s.height))
+    acc, mag = timed("blend_backward", lambda: hip_ops.blend_backward(
+        start, end, payload, attrs, g, acc_alpha, last_eff, s.width, s.height))
+    timed("point_backward", lambda: hip_ops.point_backward(
+        s.point_cloud, feat, s.point_object_id, s.camera_intrinsics, q_cp, t_cp, s.t_pointcloud_camera, ids, acc, 3,
+        1.0, 0.5, 20.0, 5.0, 1.0, False))
+torch.cuda.synchronize()
+print(f"workload={workload} M={ids.shape[0]} K={k} variant={os.environ.get('GS_VARIANT', '')}")
+tot = 0.0
+for name, pairs in times.items():
+    ms = sum(a.elapsed_time(b) for a, b in pairs[2:]) / len(pairs[2:])
+    tot += ms
+    print(f"  {name:16s} {ms:8.4f} ms")
+print(f"  {'sum':16s} {tot:8.4f} ms")
+lens = (end - start).float()
+eff = (last_eff.view(s.height // 16, 16, s.width // 16, 16).amax(dim=(1, 3)).flatten() - start).float()
+print(f"  tile list mean={lens.mean():.1f} max={lens.max():.0f}; effective (to max last) mean={eff.mean():.1f}; "
+      f"count mean={count.float().mean():.2f}")
