@@ -97,6 +97,8 @@ __global__ __launch_bounds__(GS_BLOCK) void blend_forward_kernel(
 }
 
 // ------------------------------------------------------------------------------- backward
+// Per batch of 256 list entries the 4 waves of the tile combine their partial sums in LDS
+// (ds_add_f32), then thread k flushes entry k with ONE set of hardware atomics per (tile, Gaussian).
 __global__ __launch_bounds__(GS_BLOCK) void blend_backward_kernel(
     const int32_t *__restrict__ tile_start, const int32_t *__restrict__ tile_end,
     const int32_t *__restrict__ payload, const float4 *__restrict__ attrs, const float *__restrict__ grad_image,
@@ -104,6 +106,7 @@ __global__ __launch_bounds__(GS_BLOCK) void blend_backward_kernel(
     int row_begin, int row_step, float *__restrict__ acc, float *__restrict__ magnitude_image) {
     __shared__ float4 s_a[GS_BLOCK], s_b[GS_BLOCK], s_c[GS_BLOCK];
     __shared__ int s_o[GS_BLOCK];
+    __shared__ float s_acc[GS_BLOCK][GS_ACC_STRIDE];  // [entry][value]; slot 10 = pixel count (int bits)
     __shared__ int s_max[GS_BLOCK / GS_WAVE];
     const int tw = width / GS_TILE_WIDTH;
     const TileCoord tc = owned_tile(tw, row_begin, row_step);
@@ -129,7 +132,7 @@ __global__ __launch_bounds__(GS_BLOCK) void blend_backward_kernel(
     const int end = max(max(s_max[0], s_max[1]), max(s_max[2], s_max[3]));
 
     for (int top = end; top > start; top -= GS_BLOCK) {
-        __syncthreads();
+        __syncthreads();  // previous batch fully flushed before its LDS is reused
         const int j = top - 1 - tid;
         if (j >= start) {
             const int o = payload[j];
@@ -138,6 +141,12 @@ __global__ __launch_bounds__(GS_BLOCK) void blend_backward_kernel(
             s_b[tid] = g[1];
             s_c[tid] = g[2];
             s_o[tid] = o;
+        }
+        {
+            float4 *z = reinterpret_cast<float4 *>(&s_acc[tid][0]);
+            z[0] = make_float4(0.f, 0.f, 0.f, 0.f);
+            z[1] = make_float4(0.f, 0.f, 0.f, 0.f);
+            z[2] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
         __syncthreads();
         const int n = min(GS_BLOCK, top - start);
@@ -173,17 +182,34 @@ __global__ __launch_bounds__(GS_BLOCK) void blend_backward_kernel(
                 c00 = h * gm0 * m0; c01 = h * gm0 * m1; c11 = h * gm1 * m1;
                 nv = sqrtf(v0 * v0 + v1 * v1);
             }
-            v0 = gs_wave_sum_to_lane63(v0); v1 = gs_wave_sum_to_lane63(v1);
-            c00 = gs_wave_sum_to_lane63(c00); c01 = gs_wave_sum_to_lane63(c01); c11 = gs_wave_sum_to_lane63(c11);
-            gr = gs_wave_sum_to_lane63(gr); gg = gs_wave_sum_to_lane63(gg); gb = gs_wave_sum_to_lane63(gb);
-            gl = gs_wave_sum_to_lane63(gl); nv = gs_wave_sum_to_lane63(nv);
-            if (lane == 63) {
-                float *A = acc + (size_t)GS_ACC_STRIDE * s_o[k];
-                atomicAdd(A + 0, v0); atomicAdd(A + 1, v1);
-                atomicAdd(A + 2, c00); atomicAdd(A + 3, c01); atomicAdd(A + 4, c11);
-                atomicAdd(A + 5, gr); atomicAdd(A + 6, gg); atomicAdd(A + 7, gb);
-                atomicAdd(A + 8, gl); atomicAdd(A + 9, nv);
-                atomicAdd(reinterpret_cast<int *>(A + 10), (int)__popcll(hits));
+            // reduce-scatter of the 10 partial sums over the 64 lanes: two swap+add levels halve the
+            // number of live registers (10 -> 5 -> 3), then 4 DPP row steps finish each register.
+            // Row totals land in lane 15 of each 16-lane row:
+            //   t0: rows = (v0, c00, v1, c01)   t1: rows = (c11, gg, gr, gb)   t2: rows = (gl, gl, nv, nv)
+            const float s0 = gs_fold32(v0, v1), s1 = gs_fold32(c00, c01), s2 = gs_fold32(c11, gr),
+                        s3 = gs_fold32(gg, gb), s4 = gs_fold32(gl, nv);
+            const float t0 = gs_row_sum_to_lane15(gs_fold16(s0, s1));
+            const float t1 = gs_row_sum_to_lane15(gs_fold16(s2, s3));
+            const float t2 = gs_row_sum_to_lane15(gs_fold16(s4, s4));
+            if ((lane & 15) == 15) {
+                const int row = lane >> 4;
+                const int slot = ((row & 1) << 1) | (row >> 1);  // rows (0,1,2,3) -> slots (0,2,1,3)
+                float *A = &s_acc[k][0];
+                atomicAdd(A + slot, t0);
+                atomicAdd(A + 4 + slot, t1);
+                if ((row & 1) == 0) atomicAdd(A + 8 + (row >> 1), t2);
+                if (row == 3) atomicAdd(reinterpret_cast<int *>(A + 10), (int)__popcll(hits));
+            }
+        }
+        __syncthreads();
+        // flush: thread k owns entry k of the batch -> one global atomic set per (tile, Gaussian)
+        if (tid < n) {
+            const int npix = __builtin_bit_cast(int, s_acc[tid][10]);
+            if (npix > 0) {
+                float *A = acc + (size_t)GS_ACC_STRIDE * s_o[tid];
+#pragma unroll
+                for (int v = 0; v < 10; ++v) atomicAdd(A + v, s_acc[tid][v]);
+                atomicAdd(reinterpret_cast<int *>(A + 10), npix);
             }
         }
     }

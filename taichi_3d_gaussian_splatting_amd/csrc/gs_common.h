@@ -97,6 +97,30 @@ __device__ __forceinline__ float gs_wave_sum_to_lane63(float v) {
     v += gs_dpp<0x143, 0xc, 0xf>(v);  // row_bcast:31 -> rows 2,3
     return v;
 }
+// Sum within each row of 16 lanes; the row total is valid in lane 15 of the row.
+__device__ __forceinline__ float gs_row_sum_to_lane15(float v) {
+    v += gs_dpp<0x111, 0xf, 0xf>(v);  // row_shr:1
+    v += gs_dpp<0x112, 0xf, 0xf>(v);  // row_shr:2
+    v += gs_dpp<0x114, 0xf, 0xe>(v);  // row_shr:4, banks 1-3
+    v += gs_dpp<0x118, 0xf, 0xc>(v);  // row_shr:8, banks 2-3
+    return v;
+}
+// gfx950 cross-half / cross-row swaps (v_permlane32_swap / v_permlane16_swap).  Written as inline
+// asm because ROCm 7.2's clang returns element 0 for BOTH results of the __builtin_amdgcn_permlane*_swap
+// builtins.  The s_nop's cover the VALU-write -> permlane-read and permlane-write -> DPP-read wait states,
+// which the hazard recogniser cannot see through an asm statement.
+// (semantics verified on hardware: v_permlane32_swap exchanges vdst[63:32] with src0[31:0];
+// v_permlane16_swap exchanges the odd rows of vdst with the even rows of src0)
+// fold32: returns r with  r[lane<32] = x[l]+x[l+32],  r[lane>=32] = y[l-32]+y[l]
+__device__ __forceinline__ float gs_fold32(float x, float y) {
+    asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(x), "+v"(y));
+    return x + y;
+}
+// fold16: even rows of the result hold x[row]+x[row+1], odd rows hold y[row-1]+y[row] (rows of 16 lanes)
+__device__ __forceinline__ float gs_fold16(float x, float y) {
+    asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(x), "+v"(y));
+    return x + y;
+}
 __device__ __forceinline__ float gs_readlane63(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
