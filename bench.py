@@ -131,6 +131,7 @@ def main() -> None:
     roofline, stages_ms, sizes = None, {}, {}
     if not args.no_stage_profile:
         rb, rs = op.tile_row_begin, op.tile_row_step
+        CULL = op.exact_tile_cull
         ev = lambda: torch.cuda.Event(enable_timing=True)  # noqa: E731  (events on torch's current stream,
         reps = max(3, min(args.steps, 10))                 #  the stream every kernel is launched on)
         acc_ms = {}
@@ -144,7 +145,7 @@ def main() -> None:
             return out
 
         num_tiles = (s.width // 16) * (s.height // 16)
-        db, tb = hip_ops.sort_key_bits(s.near_plane, s.far_plane, s.depth_to_sort_key_scale, num_tiles)
+        kdb, db, tb = hip_ops.key_layout(s.near_plane, s.far_plane, s.depth_to_sort_key_scale, num_tiles)
         q_cp, t_cp = hip_ops.pose_inverse(s.q_pointcloud_camera, s.t_pointcloud_camera)
         for _ in range(reps):
             f = feat.detach()
@@ -152,12 +153,12 @@ def main() -> None:
                 s.point_cloud, s.point_invalid_mask, s.point_object_id, s.camera_intrinsics, q_cp, t_cp,
                 s.near_plane, s.far_plane, s.width, s.height))
             attrs, ntiles, nowned, bsums = timed("preprocess", lambda: hip_ops.preprocess(
-                s.point_cloud, f, s.point_object_id, s.camera_intrinsics, q_cp, t_cp, ids, s.width, s.height, rb, rs))
+                s.point_cloud, f, s.point_object_id, s.camera_intrinsics, q_cp, t_cp, ids, s.width, s.height, rb, rs, CULL))
             k = timed("scan_block_sums", lambda: hip_ops.scan_block_sums(bsums, counters))
             keys, payload = timed("make_keys", lambda: hip_ops.make_keys(
-                attrs, nowned, bsums, k, s.width, s.height, s.depth_to_sort_key_scale, rb, rs))
-            timed("sort_pairs", lambda: hip_ops.sort_pairs(keys, payload, db, tb))
-            start, end = timed("tile_ranges", lambda: hip_ops.tile_ranges(keys, num_tiles))
+                attrs, nowned, bsums, k, s.width, s.height, s.depth_to_sort_key_scale, rb, rs, CULL, kdb))
+            timed("sort_pairs", lambda: hip_ops.sort_pairs(keys, payload, db, tb, kdb))
+            start, end = timed("tile_ranges", lambda: hip_ops.tile_ranges(keys, num_tiles, kdb))
             image, depth, acc_alpha, last_eff, count = timed("blend_forward", lambda: hip_ops.blend_forward(
                 start, end, payload, attrs, s.width, s.height, rb, rs))
             acc, mag = timed("blend_backward", lambda: hip_ops.blend_backward(

@@ -75,37 +75,48 @@ int gs_read_counters(const int32_t *counters, int32_t *host_counters, int n, voi
  * generate_num_overlap_tiles (RAS:106-128).  Also emits per-256-point partial sums of the
  * tile counts (block_sums int32[ceil(M/256)]) for the scan.  tile_row_begin/tile_row_step
  * restrict the tile box to the tile rows  r = begin + k*step  owned by this GPU (1 GPU: 0,1);
- * num_overlap_tiles (hook output, RAS:1136) is always the full box count and
- * num_owned_tiles the count restricted to owned rows (the one that is scanned). */
+ * num_overlap_tiles (hook output, RAS:1136) is always the full box count of the reference and
+ * num_owned_tiles the number of keys this GPU will emit (the one that is scanned).
+ * exact_tile_cull != 0 drops (tile, Gaussian) pairs whose alpha is below the 1/255 skip threshold
+ * (RAS:451) on every pixel of the tile: such pairs never change a pixel, so every operator output is
+ * unchanged while the lists that are sorted and blended get shorter; 0 = the reference's lists. */
 int gs_preprocess(const float *xyz, float *features, const int32_t *object_id,
                   const float *intrinsics, const float *q_camera_pointcloud,
                   const float *t_camera_pointcloud, const int32_t *ids, int n_visible,
                   int width, int height, int tile_row_begin, int tile_row_step,
-                  float *attrs, int32_t *num_overlap_tiles, int32_t *num_owned_tiles,
-                  int32_t *block_sums, void *stream);
+                  int exact_tile_cull, float *attrs, int32_t *num_overlap_tiles,
+                  int32_t *num_owned_tiles, int32_t *block_sums, void *stream);
 
 /* Exclusive scan of the per-block sums (in place) and total -> counters[GS_COUNTER_NUM_KEYS].
  * Replaces torch.cumsum/cat, RAS:913-922. */
 int gs_scan_block_sums(int32_t *block_sums, int n_blocks, int32_t *counters, void *stream);
 
 /* Sort-key generation.  Replaces generate_point_sort_key_by_num_overlap_tiles (RAS:131-172).
- * keys[k] = (tile_id << 32) + int32(z * depth_scale), payload[k] = offset into the visible list. */
+ * payload[k] = offset into the visible list.  Key layout:
+ *   key_depth_bits == 0 : uint64 keys[k] = (tile_id << 32) + int32(z * depth_scale)   (reference layout)
+ *   key_depth_bits  > 0 : uint32 keys[k] = (tile_id << key_depth_bits) | int32(z * depth_scale)
+ *                         same order, valid when 0 <= z*depth_scale < 2^key_depth_bits and the tile
+ *                         field fits the remaining bits (halves the sort traffic).
+ * exact_tile_cull must be the value passed to gs_preprocess. */
 int gs_make_keys(const float *attrs, const int32_t *num_owned_tiles, const int32_t *block_offsets,
                  int n_visible, int width, int height, int tile_row_begin, int tile_row_step,
-                 float depth_scale, uint64_t *keys, int32_t *payload, void *stream);
+                 int exact_tile_cull, int key_depth_bits, float depth_scale, void *keys,
+                 int32_t *payload, void *stream);
 
-/* Stable LSD radix sort of (key, payload) pairs on the bit ranges [0,depth_bits) and
- * [32,32+tile_bits) of the key; depth_bits = 64 sorts the whole key as a signed int64.
- * Replaces torch.sort + gather (RAS:947-950) with the stable tie rule.  Result is left in
+/* Stable LSD radix sort of (key, payload) pairs.  Replaces torch.sort + gather (RAS:947-950) with
+ * the stable tie rule.  key_depth_bits selects the key layout (see gs_make_keys).  64-bit layout:
+ * only the bit ranges [0,depth_bits) and [32,32+tile_bits) are sorted; depth_bits = 64 sorts the
+ * whole key as a signed int64.  32-bit layout: bits [0, key_depth_bits+tile_bits).  Result is left in
  * keys/payload (keys_alt/payload_alt are scratch of the same size). */
 size_t gs_sort_workspace_bytes(int64_t n_keys);
-int gs_sort_pairs(uint64_t *keys, int32_t *payload, uint64_t *keys_alt, int32_t *payload_alt,
-                  int64_t n_keys, int depth_bits, int tile_bits, void *workspace, void *stream);
+int gs_sort_pairs(void *keys, int32_t *payload, void *keys_alt, int32_t *payload_alt,
+                  int64_t n_keys, int key_depth_bits, int depth_bits, int tile_bits,
+                  void *workspace, void *stream);
 
 /* Per-tile [start,end) ranges.  Replaces find_tile_start_and_end (RAS:175-193) including the
  * zero-initialisation of RAS:954-957. */
-int gs_tile_ranges(const uint64_t *keys_sorted, int64_t n_keys, int32_t *tile_start,
-                   int32_t *tile_end, int n_tiles, void *stream);
+int gs_tile_ranges(const void *keys_sorted, int64_t n_keys, int key_depth_bits,
+                   int32_t *tile_start, int32_t *tile_end, int n_tiles, void *stream);
 
 /* Front-to-back alpha blending.  Replaces gaussian_point_rasterisation (RAS:318-485).
  * Tiles with tile row not in {begin + k*step} are skipped (their pixels are left untouched).

@@ -85,6 +85,8 @@ class GaussianPointCloudRasterisation(torch.nn.Module):
         # image-space sharding (multi-GPU): this instance renders tile rows begin, begin+step, ...
         self.tile_row_begin = 0
         self.tile_row_step = 1
+        # drop (tile, Gaussian) pairs that cannot reach alpha >= 1/255 anywhere in the tile (output-identical)
+        self.exact_tile_cull = True
         outer = self
 
         class _module_function(torch.autograd.Function):
@@ -112,20 +114,23 @@ class GaussianPointCloudRasterisation(torch.nn.Module):
                 _, ids, counters = hip_ops.filter_compact(
                     xyz, invalid, obj, intrinsics, q_cp, t_cp, cfg.near_plane, cfg.far_plane, width, height)
                 # RAS:887-911  per-point projection + tile counts
+                cull = outer.exact_tile_cull
                 attrs, num_overlap_tiles, num_owned_tiles, block_sums = hip_ops.preprocess(
-                    xyz, pointcloud_features, obj, intrinsics, q_cp, t_cp, ids, width, height, row_begin, row_step)
+                    xyz, pointcloud_features, obj, intrinsics, q_cp, t_cp, ids, width, height, row_begin, row_step,
+                    cull)
                 # RAS:913-922  scan (host sync #2: K)
                 n_keys = hip_ops.scan_block_sums(block_sums, counters)
                 # RAS:927-945  keys
-                keys, payload = hip_ops.make_keys(attrs, num_owned_tiles, block_sums, n_keys, width, height,
-                                                  cfg.depth_to_sort_key_scale, row_begin, row_step)
-                # RAS:947-950  sort (stable)
                 num_tiles = (width // TILE_WIDTH) * (height // TILE_HEIGHT)
-                depth_bits, tile_bits = hip_ops.sort_key_bits(cfg.near_plane, cfg.far_plane,
-                                                              cfg.depth_to_sort_key_scale, num_tiles)
-                hip_ops.sort_pairs(keys, payload, depth_bits, tile_bits)
+                key_depth_bits, depth_bits, tile_bits = hip_ops.key_layout(
+                    cfg.near_plane, cfg.far_plane, cfg.depth_to_sort_key_scale, num_tiles)
+                keys, payload = hip_ops.make_keys(attrs, num_owned_tiles, block_sums, n_keys, width, height,
+                                                  cfg.depth_to_sort_key_scale, row_begin, row_step, cull,
+                                                  key_depth_bits)
+                # RAS:947-950  sort (stable)
+                hip_ops.sort_pairs(keys, payload, depth_bits, tile_bits, key_depth_bits)
                 # RAS:952-964  tile ranges
-                tile_start, tile_end = hip_ops.tile_ranges(keys, num_tiles)
+                tile_start, tile_end = hip_ops.tile_ranges(keys, num_tiles, key_depth_bits)
                 del keys
                 # RAS:967-997  blend
                 image, depth, acc_alpha, last_eff, count = hip_ops.blend_forward(

@@ -11,6 +11,12 @@
 //            atomics -- one atomic set per (wave, Gaussian) instead of one per (pixel, Gaussian).
 #include "gs_common.h"
 
+// Automatic FMA contraction is off in this file and every fused multiply-add is written explicitly:
+// the unrolled copies of the inner loops then execute the same instruction sequence for a Gaussian
+// whatever its position in the tile list, so results do not depend on list positions (e.g. the exact
+// tile cull, which only removes non-contributing entries, leaves every output bit-identical).
+#pragma clang fp contract(off)
+
 namespace {
 
 constexpr float EPS_ALPHA = (float)(1.0 / 255.0);  // RAS:451
@@ -69,7 +75,7 @@ __global__ __launch_bounds__(GS_BLOCK) void blend_forward_kernel(
             const float4 a = s_a[k], b = s_b[k];
             const float dx = px - a.x, dy = py - a.y;
             // UTL:275-284
-            const float e = -0.5f * (dx * dx * b.x + dy * dy * b.z) - dx * dy * b.y;
+            const float e = fmaf(-0.5f, fmaf(dy * dy, b.z, dx * dx * b.x), -(dx * dy) * b.y);
             float alpha = __expf(e) * b.w * a.w;
             if (alpha < EPS_ALPHA) continue;
             alpha = fminf(alpha, CLAMP_ALPHA);
@@ -81,8 +87,8 @@ __global__ __launch_bounds__(GS_BLOCK) void blend_forward_kernel(
             const float4 c = s_c[k];
             const float wgt = alpha * T;
             last = base + k + 1;
-            Cr += c.x * wgt; Cg += c.y * wgt; Cb += c.z * wgt;
-            D += a.z * wgt;
+            Cr = fmaf(c.x, wgt, Cr); Cg = fmaf(c.y, wgt, Cg); Cb = fmaf(c.z, wgt, Cb);
+            D = fmaf(a.z, wgt, D);
             Wd += wgt;
             cnt += 1;
             T = Tn;
@@ -155,8 +161,8 @@ __global__ __launch_bounds__(GS_BLOCK) void blend_backward_kernel(
             const float4 a = s_a[k], b = s_b[k];
             const float dx = px - a.x, dy = py - a.y;
             // UTL:331-348: m = conic @ d, exponent = -0.5 d.m
-            const float m0 = b.x * dx + b.y * dy, m1 = b.y * dx + b.z * dy;
-            const float g = __expf(-0.5f * (dx * m0 + dy * m1)) * b.w;
+            const float m0 = fmaf(b.y, dy, b.x * dx), m1 = fmaf(b.z, dy, b.y * dx);
+            const float g = __expf(-0.5f * fmaf(dy, m1, dx * m0)) * b.w;
             const float pa = g * a.w;
             const bool hit = (jj < last) && (pa >= EPS_ALPHA);
             const unsigned long long hits = __ballot(hit);
@@ -170,9 +176,9 @@ __global__ __launch_bounds__(GS_BLOCK) void blend_backward_kernel(
                 T = T * inv1m;  // RAS:643, T_i = T_{i+1} / (1 - alpha_i)
                 const float aT = alpha * T;
                 gr = aT * Gr; gg = aT * Gg; gb = aT * Gb;
-                const float dLda = (c.x * T - wr * inv1m) * Gr + (c.y * T - wg * inv1m) * Gg +
-                                   (c.z * T - wb * inv1m) * Gb;
-                wr += c.x * aT; wg += c.y * aT; wb += c.z * aT;
+                const float dLda = fmaf(fmaf(c.z, T, -(wb * inv1m)), Gb,
+                                        fmaf(fmaf(c.y, T, -(wg * inv1m)), Gg, fmaf(c.x, T, -(wr * inv1m)) * Gr));
+                wr = fmaf(c.x, aT, wr); wg = fmaf(c.y, aT, wg); wb = fmaf(c.z, aT, wb);
                 gl = dLda * g * (1.f - a.w) * a.w;
                 const float dLdg = dLda * a.w;
                 const float gm0 = g * m0, gm1 = g * m1;
@@ -180,7 +186,7 @@ __global__ __launch_bounds__(GS_BLOCK) void blend_backward_kernel(
                 mag_u += fabsf(v0); mag_v += fabsf(v1);
                 const float h = 0.5f * dLdg;
                 c00 = h * gm0 * m0; c01 = h * gm0 * m1; c11 = h * gm1 * m1;
-                nv = sqrtf(v0 * v0 + v1 * v1);
+                nv = sqrtf(fmaf(v1, v1, v0 * v0));
             }
             // reduce-scatter of the 10 partial sums over the 64 lanes: two swap+add levels halve the
             // number of live registers (10 -> 5 -> 3), then 4 DPP row steps finish each register.

@@ -96,6 +96,36 @@ __device__ __forceinline__ int owned_rows(int t0v, int t1v, int begin, int step,
     return f < t1v ? (t1v - 1 - f) / step + 1 : 0;
 }
 
+// Exact per-tile cull.  A (tile, Gaussian) pair whose alpha stays below the 1/255 skip threshold
+// (RAS:451) on EVERY pixel of the tile never changes any pixel state, so dropping it from the tile's
+// list is output-identical.  alpha = amp * exp(-q/2) with q the conic quadratic form (UTL:275-284);
+// q is minimised over the convex hull of the tile's pixel centres (a superset of the pixels), which
+// lies on the edge(s) of the rectangle facing the centre.  qmax = 2 ln(255 amp) + margin; the margin
+// (1e-2 in q, i.e. 0.5 % in alpha) dwarfs the fp32 disagreement between this test and the blend kernel.
+__device__ __forceinline__ float cull_qmax(float opacity, float rescale) {
+    return 2.0f * logf(255.0f * opacity * rescale) + 1e-2f;
+}
+__device__ __forceinline__ bool tile_may_contribute(float ux, float uy, float A, float B, float C, float qmax,
+                                                    int tu, int tv) {
+    const float x0 = (float)(tu * GS_TILE_WIDTH) + 0.5f, x1 = x0 + (float)(GS_TILE_WIDTH - 1);
+    const float y0 = (float)(tv * GS_TILE_HEIGHT) + 0.5f, y1 = y0 + (float)(GS_TILE_HEIGHT - 1);
+    const float dxc = fminf(fmaxf(ux, x0), x1) - ux;  // x offset of the closest point, 0 if inside the span
+    const float dyc = fminf(fmaxf(uy, y0), y1) - uy;
+    float qmin = 0.f;
+    if (dxc != 0.f || dyc != 0.f) {
+        qmin = 3.0e38f;
+        if (dxc != 0.f) {  // edge x = const facing the centre: minimise over dy along the edge
+            const float dy = fminf(fmaxf(-B * dxc / C, y0 - uy), y1 - uy);
+            qmin = A * dxc * dxc + 2.f * B * dxc * dy + C * dy * dy;
+        }
+        if (dyc != 0.f) {
+            const float dx = fminf(fmaxf(-B * dyc / A, x0 - ux), x1 - ux);
+            qmin = fminf(qmin, A * dx * dx + 2.f * B * dx * dyc + C * dyc * dyc);
+        }
+    }
+    return !(qmin > qmax);  // NaN-safe: anything unordered is kept
+}
+
 // ------------------------------------------------------------------ pose inverse
 // UTL:396-432 inverse_SE3_qt_torch: q_inv = conj(q) (not renormalised),
 // t_inv = -rot(normalise(q_inv), t) with the Hamilton products of UTL:402-412.
@@ -224,7 +254,7 @@ __global__ __launch_bounds__(GS_BLOCK) void compact_kernel(const int8_t *__restr
 __global__ __launch_bounds__(GS_BLOCK) void preprocess_kernel(
     const float *__restrict__ xyz, float *__restrict__ feat, const int32_t *__restrict__ obj,
     const float *__restrict__ Kmat, const float *__restrict__ q_cp, const float *__restrict__ t_cp,
-    const int32_t *__restrict__ ids, int m, int width, int height, int row_begin, int row_step,
+    const int32_t *__restrict__ ids, int m, int width, int height, int row_begin, int row_step, int cull,
     float *__restrict__ attrs, int32_t *__restrict__ ntiles_full, int32_t *__restrict__ ntiles_owned,
     int32_t *__restrict__ block_sums) {
     __shared__ int s_sum;
@@ -319,6 +349,14 @@ __global__ __launch_bounds__(GS_BLOCK) void preprocess_kernel(
         tile_box(uv[0], uv[1], radius, width / GS_TILE_WIDTH, height / GS_TILE_HEIGHT, t0u, t1u, t0v, t1v);
         ntiles_full[i] = (t1u - t0u) * (t1v - t0v);
         owned = (t1u - t0u) * owned_rows(t0v, t1v, row_begin, row_step, &first);
+        if (cull && owned > 0) {
+            const float qmax = cull_qmax(1.f / (1.f + expf(-f[7])), rescale);
+            const float cA = inv * cd, cB = inv * (-cov[1]), cC = inv * ca;
+            owned = 0;
+            for (int tu = t0u; tu < t1u; ++tu)
+                for (int tv = first; tv < t1v; tv += row_step)
+                    owned += tile_may_contribute(uv[0], uv[1], cA, cB, cC, qmax, tu, tv) ? 1 : 0;
+        }
         ntiles_owned[i] = owned;
     }
     // per-block partial sum for the scan (wave reduce, then one LDS atomic per wave)
@@ -332,10 +370,14 @@ __global__ __launch_bounds__(GS_BLOCK) void preprocess_kernel(
 
 // ------------------------------------------------------------------ key generation
 // RAS:131-172 generate_point_sort_key_by_num_overlap_tiles
+// KeyT = uint64_t: reference layout (tile << 32) + int32 depth.  KeyT = uint32_t: compressed layout
+// (tile << key_depth_bits) | depth, used when the quantised depth is known to be non-negative and
+// tile and depth fit 32 bits together (same order, half the sort traffic).
+template <typename KeyT>
 __global__ __launch_bounds__(GS_BLOCK) void make_keys_kernel(
     const float *__restrict__ attrs, const int32_t *__restrict__ ntiles_owned,
     const int32_t *__restrict__ block_offsets, int m, int width, int height, int row_begin, int row_step,
-    float depth_scale, uint64_t *__restrict__ keys, int32_t *__restrict__ payload) {
+    int cull, int key_depth_bits, float depth_scale, KeyT *__restrict__ keys, int32_t *__restrict__ payload) {
     __shared__ int lds[4];
     const int i = blockIdx.x * GS_BLOCK + threadIdx.x;
     int cnt = i < m ? ntiles_owned[i] : 0;
@@ -343,7 +385,9 @@ __global__ __launch_bounds__(GS_BLOCK) void make_keys_kernel(
     int offset = block_offsets[blockIdx.x] + gs_block_excl_scan(cnt, &total, lds);
     if (i >= m || cnt == 0) return;
     const float4 a0 = reinterpret_cast<const float4 *>(attrs + (size_t)GS_ATTR_STRIDE * i)[0];
+    const float4 a1 = reinterpret_cast<const float4 *>(attrs + (size_t)GS_ATTR_STRIDE * i)[1];
     const float radius = attrs[(size_t)GS_ATTR_STRIDE * i + 11];
+    const float qmax = cull ? cull_qmax(a0.w, a1.w) : 0.f;
     const int tw = width / GS_TILE_WIDTH;
     int t0u, t1u, t0v, t1v, first;
     tile_box(a0.x, a0.y, radius, tw, height / GS_TILE_HEIGHT, t0u, t1u, t0v, t1v);
@@ -352,21 +396,31 @@ __global__ __launch_bounds__(GS_BLOCK) void make_keys_kernel(
     int k = offset;
     for (int tu = t0u; tu < t1u; ++tu)
         for (int tv = first; tv < t1v; tv += row_step) {
+            if (cull && !tile_may_contribute(a0.x, a0.y, a1.x, a1.y, a1.z, qmax, tu, tv)) continue;
             const int32_t tile = tu + tv * tw;
-            keys[k] = (uint64_t)((int64_t)dq + ((int64_t)tile << 32));
+            if (sizeof(KeyT) == 8)
+                keys[k] = (KeyT)((int64_t)dq + ((int64_t)tile << 32));
+            else
+                keys[k] = (KeyT)(((uint32_t)tile << key_depth_bits) | (uint32_t)dq);
             payload[k] = i;
             ++k;
         }
 }
 
 // RAS:175-193 find_tile_start_and_end (arrays pre-zeroed by the caller entry point)
-__global__ void tile_ranges_kernel(const uint64_t *__restrict__ keys, long long n,
+template <typename KeyT>
+__device__ __forceinline__ int32_t tile_of_key(KeyT key, int key_depth_bits) {
+    if (sizeof(KeyT) == 8) return (int32_t)((int64_t)key >> 32);
+    return (int32_t)((uint32_t)key >> key_depth_bits);
+}
+template <typename KeyT>
+__global__ void tile_ranges_kernel(const KeyT *__restrict__ keys, long long n, int key_depth_bits,
                                    int32_t *__restrict__ tile_start, int32_t *__restrict__ tile_end) {
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    int32_t t = (int32_t)((int64_t)keys[i] >> 32);
+    int32_t t = tile_of_key<KeyT>(keys[i], key_depth_bits);
     if (i + 1 < n) {
-        int32_t tn = (int32_t)((int64_t)keys[i + 1] >> 32);
+        int32_t tn = tile_of_key<KeyT>(keys[i + 1], key_depth_bits);
         if (t != tn) {
             tile_start[tn] = (int32_t)(i + 1);
             tile_end[t] = (int32_t)(i + 1);
@@ -427,15 +481,16 @@ int gs_read_counters(const int32_t *counters, int32_t *host_counters, int n, voi
 
 int gs_preprocess(const float *xyz, float *features, const int32_t *object_id, const float *intrinsics,
                   const float *q_cp, const float *t_cp, const int32_t *ids, int n_visible, int width, int height,
-                  int tile_row_begin, int tile_row_step, float *attrs, int32_t *num_overlap_tiles,
-                  int32_t *num_owned_tiles, int32_t *block_sums, void *stream) {
+                  int tile_row_begin, int tile_row_step, int exact_tile_cull, float *attrs,
+                  int32_t *num_overlap_tiles, int32_t *num_owned_tiles, int32_t *block_sums, void *stream) {
     GS_REQUIRE(n_visible >= 0, "n_visible");
     GS_REQUIRE(tile_row_step >= 1 && tile_row_begin >= 0, "tile row ownership");
     GS_REQUIRE(width % GS_TILE_WIDTH == 0 && height % GS_TILE_HEIGHT == 0, "image size must be a multiple of 16");
     if (n_visible == 0) return 0;
     hipLaunchKernelGGL(preprocess_kernel, dim3(gs_div_up(n_visible, GS_BLOCK)), dim3(GS_BLOCK), 0,
                        (hipStream_t)stream, xyz, features, object_id, intrinsics, q_cp, t_cp, ids, n_visible, width,
-                       height, tile_row_begin, tile_row_step, attrs, num_overlap_tiles, num_owned_tiles, block_sums);
+                       height, tile_row_begin, tile_row_step, exact_tile_cull, attrs, num_overlap_tiles, num_owned_tiles,
+                       block_sums);
     GS_CHECK_LAUNCH();
     return 0;
 }
@@ -453,27 +508,40 @@ int gs_scan_block_sums(int32_t *block_sums, int n_blocks, int32_t *counters, voi
 }
 
 int gs_make_keys(const float *attrs, const int32_t *num_owned_tiles, const int32_t *block_offsets, int n_visible,
-                 int width, int height, int tile_row_begin, int tile_row_step, float depth_scale, uint64_t *keys,
-                 int32_t *payload, void *stream) {
+                 int width, int height, int tile_row_begin, int tile_row_step, int exact_tile_cull,
+                 int key_depth_bits, float depth_scale, void *keys, int32_t *payload, void *stream) {
     GS_REQUIRE(n_visible >= 0, "n_visible");
     GS_REQUIRE(tile_row_step >= 1 && tile_row_begin >= 0, "tile row ownership");
+    GS_REQUIRE(key_depth_bits >= 0 && key_depth_bits < 32, "key_depth_bits");
     if (n_visible == 0) return 0;
-    hipLaunchKernelGGL(make_keys_kernel, dim3(gs_div_up(n_visible, GS_BLOCK)), dim3(GS_BLOCK), 0,
-                       (hipStream_t)stream, attrs, num_owned_tiles, block_offsets, n_visible, width, height,
-                       tile_row_begin, tile_row_step, depth_scale, keys, payload);
+    const dim3 grid(gs_div_up(n_visible, GS_BLOCK)), block(GS_BLOCK);
+    if (key_depth_bits == 0)
+        hipLaunchKernelGGL(make_keys_kernel<uint64_t>, grid, block, 0, (hipStream_t)stream, attrs, num_owned_tiles,
+                           block_offsets, n_visible, width, height, tile_row_begin, tile_row_step, exact_tile_cull,
+                           0, depth_scale, (uint64_t *)keys, payload);
+    else
+        hipLaunchKernelGGL(make_keys_kernel<uint32_t>, grid, block, 0, (hipStream_t)stream, attrs, num_owned_tiles,
+                           block_offsets, n_visible, width, height, tile_row_begin, tile_row_step, exact_tile_cull,
+                           key_depth_bits, depth_scale, (uint32_t *)keys, payload);
     GS_CHECK_LAUNCH();
     return 0;
 }
 
-int gs_tile_ranges(const uint64_t *keys_sorted, int64_t n_keys, int32_t *tile_start, int32_t *tile_end, int n_tiles,
-                   void *stream) {
+int gs_tile_ranges(const void *keys_sorted, int64_t n_keys, int key_depth_bits, int32_t *tile_start,
+                   int32_t *tile_end, int n_tiles, void *stream) {
     GS_REQUIRE(n_keys >= 0 && n_tiles > 0, "sizes");
+    GS_REQUIRE(key_depth_bits >= 0 && key_depth_bits < 32, "key_depth_bits");
     hipStream_t s = (hipStream_t)stream;
     GS_CHECK_HIP(hipMemsetAsync(tile_start, 0, sizeof(int32_t) * n_tiles, s));
     GS_CHECK_HIP(hipMemsetAsync(tile_end, 0, sizeof(int32_t) * n_tiles, s));
     if (n_keys == 0) return 0;
-    hipLaunchKernelGGL(tile_ranges_kernel, dim3(gs_div_up(n_keys, GS_BLOCK)), dim3(GS_BLOCK), 0, s, keys_sorted,
-                       (long long)n_keys, tile_start, tile_end);
+    const dim3 grid(gs_div_up(n_keys, GS_BLOCK)), block(GS_BLOCK);
+    if (key_depth_bits == 0)
+        hipLaunchKernelGGL(tile_ranges_kernel<uint64_t>, grid, block, 0, s, (const uint64_t *)keys_sorted,
+                           (long long)n_keys, 0, tile_start, tile_end);
+    else
+        hipLaunchKernelGGL(tile_ranges_kernel<uint32_t>, grid, block, 0, s, (const uint32_t *)keys_sorted,
+                           (long long)n_keys, key_depth_bits, tile_start, tile_end);
     GS_CHECK_LAUNCH();
     return 0;
 }

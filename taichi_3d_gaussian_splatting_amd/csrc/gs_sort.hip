@@ -19,12 +19,14 @@ constexpr int SORT_ROUNDS = 8;
 constexpr int SORT_ITEMS = GS_BLOCK * SORT_ROUNDS;  // keys per workgroup
 constexpr int WAVES = GS_BLOCK / GS_WAVE;
 
-__device__ __forceinline__ unsigned digit_of(uint64_t key, int shift, uint64_t flip) {
+template <typename KeyT>
+__device__ __forceinline__ unsigned digit_of(KeyT key, int shift, KeyT flip) {
     return (unsigned)(((key ^ flip) >> shift) & (RADIX - 1));
 }
 
-__global__ __launch_bounds__(GS_BLOCK) void sort_hist_kernel(const uint64_t *__restrict__ keys, long long n,
-                                                            int shift, uint64_t flip, int nblk,
+template <typename KeyT>
+__global__ __launch_bounds__(GS_BLOCK) void sort_hist_kernel(const KeyT *__restrict__ keys, long long n,
+                                                            int shift, KeyT flip, int nblk,
                                                             int32_t *__restrict__ counts) {
     __shared__ int hist[RADIX];
     hist[threadIdx.x] = 0;
@@ -33,7 +35,7 @@ __global__ __launch_bounds__(GS_BLOCK) void sort_hist_kernel(const uint64_t *__r
 #pragma unroll
     for (int r = 0; r < SORT_ROUNDS; ++r) {
         long long i = base + r * GS_BLOCK + threadIdx.x;
-        if (i < n) atomicAdd(&hist[digit_of(keys[i], shift, flip)], 1);
+        if (i < n) atomicAdd(&hist[digit_of<KeyT>(keys[i], shift, flip)], 1);
     }
     __syncthreads();
     counts[(size_t)threadIdx.x * nblk + blockIdx.x] = hist[threadIdx.x];
@@ -56,10 +58,11 @@ __global__ __launch_bounds__(GS_BLOCK) void sort_scan_rows_kernel(int32_t *__res
     if (threadIdx.x == 0) totals[blockIdx.x] = carry;
 }
 
+template <typename KeyT>
 __global__ __launch_bounds__(GS_BLOCK) void sort_scatter_kernel(
-    const uint64_t *__restrict__ keys_in, const int32_t *__restrict__ payload_in, long long n, int shift,
-    uint64_t flip, int nblk, const int32_t *__restrict__ row_offsets, const int32_t *__restrict__ totals,
-    uint64_t *__restrict__ keys_out, int32_t *__restrict__ payload_out) {
+    const KeyT *__restrict__ keys_in, const int32_t *__restrict__ payload_in, long long n, int shift,
+    KeyT flip, int nblk, const int32_t *__restrict__ row_offsets, const int32_t *__restrict__ totals,
+    KeyT *__restrict__ keys_out, int32_t *__restrict__ payload_out) {
     __shared__ int s_base[RADIX];         // global destination of the next key of each digit
     __shared__ int s_wave[WAVES][RADIX];  // per-round, per-wave digit counts
     __shared__ int lds[4];
@@ -77,13 +80,13 @@ __global__ __launch_bounds__(GS_BLOCK) void sort_scatter_kernel(
     for (int r = 0; r < SORT_ROUNDS; ++r) {
         const long long i = base + r * GS_BLOCK + threadIdx.x;
         const bool valid = i < n;
-        uint64_t key = 0;
+        KeyT key = 0;
         int32_t pay = 0;
         unsigned d = 0;
         if (valid) {
             key = keys_in[i];
             pay = payload_in[i];
-            d = digit_of(key, shift, flip);
+            d = digit_of<KeyT>(key, shift, flip);
         }
         // 64-lane match-any on the 8-bit digit: peers = lanes holding the same digit
         unsigned long long peers = __ballot(valid);
@@ -121,6 +124,33 @@ __global__ __launch_bounds__(GS_BLOCK) void sort_scatter_kernel(
 
 }  // namespace
 
+template <typename KeyT>
+static int sort_pairs_impl(KeyT *keys, int32_t *payload, KeyT *keys_alt, int32_t *payload_alt, int64_t n_keys,
+                           const int *shifts, int n_pass, KeyT flip, void *workspace, hipStream_t s) {
+    const int nblk = gs_div_up(n_keys, SORT_ITEMS);
+    int32_t *counts = (int32_t *)workspace;
+    int32_t *totals = counts + (size_t)RADIX * nblk;
+    KeyT *kin = keys, *kout = keys_alt;
+    int32_t *pin = payload, *pout = payload_alt;
+    for (int p = 0; p < n_pass; ++p) {
+        hipLaunchKernelGGL(sort_hist_kernel<KeyT>, dim3(nblk), dim3(GS_BLOCK), 0, s, kin, (long long)n_keys,
+                           shifts[p], flip, nblk, counts);
+        GS_CHECK_LAUNCH();
+        hipLaunchKernelGGL(sort_scan_rows_kernel, dim3(RADIX), dim3(GS_BLOCK), 0, s, counts, nblk, totals);
+        GS_CHECK_LAUNCH();
+        hipLaunchKernelGGL(sort_scatter_kernel<KeyT>, dim3(nblk), dim3(GS_BLOCK), 0, s, kin, pin, (long long)n_keys,
+                           shifts[p], flip, nblk, counts, totals, kout, pout);
+        GS_CHECK_LAUNCH();
+        KeyT *tk = kin; kin = kout; kout = tk;
+        int32_t *tp = pin; pin = pout; pout = tp;
+    }
+    if (kin != keys) {  // odd number of passes: result sits in the alt buffers
+        GS_CHECK_HIP(hipMemcpyAsync(keys, kin, sizeof(KeyT) * n_keys, hipMemcpyDeviceToDevice, s));
+        GS_CHECK_HIP(hipMemcpyAsync(payload, pin, sizeof(int32_t) * n_keys, hipMemcpyDeviceToDevice, s));
+    }
+    return 0;
+}
+
 extern "C" {
 
 size_t gs_sort_workspace_bytes(int64_t n_keys) {
@@ -128,17 +158,20 @@ size_t gs_sort_workspace_bytes(int64_t n_keys) {
     return sizeof(int32_t) * (RADIX * nblk + RADIX + 64);
 }
 
-int gs_sort_pairs(uint64_t *keys, int32_t *payload, uint64_t *keys_alt, int32_t *payload_alt, int64_t n_keys,
-                  int depth_bits, int tile_bits, void *workspace, void *stream) {
+int gs_sort_pairs(void *keys, int32_t *payload, void *keys_alt, int32_t *payload_alt, int64_t n_keys,
+                  int key_depth_bits, int depth_bits, int tile_bits, void *workspace, void *stream) {
     GS_REQUIRE(n_keys >= 0 && n_keys < 0x7fffffffLL, "n_keys must fit int32");
     GS_REQUIRE(depth_bits >= 0 && depth_bits <= 64 && tile_bits >= 0 && tile_bits <= 31, "bit ranges");
+    GS_REQUIRE(key_depth_bits >= 0 && key_depth_bits < 32, "key_depth_bits");
     if (n_keys <= 1) return 0;
     hipStream_t s = (hipStream_t)stream;
-    const int nblk = gs_div_up(n_keys, SORT_ITEMS);
-    int32_t *counts = (int32_t *)workspace;
-    int32_t *totals = counts + (size_t)RADIX * nblk;
-
     int shifts[16], n_pass = 0;
+    if (key_depth_bits > 0) {  // compressed 32-bit keys: one contiguous field
+        GS_REQUIRE(key_depth_bits + tile_bits <= 32, "compressed key does not fit 32 bits");
+        for (int sh = 0; sh < key_depth_bits + tile_bits; sh += RADIX_BITS) shifts[n_pass++] = sh;
+        return sort_pairs_impl<uint32_t>((uint32_t *)keys, payload, (uint32_t *)keys_alt, payload_alt, n_keys, shifts,
+                                         n_pass, 0u, workspace, s);
+    }
     uint64_t flip = 0;
     if (depth_bits >= 64) {  // full signed 64-bit order
         for (int sh = 0; sh < 64; sh += RADIX_BITS) shifts[n_pass++] = sh;
@@ -147,25 +180,8 @@ int gs_sort_pairs(uint64_t *keys, int32_t *payload, uint64_t *keys_alt, int32_t 
         for (int sh = 0; sh < depth_bits && sh < 32; sh += RADIX_BITS) shifts[n_pass++] = sh;
         for (int sh = 32; sh < 32 + tile_bits; sh += RADIX_BITS) shifts[n_pass++] = sh;
     }
-    uint64_t *kin = keys, *kout = keys_alt;
-    int32_t *pin = payload, *pout = payload_alt;
-    for (int p = 0; p < n_pass; ++p) {
-        hipLaunchKernelGGL(sort_hist_kernel, dim3(nblk), dim3(GS_BLOCK), 0, s, kin, (long long)n_keys, shifts[p],
-                           flip, nblk, counts);
-        GS_CHECK_LAUNCH();
-        hipLaunchKernelGGL(sort_scan_rows_kernel, dim3(RADIX), dim3(GS_BLOCK), 0, s, counts, nblk, totals);
-        GS_CHECK_LAUNCH();
-        hipLaunchKernelGGL(sort_scatter_kernel, dim3(nblk), dim3(GS_BLOCK), 0, s, kin, pin, (long long)n_keys,
-                           shifts[p], flip, nblk, counts, totals, kout, pout);
-        GS_CHECK_LAUNCH();
-        uint64_t *tk = kin; kin = kout; kout = tk;
-        int32_t *tp = pin; pin = pout; pout = tp;
-    }
-    if (kin != keys) {  // odd number of passes: result sits in the alt buffers
-        GS_CHECK_HIP(hipMemcpyAsync(keys, kin, sizeof(uint64_t) * n_keys, hipMemcpyDeviceToDevice, s));
-        GS_CHECK_HIP(hipMemcpyAsync(payload, pin, sizeof(int32_t) * n_keys, hipMemcpyDeviceToDevice, s));
-    }
-    return 0;
+    return sort_pairs_impl<uint64_t>((uint64_t *)keys, payload, (uint64_t *)keys_alt, payload_alt, n_keys, shifts,
+                                     n_pass, flip, workspace, s);
 }
 
 }  // extern "C"

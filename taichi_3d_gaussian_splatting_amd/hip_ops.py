@@ -75,9 +75,10 @@ def filter_compact(xyz, invalid_mask, object_id, intrinsics, q_cp, t_cp, near_pl
 
 
 def preprocess(xyz, features, object_id, intrinsics, q_cp, t_cp, ids, width, height, tile_row_begin=0,
-               tile_row_step=1):
+               tile_row_step=1, exact_tile_cull=True):
     """-> (attrs f32[M,12], num_overlap_tiles i32[M], num_owned_tiles i32[M], block_sums i32[ceil(M/256)]).
-    Normalises features[ids, 0:4] IN PLACE (RAS:196-205)."""
+    Normalises features[ids, 0:4] IN PLACE (RAS:196-205).  num_overlap_tiles is the reference's box count
+    (hook output); num_owned_tiles is the number of keys emitted (after ownership and the exact tile cull)."""
     m = ids.shape[0]
     dev = xyz.device
     attrs = torch.empty((m, ATTR_STRIDE), dtype=torch.float32, device=dev)
@@ -85,8 +86,8 @@ def preprocess(xyz, features, object_id, intrinsics, q_cp, t_cp, ids, width, hei
     nowned = torch.empty(m, dtype=torch.int32, device=dev)
     block_sums = torch.empty((m + _PRE_BLOCK - 1) // _PRE_BLOCK, dtype=torch.int32, device=dev)
     call("gs_preprocess", ptr(xyz), ptr(features), ptr(object_id), ptr(intrinsics), ptr(q_cp), ptr(t_cp), ptr(ids),
-         m, int(width), int(height), int(tile_row_begin), int(tile_row_step), ptr(attrs), ptr(ntiles), ptr(nowned),
-         ptr(block_sums), current_stream(dev))
+         m, int(width), int(height), int(tile_row_begin), int(tile_row_step), int(bool(exact_tile_cull)), ptr(attrs),
+         ptr(ntiles), ptr(nowned), ptr(block_sums), current_stream(dev))
     return attrs, ntiles, nowned, block_sums
 
 
@@ -100,14 +101,16 @@ def scan_block_sums(block_sums: torch.Tensor, counters: torch.Tensor) -> int:
 
 
 def make_keys(attrs, num_owned_tiles, block_offsets, n_keys, width, height, depth_to_sort_key_scale,
-              tile_row_begin=0, tile_row_step=1):
+              tile_row_begin=0, tile_row_step=1, exact_tile_cull=True, key_depth_bits=0):
+    """key_depth_bits == 0: int64 keys in the reference layout (tile << 32) + depth;
+    key_depth_bits > 0: 32-bit keys (tile << key_depth_bits) | depth, stored in an int32 tensor."""
     dev = attrs.device
-    keys = torch.empty(n_keys, dtype=torch.int64, device=dev)
+    keys = torch.empty(n_keys, dtype=torch.int64 if key_depth_bits == 0 else torch.int32, device=dev)
     payload = torch.empty(n_keys, dtype=torch.int32, device=dev)
     if n_keys > 0:
         call("gs_make_keys", ptr(attrs), ptr(num_owned_tiles), ptr(block_offsets), attrs.shape[0], int(width),
-             int(height), int(tile_row_begin), int(tile_row_step), float(depth_to_sort_key_scale), ptr(keys),
-             ptr(payload), current_stream(dev))
+             int(height), int(tile_row_begin), int(tile_row_step), int(bool(exact_tile_cull)), int(key_depth_bits),
+             float(depth_to_sort_key_scale), ptr(keys), ptr(payload), current_stream(dev))
     return keys, payload
 
 
@@ -120,24 +123,38 @@ def sort_key_bits(near_plane: float, far_plane: float, depth_to_sort_key_scale: 
     return 64, tile_bits  # negative depths borrow from the tile field: sort the whole signed key
 
 
-def sort_pairs(keys: torch.Tensor, payload: torch.Tensor, depth_bits: int, tile_bits: int) -> None:
+def key_layout(near_plane: float, far_plane: float, depth_to_sort_key_scale: float, num_tiles: int):
+    """-> (key_depth_bits, depth_bits, tile_bits).  key_depth_bits > 0 selects the compressed 32-bit key
+    (possible when the quantised depth is provably in [0, 2^depth_bits) and tile+depth fit 32 bits)."""
+    depth_bits, tile_bits = sort_key_bits(near_plane, far_plane, depth_to_sort_key_scale, num_tiles)
+    if depth_bits < 64 and depth_bits + tile_bits <= 32:
+        return depth_bits, depth_bits, tile_bits
+    return 0, depth_bits, tile_bits
+
+
+def sort_pairs(keys: torch.Tensor, payload: torch.Tensor, depth_bits: int, tile_bits: int,
+               key_depth_bits: int = 0) -> None:
     """Stable sort of (keys, payload) in place."""
     n = keys.shape[0]
     if n <= 1:
         return
+    if keys.dtype != (torch.int64 if key_depth_bits == 0 else torch.int32):
+        raise TypeError("key dtype does not match the key layout")
     dev = keys.device
     keys_alt, payload_alt = torch.empty_like(keys), torch.empty_like(payload)
     ws = torch.empty(_lib.load().gs_sort_workspace_bytes(n), dtype=torch.uint8, device=dev)
-    call("gs_sort_pairs", ptr(keys), ptr(payload), ptr(keys_alt), ptr(payload_alt), n, int(depth_bits),
-         int(tile_bits), ptr(ws), current_stream(dev))
+    call("gs_sort_pairs", ptr(keys), ptr(payload), ptr(keys_alt), ptr(payload_alt), n, int(key_depth_bits),
+         int(depth_bits), int(tile_bits), ptr(ws), current_stream(dev))
 
 
-def tile_ranges(keys_sorted: torch.Tensor, num_tiles: int):
+def tile_ranges(keys_sorted: torch.Tensor, num_tiles: int, key_depth_bits: int = 0):
+    if keys_sorted.dtype != (torch.int64 if key_depth_bits == 0 else torch.int32):
+        raise TypeError("key dtype does not match the key layout")
     dev = keys_sorted.device
     start = torch.empty(num_tiles, dtype=torch.int32, device=dev)
     end = torch.empty(num_tiles, dtype=torch.int32, device=dev)
-    call("gs_tile_ranges", ptr(keys_sorted), keys_sorted.shape[0], ptr(start), ptr(end), int(num_tiles),
-         current_stream(dev))
+    call("gs_tile_ranges", ptr(keys_sorted), keys_sorted.shape[0], int(key_depth_bits), ptr(start), ptr(end),
+         int(num_tiles), current_stream(dev))
     return start, end
 
 

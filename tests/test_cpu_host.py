@@ -40,10 +40,11 @@ def test_argument_validation_without_gpu(lib):
     l = lib.load()
     assert l.gs_pose_inverse(None, None, None, None, 0, None) == -1
     assert b"n_obj" in l.gs_last_error()
-    assert l.gs_sort_pairs(None, None, None, None, 10, 70, 3, None, None) == -1
+    assert l.gs_sort_pairs(None, None, None, None, 10, 0, 70, 3, None, None) == -1
     assert l.gs_blend_forward(None, None, None, None, 100, 64, 0, 1, None, None, None, None, None, None) == -1
     assert b"multiple of 16" in l.gs_last_error()
-    assert l.gs_sort_pairs(None, None, None, None, 1, 17, 13, None, None) == 0  # n <= 1: nothing to do
+    assert l.gs_sort_pairs(None, None, None, None, 1, 0, 17, 13, None, None) == 0  # n <= 1: nothing to do
+    assert l.gs_sort_pairs(None, None, None, None, 10, 25, 25, 13, None, None) == -1  # 25+13 bits > 32
     assert l.gs_sort_workspace_bytes(10_000_000) > 256 * 4 * (10_000_000 // 2048)
 
 
@@ -101,6 +102,10 @@ def test_sort_key_bits():
     assert sort_key_bits(0.4, 2000., 10., 8040) == (15, 13)    # truck config
     assert sort_key_bits(-1.0, 10., 100., 4)[0] == 64          # negative depth: full signed key
     assert sort_key_bits(0.0, 1e9, 100., 1) == (64, 0)         # quantised depth may overflow int32
+    from taichi_3d_gaussian_splatting_amd.hip_ops import key_layout
+    assert key_layout(0.8, 1000., 100., 8040) == (17, 17, 13)  # 30 bits: compressed 32-bit keys
+    assert key_layout(0.8, 1e6, 100., 8040) == (0, 27, 13)     # 40 bits: reference 64-bit layout
+    assert key_layout(-1.0, 10., 100., 4) == (0, 64, 2)
 
 
 def test_pose_helpers_match_oracle_and_scipy():

@@ -67,7 +67,7 @@ def test_preprocess(ops, scene, ofwd):
     feat = dev(s.point_cloud_features).clone()
     attrs, ntiles, nowned, block_sums = ops.preprocess(
         dev(s.point_cloud), feat, dev(s.point_object_id), dev(s.camera_intrinsics), dev(ofwd["q_cp"]),
-        dev(ofwd["t_cp"]), dev(ofwd["ids"]), s.width, s.height)
+        dev(ofwd["t_cp"]), dev(ofwd["ids"]), s.width, s.height, exact_tile_cull=False)
     a, ref = attrs.cpu().numpy(), pack_attrs(ofwd)
     # projection is evaluated in the oracle's operation order with contraction off: bit-exact
     assert np.array_equal(a[:, 0:3], ref[:, 0:3]), "uv / depth must be bit-exact"
@@ -99,7 +99,8 @@ def test_keys_sort_ranges_bit_exact(ops, scene, ofwd):
     counters = torch.zeros(ops.NUM_COUNTERS, dtype=torch.int32, device="cuda")
     k = ops.scan_block_sums(block_sums, counters)
     assert k == ofwd["keys"].shape[0]
-    keys, payload = ops.make_keys(attrs, nt, block_sums, k, s.width, s.height, s.depth_to_sort_key_scale)
+    keys, payload = ops.make_keys(attrs, nt, block_sums, k, s.width, s.height, s.depth_to_sort_key_scale,
+                                  exact_tile_cull=False, key_depth_bits=0)
     # unsorted keys: same generation order as RAS:161-172
     uk = np.empty(k, np.int64); up = np.empty(k, np.int32)
     import ctypes
@@ -117,23 +118,93 @@ def test_keys_sort_ranges_bit_exact(ops, scene, ofwd):
     start, end = ops.tile_ranges(keys, num_tiles)
     assert np.array_equal(start.cpu().numpy(), ofwd["tile_start"])
     assert np.array_equal(end.cpu().numpy(), ofwd["tile_end"])
+    # compressed 32-bit key layout: same order, same payload permutation, same tile ranges
+    kdb, db2, tb2 = ops.key_layout(s.near_plane, s.far_plane, s.depth_to_sort_key_scale, num_tiles)
+    assert kdb == db and (db2, tb2) == (db, tb)
+    keys32, payload32 = ops.make_keys(attrs, nt, block_sums, k, s.width, s.height, s.depth_to_sort_key_scale,
+                                      exact_tile_cull=False, key_depth_bits=kdb)
+    expect32 = (((uk >> 32) << kdb) | (uk & 0xffffffff)).astype(np.uint32)
+    assert np.array_equal(keys32.cpu().numpy().view(np.uint32), expect32)
+    ops.sort_pairs(keys32, payload32, db, tb, kdb)
+    assert np.array_equal(payload32.cpu().numpy(), ofwd["payload"])
+    start32, end32 = ops.tile_ranges(keys32, num_tiles, kdb)
+    assert np.array_equal(start32.cpu().numpy(), ofwd["tile_start"])
+    assert np.array_equal(end32.cpu().numpy(), ofwd["tile_end"])
 
 
-@pytest.mark.parametrize("n,depth_bits,tile_bits", [(1, 17, 13), (2, 17, 13), (257, 8, 3), (5000, 17, 13),
-                                                     (70_000, 9, 5), (300_001, 64, 13)])
-def test_radix_sort_stable_vs_numpy(ops, n, depth_bits, tile_bits):
+def test_exact_tile_cull_is_output_identical(ops, scene, ofwd):
+    """Culled (tile, Gaussian) pairs are a subset of the reference's pairs, each culled pair stays below the
+    1/255 skip threshold on all 256 pixels of its tile (checked in float64), and the blended outputs do not
+    change by a single bit."""
+    s = scene
+    attrs = dev(pack_attrs(ofwd))
+    outs = {}
+    for cull in (False, True):
+        feat = dev(s.point_cloud_features).clone()  # fresh copy: preprocess normalises q in place
+        a, nfull, nowned, bsums = ops.preprocess(
+            dev(s.point_cloud), feat, dev(s.point_object_id), dev(s.camera_intrinsics), dev(ofwd["q_cp"]),
+            dev(ofwd["t_cp"]), dev(ofwd["ids"]), s.width, s.height, exact_tile_cull=cull)
+        counters = torch.zeros(ops.NUM_COUNTERS, dtype=torch.int32, device="cuda")
+        k = ops.scan_block_sums(bsums, counters)
+        keys, payload = ops.make_keys(a, nowned, bsums, k, s.width, s.height, s.depth_to_sort_key_scale,
+                                      exact_tile_cull=cull, key_depth_bits=0)
+        assert np.array_equal(nfull.cpu().numpy(), ofwd["num_overlap_tiles"])  # hook output is the box count
+        num_tiles = (s.width // 16) * (s.height // 16)
+        db, tb = ops.sort_key_bits(s.near_plane, s.far_plane, s.depth_to_sort_key_scale, num_tiles)
+        ops.sort_pairs(keys, payload, db, tb)
+        start, end = ops.tile_ranges(keys, num_tiles)
+        img = ops.blend_forward(start, end, payload, a, s.width, s.height)
+        outs[cull] = (keys.cpu().numpy(), payload.cpu().numpy(), [t.cpu() for t in img], k)
+    k_full, k_cull = outs[False][3], outs[True][3]
+    report("exact_tile_cull", pairs_reference=k_full, pairs_kept=k_cull, kept_fraction=k_cull / k_full)
+    assert k_cull < k_full
+    pair = lambda keys, pay: (keys >> 32) * (1 << 32) + pay  # noqa: E731  (tile, point) identifier
+    full_pairs, kept_pairs = pair(outs[False][0], outs[False][1]), pair(outs[True][0], outs[True][1])
+    assert np.isin(kept_pairs, full_pairs).all()
+    culled = np.setdiff1d(full_pairs, kept_pairs)
+    tile, pt = culled >> 32, culled & 0xffffffff
+    tw = s.width // 16
+    uv, conic, al = ofwd["uv"].astype(np.float64), ofwd["conic"].astype(np.float64), ofwd["alpha"].astype(np.float64)
+    px = (tile % tw)[:, None] * 16 + (np.arange(256) % 16)[None, :] + 0.5
+    py = (tile // tw)[:, None] * 16 + (np.arange(256) // 16)[None, :] + 0.5
+    dx, dy = px - uv[pt, 0:1], py - uv[pt, 1:2]
+    e = -0.5 * (dx * dx * conic[pt, 0:1] + dy * dy * conic[pt, 2:3]) - dx * dy * conic[pt, 1:2]
+    amax = (np.exp(e) * conic[pt, 3:4] * al[pt, None]).max(axis=1)
+    report("exact_tile_cull.culled_pairs", n=len(culled), max_alpha=float(amax.max()), threshold=1 / 255)
+    assert amax.max() < 1.0 / 255.0
+    names = ["image", "depth", "acc_alpha", "last_eff", "count"]
+    for i in (0, 1, 2, 4):  # last_eff is a list position and legitimately differs
+        a, b = outs[False][2][i], outs[True][2][i]
+        ndiff = int((a != b).sum())
+        report(f"exact_tile_cull.{names[i]}", differing=ndiff,
+               max_abs=float((a.double() - b.double()).abs().max()))
+        assert ndiff == 0, names[i]  # bit-identical
+
+
+@pytest.mark.parametrize("n,depth_bits,tile_bits,compressed", [
+    (1, 17, 13, False), (2, 17, 13, True), (257, 8, 3, True), (5000, 17, 13, False), (5000, 17, 13, True),
+    (70_000, 9, 5, True), (300_001, 64, 13, False), (300_001, 19, 13, True)])
+def test_radix_sort_stable_vs_numpy(ops, n, depth_bits, tile_bits, compressed):
     rng = np.random.default_rng(n)
     if depth_bits == 64:  # negative depths: the full signed key is sorted
         dq = rng.integers(-50, 50, size=n).astype(np.int64)
     else:
         dq = rng.integers(0, 1 << min(depth_bits, 6), size=n).astype(np.int64)  # few values: many ties
+        dq[rng.integers(0, n, size=max(1, n // 7))] = (1 << depth_bits) - 1     # and the top of the range
     tile = rng.integers(0, 1 << tile_bits, size=n).astype(np.int64)
-    keys = dq + (tile << 32)
     payload = np.arange(n, dtype=np.int32)
-    k, p = dev(keys), dev(payload)
-    ops.sort_pairs(k, p, depth_bits, tile_bits)
+    if compressed:
+        keys = (dq + (tile << depth_bits)).astype(np.uint32)
+        k, p = dev(keys.view(np.int32)), dev(payload)
+        ops.sort_pairs(k, p, depth_bits, tile_bits, depth_bits)
+        got = k.cpu().numpy().view(np.uint32)
+    else:
+        keys = dq + (tile << 32)
+        k, p = dev(keys), dev(payload)
+        ops.sort_pairs(k, p, depth_bits, tile_bits)
+        got = k.cpu().numpy()
     order = np.argsort(keys, kind="stable")
-    assert np.array_equal(k.cpu().numpy(), keys[order])
+    assert np.array_equal(got, keys[order])
     assert np.array_equal(p.cpu().numpy(), payload[order])
 
 
@@ -379,20 +450,23 @@ def test_headline_size_properties(ops):
     attrs, ntiles, nowned, block_sums = ops.preprocess(s.point_cloud, feat, s.point_object_id, s.camera_intrinsics,
                                                        q_cp, t_cp, ids, s.width, s.height)
     assert torch.allclose(feat[ids.long(), :4].norm(dim=1), torch.ones(ids.shape[0], device="cuda"), atol=1e-6)
-    total = int(ntiles.sum().item())
+    assert (nowned <= ntiles).all()
+    total = int(nowned.sum().item())
     k = ops.scan_block_sums(block_sums, counters)
     assert k == total
-    keys, payload = ops.make_keys(attrs, nowned, block_sums, k, s.width, s.height, s.depth_to_sort_key_scale)
-    # histogram of payload = tile counts (every point emits exactly its count)
-    assert torch.equal(torch.bincount(payload.long(), minlength=ids.shape[0]).int(), ntiles)
     num_tiles = (s.width // 16) * (s.height // 16)
-    db, tb = ops.sort_key_bits(s.near_plane, s.far_plane, s.depth_to_sort_key_scale, num_tiles)
+    kdb, db, tb = ops.key_layout(s.near_plane, s.far_plane, s.depth_to_sort_key_scale, num_tiles)
+    assert kdb > 0  # production layout at this size: compressed 32-bit keys
+    keys, payload = ops.make_keys(attrs, nowned, block_sums, k, s.width, s.height, s.depth_to_sort_key_scale,
+                                  key_depth_bits=kdb)
+    # histogram of payload = key counts (every point emits exactly its count)
+    assert torch.equal(torch.bincount(payload.long(), minlength=ids.shape[0]).int(), nowned)
     k0, p0 = keys.clone(), payload.clone()
-    ops.sort_pairs(keys, payload, db, tb)
-    ref_keys, perm = torch.sort(k0, stable=True)
-    assert torch.equal(keys, ref_keys) and torch.equal(payload, p0[perm])  # sortedness + stability
-    start, end = ops.tile_ranges(keys, num_tiles)
-    tile_of = (keys >> 32).int()
+    ops.sort_pairs(keys, payload, db, tb, kdb)
+    ref_keys, perm = torch.sort(k0.long() & 0xffffffff, stable=True)
+    assert torch.equal(keys.long() & 0xffffffff, ref_keys) and torch.equal(payload, p0[perm])  # sorted + stable
+    start, end = ops.tile_ranges(keys, num_tiles, kdb)
+    tile_of = ((keys.long() & 0xffffffff) >> kdb).int()
     cnt = torch.bincount(tile_of.long(), minlength=num_tiles).int()
     assert torch.equal(end - start, cnt)
     image, depth, acc_alpha, last_eff, count = ops.blend_forward(start, end, payload, attrs, s.width, s.height)
@@ -403,4 +477,4 @@ def test_headline_size_properties(ops):
     tid = tiles_v[:, None] * (s.width // 16) + tiles_u[None, :]
     assert (last_eff >= start[tid]).all() and (last_eff <= end[tid]).all()
     assert (count <= last_eff - start[tid]).all()
-    report("headline.sizes", M=ids.shape[0], K=k)
+    report("headline.sizes", M=ids.shape[0], K_reference=int(ntiles.sum().item()), K_after_cull=k)

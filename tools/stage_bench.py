@@ -16,6 +16,7 @@ reps = int(sys.argv[2]) if len(sys.argv) > 2 else 10
 s = make_config_scene(workload).to("cuda")
 g = make_grad_image(s.height, s.width).to("cuda")
 times = {}
+CULL = os.environ.get('GS_CULL', '1') == '1'
 
 
 def timed(name, fn):
@@ -26,7 +27,7 @@ def timed(name, fn):
 
 
 num_tiles = (s.width // 16) * (s.height // 16)
-db, tb = hip_ops.sort_key_bits(s.near_plane, s.far_plane, s.depth_to_sort_key_scale, num_tiles)
+kdb, db, tb = hip_ops.key_layout(s.near_plane, s.far_plane, s.depth_to_sort_key_scale, num_tiles)
 q_cp, t_cp = hip_ops.pose_inverse(s.q_pointcloud_camera, s.t_pointcloud_camera)
 feat = s.point_cloud_features.clone()
 for _ in range(reps + 2):
@@ -34,12 +35,12 @@ for _ in range(reps + 2):
         s.point_cloud, s.point_invalid_mask, s.point_object_id, s.camera_intrinsics, q_cp, t_cp, s.near_plane,
         s.far_plane, s.width, s.height))
     attrs, ntiles, nowned, bsums = timed("preprocess", lambda: hip_ops.preprocess(
-        s.point_cloud, feat, s.point_object_id, s.camera_intrinsics, q_cp, t_cp, ids, s.width, s.height))
+        s.point_cloud, feat, s.point_object_id, s.camera_intrinsics, q_cp, t_cp, ids, s.width, s.height, 0, 1, CULL))
     k = timed("scan_block_sums", lambda: hip_ops.scan_block_sums(bsums, counters))
     keys, payload = timed("make_keys", lambda: hip_ops.make_keys(attrs, nowned, bsums, k, s.width, s.height,
-                                                                 s.depth_to_sort_key_scale))
-    timed("sort_pairs", lambda: hip_ops.sort_pairs(keys, payload, db, tb))
-    start, end = timed("tile_ranges", lambda: hip_ops.tile_ranges(keys, num_tiles))
+                                                                 s.depth_to_sort_key_scale, 0, 1, CULL, kdb))
+    timed("sort_pairs", lambda: hip_ops.sort_pairs(keys, payload, db, tb, kdb))
+    start, end = timed("tile_ranges", lambda: hip_ops.tile_ranges(keys, num_tiles, kdb))
     image, depth, acc_alpha, last_eff, count = timed("blend_forward", lambda: hip_ops.blend_forward(
         start, end, payload, attrs, s.width, s.height))
     acc, mag = timed("blend_backward", lambda: hip_ops.blend_backward(
@@ -48,7 +49,7 @@ for _ in range(reps + 2):
         s.point_cloud, feat, s.point_object_id, s.camera_intrinsics, q_cp, t_cp, s.t_pointcloud_camera, ids, acc, 3,
         1.0, 0.5, 20.0, 5.0, 1.0, False))
 torch.cuda.synchronize()
-print(f"workload={workload} M={ids.shape[0]} K={k} variant={os.environ.get('GS_VARIANT', '')}")
+print(f"workload={workload} M={ids.shape[0]} K={k} cull={CULL}")
 tot = 0.0
 for name, pairs in times.items():
     ms = sum(a.elapsed_time(b) for a, b in pairs[2:]) / len(pairs[2:])
