@@ -22,6 +22,7 @@ namespace {
 constexpr float EPS_ALPHA = (float)(1.0 / 255.0);  // RAS:451
 constexpr float CLAMP_ALPHA = 0.99f;               // RAS:453
 constexpr float STOP_T = 0.0001f;                  // RAS:458
+constexpr int GROUP = 4;  // list entries evaluated together in the blend loops (GS_BLOCK % GROUP == 0)
 
 struct TileCoord { int tile_u, tile_v, tile_id; };
 
@@ -68,30 +69,47 @@ __global__ __launch_bounds__(GS_BLOCK) void blend_forward_kernel(
             s_a[tid] = g[0];
             s_b[tid] = g[1];
             s_c[tid] = g[2];
+        } else {  // padding record: opacity 0 -> alpha 0, never blended
+            s_a[tid] = make_float4(0.f, 0.f, 0.f, 0.f);
+            s_b[tid] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
         __syncthreads();
         const int n = min(GS_BLOCK, end - base);
-        for (int k = 0; k < n && !done; ++k) {
-            const float4 a = s_a[k], b = s_b[k];
-            const float dx = px - a.x, dy = py - a.y;
-            // UTL:275-284
-            const float e = fmaf(-0.5f, fmaf(dy * dy, b.z, dx * dx * b.x), -(dx * dy) * b.y);
-            float alpha = __expf(e) * b.w * a.w;
-            if (alpha < EPS_ALPHA) continue;
-            alpha = fminf(alpha, CLAMP_ALPHA);
-            const float Tn = T * (1.f - alpha);
-            if (Tn < STOP_T) {  // RAS:458-460: saturated, this Gaussian is not blended
-                done = true;
-                break;
+        // Entries are evaluated in groups of GROUP: the LDS reads and the exp of a group are independent
+        // and overlap (the per-pixel blend recurrence is the only serial part), which hides their latency.
+        for (int k = 0; k < n; k += GROUP) {
+            if (__ballot(!done) == 0ull) break;  // every pixel of this wave is saturated
+            float alpha[GROUP], z[GROUP];
+#pragma unroll
+            for (int i = 0; i < GROUP; ++i) {
+                const float4 a = s_a[k + i], b = s_b[k + i];
+                const float dx = px - a.x, dy = py - a.y;
+                // UTL:275-284
+                const float e = fmaf(-0.5f, fmaf(dy * dy, b.z, dx * dx * b.x), -(dx * dy) * b.y);
+                alpha[i] = __expf(e) * b.w * a.w;
+                z[i] = a.z;
             }
-            const float4 c = s_c[k];
-            const float wgt = alpha * T;
-            last = base + k + 1;
-            Cr = fmaf(c.x, wgt, Cr); Cg = fmaf(c.y, wgt, Cg); Cb = fmaf(c.z, wgt, Cb);
-            D = fmaf(a.z, wgt, D);
-            Wd += wgt;
-            cnt += 1;
-            T = Tn;
+#pragma unroll
+            for (int i = 0; i < GROUP; ++i) {
+                const bool ok = !done && alpha[i] >= EPS_ALPHA;  // RAS:451
+                if (__ballot(ok) == 0ull) continue;              // wave-uniform skip
+                if (ok) {
+                    const float al = fminf(alpha[i], CLAMP_ALPHA);
+                    const float Tn = T * (1.f - al);
+                    if (Tn < STOP_T) {  // RAS:458-460: saturated, this Gaussian is not blended
+                        done = true;
+                    } else {
+                        const float4 c = s_c[k + i];
+                        const float wgt = al * T;
+                        last = base + k + i + 1;
+                        Cr = fmaf(c.x, wgt, Cr); Cg = fmaf(c.y, wgt, Cg); Cb = fmaf(c.z, wgt, Cb);
+                        D = fmaf(z[i], wgt, D);
+                        Wd += wgt;
+                        cnt += 1;
+                        T = Tn;
+                    }
+                }
+            }
         }
     }
     const size_t p = (size_t)pv * width + pu;
@@ -147,6 +165,9 @@ __global__ __launch_bounds__(GS_BLOCK) void blend_backward_kernel(
             s_b[tid] = g[1];
             s_c[tid] = g[2];
             s_o[tid] = o;
+        } else {  // padding record: opacity 0 -> never a hit
+            s_a[tid] = make_float4(0.f, 0.f, 0.f, 0.f);
+            s_b[tid] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
         {
             float4 *z = reinterpret_cast<float4 *>(&s_acc[tid][0]);
@@ -156,55 +177,59 @@ __global__ __launch_bounds__(GS_BLOCK) void blend_backward_kernel(
         }
         __syncthreads();
         const int n = min(GS_BLOCK, top - start);
-        for (int k = 0; k < n; ++k) {
-            const int jj = top - 1 - k;
-            const float4 a = s_a[k], b = s_b[k];
-            const float dx = px - a.x, dy = py - a.y;
-            // UTL:331-348: m = conic @ d, exponent = -0.5 d.m
-            const float m0 = fmaf(b.y, dy, b.x * dx), m1 = fmaf(b.z, dy, b.y * dx);
-            const float g = __expf(-0.5f * fmaf(dy, m1, dx * m0)) * b.w;
-            const float pa = g * a.w;
-            const bool hit = (jj < last) && (pa >= EPS_ALPHA);
-            const unsigned long long hits = __ballot(hit);
-            if (hits == 0ull) continue;  // wave-uniform skip: nobody in this wave touches the Gaussian
-            float v0 = 0.f, v1 = 0.f, c00 = 0.f, c01 = 0.f, c11 = 0.f, gr = 0.f, gg = 0.f, gb = 0.f, gl = 0.f,
-                  nv = 0.f;
-            if (hit) {
-                const float4 c = s_c[k];
-                const float alpha = fminf(pa, CLAMP_ALPHA);
-                const float inv1m = __builtin_amdgcn_rcpf(1.f - alpha);
-                T = T * inv1m;  // RAS:643, T_i = T_{i+1} / (1 - alpha_i)
-                const float aT = alpha * T;
-                gr = aT * Gr; gg = aT * Gg; gb = aT * Gb;
-                const float dLda = fmaf(fmaf(c.z, T, -(wb * inv1m)), Gb,
-                                        fmaf(fmaf(c.y, T, -(wg * inv1m)), Gg, fmaf(c.x, T, -(wr * inv1m)) * Gr));
-                wr = fmaf(c.x, aT, wr); wg = fmaf(c.y, aT, wg); wb = fmaf(c.z, aT, wb);
-                gl = dLda * g * (1.f - a.w) * a.w;
-                const float dLdg = dLda * a.w;
-                const float gm0 = g * m0, gm1 = g * m1;
-                v0 = dLdg * gm0; v1 = dLdg * gm1;
-                mag_u += fabsf(v0); mag_v += fabsf(v1);
-                const float h = 0.5f * dLdg;
-                c00 = h * gm0 * m0; c01 = h * gm0 * m1; c11 = h * gm1 * m1;
-                nv = sqrtf(fmaf(v1, v1, v0 * v0));
+        for (int k = 0; k < n; k += GROUP) {
+            // group evaluation: LDS reads + exp of GROUP entries are independent and overlap
+            float g[GROUP], m0[GROUP], m1[GROUP], op[GROUP];
+            bool hit[GROUP];
+#pragma unroll
+            for (int i = 0; i < GROUP; ++i) {
+                const float4 a = s_a[k + i], b = s_b[k + i];
+                const float dx = px - a.x, dy = py - a.y;
+                // UTL:331-348: m = conic @ d, exponent = -0.5 d.m
+                m0[i] = fmaf(b.y, dy, b.x * dx);
+                m1[i] = fmaf(b.z, dy, b.y * dx);
+                g[i] = __expf(-0.5f * fmaf(dy, m1[i], dx * m0[i])) * b.w;
+                op[i] = a.w;
+                hit[i] = (top - 1 - (k + i) < last) && (g[i] * a.w >= EPS_ALPHA);
             }
-            // reduce-scatter of the 10 partial sums over the 64 lanes: two swap+add levels halve the
-            // number of live registers (10 -> 5 -> 3), then 4 DPP row steps finish each register.
-            // Row totals land in lane 15 of each 16-lane row:
-            //   t0: rows = (v0, c00, v1, c01)   t1: rows = (c11, gg, gr, gb)   t2: rows = (gl, gl, nv, nv)
-            const float s0 = gs_fold32(v0, v1), s1 = gs_fold32(c00, c01), s2 = gs_fold32(c11, gr),
-                        s3 = gs_fold32(gg, gb), s4 = gs_fold32(gl, nv);
-            const float t0 = gs_row_sum_to_lane15(gs_fold16(s0, s1));
-            const float t1 = gs_row_sum_to_lane15(gs_fold16(s2, s3));
-            const float t2 = gs_row_sum_to_lane15(gs_fold16(s4, s4));
-            if ((lane & 15) == 15) {
-                const int row = lane >> 4;
-                const int slot = ((row & 1) << 1) | (row >> 1);  // rows (0,1,2,3) -> slots (0,2,1,3)
-                float *A = &s_acc[k][0];
-                atomicAdd(A + slot, t0);
-                atomicAdd(A + 4 + slot, t1);
-                if ((row & 1) == 0) atomicAdd(A + 8 + (row >> 1), t2);
-                if (row == 3) atomicAdd(reinterpret_cast<int *>(A + 10), (int)__popcll(hits));
+#pragma unroll
+            for (int i = 0; i < GROUP; ++i) {
+                const unsigned long long hits = __ballot(hit[i]);
+                if (hits == 0ull) continue;  // wave-uniform skip: nobody in this wave touches the Gaussian
+                float v0 = 0.f, v1 = 0.f, c00 = 0.f, c01 = 0.f, c11 = 0.f, gr = 0.f, gg = 0.f, gb = 0.f, gl = 0.f,
+                      nv = 0.f;
+                if (hit[i]) {
+                    const float4 c = s_c[k + i];
+                    const float alpha = fminf(g[i] * op[i], CLAMP_ALPHA);
+                    const float inv1m = __builtin_amdgcn_rcpf(1.f - alpha);
+                    T = T * inv1m;  // RAS:643, T_i = T_{i+1} / (1 - alpha_i)
+                    const float aT = alpha * T;
+                    gr = aT * Gr; gg = aT * Gg; gb = aT * Gb;
+                    const float dLda = fmaf(fmaf(c.z, T, -(wb * inv1m)), Gb,
+                                            fmaf(fmaf(c.y, T, -(wg * inv1m)), Gg, fmaf(c.x, T, -(wr * inv1m)) * Gr));
+                    wr = fmaf(c.x, aT, wr); wg = fmaf(c.y, aT, wg); wb = fmaf(c.z, aT, wb);
+                    gl = dLda * g[i] * (1.f - op[i]) * op[i];
+                    const float dLdg = dLda * op[i];
+                    const float gm0 = g[i] * m0[i], gm1 = g[i] * m1[i];
+                    v0 = dLdg * gm0; v1 = dLdg * gm1;
+                    mag_u += fabsf(v0); mag_v += fabsf(v1);
+                    const float h = 0.5f * dLdg;
+                    c00 = h * gm0 * m0[i]; c01 = h * gm0 * m1[i]; c11 = h * gm1 * m1[i];
+                    nv = __builtin_amdgcn_sqrtf(fmaf(v1, v1, v0 * v0));  // v_sqrt_f32, 1 ulp
+                }
+                // reduce-scatter of the 10 partial sums over the 64 lanes (gs_common.h); row totals land in
+                // lane 15 of each row:  t0: rows = (v0, c00, v1, c01)  t1: (c11, gg, gr, gb)  t2: (gl, gl, nv, nv)
+                float t0, t1, t2;
+                gs_wave_reduce10(v0, v1, c00, c01, c11, gr, gg, gb, gl, nv, t0, t1, t2);
+                if ((lane & 15) == 15) {
+                    const int row = lane >> 4;
+                    const int slot = ((row & 1) << 1) | (row >> 1);  // rows (0,1,2,3) -> slots (0,2,1,3)
+                    float *A = &s_acc[k + i][0];
+                    atomicAdd(A + slot, t0);
+                    atomicAdd(A + 4 + slot, t1);
+                    if ((row & 1) == 0) atomicAdd(A + 8 + (row >> 1), t2);
+                    if (row == 3) atomicAdd(reinterpret_cast<int *>(A + 10), (int)__popcll(hits));
+                }
             }
         }
         __syncthreads();

@@ -105,21 +105,56 @@ __device__ __forceinline__ float gs_row_sum_to_lane15(float v) {
     v += gs_dpp<0x118, 0xf, 0xc>(v);  // row_shr:8, banks 2-3
     return v;
 }
-// gfx950 cross-half / cross-row swaps (v_permlane32_swap / v_permlane16_swap).  Written as inline
-// asm because ROCm 7.2's clang returns element 0 for BOTH results of the __builtin_amdgcn_permlane*_swap
-// builtins.  The s_nop's cover the VALU-write -> permlane-read and permlane-write -> DPP-read wait states,
-// which the hazard recogniser cannot see through an asm statement.
-// (semantics verified on hardware: v_permlane32_swap exchanges vdst[63:32] with src0[31:0];
-// v_permlane16_swap exchanges the odd rows of vdst with the even rows of src0)
-// fold32: returns r with  r[lane<32] = x[l]+x[l+32],  r[lane>=32] = y[l-32]+y[l]
-__device__ __forceinline__ float gs_fold32(float x, float y) {
-    asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(x), "+v"(y));
-    return x + y;
-}
-// fold16: even rows of the result hold x[row]+x[row+1], odd rows hold y[row-1]+y[row] (rows of 16 lanes)
-__device__ __forceinline__ float gs_fold16(float x, float y) {
-    asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(x), "+v"(y));
-    return x + y;
+// ------------------------------------------------------------------ 10-value wave reduce-scatter
+// Sums ten per-lane partials over the 64 lanes of a wave in 30 VALU instructions (6 x 10 = 60 with
+// the plain DPP ladder): two swap+add levels use gfx950's v_permlane32_swap / v_permlane16_swap to
+// halve the number of live registers (10 -> 5 -> 3), then four DPP row steps finish each register.
+// On return the totals sit in lane 15 of each 16-lane row:
+//   t0: rows 0..3 = (x0, x2, x1, x3)   t1: rows = (x4, x6, x5, x7)   t2: rows = (x8, x8, x9, x9)
+// Hand-scheduled inline asm because (a) ROCm 7.2's clang returns element 0 for BOTH results of the
+// __builtin_amdgcn_permlane*_swap builtins and (b) hazards are not visible through an asm statement:
+// the leading s_nop covers "VALU write -> permlane read"; every other dependent pair below is separated
+// by >= 2 independent instructions (DPP / permlane reads of a just-written VGPR need 2 wait states).
+// Swap semantics verified on hardware: v_permlane32_swap exchanges vdst[63:32] with src0[31:0];
+// v_permlane16_swap exchanges the odd rows of vdst with the even rows of src0.
+__device__ __forceinline__ void gs_wave_reduce10(float x0, float x1, float x2, float x3, float x4, float x5,
+                                                 float x6, float x7, float x8, float x9, float &t0, float &t1,
+                                                 float &t2) {
+    float x10;
+    asm("s_nop 1\n\t"
+        "v_permlane32_swap_b32 %0, %1\n\t"   // (x0,x1): lanes<32 of x0+x1 -> sum x0, lanes>=32 -> sum x1
+        "v_permlane32_swap_b32 %2, %3\n\t"
+        "v_permlane32_swap_b32 %4, %5\n\t"
+        "v_permlane32_swap_b32 %6, %7\n\t"
+        "v_permlane32_swap_b32 %8, %9\n\t"
+        "v_add_f32 %0, %0, %1\n\t"
+        "v_add_f32 %2, %2, %3\n\t"
+        "v_add_f32 %4, %4, %5\n\t"
+        "v_add_f32 %6, %6, %7\n\t"
+        "v_add_f32 %8, %8, %9\n\t"
+        "v_mov_b32 %10, %8\n\t"
+        "v_permlane16_swap_b32 %0, %2\n\t"   // even rows: x0|x1 sums, odd rows: x2|x3 sums
+        "v_permlane16_swap_b32 %4, %6\n\t"
+        "v_permlane16_swap_b32 %8, %10\n\t"
+        "v_add_f32 %0, %0, %2\n\t"
+        "v_add_f32 %4, %4, %6\n\t"
+        "v_add_f32 %8, %8, %10\n\t"
+        "v_add_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %4, %4, %4 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %8, %8, %8 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %4, %4, %4 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %8, %8, %8 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xe\n\t"
+        "v_add_f32_dpp %4, %4, %4 row_shr:4 row_mask:0xf bank_mask:0xe\n\t"
+        "v_add_f32_dpp %8, %8, %8 row_shr:4 row_mask:0xf bank_mask:0xe\n\t"
+        "v_add_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xc\n\t"
+        "v_add_f32_dpp %4, %4, %4 row_shr:8 row_mask:0xf bank_mask:0xc\n\t"
+        "v_add_f32_dpp %8, %8, %8 row_shr:8 row_mask:0xf bank_mask:0xc\n\t"
+        "s_nop 1"
+        : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7), "+v"(x8), "+v"(x9),
+          "=&v"(x10));
+    t0 = x0; t1 = x4; t2 = x8;
 }
 __device__ __forceinline__ float gs_readlane63(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));

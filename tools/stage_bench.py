@@ -60,3 +60,7 @@ lens = (end - start).float()
 eff = (last_eff.view(s.height // 16, 16, s.width // 16, 16).amax(dim=(1, 3)).flatten() - start).float()
 print(f"  tile list mean={lens.mean():.1f} max={lens.max():.0f}; effective (to max last) mean={eff.mean():.1f}; "
       f"count mean={count.float().mean():.2f}")
+vals = eff.sort(descending=True).values
+print("  effective list percentiles: max=%d p99.9=%d p99=%d p90=%d p50=%d" % (
+    vals[0], vals[int(0.001 * len(vals))], vals[int(0.01 * len(vals))], vals[int(0.1 * len(vals))], vals[len(vals) // 2]))
+print("  sum(eff)=%d; blocks=%d" % (int(eff.sum()), len(vals)))
