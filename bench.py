@@ -37,17 +37,18 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
-def algorithmic_bytes(n, m, k, p):
+def algorithmic_bytes(n, m, k, p, key_bytes=8):
     """Compulsory HBM bytes per launch of each stage: every
-    stage input read once, every output written once; N points, M visible, K (tile,Gaussian) pairs,
-    P pixels."""
+    stage input read once, every output written once; N points, M visible, K (tile,Gaussian) pairs
+    that are sorted and blended, P pixels; key_bytes = 4 (compressed keys) or 8 (reference layout)."""
+    pair = key_bytes + 4
     return {
         "filter_compact": 18 * n + 4 * m,
         "preprocess": 244 * m + 16 * m + 48 * m + 8 * m + 4 * m,   # row+xyz+ids+obj, q write, attrs, counts
         "scan_block_sums": 8 * (m // 256 + 1),
-        "make_keys": 32 * m + 12 * k,
-        "sort_pairs": 24 * k,
-        "tile_ranges": 8 * k,
+        "make_keys": 32 * m + pair * k,
+        "sort_pairs": 2 * pair * k,
+        "tile_ranges": key_bytes * k,
         "blend_forward": 48 * k + 28 * p,
         "blend_backward": 44 * k + 28 * p + 48 * m,
         "point_backward": 244 * m + 48 * m + 248 * n,
@@ -173,7 +174,7 @@ def main() -> None:
         stages_ms = {name: sum(a.elapsed_time(b) for a, b in pairs[1:]) / max(len(pairs) - 1, 1)
                      for name, pairs in acc_ms.items()}
         p_owned = pixels if world == 1 else pixels * len(range(rb, s.height // 16, rs)) / (s.height // 16)
-        bytes_per = algorithmic_bytes(n, m, int(k), p_owned)
+        bytes_per = algorithmic_bytes(n, m, int(k), p_owned, 4 if kdb > 0 else 8)
         dominant = max(stages_ms, key=stages_ms.get)
         achieved = bytes_per[dominant] / (stages_ms[dominant] * 1e-3) / 1e9
         path_bytes = sum(bytes_per.values())
