@@ -18,11 +18,13 @@
  *    message.  Nothing throws across the boundary;
  *  - fp32 everywhere, quaternions (x,y,z,w), row-major matrices, image memory [v,u,c].
  *
- * Packed per-visible-point record `attrs` (float[M][12], 48 B, 16-B aligned), produced by
- * gs_preprocess and gathered by the blend kernels:
+ * Packed per-visible-point record `attrs` (float[M][16], 64 B, 16-B aligned), produced by
+ * gs_preprocess and gathered by the blend kernels (forward: rows 0,2,3; backward: rows 0,1,2):
  *   [0] u  [1] v  [2] z (camera depth)  [3] opacity sigmoid(logit)
  *   [4] conic A  [5] conic B  [6] conic C  [7] rescale          (UTL:257-272)
  *   [8] r  [9] g  [10] b  [11] 3-sigma radius                   (RAS:302-315)
+ *   [12] -0.5*A*log2(e)  [13] -B*log2(e)  [14] -0.5*C*log2(e)  [15] opacity*rescale
+ *        (the weight of UTL:275-284 as  amp * 2^(dx*(A'dx + B'dy) + C'dy^2), one v_exp_f32)
  * Backward accumulators `acc` (float[M][12]):
  *   [0..1] dL/duv  [2..4] dL/dcov(00,01,11)  [5..7] dL/drgb  [8] dL/dlogit
  *   [9] sum of |dL/duv| norms  [10] number of affected pixels (int32 bits)  [11] unused
@@ -40,7 +42,7 @@ extern "C" {
 #define GS_TILE_WIDTH 16      /* RAS:27 */
 #define GS_TILE_HEIGHT 16     /* RAS:28 */
 #define GS_BOUNDARY_TILES 3   /* RAS:26 */
-#define GS_ATTR_STRIDE 12
+#define GS_ATTR_STRIDE 16
 #define GS_ACC_STRIDE 12
 #define GS_FEATURE_DIM 56     /* RAS:214-226 */
 

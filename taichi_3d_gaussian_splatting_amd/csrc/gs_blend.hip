@@ -1,14 +1,16 @@
 // gs_blend.hip -- per-tile alpha blending, forward and backward, for gfx950 (wave64).
 //
-// Workgroup = one 16x16 tile = 4 wavefronts; lane = pixel (a wave covers 4 rows x 16 columns).
-// The tile's depth-sorted Gaussian list is staged through LDS in batches of 256 packed 48-B
-// records (3 x float4 per Gaussian, gathered with 16-B loads).
-//  forward : front-to-back blend (RAS:318-485, weight UTL:275-284); whole-tile early exit with a
-//            workgroup vote (the reference could not express it, RAS:387-394).
-//  backward: back-to-front traversal (RAS:531-705, gradients UTL:331-348) starting at the
-//            tile's last effective entry; the 10 per-Gaussian partial sums are reduced across
-//            the 64 lanes with DPP row shifts/broadcasts and ONE lane issues the hardware fp32
-//            atomics -- one atomic set per (wave, Gaussian) instead of one per (pixel, Gaussian).
+// Workgroup = one 16x16 tile = 2 wavefronts; every lane owns two horizontally adjacent pixels (a wave
+// covers 8 rows x 16 columns).  The tile's depth-sorted Gaussian list is staged through LDS in batches
+// of 128 packed records (3 x float4 per Gaussian, gathered with 16-B loads).
+//  forward : front-to-back blend (RAS:318-485, weight UTL:275-284); 2 waves per tile, two pixels per lane
+//            on packed fp32 math; whole-tile early exit with a workgroup vote (the reference could not
+//            express it, RAS:387-394).
+//  backward: back-to-front traversal (RAS:531-705, gradients UTL:331-348) starting at the tile's last
+//            effective entry; 2 waves per tile, two pixels per lane; the 10 per-Gaussian partial sums are
+//            reduced across the 64 lanes by a permlane-swap + DPP reduce-scatter, combined across the two
+//            waves in LDS, and flushed with one hardware-atomic set per (tile, Gaussian) instead of the
+//            reference's eleven atomics per (pixel, Gaussian).
 #include "gs_common.h"
 
 // Automatic FMA contraction is off in this file and every fused multiply-add is written explicitly:
@@ -42,125 +44,165 @@ __device__ __forceinline__ TileCoord owned_tile(int tw, int row_begin, int row_s
 }
 
 // ------------------------------------------------------------------------------- forward
-__global__ __launch_bounds__(GS_BLOCK) void blend_forward_kernel(
+// Workgroup = one tile = 2 wave64s; every lane owns TWO horizontally adjacent pixels and does its fp32
+// arithmetic on float2 values, which the compiler maps to the packed CDNA instructions
+// (v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32: two pixels per VALU issue).  The Gaussian weight uses the
+// pre-scaled row 3 of the record: alpha = amp * 2^(dx*(A'dx + B'dy) + C'dy^2)  -- 2 packed FMAs, 3 scalar
+// multiplies and one v_exp_f32 per pixel.
+typedef float v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2f fma2(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ v2f splat(float x) { return (v2f){x, x}; }
+
+constexpr int FWD_THREADS = 128;
+constexpr int FWD_BATCH = 128;
+
+__global__ __launch_bounds__(FWD_THREADS) void blend_forward_kernel(
     const int32_t *__restrict__ tile_start, const int32_t *__restrict__ tile_end,
     const int32_t *__restrict__ payload, const float4 *__restrict__ attrs, int width, int height, int row_begin,
     int row_step, float *__restrict__ image, float *__restrict__ depth, float *__restrict__ acc_alpha,
     int32_t *__restrict__ last_effective, int32_t *__restrict__ valid_count) {
-    __shared__ float4 s_a[GS_BLOCK], s_b[GS_BLOCK], s_c[GS_BLOCK];
+    __shared__ float4 s_p[FWD_BATCH], s_c[FWD_BATCH], s_q[FWD_BATCH];  // rows 0, 2, 3 of the record
     const int tw = width / GS_TILE_WIDTH;
     const TileCoord tc = owned_tile(tw, row_begin, row_step);
     const int tid = threadIdx.x;
-    const int pu = tc.tile_u * GS_TILE_WIDTH + (tid & 15);
-    const int pv = tc.tile_v * GS_TILE_HEIGHT + (tid >> 4);
+    const int pu = tc.tile_u * GS_TILE_WIDTH + 2 * (tid & 7);   // left pixel of the pair
+    const int pv = tc.tile_v * GS_TILE_HEIGHT + (tid >> 3);
     const int start = tile_start[tc.tile_id], end = tile_end[tc.tile_id];
-    const float px = (float)pu + 0.5f, py = (float)pv + 0.5f;
+    const v2f px = {(float)pu + 0.5f, (float)pu + 1.5f};
+    const float py = (float)pv + 0.5f;
 
-    float T = 1.0f, Cr = 0.f, Cg = 0.f, Cb = 0.f, D = 0.f, Wd = 0.f;
-    int last = start, cnt = 0;
-    bool done = false;
+    // alive = 1 until the pixel saturates, then 0: it multiplies alpha, so a dead pixel never passes the
+    // 1/255 test again and needs no separate predicate in the hot loop.
+    v2f T = splat(1.0f), alive = splat(1.0f);
+    v2f Cr = splat(0.f), Cg = splat(0.f), Cb = splat(0.f), D = splat(0.f), Wd = splat(0.f);
+    int last0 = start, last1 = start, cnt0 = 0, cnt1 = 0;
 
-    for (int base = start; base < end; base += GS_BLOCK) {
+    for (int base = start; base < end; base += FWD_BATCH) {
         // barrier (protects the LDS batch) + whole-tile early exit vote
-        if (__syncthreads_and(done ? 1 : 0)) break;
+        if (__syncthreads_and((alive.x + alive.y == 0.f) ? 1 : 0)) break;
         const int j = base + tid;
         if (j < end) {
-            const float4 *g = attrs + 3 * (size_t)payload[j];
-            s_a[tid] = g[0];
-            s_b[tid] = g[1];
+            const float4 *g = attrs + 4 * (size_t)payload[j];
+            s_p[tid] = g[0];
             s_c[tid] = g[2];
-        } else {  // padding record: opacity 0 -> alpha 0, never blended
-            s_a[tid] = make_float4(0.f, 0.f, 0.f, 0.f);
-            s_b[tid] = make_float4(0.f, 0.f, 0.f, 0.f);
+            s_q[tid] = g[3];
+        } else {  // padding record: amplitude 0 -> alpha 0, never blended
+            s_p[tid] = make_float4(0.f, 0.f, 0.f, 0.f);
+            s_q[tid] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
         __syncthreads();
-        const int n = min(GS_BLOCK, end - base);
+        const int n = min(FWD_BATCH, end - base);
         // Entries are evaluated in groups of GROUP: the LDS reads and the exp of a group are independent
         // and overlap (the per-pixel blend recurrence is the only serial part), which hides their latency.
         for (int k = 0; k < n; k += GROUP) {
-            if (__ballot(!done) == 0ull) break;  // every pixel of this wave is saturated
-            float alpha[GROUP], z[GROUP];
+            if (__ballot(alive.x + alive.y != 0.f) == 0ull) break;  // every pixel of this wave is saturated
+            v2f alpha[GROUP];
+            float z[GROUP];
 #pragma unroll
             for (int i = 0; i < GROUP; ++i) {
-                const float4 a = s_a[k + i], b = s_b[k + i];
-                const float dx = px - a.x, dy = py - a.y;
-                // UTL:275-284
-                const float e = fmaf(-0.5f, fmaf(dy * dy, b.z, dx * dx * b.x), -(dx * dy) * b.y);
-                alpha[i] = __expf(e) * b.w * a.w;
-                z[i] = a.z;
+                const float4 p = s_p[k + i], q = s_q[k + i];
+                const v2f dx = px - splat(p.x);
+                const float dy = py - p.y;
+                // UTL:275-284 in the log2 domain
+                const v2f e = fma2(dx, fma2(dx, splat(q.x), splat(q.y * dy)), splat(q.z * dy * dy));
+                alpha[i] = (v2f){__builtin_amdgcn_exp2f(e.x), __builtin_amdgcn_exp2f(e.y)} * splat(q.w);
+                z[i] = p.z;
             }
 #pragma unroll
             for (int i = 0; i < GROUP; ++i) {
-                const bool ok = !done && alpha[i] >= EPS_ALPHA;  // RAS:451
-                if (__ballot(ok) == 0ull) continue;              // wave-uniform skip
-                if (ok) {
-                    const float al = fminf(alpha[i], CLAMP_ALPHA);
-                    const float Tn = T * (1.f - al);
-                    if (Tn < STOP_T) {  // RAS:458-460: saturated, this Gaussian is not blended
-                        done = true;
-                    } else {
-                        const float4 c = s_c[k + i];
-                        const float wgt = al * T;
-                        last = base + k + i + 1;
-                        Cr = fmaf(c.x, wgt, Cr); Cg = fmaf(c.y, wgt, Cg); Cb = fmaf(c.z, wgt, Cb);
-                        D = fmaf(z[i], wgt, D);
-                        Wd += wgt;
-                        cnt += 1;
-                        T = Tn;
-                    }
+                const v2f a = alpha[i] * alive;
+                bool ok0 = a.x >= EPS_ALPHA, ok1 = a.y >= EPS_ALPHA;  // RAS:451
+                if (__ballot(ok0 || ok1) == 0ull) continue;           // wave-uniform skip
+                // alpha = 0 for a skipped pixel makes the update below an exact no-op (T*(1-0) = T, C += c*0)
+                v2f al = {ok0 ? __builtin_amdgcn_fmed3f(a.x, 0.f, CLAMP_ALPHA) : 0.f,
+                          ok1 ? __builtin_amdgcn_fmed3f(a.y, 0.f, CLAMP_ALPHA) : 0.f};
+                v2f Tn = T * (splat(1.f) - al);
+                const bool sat0 = ok0 && Tn.x < STOP_T, sat1 = ok1 && Tn.y < STOP_T;
+                if (__ballot(sat0 || sat1) != 0ull) {
+                    // rare: RAS:458-460 -- the first Gaussian that would push T below 1e-4 saturates the
+                    // pixel and is NOT blended
+                    if (sat0) { al.x = 0.f; alive.x = 0.f; ok0 = false; }
+                    if (sat1) { al.y = 0.f; alive.y = 0.f; ok1 = false; }
+                    Tn = T * (splat(1.f) - al);
                 }
+                const v2f wgt = al * T;
+                const float4 c = s_c[k + i];
+                Cr = fma2(splat(c.x), wgt, Cr);
+                Cg = fma2(splat(c.y), wgt, Cg);
+                Cb = fma2(splat(c.z), wgt, Cb);
+                D = fma2(splat(z[i]), wgt, D);
+                Wd = Wd + wgt;
+                T = Tn;
+                const int idx = base + k + i + 1;
+                last0 = ok0 ? idx : last0;
+                last1 = ok1 ? idx : last1;
+                cnt0 += ok0 ? 1 : 0;
+                cnt1 += ok1 ? 1 : 0;
             }
         }
     }
     const size_t p = (size_t)pv * width + pu;
-    image[3 * p] = Cr; image[3 * p + 1] = Cg; image[3 * p + 2] = Cb;
-    depth[p] = D / fmaxf(Wd, 1e-6f);  // RAS:479-480
-    acc_alpha[p] = 1.f - T;
-    last_effective[p] = last;
-    valid_count[p] = cnt;
+    float *img = image + 3 * p;
+    img[0] = Cr.x; img[1] = Cg.x; img[2] = Cb.x; img[3] = Cr.y; img[4] = Cg.y; img[5] = Cb.y;
+    depth[p] = D.x / fmaxf(Wd.x, 1e-6f);  // RAS:479-480
+    depth[p + 1] = D.y / fmaxf(Wd.y, 1e-6f);
+    acc_alpha[p] = 1.f - T.x;
+    acc_alpha[p + 1] = 1.f - T.y;
+    last_effective[p] = last0;
+    last_effective[p + 1] = last1;
+    valid_count[p] = cnt0;
+    valid_count[p + 1] = cnt1;
 }
 
 // ------------------------------------------------------------------------------- backward
-// Per batch of 256 list entries the 4 waves of the tile combine their partial sums in LDS
+// Workgroup = one tile = 2 wave64s, every lane owns two horizontally adjacent pixels (as in the forward
+// kernel).  Doubling the pixels per lane halves the number of cross-lane reductions, LDS record reads and
+// per-entry uniform work per pixel; the kernel is bound by VALU issue, and the 10-value reduction is a third
+// of the per-hit cost.  Per batch of 128 list entries the two waves combine their partial sums in LDS
 // (ds_add_f32), then thread k flushes entry k with ONE set of hardware atomics per (tile, Gaussian).
-__global__ __launch_bounds__(GS_BLOCK) void blend_backward_kernel(
+constexpr int BWD_THREADS = 128;
+constexpr int BWD_BATCH = 128;
+
+__global__ __launch_bounds__(BWD_THREADS) void blend_backward_kernel(
     const int32_t *__restrict__ tile_start, const int32_t *__restrict__ tile_end,
     const int32_t *__restrict__ payload, const float4 *__restrict__ attrs, const float *__restrict__ grad_image,
     const float *__restrict__ acc_alpha, const int32_t *__restrict__ last_effective, int width, int height,
     int row_begin, int row_step, float *__restrict__ acc, float *__restrict__ magnitude_image) {
-    __shared__ float4 s_a[GS_BLOCK], s_b[GS_BLOCK], s_c[GS_BLOCK];
-    __shared__ int s_o[GS_BLOCK];
-    __shared__ float s_acc[GS_BLOCK][GS_ACC_STRIDE];  // [entry][value]; slot 10 = pixel count (int bits)
-    __shared__ int s_max[GS_BLOCK / GS_WAVE];
+    __shared__ float4 s_a[BWD_BATCH], s_b[BWD_BATCH], s_c[BWD_BATCH];
+    __shared__ int s_o[BWD_BATCH];
+    __shared__ float s_acc[BWD_BATCH][GS_ACC_STRIDE];  // [entry][value]; slot 10 = pixel count (int bits)
+    __shared__ int s_max[BWD_THREADS / GS_WAVE];
     const int tw = width / GS_TILE_WIDTH;
     const TileCoord tc = owned_tile(tw, row_begin, row_step);
     const int tid = threadIdx.x, lane = tid & 63;
-    const int pu = tc.tile_u * GS_TILE_WIDTH + (tid & 15);
-    const int pv = tc.tile_v * GS_TILE_HEIGHT + (tid >> 4);
+    const int pu = tc.tile_u * GS_TILE_WIDTH + 2 * (tid & 7);  // left pixel of the pair
+    const int pv = tc.tile_v * GS_TILE_HEIGHT + (tid >> 3);
     const size_t p = (size_t)pv * width + pu;
     const int start = tile_start[tc.tile_id];
-    const float px = (float)pu + 0.5f, py = (float)pv + 0.5f;
+    const v2f px = {(float)pu + 0.5f, (float)pu + 1.5f};
+    const float py = (float)pv + 0.5f;
 
-    const int last = last_effective[p];
-    float T = 1.0f - acc_alpha[p];
-    float wr = 0.f, wg = 0.f, wb = 0.f;
-    const float Gr = grad_image[3 * p], Gg = grad_image[3 * p + 1], Gb = grad_image[3 * p + 2];
-    float mag_u = 0.f, mag_v = 0.f;
+    const int last0 = last_effective[p], last1 = last_effective[p + 1];
+    v2f T = {1.0f - acc_alpha[p], 1.0f - acc_alpha[p + 1]};
+    v2f wr = splat(0.f), wg = splat(0.f), wb = splat(0.f);
+    const float *gi = grad_image + 3 * p;
+    const v2f Gr = {gi[0], gi[3]}, Gg = {gi[1], gi[4]}, Gb = {gi[2], gi[5]};
+    v2f mag_u = splat(0.f), mag_v = splat(0.f);
 
     // no pixel of the tile touches an entry at or beyond the tile-wide max of `last`
-    int mx = last;
+    int mx = max(last0, last1);
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) mx = max(mx, __shfl_xor(mx, d, GS_WAVE));
     if (lane == 0) s_max[tid >> 6] = mx;
     __syncthreads();
-    const int end = max(max(s_max[0], s_max[1]), max(s_max[2], s_max[3]));
+    const int end = max(s_max[0], s_max[1]);
 
-    for (int top = end; top > start; top -= GS_BLOCK) {
+    for (int top = end; top > start; top -= BWD_BATCH) {
         __syncthreads();  // previous batch fully flushed before its LDS is reused
         const int j = top - 1 - tid;
         if (j >= start) {
             const int o = payload[j];
-            const float4 *g = attrs + 3 * (size_t)o;
+            const float4 *g = attrs + 4 * (size_t)o;
             s_a[tid] = g[0];
             s_b[tid] = g[1];
             s_c[tid] = g[2];
@@ -176,51 +218,61 @@ __global__ __launch_bounds__(GS_BLOCK) void blend_backward_kernel(
             z[2] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
         __syncthreads();
-        const int n = min(GS_BLOCK, top - start);
+        const int n = min(BWD_BATCH, top - start);
         for (int k = 0; k < n; k += GROUP) {
             // group evaluation: LDS reads + exp of GROUP entries are independent and overlap
-            float g[GROUP], m0[GROUP], m1[GROUP], op[GROUP];
-            bool hit[GROUP];
+            v2f g[GROUP], m0[GROUP], m1[GROUP], pa[GROUP];
+            float op[GROUP];
 #pragma unroll
             for (int i = 0; i < GROUP; ++i) {
                 const float4 a = s_a[k + i], b = s_b[k + i];
-                const float dx = px - a.x, dy = py - a.y;
+                const v2f dx = px - splat(a.x);
+                const float dy = py - a.y;
                 // UTL:331-348: m = conic @ d, exponent = -0.5 d.m
-                m0[i] = fmaf(b.y, dy, b.x * dx);
-                m1[i] = fmaf(b.z, dy, b.y * dx);
-                g[i] = __expf(-0.5f * fmaf(dy, m1[i], dx * m0[i])) * b.w;
+                m0[i] = fma2(dx, splat(b.x), splat(b.y * dy));
+                m1[i] = fma2(dx, splat(b.y), splat(b.z * dy));
+                const v2f e = fma2(dx, m0[i], splat(dy) * m1[i]) * splat(-0.5f * 1.4426950408889634f);
+                g[i] = (v2f){__builtin_amdgcn_exp2f(e.x), __builtin_amdgcn_exp2f(e.y)} * splat(b.w);
                 op[i] = a.w;
-                hit[i] = (top - 1 - (k + i) < last) && (g[i] * a.w >= EPS_ALPHA);
+                pa[i] = g[i] * splat(a.w);
             }
 #pragma unroll
             for (int i = 0; i < GROUP; ++i) {
-                const unsigned long long hits = __ballot(hit[i]);
-                if (hits == 0ull) continue;  // wave-uniform skip: nobody in this wave touches the Gaussian
-                float v0 = 0.f, v1 = 0.f, c00 = 0.f, c01 = 0.f, c11 = 0.f, gr = 0.f, gg = 0.f, gb = 0.f, gl = 0.f,
-                      nv = 0.f;
-                if (hit[i]) {
-                    const float4 c = s_c[k + i];
-                    const float alpha = fminf(g[i] * op[i], CLAMP_ALPHA);
-                    const float inv1m = __builtin_amdgcn_rcpf(1.f - alpha);
-                    T = T * inv1m;  // RAS:643, T_i = T_{i+1} / (1 - alpha_i)
-                    const float aT = alpha * T;
-                    gr = aT * Gr; gg = aT * Gg; gb = aT * Gb;
-                    const float dLda = fmaf(fmaf(c.z, T, -(wb * inv1m)), Gb,
-                                            fmaf(fmaf(c.y, T, -(wg * inv1m)), Gg, fmaf(c.x, T, -(wr * inv1m)) * Gr));
-                    wr = fmaf(c.x, aT, wr); wg = fmaf(c.y, aT, wg); wb = fmaf(c.z, aT, wb);
-                    gl = dLda * g[i] * (1.f - op[i]) * op[i];
-                    const float dLdg = dLda * op[i];
-                    const float gm0 = g[i] * m0[i], gm1 = g[i] * m1[i];
-                    v0 = dLdg * gm0; v1 = dLdg * gm1;
-                    mag_u += fabsf(v0); mag_v += fabsf(v1);
-                    const float h = 0.5f * dLdg;
-                    c00 = h * gm0 * m0[i]; c01 = h * gm0 * m1[i]; c11 = h * gm1 * m1[i];
-                    nv = __builtin_amdgcn_sqrtf(fmaf(v1, v1, v0 * v0));  // v_sqrt_f32, 1 ulp
-                }
-                // reduce-scatter of the 10 partial sums over the 64 lanes (gs_common.h); row totals land in
-                // lane 15 of each row:  t0: rows = (v0, c00, v1, c01)  t1: (c11, gg, gr, gb)  t2: (gl, gl, nv, nv)
+                const int jj = top - 1 - (k + i);
+                const bool hit0 = (jj < last0) && (pa[i].x >= EPS_ALPHA);
+                const bool hit1 = (jj < last1) && (pa[i].y >= EPS_ALPHA);
+                const unsigned long long hits0 = __ballot(hit0), hits1 = __ballot(hit1);
+                if ((hits0 | hits1) == 0ull) continue;  // wave-uniform skip: no pixel of this wave is touched
+                // alpha = 0 for a pixel that is not hit makes its whole update an exact no-op
+                // (1/(1-0) = 1, a*T = 0); only dL/dalpha needs an explicit mask.
+                const v2f h = {hit0 ? 1.f : 0.f, hit1 ? 1.f : 0.f};
+                const v2f alpha = {hit0 ? __builtin_amdgcn_fmed3f(pa[i].x, 0.f, CLAMP_ALPHA) : 0.f,
+                                   hit1 ? __builtin_amdgcn_fmed3f(pa[i].y, 0.f, CLAMP_ALPHA) : 0.f};
+                const v2f one_m = splat(1.f) - alpha;
+                const v2f inv1m = {__builtin_amdgcn_rcpf(one_m.x), __builtin_amdgcn_rcpf(one_m.y)};
+                T = T * inv1m;  // RAS:643, T_i = T_{i+1} / (1 - alpha_i)
+                const v2f aT = alpha * T;
+                const float4 c = s_c[k + i];
+                const v2f gr = aT * Gr, gg = aT * Gg, gb = aT * Gb;
+                v2f dLda = fma2(fma2(splat(c.z), T, -(wb * inv1m)), Gb,
+                                fma2(fma2(splat(c.y), T, -(wg * inv1m)), Gg, fma2(splat(c.x), T, -(wr * inv1m)) * Gr));
+                dLda = dLda * h;
+                wr = fma2(splat(c.x), aT, wr); wg = fma2(splat(c.y), aT, wg); wb = fma2(splat(c.z), aT, wb);
+                const v2f gl = dLda * g[i] * splat((1.f - op[i]) * op[i]);
+                const v2f dLdg = dLda * splat(op[i]);
+                const v2f gm0 = g[i] * m0[i], gm1 = g[i] * m1[i];
+                const v2f v0 = dLdg * gm0, v1 = dLdg * gm1;
+                mag_u = mag_u + (v2f){fabsf(v0.x), fabsf(v0.y)};
+                mag_v = mag_v + (v2f){fabsf(v1.x), fabsf(v1.y)};
+                const v2f hh = splat(0.5f) * dLdg;
+                const v2f c00 = hh * gm0 * m0[i], c01 = hh * gm0 * m1[i], c11 = hh * gm1 * m1[i];
+                const v2f n2 = fma2(v1, v1, v0 * v0);
+                const v2f nv = {__builtin_amdgcn_sqrtf(n2.x), __builtin_amdgcn_sqrtf(n2.y)};  // v_sqrt_f32, 1 ulp
+                // in-lane pair sums, then the 10-value reduce-scatter over the 64 lanes (gs_common.h); row
+                // totals land in lane 15 of each row: t0: (v0, c00, v1, c01)  t1: (c11, gg, gr, gb)  t2: (gl, gl, nv, nv)
                 float t0, t1, t2;
-                gs_wave_reduce10(v0, v1, c00, c01, c11, gr, gg, gb, gl, nv, t0, t1, t2);
+                gs_wave_reduce10(v0.x + v0.y, v1.x + v1.y, c00.x + c00.y, c01.x + c01.y, c11.x + c11.y, gr.x + gr.y,
+                                 gg.x + gg.y, gb.x + gb.y, gl.x + gl.y, nv.x + nv.y, t0, t1, t2);
                 if ((lane & 15) == 15) {
                     const int row = lane >> 4;
                     const int slot = ((row & 1) << 1) | (row >> 1);  // rows (0,1,2,3) -> slots (0,2,1,3)
@@ -228,7 +280,8 @@ __global__ __launch_bounds__(GS_BLOCK) void blend_backward_kernel(
                     atomicAdd(A + slot, t0);
                     atomicAdd(A + 4 + slot, t1);
                     if ((row & 1) == 0) atomicAdd(A + 8 + (row >> 1), t2);
-                    if (row == 3) atomicAdd(reinterpret_cast<int *>(A + 10), (int)__popcll(hits));
+                    if (row == 3)
+                        atomicAdd(reinterpret_cast<int *>(A + 10), (int)(__popcll(hits0) + __popcll(hits1)));
                 }
             }
         }
@@ -244,8 +297,10 @@ __global__ __launch_bounds__(GS_BLOCK) void blend_backward_kernel(
             }
         }
     }
-    magnitude_image[2 * p] = mag_u;
-    magnitude_image[2 * p + 1] = mag_v;
+    magnitude_image[2 * p] = mag_u.x;
+    magnitude_image[2 * p + 1] = mag_v.x;
+    magnitude_image[2 * p + 2] = mag_u.y;
+    magnitude_image[2 * p + 3] = mag_v.y;
 }
 
 }  // namespace
@@ -261,7 +316,7 @@ int gs_blend_forward(const int32_t *tile_start, const int32_t *tile_end, const i
     GS_REQUIRE(tile_row_step >= 1 && tile_row_begin >= 0, "tile row ownership");
     const int tw = width / GS_TILE_WIDTH, rows = owned_row_count(height / GS_TILE_HEIGHT, tile_row_begin, tile_row_step);
     if (rows == 0 || tw == 0) return 0;
-    hipLaunchKernelGGL(blend_forward_kernel, dim3(tw * rows), dim3(GS_BLOCK), 0, (hipStream_t)stream, tile_start,
+    hipLaunchKernelGGL(blend_forward_kernel, dim3(tw * rows), dim3(FWD_THREADS), 0, (hipStream_t)stream, tile_start,
                        tile_end, payload, reinterpret_cast<const float4 *>(attrs), width, height, tile_row_begin,
                        tile_row_step, image, depth, acc_alpha, last_effective, valid_count);
     GS_CHECK_LAUNCH();
@@ -280,7 +335,7 @@ int gs_blend_backward(const int32_t *tile_start, const int32_t *tile_end, const 
         GS_CHECK_HIP(hipMemsetAsync(acc, 0, sizeof(float) * GS_ACC_STRIDE * (size_t)n_visible, s));
     const int tw = width / GS_TILE_WIDTH, rows = owned_row_count(height / GS_TILE_HEIGHT, tile_row_begin, tile_row_step);
     if (rows == 0 || tw == 0) return 0;
-    hipLaunchKernelGGL(blend_backward_kernel, dim3(tw * rows), dim3(GS_BLOCK), 0, s, tile_start, tile_end, payload,
+    hipLaunchKernelGGL(blend_backward_kernel, dim3(tw * rows), dim3(BWD_THREADS), 0, s, tile_start, tile_end, payload,
                        reinterpret_cast<const float4 *>(attrs), grad_image, acc_alpha, last_effective, width, height,
                        tile_row_begin, tile_row_step, acc, magnitude_image);
     GS_CHECK_LAUNCH();

@@ -344,6 +344,11 @@ __global__ __launch_bounds__(GS_BLOCK) void preprocess_kernel(
         out[0] = make_float4(uv[0], uv[1], c[2], 1.f / (1.f + expf(-f[7])));
         out[1] = make_float4(inv * cd, inv * (-cov[1]), inv * ca, rescale);
         out[2] = make_float4(rgb[0], rgb[1], rgb[2], radius);
+        {   // forward-blend form of the same weight: amp * 2^(dx*(A'dx + B'dy) + C'dy^2)
+            const float log2e = 1.4426950408889634f;
+            out[3] = make_float4((-0.5f * log2e) * out[1].x, (-log2e) * out[1].y, (-0.5f * log2e) * out[1].z,
+                                 out[0].w * rescale);
+        }
 
         int t0u, t1u, t0v, t1v, first;
         tile_box(uv[0], uv[1], radius, width / GS_TILE_WIDTH, height / GS_TILE_HEIGHT, t0u, t1u, t0v, t1v);

@@ -17,7 +17,7 @@ from ._lib import call, current_stream, ptr
 
 TILE_WIDTH = 16
 TILE_HEIGHT = 16
-ATTR_STRIDE = 12
+ATTR_STRIDE = 16
 ACC_STRIDE = 12
 FEATURE_DIM = 56
 COUNTER_NUM_VISIBLE = 0

@@ -69,10 +69,12 @@ def test_preprocess(ops, scene, ofwd):
         dev(s.point_cloud), feat, dev(s.point_object_id), dev(s.camera_intrinsics), dev(ofwd["q_cp"]),
         dev(ofwd["t_cp"]), dev(ofwd["ids"]), s.width, s.height, exact_tile_cull=False)
     a, ref = attrs.cpu().numpy(), pack_attrs(ofwd)
+    assert a.shape[1] == 16
     # projection is evaluated in the oracle's operation order with contraction off: bit-exact
     assert np.array_equal(a[:, 0:3], ref[:, 0:3]), "uv / depth must be bit-exact"
     for name, sl, rtol in (("opacity", slice(3, 4), 1e-6), ("conic", slice(4, 7), 2e-5), ("rescale", slice(7, 8), 2e-5),
-                           ("rgb", slice(8, 11), 2e-6), ("radius", slice(11, 12), 1e-5)):
+                           ("rgb", slice(8, 11), 2e-6), ("radius", slice(11, 12), 1e-5),
+                           ("prescaled_conic", slice(12, 15), 2e-5), ("amp", slice(15, 16), 2e-5)):
         frac = close_fraction(a[:, sl], ref[:, sl], rtol=rtol, atol=1e-7)
         report(f"preprocess.{name}", close=frac, max_abs=float(np.abs(a[:, sl] - ref[:, sl]).max()))
         assert frac == 1.0, name
