@@ -153,17 +153,17 @@ def main() -> None:
             _, ids, counters = timed("filter_compact", lambda: hip_ops.filter_compact(
                 s.point_cloud, s.point_invalid_mask, s.point_object_id, s.camera_intrinsics, q_cp, t_cp,
                 s.near_plane, s.far_plane, s.width, s.height))
-            attrs, ntiles, nowned, bsums = timed("preprocess", lambda: hip_ops.preprocess(
+            attrs, ntiles, nowned, bsums, bsums_full = timed("preprocess", lambda: hip_ops.preprocess(
                 s.point_cloud, f, s.point_object_id, s.camera_intrinsics, q_cp, t_cp, ids, s.width, s.height, rb, rs, CULL))
-            k = timed("scan_block_sums", lambda: hip_ops.scan_block_sums(bsums, counters))
-            keys, payload = timed("make_keys", lambda: hip_ops.make_keys(
-                attrs, nowned, bsums, k, s.width, s.height, s.depth_to_sort_key_scale, rb, rs, CULL, kdb))
+            k, n_slots = timed("scan_block_sums", lambda: hip_ops.scan_block_sums(bsums, counters, bsums_full))
+            keys, payload, slot_off = timed("make_keys", lambda: hip_ops.make_keys(
+                attrs, nowned, bsums, k, s.width, s.height, s.depth_to_sort_key_scale, rb, rs, CULL, kdb, ntiles, bsums_full))
             timed("sort_pairs", lambda: hip_ops.sort_pairs(keys, payload, db, tb, kdb))
             start, end = timed("tile_ranges", lambda: hip_ops.tile_ranges(keys, num_tiles, kdb))
             image, depth, acc_alpha, last_eff, count = timed("blend_forward", lambda: hip_ops.blend_forward(
                 start, end, payload, attrs, s.width, s.height, rb, rs))
             acc, mag = timed("blend_backward", lambda: hip_ops.blend_backward(
-                start, end, payload, attrs, grad_image, acc_alpha, last_eff, s.width, s.height, rb, rs))
+                start, end, payload, attrs, grad_image, acc_alpha, last_eff, slot_off, ntiles, n_slots, s.width, s.height, rb, rs))
             timed("point_backward", lambda: hip_ops.point_backward(
                 s.point_cloud, f, s.point_object_id, s.camera_intrinsics, q_cp, t_cp, s.t_pointcloud_camera, ids,
                 acc, 3, cfg.grad_q_factor, cfg.grad_s_factor, cfg.grad_alpha_factor, cfg.grad_color_factor,

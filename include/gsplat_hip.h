@@ -49,6 +49,7 @@ extern "C" {
 /* counters[] slots written by the library (int32, device) */
 #define GS_COUNTER_NUM_VISIBLE 0   /* M */
 #define GS_COUNTER_NUM_KEYS 1      /* K (saturates at INT32_MAX) */
+#define GS_COUNTER_NUM_SLOTS 2     /* sum of num_overlap_tiles = number of (Gaussian, tile) slots */
 #define GS_NUM_COUNTERS 8
 
 const char *gs_last_error(void);
@@ -74,8 +75,9 @@ int gs_read_counters(const int32_t *counters, int32_t *host_counters, int n, voi
 
 /* Per-visible-point projection.  Replaces generate_point_attributes_in_camera_plane
  * (RAS:239-315, incl. the in-place quaternion normalisation RAS:196-205) and
- * generate_num_overlap_tiles (RAS:106-128).  Also emits per-256-point partial sums of the
- * tile counts (block_sums int32[ceil(M/256)]) for the scan.  tile_row_begin/tile_row_step
+ * generate_num_overlap_tiles (RAS:106-128).  Also emits per-256-point partial sums for the two scans:
+ * block_sums (of num_owned_tiles -> key offsets) and block_sums_full (of num_overlap_tiles -> slot
+ * offsets of the backward pass), both int32[ceil(M/256)].  tile_row_begin/tile_row_step
  * restrict the tile box to the tile rows  r = begin + k*step  owned by this GPU (1 GPU: 0,1);
  * num_overlap_tiles (hook output, RAS:1136) is always the full box count of the reference and
  * num_owned_tiles the number of keys this GPU will emit (the one that is scanned).
@@ -87,11 +89,14 @@ int gs_preprocess(const float *xyz, float *features, const int32_t *object_id,
                   const float *t_camera_pointcloud, const int32_t *ids, int n_visible,
                   int width, int height, int tile_row_begin, int tile_row_step,
                   int exact_tile_cull, float *attrs, int32_t *num_overlap_tiles,
-                  int32_t *num_owned_tiles, int32_t *block_sums, void *stream);
+                  int32_t *num_owned_tiles, int32_t *block_sums, int32_t *block_sums_full,
+                  void *stream);
 
-/* Exclusive scan of the per-block sums (in place) and total -> counters[GS_COUNTER_NUM_KEYS].
+/* Exclusive scan of per-block sums (in place) and total -> counters[counter_slot]
+ * (GS_COUNTER_NUM_KEYS for block_sums, GS_COUNTER_NUM_SLOTS for block_sums_full).
  * Replaces torch.cumsum/cat, RAS:913-922. */
-int gs_scan_block_sums(int32_t *block_sums, int n_blocks, int32_t *counters, void *stream);
+int gs_scan_block_sums(int32_t *block_sums, int n_blocks, int32_t *counters, int counter_slot,
+                       void *stream);
 
 /* Sort-key generation.  Replaces generate_point_sort_key_by_num_overlap_tiles (RAS:131-172).
  * payload[k] = offset into the visible list.  Key layout:
@@ -99,11 +104,15 @@ int gs_scan_block_sums(int32_t *block_sums, int n_blocks, int32_t *counters, voi
  *   key_depth_bits  > 0 : uint32 keys[k] = (tile_id << key_depth_bits) | int32(z * depth_scale)
  *                         same order, valid when 0 <= z*depth_scale < 2^key_depth_bits and the tile
  *                         field fits the remaining bits (halves the sort traffic).
- * exact_tile_cull must be the value passed to gs_preprocess. */
+ * exact_tile_cull must be the value passed to gs_preprocess.
+ * Also writes slot_offsets int32[M] = exclusive scan of num_overlap_tiles (block_offsets_full = scanned
+ * block_sums_full): slot_offsets[i] + (t1v-t0v)*(tile_u-t0u) + (tile_v-t0v) is the reference's key index
+ * of the (Gaussian i, tile) pair (RAS:163-166) and addresses its partial-gradient slot in the backward. */
 int gs_make_keys(const float *attrs, const int32_t *num_owned_tiles, const int32_t *block_offsets,
                  int n_visible, int width, int height, int tile_row_begin, int tile_row_step,
                  int exact_tile_cull, int key_depth_bits, float depth_scale, void *keys,
-                 int32_t *payload, void *stream);
+                 int32_t *payload, const int32_t *num_overlap_tiles,
+                 const int32_t *block_offsets_full, int32_t *slot_offsets, void *stream);
 
 /* Stable LSD radix sort of (key, payload) pairs.  Replaces torch.sort + gather (RAS:947-950) with
  * the stable tie rule.  key_depth_bits selects the key layout (see gs_make_keys).  64-bit layout:
@@ -129,12 +138,20 @@ int gs_blend_forward(const int32_t *tile_start, const int32_t *tile_end, const i
                      int32_t *last_effective, int32_t *valid_count, void *stream);
 
 /* Backward per-pixel pass.  Replaces the pixel loop of gaussian_point_rasterisation_backward
- * (RAS:531-705).  acc (float[M][12]) is zeroed by the library, then accumulated. */
+ * (RAS:531-705) WITHOUT its global atomics (RAS:674-696): the partial sums of a (Gaussian, tile) pair
+ * are stored as one 48-B record (layout of `acc`) in partials[slot] and slot_flags[slot] is raised
+ * (slot: see gs_make_keys; n_slots = counters[GS_COUNTER_NUM_SLOTS]; slot_flags is zeroed by the library). */
 int gs_blend_backward(const int32_t *tile_start, const int32_t *tile_end, const int32_t *payload,
                       const float *attrs, const float *grad_image, const float *acc_alpha,
-                      const int32_t *last_effective, int n_visible, int width, int height,
-                      int tile_row_begin, int tile_row_step, float *acc, float *magnitude_image,
-                      void *stream);
+                      const int32_t *last_effective, const int32_t *slot_offsets, int64_t n_slots,
+                      int width, int height, int tile_row_begin, int tile_row_step, float *partials,
+                      uint8_t *slot_flags, float *magnitude_image, void *stream);
+
+/* Per-Gaussian sum of its flagged slots, in slot order (bitwise reproducible), into acc float[M][12].
+ * Replaces the accumulation side of the reference's atomics (RAS:674-696). */
+int gs_reduce_partials(const int32_t *slot_offsets, const int32_t *num_overlap_tiles,
+                       const uint8_t *slot_flags, const float *partials, int n_visible, float *acc,
+                       void *stream);
 
 /* Backward per-point pass + gradient post-processing.  Replaces the per-point loop of
  * gaussian_point_rasterisation_backward (RAS:707-772), the dense zero-initialisation

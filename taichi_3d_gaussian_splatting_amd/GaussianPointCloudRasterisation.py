@@ -115,18 +115,18 @@ class GaussianPointCloudRasterisation(torch.nn.Module):
                     xyz, invalid, obj, intrinsics, q_cp, t_cp, cfg.near_plane, cfg.far_plane, width, height)
                 # RAS:887-911  per-point projection + tile counts
                 cull = outer.exact_tile_cull
-                attrs, num_overlap_tiles, num_owned_tiles, block_sums = hip_ops.preprocess(
+                attrs, num_overlap_tiles, num_owned_tiles, block_sums, block_sums_full = hip_ops.preprocess(
                     xyz, pointcloud_features, obj, intrinsics, q_cp, t_cp, ids, width, height, row_begin, row_step,
                     cull)
                 # RAS:913-922  scan (host sync #2: K)
-                n_keys = hip_ops.scan_block_sums(block_sums, counters)
+                n_keys, n_slots = hip_ops.scan_block_sums(block_sums, counters, block_sums_full)
                 # RAS:927-945  keys
                 num_tiles = (width // TILE_WIDTH) * (height // TILE_HEIGHT)
                 key_depth_bits, depth_bits, tile_bits = hip_ops.key_layout(
                     cfg.near_plane, cfg.far_plane, cfg.depth_to_sort_key_scale, num_tiles)
-                keys, payload = hip_ops.make_keys(attrs, num_owned_tiles, block_sums, n_keys, width, height,
-                                                  cfg.depth_to_sort_key_scale, row_begin, row_step, cull,
-                                                  key_depth_bits)
+                keys, payload, slot_offsets = hip_ops.make_keys(
+                    attrs, num_owned_tiles, block_sums, n_keys, width, height, cfg.depth_to_sort_key_scale,
+                    row_begin, row_step, cull, key_depth_bits, num_overlap_tiles, block_sums_full)
                 # RAS:947-950  sort (stable)
                 hip_ops.sort_pairs(keys, payload, depth_bits, tile_bits, key_depth_bits)
                 # RAS:952-964  tile ranges
@@ -139,7 +139,9 @@ class GaussianPointCloudRasterisation(torch.nn.Module):
                     outer.image_gather([image, depth, count])
 
                 ctx.save_for_backward(xyz, pointcloud_features, payload, ids, tile_start, tile_end, acc_alpha,
-                                      last_eff, num_overlap_tiles, obj, q_cp, t_cp, t_pc, attrs, intrinsics)
+                                      last_eff, num_overlap_tiles, obj, q_cp, t_cp, t_pc, attrs, intrinsics,
+                                      slot_offsets)
+                ctx.n_slots = n_slots
                 ctx.camera_info = camera_info
                 ctx.color_max_sh_band = color_max_sh_band
                 ctx.tile_rows = (row_begin, row_step)
@@ -151,7 +153,7 @@ class GaussianPointCloudRasterisation(torch.nn.Module):
                 grad_pointcloud = grad_pointcloud_features = None
                 if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:  # RAS:1028
                     (xyz, features, payload, ids, tile_start, tile_end, acc_alpha, last_eff, num_overlap_tiles,
-                     obj, q_cp, t_cp, t_pc, attrs, intrinsics) = ctx.saved_tensors
+                     obj, q_cp, t_cp, t_pc, attrs, intrinsics, slot_offsets) = ctx.saved_tensors
                     cfg = outer.config
                     camera_info = ctx.camera_info
                     width, height = camera_info.camera_width, camera_info.camera_height
@@ -159,8 +161,8 @@ class GaussianPointCloudRasterisation(torch.nn.Module):
                     hook = backward_valid_point_hook
                     # RAS:531-705  per-pixel pass
                     acc, magnitude_image = hip_ops.blend_backward(
-                        tile_start, tile_end, payload, attrs, grad_rasterized_image, acc_alpha, last_eff, width,
-                        height, row_begin, row_step)
+                        tile_start, tile_end, payload, attrs, grad_rasterized_image, acc_alpha, last_eff,
+                        slot_offsets, num_overlap_tiles, ctx.n_slots, width, height, row_begin, row_step)
                     if outer.grad_accumulator_reduce is not None:  # multi-GPU: sum partial tile gradients
                         outer.grad_accumulator_reduce(acc)
                     # RAS:707-772 + 1102-1125  per-point pass, band clearing and factors fused

@@ -167,7 +167,8 @@ __global__ __launch_bounds__(BWD_THREADS) void blend_backward_kernel(
     const int32_t *__restrict__ tile_start, const int32_t *__restrict__ tile_end,
     const int32_t *__restrict__ payload, const float4 *__restrict__ attrs, const float *__restrict__ grad_image,
     const float *__restrict__ acc_alpha, const int32_t *__restrict__ last_effective, int width, int height,
-    int row_begin, int row_step, float *__restrict__ acc, float *__restrict__ magnitude_image) {
+    int row_begin, int row_step, const int32_t *__restrict__ slot_offsets, float4 *__restrict__ partials,
+    uint8_t *__restrict__ slot_flags, float *__restrict__ magnitude_image) {
     __shared__ float4 s_a[BWD_BATCH], s_b[BWD_BATCH], s_c[BWD_BATCH];
     __shared__ int s_o[BWD_BATCH];
     __shared__ float s_acc[BWD_BATCH][GS_ACC_STRIDE];  // [entry][value]; slot 10 = pixel count (int bits)
@@ -286,14 +287,20 @@ __global__ __launch_bounds__(BWD_THREADS) void blend_backward_kernel(
             }
         }
         __syncthreads();
-        // flush: thread k owns entry k of the batch -> one global atomic set per (tile, Gaussian)
+        // flush: thread k owns entry k of the batch -> one 48-B store into the (Gaussian, tile) slot
         if (tid < n) {
             const int npix = __builtin_bit_cast(int, s_acc[tid][10]);
             if (npix > 0) {
-                float *A = acc + (size_t)GS_ACC_STRIDE * s_o[tid];
-#pragma unroll
-                for (int v = 0; v < 10; ++v) atomicAdd(A + v, s_acc[tid][v]);
-                atomicAdd(reinterpret_cast<int *>(A + 10), npix);
+                const float4 a = s_a[tid];
+                int t0u, t1u, t0v, t1v;
+                gs_tile_box(a.x, a.y, s_c[tid].w, tw, height / GS_TILE_HEIGHT, t0u, t1u, t0v, t1v);
+                const int slot = slot_offsets[s_o[tid]] + (t1v - t0v) * (tc.tile_u - t0u) + (tc.tile_v - t0v);
+                const float4 *S = reinterpret_cast<const float4 *>(&s_acc[tid][0]);
+                float4 *dst = partials + 3 * (size_t)slot;
+                dst[0] = S[0];
+                dst[1] = S[1];
+                dst[2] = S[2];
+                slot_flags[slot] = 1;
             }
         }
     }
@@ -301,6 +308,31 @@ __global__ __launch_bounds__(BWD_THREADS) void blend_backward_kernel(
     magnitude_image[2 * p + 1] = mag_v.x;
     magnitude_image[2 * p + 2] = mag_u.y;
     magnitude_image[2 * p + 3] = mag_v.y;
+}
+
+// Sums the flagged (Gaussian, tile) slots of every visible Gaussian, in slot order (deterministic), into the
+// accumulator record acc[i] that gs_point_backward consumes.  Slot 10 (pixel count) is summed as an integer.
+__global__ __launch_bounds__(GS_BLOCK) void reduce_partials_kernel(
+    const int32_t *__restrict__ slot_offsets, const int32_t *__restrict__ ntiles_full,
+    const uint8_t *__restrict__ slot_flags, const float4 *__restrict__ partials, int m, float4 *__restrict__ acc) {
+    const int i = blockIdx.x * GS_BLOCK + threadIdx.x;
+    if (i >= m) return;
+    const int base = slot_offsets[i], n = ntiles_full[i];
+    float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0;
+    float gl = 0.f, nv = 0.f;
+    int npix = 0;
+    for (int r = 0; r < n; ++r) {
+        if (slot_flags[base + r] == 0) continue;
+        const float4 *src = partials + 3 * (size_t)(base + r);
+        const float4 p0 = src[0], p1 = src[1], p2 = src[2];
+        a0.x += p0.x; a0.y += p0.y; a0.z += p0.z; a0.w += p0.w;
+        a1.x += p1.x; a1.y += p1.y; a1.z += p1.z; a1.w += p1.w;
+        gl += p2.x; nv += p2.y;
+        npix += __builtin_bit_cast(int, p2.z);
+    }
+    acc[3 * (size_t)i] = a0;
+    acc[3 * (size_t)i + 1] = a1;
+    acc[3 * (size_t)i + 2] = make_float4(gl, nv, __builtin_bit_cast(float, npix), 0.f);
 }
 
 }  // namespace
@@ -324,20 +356,32 @@ int gs_blend_forward(const int32_t *tile_start, const int32_t *tile_end, const i
 }
 
 int gs_blend_backward(const int32_t *tile_start, const int32_t *tile_end, const int32_t *payload, const float *attrs,
-                      const float *grad_image, const float *acc_alpha, const int32_t *last_effective, int n_visible,
-                      int width, int height, int tile_row_begin, int tile_row_step, float *acc, float *magnitude_image,
+                      const float *grad_image, const float *acc_alpha, const int32_t *last_effective,
+                      const int32_t *slot_offsets, int64_t n_slots, int width, int height, int tile_row_begin,
+                      int tile_row_step, float *partials, uint8_t *slot_flags, float *magnitude_image,
                       void *stream) {
     GS_REQUIRE(width % GS_TILE_WIDTH == 0 && height % GS_TILE_HEIGHT == 0, "image size must be a multiple of 16");
     GS_REQUIRE(tile_row_step >= 1 && tile_row_begin >= 0, "tile row ownership");
-    GS_REQUIRE(n_visible >= 0, "n_visible");
+    GS_REQUIRE(n_slots >= 0, "n_slots");
     hipStream_t s = (hipStream_t)stream;
-    if (n_visible > 0)
-        GS_CHECK_HIP(hipMemsetAsync(acc, 0, sizeof(float) * GS_ACC_STRIDE * (size_t)n_visible, s));
+    if (n_slots > 0) GS_CHECK_HIP(hipMemsetAsync(slot_flags, 0, (size_t)n_slots, s));
     const int tw = width / GS_TILE_WIDTH, rows = owned_row_count(height / GS_TILE_HEIGHT, tile_row_begin, tile_row_step);
     if (rows == 0 || tw == 0) return 0;
     hipLaunchKernelGGL(blend_backward_kernel, dim3(tw * rows), dim3(BWD_THREADS), 0, s, tile_start, tile_end, payload,
                        reinterpret_cast<const float4 *>(attrs), grad_image, acc_alpha, last_effective, width, height,
-                       tile_row_begin, tile_row_step, acc, magnitude_image);
+                       tile_row_begin, tile_row_step, slot_offsets, reinterpret_cast<float4 *>(partials), slot_flags,
+                       magnitude_image);
+    GS_CHECK_LAUNCH();
+    return 0;
+}
+
+int gs_reduce_partials(const int32_t *slot_offsets, const int32_t *num_overlap_tiles, const uint8_t *slot_flags,
+                       const float *partials, int n_visible, float *acc, void *stream) {
+    GS_REQUIRE(n_visible >= 0, "n_visible");
+    if (n_visible == 0) return 0;
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(gs_div_up(n_visible, GS_BLOCK)), dim3(GS_BLOCK), 0,
+                       (hipStream_t)stream, slot_offsets, num_overlap_tiles, slot_flags,
+                       reinterpret_cast<const float4 *>(partials), n_visible, reinterpret_cast<float4 *>(acc));
     GS_CHECK_LAUNCH();
     return 0;
 }

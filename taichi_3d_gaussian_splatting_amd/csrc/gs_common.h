@@ -44,6 +44,19 @@ static inline int gs_div_up(long long a, long long b) { return (int)((a + b - 1)
 // ------------------------------------------------------------------ wave / block primitives
 #ifdef __HIPCC__
 
+// RAS:81-103 get_bounding_box_by_point_and_radii (shared by the front end and the backward flush, which
+// must agree bit-for-bit on the box: it defines the slot of a (Gaussian, tile) pair, RAS:163-166)
+__device__ __forceinline__ void gs_tile_box(float u, float v, float r, int tw, int th, int &t0u, int &t1u,
+                                            int &t0v, int &t1v) {
+    r = fmaxf(r, 1.0f);
+    float min_u = fmaxf(0.0f, u - r), max_u = u + r;
+    float min_v = fmaxf(0.0f, v - r), max_v = v + r;
+    t0u = min((int)floorf(min_u / (float)GS_TILE_WIDTH), tw);
+    t1u = min(max((int)floorf(max_u / (float)GS_TILE_WIDTH) + 1, t0u + 1), tw);
+    t0v = min((int)floorf(min_v / (float)GS_TILE_HEIGHT), th);
+    t1v = min(max((int)floorf(max_v / (float)GS_TILE_HEIGHT) + 1, t0v + 1), th);
+}
+
 __device__ __forceinline__ int gs_lane() { return threadIdx.x & (GS_WAVE - 1); }
 
 // number of set bits of `mask` strictly below the calling lane

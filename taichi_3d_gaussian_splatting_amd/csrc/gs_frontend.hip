@@ -76,16 +76,9 @@ __device__ __forceinline__ void sh_basis(const float d[3], float Y[16]) {
 
 __device__ __forceinline__ float sigmoidf(float x) { return 1.f / (1.f + expf(-x)); }
 
-// RAS:81-103 get_bounding_box_by_point_and_radii
 __device__ __forceinline__ void tile_box(float u, float v, float r, int tw, int th, int &t0u, int &t1u,
                                          int &t0v, int &t1v) {
-    r = fmaxf(r, 1.0f);
-    float min_u = fmaxf(0.0f, u - r), max_u = u + r;
-    float min_v = fmaxf(0.0f, v - r), max_v = v + r;
-    t0u = min((int)floorf(min_u / (float)GS_TILE_WIDTH), tw);
-    t1u = min(max((int)floorf(max_u / (float)GS_TILE_WIDTH) + 1, t0u + 1), tw);
-    t0v = min((int)floorf(min_v / (float)GS_TILE_HEIGHT), th);
-    t1v = min(max((int)floorf(max_v / (float)GS_TILE_HEIGHT) + 1, t0v + 1), th);
+    gs_tile_box(u, v, r, tw, th, t0u, t1u, t0v, t1v);
 }
 
 // number of tile rows r in [t0v, t1v) with r = begin + k*step, k >= 0; first such row in *first
@@ -256,12 +249,12 @@ __global__ __launch_bounds__(GS_BLOCK) void preprocess_kernel(
     const float *__restrict__ Kmat, const float *__restrict__ q_cp, const float *__restrict__ t_cp,
     const int32_t *__restrict__ ids, int m, int width, int height, int row_begin, int row_step, int cull,
     float *__restrict__ attrs, int32_t *__restrict__ ntiles_full, int32_t *__restrict__ ntiles_owned,
-    int32_t *__restrict__ block_sums) {
-    __shared__ int s_sum;
-    if (threadIdx.x == 0) s_sum = 0;
+    int32_t *__restrict__ block_sums, int32_t *__restrict__ block_sums_full) {
+    __shared__ int s_sum, s_sum_full;
+    if (threadIdx.x == 0) { s_sum = 0; s_sum_full = 0; }
     __syncthreads();
     const int i = blockIdx.x * GS_BLOCK + threadIdx.x;
-    int owned = 0;
+    int owned = 0, full = 0;
     if (i < m) {
         const int id = ids[i];
         float4 *row4 = reinterpret_cast<float4 *>(feat + (size_t)GS_FEATURE_DIM * id);
@@ -352,7 +345,8 @@ __global__ __launch_bounds__(GS_BLOCK) void preprocess_kernel(
 
         int t0u, t1u, t0v, t1v, first;
         tile_box(uv[0], uv[1], radius, width / GS_TILE_WIDTH, height / GS_TILE_HEIGHT, t0u, t1u, t0v, t1v);
-        ntiles_full[i] = (t1u - t0u) * (t1v - t0v);
+        full = (t1u - t0u) * (t1v - t0v);
+        ntiles_full[i] = full;
         owned = (t1u - t0u) * owned_rows(t0v, t1v, row_begin, row_step, &first);
         if (cull && owned > 0) {
             const float qmax = cull_qmax(1.f / (1.f + expf(-f[7])), rescale);
@@ -364,13 +358,22 @@ __global__ __launch_bounds__(GS_BLOCK) void preprocess_kernel(
         }
         ntiles_owned[i] = owned;
     }
-    // per-block partial sum for the scan (wave reduce, then one LDS atomic per wave)
-    int s = owned;
+    // per-block partial sums for the two scans (wave reduce, then one LDS atomic per wave)
+    int s = owned, sf = full;
 #pragma unroll
-    for (int d = 32; d > 0; d >>= 1) s += __shfl_xor(s, d, GS_WAVE);
-    if (gs_lane() == 0 && s != 0) atomicAdd(&s_sum, s);
+    for (int d = 32; d > 0; d >>= 1) {
+        s += __shfl_xor(s, d, GS_WAVE);
+        sf += __shfl_xor(sf, d, GS_WAVE);
+    }
+    if (gs_lane() == 0) {
+        if (s != 0) atomicAdd(&s_sum, s);
+        if (sf != 0) atomicAdd(&s_sum_full, sf);
+    }
     __syncthreads();
-    if (threadIdx.x == 0) block_sums[blockIdx.x] = s_sum;
+    if (threadIdx.x == 0) {
+        block_sums[blockIdx.x] = s_sum;
+        block_sums_full[blockIdx.x] = s_sum_full;
+    }
 }
 
 // ------------------------------------------------------------------ key generation
@@ -382,12 +385,19 @@ template <typename KeyT>
 __global__ __launch_bounds__(GS_BLOCK) void make_keys_kernel(
     const float *__restrict__ attrs, const int32_t *__restrict__ ntiles_owned,
     const int32_t *__restrict__ block_offsets, int m, int width, int height, int row_begin, int row_step,
-    int cull, int key_depth_bits, float depth_scale, KeyT *__restrict__ keys, int32_t *__restrict__ payload) {
+    int cull, int key_depth_bits, float depth_scale, KeyT *__restrict__ keys, int32_t *__restrict__ payload,
+    const int32_t *__restrict__ ntiles_full, const int32_t *__restrict__ block_offsets_full,
+    int32_t *__restrict__ slot_offsets) {
     __shared__ int lds[4];
     const int i = blockIdx.x * GS_BLOCK + threadIdx.x;
     int cnt = i < m ? ntiles_owned[i] : 0;
     int total;
     int offset = block_offsets[blockIdx.x] + gs_block_excl_scan(cnt, &total, lds);
+    {   // exclusive scan of the reference's box counts = slot base of every Gaussian (RAS:913-922)
+        const int full = i < m ? ntiles_full[i] : 0;
+        const int so = block_offsets_full[blockIdx.x] + gs_block_excl_scan(full, &total, lds);
+        if (i < m) slot_offsets[i] = so;
+    }
     if (i >= m || cnt == 0) return;
     const float4 a0 = reinterpret_cast<const float4 *>(attrs + (size_t)GS_ATTR_STRIDE * i)[0];
     const float4 a1 = reinterpret_cast<const float4 *>(attrs + (size_t)GS_ATTR_STRIDE * i)[1];
@@ -487,7 +497,8 @@ int gs_read_counters(const int32_t *counters, int32_t *host_counters, int n, voi
 int gs_preprocess(const float *xyz, float *features, const int32_t *object_id, const float *intrinsics,
                   const float *q_cp, const float *t_cp, const int32_t *ids, int n_visible, int width, int height,
                   int tile_row_begin, int tile_row_step, int exact_tile_cull, float *attrs,
-                  int32_t *num_overlap_tiles, int32_t *num_owned_tiles, int32_t *block_sums, void *stream) {
+                  int32_t *num_overlap_tiles, int32_t *num_owned_tiles, int32_t *block_sums,
+                  int32_t *block_sums_full, void *stream) {
     GS_REQUIRE(n_visible >= 0, "n_visible");
     GS_REQUIRE(tile_row_step >= 1 && tile_row_begin >= 0, "tile row ownership");
     GS_REQUIRE(width % GS_TILE_WIDTH == 0 && height % GS_TILE_HEIGHT == 0, "image size must be a multiple of 16");
@@ -495,26 +506,29 @@ int gs_preprocess(const float *xyz, float *features, const int32_t *object_id, c
     hipLaunchKernelGGL(preprocess_kernel, dim3(gs_div_up(n_visible, GS_BLOCK)), dim3(GS_BLOCK), 0,
                        (hipStream_t)stream, xyz, features, object_id, intrinsics, q_cp, t_cp, ids, n_visible, width,
                        height, tile_row_begin, tile_row_step, exact_tile_cull, attrs, num_overlap_tiles, num_owned_tiles,
-                       block_sums);
+                       block_sums, block_sums_full);
     GS_CHECK_LAUNCH();
     return 0;
 }
 
-int gs_scan_block_sums(int32_t *block_sums, int n_blocks, int32_t *counters, void *stream) {
+int gs_scan_block_sums(int32_t *block_sums, int n_blocks, int32_t *counters, int counter_slot, void *stream) {
     GS_REQUIRE(n_blocks >= 0, "n_blocks");
+    GS_REQUIRE(counter_slot >= 0 && counter_slot < GS_NUM_COUNTERS, "counter_slot");
     if (n_blocks == 0) {
-        GS_CHECK_HIP(hipMemsetAsync(counters + GS_COUNTER_NUM_KEYS, 0, sizeof(int32_t), (hipStream_t)stream));
+        GS_CHECK_HIP(hipMemsetAsync(counters + counter_slot, 0, sizeof(int32_t), (hipStream_t)stream));
         return 0;
     }
     hipLaunchKernelGGL(scan_single_block_kernel, dim3(1), dim3(GS_BLOCK), 0, (hipStream_t)stream, block_sums,
-                       n_blocks, counters + GS_COUNTER_NUM_KEYS);
+                       n_blocks, counters + counter_slot);
     GS_CHECK_LAUNCH();
     return 0;
 }
 
 int gs_make_keys(const float *attrs, const int32_t *num_owned_tiles, const int32_t *block_offsets, int n_visible,
                  int width, int height, int tile_row_begin, int tile_row_step, int exact_tile_cull,
-                 int key_depth_bits, float depth_scale, void *keys, int32_t *payload, void *stream) {
+                 int key_depth_bits, float depth_scale, void *keys, int32_t *payload,
+                 const int32_t *num_overlap_tiles, const int32_t *block_offsets_full, int32_t *slot_offsets,
+                 void *stream) {
     GS_REQUIRE(n_visible >= 0, "n_visible");
     GS_REQUIRE(tile_row_step >= 1 && tile_row_begin >= 0, "tile row ownership");
     GS_REQUIRE(key_depth_bits >= 0 && key_depth_bits < 32, "key_depth_bits");
@@ -523,11 +537,13 @@ int gs_make_keys(const float *attrs, const int32_t *num_owned_tiles, const int32
     if (key_depth_bits == 0)
         hipLaunchKernelGGL(make_keys_kernel<uint64_t>, grid, block, 0, (hipStream_t)stream, attrs, num_owned_tiles,
                            block_offsets, n_visible, width, height, tile_row_begin, tile_row_step, exact_tile_cull,
-                           0, depth_scale, (uint64_t *)keys, payload);
+                           0, depth_scale, (uint64_t *)keys, payload, num_overlap_tiles, block_offsets_full,
+                           slot_offsets);
     else
         hipLaunchKernelGGL(make_keys_kernel<uint32_t>, grid, block, 0, (hipStream_t)stream, attrs, num_owned_tiles,
                            block_offsets, n_visible, width, height, tile_row_begin, tile_row_step, exact_tile_cull,
-                           key_depth_bits, depth_scale, (uint32_t *)keys, payload);
+                           key_depth_bits, depth_scale, (uint32_t *)keys, payload, num_overlap_tiles,
+                           block_offsets_full, slot_offsets);
     GS_CHECK_LAUNCH();
     return 0;
 }

@@ -22,6 +22,7 @@ ACC_STRIDE = 12
 FEATURE_DIM = 56
 COUNTER_NUM_VISIBLE = 0
 COUNTER_NUM_KEYS = 1
+COUNTER_NUM_SLOTS = 2
 NUM_COUNTERS = 8
 _PRE_BLOCK = 256  # points per workgroup of gs_preprocess / gs_make_keys
 
@@ -76,42 +77,59 @@ def filter_compact(xyz, invalid_mask, object_id, intrinsics, q_cp, t_cp, near_pl
 
 def preprocess(xyz, features, object_id, intrinsics, q_cp, t_cp, ids, width, height, tile_row_begin=0,
                tile_row_step=1, exact_tile_cull=True):
-    """-> (attrs f32[M,12], num_overlap_tiles i32[M], num_owned_tiles i32[M], block_sums i32[ceil(M/256)]).
+    """-> (attrs f32[M,16], num_overlap_tiles i32[M], num_owned_tiles i32[M], block_sums, block_sums_full).
     Normalises features[ids, 0:4] IN PLACE (RAS:196-205).  num_overlap_tiles is the reference's box count
-    (hook output); num_owned_tiles is the number of keys emitted (after ownership and the exact tile cull)."""
+    (hook output; its scan gives the backward slots); num_owned_tiles is the number of keys emitted (after
+    ownership and the exact tile cull); the two block_sums are int32[ceil(M/256)] partial sums of them."""
     m = ids.shape[0]
     dev = xyz.device
     attrs = torch.empty((m, ATTR_STRIDE), dtype=torch.float32, device=dev)
     ntiles = torch.empty(m, dtype=torch.int32, device=dev)
     nowned = torch.empty(m, dtype=torch.int32, device=dev)
     block_sums = torch.empty((m + _PRE_BLOCK - 1) // _PRE_BLOCK, dtype=torch.int32, device=dev)
+    block_sums_full = torch.empty_like(block_sums)
     call("gs_preprocess", ptr(xyz), ptr(features), ptr(object_id), ptr(intrinsics), ptr(q_cp), ptr(t_cp), ptr(ids),
          m, int(width), int(height), int(tile_row_begin), int(tile_row_step), int(bool(exact_tile_cull)), ptr(attrs),
-         ptr(ntiles), ptr(nowned), ptr(block_sums), current_stream(dev))
-    return attrs, ntiles, nowned, block_sums
+         ptr(ntiles), ptr(nowned), ptr(block_sums), ptr(block_sums_full), current_stream(dev))
+    return attrs, ntiles, nowned, block_sums, block_sums_full
 
 
-def scan_block_sums(block_sums: torch.Tensor, counters: torch.Tensor) -> int:
-    """In-place exclusive scan; returns K.  Blocks on the size read-back (RAS:916)."""
-    call("gs_scan_block_sums", ptr(block_sums), block_sums.shape[0], ptr(counters), current_stream(counters.device))
-    k = read_counters(counters)[COUNTER_NUM_KEYS]
-    if k >= 0x7fffffff:
+def scan_block_sums(block_sums: torch.Tensor, counters: torch.Tensor,
+                    block_sums_full: Optional[torch.Tensor] = None):
+    """In-place exclusive scans; returns K (and the number of backward slots when block_sums_full is given).
+    Blocks on ONE size read-back (RAS:916)."""
+    stream = current_stream(counters.device)
+    call("gs_scan_block_sums", ptr(block_sums), block_sums.shape[0], ptr(counters), COUNTER_NUM_KEYS, stream)
+    if block_sums_full is not None:
+        call("gs_scan_block_sums", ptr(block_sums_full), block_sums_full.shape[0], ptr(counters),
+             COUNTER_NUM_SLOTS, stream)
+    host = read_counters(counters)
+    k, n_slots = host[COUNTER_NUM_KEYS], host[COUNTER_NUM_SLOTS]
+    if k >= 0x7fffffff or n_slots >= 0x7fffffff:
         raise RuntimeError("more than 2^31-1 (tile, Gaussian) pairs: key offsets are int32 as in the reference")
-    return k
+    return k if block_sums_full is None else (k, n_slots)
 
 
 def make_keys(attrs, num_owned_tiles, block_offsets, n_keys, width, height, depth_to_sort_key_scale,
-              tile_row_begin=0, tile_row_step=1, exact_tile_cull=True, key_depth_bits=0):
-    """key_depth_bits == 0: int64 keys in the reference layout (tile << 32) + depth;
-    key_depth_bits > 0: 32-bit keys (tile << key_depth_bits) | depth, stored in an int32 tensor."""
+              tile_row_begin=0, tile_row_step=1, exact_tile_cull=True, key_depth_bits=0,
+              num_overlap_tiles=None, block_offsets_full=None):
+    """-> (keys, payload, slot_offsets).  key_depth_bits == 0: int64 keys in the reference layout
+    (tile << 32) + depth; key_depth_bits > 0: 32-bit keys (tile << key_depth_bits) | depth, stored in an int32
+    tensor.  slot_offsets i32[M] = exclusive scan of num_overlap_tiles (base of every Gaussian's backward
+    slots); computed from num_overlap_tiles + its scanned block sums when given, else from the owned counts."""
     dev = attrs.device
+    m = attrs.shape[0]
     keys = torch.empty(n_keys, dtype=torch.int64 if key_depth_bits == 0 else torch.int32, device=dev)
     payload = torch.empty(n_keys, dtype=torch.int32, device=dev)
-    if n_keys > 0:
-        call("gs_make_keys", ptr(attrs), ptr(num_owned_tiles), ptr(block_offsets), attrs.shape[0], int(width),
+    slot_offsets = torch.empty(m, dtype=torch.int32, device=dev)
+    if num_overlap_tiles is None:
+        num_overlap_tiles, block_offsets_full = num_owned_tiles, block_offsets
+    if m > 0:
+        call("gs_make_keys", ptr(attrs), ptr(num_owned_tiles), ptr(block_offsets), m, int(width),
              int(height), int(tile_row_begin), int(tile_row_step), int(bool(exact_tile_cull)), int(key_depth_bits),
-             float(depth_to_sort_key_scale), ptr(keys), ptr(payload), current_stream(dev))
-    return keys, payload
+             float(depth_to_sort_key_scale), ptr(keys), ptr(payload), ptr(num_overlap_tiles),
+             ptr(block_offsets_full), ptr(slot_offsets), current_stream(dev))
+    return keys, payload, slot_offsets
 
 
 def sort_key_bits(near_plane: float, far_plane: float, depth_to_sort_key_scale: float, num_tiles: int):
@@ -175,18 +193,25 @@ def blend_forward(tile_start, tile_end, payload, attrs, width, height, tile_row_
     return out
 
 
-def blend_backward(tile_start, tile_end, payload, attrs, grad_image, acc_alpha, last_eff, width, height,
-                   tile_row_begin=0, tile_row_step=1):
-    """-> (acc f32[M,12], magnitude_grad_viewspace_on_image f32[H,W,2])."""
+def blend_backward(tile_start, tile_end, payload, attrs, grad_image, acc_alpha, last_eff, slot_offsets,
+                   num_overlap_tiles, n_slots, width, height, tile_row_begin=0, tile_row_step=1):
+    """-> (acc f32[M,12], magnitude_grad_viewspace_on_image f32[H,W,2]).
+    Two launches: the per-pixel pass stores one partial record per (Gaussian, tile) slot (no atomics), then the
+    per-Gaussian slot reduction produces acc."""
     dev = attrs.device
     m = attrs.shape[0]
     grad_image = _f32(grad_image, "grad_rasterized_image")
+    partials = torch.empty((max(int(n_slots), 1), ACC_STRIDE), dtype=torch.float32, device=dev)
+    flags = torch.empty(max(int(n_slots), 1), dtype=torch.uint8, device=dev)
     acc = torch.empty((m, ACC_STRIDE), dtype=torch.float32, device=dev)
     alloc = torch.empty if tile_row_step == 1 else torch.zeros
     mag = alloc((height, width, 2), dtype=torch.float32, device=dev)
+    stream = current_stream(dev)
     call("gs_blend_backward", ptr(tile_start), ptr(tile_end), ptr(payload), ptr(attrs), ptr(grad_image),
-         ptr(acc_alpha), ptr(last_eff), m, int(width), int(height), int(tile_row_begin), int(tile_row_step),
-         ptr(acc), ptr(mag), current_stream(dev))
+         ptr(acc_alpha), ptr(last_eff), ptr(slot_offsets), int(n_slots), int(width), int(height),
+         int(tile_row_begin), int(tile_row_step), ptr(partials), ptr(flags), ptr(mag), stream)
+    call("gs_reduce_partials", ptr(slot_offsets), ptr(num_overlap_tiles), ptr(flags), ptr(partials), m, ptr(acc),
+         stream)
     return acc, mag
 
 

@@ -65,7 +65,7 @@ def test_filter_compact_bit_exact(ops, scene, ofwd):
 def test_preprocess(ops, scene, ofwd):
     s = scene
     feat = dev(s.point_cloud_features).clone()
-    attrs, ntiles, nowned, block_sums = ops.preprocess(
+    attrs, ntiles, nowned, block_sums, block_sums_full = ops.preprocess(
         dev(s.point_cloud), feat, dev(s.point_object_id), dev(s.camera_intrinsics), dev(ofwd["q_cp"]),
         dev(ofwd["t_cp"]), dev(ofwd["ids"]), s.width, s.height, exact_tile_cull=False)
     a, ref = attrs.cpu().numpy(), pack_attrs(ofwd)
@@ -90,6 +90,7 @@ def test_preprocess(ops, scene, ofwd):
     assert np.array_equal(nowned.cpu().numpy(), ntiles.cpu().numpy())  # 1 GPU owns every row
     sums = np.add.reduceat(ntiles.cpu().numpy(), np.arange(0, len(ofwd["ids"]), 256))
     assert np.array_equal(block_sums.cpu().numpy(), sums)
+    assert np.array_equal(block_sums_full.cpu().numpy(), sums)
 
 
 def test_keys_sort_ranges_bit_exact(ops, scene, ofwd):
@@ -101,8 +102,9 @@ def test_keys_sort_ranges_bit_exact(ops, scene, ofwd):
     counters = torch.zeros(ops.NUM_COUNTERS, dtype=torch.int32, device="cuda")
     k = ops.scan_block_sums(block_sums, counters)
     assert k == ofwd["keys"].shape[0]
-    keys, payload = ops.make_keys(attrs, nt, block_sums, k, s.width, s.height, s.depth_to_sort_key_scale,
-                                  exact_tile_cull=False, key_depth_bits=0)
+    keys, payload, slot_offsets = ops.make_keys(attrs, nt, block_sums, k, s.width, s.height,
+                                                s.depth_to_sort_key_scale, exact_tile_cull=False, key_depth_bits=0)
+    assert np.array_equal(slot_offsets.cpu().numpy(), ofwd["offsets"].astype(np.int32))  # RAS:913-922
     # unsorted keys: same generation order as RAS:161-172
     uk = np.empty(k, np.int64); up = np.empty(k, np.int32)
     import ctypes
@@ -123,8 +125,8 @@ def test_keys_sort_ranges_bit_exact(ops, scene, ofwd):
     # compressed 32-bit key layout: same order, same payload permutation, same tile ranges
     kdb, db2, tb2 = ops.key_layout(s.near_plane, s.far_plane, s.depth_to_sort_key_scale, num_tiles)
     assert kdb == db and (db2, tb2) == (db, tb)
-    keys32, payload32 = ops.make_keys(attrs, nt, block_sums, k, s.width, s.height, s.depth_to_sort_key_scale,
-                                      exact_tile_cull=False, key_depth_bits=kdb)
+    keys32, payload32, _ = ops.make_keys(attrs, nt, block_sums, k, s.width, s.height, s.depth_to_sort_key_scale,
+                                         exact_tile_cull=False, key_depth_bits=kdb)
     expect32 = (((uk >> 32) << kdb) | (uk & 0xffffffff)).astype(np.uint32)
     assert np.array_equal(keys32.cpu().numpy().view(np.uint32), expect32)
     ops.sort_pairs(keys32, payload32, db, tb, kdb)
@@ -143,13 +145,13 @@ def test_exact_tile_cull_is_output_identical(ops, scene, ofwd):
     outs = {}
     for cull in (False, True):
         feat = dev(s.point_cloud_features).clone()  # fresh copy: preprocess normalises q in place
-        a, nfull, nowned, bsums = ops.preprocess(
+        a, nfull, nowned, bsums, bsums_full = ops.preprocess(
             dev(s.point_cloud), feat, dev(s.point_object_id), dev(s.camera_intrinsics), dev(ofwd["q_cp"]),
             dev(ofwd["t_cp"]), dev(ofwd["ids"]), s.width, s.height, exact_tile_cull=cull)
         counters = torch.zeros(ops.NUM_COUNTERS, dtype=torch.int32, device="cuda")
         k = ops.scan_block_sums(bsums, counters)
-        keys, payload = ops.make_keys(a, nowned, bsums, k, s.width, s.height, s.depth_to_sort_key_scale,
-                                      exact_tile_cull=cull, key_depth_bits=0)
+        keys, payload, _ = ops.make_keys(a, nowned, bsums, k, s.width, s.height, s.depth_to_sort_key_scale,
+                                         exact_tile_cull=cull, key_depth_bits=0)
         assert np.array_equal(nfull.cpu().numpy(), ofwd["num_overlap_tiles"])  # hook output is the box count
         num_tiles = (s.width // 16) * (s.height // 16)
         db, tb = ops.sort_key_bits(s.near_plane, s.far_plane, s.depth_to_sort_key_scale, num_tiles)
@@ -258,9 +260,15 @@ def _check_acc(name, hip, ref, frac_needed=0.999):
 def test_blend_backward(ops, scene, ofwd, obwd):
     s = scene
     g, ob = obwd
-    acc, mag = ops.blend_backward(dev(ofwd["tile_start"]), dev(ofwd["tile_end"]), dev(ofwd["payload"]),
-                                  dev(pack_attrs(ofwd)), dev(g), dev(ofwd["acc_alpha"]), dev(ofwd["last_eff"]),
-                                  s.width, s.height)
+    slot_offsets = dev(ofwd["offsets"].astype(np.int32))
+    n_slots = int(ofwd["num_overlap_tiles"].sum())
+    args = (dev(ofwd["tile_start"]), dev(ofwd["tile_end"]), dev(ofwd["payload"]), dev(pack_attrs(ofwd)), dev(g),
+            dev(ofwd["acc_alpha"]), dev(ofwd["last_eff"]), slot_offsets, dev(ofwd["num_overlap_tiles"]), n_slots,
+            s.width, s.height)
+    acc, mag = ops.blend_backward(*args)
+    acc2, mag2 = ops.blend_backward(*args)
+    assert torch.equal(acc.view(torch.int32), acc2.view(torch.int32)) and torch.equal(mag, mag2), \
+        "the atomic-free backward is bitwise reproducible"
     acc = acc.cpu().numpy()
     names = ["duv_u", "duv_v", "dcov00", "dcov01", "dcov11", "dr", "dg", "db", "dlogit", "magnitude"]
     for c, nme in enumerate(names):
@@ -449,18 +457,20 @@ def test_headline_size_properties(ops):
                                              s.height)
     assert torch.equal(ids.long(), torch.nonzero(mask).flatten())  # ordered compaction
     feat = s.point_cloud_features.clone()
-    attrs, ntiles, nowned, block_sums = ops.preprocess(s.point_cloud, feat, s.point_object_id, s.camera_intrinsics,
-                                                       q_cp, t_cp, ids, s.width, s.height)
+    attrs, ntiles, nowned, block_sums, block_sums_full = ops.preprocess(
+        s.point_cloud, feat, s.point_object_id, s.camera_intrinsics, q_cp, t_cp, ids, s.width, s.height)
     assert torch.allclose(feat[ids.long(), :4].norm(dim=1), torch.ones(ids.shape[0], device="cuda"), atol=1e-6)
     assert (nowned <= ntiles).all()
     total = int(nowned.sum().item())
-    k = ops.scan_block_sums(block_sums, counters)
-    assert k == total
+    k, n_slots = ops.scan_block_sums(block_sums, counters, block_sums_full)
+    assert k == total and n_slots == int(ntiles.sum().item())
     num_tiles = (s.width // 16) * (s.height // 16)
     kdb, db, tb = ops.key_layout(s.near_plane, s.far_plane, s.depth_to_sort_key_scale, num_tiles)
     assert kdb > 0  # production layout at this size: compressed 32-bit keys
-    keys, payload = ops.make_keys(attrs, nowned, block_sums, k, s.width, s.height, s.depth_to_sort_key_scale,
-                                  key_depth_bits=kdb)
+    keys, payload, slot_offsets = ops.make_keys(attrs, nowned, block_sums, k, s.width, s.height,
+                                                s.depth_to_sort_key_scale, key_depth_bits=kdb,
+                                                num_overlap_tiles=ntiles, block_offsets_full=block_sums_full)
+    assert torch.equal(slot_offsets.long(), torch.cumsum(ntiles.long(), 0) - ntiles.long())
     # histogram of payload = key counts (every point emits exactly its count)
     assert torch.equal(torch.bincount(payload.long(), minlength=ids.shape[0]).int(), nowned)
     k0, p0 = keys.clone(), payload.clone()

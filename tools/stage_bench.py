@@ -34,17 +34,17 @@ for _ in range(reps + 2):
     _, ids, counters = timed("filter_compact", lambda: hip_ops.filter_compact(
         s.point_cloud, s.point_invalid_mask, s.point_object_id, s.camera_intrinsics, q_cp, t_cp, s.near_plane,
         s.far_plane, s.width, s.height))
-    attrs, ntiles, nowned, bsums = timed("preprocess", lambda: hip_ops.preprocess(
+    attrs, ntiles, nowned, bsums, bsums_full = timed("preprocess", lambda: hip_ops.preprocess(
         s.point_cloud, feat, s.point_object_id, s.camera_intrinsics, q_cp, t_cp, ids, s.width, s.height, 0, 1, CULL))
-    k = timed("scan_block_sums", lambda: hip_ops.scan_block_sums(bsums, counters))
-    keys, payload = timed("make_keys", lambda: hip_ops.make_keys(attrs, nowned, bsums, k, s.width, s.height,
-                                                                 s.depth_to_sort_key_scale, 0, 1, CULL, kdb))
+    k, n_slots = timed("scan_block_sums", lambda: hip_ops.scan_block_sums(bsums, counters, bsums_full))
+    keys, payload, slot_off = timed("make_keys", lambda: hip_ops.make_keys(attrs, nowned, bsums, k, s.width, s.height,
+                                                                 s.depth_to_sort_key_scale, 0, 1, CULL, kdb, ntiles, bsums_full))
     timed("sort_pairs", lambda: hip_ops.sort_pairs(keys, payload, db, tb, kdb))
     start, end = timed("tile_ranges", lambda: hip_ops.tile_ranges(keys, num_tiles, kdb))
     image, depth, acc_alpha, last_eff, count = timed("blend_forward", lambda: hip_ops.blend_forward(
         start, end, payload, attrs, s.width, s.height))
     acc, mag = timed("blend_backward", lambda: hip_ops.blend_backward(
-        start, end, payload, attrs, g, acc_alpha, last_eff, s.width, s.height))
+        start, end, payload, attrs, g, acc_alpha, last_eff, slot_off, ntiles, n_slots, s.width, s.height))
     timed("point_backward", lambda: hip_ops.point_backward(
         s.point_cloud, feat, s.point_object_id, s.camera_intrinsics, q_cp, t_cp, s.t_pointcloud_camera, ids, acc, 3,
         1.0, 0.5, 20.0, 5.0, 1.0, False))
