@@ -154,11 +154,12 @@ def main() -> None:
                 s.point_cloud, s.point_invalid_mask, s.point_object_id, s.camera_intrinsics, q_cp, t_cp,
                 s.near_plane, s.far_plane, s.width, s.height))
             attrs, ntiles, nowned, bsums, bsums_full = timed("preprocess", lambda: hip_ops.preprocess(
-                s.point_cloud, f, s.point_object_id, s.camera_intrinsics, q_cp, t_cp, ids, s.width, s.height, rb, rs, CULL))
-            k, n_slots = timed("scan_block_sums", lambda: hip_ops.scan_block_sums(bsums, counters, bsums_full))
+                s.point_cloud, f, s.point_object_id, s.camera_intrinsics, q_cp, t_cp, ids, s.width, s.height, rb, rs, CULL, s.depth_to_sort_key_scale, counters))
+            k, n_slots, max_dq = timed("scan_block_sums", lambda: hip_ops.scan_block_sums(bsums, counters, bsums_full))
+            kdb, db, tb = hip_ops.key_layout(s.near_plane, s.far_plane, s.depth_to_sort_key_scale, num_tiles, max_dq)
             keys, payload, slot_off = timed("make_keys", lambda: hip_ops.make_keys(
                 attrs, nowned, bsums, k, s.width, s.height, s.depth_to_sort_key_scale, rb, rs, CULL, kdb, ntiles, bsums_full))
-            timed("sort_pairs", lambda: hip_ops.sort_pairs(keys, payload, db, tb, kdb))
+            keys, payload = timed("sort_pairs", lambda: hip_ops.sort_pairs(keys, payload, db, tb, kdb, in_place=False))
             start, end = timed("tile_ranges", lambda: hip_ops.tile_ranges(keys, num_tiles, kdb))
             image, depth, acc_alpha, last_eff, count = timed("blend_forward", lambda: hip_ops.blend_forward(
                 start, end, payload, attrs, s.width, s.height, rb, rs))

@@ -50,6 +50,7 @@ extern "C" {
 #define GS_COUNTER_NUM_VISIBLE 0   /* M */
 #define GS_COUNTER_NUM_KEYS 1      /* K (saturates at INT32_MAX) */
 #define GS_COUNTER_NUM_SLOTS 2     /* sum of num_overlap_tiles = number of (Gaussian, tile) slots */
+#define GS_COUNTER_MAX_DEPTH_KEY 3 /* max over visible points of int32(z * depth_scale) (gs_preprocess) */
 #define GS_NUM_COUNTERS 8
 
 const char *gs_last_error(void);
@@ -83,14 +84,17 @@ int gs_read_counters(const int32_t *counters, int32_t *host_counters, int n, voi
  * num_owned_tiles the number of keys this GPU will emit (the one that is scanned).
  * exact_tile_cull != 0 drops (tile, Gaussian) pairs whose alpha is below the 1/255 skip threshold
  * (RAS:451) on every pixel of the tile: such pairs never change a pixel, so every operator output is
- * unchanged while the lists that are sorted and blended get shorter; 0 = the reference's lists. */
+ * unchanged while the lists that are sorted and blended get shorter; 0 = the reference's lists.
+ * counters (may be NULL; must be zero-initialised by the caller): counters[GS_COUNTER_MAX_DEPTH_KEY]
+ * receives the largest quantised depth int32(z*depth_scale) on screen, so that the host can size the
+ * key's depth field to the bits in use (fewer radix passes than the far_plane*depth_scale bound). */
 int gs_preprocess(const float *xyz, float *features, const int32_t *object_id,
                   const float *intrinsics, const float *q_camera_pointcloud,
                   const float *t_camera_pointcloud, const int32_t *ids, int n_visible,
                   int width, int height, int tile_row_begin, int tile_row_step,
-                  int exact_tile_cull, float *attrs, int32_t *num_overlap_tiles,
-                  int32_t *num_owned_tiles, int32_t *block_sums, int32_t *block_sums_full,
-                  void *stream);
+                  int exact_tile_cull, float depth_scale, int32_t *counters, float *attrs,
+                  int32_t *num_overlap_tiles, int32_t *num_owned_tiles, int32_t *block_sums,
+                  int32_t *block_sums_full, void *stream);
 
 /* Exclusive scan of per-block sums (in place) and total -> counters[counter_slot]
  * (GS_COUNTER_NUM_KEYS for block_sums, GS_COUNTER_NUM_SLOTS for block_sums_full).
@@ -117,12 +121,14 @@ int gs_make_keys(const float *attrs, const int32_t *num_owned_tiles, const int32
 /* Stable LSD radix sort of (key, payload) pairs.  Replaces torch.sort + gather (RAS:947-950) with
  * the stable tie rule.  key_depth_bits selects the key layout (see gs_make_keys).  64-bit layout:
  * only the bit ranges [0,depth_bits) and [32,32+tile_bits) are sorted; depth_bits = 64 sorts the
- * whole key as a signed int64.  32-bit layout: bits [0, key_depth_bits+tile_bits).  Result is left in
- * keys/payload (keys_alt/payload_alt are scratch of the same size). */
+ * whole key as a signed int64.  32-bit layout: bits [0, key_depth_bits+tile_bits).
+ * keys_alt/payload_alt are ping-pong buffers of the same size.  Returns 0 when the sorted pairs are in
+ * keys/payload, or -- only if allow_result_in_alt != 0 -- 1 when they are in keys_alt/payload_alt (odd
+ * number of passes; saves the copy back).  Negative on error. */
 size_t gs_sort_workspace_bytes(int64_t n_keys);
 int gs_sort_pairs(void *keys, int32_t *payload, void *keys_alt, int32_t *payload_alt,
                   int64_t n_keys, int key_depth_bits, int depth_bits, int tile_bits,
-                  void *workspace, void *stream);
+                  int allow_result_in_alt, void *workspace, void *stream);
 
 /* Per-tile [start,end) ranges.  Replaces find_tile_start_and_end (RAS:175-193) including the
  * zero-initialisation of RAS:954-957. */

@@ -117,18 +117,19 @@ class GaussianPointCloudRasterisation(torch.nn.Module):
                 cull = outer.exact_tile_cull
                 attrs, num_overlap_tiles, num_owned_tiles, block_sums, block_sums_full = hip_ops.preprocess(
                     xyz, pointcloud_features, obj, intrinsics, q_cp, t_cp, ids, width, height, row_begin, row_step,
-                    cull)
+                    cull, cfg.depth_to_sort_key_scale, counters)
                 # RAS:913-922  scan (host sync #2: K)
-                n_keys, n_slots = hip_ops.scan_block_sums(block_sums, counters, block_sums_full)
+                n_keys, n_slots, max_depth_key = hip_ops.scan_block_sums(block_sums, counters, block_sums_full)
                 # RAS:927-945  keys
                 num_tiles = (width // TILE_WIDTH) * (height // TILE_HEIGHT)
                 key_depth_bits, depth_bits, tile_bits = hip_ops.key_layout(
-                    cfg.near_plane, cfg.far_plane, cfg.depth_to_sort_key_scale, num_tiles)
+                    cfg.near_plane, cfg.far_plane, cfg.depth_to_sort_key_scale, num_tiles, max_depth_key)
                 keys, payload, slot_offsets = hip_ops.make_keys(
                     attrs, num_owned_tiles, block_sums, n_keys, width, height, cfg.depth_to_sort_key_scale,
                     row_begin, row_step, cull, key_depth_bits, num_overlap_tiles, block_sums_full)
                 # RAS:947-950  sort (stable)
-                hip_ops.sort_pairs(keys, payload, depth_bits, tile_bits, key_depth_bits)
+                keys, payload = hip_ops.sort_pairs(keys, payload, depth_bits, tile_bits, key_depth_bits,
+                                                   in_place=False)
                 # RAS:952-964  tile ranges
                 tile_start, tile_end = hip_ops.tile_ranges(keys, num_tiles, key_depth_bits)
                 del keys

@@ -248,13 +248,13 @@ __global__ __launch_bounds__(GS_BLOCK) void preprocess_kernel(
     const float *__restrict__ xyz, float *__restrict__ feat, const int32_t *__restrict__ obj,
     const float *__restrict__ Kmat, const float *__restrict__ q_cp, const float *__restrict__ t_cp,
     const int32_t *__restrict__ ids, int m, int width, int height, int row_begin, int row_step, int cull,
-    float *__restrict__ attrs, int32_t *__restrict__ ntiles_full, int32_t *__restrict__ ntiles_owned,
+    float depth_scale, int32_t *__restrict__ counters, float *__restrict__ attrs, int32_t *__restrict__ ntiles_full, int32_t *__restrict__ ntiles_owned,
     int32_t *__restrict__ block_sums, int32_t *__restrict__ block_sums_full) {
-    __shared__ int s_sum, s_sum_full;
-    if (threadIdx.x == 0) { s_sum = 0; s_sum_full = 0; }
+    __shared__ int s_sum, s_sum_full, s_dq;
+    if (threadIdx.x == 0) { s_sum = 0; s_sum_full = 0; s_dq = 0; }
     __syncthreads();
     const int i = blockIdx.x * GS_BLOCK + threadIdx.x;
-    int owned = 0, full = 0;
+    int owned = 0, full = 0, dq = 0;
     if (i < m) {
         const int id = ids[i];
         float4 *row4 = reinterpret_cast<float4 *>(feat + (size_t)GS_FEATURE_DIM * id);
@@ -278,6 +278,7 @@ __global__ __launch_bounds__(GS_BLOCK) void preprocess_kernel(
         const float p[3] = {xyz[3 * (size_t)id], xyz[3 * (size_t)id + 1], xyz[3 * (size_t)id + 2]};
         float uv[2], c[3];
         project_point(W, t, K, p, uv, c);
+        dq = (int32_t)(c[2] * depth_scale);  // the quantised depth of RAS:159-160 (for the key width)
 
         // GP3:161-191 project_to_camera_covariance: cov = J W Sigma W^T J^T, left to right
         float J[6] = {K[0] / c[2], 0.f, -(K[0] * c[0]) / (c[2] * c[2]),
@@ -358,21 +359,29 @@ __global__ __launch_bounds__(GS_BLOCK) void preprocess_kernel(
         }
         ntiles_owned[i] = owned;
     }
-    // per-block partial sums for the two scans (wave reduce, then one LDS atomic per wave)
+    // per-block partial sums for the two scans (wave reduce, then one LDS atomic per wave) and the
+    // largest quantised depth on screen (lets the host sort only the key bits that are in use)
     int s = owned, sf = full;
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) {
         s += __shfl_xor(s, d, GS_WAVE);
         sf += __shfl_xor(sf, d, GS_WAVE);
+        dq = max(dq, __shfl_xor(dq, d, GS_WAVE));
     }
     if (gs_lane() == 0) {
         if (s != 0) atomicAdd(&s_sum, s);
         if (sf != 0) atomicAdd(&s_sum_full, sf);
+        if (dq > 0) atomicMax(&s_dq, dq);
     }
     __syncthreads();
     if (threadIdx.x == 0) {
         block_sums[blockIdx.x] = s_sum;
         block_sums_full[blockIdx.x] = s_sum_full;
+        // one global atomic per workgroup, and only while it can still raise the maximum (a stale read
+        // merely causes a redundant atomic)
+        if (counters != nullptr && s_dq > __hip_atomic_load(&counters[GS_COUNTER_MAX_DEPTH_KEY], __ATOMIC_RELAXED,
+                                                            __HIP_MEMORY_SCOPE_AGENT))
+            atomicMax(&counters[GS_COUNTER_MAX_DEPTH_KEY], s_dq);
     }
 }
 
@@ -496,8 +505,8 @@ int gs_read_counters(const int32_t *counters, int32_t *host_counters, int n, voi
 
 int gs_preprocess(const float *xyz, float *features, const int32_t *object_id, const float *intrinsics,
                   const float *q_cp, const float *t_cp, const int32_t *ids, int n_visible, int width, int height,
-                  int tile_row_begin, int tile_row_step, int exact_tile_cull, float *attrs,
-                  int32_t *num_overlap_tiles, int32_t *num_owned_tiles, int32_t *block_sums,
+                  int tile_row_begin, int tile_row_step, int exact_tile_cull, float depth_scale, int32_t *counters,
+                  float *attrs, int32_t *num_overlap_tiles, int32_t *num_owned_tiles, int32_t *block_sums,
                   int32_t *block_sums_full, void *stream) {
     GS_REQUIRE(n_visible >= 0, "n_visible");
     GS_REQUIRE(tile_row_step >= 1 && tile_row_begin >= 0, "tile row ownership");
@@ -505,8 +514,8 @@ int gs_preprocess(const float *xyz, float *features, const int32_t *object_id, c
     if (n_visible == 0) return 0;
     hipLaunchKernelGGL(preprocess_kernel, dim3(gs_div_up(n_visible, GS_BLOCK)), dim3(GS_BLOCK), 0,
                        (hipStream_t)stream, xyz, features, object_id, intrinsics, q_cp, t_cp, ids, n_visible, width,
-                       height, tile_row_begin, tile_row_step, exact_tile_cull, attrs, num_overlap_tiles, num_owned_tiles,
-                       block_sums, block_sums_full);
+                       height, tile_row_begin, tile_row_step, exact_tile_cull, depth_scale, counters, attrs, num_overlap_tiles,
+                       num_owned_tiles, block_sums, block_sums_full);
     GS_CHECK_LAUNCH();
     return 0;
 }

@@ -126,7 +126,8 @@ __global__ __launch_bounds__(GS_BLOCK) void sort_scatter_kernel(
 
 template <typename KeyT>
 static int sort_pairs_impl(KeyT *keys, int32_t *payload, KeyT *keys_alt, int32_t *payload_alt, int64_t n_keys,
-                           const int *shifts, int n_pass, KeyT flip, void *workspace, hipStream_t s) {
+                           const int *shifts, int n_pass, KeyT flip, int allow_result_in_alt, void *workspace,
+                           hipStream_t s) {
     const int nblk = gs_div_up(n_keys, SORT_ITEMS);
     int32_t *counts = (int32_t *)workspace;
     int32_t *totals = counts + (size_t)RADIX * nblk;
@@ -145,6 +146,7 @@ static int sort_pairs_impl(KeyT *keys, int32_t *payload, KeyT *keys_alt, int32_t
         int32_t *tp = pin; pin = pout; pout = tp;
     }
     if (kin != keys) {  // odd number of passes: result sits in the alt buffers
+        if (allow_result_in_alt) return 1;
         GS_CHECK_HIP(hipMemcpyAsync(keys, kin, sizeof(KeyT) * n_keys, hipMemcpyDeviceToDevice, s));
         GS_CHECK_HIP(hipMemcpyAsync(payload, pin, sizeof(int32_t) * n_keys, hipMemcpyDeviceToDevice, s));
     }
@@ -159,7 +161,8 @@ size_t gs_sort_workspace_bytes(int64_t n_keys) {
 }
 
 int gs_sort_pairs(void *keys, int32_t *payload, void *keys_alt, int32_t *payload_alt, int64_t n_keys,
-                  int key_depth_bits, int depth_bits, int tile_bits, void *workspace, void *stream) {
+                  int key_depth_bits, int depth_bits, int tile_bits, int allow_result_in_alt, void *workspace,
+                  void *stream) {
     GS_REQUIRE(n_keys >= 0 && n_keys < 0x7fffffffLL, "n_keys must fit int32");
     GS_REQUIRE(depth_bits >= 0 && depth_bits <= 64 && tile_bits >= 0 && tile_bits <= 31, "bit ranges");
     GS_REQUIRE(key_depth_bits >= 0 && key_depth_bits < 32, "key_depth_bits");
@@ -170,7 +173,7 @@ int gs_sort_pairs(void *keys, int32_t *payload, void *keys_alt, int32_t *payload
         GS_REQUIRE(key_depth_bits + tile_bits <= 32, "compressed key does not fit 32 bits");
         for (int sh = 0; sh < key_depth_bits + tile_bits; sh += RADIX_BITS) shifts[n_pass++] = sh;
         return sort_pairs_impl<uint32_t>((uint32_t *)keys, payload, (uint32_t *)keys_alt, payload_alt, n_keys, shifts,
-                                         n_pass, 0u, workspace, s);
+                                         n_pass, 0u, allow_result_in_alt, workspace, s);
     }
     uint64_t flip = 0;
     if (depth_bits >= 64) {  // full signed 64-bit order
@@ -181,7 +184,7 @@ int gs_sort_pairs(void *keys, int32_t *payload, void *keys_alt, int32_t *payload
         for (int sh = 32; sh < 32 + tile_bits; sh += RADIX_BITS) shifts[n_pass++] = sh;
     }
     return sort_pairs_impl<uint64_t>((uint64_t *)keys, payload, (uint64_t *)keys_alt, payload_alt, n_keys, shifts,
-                                     n_pass, flip, workspace, s);
+                                     n_pass, flip, allow_result_in_alt, workspace, s);
 }
 
 }  // extern "C"

@@ -23,6 +23,7 @@ FEATURE_DIM = 56
 COUNTER_NUM_VISIBLE = 0
 COUNTER_NUM_KEYS = 1
 COUNTER_NUM_SLOTS = 2
+COUNTER_MAX_DEPTH_KEY = 3
 NUM_COUNTERS = 8
 _PRE_BLOCK = 256  # points per workgroup of gs_preprocess / gs_make_keys
 
@@ -76,7 +77,7 @@ def filter_compact(xyz, invalid_mask, object_id, intrinsics, q_cp, t_cp, near_pl
 
 
 def preprocess(xyz, features, object_id, intrinsics, q_cp, t_cp, ids, width, height, tile_row_begin=0,
-               tile_row_step=1, exact_tile_cull=True):
+               tile_row_step=1, exact_tile_cull=True, depth_to_sort_key_scale=100.0, counters=None):
     """-> (attrs f32[M,16], num_overlap_tiles i32[M], num_owned_tiles i32[M], block_sums, block_sums_full).
     Normalises features[ids, 0:4] IN PLACE (RAS:196-205).  num_overlap_tiles is the reference's box count
     (hook output; its scan gives the backward slots); num_owned_tiles is the number of keys emitted (after
@@ -89,8 +90,9 @@ def preprocess(xyz, features, object_id, intrinsics, q_cp, t_cp, ids, width, hei
     block_sums = torch.empty((m + _PRE_BLOCK - 1) // _PRE_BLOCK, dtype=torch.int32, device=dev)
     block_sums_full = torch.empty_like(block_sums)
     call("gs_preprocess", ptr(xyz), ptr(features), ptr(object_id), ptr(intrinsics), ptr(q_cp), ptr(t_cp), ptr(ids),
-         m, int(width), int(height), int(tile_row_begin), int(tile_row_step), int(bool(exact_tile_cull)), ptr(attrs),
-         ptr(ntiles), ptr(nowned), ptr(block_sums), ptr(block_sums_full), current_stream(dev))
+         m, int(width), int(height), int(tile_row_begin), int(tile_row_step), int(bool(exact_tile_cull)),
+         float(depth_to_sort_key_scale), ptr(counters), ptr(attrs), ptr(ntiles), ptr(nowned), ptr(block_sums),
+         ptr(block_sums_full), current_stream(dev))
     return attrs, ntiles, nowned, block_sums, block_sums_full
 
 
@@ -107,7 +109,7 @@ def scan_block_sums(block_sums: torch.Tensor, counters: torch.Tensor,
     k, n_slots = host[COUNTER_NUM_KEYS], host[COUNTER_NUM_SLOTS]
     if k >= 0x7fffffff or n_slots >= 0x7fffffff:
         raise RuntimeError("more than 2^31-1 (tile, Gaussian) pairs: key offsets are int32 as in the reference")
-    return k if block_sums_full is None else (k, n_slots)
+    return k if block_sums_full is None else (k, n_slots, host[COUNTER_MAX_DEPTH_KEY])
 
 
 def make_keys(attrs, num_owned_tiles, block_offsets, n_keys, width, height, depth_to_sort_key_scale,
@@ -141,28 +143,41 @@ def sort_key_bits(near_plane: float, far_plane: float, depth_to_sort_key_scale: 
     return 64, tile_bits  # negative depths borrow from the tile field: sort the whole signed key
 
 
-def key_layout(near_plane: float, far_plane: float, depth_to_sort_key_scale: float, num_tiles: int):
+def key_layout(near_plane: float, far_plane: float, depth_to_sort_key_scale: float, num_tiles: int,
+               max_depth_key: Optional[int] = None):
     """-> (key_depth_bits, depth_bits, tile_bits).  key_depth_bits > 0 selects the compressed 32-bit key
-    (possible when the quantised depth is provably in [0, 2^depth_bits) and tile+depth fit 32 bits)."""
+    (possible when the quantised depth is provably in [0, 2^depth_bits) and tile+depth fit 32 bits).
+    max_depth_key: the largest quantised depth on screen as measured by gs_preprocess; when given, the depth
+    field is sized to the bits actually in use (fewer radix passes than the far_plane*scale bound)."""
     depth_bits, tile_bits = sort_key_bits(near_plane, far_plane, depth_to_sort_key_scale, num_tiles)
+    if max_depth_key is not None and depth_bits < 64 and max_depth_key >= 0:
+        depth_bits = min(depth_bits, max(int(max_depth_key), 1).bit_length())
     if depth_bits < 64 and depth_bits + tile_bits <= 32:
         return depth_bits, depth_bits, tile_bits
     return 0, depth_bits, tile_bits
 
 
 def sort_pairs(keys: torch.Tensor, payload: torch.Tensor, depth_bits: int, tile_bits: int,
-               key_depth_bits: int = 0) -> None:
-    """Stable sort of (keys, payload) in place."""
+               key_depth_bits: int = 0, in_place: bool = True):
+    """Stable sort of (keys, payload).  in_place=True: the inputs hold the result.  in_place=False: returns the
+    (keys, payload) tensors that hold the result (the inputs or the ping-pong buffers: no copy back after an
+    odd number of passes); the other pair is scratch."""
     n = keys.shape[0]
     if n <= 1:
-        return
+        return None if in_place else (keys, payload)
     if keys.dtype != (torch.int64 if key_depth_bits == 0 else torch.int32):
         raise TypeError("key dtype does not match the key layout")
     dev = keys.device
     keys_alt, payload_alt = torch.empty_like(keys), torch.empty_like(payload)
     ws = torch.empty(_lib.load().gs_sort_workspace_bytes(n), dtype=torch.uint8, device=dev)
-    call("gs_sort_pairs", ptr(keys), ptr(payload), ptr(keys_alt), ptr(payload_alt), n, int(key_depth_bits),
-         int(depth_bits), int(tile_bits), ptr(ws), current_stream(dev))
+    status = _lib.load().gs_sort_pairs(ptr(keys), ptr(payload), ptr(keys_alt), ptr(payload_alt), n,
+                                       int(key_depth_bits), int(depth_bits), int(tile_bits), 0 if in_place else 1,
+                                       ptr(ws), current_stream(dev))
+    if status < 0:
+        _lib.check(status, "gs_sort_pairs")
+    if not in_place:
+        return (keys_alt, payload_alt) if status == 1 else (keys, payload)
+    return None
 
 
 def tile_ranges(keys_sorted: torch.Tensor, num_tiles: int, key_depth_bits: int = 0):

@@ -458,15 +458,18 @@ def test_headline_size_properties(ops):
     assert torch.equal(ids.long(), torch.nonzero(mask).flatten())  # ordered compaction
     feat = s.point_cloud_features.clone()
     attrs, ntiles, nowned, block_sums, block_sums_full = ops.preprocess(
-        s.point_cloud, feat, s.point_object_id, s.camera_intrinsics, q_cp, t_cp, ids, s.width, s.height)
+        s.point_cloud, feat, s.point_object_id, s.camera_intrinsics, q_cp, t_cp, ids, s.width, s.height,
+        depth_to_sort_key_scale=s.depth_to_sort_key_scale, counters=counters)
+    max_dq = ops.read_counters(counters)[ops.COUNTER_MAX_DEPTH_KEY]
+    assert max_dq == int((attrs[:, 2] * s.depth_to_sort_key_scale).int().max().item())
     assert torch.allclose(feat[ids.long(), :4].norm(dim=1), torch.ones(ids.shape[0], device="cuda"), atol=1e-6)
     assert (nowned <= ntiles).all()
     total = int(nowned.sum().item())
-    k, n_slots = ops.scan_block_sums(block_sums, counters, block_sums_full)
+    k, n_slots, _ = ops.scan_block_sums(block_sums, counters, block_sums_full)
     assert k == total and n_slots == int(ntiles.sum().item())
     num_tiles = (s.width // 16) * (s.height // 16)
-    kdb, db, tb = ops.key_layout(s.near_plane, s.far_plane, s.depth_to_sort_key_scale, num_tiles)
-    assert kdb > 0  # production layout at this size: compressed 32-bit keys
+    kdb, db, tb = ops.key_layout(s.near_plane, s.far_plane, s.depth_to_sort_key_scale, num_tiles, max_dq)
+    assert 0 < kdb < 17  # production layout at this size: compressed keys, depth field sized to the bits in use
     keys, payload, slot_offsets = ops.make_keys(attrs, nowned, block_sums, k, s.width, s.height,
                                                 s.depth_to_sort_key_scale, key_depth_bits=kdb,
                                                 num_overlap_tiles=ntiles, block_offsets_full=block_sums_full)
