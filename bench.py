@@ -150,7 +150,7 @@ def main() -> None:
         q_cp, t_cp = hip_ops.pose_inverse(s.q_pointcloud_camera, s.t_pointcloud_camera)
         for _ in range(reps):
             f = feat.detach()
-            _, ids, counters = timed("filter_compact", lambda: hip_ops.filter_compact(
+            vmask, ids, counters = timed("filter_compact", lambda: hip_ops.filter_compact(
                 s.point_cloud, s.point_invalid_mask, s.point_object_id, s.camera_intrinsics, q_cp, t_cp,
                 s.near_plane, s.far_plane, s.width, s.height))
             attrs, ntiles, nowned, bsums, bsums_full = timed("preprocess", lambda: hip_ops.preprocess(
@@ -168,7 +168,7 @@ def main() -> None:
             timed("point_backward", lambda: hip_ops.point_backward(
                 s.point_cloud, f, s.point_object_id, s.camera_intrinsics, q_cp, t_cp, s.t_pointcloud_camera, ids,
                 acc, 3, cfg.grad_q_factor, cfg.grad_s_factor, cfg.grad_alpha_factor, cfg.grad_color_factor,
-                cfg.grad_high_order_color_factor, False))
+                cfg.grad_high_order_color_factor, False, vmask))
         torch.cuda.synchronize()
         m = int(ids.shape[0])
         sizes = {"N": n, "M": m, "K": int(k), "P": pixels, "tiles": num_tiles}

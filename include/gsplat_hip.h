@@ -164,12 +164,14 @@ int gs_reduce_partials(const int32_t *slot_offsets, const int32_t *num_overlap_t
  * (RAS:1051-1053), _clear_grad_by_color_max_sh_band (RAS:1167-1182) and the factor scaling
  * (RAS:1105-1125; factors are the frozen class attributes RAS:782-786, passed explicitly).
  * grad_xyz float[N][3] and grad_features float[N][56] are fully written (zeros for rows that
- * are not visible).  The optional compact outputs (may be NULL) are the hook gathers of
+ * are not visible; with visible_mask = the int8[N] mask of gs_filter_compact only those rows are
+ * zero-filled, with NULL both arrays are memset first).  The optional compact outputs (may be NULL) are the hook gathers of
  * RAS:1130-1134: grad_xyz_visible float[M][3], grad_features_visible float[M][56]. */
 int gs_point_backward(const float *xyz, const float *features, const int32_t *object_id,
                       const float *intrinsics, const float *q_camera_pointcloud,
                       const float *t_camera_pointcloud, const float *t_pointcloud_camera,
-                      const int32_t *ids, int n_visible, int n_points, const float *acc,
+                      const int32_t *ids, const int8_t *visible_mask, int n_visible, int n_points,
+                      const float *acc,
                       int color_max_sh_band, float grad_q_factor, float grad_s_factor,
                       float grad_alpha_factor, float grad_color_factor,
                       float grad_high_order_color_factor, float *grad_xyz, float *grad_features,

@@ -111,7 +111,7 @@ class GaussianPointCloudRasterisation(torch.nn.Module):
                 # RAS:845  (q,t)_camera<-pointcloud
                 q_cp, t_cp = hip_ops.pose_inverse(q_pc, t_pc)
                 # RAS:848-870  frustum filter + compaction (host sync #1: M)
-                _, ids, counters = hip_ops.filter_compact(
+                visible_mask, ids, counters = hip_ops.filter_compact(
                     xyz, invalid, obj, intrinsics, q_cp, t_cp, cfg.near_plane, cfg.far_plane, width, height)
                 # RAS:887-911  per-point projection + tile counts
                 cull = outer.exact_tile_cull
@@ -141,7 +141,7 @@ class GaussianPointCloudRasterisation(torch.nn.Module):
 
                 ctx.save_for_backward(xyz, pointcloud_features, payload, ids, tile_start, tile_end, acc_alpha,
                                       last_eff, num_overlap_tiles, obj, q_cp, t_cp, t_pc, attrs, intrinsics,
-                                      slot_offsets)
+                                      slot_offsets, visible_mask)
                 ctx.n_slots = n_slots
                 ctx.camera_info = camera_info
                 ctx.color_max_sh_band = color_max_sh_band
@@ -154,7 +154,7 @@ class GaussianPointCloudRasterisation(torch.nn.Module):
                 grad_pointcloud = grad_pointcloud_features = None
                 if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:  # RAS:1028
                     (xyz, features, payload, ids, tile_start, tile_end, acc_alpha, last_eff, num_overlap_tiles,
-                     obj, q_cp, t_cp, t_pc, attrs, intrinsics, slot_offsets) = ctx.saved_tensors
+                     obj, q_cp, t_cp, t_pc, attrs, intrinsics, slot_offsets, visible_mask) = ctx.saved_tensors
                     cfg = outer.config
                     camera_info = ctx.camera_info
                     width, height = camera_info.camera_width, camera_info.camera_height
@@ -170,7 +170,8 @@ class GaussianPointCloudRasterisation(torch.nn.Module):
                     grad_pointcloud, grad_pointcloud_features, gx_vis, gf_vis = hip_ops.point_backward(
                         xyz, features, obj, intrinsics, q_cp, t_cp, t_pc, ids, acc, ctx.color_max_sh_band,
                         cfg.grad_q_factor, cfg.grad_s_factor, cfg.grad_alpha_factor, cfg.grad_color_factor,
-                        cfg.grad_high_order_color_factor, want_visible=hook is not None)
+                        cfg.grad_high_order_color_factor, want_visible=hook is not None,
+                        visible_mask=visible_mask)
                     if hook is not None:  # RAS:1127-1142
                         hook(GaussianPointCloudRasterisation.BackwardValidPointHookInput(
                             point_id_in_camera_list=ids,

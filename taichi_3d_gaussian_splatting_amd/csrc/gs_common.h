@@ -118,6 +118,37 @@ __device__ __forceinline__ float gs_row_sum_to_lane15(float v) {
     v += gs_dpp<0x118, 0xf, 0xc>(v);  // row_shr:8, banks 2-3
     return v;
 }
+// ------------------------------------------------------------------ coalesced access to 224-B feature rows
+// The feature matrix is AoS (56 floats = 14 x 16 B per Gaussian, owned by the caller).  A lane reading its own
+// row with 16-B loads makes every load instruction touch 64 different cache lines.  Instead the wave moves its
+// 64 rows cooperatively: 14 consecutive lanes handle the 14 float4 of one row (4 rows = 56 lanes per
+// instruction, 16 instructions per wave), staged through LDS so that each lane then owns its whole row.
+// rows = this wave's LDS staging area: 64 rows x GS_ROW_F4 float4 (the 15th float4 pads the row to 240 B,
+// which keeps the per-lane ds_read_b128 of one 16-lane group on distinct banks).
+#define GS_ROW_F4 15
+__device__ __forceinline__ void gs_rows_global_to_lds(const float4 *__restrict__ base, int my_row_id,
+                                                      float4 *__restrict__ rows) {
+    const int lane = gs_lane(), sub = lane / 14, c = lane - 14 * sub;
+#pragma unroll 4
+    for (int it = 0; it < 16; ++it) {
+        const int rr = it * 4 + sub;                        // row of this wave handled by my 14-lane group
+        const int rid = __shfl(my_row_id, rr & 63, GS_WAVE);  // its global row index (-1: no row)
+        if (lane < 56 && rid >= 0) rows[rr * GS_ROW_F4 + c] = base[(size_t)rid * 14 + c];
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+__device__ __forceinline__ void gs_rows_lds_to_global(float4 *__restrict__ base, int my_row_id,
+                                                      const float4 *__restrict__ rows) {
+    __builtin_amdgcn_wave_barrier();
+    const int lane = gs_lane(), sub = lane / 14, c = lane - 14 * sub;
+#pragma unroll 4
+    for (int it = 0; it < 16; ++it) {
+        const int rr = it * 4 + sub;
+        const int rid = __shfl(my_row_id, rr & 63, GS_WAVE);
+        if (lane < 56 && rid >= 0) base[(size_t)rid * 14 + c] = rows[rr * GS_ROW_F4 + c];
+    }
+}
+
 // ------------------------------------------------------------------ 10-value wave reduce-scatter
 // Sums ten per-lane partials over the 64 lanes of a wave in 30 VALU instructions (6 x 10 = 60 with
 // the plain DPP ladder): two swap+add levels use gfx950's v_permlane32_swap / v_permlane16_swap to

@@ -51,17 +51,24 @@ __global__ __launch_bounds__(GS_BLOCK) void point_backward_kernel(
     const float *__restrict__ t_pc, const int32_t *__restrict__ ids, int m, const float4 *__restrict__ acc,
     Factors fac, float *__restrict__ grad_xyz, float *__restrict__ grad_feat, float *__restrict__ grad_xyz_vis,
     float *__restrict__ grad_feat_vis) {
+    extern __shared__ __attribute__((aligned(16))) float4 s_rows[];  // [4 waves][64 rows][GS_ROW_F4]
     const int i = blockIdx.x * GS_BLOCK + threadIdx.x;
-    if (i >= m) return;
-    const int id = ids[i];
-    const float4 *row4 = reinterpret_cast<const float4 *>(feat + (size_t)GS_FEATURE_DIM * id);
+    const int id = i < m ? ids[i] : -1;
+    float4 *wave_rows = s_rows + (threadIdx.x >> 6) * (GS_WAVE * GS_ROW_F4);
+    // coalesced AoS gather of the 224-B feature rows (gs_common.h)
+    gs_rows_global_to_lds(reinterpret_cast<const float4 *>(feat), id, wave_rows);
     float f[GS_FEATURE_DIM];
 #pragma unroll
     for (int k = 0; k < GS_FEATURE_DIM / 4; ++k) {
-        float4 v = row4[k];
+        float4 v = wave_rows[gs_lane() * GS_ROW_F4 + k];
         f[4 * k] = v.x; f[4 * k + 1] = v.y; f[4 * k + 2] = v.z; f[4 * k + 3] = v.w;
     }
-    const float4 A0 = acc[3 * (size_t)i], A1 = acc[3 * (size_t)i + 1], A2 = acc[3 * (size_t)i + 2];
+    if (i >= m) {  // lanes without a row still take part in the cooperative stores below
+#pragma unroll
+        for (int k = 0; k < GS_FEATURE_DIM; ++k) f[k] = 0.f;
+    }
+    const int ic = i < m ? i : 0, idc = i < m ? id : 0;
+    const float4 A0 = acc[3 * (size_t)ic], A1 = acc[3 * (size_t)ic + 1], A2 = acc[3 * (size_t)ic + 2];
     const float g_uv[2] = {A0.x, A0.y};
     const float g00 = A0.z, g01 = A0.w, g11 = A1.x;
     const float g_rgb[3] = {A1.y, A1.z, A1.w};
@@ -70,11 +77,11 @@ __global__ __launch_bounds__(GS_BLOCK) void point_backward_kernel(
     float K[9];
 #pragma unroll
     for (int k = 0; k < 9; ++k) K[k] = Kmat[k];
-    const int o = obj[id];
+    const int o = obj[idc];
     float W[9];
     rotmat_from_q(q_cp + 4 * o, W);
     const float t[3] = {t_cp[3 * o], t_cp[3 * o + 1], t_cp[3 * o + 2]};
-    const float p[3] = {xyz[3 * (size_t)id], xyz[3 * (size_t)id + 1], xyz[3 * (size_t)id + 2]};
+    const float p[3] = {xyz[3 * (size_t)idc], xyz[3 * (size_t)idc + 1], xyz[3 * (size_t)idc + 2]};
     float c[3];
 #pragma unroll
     for (int r = 0; r < 3; ++r) c[r] = ((W[3 * r] * p[0] + W[3 * r + 1] * p[1]) + W[3 * r + 2] * p[2]) + t[r];
@@ -162,36 +169,54 @@ __global__ __launch_bounds__(GS_BLOCK) void point_backward_kernel(
             out[8 + 16 * ch + k] = k < fac.keep ? v : 0.f;  // RAS:1167-1182
         }
     }
-    float4 *dst = reinterpret_cast<float4 *>(grad_feat + (size_t)GS_FEATURE_DIM * id);
+    // coalesced AoS scatter of the gradient rows through the same LDS staging area
+    __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int k = 0; k < GS_FEATURE_DIM / 4; ++k)
-        dst[k] = make_float4(out[4 * k], out[4 * k + 1], out[4 * k + 2], out[4 * k + 3]);
+        wave_rows[gs_lane() * GS_ROW_F4 + k] = make_float4(out[4 * k], out[4 * k + 1], out[4 * k + 2], out[4 * k + 3]);
+    gs_rows_lds_to_global(reinterpret_cast<float4 *>(grad_feat), id, wave_rows);
+    if (grad_feat_vis) gs_rows_lds_to_global(reinterpret_cast<float4 *>(grad_feat_vis), i < m ? i : -1, wave_rows);
+    if (i < m) {
 #pragma unroll
-    for (int k = 0; k < 3; ++k) grad_xyz[3 * (size_t)id + k] = gx[k];
-    if (grad_feat_vis) {
-        float4 *dv = reinterpret_cast<float4 *>(grad_feat_vis + (size_t)GS_FEATURE_DIM * i);
+        for (int k = 0; k < 3; ++k) grad_xyz[3 * (size_t)id + k] = gx[k];
+        if (grad_xyz_vis) {
 #pragma unroll
-        for (int k = 0; k < GS_FEATURE_DIM / 4; ++k)
-            dv[k] = make_float4(out[4 * k], out[4 * k + 1], out[4 * k + 2], out[4 * k + 3]);
+            for (int k = 0; k < 3; ++k) grad_xyz_vis[3 * (size_t)i + k] = gx[k];
+        }
     }
-    if (grad_xyz_vis) {
-#pragma unroll
-        for (int k = 0; k < 3; ++k) grad_xyz_vis[3 * (size_t)i + k] = gx[k];
-    }
+}
+
+// Zero rows of the dense gradients for points that are NOT visible (RAS:1051-1053 zero-initialises
+// everything; the visible rows are fully written by point_backward_kernel, so only the others need zeros).
+// 14 lanes per 224-B row -> coalesced 16-B stores.
+__global__ __launch_bounds__(GS_BLOCK) void zero_invisible_rows_kernel(const int8_t *__restrict__ mask, int n,
+                                                                      float4 *__restrict__ grad_feat4,
+                                                                      float *__restrict__ grad_xyz) {
+    const long long t = (long long)blockIdx.x * GS_BLOCK + threadIdx.x;
+    const long long row = t / 16;
+    const int c = (int)(t % 16);
+    if (row >= n || mask[row] != 0) return;
+    if (c < 14) grad_feat4[row * 14 + c] = make_float4(0.f, 0.f, 0.f, 0.f);
+    else if (c == 14) { grad_xyz[3 * row] = 0.f; grad_xyz[3 * row + 1] = 0.f; grad_xyz[3 * row + 2] = 0.f; }
 }
 
 }  // namespace
 
 extern "C" int gs_point_backward(const float *xyz, const float *features, const int32_t *object_id,
                                  const float *intrinsics, const float *q_cp, const float *t_cp, const float *t_pc,
-                                 const int32_t *ids, int n_visible, int n_points, const float *acc,
+                                 const int32_t *ids, const int8_t *visible_mask, int n_visible, int n_points,
+                                 const float *acc,
                                  int color_max_sh_band, float grad_q_factor, float grad_s_factor,
                                  float grad_alpha_factor, float grad_color_factor,
                                  float grad_high_order_color_factor, float *grad_xyz, float *grad_features,
                                  float *grad_xyz_visible, float *grad_features_visible, void *stream) {
     GS_REQUIRE(n_visible >= 0 && n_points >= n_visible, "sizes");
     hipStream_t s = (hipStream_t)stream;
-    if (n_points > 0) {
+    if (n_points > 0 && visible_mask != nullptr && n_visible > 0) {
+        hipLaunchKernelGGL(zero_invisible_rows_kernel, dim3(gs_div_up(16LL * n_points, GS_BLOCK)), dim3(GS_BLOCK), 0, s,
+                           visible_mask, n_points, reinterpret_cast<float4 *>(grad_features), grad_xyz);
+        GS_CHECK_LAUNCH();
+    } else if (n_points > 0) {
         GS_CHECK_HIP(hipMemsetAsync(grad_xyz, 0, sizeof(float) * 3 * (size_t)n_points, s));
         GS_CHECK_HIP(hipMemsetAsync(grad_features, 0, sizeof(float) * GS_FEATURE_DIM * (size_t)n_points, s));
     }
@@ -200,7 +225,8 @@ extern "C" int gs_point_backward(const float *xyz, const float *features, const 
     fac.q = grad_q_factor; fac.s = grad_s_factor; fac.alpha = grad_alpha_factor;
     fac.color = grad_color_factor; fac.color_hi = grad_high_order_color_factor;
     fac.keep = color_max_sh_band <= 0 ? 1 : color_max_sh_band == 1 ? 4 : color_max_sh_band == 2 ? 9 : 16;
-    hipLaunchKernelGGL(point_backward_kernel, dim3(gs_div_up(n_visible, GS_BLOCK)), dim3(GS_BLOCK), 0, s, xyz,
+    hipLaunchKernelGGL(point_backward_kernel, dim3(gs_div_up(n_visible, GS_BLOCK)), dim3(GS_BLOCK),
+                       sizeof(float4) * GS_BLOCK * GS_ROW_F4, s, xyz,
                        features, object_id, intrinsics, q_cp, t_cp, t_pc, ids, n_visible,
                        reinterpret_cast<const float4 *>(acc), fac, grad_xyz, grad_features, grad_xyz_visible,
                        grad_features_visible);

@@ -232,7 +232,7 @@ def blend_backward(tile_start, tile_end, payload, attrs, grad_image, acc_alpha, 
 
 def point_backward(xyz, features, object_id, intrinsics, q_cp, t_cp, t_pc, ids, acc, color_max_sh_band,
                    grad_q_factor, grad_s_factor, grad_alpha_factor, grad_color_factor,
-                   grad_high_order_color_factor, want_visible: bool):
+                   grad_high_order_color_factor, want_visible: bool, visible_mask=None):
     dev = xyz.device
     n, m = xyz.shape[0], ids.shape[0]
     grad_xyz = torch.empty((n, 3), dtype=torch.float32, device=dev)
@@ -240,7 +240,7 @@ def point_backward(xyz, features, object_id, intrinsics, q_cp, t_cp, t_pc, ids, 
     gx_vis = torch.empty((m, 3), dtype=torch.float32, device=dev) if want_visible else None
     gf_vis = torch.empty((m, FEATURE_DIM), dtype=torch.float32, device=dev) if want_visible else None
     call("gs_point_backward", ptr(xyz), ptr(features), ptr(object_id), ptr(intrinsics), ptr(q_cp), ptr(t_cp),
-         ptr(t_pc), ptr(ids), m, n, ptr(acc), int(color_max_sh_band), float(grad_q_factor), float(grad_s_factor),
+         ptr(t_pc), ptr(ids), ptr(visible_mask), m, n, ptr(acc), int(color_max_sh_band), float(grad_q_factor), float(grad_s_factor),
          float(grad_alpha_factor), float(grad_color_factor), float(grad_high_order_color_factor), ptr(grad_xyz),
          ptr(grad_feat), ptr(gx_vis), ptr(gf_vis), current_stream(dev))
     return grad_xyz, grad_feat, gx_vis, gf_vis

@@ -31,7 +31,7 @@ kdb, db, tb = hip_ops.key_layout(s.near_plane, s.far_plane, s.depth_to_sort_key_
 q_cp, t_cp = hip_ops.pose_inverse(s.q_pointcloud_camera, s.t_pointcloud_camera)
 feat = s.point_cloud_features.clone()
 for _ in range(reps + 2):
-    _, ids, counters = timed("filter_compact", lambda: hip_ops.filter_compact(
+    vmask, ids, counters = timed("filter_compact", lambda: hip_ops.filter_compact(
         s.point_cloud, s.point_invalid_mask, s.point_object_id, s.camera_intrinsics, q_cp, t_cp, s.near_plane,
         s.far_plane, s.width, s.height))
     attrs, ntiles, nowned, bsums, bsums_full = timed("preprocess", lambda: hip_ops.preprocess(
@@ -48,7 +48,7 @@ for _ in range(reps + 2):
         start, end, payload, attrs, g, acc_alpha, last_eff, slot_off, ntiles, n_slots, s.width, s.height))
     timed("point_backward", lambda: hip_ops.point_backward(
         s.point_cloud, feat, s.point_object_id, s.camera_intrinsics, q_cp, t_cp, s.t_pointcloud_camera, ids, acc, 3,
-        1.0, 0.5, 20.0, 5.0, 1.0, False))
+        1.0, 0.5, 20.0, 5.0, 1.0, False, vmask))
 torch.cuda.synchronize()
 print(f"workload={workload} M={ids.shape[0]} K={k} cull={CULL}")
 tot = 0.0
