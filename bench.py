@@ -155,7 +155,7 @@ def main() -> None:
                 s.near_plane, s.far_plane, s.width, s.height))
             attrs, ntiles, nowned, bsums, bsums_full = timed("preprocess", lambda: hip_ops.preprocess(
                 s.point_cloud, f, s.point_object_id, s.camera_intrinsics, q_cp, t_cp, ids, s.width, s.height, rb, rs, CULL, s.depth_to_sort_key_scale, counters))
-            k, n_slots, max_dq = timed("scan_block_sums", lambda: hip_ops.scan_block_sums(bsums, counters, bsums_full))
+            k, n_slots, max_dq, _m = timed("scan_block_sums", lambda: hip_ops.scan_block_sums(bsums, counters, bsums_full))
             kdb, db, tb = hip_ops.key_layout(s.near_plane, s.far_plane, s.depth_to_sort_key_scale, num_tiles, max_dq)
             keys, payload, slot_off = timed("make_keys", lambda: hip_ops.make_keys(
                 attrs, nowned, bsums, k, s.width, s.height, s.depth_to_sort_key_scale, rb, rs, CULL, kdb, ntiles, bsums_full))

@@ -85,14 +85,18 @@ int gs_read_counters(const int32_t *counters, int32_t *host_counters, int n, voi
  * exact_tile_cull != 0 drops (tile, Gaussian) pairs whose alpha is below the 1/255 skip threshold
  * (RAS:451) on every pixel of the tile: such pairs never change a pixel, so every operator output is
  * unchanged while the lists that are sorted and blended get shorter; 0 = the reference's lists.
+ * n_visible_on_device != 0: n_visible is only the CAPACITY of ids/outputs (e.g. N) and the kernel takes
+ * the actual count from counters[GS_COUNTER_NUM_VISIBLE] as written by gs_filter_compact on the same
+ * stream -- the host then needs a single size read-back (M, K, slots together) instead of two.
  * counters (may be NULL; must be zero-initialised by the caller): counters[GS_COUNTER_MAX_DEPTH_KEY]
  * receives the largest quantised depth int32(z*depth_scale) on screen, so that the host can size the
  * key's depth field to the bits in use (fewer radix passes than the far_plane*depth_scale bound). */
 int gs_preprocess(const float *xyz, float *features, const int32_t *object_id,
                   const float *intrinsics, const float *q_camera_pointcloud,
                   const float *t_camera_pointcloud, const int32_t *ids, int n_visible,
-                  int width, int height, int tile_row_begin, int tile_row_step,
-                  int exact_tile_cull, float depth_scale, int32_t *counters, float *attrs,
+                  int n_visible_on_device, int width, int height, int tile_row_begin,
+                  int tile_row_step, int exact_tile_cull, float depth_scale, int32_t *counters,
+                  float *attrs,
                   int32_t *num_overlap_tiles, int32_t *num_owned_tiles, int32_t *block_sums,
                   int32_t *block_sums_full, void *stream);
 

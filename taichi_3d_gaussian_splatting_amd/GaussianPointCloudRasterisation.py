@@ -110,16 +110,22 @@ class GaussianPointCloudRasterisation(torch.nn.Module):
 
                 # RAS:845  (q,t)_camera<-pointcloud
                 q_cp, t_cp = hip_ops.pose_inverse(q_pc, t_pc)
-                # RAS:848-870  frustum filter + compaction (host sync #1: M)
+                # RAS:848-870  frustum filter + ordered compaction; M stays on the device
                 visible_mask, ids, counters = hip_ops.filter_compact(
-                    xyz, invalid, obj, intrinsics, q_cp, t_cp, cfg.near_plane, cfg.far_plane, width, height)
-                # RAS:887-911  per-point projection + tile counts
+                    xyz, invalid, obj, intrinsics, q_cp, t_cp, cfg.near_plane, cfg.far_plane, width, height,
+                    sync=False)
+                # RAS:887-911  per-point projection + tile counts (launched for the capacity N)
                 cull = outer.exact_tile_cull
                 attrs, num_overlap_tiles, num_owned_tiles, block_sums, block_sums_full = hip_ops.preprocess(
                     xyz, pointcloud_features, obj, intrinsics, q_cp, t_cp, ids, width, height, row_begin, row_step,
-                    cull, cfg.depth_to_sort_key_scale, counters)
-                # RAS:913-922  scan (host sync #2: K)
-                n_keys, n_slots, max_depth_key = hip_ops.scan_block_sums(block_sums, counters, block_sums_full)
+                    cull, cfg.depth_to_sort_key_scale, counters, n_visible_on_device=True)
+                # RAS:913-922  scans; ONE host read-back for M, K, the slot count and the depth range
+                # (the reference syncs twice: RAS:870 and RAS:916)
+                n_keys, n_slots, max_depth_key, m = hip_ops.scan_block_sums(block_sums, counters, block_sums_full)
+                nb = (m + 255) // 256
+                ids, attrs, num_overlap_tiles, num_owned_tiles = ids[:m], attrs[:m], num_overlap_tiles[:m], \
+                    num_owned_tiles[:m]
+                block_sums, block_sums_full = block_sums[:nb], block_sums_full[:nb]
                 # RAS:927-945  keys
                 num_tiles = (width // TILE_WIDTH) * (height // TILE_HEIGHT)
                 key_depth_bits, depth_bits, tile_bits = hip_ops.key_layout(

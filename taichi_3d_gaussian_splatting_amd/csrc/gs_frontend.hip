@@ -249,12 +249,14 @@ __global__ __launch_bounds__(GS_BLOCK) void compact_kernel(const int8_t *__restr
 __global__ __launch_bounds__(GS_BLOCK) void preprocess_kernel(
     const float *__restrict__ xyz, float *__restrict__ feat, const int32_t *__restrict__ obj,
     const float *__restrict__ Kmat, const float *__restrict__ q_cp, const float *__restrict__ t_cp,
-    const int32_t *__restrict__ ids, int m, int width, int height, int row_begin, int row_step, int cull,
-    float depth_scale, int32_t *__restrict__ counters, float *__restrict__ attrs, int32_t *__restrict__ ntiles_full, int32_t *__restrict__ ntiles_owned,
+    const int32_t *__restrict__ ids, int m_capacity, int use_device_count, int width, int height, int row_begin,
+    int row_step, int cull, float depth_scale, int32_t *__restrict__ counters, float *__restrict__ attrs, int32_t *__restrict__ ntiles_full, int32_t *__restrict__ ntiles_owned,
     int32_t *__restrict__ block_sums, int32_t *__restrict__ block_sums_full) {
     __shared__ int s_sum, s_sum_full, s_dq;
     if (threadIdx.x == 0) { s_sum = 0; s_sum_full = 0; s_dq = 0; }
     __syncthreads();
+    // the number of visible points may still be on its way to the host: read it on the device
+    const int m = use_device_count ? min(counters[GS_COUNTER_NUM_VISIBLE], m_capacity) : m_capacity;
     const int i = blockIdx.x * GS_BLOCK + threadIdx.x;
     int owned = 0, full = 0, dq = 0;
     if (i < m) {
@@ -506,17 +508,19 @@ int gs_read_counters(const int32_t *counters, int32_t *host_counters, int n, voi
 }
 
 int gs_preprocess(const float *xyz, float *features, const int32_t *object_id, const float *intrinsics,
-                  const float *q_cp, const float *t_cp, const int32_t *ids, int n_visible, int width, int height,
-                  int tile_row_begin, int tile_row_step, int exact_tile_cull, float depth_scale, int32_t *counters,
+                  const float *q_cp, const float *t_cp, const int32_t *ids, int n_visible, int n_visible_on_device,
+                  int width, int height, int tile_row_begin, int tile_row_step, int exact_tile_cull,
+                  float depth_scale, int32_t *counters,
                   float *attrs, int32_t *num_overlap_tiles, int32_t *num_owned_tiles, int32_t *block_sums,
                   int32_t *block_sums_full, void *stream) {
     GS_REQUIRE(n_visible >= 0, "n_visible");
     GS_REQUIRE(tile_row_step >= 1 && tile_row_begin >= 0, "tile row ownership");
     GS_REQUIRE(width % GS_TILE_WIDTH == 0 && height % GS_TILE_HEIGHT == 0, "image size must be a multiple of 16");
+    GS_REQUIRE(!n_visible_on_device || counters != nullptr, "device-side count needs counters");
     if (n_visible == 0) return 0;
     hipLaunchKernelGGL(preprocess_kernel, dim3(gs_div_up(n_visible, GS_BLOCK)), dim3(GS_BLOCK), 0,
-                       (hipStream_t)stream, xyz, features, object_id, intrinsics, q_cp, t_cp, ids, n_visible, width,
-                       height, tile_row_begin, tile_row_step, exact_tile_cull, depth_scale, counters, attrs, num_overlap_tiles,
+                       (hipStream_t)stream, xyz, features, object_id, intrinsics, q_cp, t_cp, ids, n_visible,
+                       n_visible_on_device, width, height, tile_row_begin, tile_row_step, exact_tile_cull, depth_scale, counters, attrs, num_overlap_tiles,
                        num_owned_tiles, block_sums, block_sums_full);
     GS_CHECK_LAUNCH();
     return 0;

@@ -59,8 +59,10 @@ def pose_inverse(q_pointcloud_camera: torch.Tensor, t_pointcloud_camera: torch.T
 
 
 def filter_compact(xyz, invalid_mask, object_id, intrinsics, q_cp, t_cp, near_plane, far_plane, width, height,
-                   counters: Optional[torch.Tensor] = None):
-    """-> (mask int8[N], ids int32[M], counters).  Blocks on the size read-back (RAS:870)."""
+                   counters: Optional[torch.Tensor] = None, sync: bool = True):
+    """-> (mask int8[N], ids, counters).  sync=True: blocks on the size read-back (RAS:870) and returns
+    ids int32[M]; sync=False: returns the int32[N] buffer whose first M entries are valid, M staying on the
+    device in counters[COUNTER_NUM_VISIBLE] (pass it on with preprocess(..., n_visible_on_device=True))."""
     xyz = _f32(xyz, "point_cloud")
     n = xyz.shape[0]
     dev = xyz.device
@@ -72,12 +74,15 @@ def filter_compact(xyz, invalid_mask, object_id, intrinsics, q_cp, t_cp, near_pl
     call("gs_filter_compact", ptr(xyz), ptr(invalid_mask), ptr(object_id), ptr(intrinsics), ptr(q_cp), ptr(t_cp),
          n, float(near_plane), float(far_plane), int(width), int(height), ptr(mask), ptr(ids), ptr(counters),
          ptr(ws), current_stream(dev))
+    if not sync:
+        return mask, ids, counters
     m = read_counters(counters)[COUNTER_NUM_VISIBLE]
     return mask, ids[:m], counters
 
 
 def preprocess(xyz, features, object_id, intrinsics, q_cp, t_cp, ids, width, height, tile_row_begin=0,
-               tile_row_step=1, exact_tile_cull=True, depth_to_sort_key_scale=100.0, counters=None):
+               tile_row_step=1, exact_tile_cull=True, depth_to_sort_key_scale=100.0, counters=None,
+               n_visible_on_device=False):
     """-> (attrs f32[M,16], num_overlap_tiles i32[M], num_owned_tiles i32[M], block_sums, block_sums_full).
     Normalises features[ids, 0:4] IN PLACE (RAS:196-205).  num_overlap_tiles is the reference's box count
     (hook output; its scan gives the backward slots); num_owned_tiles is the number of keys emitted (after
@@ -90,8 +95,8 @@ def preprocess(xyz, features, object_id, intrinsics, q_cp, t_cp, ids, width, hei
     block_sums = torch.empty((m + _PRE_BLOCK - 1) // _PRE_BLOCK, dtype=torch.int32, device=dev)
     block_sums_full = torch.empty_like(block_sums)
     call("gs_preprocess", ptr(xyz), ptr(features), ptr(object_id), ptr(intrinsics), ptr(q_cp), ptr(t_cp), ptr(ids),
-         m, int(width), int(height), int(tile_row_begin), int(tile_row_step), int(bool(exact_tile_cull)),
-         float(depth_to_sort_key_scale), ptr(counters), ptr(attrs), ptr(ntiles), ptr(nowned), ptr(block_sums),
+         m, int(bool(n_visible_on_device)), int(width), int(height), int(tile_row_begin), int(tile_row_step),
+         int(bool(exact_tile_cull)), float(depth_to_sort_key_scale), ptr(counters), ptr(attrs), ptr(ntiles), ptr(nowned), ptr(block_sums),
          ptr(block_sums_full), current_stream(dev))
     return attrs, ntiles, nowned, block_sums, block_sums_full
 
@@ -109,7 +114,9 @@ def scan_block_sums(block_sums: torch.Tensor, counters: torch.Tensor,
     k, n_slots = host[COUNTER_NUM_KEYS], host[COUNTER_NUM_SLOTS]
     if k >= 0x7fffffff or n_slots >= 0x7fffffff:
         raise RuntimeError("more than 2^31-1 (tile, Gaussian) pairs: key offsets are int32 as in the reference")
-    return k if block_sums_full is None else (k, n_slots, host[COUNTER_MAX_DEPTH_KEY])
+    if block_sums_full is None:
+        return k
+    return k, n_slots, host[COUNTER_MAX_DEPTH_KEY], host[COUNTER_NUM_VISIBLE]
 
 
 def make_keys(attrs, num_owned_tiles, block_offsets, n_keys, width, height, depth_to_sort_key_scale,

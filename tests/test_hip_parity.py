@@ -465,7 +465,8 @@ def test_headline_size_properties(ops):
     assert torch.allclose(feat[ids.long(), :4].norm(dim=1), torch.ones(ids.shape[0], device="cuda"), atol=1e-6)
     assert (nowned <= ntiles).all()
     total = int(nowned.sum().item())
-    k, n_slots, _ = ops.scan_block_sums(block_sums, counters, block_sums_full)
+    k, n_slots, _, m_dev = ops.scan_block_sums(block_sums, counters, block_sums_full)
+    assert m_dev == ids.shape[0]
     assert k == total and n_slots == int(ntiles.sum().item())
     num_tiles = (s.width // 16) * (s.height // 16)
     kdb, db, tb = ops.key_layout(s.near_plane, s.far_plane, s.depth_to_sort_key_scale, num_tiles, max_dq)
