@@ -318,35 +318,12 @@ __global__ __launch_bounds__(GS_BLOCK) void preprocess_kernel(
         float rescale = sqrtf(fmaxf(0.0f, det0 / det));
         float inv = 1.0f / det;
 
-        // colour: RAS:280-282,302-310; ray origin = (-R^T) t (UTL:495-510)
-        float ro[3];
-#pragma unroll
-        for (int k = 0; k < 3; ++k)
-            ro[k] = ((-W.m[k]) * t[0] + (-W.m[3 + k]) * t[1]) + (-W.m[6 + k]) * t[2];
-        float dir[3] = {p[0] - ro[0], p[1] - ro[1], p[2] - ro[2]}, Y[16];
-        sh_basis(dir, Y);
-        float rgb[3];
-#pragma unroll
-        for (int ch = 0; ch < 3; ++ch) {
-            float s = f[8 + 16 * ch] * Y[0];
-#pragma unroll
-            for (int k = 1; k < 16; ++k) s = s + f[8 + 16 * ch + k] * Y[k];
-            rgb[ch] = sigmoidf(s);
-        }
         // RAS:311-315 radius from the un-filtered covariance
         float dd = cov[0] - cov[3];
         float lam = (cov[0] + cov[3] + sqrtf(dd * dd + 4.0f * cov[1] * cov[2])) / 2.0f;
         float radius = sqrtf(lam) * 3.0f;
-
-        float4 *out = reinterpret_cast<float4 *>(attrs + (size_t)GS_ATTR_STRIDE * i);
-        out[0] = make_float4(uv[0], uv[1], c[2], 1.f / (1.f + expf(-f[7])));
-        out[1] = make_float4(inv * cd, inv * (-cov[1]), inv * ca, rescale);
-        out[2] = make_float4(rgb[0], rgb[1], rgb[2], radius);
-        {   // forward-blend form of the same weight: amp * 2^(dx*(A'dx + B'dy) + C'dy^2)
-            const float log2e = 1.4426950408889634f;
-            out[3] = make_float4((-0.5f * log2e) * out[1].x, (-log2e) * out[1].y, (-0.5f * log2e) * out[1].z,
-                                 out[0].w * rescale);
-        }
+        const float opacity = 1.f / (1.f + expf(-f[7]));  // RAS:299-300
+        const float cA = inv * cd, cB = inv * (-cov[1]), cC = inv * ca;
 
         int t0u, t1u, t0v, t1v, first;
         tile_box(uv[0], uv[1], radius, width / GS_TILE_WIDTH, height / GS_TILE_HEIGHT, t0u, t1u, t0v, t1v);
@@ -354,12 +331,40 @@ __global__ __launch_bounds__(GS_BLOCK) void preprocess_kernel(
         ntiles_full[i] = full;
         owned = (t1u - t0u) * owned_rows(t0v, t1v, row_begin, row_step, &first);
         if (cull && owned > 0) {
-            const float qmax = cull_qmax(1.f / (1.f + expf(-f[7])), rescale);
-            const float cA = inv * cd, cB = inv * (-cov[1]), cC = inv * ca;
+            const float qmax = cull_qmax(opacity, rescale);
             owned = 0;
             for (int tu = t0u; tu < t1u; ++tu)
                 for (int tv = first; tv < t1v; tv += row_step)
                     owned += tile_may_contribute(uv[0], uv[1], cA, cB, cC, qmax, tu, tv) ? 1 : 0;
+        }
+
+        float4 *out = reinterpret_cast<float4 *>(attrs + (size_t)GS_ATTR_STRIDE * i);
+        out[0] = make_float4(uv[0], uv[1], c[2], opacity);  // always: the hook exposes uv and depth of every
+                                                            // visible point (RAS:1138-1139)
+        if (owned > 0) {
+            // Only Gaussians that emit at least one key on this GPU are ever gathered by the blend kernels:
+            // the SH colour (the most expensive part) and the rest of the record are skipped otherwise
+            // (tile-row sharding: most Gaussians touch the rows of only one or two of the G GPUs).
+            // colour: RAS:280-282,302-310; ray origin = (-R^T) t (UTL:495-510)
+            float ro[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+                ro[k] = ((-W.m[k]) * t[0] + (-W.m[3 + k]) * t[1]) + (-W.m[6 + k]) * t[2];
+            float dir[3] = {p[0] - ro[0], p[1] - ro[1], p[2] - ro[2]}, Y[16];
+            sh_basis(dir, Y);
+            float rgb[3];
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) {
+                float s = f[8 + 16 * ch] * Y[0];
+#pragma unroll
+                for (int k = 1; k < 16; ++k) s = s + f[8 + 16 * ch + k] * Y[k];
+                rgb[ch] = sigmoidf(s);
+            }
+            out[1] = make_float4(cA, cB, cC, rescale);
+            out[2] = make_float4(rgb[0], rgb[1], rgb[2], radius);
+            // forward-blend form of the same weight: amp * 2^(dx*(A'dx + B'dy) + C'dy^2)
+            const float log2e = 1.4426950408889634f;
+            out[3] = make_float4((-0.5f * log2e) * cA, (-log2e) * cB, (-0.5f * log2e) * cC, opacity * rescale);
         }
         ntiles_owned[i] = owned;
     }

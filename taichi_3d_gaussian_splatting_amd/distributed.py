@@ -27,11 +27,11 @@ def owned_tile_rows(num_tile_rows: int, rank: int, world: int) -> range:
 
 
 def all_gather_tile_rows(tensors: Sequence[torch.Tensor], rank: int, world: int,
-                         group: Optional[dist.ProcessGroup] = None) -> None:
+                         group: Optional[dist.ProcessGroup] = None, force: bool = False) -> None:
     """In place: every tensor is [H, W, ...] with only this rank's tile rows valid; after the call all
     rows are valid on every rank.  One collective per call: the per-rank blocks of all tensors are
     packed into one byte buffer (fewer, larger collectives)."""
-    if world == 1:
+    if world == 1 and not force:  # force: issue the collective anyway (single-GPU test of the RCCL call path)
         return
     height = tensors[0].shape[0]
     th = height // TILE_HEIGHT
@@ -71,11 +71,11 @@ def all_reduce_accumulators(acc: torch.Tensor, group: Optional[dist.ProcessGroup
     acc[:, 10] = npix.view(torch.float32)
 
 
-def shard_rasteriser_across_tile_rows(rasteriser, group: Optional[dist.ProcessGroup] = None):
+def shard_rasteriser_across_tile_rows(rasteriser, group: Optional[dist.ProcessGroup] = None, force: bool = False):
     """Configure a ``GaussianPointCloudRasterisation`` instance for tile-row sharding over ``group``."""
     rank, world = dist.get_rank(group), dist.get_world_size(group)
     rasteriser.tile_row_begin, rasteriser.tile_row_step = rank, world
-    if world > 1:
-        rasteriser.image_gather = lambda tensors: all_gather_tile_rows(tensors, rank, world, group)
+    if world > 1 or force:
+        rasteriser.image_gather = lambda tensors: all_gather_tile_rows(tensors, rank, world, group, force)
         rasteriser.grad_accumulator_reduce = lambda acc: all_reduce_accumulators(acc, group)
     return rasteriser

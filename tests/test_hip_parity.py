@@ -72,11 +72,16 @@ def test_preprocess(ops, scene, ofwd):
     assert a.shape[1] == 16
     # projection is evaluated in the oracle's operation order with contraction off: bit-exact
     assert np.array_equal(a[:, 0:3], ref[:, 0:3]), "uv / depth must be bit-exact"
+    # rows 1-3 of the record are only written for Gaussians that emit at least one key (they are never
+    # gathered otherwise); with the cull off that is every Gaussian whose tile box is not empty
+    emits = ofwd["num_overlap_tiles"] > 0
+    report("preprocess.emitting", fraction=float(emits.mean()))
     for name, sl, rtol in (("opacity", slice(3, 4), 1e-6), ("conic", slice(4, 7), 2e-5), ("rescale", slice(7, 8), 2e-5),
                            ("rgb", slice(8, 11), 2e-6), ("radius", slice(11, 12), 1e-5),
                            ("prescaled_conic", slice(12, 15), 2e-5), ("amp", slice(15, 16), 2e-5)):
-        frac = close_fraction(a[:, sl], ref[:, sl], rtol=rtol, atol=1e-7)
-        report(f"preprocess.{name}", close=frac, max_abs=float(np.abs(a[:, sl] - ref[:, sl]).max()))
+        rows = slice(None) if name == "opacity" else emits
+        frac = close_fraction(a[rows, sl], ref[rows, sl], rtol=rtol, atol=1e-7)
+        report(f"preprocess.{name}", close=frac, max_abs=float(np.abs(a[rows, sl] - ref[rows, sl]).max()))
         assert frac == 1.0, name
     # in-place quaternion normalisation of visible rows only (RAS:196-205)
     f_hip, f_ref = feat.cpu().numpy(), ofwd["feat"]
@@ -324,15 +329,16 @@ def test_point_backward_sh_band_clearing(ops, scene, ofwd, obwd, band, keep):
 
 
 # ------------------------------------------------------------------------------- whole operator
-def _run_operator(scene, grad_image, band=3, hook=None, row=(0, 1)):
+def _run_operator(scene, grad_image, band=3, hook=None, row=(0, 1), op=None):
     from taichi_3d_gaussian_splatting_amd import CameraInfo, GaussianPointCloudRasterisation as Op
     s = scene.to("cuda")
     xyz = s.point_cloud.clone().requires_grad_(True)
     feat = s.point_cloud_features.clone().requires_grad_(True)
-    op = Op(Op.GaussianPointCloudRasterisationConfig(near_plane=s.near_plane, far_plane=s.far_plane,
-                                                     depth_to_sort_key_scale=s.depth_to_sort_key_scale),
-            backward_valid_point_hook=hook)
-    op.tile_row_begin, op.tile_row_step = row
+    if op is None:
+        op = Op(Op.GaussianPointCloudRasterisationConfig(near_plane=s.near_plane, far_plane=s.far_plane,
+                                                         depth_to_sort_key_scale=s.depth_to_sort_key_scale),
+                backward_valid_point_hook=hook)
+        op.tile_row_begin, op.tile_row_step = row
     inp = Op.GaussianPointCloudRasterisationInput(
         point_cloud=xyz, point_cloud_features=feat, point_object_id=s.point_object_id,
         point_invalid_mask=s.point_invalid_mask,
@@ -494,3 +500,42 @@ def test_headline_size_properties(ops):
     assert (last_eff >= start[tid]).all() and (last_eff <= end[tid]).all()
     assert (count <= last_eff - start[tid]).all()
     report("headline.sizes", M=ids.shape[0], K_reference=int(ntiles.sum().item()), K_after_cull=k)
+
+
+def test_rccl_collectives_on_device_world1():
+    """The collectives of the tile-row sharded path issued through RCCL (backend "nccl") on HIP tensors.
+    World size 1 (one GPU per gpurun box): exercises process-group init, dtypes and call shapes of
+    all_gather_into_tensor / all_reduce on the device; the multi-rank logic is covered by the gloo tests."""
+    import os
+    import socket
+    import torch.distributed as dist
+    from taichi_3d_gaussian_splatting_amd import distributed as D
+    from taichi_3d_gaussian_splatting_amd.synthetic import make_grad_image
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        h, w = 80, 64
+        image = torch.rand(h, w, 3, device="cuda"); depth = torch.rand(h, w, device="cuda")
+        count = torch.randint(0, 99, (h, w), device="cuda", dtype=torch.int32)
+        ref = [t.clone() for t in (image, depth, count)]
+        D.all_gather_tile_rows([image, depth, count], 0, 1, force=True)
+        assert all(torch.equal(a, b) for a, b in zip(ref, (image, depth, count)))
+        acc = torch.rand(1000, 12, device="cuda")
+        acc[:, 10] = torch.randint(0, 5000, (1000,), device="cuda", dtype=torch.int32).view(torch.float32)
+        ref_acc = acc.clone()
+        D.all_reduce_accumulators(acc)
+        assert torch.equal(acc.view(torch.int32), ref_acc.view(torch.int32))
+        # the sharded operator end to end under a (trivial) process group
+        s = small_scene(n=2000, size=128, seed=9)
+        g = make_grad_image(128, 128)
+        base = _run_operator(s, g)
+        from taichi_3d_gaussian_splatting_amd import GaussianPointCloudRasterisation as Op
+        op = D.shard_rasteriser_across_tile_rows(Op(Op.GaussianPointCloudRasterisationConfig()), force=True)
+        assert op.image_gather is not None and op.grad_accumulator_reduce is not None
+        sharded = _run_operator(s, g, op=op)
+        assert torch.equal(base[0], sharded[0]) and torch.equal(base[4].grad, sharded[4].grad)
+    finally:
+        dist.destroy_process_group()
