@@ -185,7 +185,10 @@ __global__ __launch_bounds__(BWD_THREADS) void blend_backward_kernel(
 
     const int last0 = last_effective[p], last1 = last_effective[p + 1];
     v2f T = {1.0f - acc_alpha[p], 1.0f - acc_alpha[p + 1]};
-    v2f wr = splat(0.f), wg = splat(0.f), wb = splat(0.f);
+    // S = sum_{j behind i} (c_j . G) a_j T_j: the reference keeps the colour-space suffix sum w_i (RAS:652-656)
+    // and dots it with dL/dimage; only that dot product is ever used, so the scalar is carried instead
+    // (same quantity re-associated: 6 instead of 12 flops per hit).
+    v2f S = splat(0.f);
     const float *gi = grad_image + 3 * p;
     const v2f Gr = {gi[0], gi[3]}, Gg = {gi[1], gi[4]}, Gb = {gi[2], gi[5]};
     v2f mag_u = splat(0.f), mag_v = splat(0.f);
@@ -194,6 +197,7 @@ __global__ __launch_bounds__(BWD_THREADS) void blend_backward_kernel(
     int mx = max(last0, last1);
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) mx = max(mx, __shfl_xor(mx, d, GS_WAVE));
+    const int wave_end = mx;  // no pixel of THIS wave touches an entry at or beyond wave_end
     if (lane == 0) s_max[tid >> 6] = mx;
     __syncthreads();
     const int end = max(s_max[0], s_max[1]);
@@ -221,6 +225,7 @@ __global__ __launch_bounds__(BWD_THREADS) void blend_backward_kernel(
         __syncthreads();
         const int n = min(BWD_BATCH, top - start);
         for (int k = 0; k < n; k += GROUP) {
+            if (top - 1 - (k + GROUP - 1) >= wave_end) continue;  // the whole group lies behind this wave's pixels
             // group evaluation: LDS reads + exp of GROUP entries are independent and overlap
             v2f g[GROUP], m0[GROUP], m1[GROUP], pa[GROUP];
             float op[GROUP];
@@ -255,10 +260,10 @@ __global__ __launch_bounds__(BWD_THREADS) void blend_backward_kernel(
                 const v2f aT = alpha * T;
                 const float4 c = s_c[k + i];
                 const v2f gr = aT * Gr, gg = aT * Gg, gb = aT * Gb;
-                v2f dLda = fma2(fma2(splat(c.z), T, -(wb * inv1m)), Gb,
-                                fma2(fma2(splat(c.y), T, -(wg * inv1m)), Gg, fma2(splat(c.x), T, -(wr * inv1m)) * Gr));
-                dLda = dLda * h;
-                wr = fma2(splat(c.x), aT, wr); wg = fma2(splat(c.y), aT, wg); wb = fma2(splat(c.z), aT, wb);
+                // dL/dalpha = sum_c (c_c T - w_c/(1-alpha)) G_c = T (c.G) - S/(1-alpha)       (RAS:652-657)
+                const v2f cg = fma2(splat(c.z), Gb, fma2(splat(c.y), Gg, splat(c.x) * Gr));
+                const v2f dLda = fma2(T, cg, -(S * inv1m)) * h;
+                S = fma2(cg, aT, S);
                 const v2f gl = dLda * g[i] * splat((1.f - op[i]) * op[i]);
                 const v2f dLdg = dLda * splat(op[i]);
                 const v2f gm0 = g[i] * m0[i], gm1 = g[i] * m1[i];
@@ -321,14 +326,22 @@ __global__ __launch_bounds__(GS_BLOCK) void reduce_partials_kernel(
     float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0;
     float gl = 0.f, nv = 0.f;
     int npix = 0;
-    for (int r = 0; r < n; ++r) {
-        if (slot_flags[base + r] == 0) continue;
-        const float4 *src = partials + 3 * (size_t)(base + r);
-        const float4 p0 = src[0], p1 = src[1], p2 = src[2];
-        a0.x += p0.x; a0.y += p0.y; a0.z += p0.z; a0.w += p0.w;
-        a1.x += p1.x; a1.y += p1.y; a1.z += p1.z; a1.w += p1.w;
-        gl += p2.x; nv += p2.y;
-        npix += __builtin_bit_cast(int, p2.z);
+    // two phases per chunk of 32 slots: gather the flags into a bit mask (independent byte loads), then visit
+    // only the raised slots (independent 48-B loads) -- keeps many loads in flight instead of one at a time
+    for (int r0 = 0; r0 < n; r0 += 32) {
+        const int cnt = min(32, n - r0);
+        unsigned mask = 0u;
+        for (int r = 0; r < cnt; ++r) mask |= (slot_flags[base + r0 + r] != 0 ? 1u : 0u) << r;
+        while (mask) {
+            const int r = __builtin_ctz(mask);
+            mask &= mask - 1;
+            const float4 *src = partials + 3 * (size_t)(base + r0 + r);
+            const float4 p0 = src[0], p1 = src[1], p2 = src[2];
+            a0.x += p0.x; a0.y += p0.y; a0.z += p0.z; a0.w += p0.w;
+            a1.x += p1.x; a1.y += p1.y; a1.z += p1.z; a1.w += p1.w;
+            gl += p2.x; nv += p2.y;
+            npix += __builtin_bit_cast(int, p2.z);
+        }
     }
     acc[3 * (size_t)i] = a0;
     acc[3 * (size_t)i + 1] = a1;

@@ -188,16 +188,15 @@ __global__ __launch_bounds__(GS_BLOCK) void point_backward_kernel(
 
 // Zero rows of the dense gradients for points that are NOT visible (RAS:1051-1053 zero-initialises
 // everything; the visible rows are fully written by point_backward_kernel, so only the others need zeros).
-// 14 lanes per 224-B row -> coalesced 16-B stores.
 __global__ __launch_bounds__(GS_BLOCK) void zero_invisible_rows_kernel(const int8_t *__restrict__ mask, int n,
                                                                       float4 *__restrict__ grad_feat4,
                                                                       float *__restrict__ grad_xyz) {
-    const long long t = (long long)blockIdx.x * GS_BLOCK + threadIdx.x;
-    const long long row = t / 16;
-    const int c = (int)(t % 16);
+    const int row = blockIdx.x * GS_BLOCK + threadIdx.x;
     if (row >= n || mask[row] != 0) return;
-    if (c < 14) grad_feat4[row * 14 + c] = make_float4(0.f, 0.f, 0.f, 0.f);
-    else if (c == 14) { grad_xyz[3 * row] = 0.f; grad_xyz[3 * row + 1] = 0.f; grad_xyz[3 * row + 2] = 0.f; }
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int c = 0; c < 14; ++c) grad_feat4[(size_t)row * 14 + c] = z;
+    grad_xyz[3 * (size_t)row] = 0.f; grad_xyz[3 * (size_t)row + 1] = 0.f; grad_xyz[3 * (size_t)row + 2] = 0.f;
 }
 
 }  // namespace
@@ -213,7 +212,7 @@ extern "C" int gs_point_backward(const float *xyz, const float *features, const 
     GS_REQUIRE(n_visible >= 0 && n_points >= n_visible, "sizes");
     hipStream_t s = (hipStream_t)stream;
     if (n_points > 0 && visible_mask != nullptr && n_visible > 0) {
-        hipLaunchKernelGGL(zero_invisible_rows_kernel, dim3(gs_div_up(16LL * n_points, GS_BLOCK)), dim3(GS_BLOCK), 0, s,
+        hipLaunchKernelGGL(zero_invisible_rows_kernel, dim3(gs_div_up(n_points, GS_BLOCK)), dim3(GS_BLOCK), 0, s,
                            visible_mask, n_points, reinterpret_cast<float4 *>(grad_features), grad_xyz);
         GS_CHECK_LAUNCH();
     } else if (n_points > 0) {
