@@ -36,29 +36,25 @@ def all_gather_tile_rows(tensors: Sequence[torch.Tensor], rank: int, world: int,
     height = tensors[0].shape[0]
     th = height // TILE_HEIGHT
     max_rows = (th + world - 1) // world
-    views, chunks = [], []
+    rows_mine = len(owned_tile_rows(th, rank, world))
+    views, spans, total = [], [], 0
     for t in tensors:
         assert t.shape[0] == height and t.is_contiguous()
         v = t.view(th, -1)  # one row of tiles = 16 image rows, contiguous
-        views.append(v)
-        mine = v[rank::world]
-        pad = torch.zeros((max_rows, v.shape[1]), dtype=v.dtype, device=v.device)
-        pad[: mine.shape[0]] = mine
-        chunks.append(pad.view(torch.uint8).reshape(-1))
-    send = torch.cat(chunks)
-    recv_flat = torch.empty(world * send.numel(), dtype=torch.uint8, device=send.device)
-    dist.all_gather_into_tensor(recv_flat, send, group=group)
-    recv = recv_flat.view(world, send.numel())
-    offset = 0
-    for v in views:
         nbytes = max_rows * v.shape[1] * v.element_size()
-        block = recv[:, offset: offset + nbytes].reshape(world, -1).view(v.dtype).reshape(world, max_rows, v.shape[1])
-        for r in range(world):
-            if r == rank:
-                continue
-            rows = len(owned_tile_rows(th, r, world))
-            v[r::world] = block[r, :rows]
-        offset += nbytes
+        views.append(v)
+        spans.append((total, nbytes))
+        total += nbytes
+    dev = tensors[0].device
+    send = torch.empty(total, dtype=torch.uint8, device=dev)
+    for v, (off, nbytes) in zip(views, spans):  # one strided copy per tensor into the packed send buffer
+        send[off: off + nbytes].view(v.dtype).view(max_rows, v.shape[1])[:rows_mine].copy_(v[rank::world])
+    recv = torch.empty(world * total, dtype=torch.uint8, device=dev)
+    dist.all_gather_into_tensor(recv, send, group=group)
+    recv2d = recv.view(world, total)
+    for v, (off, nbytes) in zip(views, spans):  # one copy per tensor: [G, rows, len] -> interleaved rows
+        block = recv2d[:, off: off + nbytes].view(v.dtype).unflatten(1, (max_rows, v.shape[1]))
+        v.copy_(block.permute(1, 0, 2).reshape(max_rows * world, v.shape[1])[:th])
 
 
 def all_reduce_accumulators(acc: torch.Tensor, group: Optional[dist.ProcessGroup] = None) -> None:
