@@ -50,7 +50,8 @@ def algorithmic_bytes(n, m, k, p, key_bytes=8):
         "sort_pairs": 2 * pair * k,
         "tile_ranges": key_bytes * k,
         "blend_forward": 48 * k + 28 * p,
-        "blend_backward": 44 * k + 28 * p + 48 * m,
+        "blend_backward": 44 * k + 28 * p + 48 * m,   # list re-gather, per-pixel in/out, one record per Gaussian
+        "reduce_partials": 48 * m + 8 * m,            # (the slot records themselves are blend_backward's output)
         "point_backward": 244 * m + 48 * m + 248 * n,
     }
 
@@ -163,8 +164,9 @@ def main() -> None:
             start, end = timed("tile_ranges", lambda: hip_ops.tile_ranges(keys, num_tiles, kdb))
             image, depth, acc_alpha, last_eff, count = timed("blend_forward", lambda: hip_ops.blend_forward(
                 start, end, payload, attrs, s.width, s.height, rb, rs))
-            acc, mag = timed("blend_backward", lambda: hip_ops.blend_backward(
-                start, end, payload, attrs, grad_image, acc_alpha, last_eff, slot_off, ntiles, n_slots, s.width, s.height, rb, rs))
+            partials, flags, mag = timed("blend_backward", lambda: hip_ops.blend_backward_partials(
+                start, end, payload, attrs, grad_image, acc_alpha, last_eff, slot_off, n_slots, s.width, s.height, rb, rs))
+            acc = timed("reduce_partials", lambda: hip_ops.reduce_partials(slot_off, ntiles, flags, partials))
             timed("point_backward", lambda: hip_ops.point_backward(
                 s.point_cloud, f, s.point_object_id, s.camera_intrinsics, q_cp, t_cp, s.t_pointcloud_camera, ids,
                 acc, 3, cfg.grad_q_factor, cfg.grad_s_factor, cfg.grad_alpha_factor, cfg.grad_color_factor,

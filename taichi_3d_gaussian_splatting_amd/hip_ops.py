@@ -215,26 +215,38 @@ def blend_forward(tile_start, tile_end, payload, attrs, width, height, tile_row_
     return out
 
 
-def blend_backward(tile_start, tile_end, payload, attrs, grad_image, acc_alpha, last_eff, slot_offsets,
-                   num_overlap_tiles, n_slots, width, height, tile_row_begin=0, tile_row_step=1):
-    """-> (acc f32[M,12], magnitude_grad_viewspace_on_image f32[H,W,2]).
-    Two launches: the per-pixel pass stores one partial record per (Gaussian, tile) slot (no atomics), then the
-    per-Gaussian slot reduction produces acc."""
+def blend_backward_partials(tile_start, tile_end, payload, attrs, grad_image, acc_alpha, last_eff, slot_offsets,
+                            n_slots, width, height, tile_row_begin=0, tile_row_step=1):
+    """Per-pixel backward pass -> (partials f32[S,12], slot_flags u8[S], magnitude image f32[H,W,2]): one partial
+    record per (Gaussian, tile) slot, plain stores, no atomics."""
     dev = attrs.device
-    m = attrs.shape[0]
     grad_image = _f32(grad_image, "grad_rasterized_image")
     partials = torch.empty((max(int(n_slots), 1), ACC_STRIDE), dtype=torch.float32, device=dev)
     flags = torch.empty(max(int(n_slots), 1), dtype=torch.uint8, device=dev)
-    acc = torch.empty((m, ACC_STRIDE), dtype=torch.float32, device=dev)
     alloc = torch.empty if tile_row_step == 1 else torch.zeros
     mag = alloc((height, width, 2), dtype=torch.float32, device=dev)
-    stream = current_stream(dev)
     call("gs_blend_backward", ptr(tile_start), ptr(tile_end), ptr(payload), ptr(attrs), ptr(grad_image),
          ptr(acc_alpha), ptr(last_eff), ptr(slot_offsets), int(n_slots), int(width), int(height),
-         int(tile_row_begin), int(tile_row_step), ptr(partials), ptr(flags), ptr(mag), stream)
+         int(tile_row_begin), int(tile_row_step), ptr(partials), ptr(flags), ptr(mag), current_stream(dev))
+    return partials, flags, mag
+
+
+def reduce_partials(slot_offsets, num_overlap_tiles, flags, partials):
+    """Per-Gaussian sum of its flagged slots, in slot order -> acc f32[M,12]."""
+    m = slot_offsets.shape[0]
+    acc = torch.empty((m, ACC_STRIDE), dtype=torch.float32, device=partials.device)
     call("gs_reduce_partials", ptr(slot_offsets), ptr(num_overlap_tiles), ptr(flags), ptr(partials), m, ptr(acc),
-         stream)
-    return acc, mag
+         current_stream(partials.device))
+    return acc
+
+
+def blend_backward(tile_start, tile_end, payload, attrs, grad_image, acc_alpha, last_eff, slot_offsets,
+                   num_overlap_tiles, n_slots, width, height, tile_row_begin=0, tile_row_step=1):
+    """-> (acc f32[M,12], magnitude_grad_viewspace_on_image f32[H,W,2]): blend_backward_partials + reduce_partials."""
+    partials, flags, mag = blend_backward_partials(tile_start, tile_end, payload, attrs, grad_image, acc_alpha,
+                                                   last_eff, slot_offsets, n_slots, width, height, tile_row_begin,
+                                                   tile_row_step)
+    return reduce_partials(slot_offsets, num_overlap_tiles, flags, partials), mag
 
 
 def point_backward(xyz, features, object_id, intrinsics, q_cp, t_cp, t_pc, ids, acc, color_max_sh_band,

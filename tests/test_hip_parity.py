@@ -655,3 +655,18 @@ def test_rasterisation_two_points_smoke():
     img = image.detach().cpu().numpy()
     assert np.abs(img - ref["image"]).max() <= PIXEL_TOL
     assert img[8, 8, 0] > 0.3 and count.max().item() == 1
+
+
+def test_operator_reference_key_layout_path():
+    """near_plane < 0 disables the compressed keys: the operator then sorts the reference's 64-bit
+    (tile << 32) + depth keys as signed integers (8 radix passes).  Same image and gradients as the oracle."""
+    from taichi_3d_gaussian_splatting_amd.synthetic import make_grad_image
+    from taichi_3d_gaussian_splatting_amd import hip_ops
+    s = small_scene(n=3000, size=128, seed=4, near_plane=-1.0)
+    assert hip_ops.key_layout(s.near_plane, s.far_plane, s.depth_to_sort_key_scale, 64)[0] == 0
+    f = oracle_forward(s)
+    g = make_grad_image(128, 128)
+    ob = O.backward(f, g.numpy(), 3)
+    image, depth, count, xyz, feat = _run_operator(s, g)
+    _check_image("key64.image", image.detach().cpu().numpy(), f["image"], f["margin"] < FRAGILE_MARGIN)
+    _check_acc("key64.grad_feat", feat.grad.cpu().numpy(), ob["grad_feat"])

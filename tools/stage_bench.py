@@ -44,8 +44,9 @@ for _ in range(reps + 2):
     start, end = timed("tile_ranges", lambda: hip_ops.tile_ranges(keys, num_tiles, kdb))
     image, depth, acc_alpha, last_eff, count = timed("blend_forward", lambda: hip_ops.blend_forward(
         start, end, payload, attrs, s.width, s.height))
-    acc, mag = timed("blend_backward", lambda: hip_ops.blend_backward(
-        start, end, payload, attrs, g, acc_alpha, last_eff, slot_off, ntiles, n_slots, s.width, s.height))
+    partials, flags, mag = timed("blend_backward", lambda: hip_ops.blend_backward_partials(
+        start, end, payload, attrs, g, acc_alpha, last_eff, slot_off, n_slots, s.width, s.height))
+    acc = timed("reduce_partials", lambda: hip_ops.reduce_partials(slot_off, ntiles, flags, partials))
     timed("point_backward", lambda: hip_ops.point_backward(
         s.point_cloud, feat, s.point_object_id, s.camera_intrinsics, q_cp, t_cp, s.t_pointcloud_camera, ids, acc, 3,
         1.0, 0.5, 20.0, 5.0, 1.0, False, vmask))
