@@ -67,6 +67,9 @@ def main() -> None:
     args = ap.parse_args()
 
     import torch.distributed as dist
+    from taichi_3d_gaussian_splatting_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH) and int(os.environ.get("LOCAL_RANK", "0")) == 0:
+        _lib.build()  # in-tree build of the HIP library (normally done by __graft_entry__.build())
     from taichi_3d_gaussian_splatting_amd import CameraInfo, GaussianPointCloudRasterisation as Op
     from taichi_3d_gaussian_splatting_amd import hip_ops
     from taichi_3d_gaussian_splatting_amd.distributed import shard_rasteriser_across_tile_rows

@@ -13,6 +13,14 @@ def pytest_configure(config):
 
 
 @pytest.fixture(scope="session", autouse=True)
-def _build_oracle():
+def _build_native():
+    """Build the checker (CPU oracle) and, if the in-tree library is missing or stale, the HIP library
+    (hipcc cross-compiles gfx950 without a GPU; the same image is on the GPU box)."""
     from oracle import gs_oracle
     gs_oracle.build()
+    from taichi_3d_gaussian_splatting_amd import _lib
+    csrc = os.path.join(ROOT, "taichi_3d_gaussian_splatting_amd", "csrc")
+    srcs = [os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith((".hip", ".h"))]
+    srcs.append(os.path.join(ROOT, "include", "gsplat_hip.h"))
+    if not os.path.exists(_lib.LIB_PATH) or os.path.getmtime(_lib.LIB_PATH) < max(map(os.path.getmtime, srcs)):
+        _lib.build()
