@@ -105,6 +105,10 @@ int gs_preprocess(const float *xyz, float *features, const int32_t *object_id,
  * Replaces torch.cumsum/cat, RAS:913-922. */
 int gs_scan_block_sums(int32_t *block_sums, int n_blocks, int32_t *counters, int counter_slot,
                        void *stream);
+/* Both scans of a frame in one launch: block_sums -> counters[GS_COUNTER_NUM_KEYS],
+ * block_sums_full -> counters[GS_COUNTER_NUM_SLOTS]. */
+int gs_scan_block_sums2(int32_t *block_sums, int32_t *block_sums_full, int n_blocks, int32_t *counters,
+                        void *stream);
 
 /* Sort-key generation.  Replaces generate_point_sort_key_by_num_overlap_tiles (RAS:131-172).
  * payload[k] = offset into the visible list.  Key layout:

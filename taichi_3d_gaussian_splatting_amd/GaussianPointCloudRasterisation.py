@@ -153,11 +153,16 @@ class GaussianPointCloudRasterisation(torch.nn.Module):
                 ctx.color_max_sh_band = color_max_sh_band
                 ctx.tile_rows = (row_begin, row_step)
                 ctx.mark_non_differentiable(count)
+                ctx.set_materialize_grads(False)  # no zero-filled dL/ddepth (it is ignored, RAS:1027)
                 return image, depth, count
 
             @staticmethod
             def backward(ctx, grad_rasterized_image, grad_rasterized_depth, grad_pixel_valid_point_count):
                 grad_pointcloud = grad_pointcloud_features = None
+                if grad_rasterized_image is None:  # only depth was used downstream: its gradient is ignored
+                    grad_rasterized_image = torch.zeros(
+                        (ctx.camera_info.camera_height, ctx.camera_info.camera_width, 3), dtype=torch.float32,
+                        device=ctx.saved_tensors[0].device)
                 if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:  # RAS:1028
                     (xyz, features, payload, ids, tile_start, tile_end, acc_alpha, last_eff, num_overlap_tiles,
                      obj, q_cp, t_cp, t_pc, attrs, intrinsics, slot_offsets, visible_mask) = ctx.saved_tensors

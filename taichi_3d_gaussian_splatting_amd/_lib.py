@@ -15,7 +15,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgsplat_hip.so")
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 _c = ctypes
 _P = _c.c_void_p
@@ -33,6 +33,7 @@ _SIGNATURES = {
     "gs_read_counters": (_I, [_P, _P, _I, _P]),
     "gs_preprocess": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _P, _P, _P, _P, _P, _P, _P]),
     "gs_scan_block_sums": (_I, [_P, _I, _P, _I, _P]),
+    "gs_scan_block_sums2": (_I, [_P, _P, _I, _P, _P]),
     "gs_make_keys": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _P, _P, _P, _P, _P, _P]),
     "gs_sort_workspace_bytes": (_c.c_size_t, [_I64]),
     "gs_sort_pairs": (_I, [_P, _P, _P, _P, _I64, _I, _I, _I, _I, _P, _P]),

@@ -196,10 +196,14 @@ __global__ __launch_bounds__(GS_BLOCK) void filter_kernel(
     if (threadIdx.x == 0) block_counts[blockIdx.x] = s_count;
 }
 
-// single-workgroup exclusive scan over n ints (in place); total -> *total_out (saturating)
+// single-workgroup exclusive scan over n ints (in place); total -> *total_out (saturating).
+// blockIdx.x == 1 scans the optional second array (two independent scans in one launch).
 __global__ __launch_bounds__(GS_BLOCK) void scan_single_block_kernel(int32_t *__restrict__ data, int n,
-                                                                    int32_t *__restrict__ total_out) {
+                                                                    int32_t *__restrict__ total_out,
+                                                                    int32_t *__restrict__ data2,
+                                                                    int32_t *__restrict__ total_out2) {
     __shared__ int lds[4];
+    if (blockIdx.x == 1) { data = data2; total_out = total_out2; }
     long long carry = 0;
     for (int base = 0; base < n; base += GS_BLOCK) {
         int i = base + threadIdx.x;
@@ -497,7 +501,7 @@ int gs_filter_compact(const float *xyz, const int8_t *invalid_mask, const int32_
                        q_cp, t_cp, n_points, near_plane, far_plane, width, height, mask, block_counts);
     GS_CHECK_LAUNCH();
     hipLaunchKernelGGL(scan_single_block_kernel, dim3(1), dim3(GS_BLOCK), 0, s, block_counts, nblk,
-                       counters + GS_COUNTER_NUM_VISIBLE);
+                       counters + GS_COUNTER_NUM_VISIBLE, (int32_t *)nullptr, (int32_t *)nullptr);
     GS_CHECK_LAUNCH();
     hipLaunchKernelGGL(compact_kernel, dim3(nblk), dim3(GS_BLOCK), 0, s, mask, n_points, block_counts, ids);
     GS_CHECK_LAUNCH();
@@ -539,7 +543,20 @@ int gs_scan_block_sums(int32_t *block_sums, int n_blocks, int32_t *counters, int
         return 0;
     }
     hipLaunchKernelGGL(scan_single_block_kernel, dim3(1), dim3(GS_BLOCK), 0, (hipStream_t)stream, block_sums,
-                       n_blocks, counters + counter_slot);
+                       n_blocks, counters + counter_slot, (int32_t *)nullptr, (int32_t *)nullptr);
+    GS_CHECK_LAUNCH();
+    return 0;
+}
+
+int gs_scan_block_sums2(int32_t *block_sums, int32_t *block_sums_full, int n_blocks, int32_t *counters,
+                        void *stream) {
+    GS_REQUIRE(n_blocks >= 0, "n_blocks");
+    if (n_blocks == 0) {
+        GS_CHECK_HIP(hipMemsetAsync(counters + GS_COUNTER_NUM_KEYS, 0, 2 * sizeof(int32_t), (hipStream_t)stream));
+        return 0;
+    }
+    hipLaunchKernelGGL(scan_single_block_kernel, dim3(2), dim3(GS_BLOCK), 0, (hipStream_t)stream, block_sums,
+                       n_blocks, counters + GS_COUNTER_NUM_KEYS, block_sums_full, counters + GS_COUNTER_NUM_SLOTS);
     GS_CHECK_LAUNCH();
     return 0;
 }
@@ -573,8 +590,12 @@ int gs_tile_ranges(const void *keys_sorted, int64_t n_keys, int key_depth_bits, 
     GS_REQUIRE(n_keys >= 0 && n_tiles > 0, "sizes");
     GS_REQUIRE(key_depth_bits >= 0 && key_depth_bits < 32, "key_depth_bits");
     hipStream_t s = (hipStream_t)stream;
-    GS_CHECK_HIP(hipMemsetAsync(tile_start, 0, sizeof(int32_t) * n_tiles, s));
-    GS_CHECK_HIP(hipMemsetAsync(tile_end, 0, sizeof(int32_t) * n_tiles, s));
+    if (tile_end == tile_start + n_tiles) {  // adjacent halves of one buffer: a single fill
+        GS_CHECK_HIP(hipMemsetAsync(tile_start, 0, 2 * sizeof(int32_t) * n_tiles, s));
+    } else {
+        GS_CHECK_HIP(hipMemsetAsync(tile_start, 0, sizeof(int32_t) * n_tiles, s));
+        GS_CHECK_HIP(hipMemsetAsync(tile_end, 0, sizeof(int32_t) * n_tiles, s));
+    }
     if (n_keys == 0) return 0;
     const dim3 grid(gs_div_up(n_keys, GS_BLOCK)), block(GS_BLOCK);
     if (key_depth_bits == 0)

@@ -106,10 +106,10 @@ def scan_block_sums(block_sums: torch.Tensor, counters: torch.Tensor,
     """In-place exclusive scans; returns K (and the number of backward slots when block_sums_full is given).
     Blocks on ONE size read-back (RAS:916)."""
     stream = current_stream(counters.device)
-    call("gs_scan_block_sums", ptr(block_sums), block_sums.shape[0], ptr(counters), COUNTER_NUM_KEYS, stream)
     if block_sums_full is not None:
-        call("gs_scan_block_sums", ptr(block_sums_full), block_sums_full.shape[0], ptr(counters),
-             COUNTER_NUM_SLOTS, stream)
+        call("gs_scan_block_sums2", ptr(block_sums), ptr(block_sums_full), block_sums.shape[0], ptr(counters), stream)
+    else:
+        call("gs_scan_block_sums", ptr(block_sums), block_sums.shape[0], ptr(counters), COUNTER_NUM_KEYS, stream)
     host = read_counters(counters)
     k, n_slots = host[COUNTER_NUM_KEYS], host[COUNTER_NUM_SLOTS]
     if k >= 0x7fffffff or n_slots >= 0x7fffffff:
@@ -191,8 +191,8 @@ def tile_ranges(keys_sorted: torch.Tensor, num_tiles: int, key_depth_bits: int =
     if keys_sorted.dtype != (torch.int64 if key_depth_bits == 0 else torch.int32):
         raise TypeError("key dtype does not match the key layout")
     dev = keys_sorted.device
-    start = torch.empty(num_tiles, dtype=torch.int32, device=dev)
-    end = torch.empty(num_tiles, dtype=torch.int32, device=dev)
+    both = torch.empty((2, num_tiles), dtype=torch.int32, device=dev)  # one buffer -> one fill in the library
+    start, end = both[0], both[1]
     call("gs_tile_ranges", ptr(keys_sorted), keys_sorted.shape[0], int(key_depth_bits), ptr(start), ptr(end),
          int(num_tiles), current_stream(dev))
     return start, end
