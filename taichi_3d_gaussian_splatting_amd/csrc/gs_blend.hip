@@ -264,14 +264,14 @@ __global__ __launch_bounds__(BWD_THREADS) void blend_backward_kernel(
                 const v2f cg = fma2(splat(c.z), Gb, fma2(splat(c.y), Gg, splat(c.x) * Gr));
                 const v2f dLda = fma2(T, cg, -(S * inv1m)) * h;
                 S = fma2(cg, aT, S);
-                const v2f gl = dLda * g[i] * splat((1.f - op[i]) * op[i]);
-                const v2f dLdg = dLda * splat(op[i]);
-                const v2f gm0 = g[i] * m0[i], gm1 = g[i] * m1[i];
-                const v2f v0 = dLdg * gm0, v1 = dLdg * gm1;
+                // w = dL/dg * g.  dL/dlogit = dL/dalpha * g * o(1-o) = (1-o) w and the factor 1/2 of dg/dcov are
+                // per-Gaussian constants: they are applied once per (tile, Gaussian) in the flush, after the sum.
+                const v2f w = dLda * splat(op[i]) * g[i];
+                const v2f v0 = w * m0[i], v1 = w * m1[i];  // dL/dmu = dL/dg * g * (conic @ d)   (UTL:343)
                 mag_u = mag_u + (v2f){fabsf(v0.x), fabsf(v0.y)};
                 mag_v = mag_v + (v2f){fabsf(v1.x), fabsf(v1.y)};
-                const v2f hh = splat(0.5f) * dLdg;
-                const v2f c00 = hh * gm0 * m0[i], c01 = hh * gm0 * m1[i], c11 = hh * gm1 * m1[i];
+                const v2f c00 = v0 * m0[i], c01 = v0 * m1[i], c11 = v1 * m1[i];  // 2 dL/dcov (UTL:345-346)
+                const v2f gl = w;
                 const v2f n2 = fma2(v1, v1, v0 * v0);
                 const v2f nv = {__builtin_amdgcn_sqrtf(n2.x), __builtin_amdgcn_sqrtf(n2.y)};  // v_sqrt_f32, 1 ulp
                 // in-lane pair sums, then the 10-value reduce-scatter over the 64 lanes (gs_common.h); row
@@ -302,9 +302,12 @@ __global__ __launch_bounds__(BWD_THREADS) void blend_backward_kernel(
                 const int slot = slot_offsets[s_o[tid]] + (t1v - t0v) * (tc.tile_u - t0u) + (tc.tile_v - t0v);
                 const float4 *S = reinterpret_cast<const float4 *>(&s_acc[tid][0]);
                 float4 *dst = partials + 3 * (size_t)slot;
-                dst[0] = S[0];
-                dst[1] = S[1];
-                dst[2] = S[2];
+                float4 r0 = S[0], r1 = S[1], r2 = S[2];
+                r0.z *= 0.5f; r0.w *= 0.5f; r1.x *= 0.5f;  // dg/dcov = 0.5 g (m m^T)
+                r2.x *= (1.f - a.w);                       // dL/dlogit = (1 - opacity) * sum(w)
+                dst[0] = r0;
+                dst[1] = r1;
+                dst[2] = r2;
                 slot_flags[slot] = 1;
             }
         }
