@@ -670,3 +670,27 @@ def test_operator_reference_key_layout_path():
     image, depth, count, xyz, feat = _run_operator(s, g)
     _check_image("key64.image", image.detach().cpu().numpy(), f["image"], f["margin"] < FRAGILE_MARGIN)
     _check_acc("key64.grad_feat", feat.grad.cpu().numpy(), ob["grad_feat"])
+
+
+def test_operator_degenerate_sizes():
+    """N = 0, and M > 0 with K = 0 (points inside the 48-px guard band but right of / below the image get an
+    empty tile box, Appendix A.3): zero image, zero gradients, hook still called with M rows."""
+    from taichi_3d_gaussian_splatting_amd import CameraInfo, GaussianPointCloudRasterisation as Op
+    cam = CameraInfo(torch.tensor([[48., 0, 32], [0, 48., 32], [0, 0, 1]], device="cuda"), 64, 64, 0)
+    q = torch.tensor([[0., 0., 0., 1.]], device="cuda"); t = torch.tensor([[0., 0., -3.]], device="cuda")
+    got = []
+    op = Op(Op.GaussianPointCloudRasterisationConfig(), backward_valid_point_hook=got.append)
+    for xyz0 in (torch.zeros(0, 3), torch.tensor([[4.4, 0.0, 0.0], [4.5, 4.5, 0.5]])):  # u = 32 + 48*4.4/3 = 102.4
+        n = xyz0.shape[0]
+        xyz = xyz0.cuda().requires_grad_(True)
+        feat = torch.zeros(n, 56, device="cuda"); feat[:, 3] = 1.0; feat[:, 4:7] = -6.0
+        feat.requires_grad_(True)
+        image, depth, count = op(Op.GaussianPointCloudRasterisationInput(
+            point_cloud=xyz, point_cloud_features=feat, point_object_id=torch.zeros(n, dtype=torch.int32, device="cuda"),
+            point_invalid_mask=torch.zeros(n, dtype=torch.int8, device="cuda"), camera_info=cam,
+            q_pointcloud_camera=q, t_pointcloud_camera=t))
+        image.sum().backward()
+        assert not image.any() and not depth.any() and not count.any()
+        assert xyz.grad.shape == (n, 3) and feat.grad.shape == (n, 56) and not feat.grad.any()
+    assert [int(h.point_id_in_camera_list.shape[0]) for h in got] == [0, 2]
+    assert got[1].num_overlap_tiles.tolist() == [0, 0]
