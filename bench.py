@@ -56,6 +56,22 @@ def algorithmic_bytes(n, m, k, p, key_bytes=8):
     }
 
 
+def profiled_traffic_bytes(kernel: str):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC summary (profiles/r01_hbm_traffic.csv:
+    separate --pmc FETCH_SIZE / WRITE_SIZE passes over this same command, tools/profile.sh), with the gfx950
+    correction of the MI355X guide (FETCH_SIZE counts 128-B requests as 64 B -> doubled).  None if absent."""
+    path = os.path.join(ROOT, "profiles", "r01_hbm_traffic.csv")
+    try:
+        import csv
+        with open(path) as fh:
+            for row in csv.DictReader(fh):
+                if row[""] == kernel + "_kernel":
+                    return int((float(row["hbm_read_MB_gfx950_corrected"]) + float(row["hbm_write_MB"])) * 1e6)
+    except (OSError, KeyError, ValueError):
+        pass
+    return None
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -186,7 +202,8 @@ def main() -> None:
         path_bytes = sum(bytes_per.values())
         roofline = {
             "bound": "hbm", "kernel": dominant, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-            "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+            "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
+            "traffic": profiled_traffic_bytes(dominant) if world == 1 and args.workload == "headline_1m_1080p" else None,
             "kernel_ms": round(stages_ms[dominant], 4),
             "algorithmic_bytes": int(bytes_per[dominant]),
             "path": {"algorithmic_bytes": int(path_bytes),
