@@ -185,6 +185,19 @@ int gs_point_backward(const float *xyz, const float *features, const int32_t *ob
                       float grad_high_order_color_factor, float *grad_xyz, float *grad_features,
                       float *grad_xyz_visible, float *grad_features_visible, void *stream);
 
+/* ---- adaptive-controller kernels (not on the per-frame hot path) ---------------- */
+
+/* Focal vector of every Gaussian's ellipsoid: sqrt(r_max^2 - r_min^2) along the rotated longest axis.
+ * Replaces compute_ellipsoid_offset (GaussianPointAdaptiveController.py:10-25, GaussianPoint3D.py:375-388).
+ * features float[n][56], offsets float[n][3]. */
+int gs_ellipsoid_offsets(const float *features, int n, float *offsets, void *stream);
+
+/* One sample per Gaussian from N(xyz, R S S^T R^T) by Box-Muller on caller-supplied uniforms
+ * (float[n][4], each in (0,1]).  Replaces sample_from_point (GaussianPointAdaptiveController.py:27-42,
+ * GaussianPoint3D.py:90-94,390-406), whose uniforms come from ti.random() inside the kernel. */
+int gs_sample_from_points(const float *xyz, const float *features, const float *uniforms, int n,
+                          float *samples, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -571,3 +571,37 @@ void gs_oracle_point_backward(const real *xyz, const real *feat, const int32_t *
         }
     }
 }
+
+/* ------------------------------------------------ adaptive-controller kernels (K9, K10) */
+/* GP3:375-388 get_ellipsoid_foci_vector (called by ADC:10-25) */
+void gs_oracle_ellipsoid_offsets(const real *feat, int n, real *out) {
+    for (int i = 0; i < n; ++i) {
+        const real *f = feat + (size_t)56 * i;
+        real sx = f[4], sy = f[5], sz = f[6];
+        int axis = 0;
+        if (sx < sy && sy > sz) axis = 1;
+        else if (sx < sz && sy < sz) axis = 2;
+        real R[9];
+        rotmat_from_q(f, R);
+        real ex = R_EXP(sx), ey = R_EXP(sy), ez = R_EXP(sz);
+        real rc = ex > ey ? (ex > ez ? ex : ez) : (ey > ez ? ey : ez);
+        real ra = ex < ey ? (ex < ez ? ex : ez) : (ey < ez ? ey : ez);
+        real len = R_SQRT(rc * rc - ra * ra);
+        for (int k = 0; k < 3; ++k) out[3 * i + k] = len * R[3 * k + axis];
+    }
+}
+/* GP3:390-406 sample (Box-Muller GP3:90-94) with the uniforms supplied by the caller (ADC:27-42) */
+void gs_oracle_sample_from_points(const real *xyz, const real *feat, const real *u, int n, real *out) {
+    const real two_pi = RC(2) * RC(3.141592653589);
+    for (int i = 0; i < n; ++i) {
+        const real *f = feat + (size_t)56 * i;
+        real r1 = R_SQRT(RC(-2) * (real)log((double)u[4 * i])), r2 = R_SQRT(RC(-2) * (real)log((double)u[4 * i + 2]));
+        real z1 = r1 * (real)cos((double)(two_pi * u[4 * i + 1])), z2 = r1 * (real)sin((double)(two_pi * u[4 * i + 1]));
+        real z3 = r2 * (real)cos((double)(two_pi * u[4 * i + 3]));
+        real R[9];
+        rotmat_from_q(f, R);
+        real b[3] = {R_EXP(f[4]) * z1, R_EXP(f[5]) * z2, R_EXP(f[6]) * z3};
+        for (int k = 0; k < 3; ++k)
+            out[3 * i + k] = xyz[3 * i + k] + ((R[3 * k] * b[0] + R[3 * k + 1] * b[1]) + R[3 * k + 2] * b[2]);
+    }
+}

@@ -221,3 +221,21 @@ def backward(fwd: dict, grad_image, color_max_sh_band: int = 2) -> dict:
                 num_overlap_tiles=fwd["num_overlap_tiles"], num_affected_pixels=npix,
                 point_depth=fwd["xyz_cam"][:, 2].copy(), point_uv_in_camera=fwd["uv"])
     return dict(grad_xyz=grad_xyz, grad_feat=grad_feat, acc=acc, hook=hook)
+
+
+def ellipsoid_offsets(feat, precision="f32"):
+    """GP3:375-388 / ADC:10-25."""
+    rt = _real(precision)
+    feat = np.ascontiguousarray(feat, dtype=rt)
+    out = np.empty((feat.shape[0], 3), rt)
+    _lib(precision).gs_oracle_ellipsoid_offsets(_p(feat), ctypes.c_int(feat.shape[0]), _p(out))
+    return out
+
+
+def sample_from_points(xyz, feat, uniforms, precision="f32"):
+    """GP3:390-406 / ADC:27-42 with caller-supplied uniforms [n,4]."""
+    rt = _real(precision)
+    xyz, feat, uniforms = (np.ascontiguousarray(a, dtype=rt) for a in (xyz, feat, uniforms))
+    out = np.empty((xyz.shape[0], 3), rt)
+    _lib(precision).gs_oracle_sample_from_points(_p(xyz), _p(feat), _p(uniforms), ctypes.c_int(xyz.shape[0]), _p(out))
+    return out

@@ -1,0 +1,367 @@
+"""Training loop around the rasteriser.
+
+Mirror of the reference's ``taichi_3d_gaussian_splatting/GaussianPointTrainer.py`` (TRN): same ``TrainConfig``
+fields and defaults (TRN:32-58), same schedule --
+
+* two Adam optimisers, features / positions (TRN:126-129), exponential decay of the position learning rate every
+  ``position_learning_rate_decay_interval`` iterations (TRN:131-132,181-182);
+* coarse-to-fine images: start at 1/``initial_downsample_factor`` and halve the factor every
+  ``half_downsample_factor_interval`` iterations, antialiased resize + crop to the 16-px tile grid (TRN:96-118,139-148);
+* spherical-harmonics band ``iteration // increase_color_max_sh_band_interval`` (TRN:163);
+* clamp to [0,1], HWC -> CHW, loss of ``LossFunction`` with the scale regulariser (TRN:167-175);
+* the adaptive controller is the rasteriser's backward hook and refines after the optimiser steps (TRN:85-88,192);
+* validation every ``val_interval`` iterations and at 5000 / 7000 (TRN:271-272): PSNR, SSIM, inference time,
+  ``scene_{iteration}.parquet`` and ``best_scene.parquet`` (TRN:334-415).
+
+MI355X-side choices: the scene lives on the HIP device, fused Adam kernels, no per-iteration host
+synchronisation (the loss is only read back at the logging interval, so the "problematic iteration" check of
+TRN:232-237 runs at that interval too), and -- when ``torch.distributed`` is initialised -- the rasteriser is
+sharded over tile rows (distributed.py) while loss, optimiser and controller run replicated and bit-identical
+on every rank.  TensorBoard and torchvision are optional: without ``tensorboard`` the scalars go to
+``metrics.jsonl`` and images to PNG files under the log directory; resizing uses ``F.interpolate(antialias=True)``
+(what torchvision's tensor resize calls).
+"""
+from __future__ import annotations
+
+import json
+import logging
+import os
+from collections import deque
+from dataclasses import dataclass, field
+from typing import Optional
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from .Camera import CameraInfo
+from .GaussianPointAdaptiveController import GaussianPointAdaptiveController
+from .GaussianPointCloudRasterisation import GaussianPointCloudRasterisation
+from .GaussianPointCloudScene import GaussianPointCloudScene
+from .ImagePoseDataset import ImagePoseDataset
+from .LossFunction import LossFunction, ssim
+from .yaml_config import YAMLConfig
+
+_log = logging.getLogger(__name__)
+TILE = 16
+
+
+def cycle(loader):
+    while True:
+        for item in loader:
+            yield item
+
+
+class _FileWriter:
+    """Stand-in for ``torch.utils.tensorboard.SummaryWriter`` when tensorboard is not installed: scalars and
+    histogram summaries as JSON lines, images as PNG files."""
+
+    def __init__(self, log_dir: str):
+        self.log_dir = log_dir
+        self._fh = open(os.path.join(log_dir, "metrics.jsonl"), "a")
+
+    def _emit(self, record: dict) -> None:
+        self._fh.write(json.dumps(record) + "\n")
+        self._fh.flush()
+
+    def add_scalar(self, tag: str, value, step: int) -> None:
+        self._emit({"tag": tag, "step": int(step), "value": float(value)})
+
+    def add_histogram(self, tag: str, values: torch.Tensor, step: int) -> None:
+        v = values.detach().float().flatten()
+        if v.numel() == 0:
+            return
+        q = torch.quantile(v[:: max(1, v.numel() // 100000)], torch.tensor([0.0, 0.5, 1.0], device=v.device))
+        self._emit({"tag": tag, "step": int(step), "mean": float(v.mean()), "min": float(q[0]),
+                    "median": float(q[1]), "max": float(q[2])})
+
+    def add_image(self, tag: str, chw: torch.Tensor, step: int) -> None:
+        import PIL.Image
+        arr = (chw.detach().clamp(0, 1).permute(1, 2, 0).cpu().numpy() * 255.0 + 0.5).astype(np.uint8)
+        name = tag.replace("/", "_").replace(" ", "_")
+        PIL.Image.fromarray(arr).save(os.path.join(self.log_dir, f"{name}_{int(step):07d}.png"))
+
+    def close(self) -> None:
+        self._fh.close()
+
+
+def _make_writer(log_dir: str):
+    try:
+        from torch.utils.tensorboard import SummaryWriter
+        return SummaryWriter(log_dir=log_dir)
+    except Exception:   # tensorboard missing (or broken): fall back to plain files
+        return _FileWriter(log_dir)
+
+
+def _image_grid(images, nrow: int = 2, pad: int = 2) -> torch.Tensor:
+    """Minimal ``torchvision.utils.make_grid`` for equally sized [3,H,W] tensors."""
+    h, w = images[0].shape[1:]
+    ncol = (len(images) + nrow - 1) // nrow
+    grid = torch.zeros(3, ncol * (h + pad) + pad, nrow * (w + pad) + pad, device=images[0].device)
+    for i, im in enumerate(images):
+        r, c = divmod(i, nrow)
+        grid[:, pad + r * (h + pad): pad + r * (h + pad) + h, pad + c * (w + pad): pad + c * (w + pad) + w] = im
+    return grid
+
+
+class GaussianPointCloudTrainer:
+    @dataclass
+    class TrainConfig(YAMLConfig):
+        train_dataset_json_path: str = ""
+        val_dataset_json_path: str = ""
+        pointcloud_parquet_path: str = ""
+        num_iterations: int = 300000
+        val_interval: int = 1000
+        feature_learning_rate: float = 1e-3
+        position_learning_rate: float = 1e-5
+        position_learning_rate_decay_rate: float = 0.97
+        position_learning_rate_decay_interval: int = 100
+        increase_color_max_sh_band_interval: int = 1000
+        log_loss_interval: int = 10
+        log_metrics_interval: int = 100
+        print_metrics_to_console: bool = False
+        log_image_interval: int = 1000
+        enable_taichi_kernel_profiler: bool = False      # accepted for YAML compatibility, unused (no Taichi)
+        log_taichi_kernel_profile_interval: int = 1000   # idem
+        log_validation_image: bool = True
+        initial_downsample_factor: int = 4
+        half_downsample_factor_interval: int = 250
+        summary_writer_log_dir: str = "logs"
+        output_model_dir: Optional[str] = None
+        rasterisation_config: GaussianPointCloudRasterisation.GaussianPointCloudRasterisationConfig = field(
+            default_factory=GaussianPointCloudRasterisation.GaussianPointCloudRasterisationConfig)
+        adaptive_controller_config: GaussianPointAdaptiveController.GaussianPointAdaptiveControllerConfig = field(
+            default_factory=GaussianPointAdaptiveController.GaussianPointAdaptiveControllerConfig)
+        gaussian_point_cloud_scene_config: GaussianPointCloudScene.PointCloudSceneConfig = field(
+            default_factory=GaussianPointCloudScene.PointCloudSceneConfig)
+        loss_function_config: LossFunction.LossFunctionConfig = field(
+            default_factory=LossFunction.LossFunctionConfig)
+        # additions (not in the reference)
+        num_data_loader_workers: int = 4
+        seed: int = 0
+
+    def __init__(self, config: "GaussianPointCloudTrainer.TrainConfig", device: Optional[torch.device] = None):
+        if not torch.cuda.is_available():
+            raise RuntimeError("GaussianPointCloudTrainer needs a HIP device: the rasteriser has no CPU path")
+        self.config = config
+        self.device = device or torch.device("cuda", torch.cuda.current_device())
+        self.rank = torch.distributed.get_rank() if torch.distributed.is_initialized() else 0
+        os.makedirs(config.summary_writer_log_dir, exist_ok=True)
+        if config.output_model_dir is None:
+            config.output_model_dir = config.summary_writer_log_dir
+        os.makedirs(config.output_model_dir, exist_ok=True)
+        self.writer = _make_writer(config.summary_writer_log_dir) if self.rank == 0 else None
+        torch.manual_seed(config.seed)   # the same stream on every rank keeps replicated refinement identical
+
+        self.train_dataset = ImagePoseDataset(dataset_json_path=config.train_dataset_json_path)
+        self.val_dataset = ImagePoseDataset(dataset_json_path=config.val_dataset_json_path)
+        self.scene = GaussianPointCloudScene.from_parquet(
+            config.pointcloud_parquet_path, config=config.gaussian_point_cloud_scene_config).to(self.device)
+        self.adaptive_controller = GaussianPointAdaptiveController(
+            config=config.adaptive_controller_config,
+            maintained_parameters=GaussianPointAdaptiveController.GaussianPointAdaptiveControllerMaintainedParameters(
+                pointcloud=self.scene.point_cloud,
+                pointcloud_features=self.scene.point_cloud_features,
+                point_invalid_mask=self.scene.point_invalid_mask,
+                point_object_id=self.scene.point_object_id))
+        self.rasterisation = GaussianPointCloudRasterisation(
+            config=config.rasterisation_config, backward_valid_point_hook=self.adaptive_controller.update)
+        if torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
+            from .distributed import shard_rasteriser_across_tile_rows
+            shard_rasteriser_across_tile_rows(self.rasterisation)
+        self.loss_function = LossFunction(config=config.loss_function_config)
+        self.best_psnr_score = 0.0
+
+    # ------------------------------------------------------------------ helpers
+    @staticmethod
+    def _downsample_image_and_camera_info(image: torch.Tensor, camera_info: CameraInfo, downsample_factor: int):
+        """Antialiased resize by 1/factor, crop to whole tiles, intrinsics divided by the factor (TRN:96-118)."""
+        h = camera_info.camera_height // downsample_factor
+        w = camera_info.camera_width // downsample_factor
+        image = F.interpolate(image[None], size=(h, w), mode="bilinear", antialias=True, align_corners=False)[0]
+        h, w = h - h % TILE, w - w % TILE
+        image = image[:3, :h, :w].contiguous()
+        K = camera_info.camera_intrinsics.clone()
+        K[0, 0] /= downsample_factor; K[1, 1] /= downsample_factor
+        K[0, 2] /= downsample_factor; K[1, 2] /= downsample_factor
+        return image, CameraInfo(camera_intrinsics=K, camera_height=h, camera_width=w,
+                                 camera_id=camera_info.camera_id)
+
+    @staticmethod
+    def _easy_cmap(depth: torch.Tensor) -> torch.Tensor:
+        """Three-range depth colouring (0-10 / 10-60 / 60-260), inverted (TRN:274-280)."""
+        rgb = torch.stack([depth.clamp(0, 10) / 10.0, (depth - 10).clamp(0, 50) / 50.0,
+                           (depth - 60).clamp(0, 200) / 200.0])
+        return 1.0 - rgb
+
+    @staticmethod
+    @torch.no_grad()
+    def _compute_pnsr_and_ssim(image_pred: torch.Tensor, image_gt: torch.Tensor):
+        psnr = 10.0 * torch.log10(1.0 / torch.mean((image_pred - image_gt) ** 2))
+        return psnr, ssim(image_pred.unsqueeze(0), image_gt.unsqueeze(0), data_range=1.0, size_average=True)
+
+    def _to_device(self, sample):
+        image, q, t, info = sample
+        info = CameraInfo(camera_intrinsics=info.camera_intrinsics.to(self.device, non_blocking=True),
+                          camera_height=int(info.camera_height), camera_width=int(info.camera_width),
+                          camera_id=info.camera_id)
+        return (image.to(self.device, non_blocking=True), q.to(self.device, non_blocking=True),
+                t.to(self.device, non_blocking=True), info)
+
+    def _rasterise(self, q, t, info, band: int):
+        scene = self.scene
+        return self.rasterisation(GaussianPointCloudRasterisation.GaussianPointCloudRasterisationInput(
+            point_cloud=scene.point_cloud, point_cloud_features=scene.point_cloud_features,
+            point_object_id=scene.point_object_id, point_invalid_mask=scene.point_invalid_mask,
+            camera_info=info, q_pointcloud_camera=q, t_pointcloud_camera=t, color_max_sh_band=band))
+
+    def _scalar(self, tag: str, value: float, step: int, console_key: Optional[str] = None) -> None:
+        if self.writer is not None:
+            self.writer.add_scalar(tag, value, step)
+        if console_key and self.config.print_metrics_to_console and self.rank == 0:
+            print(f"{console_key}={value};")   # the reference's console format (scraped by its CI, TRN:213-217)
+
+    def _loaders(self):
+        kw = dict(batch_size=None, pin_memory=True, num_workers=self.config.num_data_loader_workers)
+        generator = torch.Generator().manual_seed(self.config.seed)   # same shuffling on every rank
+        return (torch.utils.data.DataLoader(self.train_dataset, shuffle=True, generator=generator, **kw),
+                torch.utils.data.DataLoader(self.val_dataset, shuffle=False, **kw))
+
+    # ------------------------------------------------------------------ training (TRN:120-272)
+    def train(self):
+        cfg = self.config
+        train_loader, val_loader = self._loaders()
+        batches = cycle(train_loader)
+        feature_optimizer = torch.optim.Adam([self.scene.point_cloud_features], lr=cfg.feature_learning_rate,
+                                             betas=(0.9, 0.999), fused=True)
+        position_optimizer = torch.optim.Adam([self.scene.point_cloud], lr=cfg.position_learning_rate,
+                                              betas=(0.9, 0.999), fused=True)
+        scheduler = torch.optim.lr_scheduler.ExponentialLR(position_optimizer,
+                                                           gamma=cfg.position_learning_rate_decay_rate)
+        downsample_factor = cfg.initial_downsample_factor
+        recent_losses = deque(maxlen=100)
+        last_problematic = -1000
+
+        for iteration in range(cfg.num_iterations):
+            if iteration > 0 and iteration % cfg.half_downsample_factor_interval == 0 and downsample_factor > 1:
+                downsample_factor //= 2
+            feature_optimizer.zero_grad(set_to_none=True)
+            position_optimizer.zero_grad(set_to_none=True)
+            image_gt, q, t, info = next(batches)
+            if downsample_factor > 1:
+                image_gt, info = self._downsample_image_and_camera_info(image_gt, info, downsample_factor)
+            image_gt, q, t, info = self._to_device((image_gt, q, t, info))
+
+            band = int(iteration // cfg.increase_color_max_sh_band_interval)
+            image_pred, image_depth, pixel_valid_point_count = self._rasterise(q, t, info, band)
+            image_pred = image_pred.clamp(0.0, 1.0).permute(2, 0, 1)
+            loss, l1_loss, ssim_loss = self.loss_function(
+                image_pred, image_gt, point_invalid_mask=self.scene.point_invalid_mask,
+                pointcloud_features=self.scene.point_cloud_features)
+            loss.backward()
+            feature_optimizer.step()
+            position_optimizer.step()
+            if iteration % cfg.position_learning_rate_decay_interval == 0:
+                scheduler.step()
+
+            hook_input = self.adaptive_controller.input_data     # set on densification iterations only
+            grad_image = None
+            if hook_input is not None:
+                grad_image = hook_input.magnitude_grad_viewspace_on_image
+                if self.writer is not None:
+                    self._plot_grad_histogram(hook_input, self.writer, iteration)
+                    self._plot_value_histogram(self.scene, self.writer, iteration)
+                    self.writer.add_histogram("train/pixel_valid_point_count", pixel_valid_point_count, iteration)
+            self.adaptive_controller.refinement()
+
+            is_problematic = False
+            if iteration % cfg.log_loss_interval == 0:
+                loss_value = loss.item()    # the only regular host read-back of the loop
+                self._scalar("train/loss", loss_value, iteration, "train_loss")
+                self._scalar("train/l1 loss", l1_loss.item(), iteration, "train_l1_loss")
+                self._scalar("train/ssim loss", ssim_loss.item(), iteration, "train_ssim_loss")
+                if len(recent_losses) == recent_losses.maxlen and \
+                        iteration - last_problematic > recent_losses.maxlen * cfg.log_loss_interval and \
+                        loss_value > 1.5 * sum(recent_losses) / len(recent_losses):
+                    is_problematic, last_problematic = True, iteration
+                recent_losses.append(loss_value)
+            if iteration % cfg.log_metrics_interval == 0:
+                psnr, ssim_score = self._compute_pnsr_and_ssim(image_pred.detach(), image_gt)
+                self._scalar("train/psnr", psnr.item(), iteration, "train_psnr")
+                self._scalar("train/ssim", ssim_score.item(), iteration, "train_ssim")
+            if (iteration % cfg.log_image_interval == 0 or is_problematic) and self.writer is not None:
+                panels = [image_pred.detach(), image_gt, self._easy_cmap(image_depth),
+                          self._count_panel(pixel_valid_point_count)]
+                if grad_image is not None:
+                    g = grad_image.permute(2, 0, 1)
+                    panels += [(g[0] / g[0].max().clamp_min(1e-30)).expand(3, -1, -1),
+                               (g[1] / g[1].max().clamp_min(1e-30)).expand(3, -1, -1),
+                               (image_pred.detach() - image_gt).abs()]
+                self.writer.add_image("train/image_problematic" if is_problematic else "train/image",
+                                      _image_grid(panels), iteration)
+            del image_gt, image_pred, image_depth, pixel_valid_point_count, loss, l1_loss, ssim_loss
+            if (iteration % cfg.val_interval == 0 and iteration != 0) or iteration in (5000, 7000):
+                self.validation(val_loader, iteration)
+        if self.writer is not None and hasattr(self.writer, "flush"):
+            self.writer.flush()
+
+    @staticmethod
+    def _count_panel(count: torch.Tensor) -> torch.Tensor:
+        c = count.float()
+        return (c / c.max().clamp_min(1.0)).unsqueeze(0).expand(3, -1, -1)
+
+    @staticmethod
+    @torch.no_grad()
+    def _plot_grad_histogram(grad_input, writer, iteration: int) -> None:
+        f = grad_input.grad_pointfeatures_in_camera
+        for tag, values in (("grad/xyz_grad", grad_input.grad_point_in_camera), ("grad/uv_grad", grad_input.grad_viewspace),
+                            ("grad/q_grad", f[:, :4]), ("grad/s_grad", f[:, 4:7]), ("grad/alpha_grad", f[:, 7]),
+                            ("grad/r_grad", f[:, 8:24]), ("grad/g_grad", f[:, 24:40]), ("grad/b_grad", f[:, 40:56]),
+                            ("value/num_overlap_tiles", grad_input.num_overlap_tiles),
+                            ("value/num_affected_pixels", grad_input.num_affected_pixels)):
+            writer.add_histogram(tag, values, iteration)
+
+    @staticmethod
+    @torch.no_grad()
+    def _plot_value_histogram(scene: GaussianPointCloudScene, writer, iteration: int) -> None:
+        live = scene.point_invalid_mask == 0
+        f = scene.point_cloud_features[live]
+        writer.add_scalar("value/num_valid_points", int(live.sum()), iteration)
+        for tag, values in (("value/q", f[:, :4]), ("value/s", f[:, 4:7]), ("value/alpha", f[:, 7]),
+                            ("value/sigmoid_alpha", torch.sigmoid(f[:, 7])), ("value/r", f[:, 8:24]),
+                            ("value/g", f[:, 24:40]), ("value/b", f[:, 40:56])):
+            writer.add_histogram(tag, values, iteration)
+
+    # ------------------------------------------------------------------ validation (TRN:334-415)
+    @torch.no_grad()
+    def validation(self, val_loader, iteration: int):
+        totals = {"loss": 0.0, "psnr": 0.0, "ssim": 0.0, "ms": 0.0}
+        n = 0
+        for idx, sample in enumerate(val_loader):
+            image_gt, q, t, info = self._to_device(sample)
+            start, stop = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            start.record()
+            image_pred, image_depth, count = self._rasterise(q, t, info, band=3)
+            stop.record()
+            torch.cuda.synchronize()
+            totals["ms"] += start.elapsed_time(stop)
+            image_pred = image_pred.clamp(0.0, 1.0).permute(2, 0, 1)
+            loss, _, _ = self.loss_function(image_pred, image_gt)
+            psnr, ssim_score = self._compute_pnsr_and_ssim(image_pred, image_gt)
+            totals["loss"] += loss.item(); totals["psnr"] += psnr.item(); totals["ssim"] += ssim_score.item()
+            n += 1
+            if self.config.log_validation_image and self.writer is not None:
+                self.writer.add_image(f"val/image {idx}", _image_grid(
+                    [image_pred, image_gt, self._easy_cmap(image_depth), self._count_panel(count),
+                     (image_pred - image_gt).abs()]), iteration)
+        n = max(n, 1)
+        mean = {k: v / n for k, v in totals.items()}
+        for tag, key, console in (("val/loss", "loss", "val_loss"), ("val/psnr", "psnr", "val_psnr"),
+                                  ("val/ssim", "ssim", "val_ssim"), ("val/inference_time", "ms", "val_inference_time")):
+            self._scalar(tag, mean[key], iteration, console)
+        if self.rank == 0:
+            self.scene.to_parquet(os.path.join(self.config.output_model_dir, f"scene_{iteration}.parquet"))
+            if mean["psnr"] > self.best_psnr_score:
+                self.scene.to_parquet(os.path.join(self.config.output_model_dir, "best_scene.parquet"))
+        self.best_psnr_score = max(self.best_psnr_score, mean["psnr"])
+        return mean

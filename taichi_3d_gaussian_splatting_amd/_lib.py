@@ -15,7 +15,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgsplat_hip.so")
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 _c = ctypes
 _P = _c.c_void_p
@@ -41,6 +41,8 @@ _SIGNATURES = {
     "gs_blend_forward": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P]),
     "gs_blend_backward": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I64, _I, _I, _I, _I, _P, _P, _P, _P]),
     "gs_reduce_partials": (_I, [_P, _P, _P, _P, _I, _P, _P]),
+    "gs_ellipsoid_offsets": (_I, [_P, _I, _P, _P]),
+    "gs_sample_from_points": (_I, [_P, _P, _P, _I, _P, _P]),
     "gs_point_backward": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _I, _F, _F, _F, _F, _F,
                                _P, _P, _P, _P, _P]),
 }

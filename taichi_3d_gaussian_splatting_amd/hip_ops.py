@@ -263,3 +263,26 @@ def point_backward(xyz, features, object_id, intrinsics, q_cp, t_cp, t_pc, ids, 
          float(grad_alpha_factor), float(grad_color_factor), float(grad_high_order_color_factor), ptr(grad_xyz),
          ptr(grad_feat), ptr(gx_vis), ptr(gf_vis), current_stream(dev))
     return grad_xyz, grad_feat, gx_vis, gf_vis
+
+
+# ---------------------------------------------------------------- adaptive-controller kernels (row F2)
+def ellipsoid_offsets(features: torch.Tensor) -> torch.Tensor:
+    """Focal vector of each Gaussian's ellipsoid, f32[n,3] (ADC:10-25)."""
+    features = _f32(features, "point_cloud_features")
+    out = torch.empty((features.shape[0], 3), dtype=torch.float32, device=features.device)
+    call("gs_ellipsoid_offsets", ptr(features), features.shape[0], ptr(out), current_stream(features.device))
+    return out
+
+
+def sample_from_points(xyz: torch.Tensor, features: torch.Tensor, uniforms: Optional[torch.Tensor] = None,
+                       generator: Optional[torch.Generator] = None) -> torch.Tensor:
+    """One draw per Gaussian from N(xyz, R S S^T R^T), f32[n,3] (ADC:27-42).  uniforms f32[n,4] in (0,1]
+    (drawn with torch when omitted)."""
+    xyz, features = _f32(xyz, "point_cloud"), _f32(features, "point_cloud_features")
+    n = xyz.shape[0]
+    if uniforms is None:
+        uniforms = 1.0 - torch.rand((n, 4), dtype=torch.float32, device=xyz.device, generator=generator)
+    uniforms = _f32(uniforms, "uniforms")
+    out = torch.empty((n, 3), dtype=torch.float32, device=xyz.device)
+    call("gs_sample_from_points", ptr(xyz), ptr(features), ptr(uniforms), n, ptr(out), current_stream(xyz.device))
+    return out

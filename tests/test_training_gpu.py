@@ -1,0 +1,173 @@
+"""GPU tests of the rows either side of the hot path that are built on it: the controller's
+two HIP kernels against the oracle, the reference's own controller test (T_ADC: tests/
+GaussianPointAdaptiveController_test.py:15-95 -- optimise against a fixed 32x32 picture with the controller as
+backward hook; the loss must go down), and the trainer end to end on a synthetic multi-view data set."""
+import json
+import math
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from taichi_3d_gaussian_splatting_amd.synthetic import make_scene
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_controller_kernels_match_oracle():
+    from oracle import gs_oracle as O
+    from taichi_3d_gaussian_splatting_amd import hip_ops
+    s = make_scene(n=5000, height=64, width=64, s_min=0.01, s_max=0.3, seed=11)
+    feat = s.point_cloud_features.clone()
+    feat[:7, 4:7] = torch.tensor([[0.0, 0.0, 0.0], [1.0, 1.0, 0.0], [0.0, 1.0, 1.0], [1.0, 0.0, 1.0],
+                                  [2.0, 1.0, 0.0], [0.0, 2.0, 1.0], [0.0, 1.0, 2.0]])   # ties pick the axis rule
+    u = 1.0 - torch.rand(5000, 4, generator=torch.Generator().manual_seed(3))
+    u[0] = torch.tensor([1.0, 1.0, 1.0, 1.0]); u[1] = torch.tensor([1e-30, 0.5, 1e-38, 0.25])
+    dev = torch.device("cuda:0")
+    off = hip_ops.ellipsoid_offsets(feat.to(dev)).cpu().numpy()
+    smp = hip_ops.sample_from_points(s.point_cloud.to(dev), feat.to(dev), u.to(dev)).cpu().numpy()
+    off64 = O.ellipsoid_offsets(feat.numpy(), "f64")
+    smp64 = O.sample_from_points(s.point_cloud.numpy(), feat.numpy(), u.numpy(), "f64")
+    scale = np.exp(feat[:, 4:7].numpy()).max(1, keepdims=True)
+    # fp32 vs the f64 spec: a few ulp of the axis length (sin/cos of 2*pi*u carry ~1e-6 absolute error)
+    assert np.abs(off - off64).max() <= 4e-6 * scale.max()
+    assert (np.abs(smp - smp64) / (1.0 + 13.0 * scale)).max() <= 1e-5
+    assert np.abs(off[0]).max() == 0.0                                   # sphere: no focal distance
+    # drawn uniforms: mean / covariance of many draws from one Gaussian reproduce R S S^T R^T
+    f1 = feat[10:11].expand(200000, 56).contiguous().to(dev)
+    x1 = torch.zeros(200000, 3, device=dev)
+    draws = hip_ops.sample_from_points(x1, f1, generator=torch.Generator(device=dev).manual_seed(5)).double().cpu().numpy()
+    from scipy.spatial.transform import Rotation
+    R = Rotation.from_quat(feat[10, :4].double().numpy()).as_matrix()
+    cov = R @ np.diag(np.exp(2 * feat[10, 4:7].double().numpy())) @ R.T
+    assert np.abs(draws.mean(0)).max() < 4 * math.sqrt(cov.max() / 200000)
+    assert np.abs(np.cov(draws.T) - cov).max() < 0.02 * cov.max()
+
+
+def test_adaptive_controller_training_reduces_loss():
+    """The reference's T_ADC scenario with its default controller config; 3100 iterations cover the warm-up, 26
+    densifications, the floater phase (> 2000) and the opacity reset at 3000."""
+    from taichi_3d_gaussian_splatting_amd import CameraInfo
+    from taichi_3d_gaussian_splatting_amd import GaussianPointCloudRasterisation as RAS
+    from taichi_3d_gaussian_splatting_amd.GaussianPointAdaptiveController import GaussianPointAdaptiveController as ADC
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    n, live = 10000, 1000
+    target = torch.zeros(32, 32, 3, device=dev)
+    target[:5, :2, 0] = 1.0; target[:5, :2, 1] = 0.7
+    target[8:24, 8:24, 0] = 0.5; target[8:24, 8:24, 1] = 0.7
+    target[20:28, 20:28, 0] = 0.8; target[20:28, 20:28, 1] = 0.1
+    xyz = torch.nn.Parameter((torch.rand(n, 3, device=dev) - 0.5) * 3)
+    feat0 = torch.rand(n, 56, device=dev); feat0[:, 4:7] = math.log(0.01); feat0[:, 7] = 0.5
+    feat = torch.nn.Parameter(feat0)
+    invalid = torch.zeros(n, dtype=torch.int8, device=dev); invalid[live:] = 1
+    obj = torch.zeros(n, dtype=torch.int32, device=dev)
+    cam = CameraInfo(camera_intrinsics=torch.tensor([[32.0, 0, 16], [0, 32, 16], [0, 0, 1]], device=dev),
+                     camera_height=32, camera_width=32, camera_id=0)
+    q = torch.tensor([[0.0, 0, 0, 1]], device=dev); t = torch.tensor([[0.0, 0, -2]], device=dev)
+    ctrl = ADC(ADC.GaussianPointAdaptiveControllerConfig(),
+               ADC.GaussianPointAdaptiveControllerMaintainedParameters(xyz, feat, invalid, obj))
+    ras = RAS(RAS.GaussianPointCloudRasterisationConfig(near_plane=1.0, far_plane=10.0),
+              backward_valid_point_hook=ctrl.update)
+    opt = torch.optim.Adam([xyz, feat], lr=1e-3)
+    losses, live_counts = [], []
+    for it in range(3100):
+        opt.zero_grad()
+        image, _, _ = ras(RAS.GaussianPointCloudRasterisationInput(
+            point_cloud=xyz, point_cloud_features=feat, point_object_id=obj, point_invalid_mask=invalid,
+            camera_info=cam, q_pointcloud_camera=q, t_pointcloud_camera=t, color_max_sh_band=it // 1000))
+        loss = ((image - target) ** 2).sum()
+        loss.backward()
+        opt.step()
+        ctrl.refinement()
+        if it == 3000:   # a reset iteration (ADC:165-166): every opacity logit was clamped to <= 0.1
+            assert float(feat.detach()[:, 7].max()) <= 0.1 + 1e-6
+        if it % 100 == 0 or it == 3099:
+            losses.append(loss.item()); live_counts.append(int((invalid == 0).sum()))
+    assert losses[-1] < 0.5 * losses[0], losses
+    assert len(set(live_counts)) > 1, live_counts                # the controller changed the live set
+    assert ctrl.iteration_counter == 3099
+    assert torch.isfinite(xyz[invalid == 0]).all() and torch.isfinite(feat[invalid == 0]).all()
+
+
+def _write_dataset(root, dev):
+    """Ground truth = renders of a known scene from a ring of cameras, written as PNG + the reference's JSON."""
+    from PIL import Image
+    from taichi_3d_gaussian_splatting_amd import CameraInfo
+    from taichi_3d_gaussian_splatting_amd import GaussianPointCloudRasterisation as RAS
+    from taichi_3d_gaussian_splatting_amd.GaussianPointCloudScene import GaussianPointCloudScene as Scene
+    from taichi_3d_gaussian_splatting_amd.utils import SE3_to_quaternion_and_translation_torch
+    import pandas as pd
+    gt = make_scene(n=3000, height=128, width=160, s_min=0.03, s_max=0.12, sh_degree=0, seed=21)
+    gt.point_cloud_features[:, 7] = 1.5
+    K = torch.tensor([[140.0, 0, 80.0], [0, 140.0, 64.0], [0, 0, 1]])
+    ras = RAS(RAS.GaussianPointCloudRasterisationConfig())
+    records = {"train": [], "val": []}
+    for i in range(10):
+        ang = 2 * math.pi * i / 10
+        c, s_ = math.cos(ang), math.sin(ang)
+        Rwc = torch.tensor([[c, 0, -s_], [0, 1, 0], [s_, 0, c]], dtype=torch.float32)   # camera looks at the origin
+        T = torch.eye(4); T[:3, :3] = Rwc; T[:3, 3] = Rwc @ torch.tensor([0.0, 0.0, -3.5])
+        qq, tt = SE3_to_quaternion_and_translation_torch(T.unsqueeze(0))
+        image, _, _ = ras(RAS.GaussianPointCloudRasterisationInput(
+            point_cloud=gt.point_cloud.to(dev), point_cloud_features=gt.point_cloud_features.clone().to(dev),
+            point_object_id=gt.point_object_id.to(dev), point_invalid_mask=gt.point_invalid_mask.to(dev),
+            camera_info=CameraInfo(camera_intrinsics=K.to(dev), camera_height=128, camera_width=160, camera_id=0),
+            q_pointcloud_camera=qq.to(dev), t_pointcloud_camera=tt.to(dev), color_max_sh_band=0))
+        path = os.path.join(root, f"view_{i}.png")
+        Image.fromarray((image.clamp(0, 1).cpu().numpy() * 255 + 0.5).astype(np.uint8)).save(path)
+        records["val" if i % 5 == 4 else "train"].append(dict(
+            image_path=path, T_pointcloud_camera=T.tolist(), camera_intrinsics=K.tolist(), camera_height=128,
+            camera_width=160, camera_id=0))
+    for split, recs in records.items():
+        json.dump(recs, open(os.path.join(root, f"{split}.json"), "w"))
+    noisy = gt.point_cloud + 0.02 * torch.randn(3000, 3, generator=torch.Generator().manual_seed(1))
+    pd.DataFrame(np.concatenate([noisy.numpy(), np.full((3000, 3), 128.0)], 1),
+                 columns=["x", "y", "z", "r", "g", "b"]).to_parquet(os.path.join(root, "points.parquet"))
+
+
+def test_trainer_end_to_end(tmp_path):
+    from taichi_3d_gaussian_splatting_amd.GaussianPointTrainer import GaussianPointCloudTrainer as TRN
+    from taichi_3d_gaussian_splatting_amd.GaussianPointCloudScene import GaussianPointCloudScene as Scene
+    dev = torch.device("cuda:0")
+    root = str(tmp_path)
+    _write_dataset(root, dev)
+    cfg = TRN.TrainConfig(
+        train_dataset_json_path=os.path.join(root, "train.json"), val_dataset_json_path=os.path.join(root, "val.json"),
+        pointcloud_parquet_path=os.path.join(root, "points.parquet"), num_iterations=401, val_interval=200,
+        feature_learning_rate=5e-3, position_learning_rate=5e-5, initial_downsample_factor=2,
+        half_downsample_factor_interval=100, increase_color_max_sh_band_interval=150, log_loss_interval=10,
+        log_metrics_interval=50, log_image_interval=200, summary_writer_log_dir=os.path.join(root, "logs"),
+        num_data_loader_workers=0)
+    cfg.adaptive_controller_config.num_iterations_warm_up = 100
+    cfg.adaptive_controller_config.num_iterations_densify = 50
+    cfg.gaussian_point_cloud_scene_config.max_num_points_ratio = 3.0
+    cfg.gaussian_point_cloud_scene_config.initial_alpha = 0.5
+    cfg.loss_function_config.enable_regularization = False
+    cfg.to_yaml_file(os.path.join(root, "train.yaml"))
+    trainer = TRN(TRN.TrainConfig.from_yaml_file(os.path.join(root, "train.yaml")))
+    assert trainer.scene.point_cloud.shape[0] == 9000 and trainer.scene.point_cloud.is_cuda
+    _, val_loader = trainer._loaders()
+    before = trainer.validation(val_loader, 0)
+    trainer.train()
+    after = trainer.validation(val_loader, 401)
+    assert after["psnr"] > before["psnr"] + 3.0, (before, after)
+    assert after["loss"] < 0.6 * before["loss"] and after["ms"] > 0
+    logs = os.path.join(root, "logs")
+    for name in ("scene_200.parquet", "scene_400.parquet", "best_scene.parquet"):
+        assert os.path.exists(os.path.join(logs, name)), name
+    best = Scene.from_parquet(os.path.join(logs, "best_scene.parquet"))
+    assert best.point_cloud.shape[0] == int((trainer.scene.point_invalid_mask == 0).sum()) or \
+        best.point_cloud.shape[0] >= 2000
+    if os.path.exists(os.path.join(logs, "metrics.jsonl")):   # plain-file writer (no tensorboard installed)
+        tags = {json.loads(line)["tag"] for line in open(os.path.join(logs, "metrics.jsonl"))}
+        assert {"train/loss", "train/psnr", "val/psnr", "val/inference_time"} <= tags
+    # the reference-compatible command line: template generation
+    tmpl = os.path.join(root, "template.yaml")
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "gaussian_point_train.py"), "--train_config", tmpl,
+                           "--gen_template_only"], cwd=ROOT)
+    assert TRN.TrainConfig.from_yaml_file(tmpl) == TRN.TrainConfig()
