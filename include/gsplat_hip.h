@@ -198,6 +198,25 @@ int gs_ellipsoid_offsets(const float *features, int n, float *offsets, void *str
 int gs_sample_from_points(const float *xyz, const float *features, const float *uniforms, int n,
                           float *samples, void *stream);
 
+/* ---- fused photometric loss of the trainer --------------------------------------
+ * L = (1-lambda) * mean|x-y| + lambda * (1 - SSIM(x,y)), x = clamp(prediction,0,1) when clamp01_prediction.
+ * Replaces clamp + permute (GaussianPointTrainer.py:167-170) + LossFunction.forward (LossFunction.py:20-35,
+ * SSIM = pytorch_msssim.ssim(data_range=1, size_average=True): 11-tap sigma-1.5 Gaussian, 'valid' window) and
+ * the autograd backward of that chain.  prediction is the rasteriser output float[H][W][3]
+ * (prediction_is_hwc = 1) or float[3][H][W]; target is float[3][H][W]; H, W >= 11.
+ *   ssim_grad_maps float[9][H][W] (written by forward, read by backward; may be null for forward-only use)
+ *   workspace      float[gs_loss_workspace_floats(H, W)]
+ *   losses         float[3] = {L, L1, 1 - SSIM}
+ * backward: grad_total / grad_l1 / grad_dssim are device pointers to the upstream scalar gradients of the
+ * three outputs (null = 0); grad_prediction has the layout of prediction and is fully overwritten. */
+long long gs_loss_workspace_floats(int height, int width);
+int gs_loss_forward(const float *prediction, int prediction_is_hwc, int clamp01_prediction, const float *target,
+                    int height, int width, float lambda, float *ssim_grad_maps, float *workspace, float *losses,
+                    void *stream);
+int gs_loss_backward(const float *prediction, int prediction_is_hwc, int clamp01_prediction, const float *target,
+                     const float *ssim_grad_maps, int height, int width, float lambda, const float *grad_total,
+                     const float *grad_l1, const float *grad_dssim, float *grad_prediction, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

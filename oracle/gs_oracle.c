@@ -605,3 +605,96 @@ void gs_oracle_sample_from_points(const real *xyz, const real *feat, const real 
             out[3 * i + k] = xyz[3 * i + k] + ((R[3 * k] * b[0] + R[3 * k + 1] * b[1]) + R[3 * k + 2] * b[2]);
     }
 }
+
+/* ------------------------------------------------ trainer loss */
+/* LossFunction.py:20-35 driven by GaussianPointTrainer.py:167-176: x = clamp(pred,0,1) (TRN:168),
+ * L1 = mean|x-y| (LOS:31), SSIM = pytorch_msssim.ssim(x, y, data_range=1, size_average=True) (LOS:32-33; the
+ * dependency is not vendored: requirements.txt:4, unpinned; algorithm restated from its published definition --
+ * 11-tap Gaussian sigma 1.5, 'valid' separable filter per channel, K1=0.01, K2=0.03, mean over all outputs),
+ * L = (1-lambda) L1 + lambda (1-SSIM) (LOS:34-35).  pred float[H][W][3] (hwc) or [3][H][W]; gt [3][H][W].
+ * out[3] = {L, L1, 1-SSIM}; grad (same layout as pred, may be NULL) = g_total dL/dpred + g_l1 dL1/dpred +
+ * g_dssim d(1-SSIM)/dpred, derived by hand (reverse sweep through the two separable filters); the clamp passes
+ * gradients on the closed interval like torch.clamp.  Always evaluated in double. */
+void gs_oracle_l1_ssim(const real *pred, int hwc, int clamp, const real *gt, int H, int W, double lambda,
+                       double g_total, double g_l1, double g_dssim, double *out, real *grad) {
+    const int Ho = H - 10, Wo = W - 10;
+    double win[11], wsum = 0;
+    for (int k = 0; k < 11; ++k) { win[k] = exp(-((k - 5) * (k - 5)) / (2.0 * 1.5 * 1.5)); wsum += win[k]; }
+    for (int k = 0; k < 11; ++k) win[k] /= wsum;
+    const double c1 = 0.01 * 0.01, c2 = 0.03 * 0.03;
+    const size_t P = (size_t)H * W;
+    double *x = malloc(P * sizeof(double)), *y = malloc(P * sizeof(double));
+    double *h = malloc(5 * (size_t)H * Wo * sizeof(double));     /* after the horizontal pass */
+    double *dm = calloc(3 * P, sizeof(double));                   /* A, B, C on the output grid, zero elsewhere */
+    double *hb = malloc(3 * (size_t)H * Wo * sizeof(double));
+    double l1_sum = 0, ssim_sum = 0;
+    const double w_l1 = (g_total * (1.0 - lambda) + g_l1) / (3.0 * H * W);
+    const double w_ss = -(g_total * lambda + g_dssim) / (3.0 * Ho * (double)Wo);
+    for (int c = 0; c < 3; ++c) {
+        for (int i = 0; i < H; ++i)
+            for (int j = 0; j < W; ++j) {
+                double v = (double)(hwc ? pred[((size_t)i * W + j) * 3 + c] : pred[((size_t)c * H + i) * W + j]);
+                if (clamp) v = v < 0 ? 0 : (v > 1 ? 1 : v);
+                x[(size_t)i * W + j] = v;
+                y[(size_t)i * W + j] = (double)gt[((size_t)c * H + i) * W + j];
+                l1_sum += fabs(v - y[(size_t)i * W + j]);
+            }
+#pragma omp parallel for schedule(static)
+        for (int i = 0; i < H; ++i)
+            for (int j = 0; j < Wo; ++j) {
+                double s[5] = {0, 0, 0, 0, 0};
+                for (int k = 0; k < 11; ++k) {
+                    double a = x[(size_t)i * W + j + k], b = y[(size_t)i * W + j + k];
+                    s[0] += win[k] * a; s[1] += win[k] * b; s[2] += win[k] * a * a; s[3] += win[k] * b * b;
+                    s[4] += win[k] * a * b;
+                }
+                for (int m = 0; m < 5; ++m) h[((size_t)m * H + i) * Wo + j] = s[m];
+            }
+        memset(dm, 0, 3 * P * sizeof(double));
+        for (int i = 0; i < Ho; ++i)
+            for (int j = 0; j < Wo; ++j) {
+                double s[5] = {0, 0, 0, 0, 0};
+                for (int k = 0; k < 11; ++k)
+                    for (int m = 0; m < 5; ++m) s[m] += win[k] * h[((size_t)m * H + i + k) * Wo + j];
+                double mx = s[0], my = s[1];
+                double d1 = mx * mx + my * my + c1, d2 = (s[2] - mx * mx) + (s[3] - my * my) + c2;
+                double l = (2 * mx * my + c1) / d1, cs = (2 * (s[4] - mx * my) + c2) / d2;
+                ssim_sum += l * cs;
+                dm[0 * P + (size_t)i * W + j] = cs * (2 * my - 2 * mx * l) / d1 + l * (2 * mx * cs - 2 * my) / d2;
+                dm[1 * P + (size_t)i * W + j] = -l * cs / d2;
+                dm[2 * P + (size_t)i * W + j] = 2 * l / d2;
+            }
+        if (grad) {
+            /* transpose of the 'valid' filter: full correlation of the output-grid maps with the window */
+#pragma omp parallel for schedule(static)
+            for (int i = 0; i < Ho; ++i)
+                for (int j = 0; j < W; ++j)
+                    for (int m = 0; m < 3; ++m) {
+                        double s = 0;
+                        for (int k = 0; k < 11; ++k) {
+                            int jj = j - k;
+                            if (jj >= 0 && jj < Wo) s += win[k] * dm[m * P + (size_t)i * W + jj];
+                        }
+                        hb[((size_t)m * Ho + i) * W + j] = s;
+                    }
+#pragma omp parallel for schedule(static)
+            for (int i = 0; i < H; ++i)
+                for (int j = 0; j < W; ++j) {
+                    double t[3] = {0, 0, 0};
+                    for (int k = 0; k < 11; ++k) {
+                        int ii = i - k;
+                        if (ii >= 0 && ii < Ho)
+                            for (int m = 0; m < 3; ++m) t[m] += win[k] * hb[((size_t)m * Ho + ii) * W + j];
+                    }
+                    double xv = x[(size_t)i * W + j], yv = y[(size_t)i * W + j], d = xv - yv;
+                    double g = w_l1 * (d > 0 ? 1.0 : (d < 0 ? -1.0 : 0.0)) + w_ss * (t[0] + 2 * xv * t[1] + yv * t[2]);
+                    size_t o = hwc ? ((size_t)i * W + j) * 3 + c : ((size_t)c * H + i) * W + j;
+                    if (clamp && !((double)pred[o] >= 0 && (double)pred[o] <= 1)) g = 0;
+                    grad[o] = (real)g;
+                }
+        }
+    }
+    double l1 = l1_sum / (3.0 * H * W), dssim = 1.0 - ssim_sum / (3.0 * Ho * (double)Wo);
+    out[0] = (1.0 - lambda) * l1 + lambda * dssim; out[1] = l1; out[2] = dssim;
+    free(x); free(y); free(h); free(dm); free(hb);
+}

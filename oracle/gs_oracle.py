@@ -239,3 +239,19 @@ def sample_from_points(xyz, feat, uniforms, precision="f32"):
     out = np.empty((xyz.shape[0], 3), rt)
     _lib(precision).gs_oracle_sample_from_points(_p(xyz), _p(feat), _p(uniforms), ctypes.c_int(xyz.shape[0]), _p(out))
     return out
+
+
+def l1_ssim(pred, gt, hwc=True, clamp=True, lambda_value=0.2, g_total=1.0, g_l1=0.0, g_dssim=0.0,
+            want_grad=True, precision="f64"):
+    """Trainer loss LOS:20-35 (+ clamp TRN:168) and its hand-derived gradient; returns ((L, L1, 1-SSIM), grad)."""
+    rt = _real(precision)
+    pred = np.ascontiguousarray(pred, dtype=rt)
+    gt = np.ascontiguousarray(gt, dtype=rt)
+    H, W = gt.shape[1], gt.shape[2]
+    out = np.zeros(3, np.float64)
+    grad = np.empty_like(pred) if want_grad else None
+    _lib(precision).gs_oracle_l1_ssim(_p(pred), ctypes.c_int(int(hwc)), ctypes.c_int(int(clamp)), _p(gt),
+                                      ctypes.c_int(H), ctypes.c_int(W), ctypes.c_double(lambda_value),
+                                      ctypes.c_double(g_total), ctypes.c_double(g_l1), ctypes.c_double(g_dssim),
+                                      _p(out), _p(grad))
+    return out, grad

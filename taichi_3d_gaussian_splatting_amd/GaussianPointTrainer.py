@@ -8,7 +8,8 @@ fields and defaults (TRN:32-58), same schedule --
 * coarse-to-fine images: start at 1/``initial_downsample_factor`` and halve the factor every
   ``half_downsample_factor_interval`` iterations, antialiased resize + crop to the 16-px tile grid (TRN:96-118,139-148);
 * spherical-harmonics band ``iteration // increase_color_max_sh_band_interval`` (TRN:163);
-* clamp to [0,1], HWC -> CHW, loss of ``LossFunction`` with the scale regulariser (TRN:167-175);
+* clamp to [0,1], HWC -> CHW, loss of ``LossFunction`` with the scale regulariser (TRN:167-175) -- clamp, L1, SSIM
+  and their backward run as one fused HIP kernel pair (csrc/gs_loss.hip);
 * the adaptive controller is the rasteriser's backward hook and refines after the optimiser steps (TRN:85-88,192);
 * validation every ``val_interval`` iterations and at 5000 / 7000 (TRN:271-272): PSNR, SSIM, inference time,
   ``scene_{iteration}.parquet`` and ``best_scene.parquet`` (TRN:334-415).
@@ -254,11 +255,13 @@ class GaussianPointCloudTrainer:
 
             band = int(iteration // cfg.increase_color_max_sh_band_interval)
             image_pred, image_depth, pixel_valid_point_count = self._rasterise(q, t, info, band)
-            image_pred = image_pred.clamp(0.0, 1.0).permute(2, 0, 1)
+            # clamp (TRN:168) is folded into the fused loss kernel; the permute (TRN:170) is a view
             loss, l1_loss, ssim_loss = self.loss_function(
-                image_pred, image_gt, point_invalid_mask=self.scene.point_invalid_mask,
-                pointcloud_features=self.scene.point_cloud_features)
+                image_pred.permute(2, 0, 1), image_gt, point_invalid_mask=self.scene.point_invalid_mask,
+                pointcloud_features=self.scene.point_cloud_features, clamp_prediction=True)
             loss.backward()
+            raw_pred = image_pred.detach()
+            image_pred = None   # the clamped CHW copy is only materialised on logging iterations (below)
             feature_optimizer.step()
             position_optimizer.step()
             if iteration % cfg.position_learning_rate_decay_interval == 0:
@@ -285,21 +288,24 @@ class GaussianPointCloudTrainer:
                         loss_value > 1.5 * sum(recent_losses) / len(recent_losses):
                     is_problematic, last_problematic = True, iteration
                 recent_losses.append(loss_value)
+            log_image = (iteration % cfg.log_image_interval == 0 or is_problematic) and self.writer is not None
+            if iteration % cfg.log_metrics_interval == 0 or log_image:
+                image_pred = raw_pred.clamp(0.0, 1.0).permute(2, 0, 1)
             if iteration % cfg.log_metrics_interval == 0:
-                psnr, ssim_score = self._compute_pnsr_and_ssim(image_pred.detach(), image_gt)
+                psnr, ssim_score = self._compute_pnsr_and_ssim(image_pred, image_gt)
                 self._scalar("train/psnr", psnr.item(), iteration, "train_psnr")
                 self._scalar("train/ssim", ssim_score.item(), iteration, "train_ssim")
-            if (iteration % cfg.log_image_interval == 0 or is_problematic) and self.writer is not None:
-                panels = [image_pred.detach(), image_gt, self._easy_cmap(image_depth),
+            if log_image:
+                panels = [image_pred, image_gt, self._easy_cmap(image_depth),
                           self._count_panel(pixel_valid_point_count)]
                 if grad_image is not None:
                     g = grad_image.permute(2, 0, 1)
                     panels += [(g[0] / g[0].max().clamp_min(1e-30)).expand(3, -1, -1),
                                (g[1] / g[1].max().clamp_min(1e-30)).expand(3, -1, -1),
-                               (image_pred.detach() - image_gt).abs()]
+                               (image_pred - image_gt).abs()]
                 self.writer.add_image("train/image_problematic" if is_problematic else "train/image",
                                       _image_grid(panels), iteration)
-            del image_gt, image_pred, image_depth, pixel_valid_point_count, loss, l1_loss, ssim_loss
+            del image_gt, image_pred, raw_pred, image_depth, pixel_valid_point_count, loss, l1_loss, ssim_loss
             if (iteration % cfg.val_interval == 0 and iteration != 0) or iteration in (5000, 7000):
                 self.validation(val_loader, iteration)
         if self.writer is not None and hasattr(self.writer, "flush"):

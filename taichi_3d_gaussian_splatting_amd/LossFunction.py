@@ -7,6 +7,14 @@ Mirror of the reference's ``taichi_3d_gaussian_splatting/LossFunction.py`` (LOS:
 (``ssim(X, Y, data_range=1, size_average=True)``): separable 11-tap Gaussian window (sigma 1.5), 'valid'
 convolution per channel, K1 = 0.01, K2 = 0.03, mean over channels and images; a spatial dimension shorter than
 the window is left unfiltered, as in that package.
+
+Two implementations of the same function:
+* device tensors, one 3-channel image (the trainer's case): ``fused_l1_ssim`` -- the HIP kernels of
+  csrc/gs_loss.hip (forward + hand-derived backward, optionally with the ``clamp(0,1)`` of TRN:168 folded in).
+  Eager PyTorch needs ~6.5 ms per 1920x1072 iteration for this chain, 5x the rasteriser; the fused pair is
+  HBM-bound at ~0.1 ms.  It raises if the HIP library is missing.
+* anything else (CPU tensors, batches, other channel counts): the plain PyTorch formulation below, which is also
+  the fp32 reference the kernel tests compare against.
 """
 from __future__ import annotations
 
@@ -54,6 +62,42 @@ def ssim(x: torch.Tensor, y: torch.Tensor, data_range: float = 1.0, size_average
     return per_channel.mean() if size_average else per_channel.mean(1)
 
 
+class _FusedL1SSIM(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, prediction, target, lambda_value, clamp):
+        from . import hip_ops
+        need_grad = prediction.requires_grad
+        losses, maps = hip_ops.loss_forward(prediction.detach(), target.detach(), lambda_value, clamp, need_grad)
+        ctx.lambda_value, ctx.clamp = lambda_value, clamp
+        ctx.save_for_backward(prediction.detach(), target.detach(), maps)
+        ctx.set_materialize_grads(False)
+        return losses[0], losses[1], losses[2]
+
+    @staticmethod
+    def backward(ctx, grad_total, grad_l1, grad_dssim):
+        from . import hip_ops
+        prediction, target, maps = ctx.saved_tensors
+        if maps is None or (grad_total is None and grad_l1 is None and grad_dssim is None):
+            return None, None, None, None
+        grad = hip_ops.loss_backward(prediction, target, maps, ctx.lambda_value, ctx.clamp, grad_total, grad_l1,
+                                     grad_dssim)
+        return grad, None, None, None
+
+
+def fused_l1_ssim(prediction: torch.Tensor, target: torch.Tensor, lambda_value: float = 0.2,
+                  clamp_prediction: bool = False):
+    """(L, L1, 1 - SSIM) of one [3,H,W] image pair on the HIP device, differentiable w.r.t. ``prediction``.
+    ``prediction`` may be the ``permute(2,0,1)`` view of the rasteriser's [H,W,3] output (no copy is made);
+    ``clamp_prediction`` applies ``clamp(0,1)`` to it inside the kernel."""
+    return _FusedL1SSIM.apply(prediction, target, float(lambda_value), bool(clamp_prediction))
+
+
+def _fusable(pred: torch.Tensor, target: torch.Tensor) -> bool:
+    return (pred.is_cuda and target.is_cuda and pred.dtype == torch.float32 and target.dtype == torch.float32 and
+            pred.dim() == 4 and pred.shape[0] == 1 and pred.shape[1] == 3 and pred.shape == target.shape and
+            pred.shape[2] >= 11 and pred.shape[3] >= 11)
+
+
 class LossFunction(nn.Module):
     @dataclass
     class LossFunctionConfig(YAMLConfig):
@@ -65,14 +109,21 @@ class LossFunction(nn.Module):
         super().__init__()
         self.config = config
 
-    def forward(self, predicted_image, ground_truth_image, point_invalid_mask=None, pointcloud_features=None):
-        """Images are [C,H,W] or [B,C,H,W] in 0..1."""
+    def forward(self, predicted_image, ground_truth_image, point_invalid_mask=None, pointcloud_features=None,
+                clamp_prediction: bool = False):
+        """Images are [C,H,W] or [B,C,H,W] in 0..1.  ``clamp_prediction`` (an addition) folds the trainer's
+        ``clamp(prediction, 0, 1)`` into the loss."""
         pred = predicted_image if predicted_image.dim() == 4 else predicted_image.unsqueeze(0)
         target = ground_truth_image if ground_truth_image.dim() == 4 else ground_truth_image.unsqueeze(0)
-        l1 = (pred - target).abs().mean()
-        d_ssim = 1.0 - ssim(pred, target, data_range=1.0, size_average=True)
         lam = self.config.lambda_value
-        total = (1.0 - lam) * l1 + lam * d_ssim
+        if _fusable(pred, target):
+            total, l1, d_ssim = fused_l1_ssim(pred[0], target[0].contiguous(), lam, clamp_prediction)
+        else:
+            if clamp_prediction:
+                pred = pred.clamp(0.0, 1.0)
+            l1 = (pred - target).abs().mean()
+            d_ssim = 1.0 - ssim(pred, target, data_range=1.0, size_average=True)
+            total = (1.0 - lam) * l1 + lam * d_ssim
         if pointcloud_features is not None and self.config.enable_regularization:
             total = total + self.config.regularization_weight * self._regularization_loss(
                 point_invalid_mask, pointcloud_features)
@@ -80,6 +131,8 @@ class LossFunction(nn.Module):
 
     @staticmethod
     def _regularization_loss(point_invalid_mask, pointcloud_features):
-        """Mean Euclidean norm of the three axis lengths exp(s) of the valid Gaussians (LOS:42-54)."""
-        log_scale = pointcloud_features[point_invalid_mask == 0, 4:7]
-        return torch.exp(log_scale).norm(dim=1).mean()
+        """Mean Euclidean norm of the three axis lengths exp(s) of the valid Gaussians (LOS:42-54), written as a
+        masked mean: boolean indexing would cost a device->host synchronisation per iteration."""
+        live = (point_invalid_mask == 0).to(pointcloud_features.dtype)
+        axis_norm = torch.exp(pointcloud_features[:, 4:7]).norm(dim=1)
+        return (axis_norm * live).sum() / live.sum()

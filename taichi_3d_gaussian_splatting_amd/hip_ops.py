@@ -34,11 +34,11 @@ def _require_device(t: torch.Tensor, name: str) -> None:
             f"{name} is on {t.device}: the rasteriser runs on an AMD GPU (HIP) only; there is no CPU path")
 
 
-def _f32(t: torch.Tensor, name: str) -> torch.Tensor:
+def _f32(t: torch.Tensor, name: str, contiguous: bool = True) -> torch.Tensor:
     _require_device(t, name)
     if t.dtype != torch.float32:
         raise TypeError(f"{name} must be float32, got {t.dtype}")
-    return t.contiguous()
+    return t.contiguous() if contiguous else t
 
 
 def read_counters(counters: torch.Tensor) -> Tuple[int, ...]:
@@ -286,3 +286,48 @@ def sample_from_points(xyz: torch.Tensor, features: torch.Tensor, uniforms: Opti
     out = torch.empty((n, 3), dtype=torch.float32, device=xyz.device)
     call("gs_sample_from_points", ptr(xyz), ptr(features), ptr(uniforms), n, ptr(out), current_stream(xyz.device))
     return out
+
+
+# ---------------------------------------------------------------- fused trainer loss (row F1)
+def _image_layout(prediction: torch.Tensor):
+    """(buffer, is_hwc, H, W) for a [3,H,W] prediction that is either contiguous or the ``permute(2,0,1)`` view
+    of a contiguous [H,W,3] tensor (what the trainer hands over, TRN:170); anything else is copied."""
+    if prediction.dim() != 3 or prediction.shape[0] != 3:
+        raise ValueError("prediction must be [3,H,W]")
+    _, h, w = prediction.shape
+    if prediction.is_contiguous():
+        return prediction, 0, h, w
+    hwc = prediction.permute(1, 2, 0)
+    if hwc.is_contiguous():
+        return hwc, 1, h, w
+    return prediction.contiguous(), 0, h, w
+
+
+def loss_forward(prediction: torch.Tensor, target: torch.Tensor, lambda_value: float, clamp: bool,
+                 need_grad: bool = True):
+    """-> (losses f32[3] = {L, L1, 1-SSIM}, saved maps or None).  prediction/target [3,H,W] f32 on the device."""
+    prediction, target = _f32(prediction, "prediction", contiguous=False), _f32(target, "target")
+    buf, is_hwc, h, w = _image_layout(prediction)
+    if tuple(target.shape) != (3, h, w):
+        raise ValueError("target must be [3,H,W] like the prediction")
+    dev = buf.device
+    maps = torch.empty((9, h, w), dtype=torch.float32, device=dev) if need_grad else None
+    ws = torch.empty(_lib.load().gs_loss_workspace_floats(h, w), dtype=torch.float32, device=dev)
+    losses = torch.empty(3, dtype=torch.float32, device=dev)
+    call("gs_loss_forward", ptr(buf), is_hwc, int(clamp), ptr(target), h, w, float(lambda_value), ptr(maps), ptr(ws),
+         ptr(losses), current_stream(dev))
+    return losses, maps
+
+
+def loss_backward(prediction: torch.Tensor, target: torch.Tensor, maps: torch.Tensor, lambda_value: float,
+                  clamp: bool, grad_total: Optional[torch.Tensor], grad_l1: Optional[torch.Tensor],
+                  grad_dssim: Optional[torch.Tensor]) -> torch.Tensor:
+    """Gradient w.r.t. ``prediction`` (same shape and memory layout)."""
+    buf, is_hwc, h, w = _image_layout(prediction)
+    dev = buf.device
+    grads = [None if g is None else g.to(device=dev, dtype=torch.float32).contiguous()
+             for g in (grad_total, grad_l1, grad_dssim)]
+    out = torch.empty_like(buf)
+    call("gs_loss_backward", ptr(buf), is_hwc, int(clamp), ptr(target), ptr(maps), h, w, float(lambda_value),
+         ptr(grads[0]), ptr(grads[1]), ptr(grads[2]), ptr(out), current_stream(dev))
+    return out.permute(2, 0, 1) if is_hwc else out

@@ -223,3 +223,28 @@ def test_downsample_rule_and_colour_map():
     cm = TRN._easy_cmap(torch.tensor([[0.0, 5.0], [35.0, 260.0]]))
     assert torch.allclose(cm[:, 0, 0], torch.ones(3)) and torch.allclose(cm[:, 1, 1], torch.zeros(3))
     assert torch.allclose(cm[:, 0, 1], torch.tensor([0.5, 1.0, 1.0])) and torch.allclose(cm[:, 1, 0], torch.tensor([0.0, 0.5, 1.0]))
+
+
+# ---------------------------------------------------------------------------------------------- oracle of the loss
+@pytest.mark.parametrize("hwc,clamp", [(True, True), (False, False)])
+def test_oracle_loss_and_hand_derived_gradient_match_torch_autograd(hwc, clamp):
+    """Two independent derivations: the oracle's analytic reverse sweep (C, double) vs autograd through the
+    PyTorch restatement of pytorch_msssim's definition."""
+    torch.manual_seed(3)
+    H, W = 29, 37
+    gt = torch.rand(3, H, W, dtype=torch.float64)
+    raw = (gt + 0.3 * torch.randn(3, H, W, dtype=torch.float64)).requires_grad_(True)   # some values leave [0,1]
+    x = raw.clamp(0, 1) if clamp else raw
+    l1 = (x - gt).abs().mean()
+    d_ssim = 1 - ssim(x[None], gt[None])
+    total = 0.8 * l1 + 0.2 * d_ssim
+    g_total, g_l1, g_ds = 1.3, -0.4, 0.7
+    (g_total * total + g_l1 * l1 + g_ds * d_ssim).backward()
+    pred_np = raw.detach().permute(1, 2, 0).contiguous().numpy() if hwc else raw.detach().numpy()
+    out, grad = O.l1_ssim(pred_np, gt.numpy(), hwc=hwc, clamp=clamp, lambda_value=0.2, g_total=g_total, g_l1=g_l1,
+                          g_dssim=g_ds)
+    assert np.allclose(out, [total.item(), l1.item(), d_ssim.item()], rtol=0, atol=1e-13)
+    want = raw.grad.permute(1, 2, 0).numpy() if hwc else raw.grad.numpy()
+    assert np.abs(grad - want).max() < 1e-13
+    if clamp:
+        assert (grad[(pred_np < 0) | (pred_np > 1)] == 0).all()

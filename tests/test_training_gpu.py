@@ -171,3 +171,71 @@ def test_trainer_end_to_end(tmp_path):
     subprocess.check_call([sys.executable, os.path.join(ROOT, "gaussian_point_train.py"), "--train_config", tmpl,
                            "--gen_template_only"], cwd=ROOT)
     assert TRN.TrainConfig.from_yaml_file(tmpl) == TRN.TrainConfig()
+
+
+@pytest.mark.parametrize("H,W,hwc,clamp", [(11, 11, True, True), (16, 16, False, False), (37, 53, True, True),
+                                            (64, 96, False, True), (272, 480, True, False)])
+def test_fused_loss_kernel_matches_oracle(H, W, hwc, clamp):
+    """HIP forward/backward vs the f64 oracle (values 2e-6 absolute; gradient 1e-4 relative L2 and 1e-3 of the
+    largest entry in L-inf -- fp32 cancellation in var = E[x^2] - mu^2 bounds it), and vs the eager fp32
+    PyTorch formulation of the same loss on the device."""
+    from oracle import gs_oracle as O
+    from taichi_3d_gaussian_splatting_amd.LossFunction import fused_l1_ssim, ssim
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(H * 1000 + W)
+    gt = torch.rand(3, H, W, generator=g)
+    gt[:, : H // 3] = 0.25                                              # flat region: var ~ 0, SSIM denominators ~ C2
+    raw = gt + 0.25 * torch.randn(3, H, W, generator=g)
+    raw[0, 0, 0], raw[1, 1, 1] = 0.0, 1.0                                # clamp boundaries pass the gradient
+    store = (raw.permute(1, 2, 0).contiguous() if hwc else raw.clone()).to(dev).requires_grad_(True)
+    pred = store.permute(2, 0, 1) if hwc else store
+    total, l1, ds = fused_l1_ssim(pred, gt.to(dev), 0.2, clamp)
+    (1.3 * total - 0.4 * l1 + 0.7 * ds).backward()
+    out, grad = O.l1_ssim(store.detach().cpu().numpy(), gt.numpy(), hwc=hwc, clamp=clamp, lambda_value=0.2,
+                          g_total=1.3, g_l1=-0.4, g_dssim=0.7)
+    got = np.array([total.item(), l1.item(), ds.item()])
+    assert np.abs(got - out).max() < 2e-6, (got, out)
+    got_grad = store.grad.cpu().numpy().astype(np.float64)
+    assert got_grad.shape == grad.shape
+    rel = np.linalg.norm(got_grad - grad) / np.linalg.norm(grad)
+    assert rel < 1e-4 and np.abs(got_grad - grad).max() < 1e-3 * np.abs(grad).max(), rel
+    # eager reference on the device
+    ref_in = store.detach().clone().requires_grad_(True)
+    x = ref_in.permute(2, 0, 1) if hwc else ref_in
+    x = x.clamp(0, 1) if clamp else x
+    r_l1 = (x - gt.to(dev)).abs().mean(); r_ds = 1 - ssim(x[None], gt.to(dev)[None])
+    (1.3 * (0.8 * r_l1 + 0.2 * r_ds) - 0.4 * r_l1 + 0.7 * r_ds).backward()
+    assert abs(r_l1.item() - l1.item()) < 2e-6 and abs(r_ds.item() - ds.item()) < 5e-6
+    assert (ref_in.grad - store.grad).norm() / ref_in.grad.norm() < 2e-4
+
+
+def test_fused_loss_full_size_properties_and_module_path():
+    """1920x1072 (the headline frame): identical images give exactly L = 0; the LossFunction module takes the
+    fused path for device tensors, agrees with the eager formulation, is deterministic and only needs H,W >= 11."""
+    from taichi_3d_gaussian_splatting_amd.LossFunction import LossFunction, fused_l1_ssim, ssim
+    dev = torch.device("cuda:0")
+    H, W = 1072, 1920
+    gt = torch.rand(3, H, W, device=dev)
+    same = gt.permute(1, 2, 0).contiguous().requires_grad_(True)
+    total, l1, ds = fused_l1_ssim(same.permute(2, 0, 1), gt, 0.2, True)
+    assert l1.item() == 0.0 and abs(ds.item()) < 1e-6 and abs(total.item()) < 1e-6
+    hwc = (gt.permute(1, 2, 0) + 0.1 * torch.randn(H, W, 3, device=dev)).contiguous().requires_grad_(True)
+    loss_fn = LossFunction(LossFunction.LossFunctionConfig(lambda_value=0.2, enable_regularization=False))
+    a = loss_fn(hwc.permute(2, 0, 1), gt, clamp_prediction=True)
+    a[0].backward()
+    g1 = hwc.grad.clone(); hwc.grad = None
+    b = loss_fn(hwc.permute(2, 0, 1), gt, clamp_prediction=True)
+    b[0].backward()
+    assert torch.equal(g1, hwc.grad) and all(torch.equal(x, y) for x, y in zip(a, b))       # bitwise reproducible
+    ref_in = hwc.detach().clone().requires_grad_(True)
+    x = ref_in.clamp(0, 1).permute(2, 0, 1)
+    r_l1 = (x - gt).abs().mean(); r_ds = 1 - ssim(x[None], gt[None])
+    (0.8 * r_l1 + 0.2 * r_ds).backward()
+    assert abs(a[1].item() - r_l1.item()) < 1e-6 and abs(a[2].item() - r_ds.item()) < 1e-5
+    assert (ref_in.grad - g1).norm() / ref_in.grad.norm() < 2e-4
+    assert ((hwc.detach() < 0) | (hwc.detach() > 1)).any() and (g1[(hwc.detach() < 0) | (hwc.detach() > 1)] == 0).all()
+    with torch.no_grad():                                                                     # forward-only use
+        c = loss_fn(hwc.detach().clamp(0, 1).permute(2, 0, 1), gt)
+    assert abs(c[0].item() - a[0].item()) < 1e-6
+    with pytest.raises(RuntimeError):
+        fused_l1_ssim(torch.rand(3, 10, 40, device=dev), torch.rand(3, 10, 40, device=dev), 0.2, False)
