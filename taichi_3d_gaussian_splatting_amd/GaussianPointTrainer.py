@@ -256,10 +256,12 @@ class GaussianPointCloudTrainer:
             band = int(iteration // cfg.increase_color_max_sh_band_interval)
             image_pred, image_depth, pixel_valid_point_count = self._rasterise(q, t, info, band)
             # clamp (TRN:168) is folded into the fused loss kernel; the permute (TRN:170) is a view
-            loss, l1_loss, ssim_loss = self.loss_function(
-                image_pred.permute(2, 0, 1), image_gt, point_invalid_mask=self.scene.point_invalid_mask,
-                pointcloud_features=self.scene.point_cloud_features, clamp_prediction=True)
+            loss, l1_loss, ssim_loss = self.loss_function(image_pred.permute(2, 0, 1), image_gt, clamp_prediction=True)
             loss.backward()
+            # scale regulariser (TRN:172-174, LOS:36-38): same value and gradient, added in place
+            regulariser = self.loss_function.add_regularization_gradient_(self.scene.point_invalid_mask,
+                                                                          self.scene.point_cloud_features)
+            loss = loss.detach() if regulariser is None else loss.detach() + regulariser
             raw_pred = image_pred.detach()
             image_pred = None   # the clamped CHW copy is only materialised on logging iterations (below)
             feature_optimizer.step()

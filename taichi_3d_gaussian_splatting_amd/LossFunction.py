@@ -129,6 +129,31 @@ class LossFunction(nn.Module):
                 point_invalid_mask, pointcloud_features)
         return total, l1, d_ssim
 
+    @torch.no_grad()
+    def add_regularization_gradient_(self, point_invalid_mask: torch.Tensor, pointcloud_features: torch.Tensor):
+        """Trainer fast path (an addition): returns ``regularization_weight * R`` and adds its gradient to
+        ``pointcloud_features.grad[:, 4:7]`` in place, instead of sending R through autograd -- which would
+        materialise a dense [N,56] gradient and add it to the rasteriser's.  Call it after ``backward()`` of the
+        image loss; the sum of both equals the loss / gradient of ``forward(..., pointcloud_features=...)``.
+        Returns None when the regulariser is disabled."""
+        if not self.config.enable_regularization:
+            return None
+        weight = float(self.config.regularization_weight)
+        if pointcloud_features.grad is None:
+            pointcloud_features.grad = torch.zeros_like(pointcloud_features)
+        if pointcloud_features.is_cuda:
+            from . import hip_ops
+            value_and_count = hip_ops.scale_regulariser(pointcloud_features, point_invalid_mask)
+            hip_ops.scale_regulariser_add_gradient_(pointcloud_features, point_invalid_mask, value_and_count, weight,
+                                                    pointcloud_features.grad)
+            return weight * value_and_count[0]
+        with torch.enable_grad():
+            leaf = pointcloud_features.detach().requires_grad_(True)
+            value = self._regularization_loss(point_invalid_mask, leaf)
+            (grad,) = torch.autograd.grad(value, leaf)
+        pointcloud_features.grad.add_(grad, alpha=weight)
+        return weight * value.detach()
+
     @staticmethod
     def _regularization_loss(point_invalid_mask, pointcloud_features):
         """Mean Euclidean norm of the three axis lengths exp(s) of the valid Gaussians (LOS:42-54), written as a

@@ -248,3 +248,22 @@ def test_oracle_loss_and_hand_derived_gradient_match_torch_autograd(hwc, clamp):
     assert np.abs(grad - want).max() < 1e-13
     if clamp:
         assert (grad[(pred_np < 0) | (pred_np > 1)] == 0).all()
+
+
+def test_in_place_regulariser_equals_autograd_path():
+    torch.manual_seed(5)
+    feat = torch.nn.Parameter(torch.randn(40, 56, dtype=torch.float64))
+    invalid = (torch.rand(40) < 0.3).to(torch.int8)
+    loss_fn = LossFunction(LossFunction.LossFunctionConfig(regularization_weight=2.0))
+    x, y = torch.rand(3, 16, 16, dtype=torch.float64), torch.rand(3, 16, 16, dtype=torch.float64)
+    total, _, _ = loss_fn(x, y, point_invalid_mask=invalid, pointcloud_features=feat)
+    total.backward()
+    want_grad, want_total = feat.grad.clone(), total.item()
+    feat.grad = torch.full_like(feat, 0.5)                       # an existing (rasteriser) gradient is kept
+    image_only, _, _ = loss_fn(x, y)
+    reg = loss_fn.add_regularization_gradient_(invalid, feat)
+    assert abs(image_only.item() + reg.item() - want_total) < 1e-12
+    assert torch.allclose(feat.grad - 0.5, want_grad, atol=1e-13)
+    assert (feat.grad[invalid == 1] == 0.5).all() and (feat.grad[:, :4] == 0.5).all()
+    off = LossFunction(LossFunction.LossFunctionConfig(enable_regularization=False))
+    assert off.add_regularization_gradient_(invalid, feat) is None

@@ -39,10 +39,10 @@ for it in range(iters + 3):
         point_invalid_mask=s.point_invalid_mask, camera_info=cam, q_pointcloud_camera=s.q_pointcloud_camera,
         t_pointcloud_camera=s.t_pointcloud_camera, color_max_sh_band=3))
     t1 = ev()
-    loss, l1, ds = loss_fn(image.permute(2, 0, 1), gt, point_invalid_mask=s.point_invalid_mask,
-                           pointcloud_features=feat, clamp_prediction=True)
+    loss, l1, ds = loss_fn(image.permute(2, 0, 1), gt, clamp_prediction=True)
     t2 = ev()
     loss.backward()
+    reg = loss_fn.add_regularization_gradient_(s.point_invalid_mask, feat)
     t3 = ev()
     opt_f.step(); opt_p.step()
     t4 = ev()
