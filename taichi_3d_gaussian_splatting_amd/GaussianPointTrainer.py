@@ -14,7 +14,8 @@ fields and defaults (TRN:32-58), same schedule --
 * validation every ``val_interval`` iterations and at 5000 / 7000 (TRN:271-272): PSNR, SSIM, inference time,
   ``scene_{iteration}.parquet`` and ``best_scene.parquet`` (TRN:334-415).
 
-MI355X-side choices: the scene lives on the HIP device, fused Adam kernels, no per-iteration host
+MI355X-side choices: the scene AND the decoded training images live in HBM (``DeviceResidentSamples``: no image
+decoding, host resize or PCIe copy inside the loop), fused Adam kernels, no per-iteration host
 synchronisation (the loss is only read back at the logging interval, so the "problematic iteration" check of
 TRN:232-237 runs at that interval too), and -- when ``torch.distributed`` is initialised -- the rasteriser is
 sharded over tile rows (distributed.py) while loss, optimiser and controller run replicated and bit-identical
@@ -94,6 +95,38 @@ def _make_writer(log_dir: str):
         return _FileWriter(log_dir)
 
 
+class DeviceResidentSamples:
+    """The training set decoded once and kept in HBM (MI355X: 288 GB per GPU; 250 full-HD float images are 6 GB).
+
+    The reference streams every iteration's image through DataLoader workers and a host->device copy
+    (TRN:122-150): PNG/JPEG decoding (tens of ms per full-HD image) and a 25 MB PCIe transfer per iteration are
+    invisible next to its rasteriser, but would cap this trainer -- whose whole iteration takes ~2 ms -- far below
+    what the GPU can do.  Iterating yields ``(image, q, t, CameraInfo)`` tuples of device tensors in a fresh seeded
+    permutation per epoch (the same order on every rank)."""
+
+    def __init__(self, loader, device: torch.device, seed: int):
+        self.samples = []
+        for image, q, t, info in loader:
+            info = CameraInfo(camera_intrinsics=info.camera_intrinsics.to(device), camera_height=int(info.camera_height),
+                              camera_width=int(info.camera_width), camera_id=info.camera_id)
+            self.samples.append((image.to(device), q.to(device), t.to(device), info))
+        self._generator = torch.Generator().manual_seed(seed)
+
+    @staticmethod
+    def estimated_bytes(dataset) -> int:
+        return sum(3 * 4 * int(r["camera_height"]) * int(r["camera_width"]) for r in dataset.records)
+
+    def __len__(self) -> int:
+        return len(self.samples)
+
+    def __iter__(self):
+        for i in torch.randperm(len(self.samples), generator=self._generator).tolist():
+            image, q, t, info = self.samples[i]
+            # a fresh CameraInfo per use: callers may rescale the intrinsics
+            yield image, q, t, CameraInfo(camera_intrinsics=info.camera_intrinsics, camera_height=info.camera_height,
+                                          camera_width=info.camera_width, camera_id=info.camera_id)
+
+
 def _image_grid(images, nrow: int = 2, pad: int = 2) -> torch.Tensor:
     """Minimal ``torchvision.utils.make_grid`` for equally sized [3,H,W] tensors."""
     h, w = images[0].shape[1:]
@@ -140,6 +173,8 @@ class GaussianPointCloudTrainer:
         # additions (not in the reference)
         num_data_loader_workers: int = 4
         seed: int = 0
+        cache_dataset_on_device: bool = True      # keep the decoded training images in HBM (DeviceResidentSamples)
+        device_cache_max_gb: float = 128.0        # ... unless they would need more than this; then stream them
 
     def __init__(self, config: "GaussianPointCloudTrainer.TrainConfig", device: Optional[torch.device] = None):
         if not torch.cuda.is_available():
@@ -232,6 +267,10 @@ class GaussianPointCloudTrainer:
     def train(self):
         cfg = self.config
         train_loader, val_loader = self._loaders()
+        if cfg.cache_dataset_on_device and \
+                DeviceResidentSamples.estimated_bytes(self.train_dataset) <= cfg.device_cache_max_gb * 2 ** 30:
+            train_loader = DeviceResidentSamples(train_loader, self.device, cfg.seed)
+            _log.info("training set resident on %s: %d images", self.device, len(train_loader))
         batches = cycle(train_loader)
         feature_optimizer = torch.optim.Adam([self.scene.point_cloud_features], lr=cfg.feature_learning_rate,
                                              betas=(0.9, 0.999), fused=True)
@@ -249,9 +288,9 @@ class GaussianPointCloudTrainer:
             feature_optimizer.zero_grad(set_to_none=True)
             position_optimizer.zero_grad(set_to_none=True)
             image_gt, q, t, info = next(batches)
-            if downsample_factor > 1:
+            image_gt, q, t, info = self._to_device((image_gt, q, t, info))   # no-op for resident samples
+            if downsample_factor > 1:   # on the device (the reference resizes on the host before the copy)
                 image_gt, info = self._downsample_image_and_camera_info(image_gt, info, downsample_factor)
-            image_gt, q, t, info = self._to_device((image_gt, q, t, info))
 
             band = int(iteration // cfg.increase_color_max_sh_band_interval)
             image_pred, image_depth, pixel_valid_point_count = self._rasterise(q, t, info, band)

@@ -217,13 +217,26 @@ __global__ __launch_bounds__(GS_BLOCK) void scan_single_block_kernel(int32_t *__
     if (threadIdx.x == 0) *total_out = carry > 0x7fffffffLL ? 0x7fffffff : (int)carry;
 }
 
-// RAS:861-870: point_id[mask] -- order-preserving compaction with wave ballots
+// RAS:861-870: point_id[mask] -- order-preserving compaction with wave ballots.  Every workgroup first sums the
+// counts of the workgroups before it (at most a few thousand ints, L2-resident): cheaper than a separate scan
+// launch.  The last workgroup publishes the total (saturating) as the visible count.
 __global__ __launch_bounds__(GS_BLOCK) void compact_kernel(const int8_t *__restrict__ mask, int n,
-                                                          const int32_t *__restrict__ block_offsets,
-                                                          int32_t *__restrict__ ids) {
+                                                          const int32_t *__restrict__ block_counts,
+                                                          int32_t *__restrict__ ids, int32_t *__restrict__ total_out) {
     __shared__ int s_wave[GS_BLOCK / GS_WAVE];
-    int running = block_offsets[blockIdx.x];
+    __shared__ int s_before[GS_BLOCK / GS_WAVE];
     const int w = threadIdx.x >> 6;
+    {
+        int part = 0;
+        for (int b = threadIdx.x; b < (int)blockIdx.x; b += GS_BLOCK) part += block_counts[b];
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) part += __shfl_xor(part, d, GS_WAVE);
+        if (gs_lane() == 0) s_before[w] = part;
+        __syncthreads();
+    }
+    int running = 0;
+#pragma unroll
+    for (int k = 0; k < GS_BLOCK / GS_WAVE; ++k) running += s_before[k];
 #pragma unroll
     for (int r = 0; r < FILTER_ROUNDS; ++r) {
         int i = blockIdx.x * FILTER_ITEMS + r * GS_BLOCK + threadIdx.x;
@@ -243,6 +256,7 @@ __global__ __launch_bounds__(GS_BLOCK) void compact_kernel(const int8_t *__restr
         running += total;
         __syncthreads();
     }
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) *total_out = running;
 }
 
 // ------------------------------------------------------------------ per-visible-point projection
@@ -500,10 +514,8 @@ int gs_filter_compact(const float *xyz, const int8_t *invalid_mask, const int32_
     hipLaunchKernelGGL(filter_kernel, dim3(nblk), dim3(GS_BLOCK), 0, s, xyz, invalid_mask, object_id, intrinsics,
                        q_cp, t_cp, n_points, near_plane, far_plane, width, height, mask, block_counts);
     GS_CHECK_LAUNCH();
-    hipLaunchKernelGGL(scan_single_block_kernel, dim3(1), dim3(GS_BLOCK), 0, s, block_counts, nblk,
-                       counters + GS_COUNTER_NUM_VISIBLE, (int32_t *)nullptr, (int32_t *)nullptr);
-    GS_CHECK_LAUNCH();
-    hipLaunchKernelGGL(compact_kernel, dim3(nblk), dim3(GS_BLOCK), 0, s, mask, n_points, block_counts, ids);
+    hipLaunchKernelGGL(compact_kernel, dim3(nblk), dim3(GS_BLOCK), 0, s, mask, n_points, block_counts, ids,
+                       counters + GS_COUNTER_NUM_VISIBLE);
     GS_CHECK_LAUNCH();
     return 0;
 }

@@ -58,13 +58,13 @@ def all_gather_tile_rows(tensors: Sequence[torch.Tensor], rank: int, world: int,
 
 
 def all_reduce_accumulators(acc: torch.Tensor, group: Optional[dist.ProcessGroup] = None) -> None:
-    """Sum the [M,12] backward accumulators over ranks.  Column 10 holds an int32 pixel count in the
-    float's bits (include/gsplat_hip.h) and is reduced as integers."""
-    npix = acc[:, 10].contiguous().view(torch.int32)
-    dist.all_reduce(npix, op=dist.ReduceOp.SUM, group=group)
-    acc[:, 10] = 0.0
+    """Sum the [M,12] backward accumulators over ranks with ONE collective.  Column 10 holds an int32 pixel
+    count in the float's bits (include/gsplat_hip.h): it is converted to a float value for the reduction (a
+    pixel count is < 2^24, so the float sum is exact in any order) and back to integer bits afterwards."""
+    col = acc[:, 10]
+    col.copy_(col.view(torch.int32).to(torch.float32))
     dist.all_reduce(acc, op=dist.ReduceOp.SUM, group=group)
-    acc[:, 10] = npix.view(torch.float32)
+    col.view(torch.int32).copy_(col.round().to(torch.int32))
 
 
 def shard_rasteriser_across_tile_rows(rasteriser, group: Optional[dist.ProcessGroup] = None, force: bool = False):

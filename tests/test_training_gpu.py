@@ -166,6 +166,12 @@ def test_trainer_end_to_end(tmp_path):
     if os.path.exists(os.path.join(logs, "metrics.jsonl")):   # plain-file writer (no tensorboard installed)
         tags = {json.loads(line)["tag"] for line in open(os.path.join(logs, "metrics.jsonl"))}
         assert {"train/loss", "train/psnr", "val/psnr", "val/inference_time"} <= tags
+    # the streaming path (DataLoader + host->device copy per iteration, as the reference does) still works
+    stream_cfg = TRN.TrainConfig.from_yaml_file(os.path.join(root, "train.yaml"))
+    stream_cfg.cache_dataset_on_device, stream_cfg.num_iterations = False, 30
+    stream_cfg.summary_writer_log_dir = os.path.join(root, "logs_stream")
+    stream_cfg.output_model_dir = None
+    TRN(stream_cfg).train()
     # the reference-compatible command line: template generation
     tmpl = os.path.join(root, "template.yaml")
     subprocess.check_call([sys.executable, os.path.join(ROOT, "gaussian_point_train.py"), "--train_config", tmpl,
