@@ -67,3 +67,49 @@ def rel_l2(a: np.ndarray, b: np.ndarray) -> float:
 
 def report(name: str, **kv) -> None:
     print(f"[parity] {name}: " + ", ".join(f"{k}={v}" for k, v in kv.items()))
+
+
+class OracleRasterisation(torch.nn.Module):
+    """The operator surface (same Input dataclass, outputs, gradients and hook payload) computed by the CPU oracle.
+    TEST ONLY: lets a test run the trainer with the oracle as its rasteriser back end and compare the training
+    outcome with the HIP back end."""
+
+    def __init__(self, config, backward_valid_point_hook=None):
+        super().__init__()
+        from oracle import gs_oracle as O
+        from taichi_3d_gaussian_splatting_amd import GaussianPointCloudRasterisation as RAS
+        self.config, self.hook = config, backward_valid_point_hook
+        outer = self
+
+        class _Fn(torch.autograd.Function):
+            @staticmethod
+            def forward(ctx, xyz, feat, invalid, obj, K, q, t, height, width, band):
+                fwd = O.forward(xyz.detach().cpu().numpy(), feat.detach().cpu().numpy(), invalid.cpu().numpy(),
+                                obj.cpu().numpy(), K.cpu().numpy(), q.cpu().numpy(), t.cpu().numpy(), height, width,
+                                near_plane=config.near_plane, far_plane=config.far_plane,
+                                depth_to_sort_key_scale=config.depth_to_sort_key_scale)
+                with torch.no_grad():   # in-place quaternion normalisation of visible rows (RAS:196-205)
+                    feat.copy_(torch.from_numpy(fwd["feat"]).to(feat.device))
+                ctx.fwd, ctx.band, ctx.device = fwd, band, xyz.device
+                dev = xyz.device
+                return (torch.from_numpy(fwd["image"]).to(dev), torch.from_numpy(fwd["depth"]).to(dev),
+                        torch.from_numpy(fwd["count"]).to(dev))
+
+            @staticmethod
+            def backward(ctx, grad_image, grad_depth, grad_count):
+                bwd = O.backward(ctx.fwd, grad_image.contiguous().cpu().numpy(), ctx.band)
+                dev = ctx.device
+                if outer.hook is not None:
+                    h = bwd["hook"]
+                    outer.hook(RAS.BackwardValidPointHookInput(**{
+                        k: torch.from_numpy(np.ascontiguousarray(v)).to(dev) for k, v in h.items()}))
+                return (torch.from_numpy(bwd["grad_xyz"]).to(dev), torch.from_numpy(bwd["grad_feat"]).to(dev),
+                        None, None, None, None, None, None, None, None)
+
+        self._fn = _Fn
+
+    def forward(self, inp):
+        cam = inp.camera_info
+        return self._fn.apply(inp.point_cloud, inp.point_cloud_features, inp.point_invalid_mask, inp.point_object_id,
+                              cam.camera_intrinsics, inp.q_pointcloud_camera, inp.t_pointcloud_camera,
+                              cam.camera_height, cam.camera_width, inp.color_max_sh_band)

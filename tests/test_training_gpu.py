@@ -266,3 +266,48 @@ def test_fused_scale_regulariser_matches_eager():
     feat.grad = None                                           # no gradient yet: starts from zeros
     loss_fn.add_regularization_gradient_(invalid, feat)
     assert torch.allclose(feat.grad.double().cpu(), leaf.grad, rtol=1e-5, atol=1e-12)
+
+
+def test_trainer_hip_backend_matches_oracle_backend(tmp_path):
+    """BASELINE.md row 5 in miniature: the same training run (same data, config, seeds, loss kernels and optimiser)
+    with the HIP rasteriser and with the CPU oracle as rasteriser back end must produce the same loss curve and
+    the same validation PSNR.  Densification is kept outside the horizon (its sampling is random by design)."""
+    from tests.helpers import OracleRasterisation
+    from taichi_3d_gaussian_splatting_amd.GaussianPointTrainer import GaussianPointCloudTrainer as TRN
+    dev = torch.device("cuda:0")
+    root = str(tmp_path)
+    _write_dataset(root, dev)
+
+    def run(tag, use_oracle):
+        cfg = TRN.TrainConfig(
+            train_dataset_json_path=os.path.join(root, "train.json"), val_dataset_json_path=os.path.join(root, "val.json"),
+            pointcloud_parquet_path=os.path.join(root, "points.parquet"), num_iterations=121, val_interval=10 ** 6,
+            feature_learning_rate=5e-3, position_learning_rate=5e-5, initial_downsample_factor=2,
+            half_downsample_factor_interval=40, increase_color_max_sh_band_interval=50, log_loss_interval=5,
+            log_metrics_interval=10 ** 6, log_image_interval=10 ** 6, summary_writer_log_dir=os.path.join(root, tag),
+            num_data_loader_workers=0)
+        cfg.adaptive_controller_config.num_iterations_warm_up = 10 ** 6
+        cfg.gaussian_point_cloud_scene_config.initial_alpha = 0.5
+        trainer = TRN(cfg)
+        if use_oracle:
+            trainer.rasterisation = OracleRasterisation(cfg.rasterisation_config,
+                                                        backward_valid_point_hook=trainer.adaptive_controller.update)
+        trainer.train()
+        eval_trainer = trainer
+        if use_oracle:   # both final scenes are scored by the same (HIP) renderer
+            eval_trainer.rasterisation = TRN(cfg).rasterisation
+        _, val_loader = trainer._loaders()
+        val = eval_trainer.validation(val_loader, 121)
+        curve = [json.loads(line) for line in open(os.path.join(root, tag, "metrics.jsonl"))]
+        return val, [r["value"] for r in curve if r["tag"] == "train/loss"], trainer
+
+    val_hip, loss_hip, t_hip = run("hip", False)
+    val_ora, loss_ora, t_ora = run("oracle", True)
+    assert len(loss_hip) == len(loss_ora) == 25
+    rel = [abs(a - b) / b for a, b in zip(loss_hip, loss_ora)]
+    assert max(rel[:6]) < 2e-4 and max(rel) < 2e-2, rel           # identical start, no drift beyond 2 % by the end
+    assert loss_hip[-1] < 0.7 * loss_hip[0]
+    assert abs(val_hip["psnr"] - val_ora["psnr"]) < 0.25, (val_hip, val_ora)
+    # the parameters themselves stay together (Adam amplifies fp32-level gradient differences only slowly)
+    d = (t_hip.scene.point_cloud - t_ora.scene.point_cloud).abs().max().item()
+    assert d < 5e-3, d
