@@ -9,8 +9,9 @@
 //  backward: back-to-front traversal (RAS:531-705, gradients UTL:331-348) starting at the tile's last
 //            effective entry; 2 waves per tile, two pixels per lane; the 10 per-Gaussian partial sums are
 //            reduced across the 64 lanes by a permlane-swap + DPP reduce-scatter, combined across the two
-//            waves in LDS, and flushed with one hardware-atomic set per (tile, Gaussian) instead of the
-//            reference's eleven atomics per (pixel, Gaussian).
+//            waves in LDS (ds_add_f32), and stored once per (tile, Gaussian) into that pair's private slot -- no
+//            global atomics at all (the reference issues eleven per (pixel, Gaussian), RAS:674-696); the slots of
+//            a Gaussian are summed in a fixed order by reduce_partials_kernel, so gradients are bitwise reproducible.
 #include "gs_common.h"
 
 // Automatic FMA contraction is off in this file and every fused multiply-add is written explicitly:
@@ -159,7 +160,7 @@ __global__ __launch_bounds__(FWD_THREADS) void blend_forward_kernel(
 // kernel).  Doubling the pixels per lane halves the number of cross-lane reductions, LDS record reads and
 // per-entry uniform work per pixel; the kernel is bound by VALU issue, and the 10-value reduction is a third
 // of the per-hit cost.  Per batch of 128 list entries the two waves combine their partial sums in LDS
-// (ds_add_f32), then thread k flushes entry k with ONE set of hardware atomics per (tile, Gaussian).
+// (ds_add_f32), then thread k stores entry k's 48-B record into its (Gaussian, tile) slot (plain stores).
 constexpr int BWD_THREADS = 128;
 constexpr int BWD_BATCH = 128;
 
