@@ -18,8 +18,9 @@
 //   d SSIM/d x(q) = 1/n * sum_p w(q - p) [A(p) + 2 x(q) B(p) + y(q) C(p)]
 // so the forward kernel stores the three maps and the backward kernel is one more separable convolution.
 //
-// Tiling: a 256-thread block owns 32x16 pixels; the 42x26 halo of all three channels is staged in LDS with
-// row-contiguous (coalesced) loads in either layout, then per channel: horizontal pass -> LDS -> vertical pass.
+// Tiling: a 256-thread block owns one channel of a 32x16 pixel tile; its 42x26 halo is staged in LDS (26 KB per
+// block -> 6 blocks per CU), then horizontal pass -> LDS -> vertical pass, each thread producing 4 (2) adjacent
+// outputs from a sliding register window so that every LDS value is read once per thread, not once per tap.
 // Reductions are deterministic: per-block partial sums, then one fixed-order pass in double.
 #include "gs_common.h"
 
@@ -36,84 +37,129 @@ __device__ const float kWin[WIN] = {1.028380357e-03f, 7.598758209e-03f, 3.600077
 
 __device__ __forceinline__ float clamp01(float v, int on) { return on ? fminf(fmaxf(v, 0.f), 1.f) : v; }
 
-// Stage rows [y0, y0+rows) x cols [x0, x0+cols) of a 3-channel image into dst[c][r][col] (zero outside the image).
-template <int ROWS, int COLS, int PITCH>
-__device__ __forceinline__ void stage_image(const float *__restrict__ img, int hwc, int H, int W, int x0, int y0,
-                                            int clamp, float (*dst)[ROWS][PITCH]) {
-    if (hwc) {
-        for (int i = threadIdx.x; i < ROWS * COLS * 3; i += GS_BLOCK) {
-            const int r = i / (COLS * 3), rem = i - r * (COLS * 3), col = rem / 3, c = rem - col * 3;
-            const int gy = y0 + r, gx = x0 + col;
-            const bool in = gy >= 0 && gy < H && gx >= 0 && gx < W;
-            dst[c][r][col] = in ? clamp01(img[((size_t)gy * W + gx) * 3 + c], clamp) : 0.f;
-        }
-    } else {
-        for (int i = threadIdx.x; i < ROWS * COLS * 3; i += GS_BLOCK) {
-            const int c = i / (ROWS * COLS), rem = i - c * (ROWS * COLS), r = rem / COLS, col = rem - r * COLS;
-            const int gy = y0 + r, gx = x0 + col;
-            const bool in = gy >= 0 && gy < H && gx >= 0 && gx < W;
-            dst[c][r][col] = in ? clamp01(img[((size_t)c * H + gy) * W + gx], clamp) : 0.f;
-        }
+__device__ __forceinline__ size_t pixel_index(int hwc, int c, int gy, int gx, int H, int W) {
+    return hwc ? ((size_t)gy * W + gx) * 3 + c : ((size_t)c * H + gy) * W + gx;
+}
+
+// A workgroup owns one channel of a 32x16 pixel tile (blockIdx.x = 3 * tile_x + channel, so the three workgroups
+// that share the cache lines of an HWC image are dispatched together).
+struct TileId { int c, x0, y0; };
+__device__ __forceinline__ TileId tile_of_block() {
+    TileId t;
+    t.c = blockIdx.x % 3;
+    t.x0 = (blockIdx.x / 3) * LT_W;
+    t.y0 = blockIdx.y * LT_H;
+    return t;
+}
+
+// Stage rows [y0, y0+IN_H) x cols [x0, x0+IN_W) of one channel into dst[r][col] (zero outside the image).
+// Lane = column (42 of 64 lanes active), wave = row phase: no integer division, one address increment per row.
+__device__ __forceinline__ void stage_plane(const float *__restrict__ img, int hwc, int c, int H, int W, int x0, int y0,
+                                            int clamp, float (*dst)[IN_W + 1]) {
+    const int col = threadIdx.x & (GS_WAVE - 1), phase = threadIdx.x / GS_WAVE;
+    if (col >= IN_W) return;
+    const int gx = x0 + col;
+    const bool col_in = gx >= 0 && gx < W;
+    const size_t row_stride = hwc ? (size_t)3 * W : (size_t)W;
+    const float *src = img + (hwc ? (size_t)gx * 3 + c : (size_t)c * H * W + gx);
+#pragma unroll
+    for (int r = phase; r < IN_H; r += GS_BLOCK / GS_WAVE) {
+        const int gy = y0 + r;
+        float v = 0.f;
+        if (col_in && gy >= 0 && gy < H) v = clamp01(src[(size_t)gy * row_stride], clamp);
+        dst[r][col] = v;
     }
 }
+
+constexpr int SEG = 4;                  // outputs per thread in the horizontal passes (sliding 14-value window)
+constexpr int SEGS = LT_W / SEG;        // 8 segments per row
+constexpr int VROWS = 2;                // outputs per thread in the vertical passes (sliding 12-value window)
 
 __global__ __launch_bounds__(GS_BLOCK) void loss_forward_kernel(
     const float *__restrict__ pred, int pred_hwc, int clamp, const float *__restrict__ gt, int H, int W,
     float *__restrict__ dmap, float *__restrict__ partials) {
-    __shared__ float sx[3][IN_H][IN_W + 1];
-    __shared__ float sy[3][IN_H][IN_W + 1];
+    __shared__ float sx[IN_H][IN_W + 1];
+    __shared__ float sy[IN_H][IN_W + 1];
     __shared__ float hz[5][IN_H][LT_W + 1];
     __shared__ float red[2][GS_BLOCK / GS_WAVE];
-    const int x0 = blockIdx.x * LT_W, y0 = blockIdx.y * LT_H;
-    stage_image<IN_H, IN_W, IN_W + 1>(pred, pred_hwc, H, W, x0, y0, clamp, sx);
-    stage_image<IN_H, IN_W, IN_W + 1>(gt, 0, H, W, x0, y0, 0, sy);
+    const TileId t = tile_of_block();
+    stage_plane(pred, pred_hwc, t.c, H, W, t.x0, t.y0, clamp, sx);
+    stage_plane(gt, 0, t.c, H, W, t.x0, t.y0, 0, sy);
     __syncthreads();
-    const size_t plane = (size_t)H * W;
-    float l1 = 0.f, ssim_sum = 0.f;
-    for (int c = 0; c < 3; ++c) {
-        for (int i = threadIdx.x; i < IN_H * LT_W; i += GS_BLOCK) {   // horizontal pass, 5 window sums
-            const int r = i / LT_W, col = i - r * LT_W;
-            float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f, s4 = 0.f;
+    if (threadIdx.x < IN_H * SEGS) {   // horizontal pass: 4 adjacent outputs of one row, 5 window sums each
+        const int r = threadIdx.x / SEGS, c0 = (threadIdx.x % SEGS) * SEG;
+        float a[SEG + HALO], b[SEG + HALO];
 #pragma unroll
-            for (int k = 0; k < WIN; ++k) {
-                const float a = sx[c][r][col + k], b = sy[c][r][col + k], w = kWin[k];
-                s0 = fmaf(w, a, s0); s1 = fmaf(w, b, s1);
-                s2 = fmaf(w, a * a, s2); s3 = fmaf(w, b * b, s3); s4 = fmaf(w, a * b, s4);
+        for (int j = 0; j < SEG + HALO; ++j) { a[j] = sx[r][c0 + j]; b[j] = sy[r][c0 + j]; }
+        float acc[5][SEG];
+#pragma unroll
+        for (int o = 0; o < SEG; ++o)
+#pragma unroll
+            for (int m = 0; m < 5; ++m) acc[m][o] = 0.f;
+#pragma unroll
+        for (int j = 0; j < SEG + HALO; ++j) {
+            const float aa = a[j] * a[j], bb = b[j] * b[j], ab = a[j] * b[j];
+#pragma unroll
+            for (int o = 0; o < SEG; ++o) {
+                const int k = j - o;   // tap index of input j for output o
+                if (k >= 0 && k < WIN) {
+                    const float w = kWin[k];
+                    acc[0][o] = fmaf(w, a[j], acc[0][o]); acc[1][o] = fmaf(w, b[j], acc[1][o]);
+                    acc[2][o] = fmaf(w, aa, acc[2][o]); acc[3][o] = fmaf(w, bb, acc[3][o]);
+                    acc[4][o] = fmaf(w, ab, acc[4][o]);
+                }
             }
-            hz[0][r][col] = s0; hz[1][r][col] = s1; hz[2][r][col] = s2; hz[3][r][col] = s3; hz[4][r][col] = s4;
         }
-        __syncthreads();
-        for (int i = threadIdx.x; i < LT_H * LT_W; i += GS_BLOCK) {   // vertical pass + SSIM map and its partials
-            const int r = i / LT_W, col = i - r * LT_W;
-            const int gy = y0 + r, gx = x0 + col;
+#pragma unroll
+        for (int m = 0; m < 5; ++m)
+#pragma unroll
+            for (int o = 0; o < SEG; ++o) hz[m][r][c0 + o] = acc[m][o];
+    }
+    __syncthreads();
+    float l1 = 0.f, ssim_sum = 0.f;
+    {   // vertical pass: 2 vertically adjacent outputs per thread
+        const int col = threadIdx.x % LT_W, r0 = (threadIdx.x / LT_W) * VROWS;
+        float out[5][VROWS];
+#pragma unroll
+        for (int m = 0; m < 5; ++m) {
+            float v[VROWS + HALO];
+#pragma unroll
+            for (int j = 0; j < VROWS + HALO; ++j) v[j] = hz[m][r0 + j][col];
+#pragma unroll
+            for (int o = 0; o < VROWS; ++o) {
+                float s = 0.f;
+#pragma unroll
+                for (int k = 0; k < WIN; ++k) s = fmaf(kWin[k], v[o + k], s);
+                out[m][o] = s;
+            }
+        }
+        const size_t plane = (size_t)H * W;
+        const int gx = t.x0 + col;
+#pragma unroll
+        for (int o = 0; o < VROWS; ++o) {
+            const int gy = t.y0 + r0 + o;
             if (gy >= H || gx >= W) continue;
-            l1 += fabsf(sx[c][r][col] - sy[c][r][col]);
+            l1 += fabsf(sx[r0 + o][col] - sy[r0 + o][col]);
             float A = 0.f, B = 0.f, Cm = 0.f;
             if (gy < H - HALO && gx < W - HALO) {
-                float mx = 0.f, my = 0.f, sxx = 0.f, syy = 0.f, sxy = 0.f;
-#pragma unroll
-                for (int k = 0; k < WIN; ++k) {
-                    const float w = kWin[k];
-                    mx = fmaf(w, hz[0][r + k][col], mx); my = fmaf(w, hz[1][r + k][col], my);
-                    sxx = fmaf(w, hz[2][r + k][col], sxx); syy = fmaf(w, hz[3][r + k][col], syy);
-                    sxy = fmaf(w, hz[4][r + k][col], sxy);
-                }
+                const float mx = out[0][o], my = out[1][o], sxx = out[2][o], syy = out[3][o], sxy = out[4][o];
                 const float mxx = mx * mx, myy = my * my, mxy = mx * my;
-                const float d1 = mxx + myy + C1, d2 = (sxx - mxx) + (syy - myy) + C2;
-                const float l = (2.f * mxy + C1) / d1, cs = (2.f * (sxy - mxy) + C2) / d2;
+                // v_rcp_f32 (1 ulp) instead of five IEEE divisions: far inside the fp32 noise of var = E[x^2] - mu^2
+                const float i1 = __builtin_amdgcn_rcpf(mxx + myy + C1);
+                const float i2 = __builtin_amdgcn_rcpf((sxx - mxx) + (syy - myy) + C2);
+                const float l = (2.f * mxy + C1) * i1, cs = (2.f * (sxy - mxy) + C2) * i2;
                 ssim_sum += l * cs;
-                A = cs * (2.f * my - 2.f * mx * l) / d1 + l * (2.f * mx * cs - 2.f * my) / d2;
-                B = -l * cs / d2;
-                Cm = 2.f * l / d2;
+                A = cs * (2.f * my - 2.f * mx * l) * i1 + l * (2.f * mx * cs - 2.f * my) * i2;
+                B = -l * cs * i2;
+                Cm = 2.f * l * i2;
             }
             if (dmap) {
-                const size_t o = (size_t)gy * W + gx;
-                dmap[(0 * 3 + c) * plane + o] = A;
-                dmap[(1 * 3 + c) * plane + o] = B;
-                dmap[(2 * 3 + c) * plane + o] = Cm;
+                const size_t p = (size_t)gy * W + gx;
+                dmap[(0 * 3 + t.c) * plane + p] = A;
+                dmap[(1 * 3 + t.c) * plane + p] = B;
+                dmap[(2 * 3 + t.c) * plane + p] = Cm;
             }
         }
-        __syncthreads();
     }
     l1 = gs_wave_sum_to_lane63(l1);
     ssim_sum = gs_wave_sum_to_lane63(ssim_sum);
@@ -154,66 +200,60 @@ __global__ __launch_bounds__(GS_BLOCK) void loss_backward_kernel(
     const float *__restrict__ pred, int pred_hwc, int clamp, const float *__restrict__ gt,
     const float *__restrict__ dmap, int H, int W, float lambda, const float *__restrict__ g_total,
     const float *__restrict__ g_l1, const float *__restrict__ g_dssim, float *__restrict__ grad) {
-    __shared__ float sm[3][IN_H][IN_W + 1];    // A, B, C of one channel, with the 10-pixel halo up/left
+    __shared__ float sm[3][IN_H][IN_W + 1];    // A, B, C of this channel, with the 10-pixel halo up/left
     __shared__ float hz[3][IN_H][LT_W + 1];
-    __shared__ float sx[3][LT_H][LT_W + 1];    // raw prediction (unclamped: the clamp mask needs it)
-    __shared__ float sy[3][LT_H][LT_W + 1];
-    __shared__ float sg[3][LT_H][LT_W + 1];
-    const int x0 = blockIdx.x * LT_W, y0 = blockIdx.y * LT_H;
+    const TileId t = tile_of_block();
     const float gt_total = g_total ? *g_total : 0.f;
     const float w_l1 = (gt_total * (1.f - lambda) + (g_l1 ? *g_l1 : 0.f)) / (3.f * (float)H * (float)W);
     const float w_ss = -(gt_total * lambda + (g_dssim ? *g_dssim : 0.f)) /
                        (3.f * (float)(H - HALO) * (float)(W - HALO));
-    stage_image<LT_H, LT_W, LT_W + 1>(pred, pred_hwc, H, W, x0, y0, 0, sx);
-    stage_image<LT_H, LT_W, LT_W + 1>(gt, 0, H, W, x0, y0, 0, sy);
     const size_t plane = (size_t)H * W;
-    for (int c = 0; c < 3; ++c) {
-        for (int i = threadIdx.x; i < 3 * IN_H * IN_W; i += GS_BLOCK) {
-            const int m = i / (IN_H * IN_W), rem = i - m * (IN_H * IN_W), r = rem / IN_W, col = rem - r * IN_W;
-            const int gy = y0 - HALO + r, gx = x0 - HALO + col;
-            const bool in = gy >= 0 && gx >= 0 && gy < H && gx < W;
-            sm[m][r][col] = in ? dmap[(m * 3 + c) * plane + (size_t)gy * W + gx] : 0.f;
-        }
-        __syncthreads();
-        for (int i = threadIdx.x; i < 3 * IN_H * LT_W; i += GS_BLOCK) {
-            const int m = i / (IN_H * LT_W), rem = i - m * (IN_H * LT_W), r = rem / LT_W, col = rem - r * LT_W;
+#pragma unroll
+    for (int m = 0; m < 3; ++m)
+        stage_plane(dmap + (size_t)(m * 3 + t.c) * plane, 0, 0, H, W, t.x0 - HALO, t.y0 - HALO, 0, sm[m]);
+    __syncthreads();
+    for (int i = threadIdx.x; i < 3 * IN_H * SEGS; i += GS_BLOCK) {   // horizontal pass, 4 outputs per item
+        const int m = i / (IN_H * SEGS), rem = i - m * (IN_H * SEGS), r = rem / SEGS, c0 = (rem % SEGS) * SEG;
+        float v[SEG + HALO];
+#pragma unroll
+        for (int j = 0; j < SEG + HALO; ++j) v[j] = sm[m][r][c0 + j];
+#pragma unroll
+        for (int o = 0; o < SEG; ++o) {
             float s = 0.f;
 #pragma unroll
-            for (int k = 0; k < WIN; ++k) s = fmaf(kWin[k], sm[m][r][col + k], s);
-            hz[m][r][col] = s;
+            for (int k = 0; k < WIN; ++k) s = fmaf(kWin[k], v[o + k], s);
+            hz[m][r][c0 + o] = s;
         }
-        __syncthreads();
-        for (int i = threadIdx.x; i < LT_H * LT_W; i += GS_BLOCK) {
-            const int r = i / LT_W, col = i - r * LT_W;
-            float cA = 0.f, cB = 0.f, cC = 0.f;
-#pragma unroll
-            for (int k = 0; k < WIN; ++k) {
-                const float w = kWin[k];
-                cA = fmaf(w, hz[0][r + k][col], cA); cB = fmaf(w, hz[1][r + k][col], cB);
-                cC = fmaf(w, hz[2][r + k][col], cC);
-            }
-            const float raw = sx[c][r][col], y = sy[c][r][col];
-            const float x = clamp01(raw, clamp);
-            const float d = x - y;
-            const float sgn = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
-            float g = w_l1 * sgn + w_ss * (cA + 2.f * x * cB + y * cC);
-            if (clamp && !(raw >= 0.f && raw <= 1.f)) g = 0.f;   // torch.clamp passes the gradient on [min, max]
-            sg[c][r][col] = g;
-        }
-        __syncthreads();
     }
-    if (pred_hwc) {
-        for (int i = threadIdx.x; i < LT_H * LT_W * 3; i += GS_BLOCK) {
-            const int r = i / (LT_W * 3), rem = i - r * (LT_W * 3), col = rem / 3, c = rem - col * 3;
-            const int gy = y0 + r, gx = x0 + col;
-            if (gy < H && gx < W) grad[((size_t)gy * W + gx) * 3 + c] = sg[c][r][col];
+    __syncthreads();
+    const int col = threadIdx.x % LT_W, r0 = (threadIdx.x / LT_W) * VROWS;
+    float conv[3][VROWS];
+#pragma unroll
+    for (int m = 0; m < 3; ++m) {
+        float v[VROWS + HALO];
+#pragma unroll
+        for (int j = 0; j < VROWS + HALO; ++j) v[j] = hz[m][r0 + j][col];
+#pragma unroll
+        for (int o = 0; o < VROWS; ++o) {
+            float s = 0.f;
+#pragma unroll
+            for (int k = 0; k < WIN; ++k) s = fmaf(kWin[k], v[o + k], s);
+            conv[m][o] = s;
         }
-    } else {
-        for (int i = threadIdx.x; i < LT_H * LT_W * 3; i += GS_BLOCK) {
-            const int c = i / (LT_H * LT_W), rem = i - c * (LT_H * LT_W), r = rem / LT_W, col = rem - r * LT_W;
-            const int gy = y0 + r, gx = x0 + col;
-            if (gy < H && gx < W) grad[((size_t)c * H + gy) * W + gx] = sg[c][r][col];
-        }
+    }
+    const int gx = t.x0 + col;
+#pragma unroll
+    for (int o = 0; o < VROWS; ++o) {
+        const int gy = t.y0 + r0 + o;
+        if (gy >= H || gx >= W) continue;
+        const size_t pi = pixel_index(pred_hwc, t.c, gy, gx, H, W);
+        const float raw = pred[pi], y = gt[pixel_index(0, t.c, gy, gx, H, W)];
+        const float x = clamp01(raw, clamp);
+        const float d = x - y;
+        const float sgn = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
+        float g = w_l1 * sgn + w_ss * (conv[0][o] + 2.f * x * conv[1][o] + y * conv[2][o]);
+        if (clamp && !(raw >= 0.f && raw <= 1.f)) g = 0.f;   // torch.clamp passes the gradient on [min, max]
+        grad[pi] = g;
     }
 }
 
@@ -222,7 +262,7 @@ __global__ __launch_bounds__(GS_BLOCK) void loss_backward_kernel(
 extern "C" {
 
 long long gs_loss_workspace_floats(int height, int width) {
-    return 2LL * gs_div_up(width, LT_W) * gs_div_up(height, LT_H);
+    return 2LL * 3 * gs_div_up(width, LT_W) * gs_div_up(height, LT_H);
 }
 
 int gs_loss_forward(const float *prediction, int prediction_is_hwc, int clamp01_prediction, const float *target,
@@ -230,7 +270,7 @@ int gs_loss_forward(const float *prediction, int prediction_is_hwc, int clamp01_
                     void *stream) {
     GS_REQUIRE(height >= WIN && width >= WIN, "gs_loss_forward: the image must be at least 11x11");
     GS_REQUIRE(prediction && target && workspace && losses, "gs_loss_forward: null pointer");
-    const dim3 grid(gs_div_up(width, LT_W), gs_div_up(height, LT_H));
+    const dim3 grid(3 * gs_div_up(width, LT_W), gs_div_up(height, LT_H));
     hipLaunchKernelGGL(loss_forward_kernel, grid, dim3(GS_BLOCK), 0, (hipStream_t)stream, prediction,
                        prediction_is_hwc, clamp01_prediction, target, height, width, ssim_grad_maps, workspace);
     GS_CHECK_LAUNCH();
@@ -245,7 +285,7 @@ int gs_loss_backward(const float *prediction, int prediction_is_hwc, int clamp01
                      const float *grad_l1, const float *grad_dssim, float *grad_prediction, void *stream) {
     GS_REQUIRE(height >= WIN && width >= WIN, "gs_loss_backward: the image must be at least 11x11");
     GS_REQUIRE(prediction && target && ssim_grad_maps && grad_prediction, "gs_loss_backward: null pointer");
-    const dim3 grid(gs_div_up(width, LT_W), gs_div_up(height, LT_H));
+    const dim3 grid(3 * gs_div_up(width, LT_W), gs_div_up(height, LT_H));
     hipLaunchKernelGGL(loss_backward_kernel, grid, dim3(GS_BLOCK), 0, (hipStream_t)stream, prediction,
                        prediction_is_hwc, clamp01_prediction, target, ssim_grad_maps, height, width, lambda,
                        grad_total, grad_l1, grad_dssim, grad_prediction);
