@@ -228,6 +228,12 @@ int gs_scale_regulariser_backward(const float *features, const int8_t *point_inv
                                   const float *value_and_count, float weight, const float *upstream,
                                   float *grad_features, void *stream);
 
+/* One Adam step over a flat float buffer, in place (torch.optim.Adam semantics without weight decay / amsgrad;
+ * the reference's optimisers, GaussianPointTrainer.py:126-129).  step is the 1-based step count (bias correction);
+ * all four buffers hold n floats and are 16-byte aligned. */
+int gs_adam_step(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, long long n, double lr,
+                 double beta1, double beta2, double eps, int step, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

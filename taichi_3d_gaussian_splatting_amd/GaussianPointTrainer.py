@@ -15,7 +15,7 @@ fields and defaults (TRN:32-58), same schedule --
   ``scene_{iteration}.parquet`` and ``best_scene.parquet`` (TRN:334-415).
 
 MI355X-side choices: the scene AND the decoded training images live in HBM (``DeviceResidentSamples``: no image
-decoding, host resize or PCIe copy inside the loop), fused Adam kernels, no per-iteration host
+decoding, host resize or PCIe copy inside the loop), a hand-written streaming Adam kernel (optim.py), no per-iteration host
 synchronisation (the loss is only read back at the logging interval, so the "problematic iteration" check of
 TRN:232-237 runs at that interval too), and -- when ``torch.distributed`` is initialised -- the rasteriser is
 sharded over tile rows (distributed.py) while loss, optimiser and controller run replicated and bit-identical
@@ -42,6 +42,7 @@ from .GaussianPointCloudRasterisation import GaussianPointCloudRasterisation
 from .GaussianPointCloudScene import GaussianPointCloudScene
 from .ImagePoseDataset import ImagePoseDataset
 from .LossFunction import LossFunction, ssim
+from .optim import Adam
 from .yaml_config import YAMLConfig
 
 _log = logging.getLogger(__name__)
@@ -272,10 +273,8 @@ class GaussianPointCloudTrainer:
             train_loader = DeviceResidentSamples(train_loader, self.device, cfg.seed)
             _log.info("training set resident on %s: %d images", self.device, len(train_loader))
         batches = cycle(train_loader)
-        feature_optimizer = torch.optim.Adam([self.scene.point_cloud_features], lr=cfg.feature_learning_rate,
-                                             betas=(0.9, 0.999), fused=True)
-        position_optimizer = torch.optim.Adam([self.scene.point_cloud], lr=cfg.position_learning_rate,
-                                              betas=(0.9, 0.999), fused=True)
+        feature_optimizer = Adam([self.scene.point_cloud_features], lr=cfg.feature_learning_rate, betas=(0.9, 0.999))
+        position_optimizer = Adam([self.scene.point_cloud], lr=cfg.position_learning_rate, betas=(0.9, 0.999))
         scheduler = torch.optim.lr_scheduler.ExponentialLR(position_optimizer,
                                                            gamma=cfg.position_learning_rate_decay_rate)
         downsample_factor = cfg.initial_downsample_factor

@@ -1,0 +1,44 @@
+"""Adam for the trainer's parameter tensors on the HIP device.
+
+Same update rule, hyper-parameter names, ``param_groups`` and ``state_dict`` layout (``step``, ``exp_avg``,
+``exp_avg_sq``) as ``torch.optim.Adam`` without weight decay / amsgrad -- what the reference instantiates at
+GaussianPointTrainer.py:126-129 -- so learning-rate schedulers and checkpoints work unchanged.  The step itself is one
+streaming HIP kernel per tensor (csrc/gs_optim.hip); there is no CPU path.
+"""
+from __future__ import annotations
+
+import torch
+
+from ._lib import call, current_stream, ptr
+
+
+class Adam(torch.optim.Optimizer):
+    def __init__(self, params, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8):
+        if lr < 0 or eps < 0 or not (0 <= betas[0] < 1 and 0 <= betas[1] < 1):
+            raise ValueError("invalid Adam hyper-parameters")
+        super().__init__(params, dict(lr=lr, betas=tuple(betas), eps=eps))
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        for group in self.param_groups:
+            beta1, beta2 = group["betas"]
+            for p in group["params"]:
+                if p.grad is None:
+                    continue
+                if not (p.is_cuda and p.dtype == torch.float32 and p.is_contiguous()):
+                    raise RuntimeError("optim.Adam needs contiguous float32 parameters on the HIP device")
+                grad = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
+                state = self.state[p]
+                if not state:
+                    state["step"] = 0
+                    state["exp_avg"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+                    state["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+                state["step"] = int(state["step"]) + 1
+                call("gs_adam_step", ptr(p), ptr(grad), ptr(state["exp_avg"]), ptr(state["exp_avg_sq"]), p.numel(),
+                     float(group["lr"]), float(beta1), float(beta2), float(group["eps"]), state["step"],
+                     current_stream(p.device))
+        return loss

@@ -10,6 +10,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from taichi_3d_gaussian_splatting_amd import CameraInfo, GaussianPointCloudRasterisation as RAS  # noqa: E402
 from taichi_3d_gaussian_splatting_amd.LossFunction import LossFunction  # noqa: E402
+from taichi_3d_gaussian_splatting_amd.optim import Adam  # noqa: E402
 from taichi_3d_gaussian_splatting_amd.synthetic import make_config_scene  # noqa: E402
 
 workload = sys.argv[1] if len(sys.argv) > 1 else "headline_1m_1080p"
@@ -21,8 +22,8 @@ gt = torch.rand(3, s.height, s.width, device="cuda")
 ras = RAS(RAS.GaussianPointCloudRasterisationConfig(near_plane=s.near_plane, far_plane=s.far_plane,
                                                     depth_to_sort_key_scale=s.depth_to_sort_key_scale))
 loss_fn = LossFunction(LossFunction.LossFunctionConfig())
-opt_f = torch.optim.Adam([feat], lr=1e-3, fused=True)
-opt_p = torch.optim.Adam([xyz], lr=1e-5, fused=True)
+opt_f = Adam([feat], lr=1e-3) if os.environ.get('GS_TORCH_ADAM') != '1' else torch.optim.Adam([feat], lr=1e-3, fused=True)
+opt_p = Adam([xyz], lr=1e-5) if os.environ.get('GS_TORCH_ADAM') != '1' else torch.optim.Adam([xyz], lr=1e-5, fused=True)
 cam = CameraInfo(camera_intrinsics=s.camera_intrinsics, camera_height=s.height, camera_width=s.width, camera_id=0)
 marks = {}
 
