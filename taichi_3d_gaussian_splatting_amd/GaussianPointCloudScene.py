@@ -176,3 +176,76 @@ class GaussianPointCloudScene(nn.Module):
         with open(path, "wb") as fh:
             fh.write(("\n".join(header) + "\n").encode("ascii"))
             fh.write(rec.tobytes())
+
+    @staticmethod
+    def from_ply(path: str, config: Optional["GaussianPointCloudScene.PointCloudSceneConfig"] = None):
+        """Load a 3DGS-format PLY (what ``to_ply`` writes and what the official implementation trains): the
+        mapping the reference's benchmark uses (benchmark/inference_benchmark.py:21-82) -- ``f_rest`` is
+        channel-major [3][15], ``rot`` is (w,x,y,z) and is normalised, opacity / scales stay logit / log."""
+        config = config or GaussianPointCloudScene.PointCloudSceneConfig()
+        v = _read_ply_vertices(path)
+        n = v.shape[0]
+        names = v.dtype.names
+        rest = sorted((k for k in names if k.startswith("f_rest_")), key=lambda k: int(k.split("_")[-1]))
+        if len(rest) != 45:
+            raise ValueError(f"{path}: expected 45 f_rest_* properties (SH degree 3), found {len(rest)}")
+        xyz = np.stack([v["x"], v["y"], v["z"]], axis=1).astype(np.float32)
+        feat = np.zeros((n, 56), np.float32)
+        rot = np.stack([v[f"rot_{i}"] for i in (1, 2, 3, 0)], axis=1).astype(np.float64)   # wxyz -> xyzw
+        feat[:, 0:4] = rot / np.linalg.norm(rot, axis=1, keepdims=True)
+        feat[:, 4:7] = np.stack([v[f"scale_{i}"] for i in range(3)], axis=1)
+        feat[:, 7] = v["opacity"]
+        extra = np.stack([v[k] for k in rest], axis=1).reshape(n, 3, 15)
+        for ch in range(3):
+            feat[:, 8 + 16 * ch] = v[f"f_dc_{ch}"]
+            feat[:, 9 + 16 * ch: 24 + 16 * ch] = extra[:, ch]
+        return GaussianPointCloudScene(xyz, config, point_cloud_features=torch.from_numpy(feat))
+
+
+_PLY_TYPES = {"char": "i1", "int8": "i1", "uchar": "u1", "uint8": "u1", "short": "i2", "int16": "i2",
+              "ushort": "u2", "uint16": "u2", "int": "i4", "int32": "i4", "uint": "u4", "uint32": "u4",
+              "float": "f4", "float32": "f4", "double": "f8", "float64": "f8"}
+
+
+def _read_ply_vertices(path: str) -> np.ndarray:
+    """Minimal PLY reader: the scalar properties of the ``vertex`` element (binary little/big endian or ascii) as a
+    structured array.  List properties and other elements before ``vertex`` are not supported."""
+    with open(path, "rb") as fh:
+        if fh.readline().strip() != b"ply":
+            raise ValueError(f"{path}: not a PLY file")
+        fmt, count, props, in_vertex, seen_other = None, None, [], False, False
+        while True:
+            line = fh.readline()
+            if not line:
+                raise ValueError(f"{path}: unterminated PLY header")
+            tok = line.decode("ascii", "replace").split()
+            if not tok or tok[0] == "comment":
+                continue
+            if tok[0] == "format":
+                fmt = tok[1]
+            elif tok[0] == "element":
+                in_vertex = tok[1] == "vertex"
+                if in_vertex:
+                    if seen_other:
+                        raise ValueError(f"{path}: elements before 'vertex' are not supported")
+                    count = int(tok[2])
+                elif count is None:
+                    seen_other = True
+            elif tok[0] == "property" and in_vertex:
+                if tok[1] == "list":
+                    raise ValueError(f"{path}: list properties on vertices are not supported")
+                props.append((tok[2], _PLY_TYPES[tok[1]]))
+            elif tok[0] == "end_header":
+                break
+        if fmt is None or count is None:
+            raise ValueError(f"{path}: header lacks format or vertex element")
+        if fmt == "ascii":
+            rows = np.loadtxt(fh, max_rows=count, ndmin=2)
+            out = np.empty(count, dtype=[(nm, "<" + tp) for nm, tp in props])
+            for i, (nm, _) in enumerate(props):
+                out[nm] = rows[:, i]
+            return out
+        order = "<" if fmt == "binary_little_endian" else ">"
+        dtype = np.dtype([(nm, order + tp) for nm, tp in props])
+        data = np.frombuffer(fh.read(count * dtype.itemsize), dtype=dtype, count=count)
+        return data

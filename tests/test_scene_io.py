@@ -124,3 +124,44 @@ def test_render_script_end_to_end(tmp_path):
                     s.point_object_id.numpy(), s.camera_intrinsics.numpy(), s.q_pointcloud_camera.numpy(),
                     s.t_pointcloud_camera.numpy(), 64, 96)["image"]
     assert np.abs(frame - np.clip(ref, 0, 1)).max() <= 1.0 / 255.0 + 1e-6   # 8-bit quantisation (truncation)
+
+
+def test_ply_import_round_trip_and_formats(tmp_path):
+    """to_ply -> from_ply reproduces the scene (quaternions come back normalised); the reader also takes ascii
+    and big-endian files and rejects what it does not support."""
+    from taichi_3d_gaussian_splatting_amd.GaussianPointCloudScene import _read_ply_vertices
+    s = make_scene(n=37, height=64, width=64, s_min=0.01, s_max=0.05, seed=8)
+    scene = Scene(s.point_cloud, Scene.PointCloudSceneConfig(), point_cloud_features=s.point_cloud_features)
+    path = str(tmp_path / "a.ply")
+    scene.to_ply(path)
+    back = Scene.from_ply(path)
+    assert torch.equal(back.point_cloud.data, s.point_cloud)
+    assert torch.allclose(back.point_cloud_features.data, s.point_cloud_features, atol=1e-6)   # unit quaternions already
+    assert torch.equal(back.point_cloud_features.data[:, 4:], s.point_cloud_features[:, 4:])
+    v = _read_ply_vertices(path)
+    names = v.dtype.names
+    # the same content as ascii and as big-endian binary
+    ascii_path, be_path = str(tmp_path / "b.ply"), str(tmp_path / "c.ply")
+    header = ["ply", "format ascii 1.0", "comment made by a test", f"element vertex {len(v)}"] + \
+        [f"property float {n}" for n in names] + ["end_header"]
+    with open(ascii_path, "w") as fh:
+        fh.write("\n".join(header) + "\n")
+        for row in v:
+            fh.write(" ".join(repr(float(x)) for x in row) + "\n")
+    with open(be_path, "wb") as fh:
+        fh.write(("\n".join(["ply", "format binary_big_endian 1.0", f"element vertex {len(v)}"] +
+                            [f"property float {n}" for n in names] + ["end_header"]) + "\n").encode())
+        fh.write(v.astype([(n, ">f4") for n in names]).tobytes())
+    for other in (ascii_path, be_path):
+        again = Scene.from_ply(other)
+        assert torch.equal(again.point_cloud.data, back.point_cloud.data)
+        assert torch.equal(again.point_cloud_features.data, back.point_cloud_features.data)
+    bad = str(tmp_path / "d.ply")
+    with open(bad, "wb") as fh:
+        fh.write(b"ply\nformat ascii 1.0\nelement vertex 1\nproperty float x\nend_header\n0\n")
+    with pytest.raises((ValueError, KeyError)):
+        Scene.from_ply(bad)
+    with open(bad, "wb") as fh:
+        fh.write(b"obj\n")
+    with pytest.raises(ValueError):
+        _read_ply_vertices(bad)
