@@ -32,11 +32,24 @@ struct TileCoord { int tile_u, tile_v, tile_id; };
 // blockIdx -> owned tile.  Consecutive workgroups are dispatched round-robin over the 8 XCDs
 // (block b -> XCD b%8); the remap gives every XCD a contiguous run of tiles so that neighbouring
 // tiles (which share Gaussians) hit the same 4-MiB L2.  Speed only, never correctness.
+#ifndef GS_XCD_CHUNK
+#define GS_XCD_CHUNK 0   // 0: one contiguous run of tiles per XCD; C > 0: runs of C tiles dealt round-robin to the XCDs.
+                         // Measured (tools/xcd_sweep.sh): C = 8, 120, 480 equal the default within 1 %; C = 30 (a fixed
+                         // quarter of every tile row per XCD) is 25 % slower -- XCD load balance matters, L2 locality less.
+#endif
 __device__ __forceinline__ TileCoord owned_tile(int tw, int row_begin, int row_step) {
     const int nb = gridDim.x;
     int b = blockIdx.x;
-    const int chunk = nb / 8;
-    if (b < chunk * 8) b = (b % 8) * chunk + b / 8;
+    if (GS_XCD_CHUNK > 0) {
+        const int group = 8 * GS_XCD_CHUNK, full = (nb / group) * group;
+        if (b < full) {
+            const int x = b % 8, j = b / 8;   // XCD, position in that XCD's dispatch order
+            b = ((j / GS_XCD_CHUNK) * 8 + x) * GS_XCD_CHUNK + (j % GS_XCD_CHUNK);
+        }
+    } else {
+        const int chunk = nb / 8;
+        if (b < chunk * 8) b = (b % 8) * chunk + b / 8;
+    }
     TileCoord t;
     t.tile_u = b % tw;
     t.tile_v = row_begin + (b / tw) * row_step;
