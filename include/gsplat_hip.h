@@ -217,16 +217,15 @@ int gs_loss_backward(const float *prediction, int prediction_is_hwc, int clamp01
                      const float *ssim_grad_maps, int height, int width, float lambda, const float *grad_total,
                      const float *grad_l1, const float *grad_dssim, float *grad_prediction, void *stream);
 
-/* Scale regulariser R = mean_{live i} ||exp(s_i)||_2 (LossFunction.py:42-54: features[mask == 0, 4:7]).
- * forward : value_and_count float[2] = {R, number of live Gaussians}; workspace float[gs_scale_regulariser_workspace_floats()].
- * backward: grad_features[i][4..6] += weight * (*upstream, 1 if null) * dR/ds_i for live rows, in place -- the
- *           dense [N,56] gradient tensor eager autograd would build and add is never materialised. */
+/* Scale regulariser R = mean_{live i} ||exp(s_i)||_2 (LossFunction.py:42-54: features[mask == 0, 4:7]) and,
+ * when grad_features is not null, its gradient added in place:
+ *   grad_features[i][4..6] += weight * (*upstream, 1 if null) * dR/ds_i      for live rows
+ * -- the dense [N,56] gradient tensor eager autograd would build and add is never materialised.
+ * value_and_count float[2] = {R, number of live Gaussians}; workspace float[gs_scale_regulariser_workspace_floats()]. */
 long long gs_scale_regulariser_workspace_floats(void);
-int gs_scale_regulariser_forward(const float *features, const int8_t *point_invalid_mask, int n_points,
-                                 float *workspace, float *value_and_count, void *stream);
-int gs_scale_regulariser_backward(const float *features, const int8_t *point_invalid_mask, int n_points,
-                                  const float *value_and_count, float weight, const float *upstream,
-                                  float *grad_features, void *stream);
+int gs_scale_regulariser(const float *features, const int8_t *point_invalid_mask, int n_points, float weight,
+                         const float *upstream, float *grad_features, float *workspace, float *value_and_count,
+                         void *stream);
 
 /* One Adam step over a flat float buffer, in place (torch.optim.Adam semantics without weight decay / amsgrad;
  * the reference's optimisers, GaussianPointTrainer.py:126-129).  step is the 1-based step count (bias correction);

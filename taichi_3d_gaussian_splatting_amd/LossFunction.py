@@ -143,9 +143,8 @@ class LossFunction(nn.Module):
             pointcloud_features.grad = torch.zeros_like(pointcloud_features)
         if pointcloud_features.is_cuda:
             from . import hip_ops
-            value_and_count = hip_ops.scale_regulariser(pointcloud_features, point_invalid_mask)
-            hip_ops.scale_regulariser_add_gradient_(pointcloud_features, point_invalid_mask, value_and_count, weight,
-                                                    pointcloud_features.grad)
+            value_and_count = hip_ops.scale_regulariser(pointcloud_features, point_invalid_mask, weight,
+                                                        grad_features=pointcloud_features.grad)
             return weight * value_and_count[0]
         with torch.enable_grad():
             leaf = pointcloud_features.detach().requires_grad_(True)

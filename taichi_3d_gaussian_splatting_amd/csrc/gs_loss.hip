@@ -298,96 +298,113 @@ int gs_loss_backward(const float *prediction, int prediction_is_hwc, int clamp01
 // ---------------------------------------------------------------------------------------------------------------
 // Scale regulariser of the trainer: R = mean over live Gaussians of || exp(s) ||_2   (LossFunction.py:42-54).
 // Eager autograd materialises a dense [N,56] gradient for it and adds it to the rasteriser's (3 x 224 MB of
-// traffic at N = 1e6); here the value is one reduction and the gradient is added in place into columns 4..6 of the
-// existing feature gradient.
+// traffic at N = 1e6).  Here: a 1-byte-per-row count of the live rows, then ONE pass over the 12 scale bytes of
+// every row that produces the partial sums of the value and adds weight * dR/ds in place into columns 4..6 of the
+// existing feature gradient, then a fixed-order reduction of the partial sums.
 namespace {
 
-__global__ __launch_bounds__(GS_BLOCK) void scale_reg_partials_kernel(const float *__restrict__ feat,
-                                                                       const int8_t *__restrict__ invalid, int n,
-                                                                       float *__restrict__ partials) {
-    __shared__ float red[2][GS_BLOCK / GS_WAVE];
-    float sum = 0.f, cnt = 0.f;
+constexpr int REG_BLOCKS = 1024;
+
+constexpr int COUNT_BLOCKS = GS_BLOCK;   // partial live counts, summed by one workgroup-wide reduction in the consumers
+
+__device__ __forceinline__ int block_sum_int(int v, int *red) {
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d, GS_WAVE);
+    if (gs_lane() == 0) red[threadIdx.x / GS_WAVE] = v;
+    __syncthreads();
+    int t = 0;
+    for (int i = 0; i < GS_BLOCK / GS_WAVE; ++i) t += red[i];
+    __syncthreads();
+    return t;
+}
+
+__global__ __launch_bounds__(GS_BLOCK) void count_live_kernel(const int8_t *__restrict__ invalid, int n,
+                                                              int *__restrict__ partial_counts) {
+    __shared__ int red[GS_BLOCK / GS_WAVE];
+    int cnt = 0;
+    for (int i = blockIdx.x * GS_BLOCK + threadIdx.x; i < n; i += COUNT_BLOCKS * GS_BLOCK) cnt += invalid[i] == 0 ? 1 : 0;
+    const int t = block_sum_int(cnt, red);
+    if (threadIdx.x == 0) partial_counts[blockIdx.x] = t;
+}
+
+__global__ __launch_bounds__(GS_BLOCK) void scale_reg_kernel(const float *__restrict__ feat,
+                                                             const int8_t *__restrict__ invalid, int n,
+                                                             const int *__restrict__ live_count, float weight,
+                                                             const float *__restrict__ upstream,
+                                                             float *__restrict__ grad_feat,
+                                                             float *__restrict__ partials) {
+    __shared__ float red[GS_BLOCK / GS_WAVE];
+    __shared__ int redi[GS_BLOCK / GS_WAVE];
+    const int live = block_sum_int(live_count[threadIdx.x], redi);
+    const float scale = grad_feat ? weight * (upstream ? *upstream : 1.f) / (float)live : 0.f;
+    float sum = 0.f;
     for (int i = blockIdx.x * GS_BLOCK + threadIdx.x; i < n; i += gridDim.x * GS_BLOCK) {
         if (invalid[i] != 0) continue;
         const float *s = feat + (size_t)GS_FEATURE_DIM * i + 4;
         const float a = expf(s[0]), b = expf(s[1]), c = expf(s[2]);
-        sum += sqrtf(a * a + b * b + c * c);
-        cnt += 1.f;
+        const float nrm = sqrtf(a * a + b * b + c * c);
+        sum += nrm;
+        if (grad_feat) {
+            float *g = grad_feat + (size_t)GS_FEATURE_DIM * i + 4;
+            const float inv = scale / nrm;
+            g[0] = fmaf(a * a, inv, g[0]);
+            g[1] = fmaf(b * b, inv, g[1]);
+            g[2] = fmaf(c * c, inv, g[2]);
+        }
     }
     sum = gs_wave_sum_to_lane63(sum);
-    cnt = gs_wave_sum_to_lane63(cnt);
-    if (gs_lane() == GS_WAVE - 1) { red[0][threadIdx.x / GS_WAVE] = sum; red[1][threadIdx.x / GS_WAVE] = cnt; }
+    if (gs_lane() == GS_WAVE - 1) red[threadIdx.x / GS_WAVE] = sum;
     __syncthreads();
     if (threadIdx.x == 0) {
-        float a = 0.f, b = 0.f;
-        for (int i = 0; i < GS_BLOCK / GS_WAVE; ++i) { a += red[0][i]; b += red[1][i]; }
-        partials[2 * blockIdx.x] = a;
-        partials[2 * blockIdx.x + 1] = b;
+        float t = 0.f;
+        for (int i = 0; i < GS_BLOCK / GS_WAVE; ++i) t += red[i];
+        partials[blockIdx.x] = t;
     }
 }
 
 __global__ __launch_bounds__(GS_BLOCK) void scale_reg_finalize_kernel(const float *__restrict__ partials, int n_blocks,
+                                                                       const int *__restrict__ live_count,
                                                                        float *__restrict__ out) {
-    __shared__ double red[2][GS_BLOCK];
-    double a = 0.0, b = 0.0;
-    for (int i = threadIdx.x; i < n_blocks; i += GS_BLOCK) { a += partials[2 * i]; b += partials[2 * i + 1]; }
-    red[0][threadIdx.x] = a; red[1][threadIdx.x] = b;
+    __shared__ double red[GS_BLOCK];
+    __shared__ int redi[GS_BLOCK / GS_WAVE];
+    const int live = block_sum_int(live_count[threadIdx.x], redi);
+    double a = 0.0;
+    for (int i = threadIdx.x; i < n_blocks; i += GS_BLOCK) a += partials[i];
+    red[threadIdx.x] = a;
     __syncthreads();
     for (int s = GS_BLOCK / 2; s > 0; s >>= 1) {
-        if (threadIdx.x < s) { red[0][threadIdx.x] += red[0][threadIdx.x + s]; red[1][threadIdx.x] += red[1][threadIdx.x + s]; }
+        if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
         __syncthreads();
     }
-    if (threadIdx.x == 0) { out[0] = (float)(red[0][0] / red[1][0]); out[1] = (float)red[1][0]; }   // 0/0 = nan, like torch
+    if (threadIdx.x == 0) {   // 0/0 = nan, like torch's mean over an empty selection
+        out[0] = (float)(red[0] / (double)live);
+        out[1] = (float)live;
+    }
 }
-
-__global__ __launch_bounds__(GS_BLOCK) void scale_reg_backward_kernel(const float *__restrict__ feat,
-                                                                       const int8_t *__restrict__ invalid, int n,
-                                                                       const float *__restrict__ value_and_count,
-                                                                       float weight, const float *__restrict__ upstream,
-                                                                       float *__restrict__ grad_feat) {
-    const int i = blockIdx.x * GS_BLOCK + threadIdx.x;
-    if (i >= n || invalid[i] != 0) return;
-    const float scale = weight * (upstream ? *upstream : 1.f) / value_and_count[1];
-    const float *s = feat + (size_t)GS_FEATURE_DIM * i + 4;
-    float *g = grad_feat + (size_t)GS_FEATURE_DIM * i + 4;
-    const float a = expf(s[0]), b = expf(s[1]), c = expf(s[2]);
-    const float inv = scale / sqrtf(a * a + b * b + c * c);
-    g[0] = fmaf(a * a, inv, g[0]);
-    g[1] = fmaf(b * b, inv, g[1]);
-    g[2] = fmaf(c * c, inv, g[2]);
-}
-
-constexpr int REG_BLOCKS = 1024;
 
 }  // namespace
 
 extern "C" {
 
-long long gs_scale_regulariser_workspace_floats(void) { return 2LL * REG_BLOCKS; }
+long long gs_scale_regulariser_workspace_floats(void) { return REG_BLOCKS + COUNT_BLOCKS; }
 
-int gs_scale_regulariser_forward(const float *features, const int8_t *point_invalid_mask, int n_points,
-                                 float *workspace, float *value_and_count, void *stream) {
-    GS_REQUIRE(n_points >= 0 && workspace && value_and_count, "gs_scale_regulariser_forward: bad argument");
-    const int blocks = n_points > 0 ? (gs_div_up(n_points, GS_BLOCK) < REG_BLOCKS ? gs_div_up(n_points, GS_BLOCK) : REG_BLOCKS) : 0;
+int gs_scale_regulariser(const float *features, const int8_t *point_invalid_mask, int n_points, float weight,
+                         const float *upstream, float *grad_features, float *workspace, float *value_and_count,
+                         void *stream) {
+    GS_REQUIRE(n_points >= 0 && workspace && value_and_count, "gs_scale_regulariser: bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    int *live = reinterpret_cast<int *>(workspace + REG_BLOCKS);
+    hipLaunchKernelGGL(count_live_kernel, dim3(COUNT_BLOCKS), dim3(GS_BLOCK), 0, s, point_invalid_mask, n_points, live);
+    GS_CHECK_LAUNCH();
+    int blocks = gs_div_up(n_points, GS_BLOCK);
+    blocks = blocks < REG_BLOCKS ? blocks : REG_BLOCKS;
     if (blocks > 0) {
-        hipLaunchKernelGGL(scale_reg_partials_kernel, dim3(blocks), dim3(GS_BLOCK), 0, (hipStream_t)stream, features,
-                           point_invalid_mask, n_points, workspace);
+        hipLaunchKernelGGL(scale_reg_kernel, dim3(blocks), dim3(GS_BLOCK), 0, s, features, point_invalid_mask, n_points,
+                           live, weight, upstream, grad_features, workspace);
         GS_CHECK_LAUNCH();
     }
-    hipLaunchKernelGGL(scale_reg_finalize_kernel, dim3(1), dim3(GS_BLOCK), 0, (hipStream_t)stream, workspace, blocks,
+    hipLaunchKernelGGL(scale_reg_finalize_kernel, dim3(1), dim3(GS_BLOCK), 0, s, workspace, blocks, live,
                        value_and_count);
-    GS_CHECK_LAUNCH();
-    return 0;
-}
-
-int gs_scale_regulariser_backward(const float *features, const int8_t *point_invalid_mask, int n_points,
-                                  const float *value_and_count, float weight, const float *upstream,
-                                  float *grad_features, void *stream) {
-    GS_REQUIRE(n_points >= 0 && value_and_count && grad_features, "gs_scale_regulariser_backward: bad argument");
-    if (n_points == 0) return 0;
-    hipLaunchKernelGGL(scale_reg_backward_kernel, dim3(gs_div_up(n_points, GS_BLOCK)), dim3(GS_BLOCK), 0,
-                       (hipStream_t)stream, features, point_invalid_mask, n_points, value_and_count, weight, upstream,
-                       grad_features);
     GS_CHECK_LAUNCH();
     return 0;
 }

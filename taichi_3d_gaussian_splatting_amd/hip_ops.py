@@ -333,26 +333,22 @@ def loss_backward(prediction: torch.Tensor, target: torch.Tensor, maps: torch.Te
     return out.permute(2, 0, 1) if is_hwc else out
 
 
-def scale_regulariser(features: torch.Tensor, point_invalid_mask: torch.Tensor) -> torch.Tensor:
-    """-> f32[2] = {mean ||exp(s)|| over live Gaussians, live count} (LOS:42-54)."""
+def scale_regulariser(features: torch.Tensor, point_invalid_mask: torch.Tensor, weight: float = 0.0,
+                      grad_features: Optional[torch.Tensor] = None,
+                      upstream: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """-> f32[2] = {mean ||exp(s)|| over live Gaussians, live count} (LOS:42-54).  With ``grad_features`` (a
+    contiguous [N,56] tensor) the same pass adds ``weight * upstream * dR/ds`` into its columns 4..6, in place."""
     features = _f32(features, "point_cloud_features")
     _require_device(point_invalid_mask, "point_invalid_mask")
     if point_invalid_mask.dtype != torch.int8:
         raise TypeError("point_invalid_mask must be int8")
+    if grad_features is not None:
+        _f32(grad_features, "grad_features", False)
+        if not grad_features.is_contiguous() or grad_features.shape != features.shape:
+            raise ValueError("grad_features must be a contiguous [N,56] tensor")
     dev = features.device
     ws = torch.empty(_lib.load().gs_scale_regulariser_workspace_floats(), dtype=torch.float32, device=dev)
     out = torch.empty(2, dtype=torch.float32, device=dev)
-    call("gs_scale_regulariser_forward", ptr(features), ptr(point_invalid_mask.contiguous()), features.shape[0],
-         ptr(ws), ptr(out), current_stream(dev))
+    call("gs_scale_regulariser", ptr(features), ptr(point_invalid_mask.contiguous()), features.shape[0], float(weight),
+         ptr(upstream), ptr(grad_features), ptr(ws), ptr(out), current_stream(dev))
     return out
-
-
-def scale_regulariser_add_gradient_(features: torch.Tensor, point_invalid_mask: torch.Tensor,
-                                    value_and_count: torch.Tensor, weight: float, grad_features: torch.Tensor,
-                                    upstream: Optional[torch.Tensor] = None) -> None:
-    """grad_features[:, 4:7] += weight * upstream * d(mean ||exp(s)||)/ds, in place (live rows only)."""
-    features, grad_features = _f32(features, "point_cloud_features"), _f32(grad_features, "grad_features", False)
-    if not grad_features.is_contiguous() or grad_features.shape != features.shape:
-        raise ValueError("grad_features must be a contiguous [N,56] tensor")
-    call("gs_scale_regulariser_backward", ptr(features), ptr(point_invalid_mask.contiguous()), features.shape[0],
-         ptr(value_and_count), float(weight), ptr(upstream), ptr(grad_features), current_stream(features.device))

@@ -45,7 +45,7 @@ def test_argument_validation_without_gpu(lib):
     assert b"multiple of 16" in l.gs_last_error()
     assert l.gs_sort_pairs(None, None, None, None, 1, 0, 17, 13, 0, None, None) == 0  # n <= 1: nothing to do
     assert l.gs_sort_pairs(None, None, None, None, 10, 25, 25, 13, 0, None, None) == -1  # 25+13 bits > 32
-    assert l.gs_sort_workspace_bytes(10_000_000) > 256 * 4 * (10_000_000 // 2048)
+    assert l.gs_sort_workspace_bytes(10_000_000) > 256 * 4 * (10_000_000 // 4096)
 
 
 def test_product_path_has_no_cpu_fallback():
