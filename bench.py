@@ -97,11 +97,18 @@ def main() -> None:
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     assert torch.cuda.is_available(), "bench.py needs HIP devices"
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # one rank per GPU.  (Test hook: with fewer devices than ranks -- a 1-GPU box -- ranks share devices, which
+    # RCCL refuses, so GS_BENCH_DIST_BACKEND=gloo lets the multi-rank plumbing be exercised there.)
+    device_index = local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(device_index)
+    device = torch.device("cuda", device_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=device)  # nccl == RCCL on ROCm
+        backend = os.environ.get("GS_BENCH_DIST_BACKEND", "nccl")  # nccl == RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=device)
+        else:
+            dist.init_process_group(backend=backend)
 
     host_scene = make_config_scene(args.workload)
     s = host_scene.to(device)

@@ -1,0 +1,76 @@
+"""Tile-row sharding with REAL ranks on the device: two (and three) processes share the box's single GPU and talk
+through gloo (RCCL refuses two ranks on one device; the RCCL call path itself is covered by the world-size-1 test in
+test_hip_parity.py).  Every rank renders only its interleaved tile rows with the HIP kernels, the collectives of
+``distributed.py`` assemble image / depth / count and sum the backward accumulators, and every rank must end with
+the image and the dense gradients of the un-sharded operator -- bit for bit for everything that is not a sum over
+ranks, and to fp32 summation-order noise for the gradients of Gaussians that straddle rows of different ranks."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, n, height, width):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from taichi_3d_gaussian_splatting_amd import CameraInfo, GaussianPointCloudRasterisation as Op
+        from taichi_3d_gaussian_splatting_amd.distributed import shard_rasteriser_across_tile_rows
+        from taichi_3d_gaussian_splatting_amd.synthetic import make_grad_image, make_scene
+        dev = torch.device("cuda", 0)
+        s = make_scene(n=n, height=height, width=width, s_min=0.01, s_max=0.08, seed=3).to(dev)
+        g = make_grad_image(height, width).to(dev)
+        hooks = {}
+
+        def run(sharded):
+            xyz = s.point_cloud.clone().requires_grad_(True)
+            feat = s.point_cloud_features.clone().requires_grad_(True)
+            op = Op(Op.GaussianPointCloudRasterisationConfig(),
+                    backward_valid_point_hook=lambda h: hooks.__setitem__(sharded, h))
+            if sharded:
+                shard_rasteriser_across_tile_rows(op)
+                assert (op.tile_row_begin, op.tile_row_step) == (rank, world)
+            image, depth, count = op(Op.GaussianPointCloudRasterisationInput(
+                point_cloud=xyz, point_cloud_features=feat, point_object_id=s.point_object_id,
+                point_invalid_mask=s.point_invalid_mask,
+                camera_info=CameraInfo(camera_intrinsics=s.camera_intrinsics, camera_height=height,
+                                       camera_width=width, camera_id=0),
+                q_pointcloud_camera=s.q_pointcloud_camera, t_pointcloud_camera=s.t_pointcloud_camera,
+                color_max_sh_band=3))
+            (image * g).sum().backward()
+            return image.detach(), depth.detach(), count, xyz.grad, feat.grad
+
+        base = run(False)
+        shard = run(True)
+        assert torch.equal(base[0], shard[0]) and torch.equal(base[1], shard[1]) and torch.equal(base[2], shard[2])
+        for a, b in ((base[3], shard[3]), (base[4], shard[4])):
+            assert (a - b).abs().max() <= 2e-5 * a.abs().max()           # sums over ranks: order differs
+            assert float(((a - b).abs() > 0).float().mean()) < 0.5
+        hb, hs = hooks[False], hooks[True]
+        assert torch.equal(hb.point_id_in_camera_list, hs.point_id_in_camera_list)
+        assert torch.equal(hb.num_affected_pixels, hs.num_affected_pixels)          # integer sum: exact
+        assert torch.equal(hb.num_overlap_tiles, hs.num_overlap_tiles)
+        assert torch.allclose(hb.magnitude_grad_viewspace, hs.magnitude_grad_viewspace, rtol=1e-5, atol=1e-12)
+        # every rank holds the same result
+        mine = torch.stack([shard[3].double().sum(), shard[4].double().sum(), shard[0].double().sum()]).cpu()
+        everyone = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(everyone, mine)
+        assert all(torch.equal(everyone[0], e) for e in everyone)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,height", [(2, 144), (3, 80)])
+def test_sharded_operator_with_real_ranks(world, height):
+    mp.spawn(_worker, args=(world, _free_port(), 6000, height, 160), nprocs=world, join=True)
