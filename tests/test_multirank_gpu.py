@@ -74,3 +74,48 @@ def _worker(rank, world, port, n, height, width):
 @pytest.mark.parametrize("world,height", [(2, 144), (3, 80)])
 def test_sharded_operator_with_real_ranks(world, height):
     mp.spawn(_worker, args=(world, _free_port(), 6000, height, 160), nprocs=world, join=True)
+
+
+def _train_worker(rank, world, port, root):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from taichi_3d_gaussian_splatting_amd.GaussianPointTrainer import GaussianPointCloudTrainer as TRN
+        cfg = TRN.TrainConfig(
+            train_dataset_json_path=os.path.join(root, "train.json"), val_dataset_json_path=os.path.join(root, "val.json"),
+            pointcloud_parquet_path=os.path.join(root, "points.parquet"), num_iterations=61, val_interval=10 ** 6,
+            feature_learning_rate=5e-3, position_learning_rate=5e-5, initial_downsample_factor=2,
+            half_downsample_factor_interval=30, log_loss_interval=10, log_metrics_interval=10 ** 6,
+            log_image_interval=10 ** 6, summary_writer_log_dir=os.path.join(root, f"logs_rank{rank}"),
+            num_data_loader_workers=0)
+        cfg.adaptive_controller_config.num_iterations_warm_up = 20      # densify (with random splits) at 20 and 40
+        cfg.adaptive_controller_config.num_iterations_densify = 20
+        cfg.gaussian_point_cloud_scene_config.max_num_points_ratio = 2.0
+        cfg.gaussian_point_cloud_scene_config.initial_alpha = 0.5
+        trainer = TRN(cfg)
+        assert trainer.rasterisation.tile_row_step == world and trainer.rasterisation.tile_row_begin == rank
+        n_before = int((trainer.scene.point_invalid_mask == 0).sum())
+        trainer.train()
+        live = trainer.scene.point_invalid_mask == 0
+        assert int(live.sum()) != n_before                                # the controller acted
+        # replicated state is BIT-identical on every rank (same collective results, same seeds)
+        digest = torch.cat([trainer.scene.point_cloud.detach().double().sum().view(1),
+                            trainer.scene.point_cloud_features.detach().double().sum().view(1),
+                            live.double().sum().view(1)]).cpu()
+        everyone = [torch.zeros_like(digest) for _ in range(world)]
+        dist.all_gather(everyone, digest)
+        assert all(torch.equal(everyone[0], e) for e in everyone), everyone
+        assert torch.isfinite(digest).all()
+        if rank == 0:
+            assert os.path.exists(os.path.join(root, "logs_rank0", "metrics.jsonl"))
+        else:
+            assert not os.path.exists(os.path.join(root, f"logs_rank{rank}", "metrics.jsonl"))   # only rank 0 logs
+    finally:
+        dist.destroy_process_group()
+
+
+def test_trainer_replicated_state_stays_identical_across_ranks(tmp_path):
+    from tests.test_training_gpu import _write_dataset
+    root = str(tmp_path)
+    _write_dataset(root, torch.device("cuda:0"))
+    mp.spawn(_train_worker, args=(2, _free_port(), root), nprocs=2, join=True)
