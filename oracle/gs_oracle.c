@@ -12,7 +12,12 @@
  * source and pinned against every known-answer vector the reference's own
  * tests hold for this path (tile ranges, single-Gaussian alpha/gradients vs
  * the pure-torch comparator, 2x2 covariance vs scipy, quaternion->R vs scipy,
- * SE(3) inverse vs numpy) -- see tests/test_oracle_pins.py.  The blended
+ * SE(3) inverse vs numpy) -- see tests/test_oracle_pins.py -- and against
+ * OUTPUTS OF THE REFERENCE ITSELF for everything of it that runs without
+ * Taichi: its pure-PyTorch comparator (alpha and autograd gradients of 48
+ * Gaussians), SH basis and SE(3)/quaternion helpers, executed from
+ * /root/reference behind a Taichi stub by tests/golden/
+ * make_reference_vectors.py (tests/test_reference_vectors.py).  The blended
  * image, depth, counts and end-to-end gradients are pinned by no reference
  * test: for those, "parity unpinned" -- this file is the definition.
  *
