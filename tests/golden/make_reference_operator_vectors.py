@@ -1,0 +1,92 @@
+#!/usr/bin/env python
+"""Generates tests/golden/reference_operator_*.npz by EXECUTING THE REFERENCE'S OWN OPERATOR -- the unmodified source
+of /root/reference/taichi_3d_gaussian_splatting/{GaussianPointCloudRasterisation,GaussianPoint3D,SphericalHarmonics,
+utils,Camera}.py: its seven Taichi kernels, its torch glue, its autograd Function and its backward hook -- on tiny
+seeded scenes, with Taichi replaced by the emulation in tests/golden/taichi_emulation.py (fp32 NumPy scalars, the two
+tile blend kernels run block by block on 256 OS threads with real barriers).
+
+Run in the build container only (the GPU box has no /root/reference; takes a few minutes):
+    python tests/golden/make_reference_operator_vectors.py
+
+Scenes are chosen so that no two sort keys tie (asserted): torch.sort's tie order is the one thing the reference
+leaves undefined (RAS:947), everything else is then a function of the inputs.
+"""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, HERE)
+import taichi_emulation as E  # noqa: E402
+from taichi_3d_gaussian_splatting_amd.synthetic import make_grad_image, make_scene  # noqa: E402
+
+SCENES = {
+    # name: (make_scene kwargs, color_max_sh_band, rasteriser config overrides, opacity-logit override or None)
+    "a_40pts_32x48_sh3": (dict(n=40, height=32, width=48, s_min=0.05, s_max=0.3, sh_degree=3, seed=26), 3, {}, None),
+    "b_70pts_48x32_sh3_band1_invalid": (dict(n=70, height=48, width=32, s_min=0.03, s_max=0.2, sh_degree=3, seed=3,
+                                              invalid_fraction=0.15), 1,
+                                         dict(near_plane=0.4, far_plane=2000.0, depth_to_sort_key_scale=1000.0), None),
+    # many large, nearly opaque Gaussians: pixels saturate (T' < 1e-4, RAS:458-460) and alpha clamps at 0.99
+    "c_90pts_32x32_opaque_saturating": (dict(n=90, height=32, width=32, s_min=0.15, s_max=0.5, sh_degree=3, seed=2), 2,
+                                         dict(depth_to_sort_key_scale=100000.0), 6.0),
+}
+
+
+def main():
+    mods = E.load_reference("/root/reference")
+    RAS, CAM = mods["GaussianPointCloudRasterisation"], mods["Camera"]
+    Op = RAS.GaussianPointCloudRasterisation
+    from oracle import gs_oracle as O   # only to assert that the scene has no sort-key ties
+    only = sys.argv[1:]
+    for name, (kw, band, cfg_kw, opacity) in SCENES.items():
+        if only and name not in only:
+            continue
+        s = make_scene(**kw)
+        if opacity is not None:
+            s.point_cloud_features[:, 7] = opacity
+        f = O.forward(s.point_cloud.numpy(), s.point_cloud_features.numpy(), s.point_invalid_mask.numpy(),
+                      s.point_object_id.numpy(), s.camera_intrinsics.numpy(), s.q_pointcloud_camera.numpy(),
+                      s.t_pointcloud_camera.numpy(), s.height, s.width, **cfg_kw)
+        assert not (f["keys"][1:] == f["keys"][:-1]).any(), f"{name}: tied sort keys, pick another seed"
+        print(name, "K", len(f["keys"]), "saturated pixels", float((f["acc_alpha"] > 0.9999).mean()))
+        xyz = s.point_cloud.clone().requires_grad_(True)
+        feat = s.point_cloud_features.clone().requires_grad_(True)
+        hook = {}
+        op = Op(Op.GaussianPointCloudRasterisationConfig(**cfg_kw), backward_valid_point_hook=lambda h: hook.update(h=h))
+        t0 = time.time()
+        image, depth, count = op(Op.GaussianPointCloudRasterisationInput(
+            point_cloud=xyz, point_cloud_features=feat, point_object_id=s.point_object_id,
+            point_invalid_mask=s.point_invalid_mask,
+            camera_info=CAM.CameraInfo(camera_intrinsics=s.camera_intrinsics, camera_height=s.height,
+                                       camera_width=s.width, camera_id=0),
+            q_pointcloud_camera=s.q_pointcloud_camera, t_pointcloud_camera=s.t_pointcloud_camera,
+            color_max_sh_band=band))
+        t1 = time.time()
+        g = make_grad_image(s.height, s.width, seed=31)
+        (image * g).sum().backward()
+        t2 = time.time()
+        h = hook["h"]
+        out = dict(
+            kwargs=np.array(repr(kw)), band=np.array(band), config=np.array(repr(cfg_kw)), grad_image=g.numpy(),
+            opacity_override=np.array(np.nan if opacity is None else opacity),
+            features_after_forward=feat.detach().numpy().copy(),      # q normalised in place (RAS:196-205)
+            image=image.detach().numpy(), depth=depth.detach().numpy(), count=count.numpy(),
+            grad_xyz=xyz.grad.numpy(), grad_feat=feat.grad.numpy(),
+            hook_point_id=h.point_id_in_camera_list.numpy(), hook_grad_point=h.grad_point_in_camera.numpy(),
+            hook_grad_features=h.grad_pointfeatures_in_camera.numpy(), hook_grad_viewspace=h.grad_viewspace.numpy(),
+            hook_magnitude=h.magnitude_grad_viewspace.numpy(),
+            hook_magnitude_image=h.magnitude_grad_viewspace_on_image.numpy(),
+            hook_num_overlap_tiles=h.num_overlap_tiles.numpy(), hook_num_affected_pixels=h.num_affected_pixels.numpy(),
+            hook_depth=h.point_depth.numpy(), hook_uv=h.point_uv_in_camera.numpy())
+        np.savez_compressed(os.path.join(HERE, f"reference_operator_{name}.npz"), **out)
+        print(f"{name}: forward {t1 - t0:.1f} s, backward {t2 - t1:.1f} s, M={len(out['hook_point_id'])}, "
+              f"mean image {out['image'].mean():.4f}, max count {out['count'].max()}")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,481 @@
+"""A small pure-Python/NumPy emulation of the Taichi subset the reference rasteriser uses, so that the reference's
+OWN source files can be executed in this container (Taichi is not installed and its kernels are CUDA-only).
+
+TEST INFRASTRUCTURE ONLY, used by tests/golden/make_reference_operator_vectors.py to produce golden vectors; nothing
+in the product imports it.  What is emulated, and how faithfully:
+
+* scalars are NumPy float32 / Python ints, so every arithmetic operation rounds to fp32 like Taichi's default
+  ``default_fp=f32`` (NumPy 2 keeps float32 when a Python literal is mixed in); no fused multiply-add, no fast-math;
+* ``ti.math.vecN / matN``, ``ti.Vector``, ``ti.Matrix``, ``ti.types.vector/matrix``: class ``Mat`` -- element-wise
+  ``+ - * /``, ``@`` as an unrolled left-to-right sum of products (Taichi unrolls small matrix products the same way),
+  ``transpose / determinant / outer_product / norm / sum / dot``, ``.x .y .z .w``;
+* ``@ti.func``: plain call with ``Mat`` arguments copied first (Taichi passes matrices by value: the reference relies on
+  it, e.g. utils.py:263-264 adds 0.3 to its argument);  ``@ti.dataclass``: a record class with keyword/positional
+  constructor;  ``ti.static``: identity;  ``ti.cast`` to an integer type truncates toward zero;
+* ``@ti.kernel``: torch tensors are passed as NumPy views of the same memory; a kernel whose source does not use
+  ``ti.simt.block`` runs its loops sequentially; one that does (the two tile blend kernels) is run one 256-thread
+  block at a time on real OS threads, ``ti.simt.block.sync()`` being a ``threading.Barrier`` and ``SharedArray`` a
+  per-block array, so the barrier-separated staging through shared memory executes as written;
+* ``ti.atomic_add(a[i], v)`` statements are rewritten (AST) to a locked ``a[i] += v``; the accumulation order is the
+  thread order, where the GPU's is undefined.
+"""
+from __future__ import annotations
+
+import ast
+import inspect
+import os
+import sys
+import threading
+import types
+
+import numpy as np
+
+F32 = np.float32
+
+
+# --------------------------------------------------------------------------------------------------- vectors / matrices
+def _f(x):
+    return x if isinstance(x, (np.floating, np.integer)) and x.dtype == F32 else F32(x)
+
+
+class Mat:
+    __slots__ = ("a",)
+
+    def __init__(self, a):
+        self.a = np.array(a, dtype=F32)
+
+    # ---- structure
+    @property
+    def n(self):
+        return self.a.shape[0]
+
+    def __len__(self):
+        return self.a.shape[0]
+
+    def __iter__(self):
+        if self.a.ndim == 1:
+            return iter([self.a[i] for i in range(self.a.shape[0])])
+        return iter([Mat(self.a[i]) for i in range(self.a.shape[0])])
+
+    def __getitem__(self, idx):
+        r = self.a[idx]
+        return Mat(r) if isinstance(r, np.ndarray) else r
+
+    def __setitem__(self, idx, value):
+        self.a[idx] = value.a if isinstance(value, Mat) else _f(value)
+
+    def copy(self):
+        return Mat(self.a.copy())
+
+    def __repr__(self):
+        return f"Mat({self.a!r})"
+
+    # ---- swizzles
+    x = property(lambda s: s.a[0], lambda s, v: s.a.__setitem__(0, _f(v)))
+    y = property(lambda s: s.a[1], lambda s, v: s.a.__setitem__(1, _f(v)))
+    z = property(lambda s: s.a[2], lambda s, v: s.a.__setitem__(2, _f(v)))
+    w = property(lambda s: s.a[3], lambda s, v: s.a.__setitem__(3, _f(v)))
+
+    # ---- element-wise arithmetic (fp32)
+    @staticmethod
+    def _other(o):
+        return o.a if isinstance(o, Mat) else _f(o)
+
+    def __add__(self, o): return Mat(self.a + self._other(o))
+    def __radd__(self, o): return Mat(self._other(o) + self.a)
+    def __sub__(self, o): return Mat(self.a - self._other(o))
+    def __rsub__(self, o): return Mat(self._other(o) - self.a)
+    def __mul__(self, o): return Mat(self.a * self._other(o))
+    def __rmul__(self, o): return Mat(self._other(o) * self.a)
+    def __truediv__(self, o): return Mat(self.a / self._other(o))
+    def __rtruediv__(self, o): return Mat(self._other(o) / self.a)
+    def __neg__(self): return Mat(-self.a)
+    def __pos__(self): return self
+
+    def __iadd__(self, o):
+        self.a = self.a + self._other(o)
+        return self
+
+    def __isub__(self, o):
+        self.a = self.a - self._other(o)
+        return self
+
+    def __imul__(self, o):
+        self.a = self.a * self._other(o)
+        return self
+
+    # ---- products: unrolled, left to right, every step rounded to fp32
+    def __matmul__(self, o):
+        A, B = self.a, o.a
+        if A.ndim == 1 and B.ndim == 1:
+            s = A[0] * B[0]
+            for k in range(1, A.shape[0]):
+                s = s + A[k] * B[k]
+            return s
+        if A.ndim == 1:      # row vector @ matrix
+            out = np.empty(B.shape[1], F32)
+            for j in range(B.shape[1]):
+                s = A[0] * B[0, j]
+                for k in range(1, A.shape[0]):
+                    s = s + A[k] * B[k, j]
+                out[j] = s
+            return Mat(out)
+        if B.ndim == 1:      # matrix @ column vector
+            out = np.empty(A.shape[0], F32)
+            for i in range(A.shape[0]):
+                s = A[i, 0] * B[0]
+                for k in range(1, A.shape[1]):
+                    s = s + A[i, k] * B[k]
+                out[i] = s
+            return Mat(out)
+        out = np.empty((A.shape[0], B.shape[1]), F32)
+        for i in range(A.shape[0]):
+            for j in range(B.shape[1]):
+                s = A[i, 0] * B[0, j]
+                for k in range(1, A.shape[1]):
+                    s = s + A[i, k] * B[k, j]
+                out[i, j] = s
+        return Mat(out)
+
+    def dot(self, o):
+        return self @ o
+
+    def transpose(self):
+        return Mat(self.a.T.copy())
+
+    def determinant(self):
+        a = self.a
+        if a.shape == (2, 2):
+            return a[0, 0] * a[1, 1] - a[0, 1] * a[1, 0]
+        if a.shape == (3, 3):
+            return (a[0, 0] * (a[1, 1] * a[2, 2] - a[2, 1] * a[1, 2]) - a[1, 0] * (a[0, 1] * a[2, 2] - a[2, 1] * a[0, 2]) +
+                    a[2, 0] * (a[0, 1] * a[1, 2] - a[1, 1] * a[0, 2]))
+        raise NotImplementedError(a.shape)
+
+    def outer_product(self, o):
+        out = np.empty((self.a.shape[0], o.a.shape[0]), F32)
+        for i in range(self.a.shape[0]):
+            for j in range(o.a.shape[0]):
+                out[i, j] = self.a[i] * o.a[j]
+        return Mat(out)
+
+    def sum(self):
+        flat = self.a.reshape(-1)
+        s = flat[0]
+        for k in range(1, flat.shape[0]):
+            s = s + flat[k]
+        return s
+
+    def norm(self):
+        flat = self.a.reshape(-1)
+        s = flat[0] * flat[0]
+        for k in range(1, flat.shape[0]):
+            s = s + flat[k] * flat[k]
+        return np.sqrt(s)
+
+
+def _flatten(args):
+    out = []
+    for x in args:
+        if isinstance(x, Mat):
+            out.extend(_flatten(list(x.a.reshape(-1))))
+        elif isinstance(x, (list, tuple)):
+            out.extend(_flatten(x))
+        elif isinstance(x, np.ndarray):
+            out.extend(_flatten(list(x.reshape(-1))))
+        else:
+            out.append(x)
+    return out
+
+
+class _MatType:
+    """vecN / matNxM constructor, also usable as a type annotation."""
+
+    def __init__(self, n, m=None):
+        self.shape = (n,) if m is None else (n, m)
+
+    def __call__(self, *args):
+        if len(args) == 1 and isinstance(args[0], Mat) and args[0].a.shape == self.shape:
+            return args[0].copy()
+        flat = _flatten(args)
+        size = int(np.prod(self.shape))
+        if len(flat) == 1:
+            flat = flat * size
+        if len(flat) != size:
+            raise ValueError(f"cannot build {self.shape} from {len(flat)} values")
+        return Mat(np.array([_f(v) for v in flat], F32).reshape(self.shape))
+
+
+def _vector(values, dt=None):
+    return Mat(np.array([_f(v) for v in _flatten([values])], F32))
+
+
+def _matrix(rows, dt=None):
+    return Mat(np.array([[_f(v) for v in _flatten([r])] for r in rows], F32))
+
+
+def _elementwise(fn):
+    def apply(x):
+        if isinstance(x, Mat):
+            return Mat(fn(x.a))
+        return fn(_f(x))
+    return apply
+
+
+def _is_int(x):
+    return isinstance(x, (int, np.integer)) and not isinstance(x, bool)
+
+
+def _minmax(fn, int_fn):
+    def apply(*args):
+        r = args[0]
+        for a in args[1:]:
+            if _is_int(r) and _is_int(a):          # integer operands stay integers (Taichi's type rules)
+                r = int_fn(int(r), int(a))
+                continue
+            ra, aa = (r.a if isinstance(r, Mat) else _f(r)), (a.a if isinstance(a, Mat) else _f(a))
+            v = fn(ra, aa)
+            r = Mat(v) if isinstance(v, np.ndarray) else v
+        return r
+    return apply
+
+
+def _cast(x, t):
+    if isinstance(x, Mat):
+        return x
+    if t in (np.int32, np.int64, np.int8, int):
+        return int(x)                      # truncation toward zero, like a C cast
+    return F32(x)
+
+
+def _normalize(v):
+    return Mat(v.a / v.norm())
+
+
+# --------------------------------------------------------------------------------------------------- execution model
+_tls = threading.local()
+_atomic_lock = threading.Lock()
+
+
+class _BlockCtx:
+    def __init__(self, dim):
+        self.dim = dim
+        self.barrier = threading.Barrier(dim)
+        self.shared = {}
+        self.lock = threading.Lock()
+        self.error = None
+
+
+class _Probe(Exception):
+    pass
+
+
+def _ndrange(*bounds):
+    mode = getattr(_tls, "mode", "seq")
+    if mode == "probe":
+        _tls.probe_n = int(bounds[0])
+        raise _Probe()
+    if mode == "block":
+        return [_tls.tid] if _tls.tid < int(bounds[0]) else []
+    if len(bounds) == 1:
+        return range(int(bounds[0]))
+    import itertools
+    return itertools.product(*[range(int(b)) for b in bounds])
+
+
+def _loop_config(**kw):
+    if "block_dim" in kw:
+        _tls.block_dim = int(kw["block_dim"])
+
+
+def _shared_array(shape, dtype=F32):
+    ctx = _tls.block
+    idx = _tls.shared_calls
+    _tls.shared_calls += 1
+    with ctx.lock:
+        if idx not in ctx.shared:
+            ctx.shared[idx] = np.zeros(shape, dtype=np.dtype(dtype))
+        return ctx.shared[idx]
+
+
+def _block_sync():
+    _tls.block.barrier.wait()
+
+
+def ti_atomic_add(array, index, value):
+    with _atomic_lock:
+        array[index] += value
+
+
+def _to_numpy(x):
+    try:
+        import torch
+        if isinstance(x, torch.Tensor):
+            return x.detach().numpy()
+    except ImportError:  # pragma: no cover
+        pass
+    return x
+
+
+def _kernel(fn):
+    src = inspect.getsource(fn)
+    parallel = "simt.block" in src
+    sig = inspect.signature(fn)
+
+    def launch(*args, **kwargs):
+        bound = sig.bind(*args, **kwargs)
+        call = {k: _to_numpy(v) for k, v in bound.arguments.items()}
+        if not parallel:
+            _tls.mode = "seq"
+            return fn(**call)
+        # how many threads, and the block size: run up to the parallel loop header once
+        _tls.mode, _tls.block_dim = "probe", 256
+        try:
+            fn(**call)
+            raise RuntimeError("block kernel without an ndrange loop")
+        except _Probe:
+            pass
+        total, dim = _tls.probe_n, _tls.block_dim
+        assert total % dim == 0
+        for b in range(total // dim):
+            ctx = _BlockCtx(dim)
+
+            def body(k, ctx=ctx, b=b):
+                _tls.mode, _tls.tid, _tls.block, _tls.shared_calls = "block", b * dim + k, ctx, 0
+                try:
+                    fn(**call)
+                except threading.BrokenBarrierError:
+                    pass
+                except BaseException as exc:  # noqa: BLE001
+                    ctx.error = exc
+                    ctx.barrier.abort()
+            threads = [threading.Thread(target=body, args=(k,)) for k in range(dim)]
+            for t in threads:
+                t.start()
+            for t in threads:
+                t.join()
+            if ctx.error is not None:
+                raise ctx.error
+        _tls.mode = "seq"
+    launch.__wrapped__ = fn
+    return launch
+
+
+def _func(fn):
+    def call(*args, **kwargs):
+        args = [a.copy() if isinstance(a, Mat) else a for a in args]
+        kwargs = {k: (v.copy() if isinstance(v, Mat) else v) for k, v in kwargs.items()}
+        return fn(*args, **kwargs)
+    call.__wrapped__ = fn
+    call.__name__ = getattr(fn, "__name__", "ti_func")
+    return call
+
+
+def _dataclass(cls):
+    names = list(getattr(cls, "__annotations__", {}))
+
+    def __init__(self, *args, **kwargs):
+        for name, value in zip(names, args):
+            setattr(self, name, value)
+        for name, value in kwargs.items():
+            setattr(self, name, value)
+    cls.__init__ = __init__
+    return cls
+
+
+class _Inert:
+    """Placeholder for annotation-only API (ti.types.ndarray(...), ti.template(), ...)."""
+
+    def __call__(self, *a, **k):
+        return self
+
+    def __getattr__(self, name):
+        if name.startswith("__"):
+            raise AttributeError(name)
+        return self
+
+
+def build_taichi_module():
+    ti = types.ModuleType("taichi")
+    tm = types.ModuleType("taichi.math")
+    for mod in (tm,):
+        mod.vec2, mod.vec3, mod.vec4 = _MatType(2), _MatType(3), _MatType(4)
+        mod.mat2, mod.mat3, mod.mat4 = _MatType(2, 2), _MatType(3, 3), _MatType(4, 4)
+        mod.exp, mod.sqrt, mod.log = _elementwise(np.exp), _elementwise(np.sqrt), _elementwise(np.log)
+        mod.normalize = _normalize
+        mod.dot = lambda a, b: a @ b
+        mod.pi = np.pi
+    ti.math = tm
+    ti.f32 = ti.float32 = np.float32
+    ti.i32, ti.i64, ti.i8 = np.int32, np.int64, np.int8
+    ti.exp, ti.sqrt, ti.log = tm.exp, tm.sqrt, tm.log
+    ti.sin, ti.cos, ti.abs = _elementwise(np.sin), _elementwise(np.cos), _elementwise(np.abs)
+    ti.max, ti.min = _minmax(np.maximum, max), _minmax(np.minimum, min)
+    ti.cast = _cast
+    ti.static = lambda *a: a[0] if len(a) == 1 else a
+    ti.Vector, ti.Matrix = _vector, _matrix
+    ti.func, ti.kernel, ti.dataclass = _func, _kernel, _dataclass
+    ti.ndrange, ti.loop_config = _ndrange, _loop_config
+    types_mod = types.ModuleType("taichi.types")
+    types_mod.ndarray = _Inert()
+    types_mod.vector = lambda n, dtype=None: _MatType(n)
+    types_mod.matrix = lambda n, m, dtype=None: _MatType(n, m)
+    ti.types = types_mod
+    ti.template = _Inert()
+    simt, block = types.ModuleType("taichi.simt"), types.ModuleType("taichi.simt.block")
+    block.SharedArray, block.sync = _shared_array, _block_sync
+    simt.block = block
+    ti.simt = simt
+    ti.init = lambda *a, **k: None
+    ti.cpu, ti.cuda, ti.gpu = "cpu", "cuda", "gpu"
+    ti.profiler = _Inert()
+    return ti, tm
+
+
+# --------------------------------------------------------------------------------------------------- loading the reference
+class _AtomicRewriter(ast.NodeTransformer):
+    """``ti.atomic_add(X[idx], v)`` (statement) -> ``__ti_atomic_add__(X, idx, v)``."""
+
+    def visit_Expr(self, node):
+        self.generic_visit(node)
+        c = node.value
+        if (isinstance(c, ast.Call) and isinstance(c.func, ast.Attribute) and c.func.attr == "atomic_add" and
+                isinstance(c.func.value, ast.Name) and c.func.value.id == "ti" and len(c.args) == 2 and
+                isinstance(c.args[0], ast.Subscript)):
+            target = c.args[0]
+            new = ast.Call(func=ast.Name(id="__ti_atomic_add__", ctx=ast.Load()),
+                           args=[target.value, target.slice, c.args[1]], keywords=[])
+            return ast.copy_location(ast.Expr(value=new), node)
+        return node
+
+
+def load_reference(reference_root: str, modules=("Camera", "utils", "SphericalHarmonics", "GaussianPoint3D",
+                                                  "GaussianPointCloudRasterisation")):
+    """Execute the reference's modules, from where they lie, against the emulated ``taichi``; returns
+    {module name: module}.  ``dataclass_wizard`` (absent here too) is replaced by an empty ``YAMLWizard``."""
+    ti, tm = build_taichi_module()
+    sys.modules["taichi"], sys.modules["taichi.math"] = ti, tm
+    wizard = types.ModuleType("dataclass_wizard")
+    wizard.YAMLWizard = type("YAMLWizard", (), {})
+    sys.modules["dataclass_wizard"] = wizard
+    pkg_name = "taichi_3d_gaussian_splatting"
+    pkg_dir = os.path.join(reference_root, pkg_name)
+    pkg = types.ModuleType(pkg_name)
+    pkg.__path__ = [pkg_dir]
+    sys.modules[pkg_name] = pkg
+    loaded = {}
+    for name in modules:
+        path = os.path.join(pkg_dir, name + ".py")
+        with open(path) as fh:
+            source = fh.read()
+        tree = ast.fix_missing_locations(_AtomicRewriter().visit(ast.parse(source, filename=path)))
+        mod = types.ModuleType(f"{pkg_name}.{name}")
+        mod.__file__, mod.__package__ = path, pkg_name
+        mod.__dict__["__ti_atomic_add__"] = ti_atomic_add
+        sys.modules[mod.__name__] = mod
+        import linecache
+        linecache.cache[path] = (len(source), None, source.splitlines(True), path)   # inspect.getsource for kernels
+        exec(compile(tree, path, "exec"), mod.__dict__)
+        setattr(pkg, name, mod)
+        loaded[name] = mod
+    return loaded
