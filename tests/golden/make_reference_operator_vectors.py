@@ -31,6 +31,9 @@ SCENES = {
     "b_70pts_48x32_sh3_band1_invalid": (dict(n=70, height=48, width=32, s_min=0.03, s_max=0.2, sh_degree=3, seed=3,
                                               invalid_fraction=0.15), 1,
                                          dict(near_plane=0.4, far_plane=2000.0, depth_to_sort_key_scale=1000.0), None),
+    # two objects with their own rotated poses (point_object_id selects the pose, RAS:56-59,272-275)
+    "d_60pts_32x32_two_objects_rotated": (dict(n=60, height=32, width=32, s_min=0.05, s_max=0.25, sh_degree=3, seed=4), 3,
+                                           dict(depth_to_sort_key_scale=1000000.0), "two_objects"),
     # many large, nearly opaque Gaussians: pixels saturate (T' < 1e-4, RAS:458-460) and alpha clamps at 0.99
     "c_90pts_32x32_opaque_saturating": (dict(n=90, height=32, width=32, s_min=0.15, s_max=0.5, sh_degree=3, seed=2), 2,
                                          dict(depth_to_sort_key_scale=100000.0), 6.0),
@@ -47,6 +50,13 @@ def main():
         if only and name not in only:
             continue
         s = make_scene(**kw)
+        if opacity == "two_objects":
+            gq = torch.Generator().manual_seed(99)
+            q = torch.tensor([[0.0, 0.0, 0.0, 1.0]]).repeat(2, 1) + 0.15 * torch.randn(2, 4, generator=gq)
+            s.q_pointcloud_camera = q / q.norm(dim=1, keepdim=True)
+            s.t_pointcloud_camera = torch.tensor([[0.0, 0.0, -3.0]]).repeat(2, 1) + 0.2 * torch.randn(2, 3, generator=gq)
+            s.point_object_id = torch.randint(0, 2, (kw["n"],), generator=gq, dtype=torch.int32)
+            opacity = None
         if opacity is not None:
             s.point_cloud_features[:, 7] = opacity
         f = O.forward(s.point_cloud.numpy(), s.point_cloud_features.numpy(), s.point_invalid_mask.numpy(),
@@ -74,6 +84,9 @@ def main():
         out = dict(
             kwargs=np.array(repr(kw)), band=np.array(band), config=np.array(repr(cfg_kw)), grad_image=g.numpy(),
             opacity_override=np.array(np.nan if opacity is None else opacity),
+            in_xyz=s.point_cloud.numpy(), in_feat=s.point_cloud_features.numpy(), in_invalid=s.point_invalid_mask.numpy(),
+            in_object_id=s.point_object_id.numpy(), in_K=s.camera_intrinsics.numpy(), in_q=s.q_pointcloud_camera.numpy(),
+            in_t=s.t_pointcloud_camera.numpy(),
             features_after_forward=feat.detach().numpy().copy(),      # q normalised in place (RAS:196-205)
             image=image.detach().numpy(), depth=depth.detach().numpy(), count=count.numpy(),
             grad_xyz=xyz.grad.numpy(), grad_feat=feat.grad.numpy(),

@@ -32,6 +32,11 @@ def _load(path):
     s = make_scene(**ast.literal_eval(str(V["kwargs"])))
     if not np.isnan(float(V["opacity_override"])):
         s.point_cloud_features[:, 7] = float(V["opacity_override"])
+    if "in_xyz" in V.files:                      # archives that carry their inputs (poses / object ids not from make_scene)
+        s.point_cloud, s.point_cloud_features = torch.from_numpy(V["in_xyz"]), torch.from_numpy(V["in_feat"])
+        s.point_invalid_mask, s.point_object_id = torch.from_numpy(V["in_invalid"]), torch.from_numpy(V["in_object_id"])
+        s.camera_intrinsics = torch.from_numpy(V["in_K"])
+        s.q_pointcloud_camera, s.t_pointcloud_camera = torch.from_numpy(V["in_q"]), torch.from_numpy(V["in_t"])
     return V, s, ast.literal_eval(str(V["config"])), int(V["band"])
 
 
