@@ -49,6 +49,13 @@ def ssim(x: torch.Tensor, y: torch.Tensor, data_range: float = 1.0, size_average
     """Structural similarity of two [B,C,H,W] image batches (Wang et al. 2004, Gaussian-window form)."""
     if x.shape != y.shape or x.dim() != 4:
         raise ValueError("ssim expects two [B,C,H,W] tensors of the same shape")
+    if (_fusable(x, y) and not (x.requires_grad or y.requires_grad) and data_range == 1.0 and win_size == 11 and
+            win_sigma == 1.5 and (k1, k2) == (0.01, 0.03)):
+        # metric use on the device (PSNR/SSIM logging, validation): the fused forward kernel -- MIOpen needs ~90 ms per
+        # depth-wise 11-tap convolution at 1920x1072, i.e. seconds per SSIM evaluation
+        from . import hip_ops
+        losses, _ = hip_ops.loss_forward(x[0], y[0].contiguous(), 0.0, False, need_grad=False)
+        return 1.0 - losses[2]
     win = _gaussian_window(win_size, win_sigma, x.device, x.dtype)
     c1, c2 = (k1 * data_range) ** 2, (k2 * data_range) ** 2
     mu_x, mu_y = _blur(x, win), _blur(y, win)
