@@ -694,3 +694,33 @@ def test_operator_degenerate_sizes():
         assert xyz.grad.shape == (n, 3) and feat.grad.shape == (n, 56) and not feat.grad.any()
     assert [int(h.point_id_in_camera_list.shape[0]) for h in got] == [0, 2]
     assert got[1].num_overlap_tiles.tolist() == [0, 0]
+
+
+def test_operator_survives_non_finite_inputs():
+    """NaN / Inf rows (what a diverging optimiser produces; the controller prunes them at the next densification,
+    ADC:201-206) must not hang or crash the kernels.  They do poison the pixels they are blended into (and through
+    those the gradients of the Gaussians sharing them -- as in the reference); everything out of their reach is that
+    of the clean render."""
+    from taichi_3d_gaussian_splatting_amd.synthetic import make_grad_image
+    s = small_scene(n=3000, size=128, seed=13)
+    clean = _run_operator(s, make_grad_image(128, 128))
+    bad = small_scene(n=3000, size=128, seed=13)
+    f = bad.point_cloud_features
+    f[0, 4] = float("nan")          # scale
+    f[1, 0:4] = 0.0                 # zero quaternion -> 0/0 in the in-place normalisation
+    f[2, 7] = float("inf")          # opacity logit
+    f[3, 8:56] = float("nan")       # colour
+    f[4, 5] = 80.0                  # exp(80) overflows fp32 -> inf covariance
+    bad.point_cloud[5] = float("nan")
+    bad.point_cloud[6, 2] = float("inf")
+    image, depth, count, xyz, feat = _run_operator(bad, make_grad_image(128, 128))
+    torch.cuda.synchronize()
+    finite_rows = torch.isfinite(xyz.grad).all(dim=1) & torch.isfinite(feat.grad).all(dim=1)
+    assert finite_rows.float().mean() > 0.5
+    assert (xyz.grad[5] == 0).all() and (xyz.grad[6] == 0).all()          # not in the frustum: no gradient
+    unaffected = finite_rows & ((feat.grad - clean[4].grad).abs().amax(dim=1) < 1e-6)
+    assert unaffected.float().mean() > 0.3                                # rows out of reach: the clean gradients
+    finite_px = torch.isfinite(image).all(dim=2)
+    assert finite_px.float().mean() > 0.5
+    same = (image - clean[0]).abs().amax(dim=2) < 1e-6                    # pixels the broken rows never reach
+    assert (same & finite_px).float().mean() > 0.3
