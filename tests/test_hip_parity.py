@@ -11,7 +11,7 @@ import torch
 
 from oracle import gs_oracle as O
 from tests.helpers import (FRAGILE_MARGIN, PIXEL_TOL, close_fraction, dev, oracle_forward, pack_acc, pack_attrs,
-                           rel_l2, report, scene_numpy, small_scene)
+                           rel_l2, report, small_scene)
 
 pytestmark = pytest.mark.gpu
 

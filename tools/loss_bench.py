@@ -17,8 +17,6 @@ dev = torch.device("cuda:0")
 gt = torch.rand(3, H, W, device=dev)
 pred = (gt.permute(1, 2, 0) + 0.1 * torch.randn(H, W, 3, device=dev)).contiguous().permute(2, 0, 1)
 one = torch.ones((), device=dev)
-for name, fn in (("forward", lambda: hip_ops.loss_forward(pred, gt, 0.2, True, True)),):
-    pass
 losses, maps = hip_ops.loss_forward(pred, gt, 0.2, True, True)
 ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
 tf = tb = 0.0
