@@ -560,6 +560,22 @@ def test_operator_cfg3_truck_like_forward_backward():
     _check_acc("cfg3.grad_xyz", xyz.grad.cpu().numpy(), ob["grad_xyz"])
 
 
+@pytest.mark.parametrize("workload,tag", [("headline_1m_1080p", "headline"), ("cfg4_2m_1080p", "cfg4")])
+def test_operator_full_size_forward_backward(workload, tag):
+    """The headline workload (1e6 Gaussians) and BASELINE config 4 (2e6), 1920x1072, on one GPU against the oracle at
+    full size: image on non-fragile pixels, depth-independent counts, dense gradients."""
+    from taichi_3d_gaussian_splatting_amd.synthetic import make_config_scene, make_grad_image
+    s = make_config_scene(workload)
+    f = oracle_forward(s)
+    g = make_grad_image(s.height, s.width)
+    ob = O.backward(f, g.numpy(), 3)
+    image, depth, count, xyz, feat = _run_operator(s, g)
+    report(f"{tag}.full_size", M=len(f["ids"]), K=len(f["keys"]))
+    _check_image(f"{tag}.image", image.detach().cpu().numpy(), f["image"], f["margin"] < FRAGILE_MARGIN)
+    _check_acc(f"{tag}.grad_feat", feat.grad.cpu().numpy(), ob["grad_feat"])
+    _check_acc(f"{tag}.grad_xyz", xyz.grad.cpu().numpy(), ob["grad_xyz"])
+
+
 def test_reference_stress_distribution_runs():
     """The reference's own stress test (T_RAS:111-150): 1e5 rows of U[0,1) data, only the first 8000 valid,
     1920x1088, f = 500, camera 0.5 behind the cloud -> every Gaussian covers every tile (4.6e7 (tile, Gaussian)
