@@ -119,3 +119,25 @@ def test_trainer_replicated_state_stays_identical_across_ranks(tmp_path):
     root = str(tmp_path)
     _write_dataset(root, torch.device("cuda:0"))
     mp.spawn(_train_worker, args=(2, _free_port(), root), nprocs=2, join=True)
+
+
+def test_bench_multi_rank_contract(tmp_path):
+    """bench.py launched the way the driver launches it for N > 1 (torch.distributed.run, one process per rank), on this
+    1-GPU box with the gloo transport: rank 0 prints exactly one JSON line with the contract's fields."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, GS_BENCH_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run(
+        [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+         "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+         "--workload", "cfg2_100k_800", "--no-cpu-baseline"],
+        cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["steps"] == 3 and rec["warmup"] == 1 and rec["scaling"] == "strong"
+    assert rec["config"]["sharding"] == "tile-rows/2" and rec["value"] > 0 and rec["unit"] == "Mpixels/s"
+    assert rec["roofline"]["bound"] == "hbm" and 0 < rec["roofline"]["frac"] < 1
