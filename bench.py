@@ -195,8 +195,8 @@ def main() -> None:
             acc = timed("reduce_partials", lambda: hip_ops.reduce_partials(slot_off, ntiles, flags, partials))
             timed("point_backward", lambda: hip_ops.point_backward(
                 s.point_cloud, f, s.point_object_id, s.camera_intrinsics, q_cp, t_cp, s.t_pointcloud_camera, ids,
-                acc, 3, cfg.grad_q_factor, cfg.grad_s_factor, cfg.grad_alpha_factor, cfg.grad_color_factor,
-                cfg.grad_high_order_color_factor, False, vmask))
+                acc, attrs, 3, cfg.grad_q_factor, cfg.grad_s_factor, cfg.grad_alpha_factor, cfg.grad_color_factor,
+                cfg.grad_high_order_color_factor, False, vmask, nowned))
         torch.cuda.synchronize()
         m = int(ids.shape[0])
         sizes = {"N": n, "M": m, "K": int(k), "P": pixels, "tiles": num_tiles}

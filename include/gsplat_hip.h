@@ -174,12 +174,16 @@ int gs_reduce_partials(const int32_t *slot_offsets, const int32_t *num_overlap_t
  * grad_xyz float[N][3] and grad_features float[N][56] are fully written (zeros for rows that
  * are not visible; with visible_mask = the int8[N] mask of gs_filter_compact only those rows are
  * zero-filled, with NULL both arrays are memset first).  The optional compact outputs (may be NULL) are the hook gathers of
- * RAS:1130-1134: grad_xyz_visible float[M][3], grad_features_visible float[M][56]. */
+ * RAS:1130-1134: grad_xyz_visible float[M][3], grad_features_visible float[M][56].
+ * attrs = the packed records of gs_preprocess (float[M][16]): the colour chain takes sigmoid(SH.Y) from row 2 instead
+ * of re-reading the 192 SH bytes of every feature row; num_owned_tiles (int32[M], may be NULL = all rows complete) marks
+ * the records whose rows 1..3 were not written (no key emitted on this GPU): for those the colour is re-evaluated
+ * from the features, and only if their accumulated colour gradient is non-zero (tile-row sharding). */
 int gs_point_backward(const float *xyz, const float *features, const int32_t *object_id,
                       const float *intrinsics, const float *q_camera_pointcloud,
                       const float *t_camera_pointcloud, const float *t_pointcloud_camera,
                       const int32_t *ids, const int8_t *visible_mask, int n_visible, int n_points,
-                      const float *acc,
+                      const float *acc, const float *attrs, const int32_t *num_owned_tiles,
                       int color_max_sh_band, float grad_q_factor, float grad_s_factor,
                       float grad_alpha_factor, float grad_color_factor,
                       float grad_high_order_color_factor, float *grad_xyz, float *grad_features,

@@ -147,7 +147,7 @@ class GaussianPointCloudRasterisation(torch.nn.Module):
 
                 ctx.save_for_backward(xyz, pointcloud_features, payload, ids, tile_start, tile_end, acc_alpha,
                                       last_eff, num_overlap_tiles, obj, q_cp, t_cp, t_pc, attrs, intrinsics,
-                                      slot_offsets, visible_mask)
+                                      slot_offsets, visible_mask, num_owned_tiles)
                 ctx.n_slots = n_slots
                 ctx.camera_info = camera_info
                 ctx.color_max_sh_band = color_max_sh_band
@@ -165,7 +165,8 @@ class GaussianPointCloudRasterisation(torch.nn.Module):
                         device=ctx.saved_tensors[0].device)
                 if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:  # RAS:1028
                     (xyz, features, payload, ids, tile_start, tile_end, acc_alpha, last_eff, num_overlap_tiles,
-                     obj, q_cp, t_cp, t_pc, attrs, intrinsics, slot_offsets, visible_mask) = ctx.saved_tensors
+                     obj, q_cp, t_cp, t_pc, attrs, intrinsics, slot_offsets, visible_mask,
+                     num_owned_tiles) = ctx.saved_tensors
                     cfg = outer.config
                     camera_info = ctx.camera_info
                     width, height = camera_info.camera_width, camera_info.camera_height
@@ -179,10 +180,10 @@ class GaussianPointCloudRasterisation(torch.nn.Module):
                         outer.grad_accumulator_reduce(acc)
                     # RAS:707-772 + 1102-1125  per-point pass, band clearing and factors fused
                     grad_pointcloud, grad_pointcloud_features, gx_vis, gf_vis = hip_ops.point_backward(
-                        xyz, features, obj, intrinsics, q_cp, t_cp, t_pc, ids, acc, ctx.color_max_sh_band,
+                        xyz, features, obj, intrinsics, q_cp, t_cp, t_pc, ids, acc, attrs, ctx.color_max_sh_band,
                         cfg.grad_q_factor, cfg.grad_s_factor, cfg.grad_alpha_factor, cfg.grad_color_factor,
                         cfg.grad_high_order_color_factor, want_visible=hook is not None,
-                        visible_mask=visible_mask)
+                        visible_mask=visible_mask, num_owned_tiles=num_owned_tiles)
                     if hook is not None:  # RAS:1127-1142
                         hook(GaussianPointCloudRasterisation.BackwardValidPointHookInput(
                             point_id_in_camera_list=ids,

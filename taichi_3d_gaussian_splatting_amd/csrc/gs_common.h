@@ -118,6 +118,62 @@ __device__ __forceinline__ float gs_row_sum_to_lane15(float v) {
     v += gs_dpp<0x118, 0xf, 0xc>(v);  // row_shr:8, banks 2-3
     return v;
 }
+// ------------------------------------------------------------------ forward colour of a Gaussian, shared source
+// sigmoid(SH . Y(view direction)) exactly as gs_preprocess stores it in row 2 of the packed record.  It lives here,
+// with FMA contraction switched off inside every function, so that the two kernels that evaluate it -- the projection
+// kernel and (for Gaussians that emitted no key on this GPU, tile-row sharding) the per-point backward -- execute the
+// same instruction sequence and agree to the last bit: ranks that take different paths must still end up with
+// identical replicated gradients.
+__device__ __forceinline__ void gs_rotmat_from_q(float x, float y, float z, float w, float R[9]) {  // GP3:31-48
+#pragma clang fp contract(off)
+    float xx = x * x, yy = y * y, zz = z * z, xy = x * y, xz = x * z, yz = y * z;
+    float wx = w * x, wy = w * y, wz = w * z;
+    R[0] = 1.f - 2.f * (yy + zz); R[1] = 2.f * (xy - wz); R[2] = 2.f * (xz + wy);
+    R[3] = 2.f * (xy + wz); R[4] = 1.f - 2.f * (xx + zz); R[5] = 2.f * (yz - wx);
+    R[6] = 2.f * (xz - wy); R[7] = 2.f * (yz + wx); R[8] = 1.f - 2.f * (xx + yy);
+}
+__device__ __forceinline__ void gs_sh_basis(const float d[3], float Y[16]) {  // SPH:10-32
+#pragma clang fp contract(off)
+    float n = sqrtf((d[0] * d[0] + d[1] * d[1]) + d[2] * d[2]);
+    float x = d[0] / n, y = d[1] / n, z = d[2] / n;
+    Y[0] = 0.28209479177387814f;
+    Y[1] = -0.48860251190291987f * y;
+    Y[2] = 0.48860251190291987f * z;
+    Y[3] = -0.48860251190291987f * x;
+    Y[4] = 1.0925484305920792f * x * y;
+    Y[5] = -1.0925484305920792f * y * z;
+    Y[6] = 0.94617469575755997f * z * z - 0.31539156525251999f;
+    Y[7] = -1.0925484305920792f * x * z;
+    Y[8] = 0.54627421529603959f * x * x - 0.54627421529603959f * y * y;
+    Y[9] = 0.59004358992664352f * y * (-3.0f * x * x + y * y);
+    Y[10] = 2.8906114426405538f * x * y * z;
+    Y[11] = 0.45704579946446572f * y * (1.0f - 5.0f * z * z);
+    Y[12] = 0.3731763325901154f * z * (5.0f * z * z - 3.0f);
+    Y[13] = 0.45704579946446572f * x * (1.0f - 5.0f * z * z);
+    Y[14] = 1.4453057213202769f * z * (x * x - y * y);
+    Y[15] = 0.59004358992664352f * x * (-x * x + 3.0f * y * y);
+}
+// W = R(q_camera_pointcloud), t = t_camera_pointcloud, p = the point; coeff(ch, k) = SH coefficient k of channel ch.
+// Ray origin = (-W^T) t (UTL:495-510), colour = sigmoid(SH . Y) (RAS:280-282,302-310, GP3:333-349).
+template <typename Coeff>
+__device__ __forceinline__ void gs_view_colour(const float W[9], const float t[3], const float p[3], Coeff coeff,
+                                               float rgb[3]) {
+#pragma clang fp contract(off)
+    float ro[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) ro[k] = ((-W[k]) * t[0] + (-W[3 + k]) * t[1]) + (-W[6 + k]) * t[2];
+    const float dir[3] = {p[0] - ro[0], p[1] - ro[1], p[2] - ro[2]};
+    float Y[16];
+    gs_sh_basis(dir, Y);
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) {
+        float s = coeff(ch, 0) * Y[0];
+#pragma unroll
+        for (int k = 1; k < 16; ++k) s = s + coeff(ch, k) * Y[k];
+        rgb[ch] = 1.f / (1.f + expf(-s));
+    }
+}
+
 // ------------------------------------------------------------------ coalesced access to 224-B feature rows
 // The feature matrix is AoS (56 floats = 14 x 16 B per Gaussian, owned by the caller).  A lane reading its own
 // row with 16-B loads makes every load instruction touch 64 different cache lines.  Instead the wave moves its

@@ -17,12 +17,8 @@ struct Mat3 { float m[9]; };
 
 // GP3:31-48 rotation_matrix_from_quaternion (q = x,y,z,w; not normalised here)
 __device__ __forceinline__ Mat3 rotmat_from_q(float x, float y, float z, float w) {
-    float xx = x * x, yy = y * y, zz = z * z, xy = x * y, xz = x * z, yz = y * z;
-    float wx = w * x, wy = w * y, wz = w * z;
     Mat3 R;
-    R.m[0] = 1.f - 2.f * (yy + zz); R.m[1] = 2.f * (xy - wz); R.m[2] = 2.f * (xz + wy);
-    R.m[3] = 2.f * (xy + wz); R.m[4] = 1.f - 2.f * (xx + zz); R.m[5] = 2.f * (yz - wx);
-    R.m[6] = 2.f * (xz - wy); R.m[7] = 2.f * (yz + wx); R.m[8] = 1.f - 2.f * (xx + yy);
+    gs_rotmat_from_q(x, y, z, w, R.m);
     return R;
 }
 
@@ -50,28 +46,6 @@ __device__ __forceinline__ void matmul(const float *A, const float *B, float *C)
             for (int l = 1; l < Kd; ++l) s = s + A[i * Kd + l] * B[l * N + j];
             C[i * N + j] = s;
         }
-}
-
-// SPH:10-32 get_spherical_harmonic_from_xyz
-__device__ __forceinline__ void sh_basis(const float d[3], float Y[16]) {
-    float n = sqrtf((d[0] * d[0] + d[1] * d[1]) + d[2] * d[2]);
-    float x = d[0] / n, y = d[1] / n, z = d[2] / n;
-    Y[0] = 0.28209479177387814f;
-    Y[1] = -0.48860251190291987f * y;
-    Y[2] = 0.48860251190291987f * z;
-    Y[3] = -0.48860251190291987f * x;
-    Y[4] = 1.0925484305920792f * x * y;
-    Y[5] = -1.0925484305920792f * y * z;
-    Y[6] = 0.94617469575755997f * z * z - 0.31539156525251999f;
-    Y[7] = -1.0925484305920792f * x * z;
-    Y[8] = 0.54627421529603959f * x * x - 0.54627421529603959f * y * y;
-    Y[9] = 0.59004358992664352f * y * (-3.0f * x * x + y * y);
-    Y[10] = 2.8906114426405538f * x * y * z;
-    Y[11] = 0.45704579946446572f * y * (1.0f - 5.0f * z * z);
-    Y[12] = 0.3731763325901154f * z * (5.0f * z * z - 3.0f);
-    Y[13] = 0.45704579946446572f * x * (1.0f - 5.0f * z * z);
-    Y[14] = 1.4453057213202769f * z * (x * x - y * y);
-    Y[15] = 0.59004358992664352f * x * (-x * x + 3.0f * y * y);
 }
 
 __device__ __forceinline__ float sigmoidf(float x) { return 1.f / (1.f + expf(-x)); }
@@ -364,20 +338,8 @@ __global__ __launch_bounds__(GS_BLOCK) void preprocess_kernel(
             // the SH colour (the most expensive part) and the rest of the record are skipped otherwise
             // (tile-row sharding: most Gaussians touch the rows of only one or two of the G GPUs).
             // colour: RAS:280-282,302-310; ray origin = (-R^T) t (UTL:495-510)
-            float ro[3];
-#pragma unroll
-            for (int k = 0; k < 3; ++k)
-                ro[k] = ((-W.m[k]) * t[0] + (-W.m[3 + k]) * t[1]) + (-W.m[6 + k]) * t[2];
-            float dir[3] = {p[0] - ro[0], p[1] - ro[1], p[2] - ro[2]}, Y[16];
-            sh_basis(dir, Y);
-            float rgb[3];
-#pragma unroll
-            for (int ch = 0; ch < 3; ++ch) {
-                float s = f[8 + 16 * ch] * Y[0];
-#pragma unroll
-                for (int k = 1; k < 16; ++k) s = s + f[8 + 16 * ch + k] * Y[k];
-                rgb[ch] = sigmoidf(s);
-            }
+            float rgb[3];   // shared source with the per-point backward (gs_common.h): bit-identical there
+            gs_view_colour(W.m, t, p, [&](int ch, int k) { return f[8 + 16 * ch + k]; }, rgb);
             out[1] = make_float4(cA, cB, cC, rescale);
             out[2] = make_float4(rgb[0], rgb[1], rgb[2], radius);
             // forward-blend form of the same weight: amp * 2^(dx*(A'dx + B'dy) + C'dy^2)

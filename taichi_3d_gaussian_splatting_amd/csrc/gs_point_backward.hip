@@ -49,25 +49,20 @@ __global__ __launch_bounds__(GS_BLOCK) void point_backward_kernel(
     const float *__restrict__ xyz, const float *__restrict__ feat, const int32_t *__restrict__ obj,
     const float *__restrict__ Kmat, const float *__restrict__ q_cp, const float *__restrict__ t_cp,
     const float *__restrict__ t_pc, const int32_t *__restrict__ ids, int m, const float4 *__restrict__ acc,
-    Factors fac, float *__restrict__ grad_xyz, float *__restrict__ grad_feat, float *__restrict__ grad_xyz_vis,
+    const float4 *__restrict__ attrs, const int32_t *__restrict__ ntiles_owned, Factors fac,
+    float *__restrict__ grad_xyz, float *__restrict__ grad_feat, float *__restrict__ grad_xyz_vis,
     float *__restrict__ grad_feat_vis) {
     extern __shared__ __attribute__((aligned(16))) float4 s_rows[];  // [4 waves][64 rows][GS_ROW_F4]
     const int i = blockIdx.x * GS_BLOCK + threadIdx.x;
     const int id = i < m ? ids[i] : -1;
     float4 *wave_rows = s_rows + (threadIdx.x >> 6) * (GS_WAVE * GS_ROW_F4);
-    // coalesced AoS gather of the 224-B feature rows (gs_common.h)
-    gs_rows_global_to_lds(reinterpret_cast<const float4 *>(feat), id, wave_rows);
-    float f[GS_FEATURE_DIM];
-#pragma unroll
-    for (int k = 0; k < GS_FEATURE_DIM / 4; ++k) {
-        float4 v = wave_rows[gs_lane() * GS_ROW_F4 + k];
-        f[4 * k] = v.x; f[4 * k + 1] = v.y; f[4 * k + 2] = v.z; f[4 * k + 3] = v.w;
-    }
-    if (i >= m) {  // lanes without a row still take part in the cooperative stores below
-#pragma unroll
-        for (int k = 0; k < GS_FEATURE_DIM; ++k) f[k] = 0.f;
-    }
+    float4 *my_row = wave_rows + gs_lane() * GS_ROW_F4;   // this lane's gradient row, assembled in LDS
     const int ic = i < m ? i : 0, idc = i < m ? id : 0;
+    // Only q, s and the opacity logit of the 224-B feature row are read (2 x 16 B): the colour chain needs
+    // sigmoid'(SH . Y) = rgb (1 - rgb), and rgb was stored by the forward pass (row 2 of the packed record).
+    const float4 *frow = reinterpret_cast<const float4 *>(feat) + 14 * (size_t)idc;
+    const float4 f0 = frow[0], f1 = frow[1];
+    const float f[8] = {f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z, f1.w};
     const float4 A0 = acc[3 * (size_t)ic], A1 = acc[3 * (size_t)ic + 1], A2 = acc[3 * (size_t)ic + 2];
     const float g_uv[2] = {A0.x, A0.y};
     const float g00 = A0.z, g01 = A0.w, g11 = A1.x;
@@ -144,36 +139,46 @@ __global__ __launch_bounds__(GS_BLOCK) void point_backward_kernel(
             dM[4] * (-4 * sy * qz) + dM[5] * (2 * sz * qy) + dM[6] * (2 * sx * qx) + dM[7] * (2 * sy * qy);
     gq[3] = dM[1] * (-2 * sy * qz) + dM[2] * (2 * sz * qy) + dM[3] * (2 * sx * qz) + dM[5] * (-2 * sz * qx) +
             dM[6] * (-2 * sx * qy) + dM[7] * (2 * sy * qx);
+    my_row[0] = make_float4(gq[0] * fac.q, gq[1] * fac.q, gq[2] * fac.q, gq[3] * fac.q);
+    my_row[1] = make_float4(gs[0] * fac.s, gs[1] * fac.s, gs[2] * fac.s, g_logit * fac.alpha);
 
     // colour: RAS:749-756; ray origin = t_pointcloud_camera of the object (RAS:731)
     const float dir[3] = {p[0] - t_pc[3 * o], p[1] - t_pc[3 * o + 1], p[2] - t_pc[3 * o + 2]};
     float Y[16];
     sh_basis(dir, Y);
-
-    float out[GS_FEATURE_DIM];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) out[k] = gq[k] * fac.q;
-#pragma unroll
-    for (int k = 0; k < 3; ++k) out[4 + k] = gs[k] * fac.s;
-    out[7] = g_logit * fac.alpha;
+    // sigmoid(SH . Y) per channel: stored by the forward pass for every Gaussian that emitted a key on this GPU;
+    // a Gaussian that only reached tiles of OTHER ranks (tile-row sharding) gets its colour gradient from their
+    // accumulators after the all-reduce -- only then is the SH row read and the colour re-evaluated here
+    float sg[3] = {0.f, 0.f, 0.f};
+    const bool any_colour_grad = g_rgb[0] != 0.f || g_rgb[1] != 0.f || g_rgb[2] != 0.f;
+    if (ntiles_owned == nullptr || ntiles_owned[ic] > 0) {
+        const float4 rgb = attrs[4 * (size_t)ic + 2];
+        sg[0] = rgb.x; sg[1] = rgb.y; sg[2] = rgb.z;
+    } else if (any_colour_grad) {
+        // the same source as the forward evaluation (gs_common.h), from the same inputs: bit-identical to what the
+        // ranks that did emit this Gaussian stored
+        float Wf[9];
+        gs_rotmat_from_q(q_cp[4 * o], q_cp[4 * o + 1], q_cp[4 * o + 2], q_cp[4 * o + 3], Wf);
+        const float *coeffs = reinterpret_cast<const float *>(frow);
+        gs_view_colour(Wf, t, p, [&](int ch, int k) { return coeffs[8 + 16 * ch + k]; }, sg);
+    }
+    // (Writing the row out in two 112-B halves through a half-sized staging area -- 8 KB instead of 15 KB of LDS per wave,
+    // twice the occupancy -- was measured SLOWER: 0.140 vs 0.103 ms; partial-line stores cost more than the occupancy buys.)
 #pragma unroll
     for (int ch = 0; ch < 3; ++ch) {
-        float s = 0.f;
-#pragma unroll
-        for (int k = 0; k < 16; ++k) s += f[8 + 16 * ch + k] * Y[k];
-        const float sg = 1.f / (1.f + expf(-s));
-        const float scale = g_rgb[ch] * (sg * (1.f - sg));  // UTL:356-359
+        // UTL:356-359; a zero upstream gradient gives exact zeros whatever the stored colour holds
+        const float scale = g_rgb[ch] != 0.f ? g_rgb[ch] * (sg[ch] * (1.f - sg[ch])) : 0.f;
+        float v[16];
 #pragma unroll
         for (int k = 0; k < 16; ++k) {
-            float v = scale * Y[k] * (k == 0 ? fac.color : fac.color_hi);
-            out[8 + 16 * ch + k] = k < fac.keep ? v : 0.f;  // RAS:1167-1182
+            const float x = scale * Y[k] * (k == 0 ? fac.color : fac.color_hi);
+            v[k] = k < fac.keep ? x : 0.f;  // RAS:1167-1182
         }
-    }
-    // coalesced AoS scatter of the gradient rows through the same LDS staging area
-    __builtin_amdgcn_wave_barrier();
 #pragma unroll
-    for (int k = 0; k < GS_FEATURE_DIM / 4; ++k)
-        wave_rows[gs_lane() * GS_ROW_F4 + k] = make_float4(out[4 * k], out[4 * k + 1], out[4 * k + 2], out[4 * k + 3]);
+        for (int k4 = 0; k4 < 4; ++k4)
+            my_row[2 + 4 * ch + k4] = make_float4(v[4 * k4], v[4 * k4 + 1], v[4 * k4 + 2], v[4 * k4 + 3]);
+    }
+    // coalesced AoS scatter of the gradient rows out of the LDS staging area
     gs_rows_lds_to_global(reinterpret_cast<float4 *>(grad_feat), id, wave_rows);
     if (grad_feat_vis) gs_rows_lds_to_global(reinterpret_cast<float4 *>(grad_feat_vis), i < m ? i : -1, wave_rows);
     if (i < m) {
@@ -204,12 +209,13 @@ __global__ __launch_bounds__(GS_BLOCK) void zero_invisible_rows_kernel(const int
 extern "C" int gs_point_backward(const float *xyz, const float *features, const int32_t *object_id,
                                  const float *intrinsics, const float *q_cp, const float *t_cp, const float *t_pc,
                                  const int32_t *ids, const int8_t *visible_mask, int n_visible, int n_points,
-                                 const float *acc,
+                                 const float *acc, const float *attrs, const int32_t *num_owned_tiles,
                                  int color_max_sh_band, float grad_q_factor, float grad_s_factor,
                                  float grad_alpha_factor, float grad_color_factor,
                                  float grad_high_order_color_factor, float *grad_xyz, float *grad_features,
                                  float *grad_xyz_visible, float *grad_features_visible, void *stream) {
     GS_REQUIRE(n_visible >= 0 && n_points >= n_visible, "sizes");
+    GS_REQUIRE(n_visible == 0 || attrs != nullptr, "gs_point_backward: attrs (the packed records of the forward pass) is required");
     hipStream_t s = (hipStream_t)stream;
     if (n_points > 0 && visible_mask != nullptr && n_visible > 0) {
         hipLaunchKernelGGL(zero_invisible_rows_kernel, dim3(gs_div_up(n_points, GS_BLOCK)), dim3(GS_BLOCK), 0, s,
@@ -227,8 +233,8 @@ extern "C" int gs_point_backward(const float *xyz, const float *features, const 
     hipLaunchKernelGGL(point_backward_kernel, dim3(gs_div_up(n_visible, GS_BLOCK)), dim3(GS_BLOCK),
                        sizeof(float4) * GS_BLOCK * GS_ROW_F4, s, xyz,
                        features, object_id, intrinsics, q_cp, t_cp, t_pc, ids, n_visible,
-                       reinterpret_cast<const float4 *>(acc), fac, grad_xyz, grad_features, grad_xyz_visible,
-                       grad_features_visible);
+                       reinterpret_cast<const float4 *>(acc), reinterpret_cast<const float4 *>(attrs), num_owned_tiles,
+                       fac, grad_xyz, grad_features, grad_xyz_visible, grad_features_visible);
     GS_CHECK_LAUNCH();
     return 0;
 }

@@ -294,8 +294,8 @@ def test_point_backward(ops, scene, ofwd, obwd):
     acc = pack_acc(ob["acc"], ob["hook"]["num_affected_pixels"])
     gx, gf, gxv, gfv = ops.point_backward(
         dev(s.point_cloud), dev(ofwd["feat"]), dev(s.point_object_id), dev(s.camera_intrinsics), dev(ofwd["q_cp"]),
-        dev(ofwd["t_cp"]), dev(ofwd["t_pc"]), dev(ofwd["ids"]), dev(acc), 3, O.GRAD_Q_FACTOR, O.GRAD_S_FACTOR,
-        O.GRAD_ALPHA_FACTOR, O.GRAD_COLOR_FACTOR, O.GRAD_HIGH_ORDER_COLOR_FACTOR, want_visible=True)
+        dev(ofwd["t_cp"]), dev(ofwd["t_pc"]), dev(ofwd["ids"]), dev(acc), dev(pack_attrs(ofwd)), 3, O.GRAD_Q_FACTOR,
+        O.GRAD_S_FACTOR, O.GRAD_ALPHA_FACTOR, O.GRAD_COLOR_FACTOR, O.GRAD_HIGH_ORDER_COLOR_FACTOR, want_visible=True)
     gx, gf = gx.cpu().numpy(), gf.cpu().numpy()
     for name, hip, ref in (("xyz", gx, ob["grad_xyz"]), ("q", gf[:, :4], ob["grad_feat"][:, :4]),
                            ("s", gf[:, 4:7], ob["grad_feat"][:, 4:7]), ("logit", gf[:, 7], ob["grad_feat"][:, 7]),
@@ -318,8 +318,8 @@ def test_point_backward_sh_band_clearing(ops, scene, ofwd, obwd, band, keep):
     acc = pack_acc(ob["acc"], ob["hook"]["num_affected_pixels"])
     _, gf, _, _ = ops.point_backward(
         dev(s.point_cloud), dev(ofwd["feat"]), dev(s.point_object_id), dev(s.camera_intrinsics), dev(ofwd["q_cp"]),
-        dev(ofwd["t_cp"]), dev(ofwd["t_pc"]), dev(ofwd["ids"]), dev(acc), band, O.GRAD_Q_FACTOR, O.GRAD_S_FACTOR,
-        O.GRAD_ALPHA_FACTOR, O.GRAD_COLOR_FACTOR, O.GRAD_HIGH_ORDER_COLOR_FACTOR, want_visible=False)
+        dev(ofwd["t_cp"]), dev(ofwd["t_pc"]), dev(ofwd["ids"]), dev(acc), dev(pack_attrs(ofwd)), band, O.GRAD_Q_FACTOR,
+        O.GRAD_S_FACTOR, O.GRAD_ALPHA_FACTOR, O.GRAD_COLOR_FACTOR, O.GRAD_HIGH_ORDER_COLOR_FACTOR, want_visible=False)
     gf = gf.cpu().numpy()
     ref = ob["grad_feat"].copy()  # computed with band 3
     O.clear_grad_by_color_max_sh_band(ref, band)

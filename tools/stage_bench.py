@@ -48,8 +48,8 @@ for _ in range(reps + 2):
         start, end, payload, attrs, g, acc_alpha, last_eff, slot_off, n_slots, s.width, s.height))
     acc = timed("reduce_partials", lambda: hip_ops.reduce_partials(slot_off, ntiles, flags, partials))
     timed("point_backward", lambda: hip_ops.point_backward(
-        s.point_cloud, feat, s.point_object_id, s.camera_intrinsics, q_cp, t_cp, s.t_pointcloud_camera, ids, acc, 3,
-        1.0, 0.5, 20.0, 5.0, 1.0, False, vmask))
+        s.point_cloud, feat, s.point_object_id, s.camera_intrinsics, q_cp, t_cp, s.t_pointcloud_camera, ids, acc, attrs, 3,
+        1.0, 0.5, 20.0, 5.0, 1.0, False, vmask, nowned))
 torch.cuda.synchronize()
 print(f"workload={workload} M={ids.shape[0]} K={k} cull={CULL}")
 tot = 0.0
