@@ -116,6 +116,13 @@ class GaussianPointAdaptiveController:
         self.accumulated_position_gradients = torch.zeros(n, 3, dtype=torch.float32, device=dev)
         self.accumulated_position_gradients_norm = torch.zeros(n, dtype=torch.float32, device=dev)
 
+    def next_update_selects(self) -> bool:
+        """True if the next ``update`` call is a densification iteration, i.e. keeps its hook input (``input_data``) for
+        the trainer's histograms -- lets the trainer ask the rasteriser for the costly compact feature gradients
+        only then."""
+        nxt = self.iteration_counter + 1
+        return nxt >= self.config.num_iterations_warm_up and nxt % self.config.num_iterations_densify == 0
+
     def _is_densify_iteration(self) -> bool:
         return (self.iteration_counter >= self.config.num_iterations_warm_up and
                 self.iteration_counter % self.config.num_iterations_densify == 0)

@@ -65,7 +65,7 @@ class GaussianPointCloudRasterisation(torch.nn.Module):
     class BackwardValidPointHookInput:
         point_id_in_camera_list: torch.Tensor  # M
         grad_point_in_camera: torch.Tensor  # Mx3
-        grad_pointfeatures_in_camera: torch.Tensor  # Mx56
+        grad_pointfeatures_in_camera: Optional[torch.Tensor]  # Mx56 (None when hook_feature_gradients is off)
         grad_viewspace: torch.Tensor  # Mx2
         magnitude_grad_viewspace: torch.Tensor  # M
         magnitude_grad_viewspace_on_image: torch.Tensor  # HxWx2
@@ -183,7 +183,8 @@ class GaussianPointCloudRasterisation(torch.nn.Module):
                         xyz, features, obj, intrinsics, q_cp, t_cp, t_pc, ids, acc, attrs, ctx.color_max_sh_band,
                         cfg.grad_q_factor, cfg.grad_s_factor, cfg.grad_alpha_factor, cfg.grad_color_factor,
                         cfg.grad_high_order_color_factor, want_visible=hook is not None,
-                        visible_mask=visible_mask, num_owned_tiles=num_owned_tiles)
+                        visible_mask=visible_mask, num_owned_tiles=num_owned_tiles,
+                        want_visible_features=hook is not None and outer.hook_feature_gradients)
                     if hook is not None:  # RAS:1127-1142
                         hook(GaussianPointCloudRasterisation.BackwardValidPointHookInput(
                             point_id_in_camera_list=ids,
@@ -201,6 +202,10 @@ class GaussianPointCloudRasterisation(torch.nn.Module):
 
         self._module_function = _module_function
         # multi-GPU hooks installed by distributed.shard_rasteriser_across_tile_rows (None on 1 GPU)
+        # the hook's M-compact copy of the feature gradients (RAS:1132) costs a 224 B x M write per backward; a consumer
+        # that does not read it on every iteration (the trainer: only when the controller densifies) may switch it
+        # off, ``grad_pointfeatures_in_camera`` is then None
+        self.hook_feature_gradients: bool = True
         self.grad_accumulator_reduce: Optional[Callable[[torch.Tensor], None]] = None
         self.image_gather: Optional[Callable[[list], None]] = None
 

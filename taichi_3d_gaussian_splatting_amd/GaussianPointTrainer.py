@@ -292,6 +292,8 @@ class GaussianPointCloudTrainer:
                 image_gt, info = self._downsample_image_and_camera_info(image_gt, info, downsample_factor)
 
             band = int(iteration // cfg.increase_color_max_sh_band_interval)
+            # the compact per-feature gradients of the hook are only looked at (histograms) on densification iterations
+            self.rasterisation.hook_feature_gradients = self.adaptive_controller.next_update_selects()
             image_pred, image_depth, pixel_valid_point_count = self._rasterise(q, t, info, band)
             # clamp (TRN:168) is folded into the fused loss kernel; the permute (TRN:170) is a view
             loss, l1_loss, ssim_loss = self.loss_function(image_pred.permute(2, 0, 1), image_gt, clamp_prediction=True)

@@ -251,15 +251,18 @@ def blend_backward(tile_start, tile_end, payload, attrs, grad_image, acc_alpha, 
 
 def point_backward(xyz, features, object_id, intrinsics, q_cp, t_cp, t_pc, ids, acc, attrs, color_max_sh_band,
                    grad_q_factor, grad_s_factor, grad_alpha_factor, grad_color_factor,
-                   grad_high_order_color_factor, want_visible: bool, visible_mask=None, num_owned_tiles=None):
+                   grad_high_order_color_factor, want_visible: bool, visible_mask=None, num_owned_tiles=None,
+                   want_visible_features: Optional[bool] = None):
     """attrs: the packed records of ``preprocess`` (the colour chain reads sigmoid(SH.Y) from them);
     num_owned_tiles (optional): records with 0 owned tiles are incomplete, their colour is re-evaluated on demand."""
     dev = xyz.device
     n, m = xyz.shape[0], ids.shape[0]
     grad_xyz = torch.empty((n, 3), dtype=torch.float32, device=dev)
     grad_feat = torch.empty((n, FEATURE_DIM), dtype=torch.float32, device=dev)
+    if want_visible_features is None:
+        want_visible_features = want_visible
     gx_vis = torch.empty((m, 3), dtype=torch.float32, device=dev) if want_visible else None
-    gf_vis = torch.empty((m, FEATURE_DIM), dtype=torch.float32, device=dev) if want_visible else None
+    gf_vis = torch.empty((m, FEATURE_DIM), dtype=torch.float32, device=dev) if want_visible_features else None
     call("gs_point_backward", ptr(xyz), ptr(features), ptr(object_id), ptr(intrinsics), ptr(q_cp), ptr(t_cp),
          ptr(t_pc), ptr(ids), ptr(visible_mask), m, n, ptr(acc), ptr(attrs), ptr(num_owned_tiles), int(color_max_sh_band),
          float(grad_q_factor), float(grad_s_factor),

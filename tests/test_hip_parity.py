@@ -385,6 +385,24 @@ def test_operator_end_to_end(scene, ofwd, obwd):
                ho["grad_pointfeatures_in_camera"])
 
 
+def test_hook_feature_gradients_can_be_switched_off(scene):
+    from taichi_3d_gaussian_splatting_amd import GaussianPointCloudRasterisation as Op
+    from taichi_3d_gaussian_splatting_amd.synthetic import make_grad_image
+    g = make_grad_image(scene.height, scene.width)
+    got = {}
+    full = _run_operator(scene, g, hook=lambda h: got.setdefault("full", h))
+    op = Op(Op.GaussianPointCloudRasterisationConfig(near_plane=scene.near_plane, far_plane=scene.far_plane,
+                                                     depth_to_sort_key_scale=scene.depth_to_sort_key_scale),
+            backward_valid_point_hook=lambda h: got.setdefault("lean", h))
+    op.hook_feature_gradients = False
+    lean = _run_operator(scene, g, op=op)
+    assert got["lean"].grad_pointfeatures_in_camera is None and got["full"].grad_pointfeatures_in_camera is not None
+    for name in ("point_id_in_camera_list", "grad_point_in_camera", "grad_viewspace", "magnitude_grad_viewspace",
+                 "num_overlap_tiles", "num_affected_pixels", "point_depth", "point_uv_in_camera"):
+        assert torch.equal(getattr(got["lean"], name), getattr(got["full"], name)), name
+    assert torch.equal(full[4].grad, lean[4].grad) and torch.equal(full[3].grad, lean[3].grad)
+
+
 def test_operator_tile_row_sharding_matches_single(scene):
     """Image-space sharding: rendering tile rows {0,2,4,..} and {1,3,5,..} separately and merging
     equals the un-sharded render bit-for-bit; partial gradients add up."""
