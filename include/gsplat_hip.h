@@ -202,6 +202,18 @@ int gs_ellipsoid_offsets(const float *features, int n, float *offsets, void *str
 int gs_sample_from_points(const float *xyz, const float *features, const float *uniforms, int n,
                           float *samples, void *stream);
 
+/* Per-iteration statistics of the controller (GaussianPointAdaptiveController.py:130-146), one pass: for every visible
+ * Gaussian i with id = ids[i] (ids unique):  num_in_camera[id] += 1; num_pixels[id] += num_affected_pixels[i];
+ * view_space_gradients[id] += magnitude[i]; view_space_gradients_avg[id] += magnitude[i] / pixels[i] (0/0 counts as 0);
+ * position_gradients[id][0..2] += grad_point_in_camera[i][0..2]; position_gradients_norm[id] += |grad_point_in_camera[i]|.
+ * The accumulators are indexed by point id (N rows), the inputs by visible index (M rows). */
+int gs_controller_accumulate(const int32_t *ids, const int32_t *num_affected_pixels,
+                             const float *magnitude_grad_viewspace, const float *grad_point_in_camera, int n_visible,
+                             int32_t *accumulated_num_in_camera, int32_t *accumulated_num_pixels,
+                             float *accumulated_view_space_gradients, float *accumulated_view_space_gradients_avg,
+                             float *accumulated_position_gradients, float *accumulated_position_gradients_norm,
+                             void *stream);
+
 /* ---- fused photometric loss of the trainer --------------------------------------
  * L = (1-lambda) * mean|x-y| + lambda * (1 - SSIM(x,y)), x = clamp(prediction,0,1) when clamp01_prediction.
  * Replaces clamp + permute (GaussianPointTrainer.py:167-170) + LossFunction.forward (LossFunction.py:20-35,

@@ -294,6 +294,22 @@ def sample_from_points(xyz: torch.Tensor, features: torch.Tensor, uniforms: Opti
     return out
 
 
+def controller_accumulate(ids, num_affected_pixels, magnitude, grad_xyz, num_in_camera, num_pixels, view_grad,
+                          view_grad_avg, pos_grad, pos_grad_norm) -> None:
+    """The controller's per-iteration statistics (ADC:130-146) in one pass, in place."""
+    for t, dt, name in ((ids, torch.int32, "ids"), (num_affected_pixels, torch.int32, "num_affected_pixels"),
+                        (num_in_camera, torch.int32, "num_in_camera"), (num_pixels, torch.int32, "num_pixels"),
+                        (magnitude, torch.float32, "magnitude"), (grad_xyz, torch.float32, "grad_xyz"),
+                        (view_grad, torch.float32, "view_grad"), (view_grad_avg, torch.float32, "view_grad_avg"),
+                        (pos_grad, torch.float32, "pos_grad"), (pos_grad_norm, torch.float32, "pos_grad_norm")):
+        _require_device(t, name)
+        if t.dtype != dt or not t.is_contiguous():
+            raise TypeError(f"{name} must be a contiguous {dt} tensor")
+    call("gs_controller_accumulate", ptr(ids), ptr(num_affected_pixels), ptr(magnitude), ptr(grad_xyz), ids.shape[0],
+         ptr(num_in_camera), ptr(num_pixels), ptr(view_grad), ptr(view_grad_avg), ptr(pos_grad), ptr(pos_grad_norm),
+         current_stream(ids.device))
+
+
 # ---------------------------------------------------------------- fused trainer loss (row F1)
 def _image_layout(prediction: torch.Tensor):
     """(buffer, is_hwc, H, W) for a [3,H,W] prediction that is either contiguous or the ``permute(2,0,1)`` view

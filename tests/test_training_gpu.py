@@ -349,3 +349,39 @@ def test_adam_kernel_matches_torch_adam():
         bad = torch.nn.Parameter(torch.zeros(4))
         bad.grad = torch.zeros(4)
         Adam([bad]).step()
+
+
+def test_controller_statistics_kernel_matches_eager_update():
+    """ADC:130-146 through the single HIP pass vs the eager indexed updates (the CPU path of the same method)."""
+    from taichi_3d_gaussian_splatting_amd import GaussianPointCloudRasterisation as RAS
+    from taichi_3d_gaussian_splatting_amd.GaussianPointAdaptiveController import GaussianPointAdaptiveController as ADC
+    g = torch.Generator().manual_seed(8)
+    n = 5000
+    ctrls = {}
+    for dev in ("cpu", "cuda:0"):
+        mp = ADC.GaussianPointAdaptiveControllerMaintainedParameters(
+            torch.zeros(n, 3, device=dev), torch.zeros(n, 56, device=dev), torch.zeros(n, dtype=torch.int8, device=dev),
+            torch.zeros(n, dtype=torch.int32, device=dev))
+        ctrls[dev] = ADC(ADC.GaussianPointAdaptiveControllerConfig(num_iterations_warm_up=10 ** 6), mp,
+                         sample_from_point=lambda p, f: p)
+    for _ in range(3):
+        ids = torch.sort(torch.randperm(n, generator=g)[:3000]).values.to(torch.int32)
+        pixels = torch.randint(1, 500, (3000,), generator=g, dtype=torch.int32)
+        pixels[::7] = 0            # never blended: magnitude 0 as well -> 0/0 must count as 0
+        mag = torch.rand(3000, generator=g) * 1e-4
+        mag[::7] = 0.0
+        fields = dict(point_id_in_camera_list=ids, grad_point_in_camera=torch.randn(3000, 3, generator=g) * 1e-3,
+                      grad_pointfeatures_in_camera=None, grad_viewspace=torch.zeros(3000, 2),
+                      magnitude_grad_viewspace=mag, magnitude_grad_viewspace_on_image=torch.zeros(16, 16, 2),
+                      num_overlap_tiles=torch.ones(3000, dtype=torch.int32), num_affected_pixels=pixels,
+                      point_depth=torch.ones(3000), point_uv_in_camera=torch.zeros(3000, 2))
+        for dev, c in ctrls.items():
+            c.update(RAS.BackwardValidPointHookInput(**{k: (v if v is None else v.to(dev)) for k, v in fields.items()}))
+    a, b = ctrls["cpu"], ctrls["cuda:0"]
+    assert torch.equal(a.accumulated_num_in_camera, b.accumulated_num_in_camera.cpu())
+    assert torch.equal(a.accumulated_num_pixels, b.accumulated_num_pixels.cpu())
+    for name in ("accumulated_view_space_position_gradients", "accumulated_view_space_position_gradients_avg",
+                 "accumulated_position_gradients", "accumulated_position_gradients_norm"):
+        x, y = getattr(a, name), getattr(b, name).cpu()
+        assert torch.allclose(x, y, rtol=1e-6, atol=1e-12), name
+    assert torch.isfinite(b.accumulated_view_space_position_gradients_avg).all()
