@@ -178,7 +178,10 @@ int gs_reduce_partials(const int32_t *slot_offsets, const int32_t *num_overlap_t
  * attrs = the packed records of gs_preprocess (float[M][16]): the colour chain takes sigmoid(SH.Y) from row 2 instead
  * of re-reading the 192 SH bytes of every feature row; num_owned_tiles (int32[M], may be NULL = all rows complete) marks
  * the records whose rows 1..3 were not written (no key emitted on this GPU): for those the colour is re-evaluated
- * from the features, and only if their accumulated colour gradient is non-zero (tile-row sharding). */
+ * from the features, and only if their accumulated colour gradient is non-zero (tile-row sharding).
+ * hook_compact (may be NULL): float[7*M], the remaining M-indexed hook fields as consecutive planes --
+ * grad_viewspace [M][2] | magnitude_grad_viewspace [M] | num_affected_pixels [M] (int32 bits) | point_depth [M] |
+ * point_uv_in_camera [M][2] (RAS:1130-1139) -- written here instead of five strided column copies of acc / attrs. */
 int gs_point_backward(const float *xyz, const float *features, const int32_t *object_id,
                       const float *intrinsics, const float *q_camera_pointcloud,
                       const float *t_camera_pointcloud, const float *t_pointcloud_camera,
@@ -187,7 +190,7 @@ int gs_point_backward(const float *xyz, const float *features, const int32_t *ob
                       int color_max_sh_band, float grad_q_factor, float grad_s_factor,
                       float grad_alpha_factor, float grad_color_factor,
                       float grad_high_order_color_factor, float *grad_xyz, float *grad_features,
-                      float *grad_xyz_visible, float *grad_features_visible, void *stream);
+                      float *grad_xyz_visible, float *grad_features_visible, float *hook_compact, void *stream);
 
 /* ---- adaptive-controller kernels (not on the per-frame hot path) ---------------- */
 
@@ -248,6 +251,15 @@ int gs_scale_regulariser(const float *features, const int8_t *point_invalid_mask
  * all four buffers hold n floats and are 16-byte aligned. */
 int gs_adam_step(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, long long n, double lr,
                  double beta1, double beta2, double eps, int step, void *stream);
+
+/* The same step for the [n_rows][56] feature matrix with the gradient of the scale regulariser
+ * scale_regulariser_weight * mean_{live rows} ||exp(s)||_2 (LossFunction.py:42-54) added on the fly to columns 4..6 of
+ * the incoming gradient of live rows (point_invalid_mask == 0) -- the regulariser then needs no pass of its own over the
+ * feature and gradient matrices.  The gradient buffer itself is not modified.  workspace: int32[256]. */
+int gs_adam_step_features(float *features, const float *grad, float *exp_avg, float *exp_avg_sq, long long n_rows,
+                          double lr, double beta1, double beta2, double eps, int step,
+                          const int8_t *point_invalid_mask, double scale_regulariser_weight, int32_t *workspace,
+                          void *stream);
 
 #ifdef __cplusplus
 }

@@ -179,25 +179,22 @@ class GaussianPointCloudRasterisation(torch.nn.Module):
                     if outer.grad_accumulator_reduce is not None:  # multi-GPU: sum partial tile gradients
                         outer.grad_accumulator_reduce(acc)
                     # RAS:707-772 + 1102-1125  per-point pass, band clearing and factors fused
-                    grad_pointcloud, grad_pointcloud_features, gx_vis, gf_vis = hip_ops.point_backward(
+                    out = hip_ops.point_backward(
                         xyz, features, obj, intrinsics, q_cp, t_cp, t_pc, ids, acc, attrs, ctx.color_max_sh_band,
                         cfg.grad_q_factor, cfg.grad_s_factor, cfg.grad_alpha_factor, cfg.grad_color_factor,
                         cfg.grad_high_order_color_factor, want_visible=hook is not None,
                         visible_mask=visible_mask, num_owned_tiles=num_owned_tiles,
-                        want_visible_features=hook is not None and outer.hook_feature_gradients)
-                    if hook is not None:  # RAS:1127-1142
+                        want_visible_features=hook is not None and outer.hook_feature_gradients,
+                        want_hook_fields=hook is not None)
+                    grad_pointcloud, grad_pointcloud_features, gx_vis, gf_vis = out[:4]
+                    if hook is not None:  # RAS:1127-1142; the column fields come compact out of the same kernel
                         hook(GaussianPointCloudRasterisation.BackwardValidPointHookInput(
                             point_id_in_camera_list=ids,
                             grad_point_in_camera=gx_vis,
                             grad_pointfeatures_in_camera=gf_vis,
-                            grad_viewspace=acc[:, 0:2].contiguous(),
-                            magnitude_grad_viewspace=acc[:, 9].contiguous(),
                             magnitude_grad_viewspace_on_image=magnitude_image,
                             num_overlap_tiles=num_overlap_tiles,
-                            num_affected_pixels=acc[:, 10].contiguous().view(torch.int32),
-                            point_depth=attrs[:, 2].contiguous(),
-                            point_uv_in_camera=attrs[:, 0:2].contiguous(),
-                        ))
+                            **out[4]))
                 return grad_pointcloud, grad_pointcloud_features, None, None, None, None, None, None
 
         self._module_function = _module_function

@@ -275,6 +275,11 @@ class GaussianPointCloudTrainer:
         batches = cycle(train_loader)
         feature_optimizer = Adam([self.scene.point_cloud_features], lr=cfg.feature_learning_rate, betas=(0.9, 0.999))
         position_optimizer = Adam([self.scene.point_cloud], lr=cfg.position_learning_rate, betas=(0.9, 0.999))
+        regularised = self.loss_function.config.enable_regularization
+        if regularised:
+            feature_optimizer.set_scale_regulariser(self.scene.point_cloud_features,
+                                                    self.loss_function.config.regularization_weight,
+                                                    self.scene.point_invalid_mask)
         scheduler = torch.optim.lr_scheduler.ExponentialLR(position_optimizer,
                                                            gamma=cfg.position_learning_rate_decay_rate)
         downsample_factor = cfg.initial_downsample_factor
@@ -298,10 +303,12 @@ class GaussianPointCloudTrainer:
             # clamp (TRN:168) is folded into the fused loss kernel; the permute (TRN:170) is a view
             loss, l1_loss, ssim_loss = self.loss_function(image_pred.permute(2, 0, 1), image_gt, clamp_prediction=True)
             loss.backward()
-            # scale regulariser (TRN:172-174, LOS:36-38): same value and gradient, added in place
-            regulariser = self.loss_function.add_regularization_gradient_(self.scene.point_invalid_mask,
-                                                                          self.scene.point_cloud_features)
-            loss = loss.detach() if regulariser is None else loss.detach() + regulariser
+            # scale regulariser (TRN:172-174, LOS:36-38): its gradient is added inside the feature Adam kernel (same
+            # gradient, from the same pre-step parameters); its VALUE is only needed where the loss is logged
+            loss = loss.detach()
+            if regularised and iteration % cfg.log_loss_interval == 0:
+                loss = loss + self.loss_function.regularization_value(self.scene.point_invalid_mask,
+                                                                      self.scene.point_cloud_features)
             raw_pred = image_pred.detach()
             image_pred = None   # the clamped CHW copy is only materialised on logging iterations (below)
             feature_optimizer.step()
@@ -321,10 +328,11 @@ class GaussianPointCloudTrainer:
 
             is_problematic = False
             if iteration % cfg.log_loss_interval == 0:
-                loss_value = loss.item()    # the only regular host read-back of the loop
+                # the only regular host read-back of the loop: one copy for the three scalars
+                loss_value, l1_value, ssim_value = torch.stack([loss, l1_loss.detach(), ssim_loss.detach()]).tolist()
                 self._scalar("train/loss", loss_value, iteration, "train_loss")
-                self._scalar("train/l1 loss", l1_loss.item(), iteration, "train_l1_loss")
-                self._scalar("train/ssim loss", ssim_loss.item(), iteration, "train_ssim_loss")
+                self._scalar("train/l1 loss", l1_value, iteration, "train_l1_loss")
+                self._scalar("train/ssim loss", ssim_value, iteration, "train_ssim_loss")
                 if len(recent_losses) == recent_losses.maxlen and \
                         iteration - last_problematic > recent_losses.maxlen * cfg.log_loss_interval and \
                         loss_value > 1.5 * sum(recent_losses) / len(recent_losses):

@@ -160,6 +160,16 @@ class LossFunction(nn.Module):
         pointcloud_features.grad.add_(grad, alpha=weight)
         return weight * value.detach()
 
+    @torch.no_grad()
+    def regularization_value(self, point_invalid_mask: torch.Tensor, pointcloud_features: torch.Tensor) -> torch.Tensor:
+        """``regularization_weight * R`` without any gradient (for logging when the gradient is applied elsewhere, e.g.
+        inside ``optim.Adam.set_scale_regulariser``)."""
+        weight = float(self.config.regularization_weight)
+        if pointcloud_features.is_cuda:
+            from . import hip_ops
+            return weight * hip_ops.scale_regulariser(pointcloud_features, point_invalid_mask)[0]
+        return weight * self._regularization_loss(point_invalid_mask, pointcloud_features.detach())
+
     @staticmethod
     def _regularization_loss(point_invalid_mask, pointcloud_features):
         """Mean Euclidean norm of the three axis lengths exp(s) of the valid Gaussians (LOS:42-54), written as a

@@ -15,7 +15,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgsplat_hip.so")
-ABI_VERSION = 14
+ABI_VERSION = 15
 
 _c = ctypes
 _P = _c.c_void_p
@@ -47,11 +47,13 @@ _SIGNATURES = {
     "gs_scale_regulariser_workspace_floats": (_c.c_longlong, []),
     "gs_scale_regulariser": (_I, [_P, _P, _I, _F, _P, _P, _P, _P, _P]),
     "gs_adam_step": (_I, [_P, _P, _P, _P, _c.c_longlong, _c.c_double, _c.c_double, _c.c_double, _c.c_double, _I, _P]),
+    "gs_adam_step_features": (_I, [_P, _P, _P, _P, _c.c_longlong, _c.c_double, _c.c_double, _c.c_double, _c.c_double,
+                                   _I, _P, _c.c_double, _P, _P]),
     "gs_controller_accumulate": (_I, [_P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P]),
     "gs_ellipsoid_offsets": (_I, [_P, _I, _P, _P]),
     "gs_sample_from_points": (_I, [_P, _P, _P, _I, _P, _P]),
     "gs_point_backward": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _I, _F, _F, _F, _F, _F,
-                               _P, _P, _P, _P, _P]),
+                               _P, _P, _P, _P, _P, _P]),
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)

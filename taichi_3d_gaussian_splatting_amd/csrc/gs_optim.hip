@@ -40,7 +40,101 @@ __global__ __launch_bounds__(GS_BLOCK) void adam_kernel(float *__restrict__ para
     }
 }
 
+// Feature-matrix variant: rows of 56 floats = 14 float4; float4 #1 of a row holds (s0, s1, s2, opacity logit).  The
+// gradient of the trainer's scale regulariser  w * mean_live ||exp(s)||  (LossFunction.py:42-54) is a function of those
+// three parameters only, so it is added to the incoming gradient right here instead of in a pass of its own over the
+// feature and gradient matrices (75 us per iteration at 1.2e6 rows): g_k += w / n_live * exp(s_k)^2 / ||exp(s)||.
+__global__ __launch_bounds__(GS_BLOCK) void count_live_rows_kernel(const int8_t *__restrict__ invalid, int n,
+                                                                   int *__restrict__ partial_counts) {
+    __shared__ int red[GS_BLOCK / GS_WAVE];
+    int cnt = 0;
+    for (int i = blockIdx.x * GS_BLOCK + threadIdx.x; i < n; i += gridDim.x * GS_BLOCK) cnt += invalid[i] == 0 ? 1 : 0;
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) cnt += __shfl_xor(cnt, d, GS_WAVE);
+    if (gs_lane() == 0) red[threadIdx.x / GS_WAVE] = cnt;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int t = 0;
+        for (int i = 0; i < GS_BLOCK / GS_WAVE; ++i) t += red[i];
+        partial_counts[blockIdx.x] = t;
+    }
+}
+
+__global__ __launch_bounds__(GS_BLOCK) void adam_features_kernel(float *__restrict__ param, const float *__restrict__ grad,
+                                                                 float *__restrict__ exp_avg,
+                                                                 float *__restrict__ exp_avg_sq, long long n_rows,
+                                                                 AdamScalars k, const int8_t *__restrict__ invalid,
+                                                                 const int *__restrict__ partial_counts,
+                                                                 float reg_weight) {
+    __shared__ int red[GS_BLOCK / GS_WAVE];
+    int c = partial_counts[threadIdx.x];     // GS_BLOCK partial live counts -> n_live in every block
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) c += __shfl_xor(c, d, GS_WAVE);
+    if (gs_lane() == 0) red[threadIdx.x / GS_WAVE] = c;
+    __syncthreads();
+    int n_live = 0;
+    for (int i = 0; i < GS_BLOCK / GS_WAVE; ++i) n_live += red[i];
+    const float reg_scale = reg_weight / (float)n_live;
+    float4 *p4 = reinterpret_cast<float4 *>(param);
+    const float4 *g4 = reinterpret_cast<const float4 *>(grad);
+    float4 *m4 = reinterpret_cast<float4 *>(exp_avg), *v4 = reinterpret_cast<float4 *>(exp_avg_sq);
+    const long long n4 = n_rows * 14, stride = (long long)gridDim.x * GS_BLOCK;
+    for (long long i = (long long)blockIdx.x * GS_BLOCK + threadIdx.x; i < n4; i += stride) {
+        float4 p = p4[i], m = m4[i], v = v4[i];
+        float4 g = g4[i];
+        const long long row = i / 14;
+        if (i - row * 14 == 1 && invalid[row] == 0) {
+            const float a = expf(p.x), b = expf(p.y), cc = expf(p.z);
+            const float inv = reg_scale / sqrtf(a * a + b * b + cc * cc);
+            g.x = fmaf(a * a, inv, g.x);
+            g.y = fmaf(b * b, inv, g.y);
+            g.z = fmaf(cc * cc, inv, g.z);
+        }
+        adam_one(p.x, g.x, m.x, v.x, k);
+        adam_one(p.y, g.y, m.y, v.y, k);
+        adam_one(p.z, g.z, m.z, v.z, k);
+        adam_one(p.w, g.w, m.w, v.w, k);
+        p4[i] = p; m4[i] = m; v4[i] = v;
+    }
+}
+
+static AdamScalars adam_scalars(double lr, double beta1, double beta2, double eps, int step) {
+    // scalars are prepared in double like the Python implementation does (1 - 0.999 is 1e-3, not 1 - 0.999f)
+    AdamScalars k;
+    const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
+    k.lr_over_bc1 = (float)(lr / bc1);
+    k.inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
+    k.one_minus_beta1 = (float)(1.0 - beta1);
+    k.beta2 = (float)beta2;
+    k.one_minus_beta2 = (float)(1.0 - beta2);
+    k.eps = (float)eps;
+    return k;
+}
+
 }  // namespace
+
+extern "C" int gs_adam_step_features(float *features, const float *grad, float *exp_avg, float *exp_avg_sq,
+                                     long long n_rows, double lr, double beta1, double beta2, double eps, int step,
+                                     const int8_t *point_invalid_mask, double scale_regulariser_weight,
+                                     int32_t *workspace, void *stream) {
+    GS_REQUIRE(n_rows >= 0 && step >= 1, "gs_adam_step_features: n_rows >= 0 and step >= 1");
+    GS_REQUIRE(features && grad && exp_avg && exp_avg_sq && point_invalid_mask && workspace,
+               "gs_adam_step_features: null pointer");
+    GS_REQUIRE((((uintptr_t)features | (uintptr_t)grad | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15) == 0,
+               "gs_adam_step_features: buffers must be 16-byte aligned");
+    if (n_rows == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(count_live_rows_kernel, dim3(GS_BLOCK), dim3(GS_BLOCK), 0, s, point_invalid_mask, (int)n_rows,
+                       workspace);
+    GS_CHECK_LAUNCH();
+    long long want = (n_rows * 14 + GS_BLOCK - 1) / GS_BLOCK;
+    const int blocks = (int)(want < 1 ? 1 : (want > 256 * 16 ? 256 * 16 : want));
+    hipLaunchKernelGGL(adam_features_kernel, dim3(blocks), dim3(GS_BLOCK), 0, s, features, grad, exp_avg, exp_avg_sq,
+                       n_rows, adam_scalars(lr, beta1, beta2, eps, step), point_invalid_mask, workspace,
+                       (float)scale_regulariser_weight);
+    GS_CHECK_LAUNCH();
+    return 0;
+}
 
 extern "C" int gs_adam_step(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, long long n, double lr,
                             double beta1, double beta2, double eps, int step, void *stream) {
@@ -49,15 +143,7 @@ extern "C" int gs_adam_step(float *param, const float *grad, float *exp_avg, flo
     GS_REQUIRE((((uintptr_t)param | (uintptr_t)grad | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15) == 0,
                "gs_adam_step: buffers must be 16-byte aligned");
     if (n == 0) return 0;
-    AdamScalars k;
-    // scalars are prepared in double like the Python implementation does (1 - 0.999 is 1e-3, not 1 - 0.999f)
-    const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
-    k.lr_over_bc1 = (float)(lr / bc1);
-    k.inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
-    k.one_minus_beta1 = (float)(1.0 - beta1);
-    k.beta2 = (float)beta2;
-    k.one_minus_beta2 = (float)(1.0 - beta2);
-    k.eps = (float)eps;
+    const AdamScalars k = adam_scalars(lr, beta1, beta2, eps, step);
     long long want = (n / 4 + GS_BLOCK - 1) / GS_BLOCK;
     const int blocks = (int)(want < 1 ? 1 : (want > 256 * 16 ? 256 * 16 : want));
     hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(GS_BLOCK), 0, (hipStream_t)stream, param, grad, exp_avg,

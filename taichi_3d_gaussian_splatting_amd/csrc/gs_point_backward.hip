@@ -51,7 +51,7 @@ __global__ __launch_bounds__(GS_BLOCK) void point_backward_kernel(
     const float *__restrict__ t_pc, const int32_t *__restrict__ ids, int m, const float4 *__restrict__ acc,
     const float4 *__restrict__ attrs, const int32_t *__restrict__ ntiles_owned, Factors fac,
     float *__restrict__ grad_xyz, float *__restrict__ grad_feat, float *__restrict__ grad_xyz_vis,
-    float *__restrict__ grad_feat_vis) {
+    float *__restrict__ grad_feat_vis, float *__restrict__ hook_compact) {
     extern __shared__ __attribute__((aligned(16))) float4 s_rows[];  // [4 waves][64 rows][GS_ROW_F4]
     const int i = blockIdx.x * GS_BLOCK + threadIdx.x;
     const int id = i < m ? ids[i] : -1;
@@ -188,6 +188,16 @@ __global__ __launch_bounds__(GS_BLOCK) void point_backward_kernel(
 #pragma unroll
             for (int k = 0; k < 3; ++k) grad_xyz_vis[3 * (size_t)i + k] = gx[k];
         }
+        if (hook_compact) {   // the M-compact hook fields that are plain columns of acc / attrs (RAS:1130-1139), SoA planes
+            const float4 rec0 = attrs[4 * (size_t)i];   // u, v, depth, opacity
+            float *h = hook_compact;
+            const size_t M = (size_t)m;
+            h[2 * (size_t)i] = A0.x; h[2 * (size_t)i + 1] = A0.y;               // grad_viewspace      [M,2]
+            h[2 * M + i] = A2.y;                                                // magnitude           [M]
+            h[3 * M + i] = A2.z;                                                // num_affected_pixels [M] (int32 bits)
+            h[4 * M + i] = rec0.z;                                              // point_depth         [M]
+            h[5 * M + 2 * (size_t)i] = rec0.x; h[5 * M + 2 * (size_t)i + 1] = rec0.y;   // point_uv    [M,2]
+        }
     }
 }
 
@@ -213,7 +223,8 @@ extern "C" int gs_point_backward(const float *xyz, const float *features, const 
                                  int color_max_sh_band, float grad_q_factor, float grad_s_factor,
                                  float grad_alpha_factor, float grad_color_factor,
                                  float grad_high_order_color_factor, float *grad_xyz, float *grad_features,
-                                 float *grad_xyz_visible, float *grad_features_visible, void *stream) {
+                                 float *grad_xyz_visible, float *grad_features_visible, float *hook_compact,
+                                 void *stream) {
     GS_REQUIRE(n_visible >= 0 && n_points >= n_visible, "sizes");
     GS_REQUIRE(n_visible == 0 || attrs != nullptr, "gs_point_backward: attrs (the packed records of the forward pass) is required");
     hipStream_t s = (hipStream_t)stream;
@@ -234,7 +245,7 @@ extern "C" int gs_point_backward(const float *xyz, const float *features, const 
                        sizeof(float4) * GS_BLOCK * GS_ROW_F4, s, xyz,
                        features, object_id, intrinsics, q_cp, t_cp, t_pc, ids, n_visible,
                        reinterpret_cast<const float4 *>(acc), reinterpret_cast<const float4 *>(attrs), num_owned_tiles,
-                       fac, grad_xyz, grad_features, grad_xyz_visible, grad_features_visible);
+                       fac, grad_xyz, grad_features, grad_xyz_visible, grad_features_visible, hook_compact);
     GS_CHECK_LAUNCH();
     return 0;
 }

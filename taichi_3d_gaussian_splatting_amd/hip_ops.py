@@ -252,7 +252,7 @@ def blend_backward(tile_start, tile_end, payload, attrs, grad_image, acc_alpha, 
 def point_backward(xyz, features, object_id, intrinsics, q_cp, t_cp, t_pc, ids, acc, attrs, color_max_sh_band,
                    grad_q_factor, grad_s_factor, grad_alpha_factor, grad_color_factor,
                    grad_high_order_color_factor, want_visible: bool, visible_mask=None, num_owned_tiles=None,
-                   want_visible_features: Optional[bool] = None):
+                   want_visible_features: Optional[bool] = None, want_hook_fields: bool = False):
     """attrs: the packed records of ``preprocess`` (the colour chain reads sigmoid(SH.Y) from them);
     num_owned_tiles (optional): records with 0 owned tiles are incomplete, their colour is re-evaluated on demand."""
     dev = xyz.device
@@ -263,11 +263,17 @@ def point_backward(xyz, features, object_id, intrinsics, q_cp, t_cp, t_pc, ids, 
         want_visible_features = want_visible
     gx_vis = torch.empty((m, 3), dtype=torch.float32, device=dev) if want_visible else None
     gf_vis = torch.empty((m, FEATURE_DIM), dtype=torch.float32, device=dev) if want_visible_features else None
+    hook = torch.empty(7 * m, dtype=torch.float32, device=dev) if want_hook_fields else None
     call("gs_point_backward", ptr(xyz), ptr(features), ptr(object_id), ptr(intrinsics), ptr(q_cp), ptr(t_cp),
          ptr(t_pc), ptr(ids), ptr(visible_mask), m, n, ptr(acc), ptr(attrs), ptr(num_owned_tiles), int(color_max_sh_band),
          float(grad_q_factor), float(grad_s_factor),
          float(grad_alpha_factor), float(grad_color_factor), float(grad_high_order_color_factor), ptr(grad_xyz),
-         ptr(grad_feat), ptr(gx_vis), ptr(gf_vis), current_stream(dev))
+         ptr(grad_feat), ptr(gx_vis), ptr(gf_vis), ptr(hook), current_stream(dev))
+    if want_hook_fields:   # views of the planes: viewspace [M,2], magnitude [M], pixels i32[M], depth [M], uv [M,2]
+        fields = dict(grad_viewspace=hook[0:2 * m].view(m, 2), magnitude_grad_viewspace=hook[2 * m:3 * m],
+                      num_affected_pixels=hook[3 * m:4 * m].view(torch.int32), point_depth=hook[4 * m:5 * m],
+                      point_uv_in_camera=hook[5 * m:7 * m].view(m, 2))
+        return grad_xyz, grad_feat, gx_vis, gf_vis, fields
     return grad_xyz, grad_feat, gx_vis, gf_vis
 
 

@@ -17,6 +17,19 @@ class Adam(torch.optim.Optimizer):
         if lr < 0 or eps < 0 or not (0 <= betas[0] < 1 and 0 <= betas[1] < 1):
             raise ValueError("invalid Adam hyper-parameters")
         super().__init__(params, dict(lr=lr, betas=tuple(betas), eps=eps))
+        self._scale_regulariser = {}   # id(param) -> (weight, point_invalid_mask)
+
+    def set_scale_regulariser(self, features: torch.Tensor, weight: float, point_invalid_mask: torch.Tensor) -> None:
+        """Fuse the gradient of ``weight * mean_live ||exp(features[:, 4:7])||`` (the trainer's scale regulariser,
+        LOS:42-54) into the step of the [N,56] parameter ``features``: it is added to the incoming gradient inside the
+        Adam kernel (from the pre-step parameters), so neither autograd nor a separate pass has to produce it.
+        ``weight = 0`` switches it off."""
+        if features.dim() != 2 or features.shape[1] != 56:
+            raise ValueError("the scale regulariser applies to the [N,56] feature matrix")
+        if weight:
+            self._scale_regulariser[id(features)] = (float(weight), point_invalid_mask)
+        else:
+            self._scale_regulariser.pop(id(features), None)
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -38,6 +51,14 @@ class Adam(torch.optim.Optimizer):
                     state["exp_avg"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
                     state["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
                 state["step"] = int(state["step"]) + 1
+                reg = self._scale_regulariser.get(id(p))
+                if reg is not None:
+                    weight, mask = reg
+                    ws = torch.empty(256, dtype=torch.int32, device=p.device)
+                    call("gs_adam_step_features", ptr(p), ptr(grad), ptr(state["exp_avg"]), ptr(state["exp_avg_sq"]),
+                         p.shape[0], float(group["lr"]), float(beta1), float(beta2), float(group["eps"]), state["step"],
+                         ptr(mask), weight, ptr(ws), current_stream(p.device))
+                    continue
                 call("gs_adam_step", ptr(p), ptr(grad), ptr(state["exp_avg"]), ptr(state["exp_avg_sq"]), p.numel(),
                      float(group["lr"]), float(beta1), float(beta2), float(group["eps"]), state["step"],
                      current_stream(p.device))
