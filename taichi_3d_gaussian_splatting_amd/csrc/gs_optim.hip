@@ -78,12 +78,13 @@ __global__ __launch_bounds__(GS_BLOCK) void adam_features_kernel(float *__restri
     float4 *p4 = reinterpret_cast<float4 *>(param);
     const float4 *g4 = reinterpret_cast<const float4 *>(grad);
     float4 *m4 = reinterpret_cast<float4 *>(exp_avg), *v4 = reinterpret_cast<float4 *>(exp_avg_sq);
-    const long long n4 = n_rows * 14, stride = (long long)gridDim.x * GS_BLOCK;
-    for (long long i = (long long)blockIdx.x * GS_BLOCK + threadIdx.x; i < n4; i += stride) {
+    // 32-bit indices (the entry point checks 14 * n_rows < 2^31): a 64-bit division per float4 costs more than the update
+    const unsigned n4 = (unsigned)n_rows * 14u, stride = gridDim.x * GS_BLOCK;
+    for (unsigned i = blockIdx.x * GS_BLOCK + threadIdx.x; i < n4; i += stride) {
         float4 p = p4[i], m = m4[i], v = v4[i];
         float4 g = g4[i];
-        const long long row = i / 14;
-        if (i - row * 14 == 1 && invalid[row] == 0) {
+        const unsigned row = i / 14u;
+        if (i - row * 14u == 1u && invalid[row] == 0) {
             const float a = expf(p.x), b = expf(p.y), cc = expf(p.z);
             const float inv = reg_scale / sqrtf(a * a + b * b + cc * cc);
             g.x = fmaf(a * a, inv, g.x);
@@ -118,6 +119,7 @@ extern "C" int gs_adam_step_features(float *features, const float *grad, float *
                                      const int8_t *point_invalid_mask, double scale_regulariser_weight,
                                      int32_t *workspace, void *stream) {
     GS_REQUIRE(n_rows >= 0 && step >= 1, "gs_adam_step_features: n_rows >= 0 and step >= 1");
+    GS_REQUIRE(n_rows * 14 < 0x7fffffffLL, "gs_adam_step_features: more than 2^31 / 14 rows");
     GS_REQUIRE(features && grad && exp_avg && exp_avg_sq && point_invalid_mask && workspace,
                "gs_adam_step_features: null pointer");
     GS_REQUIRE((((uintptr_t)features | (uintptr_t)grad | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15) == 0,

@@ -24,6 +24,8 @@ ras = RAS(RAS.GaussianPointCloudRasterisationConfig(near_plane=s.near_plane, far
 loss_fn = LossFunction(LossFunction.LossFunctionConfig())
 opt_f = Adam([feat], lr=1e-3) if os.environ.get('GS_TORCH_ADAM') != '1' else torch.optim.Adam([feat], lr=1e-3, fused=True)
 opt_p = Adam([xyz], lr=1e-5) if os.environ.get('GS_TORCH_ADAM') != '1' else torch.optim.Adam([xyz], lr=1e-5, fused=True)
+if os.environ.get('GS_TORCH_ADAM') != '1':
+    opt_f.set_scale_regulariser(feat, loss_fn.config.regularization_weight, s.point_invalid_mask)
 cam = CameraInfo(camera_intrinsics=s.camera_intrinsics, camera_height=s.height, camera_width=s.width, camera_id=0)
 marks = {}
 
@@ -42,8 +44,7 @@ for it in range(iters + 3):
     t1 = ev()
     loss, l1, ds = loss_fn(image.permute(2, 0, 1), gt, clamp_prediction=True)
     t2 = ev()
-    loss.backward()
-    reg = loss_fn.add_regularization_gradient_(s.point_invalid_mask, feat)
+    loss.backward()   # the regulariser's gradient is applied inside the feature Adam kernel (as in the trainer)
     t3 = ev()
     opt_f.step(); opt_p.step()
     t4 = ev()
