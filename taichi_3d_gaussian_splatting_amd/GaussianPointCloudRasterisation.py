@@ -19,7 +19,7 @@ from typing import Callable, Optional
 
 import torch
 
-from . import hip_ops
+from . import _lib, hip_ops
 from .Camera import CameraInfo
 
 BOUNDARY_TILES = 3   # RAS:26
@@ -92,8 +92,20 @@ class GaussianPointCloudRasterisation(torch.nn.Module):
         class _module_function(torch.autograd.Function):
 
             @staticmethod
-            def forward(ctx, pointcloud, pointcloud_features, point_invalid_mask, point_object_id,
-                        q_pointcloud_camera, t_pointcloud_camera, camera_info, color_max_sh_band):
+            def forward(ctx, pointcloud, *rest):
+                if not pointcloud.is_cuda:
+                    raise RuntimeError("GaussianPointCloudRasterisation needs tensors on a HIP device (no CPU path)")
+                with _lib.stream_scope(pointcloud.device):   # one stream look-up for the ~25 launches below
+                    return _module_function._forward(ctx, pointcloud, *rest)
+
+            @staticmethod
+            def backward(ctx, *grads):
+                with _lib.stream_scope(ctx.saved_tensors[0].device):
+                    return _module_function._backward(ctx, *grads)
+
+            @staticmethod
+            def _forward(ctx, pointcloud, pointcloud_features, point_invalid_mask, point_object_id,
+                         q_pointcloud_camera, t_pointcloud_camera, camera_info, color_max_sh_band):
                 cfg = outer.config
                 width, height = camera_info.camera_width, camera_info.camera_height
                 row_begin, row_step = outer.tile_row_begin, outer.tile_row_step
@@ -157,7 +169,7 @@ class GaussianPointCloudRasterisation(torch.nn.Module):
                 return image, depth, count
 
             @staticmethod
-            def backward(ctx, grad_rasterized_image, grad_rasterized_depth, grad_pixel_valid_point_count):
+            def _backward(ctx, grad_rasterized_image, grad_rasterized_depth, grad_pixel_valid_point_count):
                 grad_pointcloud = grad_pointcloud_features = None
                 if grad_rasterized_image is None:  # only depth was used downstream: its gradient is ignored
                     grad_rasterized_image = torch.zeros(
