@@ -72,8 +72,17 @@ __device__ __forceinline__ int owned_rows(int t0v, int t1v, int begin, int step,
 __device__ __forceinline__ float cull_qmax(float opacity, float rescale) {
     return 2.0f * logf(255.0f * opacity * rescale) + 1e-2f;
 }
-__device__ __forceinline__ bool tile_may_contribute(float ux, float uy, float A, float B, float C, float qmax,
-                                                    int tu, int tv) {
+// The two ratios -B/C and -B/A (the slopes of the conic's conjugate diameters) are per-Gaussian constants: callers
+// compute them once with cull_slopes() instead of dividing per tile.
+struct CullSlopes { float nb_over_c, nb_over_a; };
+__device__ __forceinline__ CullSlopes cull_slopes(float A, float B, float C) {
+    CullSlopes s;
+    s.nb_over_c = -B / C;
+    s.nb_over_a = -B / A;
+    return s;
+}
+__device__ __forceinline__ bool tile_may_contribute(float ux, float uy, float A, float B, float C, CullSlopes sl,
+                                                    float qmax, int tu, int tv) {
     const float x0 = (float)(tu * GS_TILE_WIDTH) + 0.5f, x1 = x0 + (float)(GS_TILE_WIDTH - 1);
     const float y0 = (float)(tv * GS_TILE_HEIGHT) + 0.5f, y1 = y0 + (float)(GS_TILE_HEIGHT - 1);
     const float dxc = fminf(fmaxf(ux, x0), x1) - ux;  // x offset of the closest point, 0 if inside the span
@@ -82,11 +91,11 @@ __device__ __forceinline__ bool tile_may_contribute(float ux, float uy, float A,
     if (dxc != 0.f || dyc != 0.f) {
         qmin = 3.0e38f;
         if (dxc != 0.f) {  // edge x = const facing the centre: minimise over dy along the edge
-            const float dy = fminf(fmaxf(-B * dxc / C, y0 - uy), y1 - uy);
+            const float dy = fminf(fmaxf(sl.nb_over_c * dxc, y0 - uy), y1 - uy);
             qmin = A * dxc * dxc + 2.f * B * dxc * dy + C * dy * dy;
         }
         if (dyc != 0.f) {
-            const float dx = fminf(fmaxf(-B * dyc / A, x0 - ux), x1 - ux);
+            const float dx = fminf(fmaxf(sl.nb_over_a * dyc, x0 - ux), x1 - ux);
             qmin = fminf(qmin, A * dx * dx + 2.f * B * dx * dyc + C * dyc * dyc);
         }
     }
@@ -324,10 +333,11 @@ __global__ __launch_bounds__(GS_BLOCK) void preprocess_kernel(
         owned = (t1u - t0u) * owned_rows(t0v, t1v, row_begin, row_step, &first);
         if (cull && owned > 0) {
             const float qmax = cull_qmax(opacity, rescale);
+            const CullSlopes sl = cull_slopes(cA, cB, cC);
             owned = 0;
             for (int tu = t0u; tu < t1u; ++tu)
                 for (int tv = first; tv < t1v; tv += row_step)
-                    owned += tile_may_contribute(uv[0], uv[1], cA, cB, cC, qmax, tu, tv) ? 1 : 0;
+                    owned += tile_may_contribute(uv[0], uv[1], cA, cB, cC, sl, qmax, tu, tv) ? 1 : 0;
         }
 
         float4 *out = reinterpret_cast<float4 *>(attrs + (size_t)GS_ATTR_STRIDE * i);
@@ -401,6 +411,7 @@ __global__ __launch_bounds__(GS_BLOCK) void make_keys_kernel(
     const float4 a1 = reinterpret_cast<const float4 *>(attrs + (size_t)GS_ATTR_STRIDE * i)[1];
     const float radius = attrs[(size_t)GS_ATTR_STRIDE * i + 11];
     const float qmax = cull ? cull_qmax(a0.w, a1.w) : 0.f;
+    const CullSlopes sl = cull_slopes(a1.x, a1.y, a1.z);   // the same expression on the same stored conic as gs_preprocess
     const int tw = width / GS_TILE_WIDTH;
     int t0u, t1u, t0v, t1v, first;
     tile_box(a0.x, a0.y, radius, tw, height / GS_TILE_HEIGHT, t0u, t1u, t0v, t1v);
@@ -409,7 +420,7 @@ __global__ __launch_bounds__(GS_BLOCK) void make_keys_kernel(
     int k = offset;
     for (int tu = t0u; tu < t1u; ++tu)
         for (int tv = first; tv < t1v; tv += row_step) {
-            if (cull && !tile_may_contribute(a0.x, a0.y, a1.x, a1.y, a1.z, qmax, tu, tv)) continue;
+            if (cull && !tile_may_contribute(a0.x, a0.y, a1.x, a1.y, a1.z, sl, qmax, tu, tv)) continue;
             const int32_t tile = tu + tv * tw;
             if (sizeof(KeyT) == 8)
                 keys[k] = (KeyT)((int64_t)dq + ((int64_t)tile << 32));
