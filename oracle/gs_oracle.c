@@ -14,7 +14,7 @@
  * pass-by-value matrices, the two tile kernels run block by block on 256 OS
  * threads with real barriers).  tests/golden/make_reference_operator_vectors.py
  * runs the reference's whole operator -- seven kernels, torch glue, autograd
- * Function, backward hook -- on four tiny tie-free scenes and commits inputs
+ * Function, backward hook -- on five tiny tie-free scenes and commits inputs
  * and outputs; tests/test_reference_operator.py holds this oracle to them:
  * image L-inf 1.2e-7..1.8e-7, gradients 2e-7..1e-6 relative L2, visible ids,
  * tile counts, per-pixel counts and affected-pixel counts identical (fp32

@@ -31,6 +31,9 @@ SCENES = {
     "b_70pts_48x32_sh3_band1_invalid": (dict(n=70, height=48, width=32, s_min=0.03, s_max=0.2, sh_degree=3, seed=3,
                                               invalid_fraction=0.15), 1,
                                          dict(near_plane=0.4, far_plane=2000.0, depth_to_sort_key_scale=1000.0), None),
+    # sixteen tiles, default planes and depth scale (quantised depths 200..400: a tie-free seed had to be searched)
+    "e_70pts_64x64_default_config": (dict(n=70, height=64, width=64, s_min=0.03, s_max=0.15, sh_degree=3, seed=34,
+                                           invalid_fraction=0.05), 3, {}, None),
     # two objects with their own rotated poses (point_object_id selects the pose, RAS:56-59,272-275)
     "d_60pts_32x32_two_objects_rotated": (dict(n=60, height=32, width=32, s_min=0.05, s_max=0.25, sh_degree=3, seed=4), 3,
                                            dict(depth_to_sort_key_scale=1000000.0), "two_objects"),
