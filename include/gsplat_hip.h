@@ -19,7 +19,7 @@
  *  - fp32 everywhere, quaternions (x,y,z,w), row-major matrices, image memory [v,u,c].
  *
  * Packed per-visible-point record `attrs` (float[M][16], 64 B, 16-B aligned), produced by
- * gs_preprocess and gathered by the blend kernels (forward: rows 0,2,3; backward: rows 0,1,2):
+ * gs_preprocess and gathered by the blend kernels (forward: rows 0,2,3; backward: all four):
  *   [0] u  [1] v  [2] z (camera depth)  [3] opacity sigmoid(logit)
  *   [4] conic A  [5] conic B  [6] conic C  [7] rescale          (UTL:257-272)
  *   [8] r  [9] g  [10] b  [11] 3-sigma radius                   (RAS:302-315)
@@ -145,21 +145,34 @@ int gs_tile_ranges(const void *keys_sorted, int64_t n_keys, int key_depth_bits,
 
 /* Front-to-back alpha blending.  Replaces gaussian_point_rasterisation (RAS:318-485).
  * Tiles with tile row not in {begin + k*step} are skipped (their pixels are left untouched).
- * All five outputs are always written for owned tiles (also when n_keys == 0: zeros). */
+ * flags = 0: all five outputs are written for owned tiles (also when n_keys == 0: zeros).
+ * GS_BLEND_RGB_ONLY: the reference's rgb_only (RAS:464-469,478-484): depth and valid_count are neither computed nor
+ *   written (may be NULL).  GS_BLEND_NO_STATE: acc_alpha and last_effective -- the state only the backward pass
+ *   reads -- are neither tracked nor written (may be NULL): the inference path.  The two flags combine.
+ * debug_pixel_hits (may be NULL; tests): uint32[H][W][2] = per pixel {number of blended Gaussians, wrap-around sum
+ *   of (payload + 1) * 2654435761}; gs_blend_backward fills the same record for the pairs IT treats as blended. */
+#define GS_BLEND_RGB_ONLY 1
+#define GS_BLEND_NO_STATE 2
 int gs_blend_forward(const int32_t *tile_start, const int32_t *tile_end, const int32_t *payload,
                      const float *attrs, int width, int height, int tile_row_begin,
                      int tile_row_step, float *image, float *depth, float *acc_alpha,
-                     int32_t *last_effective, int32_t *valid_count, void *stream);
+                     int32_t *last_effective, int32_t *valid_count, int flags,
+                     uint32_t *debug_pixel_hits, void *stream);
 
 /* Backward per-pixel pass.  Replaces the pixel loop of gaussian_point_rasterisation_backward
  * (RAS:531-705) WITHOUT its global atomics (RAS:674-696): the partial sums of a (Gaussian, tile) pair
  * are stored as one 48-B record (layout of `acc`) in partials[slot] and slot_flags[slot] is raised
- * (slot: see gs_make_keys; n_slots = counters[GS_COUNTER_NUM_SLOTS]; slot_flags is zeroed by the library). */
+ * (slot: see gs_make_keys; n_slots = counters[GS_COUNTER_NUM_SLOTS]; slot_flags is zeroed by the library).
+ * alpha is evaluated by the same device function as in gs_blend_forward, so both passes take the same
+ * alpha >= 1/255 decision for every (pixel, Gaussian) pair.  flags: GS_BLEND_BACKWARD_V1 selects the round-1 kernel
+ * (A/B baseline).  debug_pixel_hits: see gs_blend_forward. */
+#define GS_BLEND_BACKWARD_V1 1
 int gs_blend_backward(const int32_t *tile_start, const int32_t *tile_end, const int32_t *payload,
                       const float *attrs, const float *grad_image, const float *acc_alpha,
                       const int32_t *last_effective, const int32_t *slot_offsets, int64_t n_slots,
                       int width, int height, int tile_row_begin, int tile_row_step, float *partials,
-                      uint8_t *slot_flags, float *magnitude_image, void *stream);
+                      uint8_t *slot_flags, float *magnitude_image, int flags,
+                      uint32_t *debug_pixel_hits, void *stream);
 
 /* Per-Gaussian sum of its flagged slots, in slot order (bitwise reproducible), into acc float[M][12].
  * Replaces the accumulation side of the reference's atomics (RAS:674-696). */

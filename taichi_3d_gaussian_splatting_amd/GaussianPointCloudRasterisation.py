@@ -35,6 +35,69 @@ def find_tile_start_and_end(point_in_camera_sort_key: torch.Tensor, tile_points_
     tile_points_end.copy_(end)
 
 
+@dataclass
+class GaussianPoint3DRow:
+    """What ``load_point_cloud_row_into_gaussian_point_3d`` returns when no Taichi struct is available: the seven
+    members of the reference's ``GaussianPoint3D`` (GP3:97-109), as tensors/arrays sliced out of the two inputs."""
+    translation: object  # xyz
+    cov_rotation: object  # quaternion x, y, z, w (feature columns 0-3)
+    cov_scale: object  # log-scale (columns 4-6)
+    alpha: object  # opacity logit (column 7)
+    color_r: object  # 16 SH coefficients (columns 8-23)
+    color_g: object  # columns 24-39
+    color_b: object  # columns 40-55
+
+
+def _build_row_loader():
+    """RAS:208-236.  The reference's controller imports this helper next to the operator (ADC:4) and calls it inside
+    its two Taichi kernels (ADC:10-42), so a drop-in module has to export it.  When Taichi and the host package's
+    ``GaussianPoint3D`` struct are importable (this module registered as ``taichi_3d_gaussian_splatting.
+    GaussianPointCloudRasterisation``) it is a ``ti.func`` producing that struct; otherwise
+    a plain function producing ``GaussianPoint3DRow``.  Column layout: RAS:214-226."""
+    columns = dict(cov_rotation=(0, 4), cov_scale=(4, 7), color_r=(8, 24), color_g=(24, 40), color_b=(40, 56))
+    try:
+        import importlib
+        import taichi as ti
+        host = "taichi_3d_gaussian_splatting"   # the package this module is injected into
+        point_struct = importlib.import_module(host + ".GaussianPoint3D").GaussianPoint3D
+        vec16f = importlib.import_module(host + ".SphericalHarmonics").vec16f
+    except Exception:  # no Taichi / no host package: the plain-Python form
+        def load_point_cloud_row_into_gaussian_point_3d(pointcloud, pointcloud_features, point_id):
+            row = pointcloud_features[point_id]
+            parts = {name: row[a:b] for name, (a, b) in columns.items()}
+            return GaussianPoint3DRow(translation=pointcloud[point_id], alpha=row[7], **parts)
+        return load_point_cloud_row_into_gaussian_point_3d
+
+    @ti.func
+    def load_point_cloud_row_into_gaussian_point_3d(
+            pointcloud: ti.types.ndarray(ti.f32, ndim=2),  # (N, 3)
+            pointcloud_features: ti.types.ndarray(ti.f32, ndim=2),  # (N, 56)
+            point_id: ti.i32):
+        return point_struct(
+            translation=ti.math.vec3([pointcloud[point_id, c] for c in ti.static(range(3))]),
+            cov_rotation=ti.math.vec4([pointcloud_features[point_id, c] for c in ti.static(range(0, 4))]),
+            cov_scale=ti.math.vec3([pointcloud_features[point_id, c] for c in ti.static(range(4, 7))]),
+            alpha=pointcloud_features[point_id, 7],
+            color_r=vec16f([pointcloud_features[point_id, c] for c in ti.static(range(8, 24))]),
+            color_g=vec16f([pointcloud_features[point_id, c] for c in ti.static(range(24, 40))]),
+            color_b=vec16f([pointcloud_features[point_id, c] for c in ti.static(range(40, 56))]))
+    return load_point_cloud_row_into_gaussian_point_3d
+
+
+def __getattr__(name):
+    # PEP 562: built on first use -- by then the importing package (the reference's controller, ADC:4) is known and its
+    # Taichi struct can be imported; building it at module import would import the host package half-initialised.
+    if name == "load_point_cloud_row_into_gaussian_point_3d":
+        fn = _build_row_loader()
+        globals()[name] = fn
+        return fn
+    raise AttributeError(f"module {__name__!r} has no attribute {name!r}")
+
+
+__all__ = ["BOUNDARY_TILES", "TILE_WIDTH", "TILE_HEIGHT", "CameraInfo", "GaussianPoint3DRow",
+           "GaussianPointCloudRasterisation", "find_tile_start_and_end", "load_point_cloud_row_into_gaussian_point_3d"]
+
+
 class GaussianPointCloudRasterisation(torch.nn.Module):
     @dataclass
     class GaussianPointCloudRasterisationConfig:
@@ -100,12 +163,14 @@ class GaussianPointCloudRasterisation(torch.nn.Module):
 
             @staticmethod
             def backward(ctx, *grads):
+                if not ctx.saved_tensors:   # forward ran without backward state (nothing differentiable was asked for)
+                    return (None,) * 9
                 with _lib.stream_scope(ctx.saved_tensors[0].device):
                     return _module_function._backward(ctx, *grads)
 
             @staticmethod
             def _forward(ctx, pointcloud, pointcloud_features, point_invalid_mask, point_object_id,
-                         q_pointcloud_camera, t_pointcloud_camera, camera_info, color_max_sh_band):
+                         q_pointcloud_camera, t_pointcloud_camera, camera_info, color_max_sh_band, need_state):
                 cfg = outer.config
                 width, height = camera_info.camera_width, camera_info.camera_height
                 row_begin, row_step = outer.tile_row_begin, outer.tile_row_step
@@ -151,11 +216,22 @@ class GaussianPointCloudRasterisation(torch.nn.Module):
                 # RAS:952-964  tile ranges
                 tile_start, tile_end = hip_ops.tile_ranges(keys, num_tiles, key_depth_bits)
                 del keys
-                # RAS:967-997  blend
+                # RAS:967-997  blend.  rgb_only (RAS:464-469,478-484): depth and count are not computed -- the reference
+                # returns uninitialised memory for them, this operator zeros.  The state the backward pass reads
+                # (acc_alpha, last_effective) is produced whenever a gradient can be asked for -- also with rgb_only,
+                # where the reference's backward would read garbage -- and skipped otherwise (inference).
+                rgb_only = bool(cfg.rgb_only)
                 image, depth, acc_alpha, last_eff, count = hip_ops.blend_forward(
-                    tile_start, tile_end, payload, attrs, width, height, row_begin, row_step)
+                    tile_start, tile_end, payload, attrs, width, height, row_begin, row_step,
+                    rgb_only=rgb_only, need_state=need_state)
+                if rgb_only:
+                    depth = torch.zeros((height, width), dtype=torch.float32, device=xyz.device)
+                    count = torch.zeros((height, width), dtype=torch.int32, device=xyz.device)
                 if outer.image_gather is not None:  # multi-GPU: all-gather the tile rows of the other ranks
-                    outer.image_gather([image, depth, count])
+                    outer.image_gather([image] if rgb_only else [image, depth, count])
+                if not need_state:   # nothing to save: no backward pass will run
+                    ctx.mark_non_differentiable(count)
+                    return image, depth, count
 
                 ctx.save_for_backward(xyz, pointcloud_features, payload, ids, tile_start, tile_end, acc_alpha,
                                       last_eff, num_overlap_tiles, obj, q_cp, t_cp, t_pc, attrs, intrinsics,
@@ -207,7 +283,7 @@ class GaussianPointCloudRasterisation(torch.nn.Module):
                             magnitude_grad_viewspace_on_image=magnitude_image,
                             num_overlap_tiles=num_overlap_tiles,
                             **out[4]))
-                return grad_pointcloud, grad_pointcloud_features, None, None, None, None, None, None
+                return grad_pointcloud, grad_pointcloud_features, None, None, None, None, None, None, None
 
         self._module_function = _module_function
         # multi-GPU hooks installed by distributed.shard_rasteriser_across_tile_rows (None on 1 GPU)
@@ -222,6 +298,10 @@ class GaussianPointCloudRasterisation(torch.nn.Module):
         camera_info = input_data.camera_info
         assert camera_info.camera_width % TILE_WIDTH == 0    # RAS:1193
         assert camera_info.camera_height % TILE_HEIGHT == 0  # RAS:1194
+        # will anything be back-propagated through this call?  (Function.forward itself always runs in no-grad mode, so
+        # the question is answered here.)  If not, the forward skips the state only the backward pass reads.
+        need_state = torch.is_grad_enabled() and (input_data.point_cloud.requires_grad or
+                                                  input_data.point_cloud_features.requires_grad)
         return self._module_function.apply(
             input_data.point_cloud,
             input_data.point_cloud_features,
@@ -231,4 +311,5 @@ class GaussianPointCloudRasterisation(torch.nn.Module):
             input_data.t_pointcloud_camera,
             camera_info,
             input_data.color_max_sh_band,
+            need_state,
         )

@@ -7,11 +7,13 @@
 //            on packed fp32 math; whole-tile early exit with a workgroup vote (the reference could not
 //            express it, RAS:387-394).
 //  backward: back-to-front traversal (RAS:531-705, gradients UTL:331-348) starting at the tile's last
-//            effective entry; 2 waves per tile, two pixels per lane; the 10 per-Gaussian partial sums are
-//            reduced across the 64 lanes by a permlane-swap + DPP reduce-scatter, combined across the two
-//            waves in LDS (ds_add_f32), and stored once per (tile, Gaussian) into that pair's private slot -- no
-//            global atomics at all (the reference issues eleven per (pixel, Gaussian), RAS:674-696); the slots of
-//            a Gaussian are summed in a fixed order by reduce_partials_kernel, so gradients are bitwise reproducible.
+//            effective entry; 2 waves per tile, two pixels per lane; alpha is evaluated by the SAME expression as in
+//            the forward kernel (gs_pair_alpha below), so the hit test alpha >= 1/255 decides identically in both
+//            passes; the per-Gaussian partial sums (ten gradients + the pixel count) are reduced across the 64 lanes
+//            by a permlane-swap + DPP reduce-scatter, combined across the two waves in LDS (ds_add_f32), and stored
+//            once per (tile, Gaussian) into that pair's private slot -- no global atomics at all (the reference issues
+//            eleven per (pixel, Gaussian), RAS:674-696); the slots of a Gaussian are summed in a fixed order by
+//            reduce_partials_kernel, so gradients are bitwise reproducible.
 #include "gs_common.h"
 
 // Automatic FMA contraction is off in this file and every fused multiply-add is written explicitly:
@@ -67,15 +69,34 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ v2f fma2(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
 __device__ __forceinline__ v2f splat(float x) { return (v2f){x, x}; }
 
+// The Gaussian weight of one list entry at the two pixels of a lane (UTL:275-284 in the log2 domain, from rows 0 and 3
+// of the packed record).  BOTH blend kernels call this and nothing else to evaluate alpha: with contraction off the
+// two inlined copies are the same instruction sequence, so the forward and the backward pass take identical
+// `alpha >= 1/255` decisions for every (pixel, Gaussian) pair (RAS:451 vs RAS:631).
+__device__ __forceinline__ v2f gs_pair_alpha(const float4 p, const float4 q, const v2f px, const float py,
+                                             v2f &dx, float &dy) {
+    dx = px - splat(p.x);
+    dy = py - p.y;
+    const v2f e = fma2(dx, fma2(dx, splat(q.x), splat(q.y * dy)), splat(q.z * dy * dy));
+    return (v2f){__builtin_amdgcn_exp2f(e.x), __builtin_amdgcn_exp2f(e.y)} * splat(q.w);
+}
+__device__ __forceinline__ unsigned long long gs_ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+
 constexpr int FWD_THREADS = 128;
 constexpr int FWD_BATCH = 128;
+constexpr unsigned GS_HASH_MUL = 2654435761u;
 
+// AUX:   depth and per-pixel count are produced (off with rgb_only, RAS:464-469,478-484)
+// STATE: acc_alpha / last_effective are produced (what the backward pass needs; off for inference)
+// DEBUG: per-pixel {number of blended Gaussians, wrap-around sum of (payload+1)*GS_HASH_MUL} -> debug_hits (tests)
+template <bool AUX, bool STATE, bool DEBUG>
 __global__ __launch_bounds__(FWD_THREADS) void blend_forward_kernel(
     const int32_t *__restrict__ tile_start, const int32_t *__restrict__ tile_end,
     const int32_t *__restrict__ payload, const float4 *__restrict__ attrs, int width, int height, int row_begin,
     int row_step, float *__restrict__ image, float *__restrict__ depth, float *__restrict__ acc_alpha,
-    int32_t *__restrict__ last_effective, int32_t *__restrict__ valid_count) {
+    int32_t *__restrict__ last_effective, int32_t *__restrict__ valid_count, uint32_t *__restrict__ debug_hits) {
     __shared__ float4 s_p[FWD_BATCH], s_c[FWD_BATCH], s_q[FWD_BATCH];  // rows 0, 2, 3 of the record
+    __shared__ int s_o[DEBUG ? FWD_BATCH : 1];
     const int tw = width / GS_TILE_WIDTH;
     const TileCoord tc = owned_tile(tw, row_begin, row_step);
     const int tid = threadIdx.x;
@@ -90,16 +111,19 @@ __global__ __launch_bounds__(FWD_THREADS) void blend_forward_kernel(
     v2f T = splat(1.0f), alive = splat(1.0f);
     v2f Cr = splat(0.f), Cg = splat(0.f), Cb = splat(0.f), D = splat(0.f), Wd = splat(0.f);
     int last0 = start, last1 = start, cnt0 = 0, cnt1 = 0;
+    unsigned dh0 = 0u, dh1 = 0u, dc0 = 0u, dc1 = 0u;
 
     for (int base = start; base < end; base += FWD_BATCH) {
         // barrier (protects the LDS batch) + whole-tile early exit vote
         if (__syncthreads_and((alive.x + alive.y == 0.f) ? 1 : 0)) break;
         const int j = base + tid;
         if (j < end) {
-            const float4 *g = attrs + 4 * (size_t)payload[j];
+            const int o = payload[j];
+            const float4 *g = attrs + 4 * (size_t)o;
             s_p[tid] = g[0];
             s_c[tid] = g[2];
             s_q[tid] = g[3];
+            if (DEBUG) s_o[tid] = o;
         } else {  // padding record: amplitude 0 -> alpha 0, never blended
             s_p[tid] = make_float4(0.f, 0.f, 0.f, 0.f);
             s_q[tid] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -109,30 +133,29 @@ __global__ __launch_bounds__(FWD_THREADS) void blend_forward_kernel(
         // Entries are evaluated in groups of GROUP: the LDS reads and the exp of a group are independent
         // and overlap (the per-pixel blend recurrence is the only serial part), which hides their latency.
         for (int k = 0; k < n; k += GROUP) {
-            if (__ballot(alive.x + alive.y != 0.f) == 0ull) break;  // every pixel of this wave is saturated
+            if (gs_ballot(alive.x + alive.y != 0.f) == 0ull) break;  // every pixel of this wave is saturated
             v2f alpha[GROUP];
             float z[GROUP];
 #pragma unroll
             for (int i = 0; i < GROUP; ++i) {
-                const float4 p = s_p[k + i], q = s_q[k + i];
-                const v2f dx = px - splat(p.x);
-                const float dy = py - p.y;
-                // UTL:275-284 in the log2 domain
-                const v2f e = fma2(dx, fma2(dx, splat(q.x), splat(q.y * dy)), splat(q.z * dy * dy));
-                alpha[i] = (v2f){__builtin_amdgcn_exp2f(e.x), __builtin_amdgcn_exp2f(e.y)} * splat(q.w);
+                v2f dx;
+                float dy;
+                const float4 p = s_p[k + i];
+                alpha[i] = gs_pair_alpha(p, s_q[k + i], px, py, dx, dy);
                 z[i] = p.z;
             }
 #pragma unroll
             for (int i = 0; i < GROUP; ++i) {
+                // a = alpha for a live pixel (x * 1.0f is exact), 0 for a saturated one
                 const v2f a = alpha[i] * alive;
                 bool ok0 = a.x >= EPS_ALPHA, ok1 = a.y >= EPS_ALPHA;  // RAS:451
-                if (__ballot(ok0 || ok1) == 0ull) continue;           // wave-uniform skip
+                if (gs_ballot(ok0 || ok1) == 0ull) continue;          // wave-uniform skip
                 // alpha = 0 for a skipped pixel makes the update below an exact no-op (T*(1-0) = T, C += c*0)
                 v2f al = {ok0 ? __builtin_amdgcn_fmed3f(a.x, 0.f, CLAMP_ALPHA) : 0.f,
                           ok1 ? __builtin_amdgcn_fmed3f(a.y, 0.f, CLAMP_ALPHA) : 0.f};
                 v2f Tn = T * (splat(1.f) - al);
                 const bool sat0 = ok0 && Tn.x < STOP_T, sat1 = ok1 && Tn.y < STOP_T;
-                if (__ballot(sat0 || sat1) != 0ull) {
+                if (gs_ballot(sat0 || sat1) != 0ull) {
                     // rare: RAS:458-460 -- the first Gaussian that would push T below 1e-4 saturates the
                     // pixel and is NOT blended
                     if (sat0) { al.x = 0.f; alive.x = 0.f; ok0 = false; }
@@ -144,28 +167,45 @@ __global__ __launch_bounds__(FWD_THREADS) void blend_forward_kernel(
                 Cr = fma2(splat(c.x), wgt, Cr);
                 Cg = fma2(splat(c.y), wgt, Cg);
                 Cb = fma2(splat(c.z), wgt, Cb);
-                D = fma2(splat(z[i]), wgt, D);
-                Wd = Wd + wgt;
+                if (AUX) {
+                    D = fma2(splat(z[i]), wgt, D);
+                    Wd = Wd + wgt;
+                    cnt0 += ok0 ? 1 : 0;
+                    cnt1 += ok1 ? 1 : 0;
+                }
                 T = Tn;
-                const int idx = base + k + i + 1;
-                last0 = ok0 ? idx : last0;
-                last1 = ok1 ? idx : last1;
-                cnt0 += ok0 ? 1 : 0;
-                cnt1 += ok1 ? 1 : 0;
+                if (STATE) {
+                    const int idx = base + k + i + 1;
+                    last0 = ok0 ? idx : last0;
+                    last1 = ok1 ? idx : last1;
+                }
+                if (DEBUG) {
+                    const unsigned hv = (unsigned)(s_o[k + i] + 1) * GS_HASH_MUL;
+                    dc0 += ok0 ? 1u : 0u; dh0 += ok0 ? hv : 0u;
+                    dc1 += ok1 ? 1u : 0u; dh1 += ok1 ? hv : 0u;
+                }
             }
         }
     }
     const size_t p = (size_t)pv * width + pu;
     float *img = image + 3 * p;
     img[0] = Cr.x; img[1] = Cg.x; img[2] = Cb.x; img[3] = Cr.y; img[4] = Cg.y; img[5] = Cb.y;
-    depth[p] = D.x / fmaxf(Wd.x, 1e-6f);  // RAS:479-480
-    depth[p + 1] = D.y / fmaxf(Wd.y, 1e-6f);
-    acc_alpha[p] = 1.f - T.x;
-    acc_alpha[p + 1] = 1.f - T.y;
-    last_effective[p] = last0;
-    last_effective[p + 1] = last1;
-    valid_count[p] = cnt0;
-    valid_count[p + 1] = cnt1;
+    if (AUX) {
+        depth[p] = D.x / fmaxf(Wd.x, 1e-6f);  // RAS:479-480
+        depth[p + 1] = D.y / fmaxf(Wd.y, 1e-6f);
+        valid_count[p] = cnt0;
+        valid_count[p + 1] = cnt1;
+    }
+    if (STATE) {
+        acc_alpha[p] = 1.f - T.x;
+        acc_alpha[p + 1] = 1.f - T.y;
+        last_effective[p] = last0;
+        last_effective[p + 1] = last1;
+    }
+    if (DEBUG) {
+        debug_hits[2 * p] = dc0; debug_hits[2 * p + 1] = dh0;
+        debug_hits[2 * p + 2] = dc1; debug_hits[2 * p + 3] = dh1;
+    }
 }
 
 // ------------------------------------------------------------------------------- backward
@@ -177,7 +217,9 @@ __global__ __launch_bounds__(FWD_THREADS) void blend_forward_kernel(
 constexpr int BWD_THREADS = 128;
 constexpr int BWD_BATCH = 128;
 
-__global__ __launch_bounds__(BWD_THREADS) void blend_backward_kernel(
+// ---- v1 (round 1): alpha from rows 0/1 by exp2(-0.5 d.m log2e) * rescale * opacity; ten values reduced, the pixel
+// count through an integer LDS atomic.  Kept selectable (GS_BLEND_BACKWARD_V1) as the A/B baseline of v2 below.
+__global__ __launch_bounds__(BWD_THREADS) void blend_backward_kernel_v1(
     const int32_t *__restrict__ tile_start, const int32_t *__restrict__ tile_end,
     const int32_t *__restrict__ payload, const float4 *__restrict__ attrs, const float *__restrict__ grad_image,
     const float *__restrict__ acc_alpha, const int32_t *__restrict__ last_effective, int width, int height,
@@ -332,6 +374,167 @@ __global__ __launch_bounds__(BWD_THREADS) void blend_backward_kernel(
     magnitude_image[2 * p + 3] = mag_v.y;
 }
 
+// ---- v2: alpha by gs_pair_alpha (the forward's expression: identical hit decisions), conic products only on the hit
+// path, w = dL/dalpha * alpha_unclamped (= dL/dg * g, UTL:343), twelve-value reduce-scatter that carries the pixel
+// count as a float (exact below 2^24) so that all three result registers take the same LDS path.
+template <bool DEBUG>
+__global__ __launch_bounds__(BWD_THREADS) void blend_backward_kernel(
+    const int32_t *__restrict__ tile_start, const int32_t *__restrict__ tile_end,
+    const int32_t *__restrict__ payload, const float4 *__restrict__ attrs, const float *__restrict__ grad_image,
+    const float *__restrict__ acc_alpha, const int32_t *__restrict__ last_effective, int width, int height,
+    int row_begin, int row_step, const int32_t *__restrict__ slot_offsets, float4 *__restrict__ partials,
+    uint8_t *__restrict__ slot_flags, float *__restrict__ magnitude_image, uint32_t *__restrict__ debug_hits) {
+    __shared__ float4 s_p[BWD_BATCH], s_b[BWD_BATCH], s_c[BWD_BATCH], s_q[BWD_BATCH];  // rows 0..3 of the record
+    __shared__ int s_o[BWD_BATCH];
+    __shared__ float s_acc[BWD_BATCH][GS_ACC_STRIDE];  // [entry][value]; value 10 = pixel count (as a float)
+    __shared__ int s_max[BWD_THREADS / GS_WAVE];
+    const int tw = width / GS_TILE_WIDTH;
+    const TileCoord tc = owned_tile(tw, row_begin, row_step);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int pu = tc.tile_u * GS_TILE_WIDTH + 2 * (tid & 7);  // left pixel of the pair
+    const int pv = tc.tile_v * GS_TILE_HEIGHT + (tid >> 3);
+    const size_t p = (size_t)pv * width + pu;
+    const int start = tile_start[tc.tile_id];
+    const v2f px = {(float)pu + 0.5f, (float)pu + 1.5f};
+    const float py = (float)pv + 0.5f;
+
+    const int last0 = last_effective[p], last1 = last_effective[p + 1];
+    v2f T = {1.0f - acc_alpha[p], 1.0f - acc_alpha[p + 1]};
+    // S = sum_{j behind i} (c_j . G) a_j T_j: the reference keeps the colour-space suffix sum w_i (RAS:652-656)
+    // and dots it with dL/dimage; only that dot product is ever used, so the scalar is carried instead
+    // (same quantity re-associated: 6 instead of 12 flops per hit).
+    v2f S = splat(0.f);
+    const float *gi = grad_image + 3 * p;
+    const v2f Gr = {gi[0], gi[3]}, Gg = {gi[1], gi[4]}, Gb = {gi[2], gi[5]};
+    v2f mag_u = splat(0.f), mag_v = splat(0.f);
+    unsigned dh0 = 0u, dh1 = 0u, dc0 = 0u, dc1 = 0u;
+
+    // no pixel of the tile touches an entry at or beyond the tile-wide max of `last`
+    int mx = max(last0, last1);
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) mx = max(mx, __shfl_xor(mx, d, GS_WAVE));
+    const int wave_end = mx;  // no pixel of THIS wave touches an entry at or beyond wave_end
+    if (lane == 0) s_max[tid >> 6] = mx;
+    __syncthreads();
+    const int end = max(s_max[0], s_max[1]);
+    // LDS destination of this lane's reduce-scatter results (lane 15 of row r holds the totals of three values)
+    const int row = lane >> 4;
+    const int slot = ((row & 1) << 1) | (row >> 1);  // rows (0,1,2,3) -> values (0,2,1,3) of each result register
+    const bool row_tail = (lane & 15) == 15;
+
+    for (int top = end; top > start; top -= BWD_BATCH) {
+        __syncthreads();  // previous batch fully flushed before its LDS is reused
+        const int j = top - 1 - tid;
+        if (j >= start) {
+            const int o = payload[j];
+            const float4 *g = attrs + 4 * (size_t)o;
+            s_p[tid] = g[0];
+            s_b[tid] = g[1];
+            s_c[tid] = g[2];
+            s_q[tid] = g[3];
+            s_o[tid] = o;
+        } else {  // padding record: amplitude 0 -> alpha 0, never a hit
+            s_p[tid] = make_float4(0.f, 0.f, 0.f, 0.f);
+            s_q[tid] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        {
+            float4 *z = reinterpret_cast<float4 *>(&s_acc[tid][0]);
+            z[0] = make_float4(0.f, 0.f, 0.f, 0.f);
+            z[1] = make_float4(0.f, 0.f, 0.f, 0.f);
+            z[2] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        __syncthreads();
+        const int n = min(BWD_BATCH, top - start);
+        for (int k = 0; k < n; k += GROUP) {
+            if (top - 1 - (k + GROUP - 1) >= wave_end) continue;  // the whole group lies behind this wave's pixels
+            // group evaluation: LDS reads + exp of GROUP entries are independent and overlap
+            v2f alpha[GROUP], dx[GROUP];
+            float dy[GROUP];
+#pragma unroll
+            for (int i = 0; i < GROUP; ++i) alpha[i] = gs_pair_alpha(s_p[k + i], s_q[k + i], px, py, dx[i], dy[i]);
+#pragma unroll
+            for (int i = 0; i < GROUP; ++i) {
+                const bool a0 = alpha[i].x >= EPS_ALPHA, a1 = alpha[i].y >= EPS_ALPHA;  // RAS:631, as RAS:451
+                if (gs_ballot(a0 || a1) == 0ull) continue;  // wave-uniform skip: no pixel of this wave is touched
+                const int jj = top - 1 - (k + i);
+                const bool hit0 = a0 && (jj < last0), hit1 = a1 && (jj < last1);  // RAS:618 (effective range)
+                if (gs_ballot(hit0 || hit1) == 0ull) continue;
+                // alpha = 0 for a pixel that is not hit makes its whole update an exact no-op
+                // (1/(1-0) = 1, a*T = 0); only dL/dalpha needs an explicit mask.
+                const v2f h = {hit0 ? 1.f : 0.f, hit1 ? 1.f : 0.f};
+                const v2f al = {hit0 ? __builtin_amdgcn_fmed3f(alpha[i].x, 0.f, CLAMP_ALPHA) : 0.f,
+                                hit1 ? __builtin_amdgcn_fmed3f(alpha[i].y, 0.f, CLAMP_ALPHA) : 0.f};
+                const v2f one_m = splat(1.f) - al;
+                const v2f inv1m = {__builtin_amdgcn_rcpf(one_m.x), __builtin_amdgcn_rcpf(one_m.y)};
+                T = T * inv1m;  // RAS:643, T_i = T_{i+1} / (1 - alpha_i)
+                const v2f aT = al * T;
+                const float4 c = s_c[k + i], b = s_b[k + i];
+                const v2f gr = aT * Gr, gg = aT * Gg, gb = aT * Gb;
+                // dL/dalpha = sum_c (c_c T - w_c/(1-alpha)) G_c = T (c.G) - S/(1-alpha)       (RAS:652-657)
+                const v2f cg = fma2(splat(c.z), Gb, fma2(splat(c.y), Gg, splat(c.x) * Gr));
+                const v2f dLda = fma2(T, cg, -(S * inv1m)) * h;
+                S = fma2(cg, aT, S);
+                // w = dL/dg * g = dL/dalpha * opacity * g = dL/dalpha * alpha (unclamped).  dL/dlogit = (1-o) w and the
+                // factor 1/2 of dg/dcov are per-Gaussian constants: applied once per (tile, Gaussian) in the flush.
+                const v2f w = dLda * alpha[i];
+                // UTL:331-348: m = conic @ d
+                const v2f m0 = fma2(dx[i], splat(b.x), splat(b.y * dy[i]));
+                const v2f m1 = fma2(dx[i], splat(b.y), splat(b.z * dy[i]));
+                const v2f v0 = w * m0, v1 = w * m1;  // dL/dmu = dL/dg * g * (conic @ d)   (UTL:343)
+                mag_u = mag_u + (v2f){fabsf(v0.x), fabsf(v0.y)};
+                mag_v = mag_v + (v2f){fabsf(v1.x), fabsf(v1.y)};
+                const v2f c00 = v0 * m0, c01 = v0 * m1, c11 = v1 * m1;  // 2 dL/dcov (UTL:345-346)
+                const v2f n2 = fma2(v1, v1, v0 * v0);
+                const v2f nv = {__builtin_amdgcn_sqrtf(n2.x), __builtin_amdgcn_sqrtf(n2.y)};  // v_sqrt_f32, 1 ulp
+                if (DEBUG) {
+                    const unsigned hv = (unsigned)(s_o[k + i] + 1) * GS_HASH_MUL;
+                    dc0 += hit0 ? 1u : 0u; dh0 += hit0 ? hv : 0u;
+                    dc1 += hit1 ? 1u : 0u; dh1 += hit1 ? hv : 0u;
+                }
+                // in-lane pair sums, then the 12-value reduce-scatter over the 64 lanes (gs_common.h); row totals
+                // land in lane 15 of each row: t0 (v0, c00, v1, c01)  t1 (c11, gg, gr, gb)  t2 (w, count, |v|, 0)
+                float t0, t1, t2;
+                gs_wave_reduce12(v0.x + v0.y, v1.x + v1.y, c00.x + c00.y, c01.x + c01.y, c11.x + c11.y, gr.x + gr.y,
+                                 gg.x + gg.y, gb.x + gb.y, w.x + w.y, nv.x + nv.y, h.x + h.y, 0.f, t0, t1, t2);
+                if (row_tail) {
+                    float *A = &s_acc[k + i][slot];
+                    atomicAdd(A, t0);
+                    atomicAdd(A + 4, t1);
+                    atomicAdd(A + 8, t2);
+                }
+            }
+        }
+        __syncthreads();
+        // flush: thread k owns entry k of the batch -> one 48-B store into the (Gaussian, tile) slot
+        if (tid < n) {
+            const float4 *Sa = reinterpret_cast<const float4 *>(&s_acc[tid][0]);
+            float4 r0 = Sa[0], r1 = Sa[1], r2 = Sa[2];
+            if (r2.z > 0.f) {
+                const float4 a = s_p[tid];
+                int t0u, t1u, t0v, t1v;
+                gs_tile_box(a.x, a.y, s_c[tid].w, tw, height / GS_TILE_HEIGHT, t0u, t1u, t0v, t1v);
+                const int dst_slot = slot_offsets[s_o[tid]] + (t1v - t0v) * (tc.tile_u - t0u) + (tc.tile_v - t0v);
+                float4 *dst = partials + 3 * (size_t)dst_slot;
+                r0.z *= 0.5f; r0.w *= 0.5f; r1.x *= 0.5f;  // dg/dcov = 0.5 g (m m^T)
+                r2.x *= (1.f - a.w);                       // dL/dlogit = (1 - opacity) * sum(w)
+                r2.z = __builtin_bit_cast(float, (int)r2.z);  // pixel count: float sum -> int32 bits (layout of `acc`)
+                dst[0] = r0;
+                dst[1] = r1;
+                dst[2] = r2;
+                slot_flags[dst_slot] = 1;
+            }
+        }
+    }
+    magnitude_image[2 * p] = mag_u.x;
+    magnitude_image[2 * p + 1] = mag_v.x;
+    magnitude_image[2 * p + 2] = mag_u.y;
+    magnitude_image[2 * p + 3] = mag_v.y;
+    if (DEBUG) {
+        debug_hits[2 * p] = dc0; debug_hits[2 * p + 1] = dh0;
+        debug_hits[2 * p + 2] = dc1; debug_hits[2 * p + 3] = dh1;
+    }
+}
+
 // Sums the flagged (Gaussian, tile) slots of every visible Gaussian, in slot order (deterministic), into the
 // accumulator record acc[i] that gs_point_backward consumes.  Slot 10 (pixel count) is summed as an integer.
 __global__ __launch_bounds__(GS_BLOCK) void reduce_partials_kernel(
@@ -365,6 +568,21 @@ __global__ __launch_bounds__(GS_BLOCK) void reduce_partials_kernel(
     acc[3 * (size_t)i + 2] = make_float4(gl, nv, __builtin_bit_cast(float, npix), 0.f);
 }
 
+template <bool AUX, bool STATE>
+static void launch_forward(bool debug, dim3 grid, hipStream_t s, const int32_t *tile_start, const int32_t *tile_end,
+                           const int32_t *payload, const float4 *attrs, int width, int height, int rb, int rs,
+                           float *image, float *depth, float *acc_alpha, int32_t *last_effective,
+                           int32_t *valid_count, uint32_t *debug_hits) {
+    if (debug)
+        hipLaunchKernelGGL((blend_forward_kernel<AUX, STATE, true>), grid, dim3(FWD_THREADS), 0, s, tile_start, tile_end,
+                           payload, attrs, width, height, rb, rs, image, depth, acc_alpha, last_effective, valid_count,
+                           debug_hits);
+    else
+        hipLaunchKernelGGL((blend_forward_kernel<AUX, STATE, false>), grid, dim3(FWD_THREADS), 0, s, tile_start, tile_end,
+                           payload, attrs, width, height, rb, rs, image, depth, acc_alpha, last_effective, valid_count,
+                           debug_hits);
+}
+
 }  // namespace
 
 extern "C" {
@@ -373,14 +591,29 @@ static int owned_row_count(int th, int begin, int step) { return begin < th ? (t
 
 int gs_blend_forward(const int32_t *tile_start, const int32_t *tile_end, const int32_t *payload, const float *attrs,
                      int width, int height, int tile_row_begin, int tile_row_step, float *image, float *depth,
-                     float *acc_alpha, int32_t *last_effective, int32_t *valid_count, void *stream) {
+                     float *acc_alpha, int32_t *last_effective, int32_t *valid_count, int flags,
+                     uint32_t *debug_pixel_hits, void *stream) {
     GS_REQUIRE(width % GS_TILE_WIDTH == 0 && height % GS_TILE_HEIGHT == 0, "image size must be a multiple of 16");
     GS_REQUIRE(tile_row_step >= 1 && tile_row_begin >= 0, "tile row ownership");
+    const bool aux = !(flags & GS_BLEND_RGB_ONLY), state = !(flags & GS_BLEND_NO_STATE);
+    GS_REQUIRE(image != nullptr, "image");
+    GS_REQUIRE(!aux || (depth != nullptr && valid_count != nullptr), "depth / valid_count (or pass GS_BLEND_RGB_ONLY)");
+    GS_REQUIRE(!state || (acc_alpha != nullptr && last_effective != nullptr),
+               "acc_alpha / last_effective (or pass GS_BLEND_NO_STATE)");
     const int tw = width / GS_TILE_WIDTH, rows = owned_row_count(height / GS_TILE_HEIGHT, tile_row_begin, tile_row_step);
     if (rows == 0 || tw == 0) return 0;
-    hipLaunchKernelGGL(blend_forward_kernel, dim3(tw * rows), dim3(FWD_THREADS), 0, (hipStream_t)stream, tile_start,
-                       tile_end, payload, reinterpret_cast<const float4 *>(attrs), width, height, tile_row_begin,
-                       tile_row_step, image, depth, acc_alpha, last_effective, valid_count);
+    const dim3 grid(tw * rows);
+    const float4 *a4 = reinterpret_cast<const float4 *>(attrs);
+    hipStream_t s = (hipStream_t)stream;
+    const bool dbg = debug_pixel_hits != nullptr;
+#define GS_FWD(AUX, STATE)                                                                                          \
+    launch_forward<AUX, STATE>(dbg, grid, s, tile_start, tile_end, payload, a4, width, height, tile_row_begin,      \
+                               tile_row_step, image, depth, acc_alpha, last_effective, valid_count, debug_pixel_hits)
+    if (aux && state) GS_FWD(true, true);
+    else if (aux) GS_FWD(true, false);
+    else if (state) GS_FWD(false, true);
+    else GS_FWD(false, false);
+#undef GS_FWD
     GS_CHECK_LAUNCH();
     return 0;
 }
@@ -388,19 +621,31 @@ int gs_blend_forward(const int32_t *tile_start, const int32_t *tile_end, const i
 int gs_blend_backward(const int32_t *tile_start, const int32_t *tile_end, const int32_t *payload, const float *attrs,
                       const float *grad_image, const float *acc_alpha, const int32_t *last_effective,
                       const int32_t *slot_offsets, int64_t n_slots, int width, int height, int tile_row_begin,
-                      int tile_row_step, float *partials, uint8_t *slot_flags, float *magnitude_image,
-                      void *stream) {
+                      int tile_row_step, float *partials, uint8_t *slot_flags, float *magnitude_image, int flags,
+                      uint32_t *debug_pixel_hits, void *stream) {
     GS_REQUIRE(width % GS_TILE_WIDTH == 0 && height % GS_TILE_HEIGHT == 0, "image size must be a multiple of 16");
     GS_REQUIRE(tile_row_step >= 1 && tile_row_begin >= 0, "tile row ownership");
     GS_REQUIRE(n_slots >= 0, "n_slots");
+    GS_REQUIRE(!(flags & GS_BLEND_BACKWARD_V1) || debug_pixel_hits == nullptr, "debug counters need the v2 kernel");
     hipStream_t s = (hipStream_t)stream;
     if (n_slots > 0) GS_CHECK_HIP(hipMemsetAsync(slot_flags, 0, (size_t)n_slots, s));
     const int tw = width / GS_TILE_WIDTH, rows = owned_row_count(height / GS_TILE_HEIGHT, tile_row_begin, tile_row_step);
     if (rows == 0 || tw == 0) return 0;
-    hipLaunchKernelGGL(blend_backward_kernel, dim3(tw * rows), dim3(BWD_THREADS), 0, s, tile_start, tile_end, payload,
-                       reinterpret_cast<const float4 *>(attrs), grad_image, acc_alpha, last_effective, width, height,
-                       tile_row_begin, tile_row_step, slot_offsets, reinterpret_cast<float4 *>(partials), slot_flags,
-                       magnitude_image);
+    const dim3 grid(tw * rows), block(BWD_THREADS);
+    const float4 *a4 = reinterpret_cast<const float4 *>(attrs);
+    float4 *p4 = reinterpret_cast<float4 *>(partials);
+    if (flags & GS_BLEND_BACKWARD_V1)
+        hipLaunchKernelGGL(blend_backward_kernel_v1, grid, block, 0, s, tile_start, tile_end, payload, a4, grad_image,
+                           acc_alpha, last_effective, width, height, tile_row_begin, tile_row_step, slot_offsets, p4,
+                           slot_flags, magnitude_image);
+    else if (debug_pixel_hits != nullptr)
+        hipLaunchKernelGGL(blend_backward_kernel<true>, grid, block, 0, s, tile_start, tile_end, payload, a4, grad_image,
+                           acc_alpha, last_effective, width, height, tile_row_begin, tile_row_step, slot_offsets, p4,
+                           slot_flags, magnitude_image, debug_pixel_hits);
+    else
+        hipLaunchKernelGGL(blend_backward_kernel<false>, grid, block, 0, s, tile_start, tile_end, payload, a4, grad_image,
+                           acc_alpha, last_effective, width, height, tile_row_begin, tile_row_step, slot_offsets, p4,
+                           slot_flags, magnitude_image, debug_pixel_hits);
     GS_CHECK_LAUNCH();
     return 0;
 }

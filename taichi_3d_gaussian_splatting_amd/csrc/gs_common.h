@@ -256,6 +256,47 @@ __device__ __forceinline__ void gs_wave_reduce10(float x0, float x1, float x2, f
           "=&v"(x10));
     t0 = x0; t1 = x4; t2 = x8;
 }
+// Twelve-value variant (same scheme, no odd register to duplicate: 12 -> 6 -> 3, then four DPP row steps each):
+//   t0: rows 0..3 = (x0, x2, x1, x3)   t1: rows = (x4, x6, x5, x7)   t2: rows = (x8, x10, x9, x11)
+__device__ __forceinline__ void gs_wave_reduce12(float x0, float x1, float x2, float x3, float x4, float x5,
+                                                 float x6, float x7, float x8, float x9, float x10, float x11,
+                                                 float &t0, float &t1, float &t2) {
+    asm("s_nop 1\n\t"
+        "v_permlane32_swap_b32 %0, %1\n\t"
+        "v_permlane32_swap_b32 %2, %3\n\t"
+        "v_permlane32_swap_b32 %4, %5\n\t"
+        "v_permlane32_swap_b32 %6, %7\n\t"
+        "v_permlane32_swap_b32 %8, %9\n\t"
+        "v_permlane32_swap_b32 %10, %11\n\t"
+        "v_add_f32 %0, %0, %1\n\t"
+        "v_add_f32 %2, %2, %3\n\t"
+        "v_add_f32 %4, %4, %5\n\t"
+        "v_add_f32 %6, %6, %7\n\t"
+        "v_add_f32 %8, %8, %9\n\t"
+        "v_add_f32 %10, %10, %11\n\t"
+        "v_permlane16_swap_b32 %0, %2\n\t"
+        "v_permlane16_swap_b32 %4, %6\n\t"
+        "v_permlane16_swap_b32 %8, %10\n\t"
+        "v_add_f32 %0, %0, %2\n\t"
+        "v_add_f32 %4, %4, %6\n\t"
+        "v_add_f32 %8, %8, %10\n\t"
+        "v_add_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %4, %4, %4 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %8, %8, %8 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %4, %4, %4 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %8, %8, %8 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xe\n\t"
+        "v_add_f32_dpp %4, %4, %4 row_shr:4 row_mask:0xf bank_mask:0xe\n\t"
+        "v_add_f32_dpp %8, %8, %8 row_shr:4 row_mask:0xf bank_mask:0xe\n\t"
+        "v_add_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xc\n\t"
+        "v_add_f32_dpp %4, %4, %4 row_shr:8 row_mask:0xf bank_mask:0xc\n\t"
+        "v_add_f32_dpp %8, %8, %8 row_shr:8 row_mask:0xf bank_mask:0xc\n\t"
+        "s_nop 1"
+        : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7), "+v"(x8), "+v"(x9),
+          "+v"(x10), "+v"(x11));
+    t0 = x0; t1 = x4; t2 = x8;
+}
 __device__ __forceinline__ float gs_readlane63(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }

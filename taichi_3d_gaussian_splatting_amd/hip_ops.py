@@ -198,37 +198,50 @@ def tile_ranges(keys_sorted: torch.Tensor, num_tiles: int, key_depth_bits: int =
     return start, end
 
 
+BLEND_RGB_ONLY = 1      # include/gsplat_hip.h GS_BLEND_RGB_ONLY: no depth / per-pixel count (RAS:464-469,478-484)
+BLEND_NO_STATE = 2      # GS_BLEND_NO_STATE: no acc_alpha / last_effective (nothing will be back-propagated)
+BLEND_BACKWARD_V1 = 1   # GS_BLEND_BACKWARD_V1: the round-1 backward kernel (A/B baseline)
+
+
 def blend_forward(tile_start, tile_end, payload, attrs, width, height, tile_row_begin=0, tile_row_step=1,
-                  out=None):
+                  out=None, rgb_only=False, need_state=True, debug_hits=False):
+    """-> (image, depth, acc_alpha, last_effective, count).  rgb_only: depth and count are not computed (returned
+    as None); need_state=False: acc_alpha / last_effective are not computed (None) -- the inference path.
+    debug_hits=True appends a uint32-as-int32 [H,W,2] tensor {blended count, hash of blended payloads} per pixel."""
     dev = tile_start.device
+    flags = (BLEND_RGB_ONLY if rgb_only else 0) | (0 if need_state else BLEND_NO_STATE)
     if out is None:
         alloc = torch.empty if tile_row_step == 1 else torch.zeros  # un-owned tiles are left untouched
-        out = (alloc((height, width, 3), dtype=torch.float32, device=dev),
-               alloc((height, width), dtype=torch.float32, device=dev),
-               alloc((height, width), dtype=torch.float32, device=dev),
-               alloc((height, width), dtype=torch.int32, device=dev),
-               alloc((height, width), dtype=torch.int32, device=dev))
+        f32 = lambda *shape: alloc(shape, dtype=torch.float32, device=dev)   # noqa: E731
+        i32 = lambda *shape: alloc(shape, dtype=torch.int32, device=dev)     # noqa: E731
+        out = (f32(height, width, 3), None if rgb_only else f32(height, width),
+               f32(height, width) if need_state else None, i32(height, width) if need_state else None,
+               None if rgb_only else i32(height, width))
     image, depth, acc_alpha, last_eff, count = out
+    dbg = torch.zeros((height, width, 2), dtype=torch.int32, device=dev) if debug_hits else None
     call("gs_blend_forward", ptr(tile_start), ptr(tile_end), ptr(payload), ptr(attrs), int(width), int(height),
          int(tile_row_begin), int(tile_row_step), ptr(image), ptr(depth), ptr(acc_alpha), ptr(last_eff), ptr(count),
-         current_stream(dev))
-    return out
+         flags, ptr(dbg), current_stream(dev))
+    return out + (dbg,) if debug_hits else out
 
 
 def blend_backward_partials(tile_start, tile_end, payload, attrs, grad_image, acc_alpha, last_eff, slot_offsets,
-                            n_slots, width, height, tile_row_begin=0, tile_row_step=1):
+                            n_slots, width, height, tile_row_begin=0, tile_row_step=1, variant=0, debug_hits=False):
     """Per-pixel backward pass -> (partials f32[S,12], slot_flags u8[S], magnitude image f32[H,W,2]): one partial
-    record per (Gaussian, tile) slot, plain stores, no atomics."""
+    record per (Gaussian, tile) slot, plain stores, no atomics.  variant: 0 or BLEND_BACKWARD_V1.  debug_hits=True
+    appends the per-pixel {count, hash} record of the pairs the backward treated as blended (see blend_forward)."""
     dev = attrs.device
     grad_image = _f32(grad_image, "grad_rasterized_image")
     partials = torch.empty((max(int(n_slots), 1), ACC_STRIDE), dtype=torch.float32, device=dev)
     flags = torch.empty(max(int(n_slots), 1), dtype=torch.uint8, device=dev)
     alloc = torch.empty if tile_row_step == 1 else torch.zeros
     mag = alloc((height, width, 2), dtype=torch.float32, device=dev)
+    dbg = torch.zeros((height, width, 2), dtype=torch.int32, device=dev) if debug_hits else None
     call("gs_blend_backward", ptr(tile_start), ptr(tile_end), ptr(payload), ptr(attrs), ptr(grad_image),
          ptr(acc_alpha), ptr(last_eff), ptr(slot_offsets), int(n_slots), int(width), int(height),
-         int(tile_row_begin), int(tile_row_step), ptr(partials), ptr(flags), ptr(mag), current_stream(dev))
-    return partials, flags, mag
+         int(tile_row_begin), int(tile_row_step), ptr(partials), ptr(flags), ptr(mag), int(variant), ptr(dbg),
+         current_stream(dev))
+    return (partials, flags, mag, dbg) if debug_hits else (partials, flags, mag)
 
 
 def reduce_partials(slot_offsets, num_overlap_tiles, flags, partials):
@@ -241,11 +254,11 @@ def reduce_partials(slot_offsets, num_overlap_tiles, flags, partials):
 
 
 def blend_backward(tile_start, tile_end, payload, attrs, grad_image, acc_alpha, last_eff, slot_offsets,
-                   num_overlap_tiles, n_slots, width, height, tile_row_begin=0, tile_row_step=1):
+                   num_overlap_tiles, n_slots, width, height, tile_row_begin=0, tile_row_step=1, variant=0):
     """-> (acc f32[M,12], magnitude_grad_viewspace_on_image f32[H,W,2]): blend_backward_partials + reduce_partials."""
     partials, flags, mag = blend_backward_partials(tile_start, tile_end, payload, attrs, grad_image, acc_alpha,
                                                    last_eff, slot_offsets, n_slots, width, height, tile_row_begin,
-                                                   tile_row_step)
+                                                   tile_row_step, variant)
     return reduce_partials(slot_offsets, num_overlap_tiles, flags, partials), mag
 
 

@@ -40,18 +40,33 @@ SCENES = {
     # many large, nearly opaque Gaussians: pixels saturate (T' < 1e-4, RAS:458-460) and alpha clamps at 0.99
     "c_90pts_32x32_opaque_saturating": (dict(n=90, height=32, width=32, s_min=0.15, s_max=0.5, sh_degree=3, seed=2), 2,
                                          dict(depth_to_sort_key_scale=100000.0), 6.0),
+    # MULTI-BATCH staging: 600 large, faint Gaussians over two tiles -> > 512 entries in one tile, so the forward's
+    # group loop (RAS:382-386) and the backward's block loop with its clamp (RAS:574-585) run 3 batches of 256
+    "f_600pts_16x32_three_batches": (dict(n=600, height=16, width=32, s_min=0.2, s_max=0.8, sh_degree=3, seed=11), 3,
+                                      dict(depth_to_sort_key_scale=1000000.0), -3.0),
+    # 128 x 128 = 64 tiles, Gaussians of mixed size, a few invalid rows
+    "g_160pts_128x128": (dict(n=160, height=128, width=128, s_min=0.02, s_max=0.2, sh_degree=3, seed=7,
+                              invalid_fraction=0.05), 2, dict(depth_to_sort_key_scale=100000.0), None),
+    # TIED sort keys (default depth scale, 1/100 units): the reference's torch.sort leaves their order undefined
+    # (RAS:947), so THIS scene is generated with that one call patched to sort(stable=True) -- the tie rule of the
+    # oracle and of the HIP path.  Shows that the tie rule is the only difference on scenes with ties.
+    "h_200pts_32x32_tied_keys_stable_sort": (dict(n=200, height=32, width=32, s_min=0.05, s_max=0.3, sh_degree=3, seed=5),
+                                             3, dict(depth_to_sort_key_scale=20.0), None),
 }
+STABLE_SORT_PATCH = ("point_in_camera_sort_key.sort()", "point_in_camera_sort_key.sort(stable=True)")
 
 
 def main():
-    mods = E.load_reference("/root/reference")
-    RAS, CAM = mods["GaussianPointCloudRasterisation"], mods["Camera"]
-    Op = RAS.GaussianPointCloudRasterisation
     from oracle import gs_oracle as O   # only to assert that the scene has no sort-key ties
     only = sys.argv[1:]
     for name, (kw, band, cfg_kw, opacity) in SCENES.items():
         if only and name not in only:
             continue
+        tied = "tied_keys_stable_sort" in name
+        mods = E.load_reference("/root/reference", source_patches={
+            "GaussianPointCloudRasterisation": [STABLE_SORT_PATCH]} if tied else None)
+        RAS, CAM = mods["GaussianPointCloudRasterisation"], mods["Camera"]
+        Op = RAS.GaussianPointCloudRasterisation
         s = make_scene(**kw)
         if opacity == "two_objects":
             gq = torch.Generator().manual_seed(99)
@@ -65,8 +80,12 @@ def main():
         f = O.forward(s.point_cloud.numpy(), s.point_cloud_features.numpy(), s.point_invalid_mask.numpy(),
                       s.point_object_id.numpy(), s.camera_intrinsics.numpy(), s.q_pointcloud_camera.numpy(),
                       s.t_pointcloud_camera.numpy(), s.height, s.width, **cfg_kw)
-        assert not (f["keys"][1:] == f["keys"][:-1]).any(), f"{name}: tied sort keys, pick another seed"
-        print(name, "K", len(f["keys"]), "saturated pixels", float((f["acc_alpha"] > 0.9999).mean()))
+        ties = float((f["keys"][1:] == f["keys"][:-1]).mean())
+        assert tied or ties == 0, f"{name}: tied sort keys, pick another seed"
+        assert not tied or ties > 0.02, f"{name}: wanted tied keys"
+        per_tile = f["tile_end"] - f["tile_start"]
+        print(name, "K", len(f["keys"]), "longest tile list", int(per_tile.max()), "tie fraction", ties,
+              "saturated pixels", float((f["acc_alpha"] > 0.9999).mean()), flush=True)
         xyz = s.point_cloud.clone().requires_grad_(True)
         feat = s.point_cloud_features.clone().requires_grad_(True)
         hook = {}
@@ -85,7 +104,7 @@ def main():
         t2 = time.time()
         h = hook["h"]
         out = dict(
-            kwargs=np.array(repr(kw)), band=np.array(band), config=np.array(repr(cfg_kw)), grad_image=g.numpy(),
+            kwargs=np.array(repr(kw)), band=np.array(band), stable_sort_patch=np.array(int(tied)), config=np.array(repr(cfg_kw)), grad_image=g.numpy(),
             opacity_override=np.array(np.nan if opacity is None else opacity),
             in_xyz=s.point_cloud.numpy(), in_feat=s.point_cloud_features.numpy(), in_invalid=s.point_invalid_mask.numpy(),
             in_object_id=s.point_object_id.numpy(), in_K=s.camera_intrinsics.numpy(), in_q=s.q_pointcloud_camera.numpy(),

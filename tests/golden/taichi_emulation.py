@@ -450,9 +450,12 @@ class _AtomicRewriter(ast.NodeTransformer):
 
 
 def load_reference(reference_root: str, modules=("Camera", "utils", "SphericalHarmonics", "GaussianPoint3D",
-                                                  "GaussianPointCloudRasterisation")):
+                                                  "GaussianPointCloudRasterisation"), source_patches=None):
     """Execute the reference's modules, from where they lie, against the emulated ``taichi``; returns
-    {module name: module}.  ``dataclass_wizard`` (absent here too) is replaced by an empty ``YAMLWizard``."""
+    {module name: module}.  ``dataclass_wizard`` (absent here too) is replaced by an empty ``YAMLWizard``.
+    source_patches: {module name: [(old, new), ...]} literal one-for-one text replacements applied to the source
+    before execution (each ``old`` must occur exactly once) -- used for exactly one experiment, the stable-sort patch of
+    make_reference_operator_vectors.py; vectors generated with a patch say so."""
     ti, tm = build_taichi_module()
     sys.modules["taichi"], sys.modules["taichi.math"] = ti, tm
     wizard = types.ModuleType("dataclass_wizard")
@@ -468,6 +471,9 @@ def load_reference(reference_root: str, modules=("Camera", "utils", "SphericalHa
         path = os.path.join(pkg_dir, name + ".py")
         with open(path) as fh:
             source = fh.read()
+        for old, new in (source_patches or {}).get(name, []):
+            assert source.count(old) == 1, (name, old)
+            source = source.replace(old, new)
         tree = ast.fix_missing_locations(_AtomicRewriter().visit(ast.parse(source, filename=path)))
         mod = types.ModuleType(f"{pkg_name}.{name}")
         mod.__file__, mod.__package__ = path, pkg_name

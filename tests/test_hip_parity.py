@@ -91,7 +91,7 @@ def test_preprocess(ops, scene, ofwd):
     assert np.array_equal(f_hip[invisible], s.point_cloud_features.numpy()[invisible])
     mism = int((ntiles.cpu().numpy() != ofwd["num_overlap_tiles"]).sum())
     report("preprocess.num_overlap_tiles", mismatches=mism, m=len(ofwd["ids"]))
-    assert mism <= max(1, len(ofwd["ids"]) // 10_000)
+    assert mism == 0   # integer work: identical (uv and the radius chain are evaluated in the oracle's operation order)
     assert np.array_equal(nowned.cpu().numpy(), ntiles.cpu().numpy())  # 1 GPU owns every row
     sums = np.add.reduceat(ntiles.cpu().numpy(), np.arange(0, len(ofwd["ids"]), 256))
     assert np.array_equal(block_sums.cpu().numpy(), sums)
@@ -228,14 +228,25 @@ def test_find_tile_start_and_end_known_answer(ops):
     assert start.tolist() == [0, 0, 2, 5] and end.tolist() == [0, 2, 5, 7]
 
 
+FRAGILE_PIXEL_BOUND = 5e-3   # a flipped 1/255 skip or T' < 1e-4 stop moves a pixel by at most ~alpha*T*c <= 4e-3
+REGRESSION_PIXEL_TOL = 5e-6  # 10x the largest non-fragile L-inf observed on any workload (5.1e-7, round 2)
+
+
 def _check_image(name, hip, ref, fragile):
+    """North star: L-inf <= 1e-4 on every pixel whose blend decisions are not within 5e-8 of a threshold (the oracle
+    reports them).  On those fragile pixels the error is bounded too (one skipped / added Gaussian) and the number
+    that actually flipped is reported.  The regression bar (5e-6) is 10x what is observed."""
     diff = np.abs(hip.astype(np.float64) - ref.astype(np.float64))
     if diff.ndim == 3:
         diff = diff.max(axis=2)
     ok = ~fragile
+    flipped = int((diff[fragile] > REGRESSION_PIXEL_TOL).sum())
     report(name, linf_nonfragile=float(diff[ok].max()), linf_all=float(diff.max()),
-           fragile_fraction=float(fragile.mean()), over_tol_all=int((diff > PIXEL_TOL).sum()))
+           fragile_fraction=float(fragile.mean()), fragile_pixels=int(fragile.sum()), flipped_pixels=flipped,
+           over_tol_all=int((diff > PIXEL_TOL).sum()))
     assert diff[ok].max() <= PIXEL_TOL
+    assert diff[ok].max() <= REGRESSION_PIXEL_TOL
+    assert diff.max() <= FRAGILE_PIXEL_BOUND
     assert fragile.mean() < 0.02
 
 
@@ -253,13 +264,41 @@ def test_blend_forward(ops, scene, ofwd):
     assert np.array_equal(count[ok], ofwd["count"][ok])
 
 
-def _check_acc(name, hip, ref, frac_needed=0.999):
+STAGE_GRAD_TOL = 5e-6     # kernel vs oracle on identical inputs: observed 1.3e-7 .. 4.7e-7 relative L2
+MASKED_GRAD_TOL = 2e-5    # whole operator, upstream gradient zeroed on the fragile pixels: observed <= 2e-6
+FLIP_GRAD_TOL = 2e-4      # whole operator, all pixels: a flipped (pixel, Gaussian) pair is a discrete change of the
+                          # gradient; observed 5e-6 (10k Gaussians) .. 3.3e-5 (1e6)
+
+
+def _check_acc(name, hip, ref, tol=STAGE_GRAD_TOL, frac_needed=None):
+    """Relative L2 below `tol`, and (almost) every entry within rel 2e-4 of the reference (abs floor 2e-6 of the
+    largest entry)."""
+    if frac_needed is None:
+        frac_needed = 0.9999 if tol <= STAGE_GRAD_TOL else 0.999
     scale = float(np.abs(ref).max()) + 1e-30
-    frac = close_fraction(hip, ref, rtol=2e-3, atol=2e-6 * scale)
+    frac = close_fraction(hip, ref, rtol=2e-4, atol=2e-6 * scale)
     r = rel_l2(hip, ref)
-    report(name, close_fraction=frac, rel_l2=r, scale=scale)
+    report(name, close_fraction=frac, rel_l2=r, scale=scale, tol=tol)
+    assert r < tol, name
     assert frac >= frac_needed, name
-    assert r < 2e-3, name
+
+
+def _operator_vs_oracle(tag, scene, f, band=3):
+    """Whole operator against the oracle: image; gradients with the upstream gradient zeroed on the fragile pixels
+    (a flipped threshold decision then contributes nothing: tight bar); gradients on all pixels (loose bar)."""
+    from taichi_3d_gaussian_splatting_amd.synthetic import make_grad_image
+    fragile = f["margin"] < FRAGILE_MARGIN
+    g = make_grad_image(scene.height, scene.width)
+    g_masked = g * torch.from_numpy(~fragile)[:, :, None]
+    for kind, gi, tol in (("masked", g_masked, MASKED_GRAD_TOL), ("all_pixels", g, FLIP_GRAD_TOL)):
+        ob = O.backward(f, gi.numpy(), band)
+        image, depth, count, xyz, feat = _run_operator(scene, gi, band)
+        if kind == "masked":
+            _check_image(f"{tag}.image", image.detach().cpu().numpy(), f["image"], fragile)
+            ok = ~fragile
+            assert np.array_equal(count.cpu().numpy()[ok], f["count"][ok])
+        _check_acc(f"{tag}.{kind}.grad_feat", feat.grad.cpu().numpy(), ob["grad_feat"], tol)
+        _check_acc(f"{tag}.{kind}.grad_xyz", xyz.grad.cpu().numpy(), ob["grad_xyz"], tol)
 
 
 def test_blend_backward(ops, scene, ofwd, obwd):
@@ -281,11 +320,16 @@ def test_blend_backward(ops, scene, ofwd, obwd):
     npix = acc[:, 10].copy().view(np.int32)
     ref_npix = ob["hook"]["num_affected_pixels"]
     mism = int((npix != ref_npix).sum())
+    n_fragile = int((ofwd["margin"] < FRAGILE_MARGIN).sum())
     report("blend_backward.num_affected_pixels", mismatched_points=mism,
-           max_abs=int(np.abs(npix - ref_npix).max()))
-    assert mism <= 0.01 * len(npix) and np.abs(npix - ref_npix).max() <= 2
-    _check_acc("blend_backward.magnitude_image", mag.cpu().numpy(), ob["hook"]["magnitude_grad_viewspace_on_image"],
-               frac_needed=0.995)
+           total_abs=int(np.abs(npix - ref_npix).sum()), fragile_pixels=n_fragile)
+    # integer output: a (pixel, Gaussian) pair can only be counted differently on a fragile pixel, one pair per pixel
+    assert int(np.abs(npix - ref_npix).sum()) <= n_fragile
+    _check_acc("blend_backward.magnitude_image", mag.cpu().numpy(), ob["hook"]["magnitude_grad_viewspace_on_image"])
+    # the round-1 kernel (selectable) computes the same sums by a different alpha expression
+    acc1, mag1 = ops.blend_backward(*args, variant=ops.BLEND_BACKWARD_V1)
+    for c, nme in enumerate(names):
+        _check_acc(f"blend_backward.v1_vs_v2.{nme}", acc1.cpu().numpy()[:, c], acc[:, c])
 
 
 def test_point_backward(ops, scene, ofwd, obwd):
@@ -367,9 +411,9 @@ def test_operator_end_to_end(scene, ofwd, obwd):
     assert np.array_equal(count.cpu().numpy()[ok], ofwd["count"][ok])
     # side effect: visible quaternions normalised in place in the caller's tensor
     assert np.allclose(feat.detach().cpu().numpy()[:, :4], ofwd["feat"][:, :4], atol=1e-7)
-    # gradients (fp32 tolerance: 99.9 % of entries within rel 2e-3, global rel-L2 < 2e-3)
-    _check_acc("operator.grad_xyz", xyz.grad.cpu().numpy(), ob["grad_xyz"])
-    _check_acc("operator.grad_feat", feat.grad.cpu().numpy(), ob["grad_feat"])
+    # gradients over all pixels (flips included); the masked comparison is test_operator_masked_gradients
+    _check_acc("operator.grad_xyz", xyz.grad.cpu().numpy(), ob["grad_xyz"], FLIP_GRAD_TOL)
+    _check_acc("operator.grad_feat", feat.grad.cpu().numpy(), ob["grad_feat"], FLIP_GRAD_TOL)
     h, ho = got["h"], ob["hook"]
     m = len(ofwd["ids"])
     assert np.array_equal(h.point_id_in_camera_list.cpu().numpy(), ho["point_id_in_camera_list"])
@@ -380,9 +424,98 @@ def test_operator_end_to_end(scene, ofwd, obwd):
     assert np.array_equal(h.num_overlap_tiles.cpu().numpy(), ho["num_overlap_tiles"])
     assert np.array_equal(h.point_depth.cpu().numpy(), ho["point_depth"])
     assert np.array_equal(h.point_uv_in_camera.cpu().numpy(), ho["point_uv_in_camera"])
-    _check_acc("operator.hook.grad_viewspace", h.grad_viewspace.cpu().numpy(), ho["grad_viewspace"])
+    _check_acc("operator.hook.grad_viewspace", h.grad_viewspace.cpu().numpy(), ho["grad_viewspace"], FLIP_GRAD_TOL)
     _check_acc("operator.hook.grad_pointfeatures", h.grad_pointfeatures_in_camera.cpu().numpy(),
-               ho["grad_pointfeatures_in_camera"])
+               ho["grad_pointfeatures_in_camera"], FLIP_GRAD_TOL)
+
+
+def test_operator_masked_gradients(scene, ofwd):
+    _operator_vs_oracle("operator10k", scene, ofwd)
+
+
+def _stages_to_ranges(ops, s):
+    """HIP front end on a device scene -> everything the two blend kernels need."""
+    q_cp, t_cp = ops.pose_inverse(s.q_pointcloud_camera, s.t_pointcloud_camera)
+    mask, ids, counters = ops.filter_compact(s.point_cloud, s.point_invalid_mask, s.point_object_id,
+                                             s.camera_intrinsics, q_cp, t_cp, s.near_plane, s.far_plane, s.width,
+                                             s.height)
+    feat = s.point_cloud_features.clone()
+    attrs, ntiles, nowned, bsums, bsums_full = ops.preprocess(
+        s.point_cloud, feat, s.point_object_id, s.camera_intrinsics, q_cp, t_cp, ids, s.width, s.height,
+        depth_to_sort_key_scale=s.depth_to_sort_key_scale, counters=counters)
+    k, n_slots, max_dq, _ = ops.scan_block_sums(bsums, counters, bsums_full)
+    num_tiles = (s.width // 16) * (s.height // 16)
+    kdb, db, tb = ops.key_layout(s.near_plane, s.far_plane, s.depth_to_sort_key_scale, num_tiles, max_dq)
+    keys, payload, slot_offsets = ops.make_keys(attrs, nowned, bsums, k, s.width, s.height, s.depth_to_sort_key_scale,
+                                                key_depth_bits=kdb, num_overlap_tiles=ntiles,
+                                                block_offsets_full=bsums_full)
+    ops.sort_pairs(keys, payload, db, tb, kdb)
+    start, end = ops.tile_ranges(keys, num_tiles, kdb)
+    return dict(attrs=attrs, ntiles=ntiles, payload=payload, start=start, end=end, slot_offsets=slot_offsets,
+                n_slots=n_slots, k=k)
+
+
+@pytest.mark.parametrize("workload", ["cfg2_100k_800", "headline_1m_1080p", "cfg3_400k_1080p"])
+def test_forward_and_backward_blend_the_same_pairs(ops, workload):
+    """a (pixel, Gaussian) pair must be treated as blended by the backward pass iff the forward
+    pass blended it.  Both kernels evaluate alpha through the same device function; here every pixel's blended set is
+    compared through {count, hash of the blended Gaussians' list offsets}: identical on EVERY pixel, at full size."""
+    from taichi_3d_gaussian_splatting_amd.synthetic import make_config_scene, make_grad_image
+    s = make_config_scene(workload).to("cuda")
+    st = _stages_to_ranges(ops, s)
+    image, depth, acc_alpha, last_eff, count, dbg_f = ops.blend_forward(
+        st["start"], st["end"], st["payload"], st["attrs"], s.width, s.height, debug_hits=True)
+    assert torch.equal(dbg_f[:, :, 0], count)
+    g = make_grad_image(s.height, s.width).cuda()
+    partials, flags, mag, dbg_b = ops.blend_backward_partials(
+        st["start"], st["end"], st["payload"], st["attrs"], g, acc_alpha, last_eff, st["slot_offsets"], st["n_slots"],
+        s.width, s.height, debug_hits=True)
+    differing = int((dbg_f != dbg_b).any(dim=2).sum())
+    report(f"hit_sets.{workload}", pixels=s.height * s.width, blended_pairs=int(count.sum()),
+           pixels_with_different_sets=differing)
+    assert differing == 0
+    # and the debug build changes nothing: same partial sums as the production kernel, bit for bit
+    partials2, flags2, mag2 = ops.blend_backward_partials(
+        st["start"], st["end"], st["payload"], st["attrs"], g, acc_alpha, last_eff, st["slot_offsets"], st["n_slots"],
+        s.width, s.height)
+    raised = flags.bool()
+    assert torch.equal(flags, flags2) and torch.equal(mag, mag2)
+    assert torch.equal(partials[raised].view(torch.int32), partials2[raised].view(torch.int32))
+    # per-Gaussian pixel counts of the backward add up to the forward's per-pixel counts
+    acc = ops.reduce_partials(st["slot_offsets"], st["ntiles"], flags, partials)
+    assert int(acc[:, 10].contiguous().view(torch.int32).sum()) == int(count.sum())
+
+
+def test_rgb_only_and_inference_paths(ops, scene):
+    """rgb_only (RAS:464-469,478-484) and the no-gradient path: the image is bit-identical to the full forward; depth and
+    count are zeros under rgb_only; gradients under rgb_only equal those of the default configuration."""
+    from taichi_3d_gaussian_splatting_amd import GaussianPointCloudRasterisation as Op
+    from taichi_3d_gaussian_splatting_amd.synthetic import make_grad_image
+    g = make_grad_image(scene.height, scene.width)
+    full = _run_operator(scene, g)
+    cfg = dict(near_plane=scene.near_plane, far_plane=scene.far_plane,
+               depth_to_sort_key_scale=scene.depth_to_sort_key_scale)
+    rgb = _run_operator(scene, g, op=Op(Op.GaussianPointCloudRasterisationConfig(rgb_only=True, **cfg)))
+    assert torch.equal(rgb[0], full[0]) and not rgb[1].any() and not rgb[2].any()
+    assert torch.equal(rgb[4].grad, full[4].grad) and torch.equal(rgb[3].grad, full[3].grad)
+    with torch.no_grad():
+        inf = _run_operator(scene, None)
+        inf_rgb = _run_operator(scene, None, op=Op(Op.GaussianPointCloudRasterisationConfig(rgb_only=True, **cfg)))
+    assert torch.equal(inf[0], full[0]) and torch.equal(inf[1], full[1]) and torch.equal(inf[2], full[2])
+    assert torch.equal(inf_rgb[0], full[0]) and not inf_rgb[1].any()
+    # stage level: every flag combination writes the same image
+    st = _stages_to_ranges(ops, scene.to("cuda"))
+    ref = ops.blend_forward(st["start"], st["end"], st["payload"], st["attrs"], scene.width, scene.height)
+    for rgb_only in (False, True):
+        for need_state in (False, True):
+            out = ops.blend_forward(st["start"], st["end"], st["payload"], st["attrs"], scene.width, scene.height,
+                                    rgb_only=rgb_only, need_state=need_state)
+            assert torch.equal(out[0], ref[0])
+            assert (out[1] is None) == rgb_only and (out[2] is None) == (not need_state)
+            if not rgb_only:
+                assert torch.equal(out[1], ref[1]) and torch.equal(out[4], ref[4])
+            if need_state:
+                assert torch.equal(out[2], ref[2]) and torch.equal(out[3], ref[3])
 
 
 def test_hook_feature_gradients_can_be_switched_off(scene):
@@ -453,8 +586,8 @@ def test_operator_multi_object_poses():
     ob = O.backward(f, g.numpy(), 3)
     image, depth, count, xyz, feat = _run_operator(s, g)
     _check_image("multi_object.image", image.detach().cpu().numpy(), f["image"], f["margin"] < FRAGILE_MARGIN)
-    _check_acc("multi_object.grad_feat", feat.grad.cpu().numpy(), ob["grad_feat"])
-    _check_acc("multi_object.grad_xyz", xyz.grad.cpu().numpy(), ob["grad_xyz"])
+    _check_acc("multi_object.grad_feat", feat.grad.cpu().numpy(), ob["grad_feat"], FLIP_GRAD_TOL)
+    _check_acc("multi_object.grad_xyz", xyz.grad.cpu().numpy(), ob["grad_xyz"], FLIP_GRAD_TOL)
 
 
 def test_operator_cfg2_size_forward_backward():
@@ -462,13 +595,8 @@ def test_operator_cfg2_size_forward_backward():
     from taichi_3d_gaussian_splatting_amd.synthetic import make_config_scene, make_grad_image
     s = make_config_scene("cfg2_100k_800")
     f = oracle_forward(s)
-    g = make_grad_image(s.height, s.width)
-    ob = O.backward(f, g.numpy(), 3)
-    image, depth, count, xyz, feat = _run_operator(s, g)
     report("cfg2.sizes", M=len(f["ids"]), K=len(f["keys"]))
-    _check_image("cfg2.image", image.detach().cpu().numpy(), f["image"], f["margin"] < FRAGILE_MARGIN)
-    _check_acc("cfg2.grad_feat", feat.grad.cpu().numpy(), ob["grad_feat"])
-    _check_acc("cfg2.grad_xyz", xyz.grad.cpu().numpy(), ob["grad_xyz"])
+    _operator_vs_oracle("cfg2", s, f)
 
 
 def test_headline_size_properties(ops):
@@ -566,16 +694,11 @@ def test_operator_cfg3_truck_like_forward_backward():
     from taichi_3d_gaussian_splatting_amd.synthetic import make_config_scene, make_grad_image
     s = make_config_scene("cfg3_400k_1080p")
     f = oracle_forward(s)
-    g = make_grad_image(s.height, s.width)
-    ob = O.backward(f, g.numpy(), 3)
-    image, depth, count, xyz, feat = _run_operator(s, g)
     keys = f["keys"]
     ties = float(np.mean(keys[1:] == keys[:-1]))
     report("cfg3.sizes", M=len(f["ids"]), K=len(keys), tie_fraction=ties)
     assert ties > 0.5
-    _check_image("cfg3.image", image.detach().cpu().numpy(), f["image"], f["margin"] < FRAGILE_MARGIN)
-    _check_acc("cfg3.grad_feat", feat.grad.cpu().numpy(), ob["grad_feat"])
-    _check_acc("cfg3.grad_xyz", xyz.grad.cpu().numpy(), ob["grad_xyz"])
+    _operator_vs_oracle("cfg3", s, f)
 
 
 @pytest.mark.parametrize("workload,tag", [("headline_1m_1080p", "headline"), ("cfg4_2m_1080p", "cfg4")])
@@ -585,13 +708,8 @@ def test_operator_full_size_forward_backward(workload, tag):
     from taichi_3d_gaussian_splatting_amd.synthetic import make_config_scene, make_grad_image
     s = make_config_scene(workload)
     f = oracle_forward(s)
-    g = make_grad_image(s.height, s.width)
-    ob = O.backward(f, g.numpy(), 3)
-    image, depth, count, xyz, feat = _run_operator(s, g)
     report(f"{tag}.full_size", M=len(f["ids"]), K=len(f["keys"]))
-    _check_image(f"{tag}.image", image.detach().cpu().numpy(), f["image"], f["margin"] < FRAGILE_MARGIN)
-    _check_acc(f"{tag}.grad_feat", feat.grad.cpu().numpy(), ob["grad_feat"])
-    _check_acc(f"{tag}.grad_xyz", xyz.grad.cpu().numpy(), ob["grad_xyz"])
+    _operator_vs_oracle(tag, s, f)
 
 
 def test_reference_stress_distribution_runs():
@@ -703,7 +821,7 @@ def test_operator_reference_key_layout_path():
     ob = O.backward(f, g.numpy(), 3)
     image, depth, count, xyz, feat = _run_operator(s, g)
     _check_image("key64.image", image.detach().cpu().numpy(), f["image"], f["margin"] < FRAGILE_MARGIN)
-    _check_acc("key64.grad_feat", feat.grad.cpu().numpy(), ob["grad_feat"])
+    _check_acc("key64.grad_feat", feat.grad.cpu().numpy(), ob["grad_feat"], FLIP_GRAD_TOL)
 
 
 def test_operator_degenerate_sizes():

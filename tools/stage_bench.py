@@ -17,6 +17,7 @@ s = make_config_scene(workload).to("cuda")
 g = make_grad_image(s.height, s.width).to("cuda")
 times = {}
 CULL = os.environ.get('GS_CULL', '1') == '1'
+AB = os.environ.get('GS_AB', '0') == '1'
 
 
 def timed(name, fn):
@@ -44,6 +45,12 @@ for _ in range(reps + 2):
     start, end = timed("tile_ranges", lambda: hip_ops.tile_ranges(keys, num_tiles, kdb))
     image, depth, acc_alpha, last_eff, count = timed("blend_forward", lambda: hip_ops.blend_forward(
         start, end, payload, attrs, s.width, s.height))
+    if AB:   # A/B arms: inference forward (image only) and the round-1 backward kernel
+        timed("blend_forward_rgb_nostate", lambda: hip_ops.blend_forward(
+            start, end, payload, attrs, s.width, s.height, rgb_only=True, need_state=False))
+        timed("blend_backward_v1", lambda: hip_ops.blend_backward_partials(
+            start, end, payload, attrs, g, acc_alpha, last_eff, slot_off, n_slots, s.width, s.height,
+            variant=hip_ops.BLEND_BACKWARD_V1))
     partials, flags, mag = timed("blend_backward", lambda: hip_ops.blend_backward_partials(
         start, end, payload, attrs, g, acc_alpha, last_eff, slot_off, n_slots, s.width, s.height))
     acc = timed("reduce_partials", lambda: hip_ops.reduce_partials(slot_off, ntiles, flags, partials))
@@ -55,7 +62,7 @@ print(f"workload={workload} M={ids.shape[0]} K={k} cull={CULL}")
 tot = 0.0
 for name, pairs in times.items():
     ms = sum(a.elapsed_time(b) for a, b in pairs[2:]) / len(pairs[2:])
-    tot += ms
+    tot += 0.0 if name in ("blend_forward_rgb_nostate", "blend_backward_v1") else ms
     print(f"  {name:16s} {ms:8.4f} ms")
 print(f"  {'sum':16s} {tot:8.4f} ms")
 lens = (end - start).float()
