@@ -425,67 +425,82 @@ void gs_oracle_blend_backward(int height, int width, const int32_t *tile_start, 
                               const real *acc_alpha, const int32_t *last_eff, int m,
                               real *acc_out /* [M,10] */, int32_t *npix /* [M] */,
                               real *mag_image /* [H,W,2] */) {
-    int tw = width / TILE_W;
+    /* The reference scatters eleven atomics per contributing (pixel, Gaussian) pair (RAS:674-696).  On a CPU those
+     * atomics would be the whole run time, so -- as a fair CPU implementation would -- a tile first sums its pairs
+     * into a private record per list entry (one thread owns a tile, its pixels run in order), in double, and the
+     * records of a Gaussian are added up afterwards in ascending list position.  No atomics, deterministic. */
+    int tw = width / TILE_W, th = height / TILE_H;
     const real eps_alpha = (real)(1. / 255.), clamp = (real)0.99;
-    double *acc = (double *)calloc((size_t)m * 10, sizeof(double));
-    memset(npix, 0, sizeof(int32_t) * (size_t)m);
-#pragma omp parallel for schedule(dynamic, 4)
-    for (int pix = 0; pix < height * width; ++pix) {
-        int tile = pix / (TILE_W * TILE_H), in_tile = pix % (TILE_W * TILE_H);
+    long long n_keys = 0;
+    for (int t = 0; t < tw * th; ++t)
+        if (tile_end[t] > n_keys) n_keys = tile_end[t];
+    double *part = (double *)calloc((size_t)(n_keys > 0 ? n_keys : 1) * 10, sizeof(double));
+    int32_t *part_n = (int32_t *)calloc((size_t)(n_keys > 0 ? n_keys : 1), sizeof(int32_t));
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int tile = 0; tile < tw * th; ++tile) {
         int tu = tile % tw, tv = tile / tw;
-        int pu = tu * TILE_W + in_tile % TILE_W, pv = tv * TILE_H + in_tile / TILE_W;
-        size_t p = (size_t)pv * width + pu;
         int start = tile_start[tile], end = tile_end[tile];
-        int last = last_eff[p];
-        real T = RC(1.0) - acc_alpha[p];
-        real w[3] = {0, 0, 0};
-        real G[3] = {grad_image[3 * p], grad_image[3 * p + 1], grad_image[3 * p + 2]};
-        real mag[2] = {0, 0};
-        real px = (real)pu + RC(0.5), py = (real)pv + RC(0.5);
-        for (int j = end - 1; j >= start; --j) {
-            if (j >= last) continue;
-            int o = payload[j];
-            real dx = px - uv[2 * o], dy = py - uv[2 * o + 1];
-            const real *cn = conic + 4 * o;
-            /* UTL:331-348: m = inv_cov @ d, exponent = -0.5 * d.m */
-            real m0 = cn[0] * dx + cn[1] * dy, m1 = cn[1] * dx + cn[2] * dy;
-            real e = RC(-0.5) * (dx * m0 + dy * m1);
-            real g = R_EXP(e) * cn[3];
-            real a_pt = alpha_pt[o];
-            real pa = g * a_pt;
-            if (pa >= eps_alpha) {
-                real a = pa < clamp ? pa : clamp;
-                T = T / (RC(1.) - a);
-                real aT = a * T;
-                real gc[3] = {aT * G[0], aT * G[1], aT * G[2]};
-                const real *c = rgb + 3 * o;
-                real one_m = RC(1.) - a;
-                real dLda = ((c[0] * T - w[0] / one_m) * G[0] + (c[1] * T - w[1] / one_m) * G[1]) +
-                            (c[2] * T - w[2] / one_m) * G[2];
-                w[0] += c[0] * a * T; w[1] += c[1] * a * T; w[2] += c[2] * a * T;
-                real dlogit = dLda * g * (RC(1.) - a_pt) * a_pt;
-                real dLdg = dLda * a_pt;
-                real v0 = dLdg * (g * m0), v1 = dLdg * (g * m1); /* dg/dmu = g * m */
-                mag[0] += R_FABS(v0); mag[1] += R_FABS(v1);
-                /* dg/dcov = 0.5 g (m m^T) */
-                real c00 = dLdg * (RC(0.5) * g * (m0 * m0));
-                real c01 = dLdg * (RC(0.5) * g * (m0 * m1));
-                real c11 = dLdg * (RC(0.5) * g * (m1 * m1));
-                real nv = R_SQRT(v0 * v0 + v1 * v1);
-                double *A = acc + (size_t)10 * o;
-                double vals[10] = {v0, v1, c00, c01, c11, gc[0], gc[1], gc[2], dlogit, nv};
-                for (int k = 0; k < 10; ++k) {
-#pragma omp atomic
-                    A[k] += vals[k];
+        for (int in_tile = 0; in_tile < TILE_W * TILE_H; ++in_tile) {
+            int pu = tu * TILE_W + in_tile % TILE_W, pv = tv * TILE_H + in_tile / TILE_W;
+            size_t p = (size_t)pv * width + pu;
+            int last = last_eff[p];
+            real T = RC(1.0) - acc_alpha[p];
+            real w[3] = {0, 0, 0};
+            real G[3] = {grad_image[3 * p], grad_image[3 * p + 1], grad_image[3 * p + 2]};
+            real mag[2] = {0, 0};
+            real px = (real)pu + RC(0.5), py = (real)pv + RC(0.5);
+            for (int j = (last < end ? last : end) - 1; j >= start; --j) { /* entries at or beyond `last` are skipped, RAS:618 */
+                int o = payload[j];
+                real dx = px - uv[2 * o], dy = py - uv[2 * o + 1];
+                const real *cn = conic + 4 * o;
+                /* UTL:331-348: m = inv_cov @ d, exponent = -0.5 * d.m */
+                real m0 = cn[0] * dx + cn[1] * dy, m1 = cn[1] * dx + cn[2] * dy;
+                real e = RC(-0.5) * (dx * m0 + dy * m1);
+                real g = R_EXP(e) * cn[3];
+                real a_pt = alpha_pt[o];
+                real pa = g * a_pt;
+                if (pa >= eps_alpha) {
+                    real a = pa < clamp ? pa : clamp;
+                    T = T / (RC(1.) - a);
+                    real aT = a * T;
+                    real gc[3] = {aT * G[0], aT * G[1], aT * G[2]};
+                    const real *c = rgb + 3 * o;
+                    real one_m = RC(1.) - a;
+                    real dLda = ((c[0] * T - w[0] / one_m) * G[0] + (c[1] * T - w[1] / one_m) * G[1]) +
+                                (c[2] * T - w[2] / one_m) * G[2];
+                    w[0] += c[0] * a * T; w[1] += c[1] * a * T; w[2] += c[2] * a * T;
+                    real dlogit = dLda * g * (RC(1.) - a_pt) * a_pt;
+                    real dLdg = dLda * a_pt;
+                    real v0 = dLdg * (g * m0), v1 = dLdg * (g * m1); /* dg/dmu = g * m */
+                    mag[0] += R_FABS(v0); mag[1] += R_FABS(v1);
+                    /* dg/dcov = 0.5 g (m m^T) */
+                    real c00 = dLdg * (RC(0.5) * g * (m0 * m0));
+                    real c01 = dLdg * (RC(0.5) * g * (m0 * m1));
+                    real c11 = dLdg * (RC(0.5) * g * (m1 * m1));
+                    real nv = R_SQRT(v0 * v0 + v1 * v1);
+                    double *A = part + (size_t)10 * j;
+                    A[0] += v0; A[1] += v1; A[2] += c00; A[3] += c01; A[4] += c11;
+                    A[5] += gc[0]; A[6] += gc[1]; A[7] += gc[2]; A[8] += dlogit; A[9] += nv;
+                    part_n[j] += 1;
                 }
-#pragma omp atomic
-                npix[o] += 1;
             }
+            mag_image[2 * p] = mag[0]; mag_image[2 * p + 1] = mag[1];
         }
-        mag_image[2 * p] = mag[0]; mag_image[2 * p + 1] = mag[1];
+    }
+    /* per-Gaussian sums in ascending list position; the ten components are independent (one thread each) */
+    double *acc = (double *)calloc((size_t)(m > 0 ? m : 1) * 10, sizeof(double));
+    memset(npix, 0, sizeof(int32_t) * (size_t)m);
+#pragma omp parallel for schedule(static, 1)
+    for (int k = 0; k < 11; ++k) {
+        if (k == 10) {
+            for (long long j = 0; j < n_keys; ++j) npix[payload[j]] += part_n[j];
+        } else {
+            for (long long j = 0; j < n_keys; ++j)
+                if (part_n[j]) acc[(size_t)10 * payload[j] + k] += part[(size_t)10 * j + k];
+        }
     }
     for (size_t i = 0; i < (size_t)m * 10; ++i) acc_out[i] = (real)acc[i];
-    free(acc);
+    free(acc); free(part); free(part_n);
 }
 
 /* ------------------------------------------- K8: backward per-point pass */

@@ -145,8 +145,11 @@ class GaussianPointCloudScene(nn.Module):
         the cloud x radius_factor, mid-grey if the cloud has colours."""
         extent = max(df[c].max() - df[c].min() for c in "xyz") / 2.0
         radius = extent * radius_factor
-        phi = 2.0 * np.pi * np.random.rand(num_points)
-        theta = np.arccos(2.0 * np.random.rand(num_points) - 1.0)
+        # own, fixed-seed generator (the reference draws from the global numpy state, SCN:222-223): every rank of a
+        # multi-GPU run builds its replica of the scene from the parquet and the replicas must be identical
+        rng = np.random.default_rng(0x5EED)
+        phi = 2.0 * np.pi * rng.random(num_points)
+        theta = np.arccos(2.0 * rng.random(num_points) - 1.0)
         pts = {"x": radius * np.sin(theta) * np.cos(phi), "y": radius * np.sin(theta) * np.sin(phi),
                "z": radius * np.cos(theta)}
         if {"r", "g", "b"}.issubset(df.columns):

@@ -194,6 +194,13 @@ class GaussianPointCloudTrainer:
         self.val_dataset = ImagePoseDataset(dataset_json_path=config.val_dataset_json_path)
         self.scene = GaussianPointCloudScene.from_parquet(
             config.pointcloud_parquet_path, config=config.gaussian_point_cloud_scene_config).to(self.device)
+        if torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
+            # one authoritative replica: whatever randomness went into the construction (KD-tree initialisation, the
+            # sky sphere), every rank starts from rank 0's tensors
+            with torch.no_grad():
+                for t in (self.scene.point_cloud, self.scene.point_cloud_features, self.scene.point_invalid_mask,
+                          self.scene.point_object_id):
+                    torch.distributed.broadcast(t.data if isinstance(t, torch.nn.Parameter) else t, src=0)
         self.adaptive_controller = GaussianPointAdaptiveController(
             config=config.adaptive_controller_config,
             maintained_parameters=GaussianPointAdaptiveController.GaussianPointAdaptiveControllerMaintainedParameters(
@@ -256,7 +263,9 @@ class GaussianPointCloudTrainer:
         if self.writer is not None:
             self.writer.add_scalar(tag, value, step)
         if console_key and self.config.print_metrics_to_console and self.rank == 0:
-            print(f"{console_key}={value};")   # the reference's console format (scraped by its CI, TRN:213-217)
+            print(f"{console_key}={value};")   # the reference's console format (scraped by its CI, TRN:213-231,403-409)
+            if console_key.endswith(("_psnr", "_ssim")):   # plus the per-iteration keys, e.g. train_psnr_7000= (TRN:229)
+                print(f"{console_key}_{step}={value};")
 
     def _loaders(self):
         kw = dict(batch_size=None, pin_memory=True, num_workers=self.config.num_data_loader_workers)
@@ -330,6 +339,8 @@ class GaussianPointCloudTrainer:
             if iteration % cfg.log_loss_interval == 0:
                 # the only regular host read-back of the loop: one copy for the three scalars
                 loss_value, l1_value, ssim_value = torch.stack([loss, l1_loss.detach(), ssim_loss.detach()]).tolist()
+                if cfg.print_metrics_to_console and self.rank == 0:
+                    print(f"train_iteration={iteration};")   # TRN:213
                 self._scalar("train/loss", loss_value, iteration, "train_loss")
                 self._scalar("train/l1 loss", l1_value, iteration, "train_l1_loss")
                 self._scalar("train/ssim loss", ssim_value, iteration, "train_ssim_loss")

@@ -50,7 +50,7 @@ def ssim(x: torch.Tensor, y: torch.Tensor, data_range: float = 1.0, size_average
     if x.shape != y.shape or x.dim() != 4:
         raise ValueError("ssim expects two [B,C,H,W] tensors of the same shape")
     if (_fusable(x, y) and not (x.requires_grad or y.requires_grad) and data_range == 1.0 and win_size == 11 and
-            win_sigma == 1.5 and (k1, k2) == (0.01, 0.03)):
+            win_sigma == 1.5 and (k1, k2) == (0.01, 0.03) and size_average):
         # metric use on the device (PSNR/SSIM logging, validation): the fused forward kernel -- MIOpen needs ~90 ms per
         # depth-wise 11-tap convolution at 1920x1072, i.e. seconds per SSIM evaluation
         from . import hip_ops
@@ -174,6 +174,8 @@ class LossFunction(nn.Module):
     def _regularization_loss(point_invalid_mask, pointcloud_features):
         """Mean Euclidean norm of the three axis lengths exp(s) of the valid Gaussians (LOS:42-54), written as a
         masked mean: boolean indexing would cost a device->host synchronisation per iteration."""
-        live = (point_invalid_mask == 0).to(pointcloud_features.dtype)
-        axis_norm = torch.exp(pointcloud_features[:, 4:7]).norm(dim=1)
-        return (axis_norm * live).sum() / live.sum()
+        live = point_invalid_mask == 0
+        # rows the controller invalidated may hold NaN (that is why they were invalidated): select, do not multiply
+        scale = torch.where(live[:, None], pointcloud_features[:, 4:7], torch.zeros_like(pointcloud_features[:, 4:7]))
+        axis_norm = torch.where(live, torch.exp(scale).norm(dim=1), torch.zeros_like(scale[:, 0]))
+        return axis_norm.sum() / live.sum()

@@ -57,10 +57,29 @@ def all_gather_tile_rows(tensors: Sequence[torch.Tensor], rank: int, world: int,
         v.copy_(block.permute(1, 0, 2).reshape(max_rows * world, v.shape[1])[:th])
 
 
+_replica_checks = {"calls": 0}
+
+
+def _check_replicas_agree(m: int, device, group) -> None:
+    """The accumulators are [M,12] with M = number of Gaussians in the frustum: the replicated point clouds must agree
+    or the all-reduce below would add rows of different Gaussians (or hang on unequal sizes).  Checked with one tiny
+    collective on the first call and then every 1000th (replicas that start identical stay identical: the optimiser
+    and the controller are deterministic under identical seeds)."""
+    _replica_checks["calls"] += 1
+    if _replica_checks["calls"] % 1000 != 1:
+        return
+    sizes = torch.tensor([m, -m], dtype=torch.int64, device=device)
+    dist.all_reduce(sizes, op=dist.ReduceOp.MAX, group=group)
+    if int(sizes[0]) != m or int(sizes[1]) != -m:
+        raise RuntimeError(f"rank {dist.get_rank(group)}: {m} Gaussians in the frustum, other ranks between "
+                           f"{-int(sizes[1])} and {int(sizes[0])}: the replicated point clouds have diverged")
+
+
 def all_reduce_accumulators(acc: torch.Tensor, group: Optional[dist.ProcessGroup] = None) -> None:
     """Sum the [M,12] backward accumulators over ranks with ONE collective.  Column 10 holds an int32 pixel
     count in the float's bits (include/gsplat_hip.h): it is converted to a float value for the reduction (a
     pixel count is < 2^24, so the float sum is exact in any order) and back to integer bits afterwards."""
+    _check_replicas_agree(acc.shape[0], acc.device, group)
     col = acc[:, 10]
     col.copy_(col.view(torch.int32).to(torch.float32))
     dist.all_reduce(acc, op=dist.ReduceOp.SUM, group=group)

@@ -12,6 +12,18 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run through gpurun)")
 
 
+def pytest_collection_modifyitems(config, items):
+    """Without a HIP device the gpu-marked tests are skipped (a CPU-only run then still reports CPU-side regressions)
+    -- except on a gpurun box (GRAFT_REPO_ROOT is set there), where a missing device must fail loudly."""
+    import torch
+    if torch.cuda.is_available() or os.environ.get("GRAFT_REPO_ROOT"):
+        return
+    skip = pytest.mark.skip(reason="no HIP device (gpu tests run through gpurun)")
+    for item in items:
+        if "gpu" in item.keywords:
+            item.add_marker(skip)
+
+
 @pytest.fixture(scope="session", autouse=True)
 def _build_native():
     """Build the checker (CPU oracle) and, if the in-tree library is missing or stale, the HIP library

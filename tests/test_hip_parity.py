@@ -264,10 +264,15 @@ def test_blend_forward(ops, scene, ofwd):
     assert np.array_equal(count[ok], ofwd["count"][ok])
 
 
-STAGE_GRAD_TOL = 5e-6     # kernel vs oracle on identical inputs: observed 1.3e-7 .. 4.7e-7 relative L2
-MASKED_GRAD_TOL = 2e-5    # whole operator, upstream gradient zeroed on the fragile pixels: observed <= 2e-6
-FLIP_GRAD_TOL = 2e-4      # whole operator, all pixels: a flipped (pixel, Gaussian) pair is a discrete change of the
-                          # gradient; observed 5e-6 (10k Gaussians) .. 3.3e-5 (1e6)
+# Gradient bars (relative L2), each within 10x of what is observed (gpurun_out/pytest_r02b.log, round 2):
+STAGE_GRAD_TOL = 5e-6     # one kernel vs the oracle on IDENTICAL inputs: observed 1.5e-7 .. 5.1e-7
+MASKED_GRAD_TOL = 3e-5    # whole operator, upstream gradient zeroed on the fragile pixels (no flipped threshold decision
+                          # can contribute): observed 4.8e-6 (1e4 Gaussians) .. 1.2e-5 (4e5 .. 2e6).  This is the fp32
+                          # conditioning of the front end, not the blend kernels: exp(s) differs by an ulp between the
+                          # device and glibc and the 2x2 inverse amplifies it (conic: 2e-5 relative, test_preprocess);
+                          # test_operator_is_as_close_to_the_f64_spec_as_the_fp32_oracle puts a number on that
+FLIP_GRAD_TOL = 1e-4      # whole operator, all pixels: a flipped (pixel, Gaussian) pair is a discrete change of the
+                          # gradient; observed 4.8e-6 (1e4 Gaussians) .. 4.0e-5 (4e5, 99 % tied keys)
 
 
 def _check_acc(name, hip, ref, tol=STAGE_GRAD_TOL, frac_needed=None):
@@ -431,6 +436,25 @@ def test_operator_end_to_end(scene, ofwd, obwd):
 
 def test_operator_masked_gradients(scene, ofwd):
     _operator_vs_oracle("operator10k", scene, ofwd)
+
+
+def test_operator_is_as_close_to_the_f64_spec_as_the_fp32_oracle(scene, ofwd):
+    """Where the remaining operator-level gradient difference comes from: against the float64 build of the oracle
+    (the spec), the HIP operator is no further away than the fp32 oracle itself -- both carry the fp32 rounding of the
+    projection / conic chain.  Upstream gradient zeroed where either precision sits on a threshold."""
+    from taichi_3d_gaussian_splatting_amd.synthetic import make_grad_image
+    f64 = oracle_forward(scene, precision="f64")
+    same_decisions = (f64["count"] == ofwd["count"]) & (f64["last_eff"] == ofwd["last_eff"])
+    keep = same_decisions & (ofwd["margin"] >= FRAGILE_MARGIN) & (f64["margin"] >= FRAGILE_MARGIN)
+    g = make_grad_image(scene.height, scene.width) * torch.from_numpy(keep)[:, :, None]
+    spec = O.backward(f64, g.numpy().astype(np.float64), 3)
+    o32 = O.backward(ofwd, g.numpy(), 3)
+    image, depth, count, xyz, feat = _run_operator(scene, g)
+    for name, hip, a32, a64 in (("grad_feat", feat.grad.cpu().numpy(), o32["grad_feat"], spec["grad_feat"]),
+                                ("grad_xyz", xyz.grad.cpu().numpy(), o32["grad_xyz"], spec["grad_xyz"])):
+        e_hip, e_o32 = rel_l2(hip, a64), rel_l2(a32, a64)
+        report(f"f64_spec.{name}", hip_vs_f64=e_hip, fp32_oracle_vs_f64=e_o32, kept_pixels=float(keep.mean()))
+        assert e_hip <= 3.0 * e_o32 + 1e-6
 
 
 def _stages_to_ranges(ops, s):
