@@ -158,8 +158,8 @@ def main() -> None:
     n = s.point_cloud.shape[0]
     roofline, stages_ms, sizes = None, {}, {}
     if not args.no_stage_profile:
-        rb, rs = op.tile_row_begin, op.tile_row_step
-        CULL = op.exact_tile_cull
+        layout = hip_ops.ListLayout(bin_shift=op.bin_shift, exact_cull=op.exact_tile_cull, row_begin=op.tile_row_begin,
+                                    row_step=op.tile_row_step, row_end=op.tile_row_end)
         ev = lambda: torch.cuda.Event(enable_timing=True)  # noqa: E731  (events on torch's current stream,
         reps = max(3, min(args.steps, 10))                 #  the stream every kernel is launched on)
         acc_ms = {}
@@ -173,7 +173,8 @@ def main() -> None:
             return out
 
         num_tiles = (s.width // 16) * (s.height // 16)
-        kdb, db, tb = hip_ops.key_layout(s.near_plane, s.far_plane, s.depth_to_sort_key_scale, num_tiles)
+        num_bins = layout.num_bins(s.width, s.height)
+        kdb, db, tb = hip_ops.key_layout(s.near_plane, s.far_plane, s.depth_to_sort_key_scale, num_bins)
         q_cp, t_cp = hip_ops.pose_inverse(s.q_pointcloud_camera, s.t_pointcloud_camera)
         for _ in range(reps):
             f = feat.detach()
@@ -181,17 +182,18 @@ def main() -> None:
                 s.point_cloud, s.point_invalid_mask, s.point_object_id, s.camera_intrinsics, q_cp, t_cp,
                 s.near_plane, s.far_plane, s.width, s.height))
             attrs, ntiles, nowned, bsums, bsums_full = timed("preprocess", lambda: hip_ops.preprocess(
-                s.point_cloud, f, s.point_object_id, s.camera_intrinsics, q_cp, t_cp, ids, s.width, s.height, rb, rs, CULL, s.depth_to_sort_key_scale, counters))
+                s.point_cloud, f, s.point_object_id, s.camera_intrinsics, q_cp, t_cp, ids, s.width, s.height, layout,
+                s.depth_to_sort_key_scale, counters))
             k, n_slots, max_dq, _m = timed("scan_block_sums", lambda: hip_ops.scan_block_sums(bsums, counters, bsums_full))
-            kdb, db, tb = hip_ops.key_layout(s.near_plane, s.far_plane, s.depth_to_sort_key_scale, num_tiles, max_dq)
+            kdb, db, tb = hip_ops.key_layout(s.near_plane, s.far_plane, s.depth_to_sort_key_scale, num_bins, max_dq)
             keys, payload, slot_off = timed("make_keys", lambda: hip_ops.make_keys(
-                attrs, nowned, bsums, k, s.width, s.height, s.depth_to_sort_key_scale, rb, rs, CULL, kdb, ntiles, bsums_full))
+                attrs, nowned, bsums, k, s.width, s.height, s.depth_to_sort_key_scale, layout, kdb, ntiles, bsums_full))
             keys, payload = timed("sort_pairs", lambda: hip_ops.sort_pairs(keys, payload, db, tb, kdb, in_place=False))
-            start, end = timed("tile_ranges", lambda: hip_ops.tile_ranges(keys, num_tiles, kdb))
+            start, end = timed("tile_ranges", lambda: hip_ops.tile_ranges(keys, num_bins, kdb))
             image, depth, acc_alpha, last_eff, count = timed("blend_forward", lambda: hip_ops.blend_forward(
-                start, end, payload, attrs, s.width, s.height, rb, rs))
+                start, end, payload, attrs, s.width, s.height, layout))
             partials, flags, mag = timed("blend_backward", lambda: hip_ops.blend_backward_partials(
-                start, end, payload, attrs, grad_image, acc_alpha, last_eff, slot_off, n_slots, s.width, s.height, rb, rs))
+                start, payload, attrs, grad_image, acc_alpha, last_eff, slot_off, n_slots, s.width, s.height, layout))
             acc = timed("reduce_partials", lambda: hip_ops.reduce_partials(slot_off, ntiles, flags, partials))
             timed("point_backward", lambda: hip_ops.point_backward(
                 s.point_cloud, f, s.point_object_id, s.camera_intrinsics, q_cp, t_cp, s.t_pointcloud_camera, ids,
@@ -202,7 +204,7 @@ def main() -> None:
         sizes = {"N": n, "M": m, "K": int(k), "P": pixels, "tiles": num_tiles}
         stages_ms = {name: sum(a.elapsed_time(b) for a, b in pairs[1:]) / max(len(pairs) - 1, 1)
                      for name, pairs in acc_ms.items()}
-        p_owned = pixels if world == 1 else pixels * len(range(rb, s.height // 16, rs)) / (s.height // 16)
+        p_owned = pixels if world == 1 else pixels * len(layout.owned_rows(s.height)) / (s.height // 16)
         bytes_per = algorithmic_bytes(n, m, int(k), p_owned, 4 if kdb > 0 else 8)
         dominant = max(stages_ms, key=stages_ms.get)
         achieved = bytes_per[dominant] / (stages_ms[dominant] * 1e-3) / 1e9

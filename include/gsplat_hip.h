@@ -19,12 +19,20 @@
  *  - fp32 everywhere, quaternions (x,y,z,w), row-major matrices, image memory [v,u,c].
  *
  * Packed per-visible-point record `attrs` (float[M][16], 64 B, 16-B aligned), produced by
- * gs_preprocess and gathered by the blend kernels (forward: rows 0,2,3; backward: all four):
- *   [0] u  [1] v  [2] z (camera depth)  [3] opacity sigmoid(logit)
- *   [4] conic A  [5] conic B  [6] conic C  [7] rescale          (UTL:257-272)
- *   [8] r  [9] g  [10] b  [11] 3-sigma radius                   (RAS:302-315)
- *   [12] -0.5*A*log2(e)  [13] -B*log2(e)  [14] -0.5*C*log2(e)  [15] opacity*rescale
+ * gs_preprocess and gathered by the blend kernels with 16-B loads (rows 0 and 1 decide whether a list
+ * entry belongs to a tile; forward blends from rows 0,2,3; backward from all four):
+ *   [0] u  [1] v  [2] z (camera depth)  [3] qmax = 2 ln(255 opacity rescale) + 0.01 (exact-cull bound; +inf = off)
+ *   [4] conic A  [5] conic B  [6] conic C  [7] 3-sigma radius   (UTL:257-272, RAS:311-315)
+ *   [8] r  [9] g  [10] b  [11] opacity sigmoid(logit)            (RAS:299-310)
+ *   [12] -0.5*A*log2(e)  [13] -B*log2(e)  [14] -0.5*C*log2(e)  [15] amp = opacity*rescale
  *        (the weight of UTL:275-284 as  amp * 2^(dx*(A'dx + B'dy) + C'dy^2), one v_exp_f32)
+ * Lists.  Sort keys are emitted per BIN of (1 << bin_shift)^2 tiles (bin_shift = 2: 64 x 64 pixels; 0: the
+ * reference's per-tile keys).  A blend workgroup (one 16 x 16 tile) walks its bin's depth-sorted list and keeps,
+ * in order, the entries that belong to its tile: `filter` = GS_FILTER_BOX (the tile lies in the Gaussian's tile
+ * box, RAS:81-103 -- mandatory for bin_shift > 0) | GS_FILTER_CULL (exact contribution test).  The sequence of
+ * Gaussians a tile blends is the reference's per-tile sorted list (minus pairs that cannot contribute).
+ * Tile-row ownership (image-space sharding): rows {tile_row_begin + k*tile_row_step} below tile_row_end
+ * (pass the number of tile rows, or any larger value, for "no upper bound").
  * Backward accumulators `acc` (float[M][12]):
  *   [0..1] dL/duv  [2..4] dL/dcov(00,01,11)  [5..7] dL/drgb  [8] dL/dlogit
  *   [9] sum of |dL/duv| norms  [10] number of affected pixels (int32 bits)  [11] unused
@@ -39,6 +47,8 @@
 extern "C" {
 #endif
 
+#define GS_FILTER_BOX 1
+#define GS_FILTER_CULL 2
 #define GS_TILE_WIDTH 16      /* RAS:27 */
 #define GS_TILE_HEIGHT 16     /* RAS:28 */
 #define GS_BOUNDARY_TILES 3   /* RAS:26 */
@@ -81,10 +91,11 @@ int gs_read_counters(const int32_t *counters, int32_t *host_counters, int n, voi
  * offsets of the backward pass), both int32[ceil(M/256)].  tile_row_begin/tile_row_step
  * restrict the tile box to the tile rows  r = begin + k*step  owned by this GPU (1 GPU: 0,1);
  * num_overlap_tiles (hook output, RAS:1136) is always the full box count of the reference and
- * num_owned_tiles the number of keys this GPU will emit (the one that is scanned).
- * exact_tile_cull != 0 drops (tile, Gaussian) pairs whose alpha is below the 1/255 skip threshold
- * (RAS:451) on every pixel of the tile: such pairs never change a pixel, so every operator output is
- * unchanged while the lists that are sorted and blended get shorter; 0 = the reference's lists.
+ * num_keys the number of sort keys this GPU will emit (one per bin reached in an owned tile row; the one that is
+ * scanned).  exact_tile_cull != 0 drops (bin, Gaussian) pairs whose alpha is below the 1/255 skip threshold
+ * (RAS:451) on every pixel of the bin's tiles inside the Gaussian's box: such pairs never change a pixel, so every
+ * operator output is unchanged while the lists that are sorted get shorter; it also stores the bound in attrs[3] for
+ * the per-tile test of the blend kernels.  0 = every bin of the box, attrs[3] = +inf.
  * n_visible_on_device != 0: n_visible is only the CAPACITY of ids/outputs (e.g. N) and the kernel takes
  * the actual count from counters[GS_COUNTER_NUM_VISIBLE] as written by gs_filter_compact on the same
  * stream -- the host then needs a single size read-back (M, K, slots together) instead of two.
@@ -95,9 +106,9 @@ int gs_preprocess(const float *xyz, float *features, const int32_t *object_id,
                   const float *intrinsics, const float *q_camera_pointcloud,
                   const float *t_camera_pointcloud, const int32_t *ids, int n_visible,
                   int n_visible_on_device, int width, int height, int tile_row_begin,
-                  int tile_row_step, int exact_tile_cull, float depth_scale, int32_t *counters,
-                  float *attrs,
-                  int32_t *num_overlap_tiles, int32_t *num_owned_tiles, int32_t *block_sums,
+                  int tile_row_step, int tile_row_end, int bin_shift, int exact_tile_cull,
+                  float depth_scale, int32_t *counters, float *attrs,
+                  int32_t *num_overlap_tiles, int32_t *num_keys, int32_t *block_sums,
                   int32_t *block_sums_full, void *stream);
 
 /* Exclusive scan of per-block sums (in place) and total -> counters[counter_slot]
@@ -112,17 +123,20 @@ int gs_scan_block_sums2(int32_t *block_sums, int32_t *block_sums_full, int n_blo
 
 /* Sort-key generation.  Replaces generate_point_sort_key_by_num_overlap_tiles (RAS:131-172).
  * payload[k] = offset into the visible list.  Key layout:
- *   key_depth_bits == 0 : uint64 keys[k] = (tile_id << 32) + int32(z * depth_scale)   (reference layout)
- *   key_depth_bits  > 0 : uint32 keys[k] = (tile_id << key_depth_bits) | int32(z * depth_scale)
- *                         same order, valid when 0 <= z*depth_scale < 2^key_depth_bits and the tile
+ *   key_depth_bits == 0 : uint64 keys[k] = (bin_id << 32) + int32(z * depth_scale)   (reference layout; with
+ *                         bin_shift = 0 exactly the reference's keys)
+ *   key_depth_bits  > 0 : uint32 keys[k] = (bin_id << key_depth_bits) | int32(z * depth_scale)
+ *                         same order, valid when 0 <= z*depth_scale < 2^key_depth_bits and the bin
  *                         field fits the remaining bits (halves the sort traffic).
- * exact_tile_cull must be the value passed to gs_preprocess.
- * Also writes slot_offsets int32[M] = exclusive scan of num_overlap_tiles (block_offsets_full = scanned
+ * bin_id = bin_u + bin_v * ceil(tiles_per_row / 2^bin_shift).  Ownership, bin_shift and exact_tile_cull must be
+ * the values passed to gs_preprocess.
+ * Optionally (slot_offsets may be NULL: inference) writes slot_offsets int32[M] = exclusive scan of num_overlap_tiles (block_offsets_full = scanned
  * block_sums_full): slot_offsets[i] + (t1v-t0v)*(tile_u-t0u) + (tile_v-t0v) is the reference's key index
  * of the (Gaussian i, tile) pair (RAS:163-166) and addresses its partial-gradient slot in the backward. */
-int gs_make_keys(const float *attrs, const int32_t *num_owned_tiles, const int32_t *block_offsets,
+int gs_make_keys(const float *attrs, const int32_t *num_keys, const int32_t *block_offsets,
                  int n_visible, int width, int height, int tile_row_begin, int tile_row_step,
-                 int exact_tile_cull, int key_depth_bits, float depth_scale, void *keys,
+                 int tile_row_end, int bin_shift, int exact_tile_cull, int key_depth_bits,
+                 float depth_scale, void *keys,
                  int32_t *payload, const int32_t *num_overlap_tiles,
                  const int32_t *block_offsets_full, int32_t *slot_offsets, void *stream);
 
@@ -138,40 +152,42 @@ int gs_sort_pairs(void *keys, int32_t *payload, void *keys_alt, int32_t *payload
                   int64_t n_keys, int key_depth_bits, int depth_bits, int tile_bits,
                   int allow_result_in_alt, void *workspace, void *stream);
 
-/* Per-tile [start,end) ranges.  Replaces find_tile_start_and_end (RAS:175-193) including the
- * zero-initialisation of RAS:954-957. */
+/* Per-bin [start,end) ranges (n_tiles = number of bins; per tile with bin_shift = 0).  Replaces
+ * find_tile_start_and_end (RAS:175-193) including the zero-initialisation of RAS:954-957. */
 int gs_tile_ranges(const void *keys_sorted, int64_t n_keys, int key_depth_bits,
                    int32_t *tile_start, int32_t *tile_end, int n_tiles, void *stream);
 
 /* Front-to-back alpha blending.  Replaces gaussian_point_rasterisation (RAS:318-485).
- * Tiles with tile row not in {begin + k*step} are skipped (their pixels are left untouched).
+ * bin_start/bin_end: the ranges of gs_tile_ranges; bin_shift/filter: see "Lists" above.
+ * Tiles in tile rows this GPU does not own are skipped (their pixels are left untouched).
  * flags = 0: all five outputs are written for owned tiles (also when n_keys == 0: zeros).
  * GS_BLEND_RGB_ONLY: the reference's rgb_only (RAS:464-469,478-484): depth and valid_count are neither computed nor
  *   written (may be NULL).  GS_BLEND_NO_STATE: acc_alpha and last_effective -- the state only the backward pass
  *   reads -- are neither tracked nor written (may be NULL): the inference path.  The two flags combine.
+ * last_effective = 1 + list position of the last Gaussian blended into the pixel (bin_start of its bin if none).
  * debug_pixel_hits (may be NULL; tests): uint32[H][W][2] = per pixel {number of blended Gaussians, wrap-around sum
  *   of (payload + 1) * 2654435761}; gs_blend_backward fills the same record for the pairs IT treats as blended. */
 #define GS_BLEND_RGB_ONLY 1
 #define GS_BLEND_NO_STATE 2
-int gs_blend_forward(const int32_t *tile_start, const int32_t *tile_end, const int32_t *payload,
+int gs_blend_forward(const int32_t *bin_start, const int32_t *bin_end, const int32_t *payload,
                      const float *attrs, int width, int height, int tile_row_begin,
-                     int tile_row_step, float *image, float *depth, float *acc_alpha,
-                     int32_t *last_effective, int32_t *valid_count, int flags,
-                     uint32_t *debug_pixel_hits, void *stream);
+                     int tile_row_step, int tile_row_end, int bin_shift, int filter, float *image,
+                     float *depth, float *acc_alpha, int32_t *last_effective, int32_t *valid_count,
+                     int flags, uint32_t *debug_pixel_hits, void *stream);
 
 /* Backward per-pixel pass.  Replaces the pixel loop of gaussian_point_rasterisation_backward
  * (RAS:531-705) WITHOUT its global atomics (RAS:674-696): the partial sums of a (Gaussian, tile) pair
  * are stored as one 48-B record (layout of `acc`) in partials[slot] and slot_flags[slot] is raised
  * (slot: see gs_make_keys; n_slots = counters[GS_COUNTER_NUM_SLOTS]; slot_flags is zeroed by the library).
- * alpha is evaluated by the same device function as in gs_blend_forward, so both passes take the same
- * alpha >= 1/255 decision for every (pixel, Gaussian) pair.  flags: GS_BLEND_BACKWARD_V1 selects the round-1 kernel
- * (A/B baseline).  debug_pixel_hits: see gs_blend_forward. */
-#define GS_BLEND_BACKWARD_V1 1
-int gs_blend_backward(const int32_t *tile_start, const int32_t *tile_end, const int32_t *payload,
-                      const float *attrs, const float *grad_image, const float *acc_alpha,
-                      const int32_t *last_effective, const int32_t *slot_offsets, int64_t n_slots,
-                      int width, int height, int tile_row_begin, int tile_row_step, float *partials,
-                      uint8_t *slot_flags, float *magnitude_image, int flags,
+ * The walk starts at the tile-wide maximum of last_effective and runs down to bin_start; bin_shift and filter
+ * must be the forward's.  alpha is evaluated by the same device function as in gs_blend_forward and the staging
+ * filter is the same function on the same records, so both passes treat exactly the same (pixel, Gaussian)
+ * pairs as blended.  debug_pixel_hits: see gs_blend_forward. */
+int gs_blend_backward(const int32_t *bin_start, const int32_t *payload, const float *attrs,
+                      const float *grad_image, const float *acc_alpha, const int32_t *last_effective,
+                      const int32_t *slot_offsets, int64_t n_slots, int width, int height,
+                      int tile_row_begin, int tile_row_step, int tile_row_end, int bin_shift,
+                      int filter, float *partials, uint8_t *slot_flags, float *magnitude_image,
                       uint32_t *debug_pixel_hits, void *stream);
 
 /* Per-Gaussian sum of its flagged slots, in slot order (bitwise reproducible), into acc float[M][12].

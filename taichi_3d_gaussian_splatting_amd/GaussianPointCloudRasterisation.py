@@ -29,7 +29,8 @@ TILE_HEIGHT = 16     # RAS:28
 
 def find_tile_start_and_end(point_in_camera_sort_key: torch.Tensor, tile_points_start: torch.Tensor,
                             tile_points_end: torch.Tensor) -> None:
-    """Same call shape as the reference kernel RAS:175-193: fills the (pre-zeroed) ranges in place."""
+    """Same call shape as the reference kernel RAS:175-193 (int64 keys (tile << 32) + depth): fills the (pre-zeroed)
+    ranges in place."""
     start, end = hip_ops.tile_ranges(point_in_camera_sort_key.contiguous(), tile_points_start.shape[0])
     tile_points_start.copy_(start)
     tile_points_end.copy_(end)
@@ -145,11 +146,15 @@ class GaussianPointCloudRasterisation(torch.nn.Module):
     ):
         super().__init__()
         self.config = config
-        # image-space sharding (multi-GPU): this instance renders tile rows begin, begin+step, ...
+        # image-space sharding (multi-GPU): this instance renders tile rows begin, begin+step, ... below end
         self.tile_row_begin = 0
         self.tile_row_step = 1
-        # drop (tile, Gaussian) pairs that cannot reach alpha >= 1/255 anywhere in the tile (output-identical)
+        self.tile_row_end = hip_ops._NO_ROW_LIMIT
+        # drop (bin | tile, Gaussian) pairs that cannot reach alpha >= 1/255 anywhere in the bin | tile (output-identical)
         self.exact_tile_cull = True
+        # sort keys per bin of (1 << bin_shift)^2 tiles (2: 64 x 64 pixels; 0: per tile as the reference); the blend
+        # kernels recover each tile's list from its bin's list, in order (hip_ops.ListLayout)
+        self.bin_shift = 2
         outer = self
 
         class _module_function(torch.autograd.Function):
@@ -173,7 +178,9 @@ class GaussianPointCloudRasterisation(torch.nn.Module):
                          q_pointcloud_camera, t_pointcloud_camera, camera_info, color_max_sh_band, need_state):
                 cfg = outer.config
                 width, height = camera_info.camera_width, camera_info.camera_height
-                row_begin, row_step = outer.tile_row_begin, outer.tile_row_step
+                layout = hip_ops.ListLayout(bin_shift=outer.bin_shift, exact_cull=outer.exact_tile_cull,
+                                            row_begin=outer.tile_row_begin, row_step=outer.tile_row_step,
+                                            row_end=outer.tile_row_end)
                 if not pointcloud_features.is_contiguous():
                     raise ValueError("point_cloud_features must be contiguous (it is normalised in place)")
                 if pointcloud_features.dtype != torch.float32 or pointcloud_features.shape[1] != 56:
@@ -192,10 +199,9 @@ class GaussianPointCloudRasterisation(torch.nn.Module):
                     xyz, invalid, obj, intrinsics, q_cp, t_cp, cfg.near_plane, cfg.far_plane, width, height,
                     sync=False)
                 # RAS:887-911  per-point projection + tile counts (launched for the capacity N)
-                cull = outer.exact_tile_cull
                 attrs, num_overlap_tiles, num_owned_tiles, block_sums, block_sums_full = hip_ops.preprocess(
-                    xyz, pointcloud_features, obj, intrinsics, q_cp, t_cp, ids, width, height, row_begin, row_step,
-                    cull, cfg.depth_to_sort_key_scale, counters, n_visible_on_device=True)
+                    xyz, pointcloud_features, obj, intrinsics, q_cp, t_cp, ids, width, height, layout,
+                    cfg.depth_to_sort_key_scale, counters, n_visible_on_device=True)
                 # RAS:913-922  scans; ONE host read-back for M, K, the slot count and the depth range
                 # (the reference syncs twice: RAS:870 and RAS:916)
                 n_keys, n_slots, max_depth_key, m = hip_ops.scan_block_sums(block_sums, counters, block_sums_full)
@@ -203,18 +209,18 @@ class GaussianPointCloudRasterisation(torch.nn.Module):
                 ids, attrs, num_overlap_tiles, num_owned_tiles = ids[:m], attrs[:m], num_overlap_tiles[:m], \
                     num_owned_tiles[:m]
                 block_sums, block_sums_full = block_sums[:nb], block_sums_full[:nb]
-                # RAS:927-945  keys
-                num_tiles = (width // TILE_WIDTH) * (height // TILE_HEIGHT)
+                # RAS:927-945  keys: one per (bin, Gaussian)
+                num_bins = layout.num_bins(width, height)
                 key_depth_bits, depth_bits, tile_bits = hip_ops.key_layout(
-                    cfg.near_plane, cfg.far_plane, cfg.depth_to_sort_key_scale, num_tiles, max_depth_key)
+                    cfg.near_plane, cfg.far_plane, cfg.depth_to_sort_key_scale, num_bins, max_depth_key)
                 keys, payload, slot_offsets = hip_ops.make_keys(
                     attrs, num_owned_tiles, block_sums, n_keys, width, height, cfg.depth_to_sort_key_scale,
-                    row_begin, row_step, cull, key_depth_bits, num_overlap_tiles, block_sums_full)
+                    layout, key_depth_bits, num_overlap_tiles, block_sums_full)
                 # RAS:947-950  sort (stable)
                 keys, payload = hip_ops.sort_pairs(keys, payload, depth_bits, tile_bits, key_depth_bits,
                                                    in_place=False)
-                # RAS:952-964  tile ranges
-                tile_start, tile_end = hip_ops.tile_ranges(keys, num_tiles, key_depth_bits)
+                # RAS:952-964  list ranges (per bin)
+                tile_start, tile_end = hip_ops.tile_ranges(keys, num_bins, key_depth_bits)
                 del keys
                 # RAS:967-997  blend.  rgb_only (RAS:464-469,478-484): depth and count are not computed -- the reference
                 # returns uninitialised memory for them, this operator zeros.  The state the backward pass reads
@@ -222,7 +228,7 @@ class GaussianPointCloudRasterisation(torch.nn.Module):
                 # where the reference's backward would read garbage -- and skipped otherwise (inference).
                 rgb_only = bool(cfg.rgb_only)
                 image, depth, acc_alpha, last_eff, count = hip_ops.blend_forward(
-                    tile_start, tile_end, payload, attrs, width, height, row_begin, row_step,
+                    tile_start, tile_end, payload, attrs, width, height, layout,
                     rgb_only=rgb_only, need_state=need_state)
                 if rgb_only:
                     depth = torch.zeros((height, width), dtype=torch.float32, device=xyz.device)
@@ -233,13 +239,13 @@ class GaussianPointCloudRasterisation(torch.nn.Module):
                     ctx.mark_non_differentiable(count)
                     return image, depth, count
 
-                ctx.save_for_backward(xyz, pointcloud_features, payload, ids, tile_start, tile_end, acc_alpha,
+                ctx.save_for_backward(xyz, pointcloud_features, payload, ids, tile_start, acc_alpha,
                                       last_eff, num_overlap_tiles, obj, q_cp, t_cp, t_pc, attrs, intrinsics,
                                       slot_offsets, visible_mask, num_owned_tiles)
                 ctx.n_slots = n_slots
                 ctx.camera_info = camera_info
                 ctx.color_max_sh_band = color_max_sh_band
-                ctx.tile_rows = (row_begin, row_step)
+                ctx.layout = layout
                 ctx.mark_non_differentiable(count)
                 ctx.set_materialize_grads(False)  # no zero-filled dL/ddepth (it is ignored, RAS:1027)
                 return image, depth, count
@@ -252,18 +258,17 @@ class GaussianPointCloudRasterisation(torch.nn.Module):
                         (ctx.camera_info.camera_height, ctx.camera_info.camera_width, 3), dtype=torch.float32,
                         device=ctx.saved_tensors[0].device)
                 if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:  # RAS:1028
-                    (xyz, features, payload, ids, tile_start, tile_end, acc_alpha, last_eff, num_overlap_tiles,
+                    (xyz, features, payload, ids, tile_start, acc_alpha, last_eff, num_overlap_tiles,
                      obj, q_cp, t_cp, t_pc, attrs, intrinsics, slot_offsets, visible_mask,
                      num_owned_tiles) = ctx.saved_tensors
                     cfg = outer.config
                     camera_info = ctx.camera_info
                     width, height = camera_info.camera_width, camera_info.camera_height
-                    row_begin, row_step = ctx.tile_rows
                     hook = backward_valid_point_hook
                     # RAS:531-705  per-pixel pass
                     acc, magnitude_image = hip_ops.blend_backward(
-                        tile_start, tile_end, payload, attrs, grad_rasterized_image, acc_alpha, last_eff,
-                        slot_offsets, num_overlap_tiles, ctx.n_slots, width, height, row_begin, row_step)
+                        tile_start, payload, attrs, grad_rasterized_image, acc_alpha, last_eff,
+                        slot_offsets, num_overlap_tiles, ctx.n_slots, width, height, ctx.layout)
                     if outer.grad_accumulator_reduce is not None:  # multi-GPU: sum partial tile gradients
                         outer.grad_accumulator_reduce(acc)
                     # RAS:707-772 + 1102-1125  per-point pass, band clearing and factors fused

@@ -1,8 +1,10 @@
 // gs_blend.hip -- per-tile alpha blending, forward and backward, for gfx950 (wave64).
 //
 // Workgroup = one 16x16 tile = 2 wavefronts; every lane owns two horizontally adjacent pixels (a wave
-// covers 8 rows x 16 columns).  The tile's depth-sorted Gaussian list is staged through LDS in batches
-// of 128 packed records (3 x float4 per Gaussian, gathered with 16-B loads).
+// covers 8 rows x 16 columns).  Lists are sorted per BIN of (1 << bin_shift)^2 tiles (gs_make_keys); a tile walks its
+// bin's depth-sorted list, keeps the entries that belong to it (tile box of RAS:81-103 + exact contribution test,
+// gs_entry_in_tile) with an ORDER-PRESERVING compaction (wave ballots + mbcnt) and stages up to 128 packed records
+// (16-B gathers) in LDS per blend round -- the sequence a tile blends is exactly the reference's per-tile list.
 //  forward : front-to-back blend (RAS:318-485, weight UTL:275-284); 2 waves per tile, two pixels per lane
 //            on packed fp32 math; whole-tile early exit with a workgroup vote (the reference could not
 //            express it, RAS:387-394).
@@ -82,27 +84,87 @@ __device__ __forceinline__ v2f gs_pair_alpha(const float4 p, const float4 q, con
 }
 __device__ __forceinline__ unsigned long long gs_ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 
-constexpr int FWD_THREADS = 128;
-constexpr int FWD_BATCH = 128;
+constexpr int BLEND_THREADS = 128;
+constexpr int BATCH = 128;               // staged (kept) entries per blend round
+constexpr int FILL_PER_THREAD = 1;       // list entries examined per thread and fill step (2: +10 VGPRs, one wave/SIMD less)
+constexpr int FILL = BLEND_THREADS * FILL_PER_THREAD;
 constexpr unsigned GS_HASH_MUL = 2654435761u;
 
+// One fill step of the list staging, shared by both kernels.  The workgroup examines FILL consecutive list positions
+// (ascending from `pos` when DIR = +1, descending from `pos` when DIR = -1, bounded by `limit`), keeps the entries that
+// belong to the tile and appends them IN LIST ORDER behind the `nbuf` entries already staged; at most BATCH - nbuf are
+// accepted and the walk resumes at the first entry that did not fit.  Returns through `pos` / `nbuf` (uniform).
+// keep(row0, row1) is the membership test; store(slot, j, o, rows) writes a kept entry to the kernel's LDS arrays.
+// Two barriers per step.  s_cnt: int[4], s_next: int[1] in LDS.
+template <int DIR, typename Keep, typename Store>
+__device__ __forceinline__ void gs_fill_step(const int32_t *__restrict__ payload, const float4 *__restrict__ attrs,
+                                             int &pos, int limit, int &nbuf, int *s_cnt, int *s_next, Keep keep,
+                                             Store store) {
+    const int tid = threadIdx.x, w = tid >> 6;
+    int j[FILL_PER_THREAD], o[FILL_PER_THREAD];
+    float4 r[FILL_PER_THREAD][4];
+    bool kept[FILL_PER_THREAD];
+    unsigned long long bal[FILL_PER_THREAD];
+#pragma unroll
+    for (int h = 0; h < FILL_PER_THREAD; ++h) {
+        j[h] = pos + DIR * (h * BLEND_THREADS + tid);
+        const bool valid = DIR > 0 ? j[h] < limit : j[h] >= limit;
+        o[h] = valid ? payload[j[h]] : 0;
+        kept[h] = valid;
+    }
+#pragma unroll
+    for (int h = 0; h < FILL_PER_THREAD; ++h) {
+        const float4 *g = attrs + 4 * (size_t)o[h];
+        if (kept[h]) { r[h][0] = g[0]; r[h][1] = g[1]; r[h][2] = g[2]; r[h][3] = g[3]; }
+    }
+#pragma unroll
+    for (int h = 0; h < FILL_PER_THREAD; ++h) {
+        kept[h] = kept[h] && keep(r[h][0], r[h][1]);
+        bal[h] = gs_ballot(kept[h]);
+        if ((tid & 63) == 0) s_cnt[2 * h + w] = __popcll(bal[h]);
+    }
+    __syncthreads();
+    int before = nbuf;   // staged entries ahead of this half-step's first wave
+#pragma unroll
+    for (int h = 0; h < FILL_PER_THREAD; ++h) {
+        const int c0 = s_cnt[2 * h], c1 = s_cnt[2 * h + 1];
+        const int slot = before + (w ? c0 : 0) + gs_mbcnt(bal[h]);
+        if (kept[h]) {
+            if (slot < BATCH) store(slot, j[h], o[h], r[h]);
+            else if (slot == BATCH) *s_next = j[h];   // first entry that does not fit: the walk resumes here
+        }
+        before += c0 + c1;
+    }
+    __syncthreads();
+    // s_next is written (by exactly one thread) and read only when the step overflowed the batch -- and then the fill
+    // loop ends, so the next write is at least one more barrier away from this read
+    pos = before > BATCH ? *s_next : pos + DIR * FILL;
+    nbuf = min(before, BATCH);
+}
+
+// ------------------------------------------------------------------------------- forward
 // AUX:   depth and per-pixel count are produced (off with rgb_only, RAS:464-469,478-484)
 // STATE: acc_alpha / last_effective are produced (what the backward pass needs; off for inference)
 // DEBUG: per-pixel {number of blended Gaussians, wrap-around sum of (payload+1)*GS_HASH_MUL} -> debug_hits (tests)
 template <bool AUX, bool STATE, bool DEBUG>
-__global__ __launch_bounds__(FWD_THREADS) void blend_forward_kernel(
-    const int32_t *__restrict__ tile_start, const int32_t *__restrict__ tile_end,
+__global__ __launch_bounds__(BLEND_THREADS) void blend_forward_kernel(
+    const int32_t *__restrict__ bin_start, const int32_t *__restrict__ bin_end,
     const int32_t *__restrict__ payload, const float4 *__restrict__ attrs, int width, int height, int row_begin,
-    int row_step, float *__restrict__ image, float *__restrict__ depth, float *__restrict__ acc_alpha,
-    int32_t *__restrict__ last_effective, int32_t *__restrict__ valid_count, uint32_t *__restrict__ debug_hits) {
-    __shared__ float4 s_p[FWD_BATCH], s_c[FWD_BATCH], s_q[FWD_BATCH];  // rows 0, 2, 3 of the record
-    __shared__ int s_o[DEBUG ? FWD_BATCH : 1];
-    const int tw = width / GS_TILE_WIDTH;
+    int row_step, int bin_shift, int filter, float *__restrict__ image, float *__restrict__ depth,
+    float *__restrict__ acc_alpha, int32_t *__restrict__ last_effective, int32_t *__restrict__ valid_count,
+    uint32_t *__restrict__ debug_hits) {
+    __shared__ float4 s_p[BATCH], s_c[BATCH], s_q[BATCH];  // rows 0, 2, 3 of the kept records
+    __shared__ int s_j[BATCH];                             // their list positions (last_effective is one of them + 1)
+    __shared__ int s_o[DEBUG ? BATCH : 1];
+    __shared__ int s_cnt[2 * FILL_PER_THREAD], s_next[1];
+    const int tw = width / GS_TILE_WIDTH, th = height / GS_TILE_HEIGHT;
     const TileCoord tc = owned_tile(tw, row_begin, row_step);
     const int tid = threadIdx.x;
     const int pu = tc.tile_u * GS_TILE_WIDTH + 2 * (tid & 7);   // left pixel of the pair
     const int pv = tc.tile_v * GS_TILE_HEIGHT + (tid >> 3);
-    const int start = tile_start[tc.tile_id], end = tile_end[tc.tile_id];
+    const int bins_u = (tw + (1 << bin_shift) - 1) >> bin_shift;
+    const int bin = (tc.tile_u >> bin_shift) + (tc.tile_v >> bin_shift) * bins_u;
+    const int start = bin_start[bin], end = bin_end[bin];
     const v2f px = {(float)pu + 0.5f, (float)pu + 1.5f};
     const float py = (float)pv + 0.5f;
 
@@ -113,26 +175,32 @@ __global__ __launch_bounds__(FWD_THREADS) void blend_forward_kernel(
     int last0 = start, last1 = start, cnt0 = 0, cnt1 = 0;
     unsigned dh0 = 0u, dh1 = 0u, dc0 = 0u, dc1 = 0u;
 
-    for (int base = start; base < end; base += FWD_BATCH) {
-        // barrier (protects the LDS batch) + whole-tile early exit vote
+    auto keep = [&](const float4 r0, const float4 r1) {
+        return gs_entry_in_tile(r0, r1, tc.tile_u, tc.tile_v, tw, th, filter);
+    };
+    auto store = [&](int slot, int j, int o, const float4 *r) {
+        s_p[slot] = r[0]; s_c[slot] = r[2]; s_q[slot] = r[3];
+        s_j[slot] = j;
+        if (DEBUG) s_o[slot] = o;
+    };
+
+    int pos = start;
+    while (pos < end) {
+        // barrier (protects the staged batch) + whole-tile early exit vote
         if (__syncthreads_and((alive.x + alive.y == 0.f) ? 1 : 0)) break;
-        const int j = base + tid;
-        if (j < end) {
-            const int o = payload[j];
-            const float4 *g = attrs + 4 * (size_t)o;
-            s_p[tid] = g[0];
-            s_c[tid] = g[2];
-            s_q[tid] = g[3];
-            if (DEBUG) s_o[tid] = o;
-        } else {  // padding record: amplitude 0 -> alpha 0, never blended
-            s_p[tid] = make_float4(0.f, 0.f, 0.f, 0.f);
-            s_q[tid] = make_float4(0.f, 0.f, 0.f, 0.f);
+        int nbuf = 0;
+        while (nbuf < BATCH && pos < end) gs_fill_step<+1>(payload, attrs, pos, end, nbuf, s_cnt, s_next, keep, store);
+        {   // pad to a multiple of GROUP with inert records (amplitude 0 -> alpha 0, never blended)
+            const int padded = (nbuf + GROUP - 1) & ~(GROUP - 1);
+            if (tid < padded - nbuf) {
+                s_p[nbuf + tid] = make_float4(0.f, 0.f, 0.f, 0.f);
+                s_q[nbuf + tid] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
         }
         __syncthreads();
-        const int n = min(FWD_BATCH, end - base);
         // Entries are evaluated in groups of GROUP: the LDS reads and the exp of a group are independent
         // and overlap (the per-pixel blend recurrence is the only serial part), which hides their latency.
-        for (int k = 0; k < n; k += GROUP) {
+        for (int k = 0; k < nbuf; k += GROUP) {
             if (gs_ballot(alive.x + alive.y != 0.f) == 0ull) break;  // every pixel of this wave is saturated
             v2f alpha[GROUP];
             float z[GROUP];
@@ -175,7 +243,7 @@ __global__ __launch_bounds__(FWD_THREADS) void blend_forward_kernel(
                 }
                 T = Tn;
                 if (STATE) {
-                    const int idx = base + k + i + 1;
+                    const int idx = s_j[k + i] + 1;
                     last0 = ok0 ? idx : last0;
                     last1 = ok1 ? idx : last1;
                 }
@@ -209,192 +277,33 @@ __global__ __launch_bounds__(FWD_THREADS) void blend_forward_kernel(
 }
 
 // ------------------------------------------------------------------------------- backward
-// Workgroup = one tile = 2 wave64s, every lane owns two horizontally adjacent pixels (as in the forward
-// kernel).  Doubling the pixels per lane halves the number of cross-lane reductions, LDS record reads and
-// per-entry uniform work per pixel; the kernel is bound by VALU issue, and the 10-value reduction is a third
-// of the per-hit cost.  Per batch of 128 list entries the two waves combine their partial sums in LDS
-// (ds_add_f32), then thread k stores entry k's 48-B record into its (Gaussian, tile) slot (plain stores).
-constexpr int BWD_THREADS = 128;
-constexpr int BWD_BATCH = 128;
-
-// ---- v1 (round 1): alpha from rows 0/1 by exp2(-0.5 d.m log2e) * rescale * opacity; ten values reduced, the pixel
-// count through an integer LDS atomic.  Kept selectable (GS_BLEND_BACKWARD_V1) as the A/B baseline of v2 below.
-__global__ __launch_bounds__(BWD_THREADS) void blend_backward_kernel_v1(
-    const int32_t *__restrict__ tile_start, const int32_t *__restrict__ tile_end,
-    const int32_t *__restrict__ payload, const float4 *__restrict__ attrs, const float *__restrict__ grad_image,
-    const float *__restrict__ acc_alpha, const int32_t *__restrict__ last_effective, int width, int height,
-    int row_begin, int row_step, const int32_t *__restrict__ slot_offsets, float4 *__restrict__ partials,
-    uint8_t *__restrict__ slot_flags, float *__restrict__ magnitude_image) {
-    __shared__ float4 s_a[BWD_BATCH], s_b[BWD_BATCH], s_c[BWD_BATCH];
-    __shared__ int s_o[BWD_BATCH];
-    __shared__ float s_acc[BWD_BATCH][GS_ACC_STRIDE];  // [entry][value]; slot 10 = pixel count (int bits)
-    __shared__ int s_max[BWD_THREADS / GS_WAVE];
-    const int tw = width / GS_TILE_WIDTH;
-    const TileCoord tc = owned_tile(tw, row_begin, row_step);
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int pu = tc.tile_u * GS_TILE_WIDTH + 2 * (tid & 7);  // left pixel of the pair
-    const int pv = tc.tile_v * GS_TILE_HEIGHT + (tid >> 3);
-    const size_t p = (size_t)pv * width + pu;
-    const int start = tile_start[tc.tile_id];
-    const v2f px = {(float)pu + 0.5f, (float)pu + 1.5f};
-    const float py = (float)pv + 0.5f;
-
-    const int last0 = last_effective[p], last1 = last_effective[p + 1];
-    v2f T = {1.0f - acc_alpha[p], 1.0f - acc_alpha[p + 1]};
-    // S = sum_{j behind i} (c_j . G) a_j T_j: the reference keeps the colour-space suffix sum w_i (RAS:652-656)
-    // and dots it with dL/dimage; only that dot product is ever used, so the scalar is carried instead
-    // (same quantity re-associated: 6 instead of 12 flops per hit).
-    v2f S = splat(0.f);
-    const float *gi = grad_image + 3 * p;
-    const v2f Gr = {gi[0], gi[3]}, Gg = {gi[1], gi[4]}, Gb = {gi[2], gi[5]};
-    v2f mag_u = splat(0.f), mag_v = splat(0.f);
-
-    // no pixel of the tile touches an entry at or beyond the tile-wide max of `last`
-    int mx = max(last0, last1);
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) mx = max(mx, __shfl_xor(mx, d, GS_WAVE));
-    const int wave_end = mx;  // no pixel of THIS wave touches an entry at or beyond wave_end
-    if (lane == 0) s_max[tid >> 6] = mx;
-    __syncthreads();
-    const int end = max(s_max[0], s_max[1]);
-
-    for (int top = end; top > start; top -= BWD_BATCH) {
-        __syncthreads();  // previous batch fully flushed before its LDS is reused
-        const int j = top - 1 - tid;
-        if (j >= start) {
-            const int o = payload[j];
-            const float4 *g = attrs + 4 * (size_t)o;
-            s_a[tid] = g[0];
-            s_b[tid] = g[1];
-            s_c[tid] = g[2];
-            s_o[tid] = o;
-        } else {  // padding record: opacity 0 -> never a hit
-            s_a[tid] = make_float4(0.f, 0.f, 0.f, 0.f);
-            s_b[tid] = make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-        {
-            float4 *z = reinterpret_cast<float4 *>(&s_acc[tid][0]);
-            z[0] = make_float4(0.f, 0.f, 0.f, 0.f);
-            z[1] = make_float4(0.f, 0.f, 0.f, 0.f);
-            z[2] = make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-        __syncthreads();
-        const int n = min(BWD_BATCH, top - start);
-        for (int k = 0; k < n; k += GROUP) {
-            if (top - 1 - (k + GROUP - 1) >= wave_end) continue;  // the whole group lies behind this wave's pixels
-            // group evaluation: LDS reads + exp of GROUP entries are independent and overlap
-            v2f g[GROUP], m0[GROUP], m1[GROUP], pa[GROUP];
-            float op[GROUP];
-#pragma unroll
-            for (int i = 0; i < GROUP; ++i) {
-                const float4 a = s_a[k + i], b = s_b[k + i];
-                const v2f dx = px - splat(a.x);
-                const float dy = py - a.y;
-                // UTL:331-348: m = conic @ d, exponent = -0.5 d.m
-                m0[i] = fma2(dx, splat(b.x), splat(b.y * dy));
-                m1[i] = fma2(dx, splat(b.y), splat(b.z * dy));
-                const v2f e = fma2(dx, m0[i], splat(dy) * m1[i]) * splat(-0.5f * 1.4426950408889634f);
-                g[i] = (v2f){__builtin_amdgcn_exp2f(e.x), __builtin_amdgcn_exp2f(e.y)} * splat(b.w);
-                op[i] = a.w;
-                pa[i] = g[i] * splat(a.w);
-            }
-#pragma unroll
-            for (int i = 0; i < GROUP; ++i) {
-                const int jj = top - 1 - (k + i);
-                const bool hit0 = (jj < last0) && (pa[i].x >= EPS_ALPHA);
-                const bool hit1 = (jj < last1) && (pa[i].y >= EPS_ALPHA);
-                const unsigned long long hits0 = __ballot(hit0), hits1 = __ballot(hit1);
-                if ((hits0 | hits1) == 0ull) continue;  // wave-uniform skip: no pixel of this wave is touched
-                // alpha = 0 for a pixel that is not hit makes its whole update an exact no-op
-                // (1/(1-0) = 1, a*T = 0); only dL/dalpha needs an explicit mask.
-                const v2f h = {hit0 ? 1.f : 0.f, hit1 ? 1.f : 0.f};
-                const v2f alpha = {hit0 ? __builtin_amdgcn_fmed3f(pa[i].x, 0.f, CLAMP_ALPHA) : 0.f,
-                                   hit1 ? __builtin_amdgcn_fmed3f(pa[i].y, 0.f, CLAMP_ALPHA) : 0.f};
-                const v2f one_m = splat(1.f) - alpha;
-                const v2f inv1m = {__builtin_amdgcn_rcpf(one_m.x), __builtin_amdgcn_rcpf(one_m.y)};
-                T = T * inv1m;  // RAS:643, T_i = T_{i+1} / (1 - alpha_i)
-                const v2f aT = alpha * T;
-                const float4 c = s_c[k + i];
-                const v2f gr = aT * Gr, gg = aT * Gg, gb = aT * Gb;
-                // dL/dalpha = sum_c (c_c T - w_c/(1-alpha)) G_c = T (c.G) - S/(1-alpha)       (RAS:652-657)
-                const v2f cg = fma2(splat(c.z), Gb, fma2(splat(c.y), Gg, splat(c.x) * Gr));
-                const v2f dLda = fma2(T, cg, -(S * inv1m)) * h;
-                S = fma2(cg, aT, S);
-                // w = dL/dg * g.  dL/dlogit = dL/dalpha * g * o(1-o) = (1-o) w and the factor 1/2 of dg/dcov are
-                // per-Gaussian constants: they are applied once per (tile, Gaussian) in the flush, after the sum.
-                const v2f w = dLda * splat(op[i]) * g[i];
-                const v2f v0 = w * m0[i], v1 = w * m1[i];  // dL/dmu = dL/dg * g * (conic @ d)   (UTL:343)
-                mag_u = mag_u + (v2f){fabsf(v0.x), fabsf(v0.y)};
-                mag_v = mag_v + (v2f){fabsf(v1.x), fabsf(v1.y)};
-                const v2f c00 = v0 * m0[i], c01 = v0 * m1[i], c11 = v1 * m1[i];  // 2 dL/dcov (UTL:345-346)
-                const v2f gl = w;
-                const v2f n2 = fma2(v1, v1, v0 * v0);
-                const v2f nv = {__builtin_amdgcn_sqrtf(n2.x), __builtin_amdgcn_sqrtf(n2.y)};  // v_sqrt_f32, 1 ulp
-                // in-lane pair sums, then the 10-value reduce-scatter over the 64 lanes (gs_common.h); row
-                // totals land in lane 15 of each row: t0: (v0, c00, v1, c01)  t1: (c11, gg, gr, gb)  t2: (gl, gl, nv, nv)
-                float t0, t1, t2;
-                gs_wave_reduce10(v0.x + v0.y, v1.x + v1.y, c00.x + c00.y, c01.x + c01.y, c11.x + c11.y, gr.x + gr.y,
-                                 gg.x + gg.y, gb.x + gb.y, gl.x + gl.y, nv.x + nv.y, t0, t1, t2);
-                if ((lane & 15) == 15) {
-                    const int row = lane >> 4;
-                    const int slot = ((row & 1) << 1) | (row >> 1);  // rows (0,1,2,3) -> slots (0,2,1,3)
-                    float *A = &s_acc[k + i][0];
-                    atomicAdd(A + slot, t0);
-                    atomicAdd(A + 4 + slot, t1);
-                    if ((row & 1) == 0) atomicAdd(A + 8 + (row >> 1), t2);
-                    if (row == 3)
-                        atomicAdd(reinterpret_cast<int *>(A + 10), (int)(__popcll(hits0) + __popcll(hits1)));
-                }
-            }
-        }
-        __syncthreads();
-        // flush: thread k owns entry k of the batch -> one 48-B store into the (Gaussian, tile) slot
-        if (tid < n) {
-            const int npix = __builtin_bit_cast(int, s_acc[tid][10]);
-            if (npix > 0) {
-                const float4 a = s_a[tid];
-                int t0u, t1u, t0v, t1v;
-                gs_tile_box(a.x, a.y, s_c[tid].w, tw, height / GS_TILE_HEIGHT, t0u, t1u, t0v, t1v);
-                const int slot = slot_offsets[s_o[tid]] + (t1v - t0v) * (tc.tile_u - t0u) + (tc.tile_v - t0v);
-                const float4 *S = reinterpret_cast<const float4 *>(&s_acc[tid][0]);
-                float4 *dst = partials + 3 * (size_t)slot;
-                float4 r0 = S[0], r1 = S[1], r2 = S[2];
-                r0.z *= 0.5f; r0.w *= 0.5f; r1.x *= 0.5f;  // dg/dcov = 0.5 g (m m^T)
-                r2.x *= (1.f - a.w);                       // dL/dlogit = (1 - opacity) * sum(w)
-                dst[0] = r0;
-                dst[1] = r1;
-                dst[2] = r2;
-                slot_flags[slot] = 1;
-            }
-        }
-    }
-    magnitude_image[2 * p] = mag_u.x;
-    magnitude_image[2 * p + 1] = mag_v.x;
-    magnitude_image[2 * p + 2] = mag_u.y;
-    magnitude_image[2 * p + 3] = mag_v.y;
-}
-
-// ---- v2: alpha by gs_pair_alpha (the forward's expression: identical hit decisions), conic products only on the hit
-// path, w = dL/dalpha * alpha_unclamped (= dL/dg * g, UTL:343), twelve-value reduce-scatter that carries the pixel
-// count as a float (exact below 2^24) so that all three result registers take the same LDS path.
+// Workgroup = one tile = 2 wave64s, every lane owns two horizontally adjacent pixels (as in the forward kernel).
+// Doubling the pixels per lane halves the number of cross-lane reductions, LDS record reads and per-entry uniform work
+// per pixel; the kernel is bound by VALU issue.  alpha comes from gs_pair_alpha (the forward's expression: identical hit
+// decisions), the conic products are formed only on the hit path, w = dL/dalpha * alpha_unclamped (= dL/dg * g,
+// UTL:343), and the twelve-value reduce-scatter carries the pixel count as a float (exact below 2^24).  Per round of up
+// to 128 staged entries the two waves combine their partial sums in LDS (ds_add_f32), then thread k stores entry k's
+// 48-B record into its (Gaussian, tile) slot (plain stores).
 template <bool DEBUG>
-__global__ __launch_bounds__(BWD_THREADS) void blend_backward_kernel(
-    const int32_t *__restrict__ tile_start, const int32_t *__restrict__ tile_end,
-    const int32_t *__restrict__ payload, const float4 *__restrict__ attrs, const float *__restrict__ grad_image,
-    const float *__restrict__ acc_alpha, const int32_t *__restrict__ last_effective, int width, int height,
-    int row_begin, int row_step, const int32_t *__restrict__ slot_offsets, float4 *__restrict__ partials,
+__global__ __launch_bounds__(BLEND_THREADS) void blend_backward_kernel(
+    const int32_t *__restrict__ bin_start, const int32_t *__restrict__ payload,
+    const float4 *__restrict__ attrs, const float *__restrict__ grad_image, const float *__restrict__ acc_alpha,
+    const int32_t *__restrict__ last_effective, int width, int height, int row_begin, int row_step, int bin_shift,
+    int filter, const int32_t *__restrict__ slot_offsets, float4 *__restrict__ partials,
     uint8_t *__restrict__ slot_flags, float *__restrict__ magnitude_image, uint32_t *__restrict__ debug_hits) {
-    __shared__ float4 s_p[BWD_BATCH], s_b[BWD_BATCH], s_c[BWD_BATCH], s_q[BWD_BATCH];  // rows 0..3 of the record
-    __shared__ int s_o[BWD_BATCH];
-    __shared__ float s_acc[BWD_BATCH][GS_ACC_STRIDE];  // [entry][value]; value 10 = pixel count (as a float)
-    __shared__ int s_max[BWD_THREADS / GS_WAVE];
-    const int tw = width / GS_TILE_WIDTH;
+    __shared__ float4 s_p[BATCH], s_b[BATCH], s_c[BATCH], s_q[BATCH];  // rows 0..3 of the kept records
+    __shared__ int s_j[BATCH], s_o[BATCH];
+    __shared__ float s_acc[BATCH][GS_ACC_STRIDE];  // [entry][value]; value 10 = pixel count (as a float)
+    __shared__ int s_max[BLEND_THREADS / GS_WAVE];
+    __shared__ int s_cnt[2 * FILL_PER_THREAD], s_next[1];
+    const int tw = width / GS_TILE_WIDTH, th = height / GS_TILE_HEIGHT;
     const TileCoord tc = owned_tile(tw, row_begin, row_step);
     const int tid = threadIdx.x, lane = tid & 63;
     const int pu = tc.tile_u * GS_TILE_WIDTH + 2 * (tid & 7);  // left pixel of the pair
     const int pv = tc.tile_v * GS_TILE_HEIGHT + (tid >> 3);
     const size_t p = (size_t)pv * width + pu;
-    const int start = tile_start[tc.tile_id];
+    const int bins_u = (tw + (1 << bin_shift) - 1) >> bin_shift;
+    const int start = bin_start[(tc.tile_u >> bin_shift) + (tc.tile_v >> bin_shift) * bins_u];
     const v2f px = {(float)pu + 0.5f, (float)pu + 1.5f};
     const float py = (float)pv + 0.5f;
 
@@ -409,11 +318,11 @@ __global__ __launch_bounds__(BWD_THREADS) void blend_backward_kernel(
     v2f mag_u = splat(0.f), mag_v = splat(0.f);
     unsigned dh0 = 0u, dh1 = 0u, dc0 = 0u, dc1 = 0u;
 
-    // no pixel of the tile touches an entry at or beyond the tile-wide max of `last`
+    // no pixel of the tile touches a list position at or beyond the tile-wide max of `last`
     int mx = max(last0, last1);
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) mx = max(mx, __shfl_xor(mx, d, GS_WAVE));
-    const int wave_end = mx;  // no pixel of THIS wave touches an entry at or beyond wave_end
+    const int wave_end = mx;  // no pixel of THIS wave touches a position at or beyond wave_end
     if (lane == 0) s_max[tid >> 6] = mx;
     __syncthreads();
     const int end = max(s_max[0], s_max[1]);
@@ -422,31 +331,35 @@ __global__ __launch_bounds__(BWD_THREADS) void blend_backward_kernel(
     const int slot = ((row & 1) << 1) | (row >> 1);  // rows (0,1,2,3) -> values (0,2,1,3) of each result register
     const bool row_tail = (lane & 15) == 15;
 
-    for (int top = end; top > start; top -= BWD_BATCH) {
-        __syncthreads();  // previous batch fully flushed before its LDS is reused
-        const int j = top - 1 - tid;
-        if (j >= start) {
-            const int o = payload[j];
-            const float4 *g = attrs + 4 * (size_t)o;
-            s_p[tid] = g[0];
-            s_b[tid] = g[1];
-            s_c[tid] = g[2];
-            s_q[tid] = g[3];
-            s_o[tid] = o;
-        } else {  // padding record: amplitude 0 -> alpha 0, never a hit
-            s_p[tid] = make_float4(0.f, 0.f, 0.f, 0.f);
-            s_q[tid] = make_float4(0.f, 0.f, 0.f, 0.f);
-        }
+    auto keep = [&](const float4 r0, const float4 r1) {
+        return gs_entry_in_tile(r0, r1, tc.tile_u, tc.tile_v, tw, th, filter);
+    };
+    auto store = [&](int slot_, int j, int o, const float4 *r) {
+        s_p[slot_] = r[0]; s_b[slot_] = r[1]; s_c[slot_] = r[2]; s_q[slot_] = r[3];
+        s_j[slot_] = j; s_o[slot_] = o;
+    };
+
+    int pos = end - 1;   // next list position to examine, walking down to `start`
+    while (pos >= start) {
+        __syncthreads();  // previous round fully flushed before its LDS is reused
+        int nbuf = 0;
+        while (nbuf < BATCH && pos >= start)
+            gs_fill_step<-1>(payload, attrs, pos, start, nbuf, s_cnt, s_next, keep, store);
         {
+            const int padded = (nbuf + GROUP - 1) & ~(GROUP - 1);
+            if (tid < padded - nbuf) {   // inert padding: amplitude 0 -> alpha 0, never a hit
+                s_p[nbuf + tid] = make_float4(0.f, 0.f, 0.f, 0.f);
+                s_q[nbuf + tid] = make_float4(0.f, 0.f, 0.f, 0.f);
+                s_j[nbuf + tid] = -1;
+            }
             float4 *z = reinterpret_cast<float4 *>(&s_acc[tid][0]);
             z[0] = make_float4(0.f, 0.f, 0.f, 0.f);
             z[1] = make_float4(0.f, 0.f, 0.f, 0.f);
             z[2] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
         __syncthreads();
-        const int n = min(BWD_BATCH, top - start);
-        for (int k = 0; k < n; k += GROUP) {
-            if (top - 1 - (k + GROUP - 1) >= wave_end) continue;  // the whole group lies behind this wave's pixels
+        for (int k = 0; k < nbuf; k += GROUP) {
+            if (s_j[k + GROUP - 1] >= wave_end) continue;  // descending positions: the whole group lies behind this wave's pixels
             // group evaluation: LDS reads + exp of GROUP entries are independent and overlap
             v2f alpha[GROUP], dx[GROUP];
             float dy[GROUP];
@@ -456,9 +369,9 @@ __global__ __launch_bounds__(BWD_THREADS) void blend_backward_kernel(
             for (int i = 0; i < GROUP; ++i) {
                 const bool a0 = alpha[i].x >= EPS_ALPHA, a1 = alpha[i].y >= EPS_ALPHA;  // RAS:631, as RAS:451
                 if (gs_ballot(a0 || a1) == 0ull) continue;  // wave-uniform skip: no pixel of this wave is touched
-                const int jj = top - 1 - (k + i);
+                const int jj = s_j[k + i];
                 const bool hit0 = a0 && (jj < last0), hit1 = a1 && (jj < last1);  // RAS:618 (effective range)
-                if (gs_ballot(hit0 || hit1) == 0ull) continue;
+                if ((gs_ballot(hit0) | gs_ballot(hit1)) == 0ull) continue;
                 // alpha = 0 for a pixel that is not hit makes its whole update an exact no-op
                 // (1/(1-0) = 1, a*T = 0); only dL/dalpha needs an explicit mask.
                 const v2f h = {hit0 ? 1.f : 0.f, hit1 ? 1.f : 0.f};
@@ -505,18 +418,18 @@ __global__ __launch_bounds__(BWD_THREADS) void blend_backward_kernel(
             }
         }
         __syncthreads();
-        // flush: thread k owns entry k of the batch -> one 48-B store into the (Gaussian, tile) slot
-        if (tid < n) {
+        // flush: thread k owns staged entry k -> one 48-B store into the (Gaussian, tile) slot
+        if (tid < nbuf) {
             const float4 *Sa = reinterpret_cast<const float4 *>(&s_acc[tid][0]);
             float4 r0 = Sa[0], r1 = Sa[1], r2 = Sa[2];
             if (r2.z > 0.f) {
                 const float4 a = s_p[tid];
                 int t0u, t1u, t0v, t1v;
-                gs_tile_box(a.x, a.y, s_c[tid].w, tw, height / GS_TILE_HEIGHT, t0u, t1u, t0v, t1v);
+                gs_tile_box(a.x, a.y, s_b[tid].w, tw, th, t0u, t1u, t0v, t1v);
                 const int dst_slot = slot_offsets[s_o[tid]] + (t1v - t0v) * (tc.tile_u - t0u) + (tc.tile_v - t0v);
                 float4 *dst = partials + 3 * (size_t)dst_slot;
                 r0.z *= 0.5f; r0.w *= 0.5f; r1.x *= 0.5f;  // dg/dcov = 0.5 g (m m^T)
-                r2.x *= (1.f - a.w);                       // dL/dlogit = (1 - opacity) * sum(w)
+                r2.x *= (1.f - s_c[tid].w);                // dL/dlogit = (1 - opacity) * sum(w)
                 r2.z = __builtin_bit_cast(float, (int)r2.z);  // pixel count: float sum -> int32 bits (layout of `acc`)
                 dst[0] = r0;
                 dst[1] = r1;
@@ -569,46 +482,53 @@ __global__ __launch_bounds__(GS_BLOCK) void reduce_partials_kernel(
 }
 
 template <bool AUX, bool STATE>
-static void launch_forward(bool debug, dim3 grid, hipStream_t s, const int32_t *tile_start, const int32_t *tile_end,
+static void launch_forward(bool debug, dim3 grid, hipStream_t s, const int32_t *bin_start, const int32_t *bin_end,
                            const int32_t *payload, const float4 *attrs, int width, int height, int rb, int rs,
-                           float *image, float *depth, float *acc_alpha, int32_t *last_effective,
-                           int32_t *valid_count, uint32_t *debug_hits) {
+                           int bin_shift, int filter, float *image, float *depth, float *acc_alpha,
+                           int32_t *last_effective, int32_t *valid_count, uint32_t *debug_hits) {
     if (debug)
-        hipLaunchKernelGGL((blend_forward_kernel<AUX, STATE, true>), grid, dim3(FWD_THREADS), 0, s, tile_start, tile_end,
-                           payload, attrs, width, height, rb, rs, image, depth, acc_alpha, last_effective, valid_count,
-                           debug_hits);
+        hipLaunchKernelGGL((blend_forward_kernel<AUX, STATE, true>), grid, dim3(BLEND_THREADS), 0, s, bin_start, bin_end,
+                           payload, attrs, width, height, rb, rs, bin_shift, filter, image, depth, acc_alpha,
+                           last_effective, valid_count, debug_hits);
     else
-        hipLaunchKernelGGL((blend_forward_kernel<AUX, STATE, false>), grid, dim3(FWD_THREADS), 0, s, tile_start, tile_end,
-                           payload, attrs, width, height, rb, rs, image, depth, acc_alpha, last_effective, valid_count,
-                           debug_hits);
+        hipLaunchKernelGGL((blend_forward_kernel<AUX, STATE, false>), grid, dim3(BLEND_THREADS), 0, s, bin_start, bin_end,
+                           payload, attrs, width, height, rb, rs, bin_shift, filter, image, depth, acc_alpha,
+                           last_effective, valid_count, debug_hits);
 }
 
 }  // namespace
 
 extern "C" {
 
-static int owned_row_count(int th, int begin, int step) { return begin < th ? (th - 1 - begin) / step + 1 : 0; }
+static int owned_row_count(int th, int begin, int step, int end) {
+    const int hi = end < th ? end : th;
+    return begin < hi ? (hi - 1 - begin) / step + 1 : 0;
+}
 
-int gs_blend_forward(const int32_t *tile_start, const int32_t *tile_end, const int32_t *payload, const float *attrs,
-                     int width, int height, int tile_row_begin, int tile_row_step, float *image, float *depth,
-                     float *acc_alpha, int32_t *last_effective, int32_t *valid_count, int flags,
-                     uint32_t *debug_pixel_hits, void *stream) {
+int gs_blend_forward(const int32_t *bin_start, const int32_t *bin_end, const int32_t *payload, const float *attrs,
+                     int width, int height, int tile_row_begin, int tile_row_step, int tile_row_end, int bin_shift,
+                     int filter, float *image, float *depth, float *acc_alpha, int32_t *last_effective,
+                     int32_t *valid_count, int flags, uint32_t *debug_pixel_hits, void *stream) {
     GS_REQUIRE(width % GS_TILE_WIDTH == 0 && height % GS_TILE_HEIGHT == 0, "image size must be a multiple of 16");
-    GS_REQUIRE(tile_row_step >= 1 && tile_row_begin >= 0, "tile row ownership");
+    GS_REQUIRE(tile_row_step >= 1 && tile_row_begin >= 0 && tile_row_end >= 0, "tile row ownership");
+    GS_REQUIRE(bin_shift >= 0 && bin_shift <= 4, "bin_shift");
+    GS_REQUIRE(bin_shift == 0 || (filter & GS_FILTER_BOX), "lists that cover several tiles need the box filter");
     const bool aux = !(flags & GS_BLEND_RGB_ONLY), state = !(flags & GS_BLEND_NO_STATE);
     GS_REQUIRE(image != nullptr, "image");
     GS_REQUIRE(!aux || (depth != nullptr && valid_count != nullptr), "depth / valid_count (or pass GS_BLEND_RGB_ONLY)");
     GS_REQUIRE(!state || (acc_alpha != nullptr && last_effective != nullptr),
                "acc_alpha / last_effective (or pass GS_BLEND_NO_STATE)");
-    const int tw = width / GS_TILE_WIDTH, rows = owned_row_count(height / GS_TILE_HEIGHT, tile_row_begin, tile_row_step);
+    const int tw = width / GS_TILE_WIDTH;
+    const int rows = owned_row_count(height / GS_TILE_HEIGHT, tile_row_begin, tile_row_step, tile_row_end);
     if (rows == 0 || tw == 0) return 0;
     const dim3 grid(tw * rows);
     const float4 *a4 = reinterpret_cast<const float4 *>(attrs);
     hipStream_t s = (hipStream_t)stream;
     const bool dbg = debug_pixel_hits != nullptr;
 #define GS_FWD(AUX, STATE)                                                                                          \
-    launch_forward<AUX, STATE>(dbg, grid, s, tile_start, tile_end, payload, a4, width, height, tile_row_begin,      \
-                               tile_row_step, image, depth, acc_alpha, last_effective, valid_count, debug_pixel_hits)
+    launch_forward<AUX, STATE>(dbg, grid, s, bin_start, bin_end, payload, a4, width, height, tile_row_begin,        \
+                               tile_row_step, bin_shift, filter, image, depth, acc_alpha, last_effective,           \
+                               valid_count, debug_pixel_hits)
     if (aux && state) GS_FWD(true, true);
     else if (aux) GS_FWD(true, false);
     else if (state) GS_FWD(false, true);
@@ -618,34 +538,32 @@ int gs_blend_forward(const int32_t *tile_start, const int32_t *tile_end, const i
     return 0;
 }
 
-int gs_blend_backward(const int32_t *tile_start, const int32_t *tile_end, const int32_t *payload, const float *attrs,
+int gs_blend_backward(const int32_t *bin_start, const int32_t *payload, const float *attrs,
                       const float *grad_image, const float *acc_alpha, const int32_t *last_effective,
                       const int32_t *slot_offsets, int64_t n_slots, int width, int height, int tile_row_begin,
-                      int tile_row_step, float *partials, uint8_t *slot_flags, float *magnitude_image, int flags,
-                      uint32_t *debug_pixel_hits, void *stream) {
+                      int tile_row_step, int tile_row_end, int bin_shift, int filter, float *partials,
+                      uint8_t *slot_flags, float *magnitude_image, uint32_t *debug_pixel_hits, void *stream) {
     GS_REQUIRE(width % GS_TILE_WIDTH == 0 && height % GS_TILE_HEIGHT == 0, "image size must be a multiple of 16");
-    GS_REQUIRE(tile_row_step >= 1 && tile_row_begin >= 0, "tile row ownership");
+    GS_REQUIRE(tile_row_step >= 1 && tile_row_begin >= 0 && tile_row_end >= 0, "tile row ownership");
+    GS_REQUIRE(bin_shift >= 0 && bin_shift <= 4, "bin_shift");
+    GS_REQUIRE(bin_shift == 0 || (filter & GS_FILTER_BOX), "lists that cover several tiles need the box filter");
     GS_REQUIRE(n_slots >= 0, "n_slots");
-    GS_REQUIRE(!(flags & GS_BLEND_BACKWARD_V1) || debug_pixel_hits == nullptr, "debug counters need the v2 kernel");
     hipStream_t s = (hipStream_t)stream;
     if (n_slots > 0) GS_CHECK_HIP(hipMemsetAsync(slot_flags, 0, (size_t)n_slots, s));
-    const int tw = width / GS_TILE_WIDTH, rows = owned_row_count(height / GS_TILE_HEIGHT, tile_row_begin, tile_row_step);
+    const int tw = width / GS_TILE_WIDTH;
+    const int rows = owned_row_count(height / GS_TILE_HEIGHT, tile_row_begin, tile_row_step, tile_row_end);
     if (rows == 0 || tw == 0) return 0;
-    const dim3 grid(tw * rows), block(BWD_THREADS);
+    const dim3 grid(tw * rows), block(BLEND_THREADS);
     const float4 *a4 = reinterpret_cast<const float4 *>(attrs);
     float4 *p4 = reinterpret_cast<float4 *>(partials);
-    if (flags & GS_BLEND_BACKWARD_V1)
-        hipLaunchKernelGGL(blend_backward_kernel_v1, grid, block, 0, s, tile_start, tile_end, payload, a4, grad_image,
-                           acc_alpha, last_effective, width, height, tile_row_begin, tile_row_step, slot_offsets, p4,
-                           slot_flags, magnitude_image);
-    else if (debug_pixel_hits != nullptr)
-        hipLaunchKernelGGL(blend_backward_kernel<true>, grid, block, 0, s, tile_start, tile_end, payload, a4, grad_image,
-                           acc_alpha, last_effective, width, height, tile_row_begin, tile_row_step, slot_offsets, p4,
-                           slot_flags, magnitude_image, debug_pixel_hits);
+    if (debug_pixel_hits != nullptr)
+        hipLaunchKernelGGL(blend_backward_kernel<true>, grid, block, 0, s, bin_start, payload, a4, grad_image,
+                           acc_alpha, last_effective, width, height, tile_row_begin, tile_row_step, bin_shift, filter,
+                           slot_offsets, p4, slot_flags, magnitude_image, debug_pixel_hits);
     else
-        hipLaunchKernelGGL(blend_backward_kernel<false>, grid, block, 0, s, tile_start, tile_end, payload, a4, grad_image,
-                           acc_alpha, last_effective, width, height, tile_row_begin, tile_row_step, slot_offsets, p4,
-                           slot_flags, magnitude_image, debug_pixel_hits);
+        hipLaunchKernelGGL(blend_backward_kernel<false>, grid, block, 0, s, bin_start, payload, a4, grad_image,
+                           acc_alpha, last_effective, width, height, tile_row_begin, tile_row_step, bin_shift, filter,
+                           slot_offsets, p4, slot_flags, magnitude_image, debug_pixel_hits);
     GS_CHECK_LAUNCH();
     return 0;
 }

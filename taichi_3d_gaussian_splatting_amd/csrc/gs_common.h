@@ -57,6 +57,60 @@ __device__ __forceinline__ void gs_tile_box(float u, float v, float r, int tw, i
     t1v = min(max((int)floorf(max_v / (float)GS_TILE_HEIGHT) + 1, t0v + 1), th);
 }
 
+
+// ------------------------------------------------------------------ exact contribution test (output-identical culling)
+// A (pixel rectangle, Gaussian) pair whose alpha stays below the 1/255 skip threshold (RAS:451) on EVERY pixel centre of
+// the rectangle never changes any pixel state, so dropping it from a list is output-identical.  alpha = amp * exp(-q/2)
+// with q the conic quadratic form (UTL:275-284); q is minimised over the convex hull of the rectangle's pixel centres
+// (a superset of the pixels), which lies on the edge(s) of the rectangle facing the centre.  qmax = 2 ln(255 amp) +
+// margin; the margin (1e-2 in q, i.e. 0.5 % in alpha) dwarfs every fp32 disagreement between this test and the blend
+// kernels (and the error of the approximate reciprocals below: < 1e-5 in q).  The same function serves the front end
+// (per 64 x 64-pixel bin: which bins get a sort key) and the blend kernels (per 16 x 16 tile: which entries of the bin's
+// list are staged for this tile); the two decisions need not agree -- each one only ever removes pairs that contribute
+// nothing.
+__device__ __forceinline__ float gs_cull_qmax(float amp) { return 2.0f * logf(255.0f * amp) + 1e-2f; }
+
+// [x0, x1] x [y0, y1]: pixel-CENTRE coordinates of the rectangle's corner pixels.
+__device__ __forceinline__ bool gs_rect_may_contribute(float ux, float uy, float A, float B, float C, float qmax,
+                                                       float x0, float x1, float y0, float y1) {
+#pragma clang fp contract(off)
+    const float dxc = fminf(fmaxf(ux, x0), x1) - ux;  // x offset of the closest point, 0 if inside the span
+    const float dyc = fminf(fmaxf(uy, y0), y1) - uy;
+    float qmin = 0.f;
+    if (dxc != 0.f || dyc != 0.f) {
+        qmin = 3.0e38f;
+        if (dxc != 0.f) {  // edge x = const facing the centre: minimise over dy along the edge (slope -B/C)
+            const float dy = fminf(fmaxf((-B * __builtin_amdgcn_rcpf(C)) * dxc, y0 - uy), y1 - uy);
+            qmin = A * dxc * dxc + 2.f * B * dxc * dy + C * dy * dy;
+        }
+        if (dyc != 0.f) {
+            const float dx = fminf(fmaxf((-B * __builtin_amdgcn_rcpf(A)) * dyc, x0 - ux), x1 - ux);
+            qmin = fminf(qmin, A * dx * dx + 2.f * B * dx * dyc + C * dyc * dyc);
+        }
+    }
+    return !(qmin > qmax);  // NaN-safe: anything unordered is kept
+}
+
+// Staging filter of the blend kernels: does list entry (rows 0 and 1 of its record) belong to tile (tile_u, tile_v)?
+//   GS_FILTER_BOX : the tile lies inside the Gaussian's tile box (RAS:81-103) -- the reference emits a key for exactly
+//                   those tiles (RAS:131-172); needed whenever a list covers more than one tile (bins)
+//   GS_FILTER_CULL: the exact contribution test above on the tile's 16 x 16 pixels
+__device__ __forceinline__ bool gs_entry_in_tile(const float4 r0, const float4 r1, int tile_u, int tile_v, int tw,
+                                                 int th, int filter) {
+    bool keep = true;
+    if (filter & GS_FILTER_BOX) {
+        int t0u, t1u, t0v, t1v;
+        gs_tile_box(r0.x, r0.y, r1.w, tw, th, t0u, t1u, t0v, t1v);
+        keep = tile_u >= t0u && tile_u < t1u && tile_v >= t0v && tile_v < t1v;
+    }
+    if (filter & GS_FILTER_CULL) {
+        const float x0 = (float)(tile_u * GS_TILE_WIDTH) + 0.5f, y0 = (float)(tile_v * GS_TILE_HEIGHT) + 0.5f;
+        keep = keep && gs_rect_may_contribute(r0.x, r0.y, r1.x, r1.y, r1.z, r0.w, x0, x0 + (float)(GS_TILE_WIDTH - 1),
+                                              y0, y0 + (float)(GS_TILE_HEIGHT - 1));
+    }
+    return keep;
+}
+
 __device__ __forceinline__ int gs_lane() { return threadIdx.x & (GS_WAVE - 1); }
 
 // number of set bits of `mask` strictly below the calling lane

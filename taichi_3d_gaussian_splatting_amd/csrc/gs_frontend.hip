@@ -55,51 +55,39 @@ __device__ __forceinline__ void tile_box(float u, float v, float r, int tw, int 
     gs_tile_box(u, v, r, tw, th, t0u, t1u, t0v, t1v);
 }
 
-// number of tile rows r in [t0v, t1v) with r = begin + k*step, k >= 0; first such row in *first
-__device__ __forceinline__ int owned_rows(int t0v, int t1v, int begin, int step, int *first) {
-    int f = begin;
-    if (t0v > begin) f = begin + ((t0v - begin + step - 1) / step) * step;
-    *first = f;
-    return f < t1v ? (t1v - 1 - f) / step + 1 : 0;
+// Tile-row ownership of one GPU (image-space sharding): rows {begin + k*step, k >= 0} below `end`.
+struct RowOwner { int begin, step, end; };
+// number of owned tile rows in [lo, hi)
+__device__ __forceinline__ int owned_rows(int lo, int hi, RowOwner ow) {
+    hi = min(hi, ow.end);
+    int f = ow.begin;
+    if (lo > ow.begin) f = ow.begin + ((lo - ow.begin + ow.step - 1) / ow.step) * ow.step;
+    return f < hi ? (hi - 1 - f) / ow.step + 1 : 0;
 }
 
-// Exact per-tile cull.  A (tile, Gaussian) pair whose alpha stays below the 1/255 skip threshold
-// (RAS:451) on EVERY pixel of the tile never changes any pixel state, so dropping it from the tile's
-// list is output-identical.  alpha = amp * exp(-q/2) with q the conic quadratic form (UTL:275-284);
-// q is minimised over the convex hull of the tile's pixel centres (a superset of the pixels), which
-// lies on the edge(s) of the rectangle facing the centre.  qmax = 2 ln(255 amp) + margin; the margin
-// (1e-2 in q, i.e. 0.5 % in alpha) dwarfs the fp32 disagreement between this test and the blend kernel.
-__device__ __forceinline__ float cull_qmax(float opacity, float rescale) {
-    return 2.0f * logf(255.0f * opacity * rescale) + 1e-2f;
+// Sort keys are emitted per BIN = (1 << bin_shift)^2 tiles (default 4 x 4 tiles = 64 x 64 pixels), not per tile: the
+// blend kernels walk their bin's depth-sorted list and stage the entries that belong to their own tile (box test + exact
+// contribution test, gs_entry_in_tile).  The per-tile sequence is unchanged -- the bin list filtered by tile membership
+// is the tile's list in the same (depth, index) order -- but 3-16x fewer keys are generated, sorted and ranged.
+// A Gaussian emits a key for bin (bu, bv) iff the bin holds a tile of its box (RAS:81-103) in a tile row this GPU owns
+// and (with the exact cull) the Gaussian can reach alpha >= 1/255 somewhere on those tiles.
+struct BinBox { int b0u, b1u, b0v, b1v; };
+__device__ __forceinline__ BinBox bin_box(int t0u, int t1u, int t0v, int t1v, int bin_shift) {
+    BinBox b;
+    b.b0u = t0u >> bin_shift; b.b1u = t1u > t0u ? ((t1u - 1) >> bin_shift) + 1 : b.b0u;
+    b.b0v = t0v >> bin_shift; b.b1v = t1v > t0v ? ((t1v - 1) >> bin_shift) + 1 : b.b0v;
+    return b;
 }
-// The two ratios -B/C and -B/A (the slopes of the conic's conjugate diameters) are per-Gaussian constants: callers
-// compute them once with cull_slopes() instead of dividing per tile.
-struct CullSlopes { float nb_over_c, nb_over_a; };
-__device__ __forceinline__ CullSlopes cull_slopes(float A, float B, float C) {
-    CullSlopes s;
-    s.nb_over_c = -B / C;
-    s.nb_over_a = -B / A;
-    return s;
-}
-__device__ __forceinline__ bool tile_may_contribute(float ux, float uy, float A, float B, float C, CullSlopes sl,
-                                                    float qmax, int tu, int tv) {
-    const float x0 = (float)(tu * GS_TILE_WIDTH) + 0.5f, x1 = x0 + (float)(GS_TILE_WIDTH - 1);
-    const float y0 = (float)(tv * GS_TILE_HEIGHT) + 0.5f, y1 = y0 + (float)(GS_TILE_HEIGHT - 1);
-    const float dxc = fminf(fmaxf(ux, x0), x1) - ux;  // x offset of the closest point, 0 if inside the span
-    const float dyc = fminf(fmaxf(uy, y0), y1) - uy;
-    float qmin = 0.f;
-    if (dxc != 0.f || dyc != 0.f) {
-        qmin = 3.0e38f;
-        if (dxc != 0.f) {  // edge x = const facing the centre: minimise over dy along the edge
-            const float dy = fminf(fmaxf(sl.nb_over_c * dxc, y0 - uy), y1 - uy);
-            qmin = A * dxc * dxc + 2.f * B * dxc * dy + C * dy * dy;
-        }
-        if (dyc != 0.f) {
-            const float dx = fminf(fmaxf(sl.nb_over_a * dyc, x0 - ux), x1 - ux);
-            qmin = fminf(qmin, A * dx * dx + 2.f * B * dx * dyc + C * dyc * dyc);
-        }
-    }
-    return !(qmin > qmax);  // NaN-safe: anything unordered is kept
+__device__ __forceinline__ bool bin_emits(int bu, int bv, int t0u, int t1u, int t0v, int t1v, int bin_shift,
+                                          RowOwner ow, int cull, float ux, float uy, float A, float B, float C,
+                                          float qmax) {
+    const int u_lo = max(t0u, bu << bin_shift), u_hi = min(t1u, (bu + 1) << bin_shift);   // tiles of the box in this bin
+    const int v_lo = max(t0v, bv << bin_shift), v_hi = min(t1v, (bv + 1) << bin_shift);
+    if (owned_rows(v_lo, v_hi, ow) == 0) return false;
+    if (!cull) return true;
+    return gs_rect_may_contribute(ux, uy, A, B, C, qmax, (float)(u_lo * GS_TILE_WIDTH) + 0.5f,
+                                  (float)(u_hi * GS_TILE_WIDTH) - 0.5f, (float)(v_lo * GS_TILE_HEIGHT) + 0.5f,
+                                  (float)(v_hi * GS_TILE_HEIGHT) - 0.5f);
 }
 
 // ------------------------------------------------------------------ pose inverse
@@ -250,9 +238,10 @@ __global__ __launch_bounds__(GS_BLOCK) void compact_kernel(const int8_t *__restr
 __global__ __launch_bounds__(GS_BLOCK) void preprocess_kernel(
     const float *__restrict__ xyz, float *__restrict__ feat, const int32_t *__restrict__ obj,
     const float *__restrict__ Kmat, const float *__restrict__ q_cp, const float *__restrict__ t_cp,
-    const int32_t *__restrict__ ids, int m_capacity, int use_device_count, int width, int height, int row_begin,
-    int row_step, int cull, float depth_scale, int32_t *__restrict__ counters, float *__restrict__ attrs, int32_t *__restrict__ ntiles_full, int32_t *__restrict__ ntiles_owned,
-    int32_t *__restrict__ block_sums, int32_t *__restrict__ block_sums_full) {
+    const int32_t *__restrict__ ids, int m_capacity, int use_device_count, int width, int height, RowOwner ow,
+    int bin_shift, int cull, float depth_scale, int32_t *__restrict__ counters, float *__restrict__ attrs,
+    int32_t *__restrict__ ntiles_full, int32_t *__restrict__ nkeys, int32_t *__restrict__ block_sums,
+    int32_t *__restrict__ block_sums_full) {
     __shared__ int s_sum, s_sum_full, s_dq;
     if (threadIdx.x == 0) { s_sum = 0; s_sum_full = 0; s_dq = 0; }
     __syncthreads();
@@ -326,23 +315,25 @@ __global__ __launch_bounds__(GS_BLOCK) void preprocess_kernel(
         const float opacity = 1.f / (1.f + expf(-f[7]));  // RAS:299-300
         const float cA = inv * cd, cB = inv * (-cov[1]), cC = inv * ca;
 
-        int t0u, t1u, t0v, t1v, first;
+        int t0u, t1u, t0v, t1v;
         tile_box(uv[0], uv[1], radius, width / GS_TILE_WIDTH, height / GS_TILE_HEIGHT, t0u, t1u, t0v, t1v);
         full = (t1u - t0u) * (t1v - t0v);
         ntiles_full[i] = full;
-        owned = (t1u - t0u) * owned_rows(t0v, t1v, row_begin, row_step, &first);
-        if (cull && owned > 0) {
-            const float qmax = cull_qmax(opacity, rescale);
-            const CullSlopes sl = cull_slopes(cA, cB, cC);
-            owned = 0;
-            for (int tu = t0u; tu < t1u; ++tu)
-                for (int tv = first; tv < t1v; tv += row_step)
-                    owned += tile_may_contribute(uv[0], uv[1], cA, cB, cC, sl, qmax, tu, tv) ? 1 : 0;
+        // the exact-cull bound of this Gaussian; +inf (never culled) when the cull is off.  Stored in the record: the
+        // blend kernels apply the same test per tile.
+        const float amp = opacity * rescale;
+        const float qmax = cull ? gs_cull_qmax(amp) : __builtin_inff();
+        if (full > 0 && owned_rows(t0v, t1v, ow) > 0) {   // number of sort keys = bins reached on this GPU
+            const BinBox bb = bin_box(t0u, t1u, t0v, t1v, bin_shift);
+            for (int bu = bb.b0u; bu < bb.b1u; ++bu)
+                for (int bv = bb.b0v; bv < bb.b1v; ++bv)
+                    owned += bin_emits(bu, bv, t0u, t1u, t0v, t1v, bin_shift, ow, cull, uv[0], uv[1], cA, cB, cC, qmax)
+                                 ? 1 : 0;
         }
 
         float4 *out = reinterpret_cast<float4 *>(attrs + (size_t)GS_ATTR_STRIDE * i);
-        out[0] = make_float4(uv[0], uv[1], c[2], opacity);  // always: the hook exposes uv and depth of every
-                                                            // visible point (RAS:1138-1139)
+        out[0] = make_float4(uv[0], uv[1], c[2], qmax);  // always: the hook exposes uv and depth of every
+                                                         // visible point (RAS:1138-1139)
         if (owned > 0) {
             // Only Gaussians that emit at least one key on this GPU are ever gathered by the blend kernels:
             // the SH colour (the most expensive part) and the rest of the record are skipped otherwise
@@ -350,13 +341,13 @@ __global__ __launch_bounds__(GS_BLOCK) void preprocess_kernel(
             // colour: RAS:280-282,302-310; ray origin = (-R^T) t (UTL:495-510)
             float rgb[3];   // shared source with the per-point backward (gs_common.h): bit-identical there
             gs_view_colour(W.m, t, p, [&](int ch, int k) { return f[8 + 16 * ch + k]; }, rgb);
-            out[1] = make_float4(cA, cB, cC, rescale);
-            out[2] = make_float4(rgb[0], rgb[1], rgb[2], radius);
-            // forward-blend form of the same weight: amp * 2^(dx*(A'dx + B'dy) + C'dy^2)
+            out[1] = make_float4(cA, cB, cC, radius);
+            out[2] = make_float4(rgb[0], rgb[1], rgb[2], opacity);
+            // the weight UTL:275-284 in the log2 domain: amp * 2^(dx*(A'dx + B'dy) + C'dy^2)
             const float log2e = 1.4426950408889634f;
-            out[3] = make_float4((-0.5f * log2e) * cA, (-log2e) * cB, (-0.5f * log2e) * cC, opacity * rescale);
+            out[3] = make_float4((-0.5f * log2e) * cA, (-log2e) * cB, (-0.5f * log2e) * cC, amp);
         }
-        ntiles_owned[i] = owned;
+        nkeys[i] = owned;
     }
     // per-block partial sums for the two scans (wave reduce, then one LDS atomic per wave) and the
     // largest quantised depth on screen (lets the host sort only the key bits that are in use)
@@ -391,17 +382,17 @@ __global__ __launch_bounds__(GS_BLOCK) void preprocess_kernel(
 // tile and depth fit 32 bits together (same order, half the sort traffic).
 template <typename KeyT>
 __global__ __launch_bounds__(GS_BLOCK) void make_keys_kernel(
-    const float *__restrict__ attrs, const int32_t *__restrict__ ntiles_owned,
-    const int32_t *__restrict__ block_offsets, int m, int width, int height, int row_begin, int row_step,
+    const float *__restrict__ attrs, const int32_t *__restrict__ nkeys,
+    const int32_t *__restrict__ block_offsets, int m, int width, int height, RowOwner ow, int bin_shift,
     int cull, int key_depth_bits, float depth_scale, KeyT *__restrict__ keys, int32_t *__restrict__ payload,
     const int32_t *__restrict__ ntiles_full, const int32_t *__restrict__ block_offsets_full,
     int32_t *__restrict__ slot_offsets) {
     __shared__ int lds[4];
     const int i = blockIdx.x * GS_BLOCK + threadIdx.x;
-    int cnt = i < m ? ntiles_owned[i] : 0;
+    int cnt = i < m ? nkeys[i] : 0;
     int total;
     int offset = block_offsets[blockIdx.x] + gs_block_excl_scan(cnt, &total, lds);
-    {   // exclusive scan of the reference's box counts = slot base of every Gaussian (RAS:913-922)
+    if (slot_offsets != nullptr) {   // exclusive scan of the reference's box counts = slot base of every Gaussian (RAS:913-922)
         const int full = i < m ? ntiles_full[i] : 0;
         const int so = block_offsets_full[blockIdx.x] + gs_block_excl_scan(full, &total, lds);
         if (i < m) slot_offsets[i] = so;
@@ -409,23 +400,22 @@ __global__ __launch_bounds__(GS_BLOCK) void make_keys_kernel(
     if (i >= m || cnt == 0) return;
     const float4 a0 = reinterpret_cast<const float4 *>(attrs + (size_t)GS_ATTR_STRIDE * i)[0];
     const float4 a1 = reinterpret_cast<const float4 *>(attrs + (size_t)GS_ATTR_STRIDE * i)[1];
-    const float radius = attrs[(size_t)GS_ATTR_STRIDE * i + 11];
-    const float qmax = cull ? cull_qmax(a0.w, a1.w) : 0.f;
-    const CullSlopes sl = cull_slopes(a1.x, a1.y, a1.z);   // the same expression on the same stored conic as gs_preprocess
     const int tw = width / GS_TILE_WIDTH;
-    int t0u, t1u, t0v, t1v, first;
-    tile_box(a0.x, a0.y, radius, tw, height / GS_TILE_HEIGHT, t0u, t1u, t0v, t1v);
-    owned_rows(t0v, t1v, row_begin, row_step, &first);
+    const int bins_u = (tw + (1 << bin_shift) - 1) >> bin_shift;
+    int t0u, t1u, t0v, t1v;
+    tile_box(a0.x, a0.y, a1.w, tw, height / GS_TILE_HEIGHT, t0u, t1u, t0v, t1v);
+    const BinBox bb = bin_box(t0u, t1u, t0v, t1v, bin_shift);
     const int32_t dq = (int32_t)(a0.z * depth_scale);  // truncation toward zero, RAS:159-160
     int k = offset;
-    for (int tu = t0u; tu < t1u; ++tu)
-        for (int tv = first; tv < t1v; tv += row_step) {
-            if (cull && !tile_may_contribute(a0.x, a0.y, a1.x, a1.y, a1.z, sl, qmax, tu, tv)) continue;
-            const int32_t tile = tu + tv * tw;
+    for (int bu = bb.b0u; bu < bb.b1u; ++bu)
+        for (int bv = bb.b0v; bv < bb.b1v; ++bv) {
+            // the same expression on the same stored values as gs_preprocess: the two kernels agree on the count
+            if (!bin_emits(bu, bv, t0u, t1u, t0v, t1v, bin_shift, ow, cull, a0.x, a0.y, a1.x, a1.y, a1.z, a0.w)) continue;
+            const int32_t bin = bu + bv * bins_u;
             if (sizeof(KeyT) == 8)
-                keys[k] = (KeyT)((int64_t)dq + ((int64_t)tile << 32));
+                keys[k] = (KeyT)((int64_t)dq + ((int64_t)bin << 32));
             else
-                keys[k] = (KeyT)(((uint32_t)tile << key_depth_bits) | (uint32_t)dq);
+                keys[k] = (KeyT)(((uint32_t)bin << key_depth_bits) | (uint32_t)dq);
             payload[k] = i;
             ++k;
         }
@@ -503,19 +493,21 @@ int gs_read_counters(const int32_t *counters, int32_t *host_counters, int n, voi
 
 int gs_preprocess(const float *xyz, float *features, const int32_t *object_id, const float *intrinsics,
                   const float *q_cp, const float *t_cp, const int32_t *ids, int n_visible, int n_visible_on_device,
-                  int width, int height, int tile_row_begin, int tile_row_step, int exact_tile_cull,
-                  float depth_scale, int32_t *counters,
-                  float *attrs, int32_t *num_overlap_tiles, int32_t *num_owned_tiles, int32_t *block_sums,
+                  int width, int height, int tile_row_begin, int tile_row_step, int tile_row_end, int bin_shift,
+                  int exact_tile_cull, float depth_scale, int32_t *counters,
+                  float *attrs, int32_t *num_overlap_tiles, int32_t *num_keys, int32_t *block_sums,
                   int32_t *block_sums_full, void *stream) {
     GS_REQUIRE(n_visible >= 0, "n_visible");
-    GS_REQUIRE(tile_row_step >= 1 && tile_row_begin >= 0, "tile row ownership");
+    GS_REQUIRE(tile_row_step >= 1 && tile_row_begin >= 0 && tile_row_end >= 0, "tile row ownership");
+    GS_REQUIRE(bin_shift >= 0 && bin_shift <= 4, "bin_shift");
     GS_REQUIRE(width % GS_TILE_WIDTH == 0 && height % GS_TILE_HEIGHT == 0, "image size must be a multiple of 16");
     GS_REQUIRE(!n_visible_on_device || counters != nullptr, "device-side count needs counters");
     if (n_visible == 0) return 0;
     hipLaunchKernelGGL(preprocess_kernel, dim3(gs_div_up(n_visible, GS_BLOCK)), dim3(GS_BLOCK), 0,
                        (hipStream_t)stream, xyz, features, object_id, intrinsics, q_cp, t_cp, ids, n_visible,
-                       n_visible_on_device, width, height, tile_row_begin, tile_row_step, exact_tile_cull, depth_scale, counters, attrs, num_overlap_tiles,
-                       num_owned_tiles, block_sums, block_sums_full);
+                       n_visible_on_device, width, height, RowOwner{tile_row_begin, tile_row_step, tile_row_end},
+                       bin_shift, exact_tile_cull, depth_scale, counters, attrs, num_overlap_tiles, num_keys,
+                       block_sums, block_sums_full);
     GS_CHECK_LAUNCH();
     return 0;
 }
@@ -546,32 +538,34 @@ int gs_scan_block_sums2(int32_t *block_sums, int32_t *block_sums_full, int n_blo
     return 0;
 }
 
-int gs_make_keys(const float *attrs, const int32_t *num_owned_tiles, const int32_t *block_offsets, int n_visible,
-                 int width, int height, int tile_row_begin, int tile_row_step, int exact_tile_cull,
-                 int key_depth_bits, float depth_scale, void *keys, int32_t *payload,
+int gs_make_keys(const float *attrs, const int32_t *num_keys, const int32_t *block_offsets, int n_visible,
+                 int width, int height, int tile_row_begin, int tile_row_step, int tile_row_end, int bin_shift,
+                 int exact_tile_cull, int key_depth_bits, float depth_scale, void *keys, int32_t *payload,
                  const int32_t *num_overlap_tiles, const int32_t *block_offsets_full, int32_t *slot_offsets,
                  void *stream) {
     GS_REQUIRE(n_visible >= 0, "n_visible");
-    GS_REQUIRE(tile_row_step >= 1 && tile_row_begin >= 0, "tile row ownership");
+    GS_REQUIRE(tile_row_step >= 1 && tile_row_begin >= 0 && tile_row_end >= 0, "tile row ownership");
+    GS_REQUIRE(bin_shift >= 0 && bin_shift <= 4, "bin_shift");
     GS_REQUIRE(key_depth_bits >= 0 && key_depth_bits < 32, "key_depth_bits");
+    GS_REQUIRE(slot_offsets == nullptr || (num_overlap_tiles != nullptr && block_offsets_full != nullptr),
+               "slot_offsets needs num_overlap_tiles and its scanned block sums");
     if (n_visible == 0) return 0;
     const dim3 grid(gs_div_up(n_visible, GS_BLOCK)), block(GS_BLOCK);
+    const RowOwner ow{tile_row_begin, tile_row_step, tile_row_end};
     if (key_depth_bits == 0)
-        hipLaunchKernelGGL(make_keys_kernel<uint64_t>, grid, block, 0, (hipStream_t)stream, attrs, num_owned_tiles,
-                           block_offsets, n_visible, width, height, tile_row_begin, tile_row_step, exact_tile_cull,
-                           0, depth_scale, (uint64_t *)keys, payload, num_overlap_tiles, block_offsets_full,
-                           slot_offsets);
+        hipLaunchKernelGGL(make_keys_kernel<uint64_t>, grid, block, 0, (hipStream_t)stream, attrs, num_keys,
+                           block_offsets, n_visible, width, height, ow, bin_shift, exact_tile_cull, 0, depth_scale,
+                           (uint64_t *)keys, payload, num_overlap_tiles, block_offsets_full, slot_offsets);
     else
-        hipLaunchKernelGGL(make_keys_kernel<uint32_t>, grid, block, 0, (hipStream_t)stream, attrs, num_owned_tiles,
-                           block_offsets, n_visible, width, height, tile_row_begin, tile_row_step, exact_tile_cull,
-                           key_depth_bits, depth_scale, (uint32_t *)keys, payload, num_overlap_tiles,
-                           block_offsets_full, slot_offsets);
+        hipLaunchKernelGGL(make_keys_kernel<uint32_t>, grid, block, 0, (hipStream_t)stream, attrs, num_keys,
+                           block_offsets, n_visible, width, height, ow, bin_shift, exact_tile_cull, key_depth_bits,
+                           depth_scale, (uint32_t *)keys, payload, num_overlap_tiles, block_offsets_full, slot_offsets);
     GS_CHECK_LAUNCH();
     return 0;
 }
 
 int gs_tile_ranges(const void *keys_sorted, int64_t n_keys, int key_depth_bits, int32_t *tile_start,
-                   int32_t *tile_end, int n_tiles, void *stream) {
+                   int32_t *tile_end, int n_tiles /* number of bins */, void *stream) {
     GS_REQUIRE(n_keys >= 0 && n_tiles > 0, "sizes");
     GS_REQUIRE(key_depth_bits >= 0 && key_depth_bits < 32, "key_depth_bits");
     hipStream_t s = (hipStream_t)stream;

@@ -8,6 +8,7 @@ PyTorch is plumbing here (device memory + streams); all arithmetic runs in the H
 from __future__ import annotations
 
 import ctypes
+from dataclasses import dataclass
 from typing import Optional, Tuple
 
 import torch
@@ -26,6 +27,49 @@ COUNTER_NUM_SLOTS = 2
 COUNTER_MAX_DEPTH_KEY = 3
 NUM_COUNTERS = 8
 _PRE_BLOCK = 256  # points per workgroup of gs_preprocess / gs_make_keys
+FILTER_BOX = 1     # include/gsplat_hip.h GS_FILTER_BOX
+FILTER_CULL = 2    # GS_FILTER_CULL
+_NO_ROW_LIMIT = 1 << 30
+
+
+@dataclass(frozen=True)
+class ListLayout:
+    """How the sorted lists of one frame are organised (the same object goes to preprocess, make_keys, tile_ranges and
+    both blend passes -- they must agree):
+      bin_shift   : sort keys are emitted per bin of (1 << bin_shift)^2 tiles; 2 = 64 x 64 pixels (default), 0 = per
+                    tile as in the reference (RAS:131-172)
+      exact_cull  : drop (bin | tile, Gaussian) pairs that cannot reach alpha >= 1/255 (output-identical)
+      row_begin / row_step / row_end : the tile rows {row_begin + k*row_step} < row_end this GPU renders
+      prefiltered : the lists hold exactly the entries of each tile already (bin_shift 0 only; e.g. the oracle's lists
+                    fed to a blend kernel in a test): no staging filter at all."""
+    bin_shift: int = 2
+    exact_cull: bool = True
+    row_begin: int = 0
+    row_step: int = 1
+    row_end: int = _NO_ROW_LIMIT
+    prefiltered: bool = False
+
+    @property
+    def filter(self) -> int:
+        if self.prefiltered:
+            if self.bin_shift != 0:
+                raise ValueError("prefiltered lists are per-tile lists (bin_shift 0)")
+            return 0
+        return FILTER_BOX | (FILTER_CULL if self.exact_cull else 0)
+
+    @property
+    def sharded(self) -> bool:
+        return self.row_begin != 0 or self.row_step != 1 or self.row_end < _NO_ROW_LIMIT
+
+    def num_bins(self, width: int, height: int) -> int:
+        side = TILE_WIDTH << self.bin_shift
+        return ((width + side - 1) // side) * ((height + side - 1) // side)
+
+    def owned_rows(self, height: int) -> range:
+        return range(self.row_begin, min(height // TILE_HEIGHT, self.row_end), self.row_step)
+
+
+PER_TILE_LISTS = ListLayout(bin_shift=0, exact_cull=False, prefiltered=True)   # the reference's lists, taken as given
 
 
 def _require_device(t: torch.Tensor, name: str) -> None:
@@ -80,25 +124,24 @@ def filter_compact(xyz, invalid_mask, object_id, intrinsics, q_cp, t_cp, near_pl
     return mask, ids[:m], counters
 
 
-def preprocess(xyz, features, object_id, intrinsics, q_cp, t_cp, ids, width, height, tile_row_begin=0,
-               tile_row_step=1, exact_tile_cull=True, depth_to_sort_key_scale=100.0, counters=None,
-               n_visible_on_device=False):
-    """-> (attrs f32[M,16], num_overlap_tiles i32[M], num_owned_tiles i32[M], block_sums, block_sums_full).
+def preprocess(xyz, features, object_id, intrinsics, q_cp, t_cp, ids, width, height, layout: ListLayout = ListLayout(),
+               depth_to_sort_key_scale=100.0, counters=None, n_visible_on_device=False):
+    """-> (attrs f32[M,16], num_overlap_tiles i32[M], num_keys i32[M], block_sums, block_sums_full).
     Normalises features[ids, 0:4] IN PLACE (RAS:196-205).  num_overlap_tiles is the reference's box count
-    (hook output; its scan gives the backward slots); num_owned_tiles is the number of keys emitted (after
-    ownership and the exact tile cull); the two block_sums are int32[ceil(M/256)] partial sums of them."""
+    (hook output; its scan gives the backward slots); num_keys is the number of sort keys emitted (bins reached in
+    owned tile rows, after the exact cull); the two block_sums are int32[ceil(M/256)] partial sums of them."""
     m = ids.shape[0]
     dev = xyz.device
     attrs = torch.empty((m, ATTR_STRIDE), dtype=torch.float32, device=dev)
     ntiles = torch.empty(m, dtype=torch.int32, device=dev)
-    nowned = torch.empty(m, dtype=torch.int32, device=dev)
+    nkeys = torch.empty(m, dtype=torch.int32, device=dev)
     block_sums = torch.empty((m + _PRE_BLOCK - 1) // _PRE_BLOCK, dtype=torch.int32, device=dev)
     block_sums_full = torch.empty_like(block_sums)
     call("gs_preprocess", ptr(xyz), ptr(features), ptr(object_id), ptr(intrinsics), ptr(q_cp), ptr(t_cp), ptr(ids),
-         m, int(bool(n_visible_on_device)), int(width), int(height), int(tile_row_begin), int(tile_row_step),
-         int(bool(exact_tile_cull)), float(depth_to_sort_key_scale), ptr(counters), ptr(attrs), ptr(ntiles), ptr(nowned), ptr(block_sums),
-         ptr(block_sums_full), current_stream(dev))
-    return attrs, ntiles, nowned, block_sums, block_sums_full
+         m, int(bool(n_visible_on_device)), int(width), int(height), layout.row_begin, layout.row_step, layout.row_end,
+         layout.bin_shift, int(layout.exact_cull), float(depth_to_sort_key_scale), ptr(counters), ptr(attrs),
+         ptr(ntiles), ptr(nkeys), ptr(block_sums), ptr(block_sums_full), current_stream(dev))
+    return attrs, ntiles, nkeys, block_sums, block_sums_full
 
 
 def scan_block_sums(block_sums: torch.Tensor, counters: torch.Tensor,
@@ -119,24 +162,21 @@ def scan_block_sums(block_sums: torch.Tensor, counters: torch.Tensor,
     return k, n_slots, host[COUNTER_MAX_DEPTH_KEY], host[COUNTER_NUM_VISIBLE]
 
 
-def make_keys(attrs, num_owned_tiles, block_offsets, n_keys, width, height, depth_to_sort_key_scale,
-              tile_row_begin=0, tile_row_step=1, exact_tile_cull=True, key_depth_bits=0,
-              num_overlap_tiles=None, block_offsets_full=None):
+def make_keys(attrs, num_keys, block_offsets, n_keys, width, height, depth_to_sort_key_scale,
+              layout: ListLayout = ListLayout(), key_depth_bits=0, num_overlap_tiles=None, block_offsets_full=None):
     """-> (keys, payload, slot_offsets).  key_depth_bits == 0: int64 keys in the reference layout
-    (tile << 32) + depth; key_depth_bits > 0: 32-bit keys (tile << key_depth_bits) | depth, stored in an int32
+    (bin << 32) + depth; key_depth_bits > 0: 32-bit keys (bin << key_depth_bits) | depth, stored in an int32
     tensor.  slot_offsets i32[M] = exclusive scan of num_overlap_tiles (base of every Gaussian's backward
-    slots); computed from num_overlap_tiles + its scanned block sums when given, else from the owned counts."""
+    slots) when num_overlap_tiles + its scanned block sums are given, else None (inference)."""
     dev = attrs.device
     m = attrs.shape[0]
     keys = torch.empty(n_keys, dtype=torch.int64 if key_depth_bits == 0 else torch.int32, device=dev)
     payload = torch.empty(n_keys, dtype=torch.int32, device=dev)
-    slot_offsets = torch.empty(m, dtype=torch.int32, device=dev)
-    if num_overlap_tiles is None:
-        num_overlap_tiles, block_offsets_full = num_owned_tiles, block_offsets
+    slot_offsets = torch.empty(m, dtype=torch.int32, device=dev) if num_overlap_tiles is not None else None
     if m > 0:
-        call("gs_make_keys", ptr(attrs), ptr(num_owned_tiles), ptr(block_offsets), m, int(width),
-             int(height), int(tile_row_begin), int(tile_row_step), int(bool(exact_tile_cull)), int(key_depth_bits),
-             float(depth_to_sort_key_scale), ptr(keys), ptr(payload), ptr(num_overlap_tiles),
+        call("gs_make_keys", ptr(attrs), ptr(num_keys), ptr(block_offsets), m, int(width), int(height),
+             layout.row_begin, layout.row_step, layout.row_end, layout.bin_shift, int(layout.exact_cull),
+             int(key_depth_bits), float(depth_to_sort_key_scale), ptr(keys), ptr(payload), ptr(num_overlap_tiles),
              ptr(block_offsets_full), ptr(slot_offsets), current_stream(dev))
     return keys, payload, slot_offsets
 
@@ -188,6 +228,7 @@ def sort_pairs(keys: torch.Tensor, payload: torch.Tensor, depth_bits: int, tile_
 
 
 def tile_ranges(keys_sorted: torch.Tensor, num_tiles: int, key_depth_bits: int = 0):
+    """Per-bin [start, end) ranges of the sorted keys (num_tiles = number of bins; tiles with bin_shift 0)."""
     if keys_sorted.dtype != (torch.int64 if key_depth_bits == 0 else torch.int32):
         raise TypeError("key dtype does not match the key layout")
     dev = keys_sorted.device
@@ -200,18 +241,17 @@ def tile_ranges(keys_sorted: torch.Tensor, num_tiles: int, key_depth_bits: int =
 
 BLEND_RGB_ONLY = 1      # include/gsplat_hip.h GS_BLEND_RGB_ONLY: no depth / per-pixel count (RAS:464-469,478-484)
 BLEND_NO_STATE = 2      # GS_BLEND_NO_STATE: no acc_alpha / last_effective (nothing will be back-propagated)
-BLEND_BACKWARD_V1 = 1   # GS_BLEND_BACKWARD_V1: the round-1 backward kernel (A/B baseline)
 
 
-def blend_forward(tile_start, tile_end, payload, attrs, width, height, tile_row_begin=0, tile_row_step=1,
+def blend_forward(bin_start, bin_end, payload, attrs, width, height, layout: ListLayout = ListLayout(),
                   out=None, rgb_only=False, need_state=True, debug_hits=False):
     """-> (image, depth, acc_alpha, last_effective, count).  rgb_only: depth and count are not computed (returned
     as None); need_state=False: acc_alpha / last_effective are not computed (None) -- the inference path.
     debug_hits=True appends a uint32-as-int32 [H,W,2] tensor {blended count, hash of blended payloads} per pixel."""
-    dev = tile_start.device
+    dev = bin_start.device
     flags = (BLEND_RGB_ONLY if rgb_only else 0) | (0 if need_state else BLEND_NO_STATE)
     if out is None:
-        alloc = torch.empty if tile_row_step == 1 else torch.zeros  # un-owned tiles are left untouched
+        alloc = torch.zeros if layout.sharded else torch.empty  # un-owned tiles are left untouched
         f32 = lambda *shape: alloc(shape, dtype=torch.float32, device=dev)   # noqa: E731
         i32 = lambda *shape: alloc(shape, dtype=torch.int32, device=dev)     # noqa: E731
         out = (f32(height, width, 3), None if rgb_only else f32(height, width),
@@ -219,27 +259,27 @@ def blend_forward(tile_start, tile_end, payload, attrs, width, height, tile_row_
                None if rgb_only else i32(height, width))
     image, depth, acc_alpha, last_eff, count = out
     dbg = torch.zeros((height, width, 2), dtype=torch.int32, device=dev) if debug_hits else None
-    call("gs_blend_forward", ptr(tile_start), ptr(tile_end), ptr(payload), ptr(attrs), int(width), int(height),
-         int(tile_row_begin), int(tile_row_step), ptr(image), ptr(depth), ptr(acc_alpha), ptr(last_eff), ptr(count),
-         flags, ptr(dbg), current_stream(dev))
+    call("gs_blend_forward", ptr(bin_start), ptr(bin_end), ptr(payload), ptr(attrs), int(width), int(height),
+         layout.row_begin, layout.row_step, layout.row_end, layout.bin_shift, layout.filter, ptr(image), ptr(depth),
+         ptr(acc_alpha), ptr(last_eff), ptr(count), flags, ptr(dbg), current_stream(dev))
     return out + (dbg,) if debug_hits else out
 
 
-def blend_backward_partials(tile_start, tile_end, payload, attrs, grad_image, acc_alpha, last_eff, slot_offsets,
-                            n_slots, width, height, tile_row_begin=0, tile_row_step=1, variant=0, debug_hits=False):
+def blend_backward_partials(bin_start, payload, attrs, grad_image, acc_alpha, last_eff, slot_offsets, n_slots,
+                            width, height, layout: ListLayout = ListLayout(), debug_hits=False):
     """Per-pixel backward pass -> (partials f32[S,12], slot_flags u8[S], magnitude image f32[H,W,2]): one partial
-    record per (Gaussian, tile) slot, plain stores, no atomics.  variant: 0 or BLEND_BACKWARD_V1.  debug_hits=True
-    appends the per-pixel {count, hash} record of the pairs the backward treated as blended (see blend_forward)."""
+    record per (Gaussian, tile) slot, plain stores, no atomics.  debug_hits=True appends the per-pixel
+    {count, hash} record of the pairs the backward treated as blended (see blend_forward)."""
     dev = attrs.device
     grad_image = _f32(grad_image, "grad_rasterized_image")
     partials = torch.empty((max(int(n_slots), 1), ACC_STRIDE), dtype=torch.float32, device=dev)
     flags = torch.empty(max(int(n_slots), 1), dtype=torch.uint8, device=dev)
-    alloc = torch.empty if tile_row_step == 1 else torch.zeros
+    alloc = torch.zeros if layout.sharded else torch.empty
     mag = alloc((height, width, 2), dtype=torch.float32, device=dev)
     dbg = torch.zeros((height, width, 2), dtype=torch.int32, device=dev) if debug_hits else None
-    call("gs_blend_backward", ptr(tile_start), ptr(tile_end), ptr(payload), ptr(attrs), ptr(grad_image),
-         ptr(acc_alpha), ptr(last_eff), ptr(slot_offsets), int(n_slots), int(width), int(height),
-         int(tile_row_begin), int(tile_row_step), ptr(partials), ptr(flags), ptr(mag), int(variant), ptr(dbg),
+    call("gs_blend_backward", ptr(bin_start), ptr(payload), ptr(attrs), ptr(grad_image), ptr(acc_alpha),
+         ptr(last_eff), ptr(slot_offsets), int(n_slots), int(width), int(height), layout.row_begin, layout.row_step,
+         layout.row_end, layout.bin_shift, layout.filter, ptr(partials), ptr(flags), ptr(mag), ptr(dbg),
          current_stream(dev))
     return (partials, flags, mag, dbg) if debug_hits else (partials, flags, mag)
 
@@ -253,12 +293,11 @@ def reduce_partials(slot_offsets, num_overlap_tiles, flags, partials):
     return acc
 
 
-def blend_backward(tile_start, tile_end, payload, attrs, grad_image, acc_alpha, last_eff, slot_offsets,
-                   num_overlap_tiles, n_slots, width, height, tile_row_begin=0, tile_row_step=1, variant=0):
+def blend_backward(bin_start, payload, attrs, grad_image, acc_alpha, last_eff, slot_offsets, num_overlap_tiles,
+                   n_slots, width, height, layout: ListLayout = ListLayout()):
     """-> (acc f32[M,12], magnitude_grad_viewspace_on_image f32[H,W,2]): blend_backward_partials + reduce_partials."""
-    partials, flags, mag = blend_backward_partials(tile_start, tile_end, payload, attrs, grad_image, acc_alpha,
-                                                   last_eff, slot_offsets, n_slots, width, height, tile_row_begin,
-                                                   tile_row_step, variant)
+    partials, flags, mag = blend_backward_partials(bin_start, payload, attrs, grad_image, acc_alpha, last_eff,
+                                                   slot_offsets, n_slots, width, height, layout)
     return reduce_partials(slot_offsets, num_overlap_tiles, flags, partials), mag
 
 

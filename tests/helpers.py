@@ -25,17 +25,21 @@ def oracle_forward(s: SyntheticScene, precision="f32", want_margin=True):
                      want_margin=want_margin)
 
 
-def pack_attrs(f: dict) -> np.ndarray:
+def pack_attrs(f: dict, exact_cull: bool = False) -> np.ndarray:
     """Oracle SoA intermediates -> the packed [M,16] record of include/gsplat_hip.h."""
     m = f["ids"].shape[0]
     a = np.empty((m, 16), np.float32)
-    a[:, 0:2] = f["uv"]; a[:, 2] = f["xyz_cam"][:, 2]; a[:, 3] = f["alpha"]
-    a[:, 4:8] = f["conic"]; a[:, 8:11] = f["rgb"]; a[:, 11] = f["radii"]
+    amp = f["alpha"] * f["conic"][:, 3]                                   # opacity * rescale
+    a[:, 0:2] = f["uv"]; a[:, 2] = f["xyz_cam"][:, 2]
+    with np.errstate(divide="ignore", invalid="ignore"):
+        a[:, 3] = (np.float32(2.0) * np.log(np.float32(255.0) * amp) + np.float32(1e-2)) if exact_cull else np.inf
+    a[:, 4:7] = f["conic"][:, 0:3]; a[:, 7] = f["radii"]
+    a[:, 8:11] = f["rgb"]; a[:, 11] = f["alpha"]
     log2e = np.float32(1.4426950408889634)
     a[:, 12] = (np.float32(-0.5) * log2e) * a[:, 4]
     a[:, 13] = (-log2e) * a[:, 5]
     a[:, 14] = (np.float32(-0.5) * log2e) * a[:, 6]
-    a[:, 15] = a[:, 3] * a[:, 7]
+    a[:, 15] = amp
     return a
 
 

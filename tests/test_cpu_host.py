@@ -41,8 +41,11 @@ def test_argument_validation_without_gpu(lib):
     assert l.gs_pose_inverse(None, None, None, None, 0, None) == -1
     assert b"n_obj" in l.gs_last_error()
     assert l.gs_sort_pairs(None, None, None, None, 10, 0, 70, 3, 0, None, None) == -1
-    assert l.gs_blend_forward(None, None, None, None, 100, 64, 0, 1, None, None, None, None, None, 0, None, None) == -1
+    assert l.gs_blend_forward(None, None, None, None, 100, 64, 0, 1, 4, 2, 3, None, None, None, None, None, 0, None, None) == -1
     assert b"multiple of 16" in l.gs_last_error()
+    # lists that cover several tiles (bins) cannot be blended without the tile-box filter
+    assert l.gs_blend_forward(None, None, None, None, 128, 64, 0, 1, 4, 2, 0, None, None, None, None, None, 0, None, None) == -1
+    assert b"box filter" in l.gs_last_error()
     assert l.gs_sort_pairs(None, None, None, None, 1, 0, 17, 13, 0, None, None) == 0  # n <= 1: nothing to do
     assert l.gs_sort_pairs(None, None, None, None, 10, 25, 25, 13, 0, None, None) == -1  # 25+13 bits > 32
     assert l.gs_sort_workspace_bytes(10_000_000) > 256 * 4 * (10_000_000 // 4096)
@@ -134,3 +137,18 @@ def test_synthetic_scene_is_deterministic_and_matches_survey_sizes():
     # SURVEY.md section 8 preamble: cfg1 M = 1e4, K ~ 4.8e4
     assert len(f["ids"]) == 10_000 and 4.5e4 < len(f["keys"]) < 5.1e4
     assert not a.point_cloud_features[:, 9:24].any()  # "SH degree 0" = higher orders are zero in the data
+
+
+def test_list_layout_object():
+    from taichi_3d_gaussian_splatting_amd.hip_ops import FILTER_BOX, FILTER_CULL, PER_TILE_LISTS, ListLayout
+    d = ListLayout()
+    assert (d.bin_shift, d.exact_cull, d.filter, d.sharded) == (2, True, FILTER_BOX | FILTER_CULL, False)
+    assert d.num_bins(1920, 1072) == 30 * 17 and ListLayout(bin_shift=0).num_bins(1920, 1072) == 120 * 67
+    assert ListLayout(exact_cull=False).filter == FILTER_BOX
+    assert PER_TILE_LISTS.filter == 0 and PER_TILE_LISTS.bin_shift == 0
+    with pytest.raises(ValueError):
+        ListLayout(bin_shift=2, prefiltered=True).filter
+    band = ListLayout(row_begin=8, row_end=20)
+    assert band.sharded and list(band.owned_rows(1072)) == list(range(8, 20))
+    assert list(ListLayout(row_begin=1, row_step=3).owned_rows(160)) == [1, 4, 7]
+    assert list(ListLayout(row_begin=60, row_end=100).owned_rows(1072)) == list(range(60, 67))

@@ -65,9 +65,10 @@ def test_filter_compact_bit_exact(ops, scene, ofwd):
 def test_preprocess(ops, scene, ofwd):
     s = scene
     feat = dev(s.point_cloud_features).clone()
+    per_tile = ops.ListLayout(bin_shift=0, exact_cull=False)   # the reference's binning: one key per tile of the box
     attrs, ntiles, nowned, block_sums, block_sums_full = ops.preprocess(
         dev(s.point_cloud), feat, dev(s.point_object_id), dev(s.camera_intrinsics), dev(ofwd["q_cp"]),
-        dev(ofwd["t_cp"]), dev(ofwd["ids"]), s.width, s.height, exact_tile_cull=False)
+        dev(ofwd["t_cp"]), dev(ofwd["ids"]), s.width, s.height, per_tile)
     a, ref = attrs.cpu().numpy(), pack_attrs(ofwd)
     assert a.shape[1] == 16
     # projection is evaluated in the oracle's operation order with contraction off: bit-exact
@@ -76,10 +77,11 @@ def test_preprocess(ops, scene, ofwd):
     # gathered otherwise); with the cull off that is every Gaussian whose tile box is not empty
     emits = ofwd["num_overlap_tiles"] > 0
     report("preprocess.emitting", fraction=float(emits.mean()))
-    for name, sl, rtol in (("opacity", slice(3, 4), 1e-6), ("conic", slice(4, 7), 2e-5), ("rescale", slice(7, 8), 2e-5),
-                           ("rgb", slice(8, 11), 2e-6), ("radius", slice(11, 12), 1e-5),
-                           ("prescaled_conic", slice(12, 15), 2e-5), ("amp", slice(15, 16), 2e-5)):
-        rows = slice(None) if name == "opacity" else emits
+    assert np.isinf(a[:, 3]).all() and (a[:, 3] > 0).all()     # cull off: the stored bound is +inf
+    for name, sl, rtol in (("conic", slice(4, 7), 2e-5), ("radius", slice(7, 8), 1e-5), ("rgb", slice(8, 11), 2e-6),
+                           ("opacity", slice(11, 12), 1e-6), ("prescaled_conic", slice(12, 15), 2e-5),
+                           ("amp", slice(15, 16), 2e-5)):
+        rows = emits
         frac = close_fraction(a[rows, sl], ref[rows, sl], rtol=rtol, atol=1e-7)
         report(f"preprocess.{name}", close=frac, max_abs=float(np.abs(a[rows, sl] - ref[rows, sl]).max()))
         assert frac == 1.0, name
@@ -92,10 +94,47 @@ def test_preprocess(ops, scene, ofwd):
     mism = int((ntiles.cpu().numpy() != ofwd["num_overlap_tiles"]).sum())
     report("preprocess.num_overlap_tiles", mismatches=mism, m=len(ofwd["ids"]))
     assert mism == 0   # integer work: identical (uv and the radius chain are evaluated in the oracle's operation order)
-    assert np.array_equal(nowned.cpu().numpy(), ntiles.cpu().numpy())  # 1 GPU owns every row
+    assert np.array_equal(nowned.cpu().numpy(), ntiles.cpu().numpy())  # 1 GPU owns every row, one key per tile
     sums = np.add.reduceat(ntiles.cpu().numpy(), np.arange(0, len(ofwd["ids"]), 256))
     assert np.array_equal(block_sums.cpu().numpy(), sums)
     assert np.array_equal(block_sums_full.cpu().numpy(), sums)
+    # production layout: keys per 64 x 64-pixel bin, exact cull on: the box count (hook output) is unchanged, the key
+    # count is the number of bins of the box (at most), the cull bound is stored
+    feat2 = dev(s.point_cloud_features).clone()
+    attrs2, ntiles2, nkeys2, bs2, bsf2 = ops.preprocess(
+        dev(s.point_cloud), feat2, dev(s.point_object_id), dev(s.camera_intrinsics), dev(ofwd["q_cp"]),
+        dev(ofwd["t_cp"]), dev(ofwd["ids"]), s.width, s.height, ops.ListLayout())
+    assert torch.equal(ntiles2, ntiles) and torch.equal(bsf2, block_sums_full)
+    assert (nkeys2 <= ntiles2).all() and int(nkeys2.sum()) < int(ntiles2.sum())
+    a2 = attrs2.cpu().numpy()
+    assert np.array_equal(a2[:, 0:3], a[:, 0:3])
+    ref_q = pack_attrs(ofwd, exact_cull=True)[:, 3]
+    live = emits & (nkeys2.cpu().numpy() > 0)
+    assert np.allclose(a2[live, 3], ref_q[live], rtol=1e-5, atol=1e-5)
+    box_bins = O_box_bins(ofwd, s.width, s.height, 2)
+    assert (nkeys2.cpu().numpy() <= box_bins).all()
+    report("preprocess.bins", keys_per_tile_layout=int(ntiles.sum()), keys_bins_no_cull=int(box_bins.sum()),
+           keys_bins_cull=int(nkeys2.sum()))
+
+
+def O_tile_boxes(f, width, height):
+    """Tile boxes [t0u, t1u) x [t0v, t1v) of RAS:81-103 restated on the oracle's uv / radii."""
+    tw, th = width // 16, height // 16
+    u, v = f["uv"][:, 0].astype(np.float32), f["uv"][:, 1].astype(np.float32)
+    r = np.maximum(f["radii"].astype(np.float32), np.float32(1.0))
+    t0u = np.minimum(np.floor(np.maximum(np.float32(0), u - r) / np.float32(16)).astype(np.int64), tw)
+    t1u = np.minimum(np.maximum(np.floor((u + r) / np.float32(16)).astype(np.int64) + 1, t0u + 1), tw)
+    t0v = np.minimum(np.floor(np.maximum(np.float32(0), v - r) / np.float32(16)).astype(np.int64), th)
+    t1v = np.minimum(np.maximum(np.floor((v + r) / np.float32(16)).astype(np.int64) + 1, t0v + 1), th)
+    return t0u, t1u, t0v, t1v
+
+
+def O_box_bins(f, width, height, bin_shift):
+    """Number of (1 << bin_shift)^2-tile bins under each Gaussian's tile box."""
+    t0u, t1u, t0v, t1v = O_tile_boxes(f, width, height)
+    nu = np.where(t1u > t0u, ((t1u - 1) >> bin_shift) - (t0u >> bin_shift) + 1, 0)
+    nv = np.where(t1v > t0v, ((t1v - 1) >> bin_shift) - (t0v >> bin_shift) + 1, 0)
+    return nu * nv
 
 
 def test_keys_sort_ranges_bit_exact(ops, scene, ofwd):
@@ -107,8 +146,11 @@ def test_keys_sort_ranges_bit_exact(ops, scene, ofwd):
     counters = torch.zeros(ops.NUM_COUNTERS, dtype=torch.int32, device="cuda")
     k = ops.scan_block_sums(block_sums, counters)
     assert k == ofwd["keys"].shape[0]
+    per_tile = ops.ListLayout(bin_shift=0, exact_cull=False)   # the reference's keys: one per tile of the box
+    block_sums_full = block_sums.clone()
     keys, payload, slot_offsets = ops.make_keys(attrs, nt, block_sums, k, s.width, s.height,
-                                                s.depth_to_sort_key_scale, exact_tile_cull=False, key_depth_bits=0)
+                                                s.depth_to_sort_key_scale, per_tile, key_depth_bits=0,
+                                                num_overlap_tiles=nt, block_offsets_full=block_sums_full)
     assert np.array_equal(slot_offsets.cpu().numpy(), ofwd["offsets"].astype(np.int32))  # RAS:913-922
     # unsorted keys: same generation order as RAS:161-172
     uk = np.empty(k, np.int64); up = np.empty(k, np.int32)
@@ -130,8 +172,9 @@ def test_keys_sort_ranges_bit_exact(ops, scene, ofwd):
     # compressed 32-bit key layout: same order, same payload permutation, same tile ranges
     kdb, db2, tb2 = ops.key_layout(s.near_plane, s.far_plane, s.depth_to_sort_key_scale, num_tiles)
     assert kdb == db and (db2, tb2) == (db, tb)
-    keys32, payload32, _ = ops.make_keys(attrs, nt, block_sums, k, s.width, s.height, s.depth_to_sort_key_scale,
-                                         exact_tile_cull=False, key_depth_bits=kdb)
+    keys32, payload32, none = ops.make_keys(attrs, nt, block_sums, k, s.width, s.height, s.depth_to_sort_key_scale,
+                                            per_tile, key_depth_bits=kdb)
+    assert none is None   # no slot offsets asked for (inference)
     expect32 = (((uk >> 32) << kdb) | (uk & 0xffffffff)).astype(np.uint32)
     assert np.array_equal(keys32.cpu().numpy().view(np.uint32), expect32)
     ops.sort_pairs(keys32, payload32, db, tb, kdb)
@@ -141,53 +184,76 @@ def test_keys_sort_ranges_bit_exact(ops, scene, ofwd):
     assert np.array_equal(end32.cpu().numpy(), ofwd["tile_end"])
 
 
-def test_exact_tile_cull_is_output_identical(ops, scene, ofwd):
-    """Culled (tile, Gaussian) pairs are a subset of the reference's pairs, each culled pair stays below the
-    1/255 skip threshold on all 256 pixels of its tile (checked in float64), and the blended outputs do not
-    change by a single bit."""
+def _pipeline(ops, s, ofwd, layout, g=None):
+    """HIP stages after the frustum filter under a list layout -> forward outputs (+ debug hit records), sorted keys,
+    and (with an upstream gradient g) the backward accumulators."""
+    feat = dev(s.point_cloud_features).clone()  # fresh copy: preprocess normalises q in place
+    a, nfull, nkeys, bsums, bsums_full = ops.preprocess(
+        dev(s.point_cloud), feat, dev(s.point_object_id), dev(s.camera_intrinsics), dev(ofwd["q_cp"]),
+        dev(ofwd["t_cp"]), dev(ofwd["ids"]), s.width, s.height, layout, s.depth_to_sort_key_scale)
+    counters = torch.zeros(ops.NUM_COUNTERS, dtype=torch.int32, device="cuda")
+    k, n_slots, _, _ = ops.scan_block_sums(bsums, counters, bsums_full)
+    keys, payload, slot_offsets = ops.make_keys(a, nkeys, bsums, k, s.width, s.height, s.depth_to_sort_key_scale,
+                                                layout, 0, nfull, bsums_full)
+    assert np.array_equal(nfull.cpu().numpy(), ofwd["num_overlap_tiles"])  # hook output is always the box count
+    assert np.array_equal(slot_offsets.cpu().numpy(), ofwd["offsets"].astype(np.int32))
+    nb = layout.num_bins(s.width, s.height)
+    db, tb = ops.sort_key_bits(s.near_plane, s.far_plane, s.depth_to_sort_key_scale, nb)
+    ops.sort_pairs(keys, payload, db, tb)
+    start, end = ops.tile_ranges(keys, nb)
+    out = ops.blend_forward(start, end, payload, a, s.width, s.height, layout, debug_hits=True)
+    res = dict(k=k, keys=keys.cpu().numpy(), payload=payload.cpu().numpy(), fwd=[t.cpu() for t in out])
+    if g is not None:
+        image, depth, acc_alpha, last_eff, count, _ = out
+        partials, flags, mag, dbg = ops.blend_backward_partials(start, payload, a, g, acc_alpha, last_eff, slot_offsets,
+                                                                n_slots, s.width, s.height, layout, debug_hits=True)
+        res.update(acc=ops.reduce_partials(slot_offsets, nfull, flags, partials).cpu(), mag=mag.cpu(), bwd_dbg=dbg.cpu())
+    return res
+
+
+def test_list_layouts_are_output_identical(ops, scene, ofwd, obwd):
+    """The reference sorts one key per (tile, Gaussian) of the tile box (RAS:131-172).  The production layout sorts one
+    key per (64 x 64-pixel bin, Gaussian), drops pairs that cannot reach alpha >= 1/255, and lets every tile recover its
+    own list from its bin's list.  Every combination blends the SAME Gaussians into every pixel in the same order:
+    image, depth, accumulated alpha, counts and the per-pixel {count, hash} of blended Gaussians are bit-identical,
+    and so are the backward sums."""
     s = scene
-    attrs = dev(pack_attrs(ofwd))
-    outs = {}
-    for cull in (False, True):
-        feat = dev(s.point_cloud_features).clone()  # fresh copy: preprocess normalises q in place
-        a, nfull, nowned, bsums, bsums_full = ops.preprocess(
-            dev(s.point_cloud), feat, dev(s.point_object_id), dev(s.camera_intrinsics), dev(ofwd["q_cp"]),
-            dev(ofwd["t_cp"]), dev(ofwd["ids"]), s.width, s.height, exact_tile_cull=cull)
-        counters = torch.zeros(ops.NUM_COUNTERS, dtype=torch.int32, device="cuda")
-        k = ops.scan_block_sums(bsums, counters)
-        keys, payload, _ = ops.make_keys(a, nowned, bsums, k, s.width, s.height, s.depth_to_sort_key_scale,
-                                         exact_tile_cull=cull, key_depth_bits=0)
-        assert np.array_equal(nfull.cpu().numpy(), ofwd["num_overlap_tiles"])  # hook output is the box count
-        num_tiles = (s.width // 16) * (s.height // 16)
-        db, tb = ops.sort_key_bits(s.near_plane, s.far_plane, s.depth_to_sort_key_scale, num_tiles)
-        ops.sort_pairs(keys, payload, db, tb)
-        start, end = ops.tile_ranges(keys, num_tiles)
-        img = ops.blend_forward(start, end, payload, a, s.width, s.height)
-        outs[cull] = (keys.cpu().numpy(), payload.cpu().numpy(), [t.cpu() for t in img], k)
-    k_full, k_cull = outs[False][3], outs[True][3]
-    report("exact_tile_cull", pairs_reference=k_full, pairs_kept=k_cull, kept_fraction=k_cull / k_full)
-    assert k_cull < k_full
-    pair = lambda keys, pay: (keys >> 32) * (1 << 32) + pay  # noqa: E731  (tile, point) identifier
-    full_pairs, kept_pairs = pair(outs[False][0], outs[False][1]), pair(outs[True][0], outs[True][1])
-    assert np.isin(kept_pairs, full_pairs).all()
-    culled = np.setdiff1d(full_pairs, kept_pairs)
-    tile, pt = culled >> 32, culled & 0xffffffff
-    tw = s.width // 16
+    g = dev(obwd[0])
+    layouts = {"tile": ops.ListLayout(bin_shift=0, exact_cull=False), "tile+cull": ops.ListLayout(bin_shift=0),
+               "bin": ops.ListLayout(bin_shift=2, exact_cull=False), "bin+cull": ops.ListLayout(),
+               "bin8+cull": ops.ListLayout(bin_shift=3)}
+    outs = {name: _pipeline(ops, s, ofwd, lay, g) for name, lay in layouts.items()}
+    ref = outs["tile"]
+    assert np.array_equal(ref["keys"], ofwd["keys"]) and np.array_equal(ref["payload"], ofwd["payload"])
+    report("list_layouts", **{name: o["k"] for name, o in outs.items()})
+    assert outs["bin+cull"]["k"] < outs["bin"]["k"] < ref["k"] and outs["tile+cull"]["k"] < ref["k"]
+    names = ["image", "depth", "acc_alpha", "last_eff", "count", "debug_hits"]
+    for name, o in outs.items():
+        for i in (0, 1, 2, 4, 5):  # last_eff is a list position and legitimately differs between layouts
+            assert torch.equal(o["fwd"][i], ref["fwd"][i]), (name, names[i])
+        assert torch.equal(o["bwd_dbg"], ref["fwd"][5]), name            # backward treats the same pairs as blended
+        assert torch.equal(o["acc"].view(torch.int32), ref["acc"].view(torch.int32)), name
+        assert torch.equal(o["mag"], ref["mag"]), name
+    # every (bin, Gaussian) key the cull dropped stays below 1/255 on all pixels of the bin (float64 check)
+    full, kept = outs["bin"], outs["bin+cull"]
+    pair = lambda o: (o["keys"] >> 32) * (1 << 32) + o["payload"]  # noqa: E731  (bin, point) identifier
+    culled = np.setdiff1d(pair(full), pair(kept))
+    assert np.isin(pair(kept), pair(full)).all() and len(culled) > 0
+    bins_u = (s.width // 16 + 3) // 4
+    b, pt = culled >> 32, culled & 0xffffffff
     uv, conic, al = ofwd["uv"].astype(np.float64), ofwd["conic"].astype(np.float64), ofwd["alpha"].astype(np.float64)
-    px = (tile % tw)[:, None] * 16 + (np.arange(256) % 16)[None, :] + 0.5
-    py = (tile // tw)[:, None] * 16 + (np.arange(256) // 16)[None, :] + 0.5
+    px = (b % bins_u)[:, None] * 64 + (np.arange(4096) % 64)[None, :] + 0.5
+    py = (b // bins_u)[:, None] * 64 + (np.arange(4096) // 64)[None, :] + 0.5
     dx, dy = px - uv[pt, 0:1], py - uv[pt, 1:2]
     e = -0.5 * (dx * dx * conic[pt, 0:1] + dy * dy * conic[pt, 2:3]) - dx * dy * conic[pt, 1:2]
-    amax = (np.exp(e) * conic[pt, 3:4] * al[pt, None]).max(axis=1)
-    report("exact_tile_cull.culled_pairs", n=len(culled), max_alpha=float(amax.max()), threshold=1 / 255)
+    alpha = np.exp(e) * conic[pt, 3:4] * al[pt, None]
+    # only the bin's tiles inside the Gaussian's tile box count: the reference never blends outside the box
+    box = O_tile_boxes(ofwd, s.width, s.height)
+    in_box = ((px // 16 >= box[0][pt, None]) & (px // 16 < box[1][pt, None]) &
+              (py // 16 >= box[2][pt, None]) & (py // 16 < box[3][pt, None]))
+    amax = np.where(in_box, alpha, 0.0).max(axis=1)
+    report("list_layouts.culled_bin_pairs", n=len(culled), max_alpha=float(amax.max()), threshold=1 / 255)
     assert amax.max() < 1.0 / 255.0
-    names = ["image", "depth", "acc_alpha", "last_eff", "count"]
-    for i in (0, 1, 2, 4):  # last_eff is a list position and legitimately differs
-        a, b = outs[False][2][i], outs[True][2][i]
-        ndiff = int((a != b).sum())
-        report(f"exact_tile_cull.{names[i]}", differing=ndiff,
-               max_abs=float((a.double() - b.double()).abs().max()))
-        assert ndiff == 0, names[i]  # bit-identical
 
 
 @pytest.mark.parametrize("n,depth_bits,tile_bits,compressed", [
@@ -253,7 +319,7 @@ def _check_image(name, hip, ref, fragile):
 def test_blend_forward(ops, scene, ofwd):
     s = scene
     out = ops.blend_forward(dev(ofwd["tile_start"]), dev(ofwd["tile_end"]), dev(ofwd["payload"]),
-                            dev(pack_attrs(ofwd)), s.width, s.height)
+                            dev(pack_attrs(ofwd)), s.width, s.height, ops.PER_TILE_LISTS)
     image, depth, acc_alpha, last_eff, count = [t.cpu().numpy() for t in out]
     fragile = ofwd["margin"] < FRAGILE_MARGIN
     _check_image("blend_forward.image", image, ofwd["image"], fragile)
@@ -311,9 +377,9 @@ def test_blend_backward(ops, scene, ofwd, obwd):
     g, ob = obwd
     slot_offsets = dev(ofwd["offsets"].astype(np.int32))
     n_slots = int(ofwd["num_overlap_tiles"].sum())
-    args = (dev(ofwd["tile_start"]), dev(ofwd["tile_end"]), dev(ofwd["payload"]), dev(pack_attrs(ofwd)), dev(g),
+    args = (dev(ofwd["tile_start"]), dev(ofwd["payload"]), dev(pack_attrs(ofwd)), dev(g),
             dev(ofwd["acc_alpha"]), dev(ofwd["last_eff"]), slot_offsets, dev(ofwd["num_overlap_tiles"]), n_slots,
-            s.width, s.height)
+            s.width, s.height, ops.PER_TILE_LISTS)
     acc, mag = ops.blend_backward(*args)
     acc2, mag2 = ops.blend_backward(*args)
     assert torch.equal(acc.view(torch.int32), acc2.view(torch.int32)) and torch.equal(mag, mag2), \
@@ -331,10 +397,7 @@ def test_blend_backward(ops, scene, ofwd, obwd):
     # integer output: a (pixel, Gaussian) pair can only be counted differently on a fragile pixel, one pair per pixel
     assert int(np.abs(npix - ref_npix).sum()) <= n_fragile
     _check_acc("blend_backward.magnitude_image", mag.cpu().numpy(), ob["hook"]["magnitude_grad_viewspace_on_image"])
-    # the round-1 kernel (selectable) computes the same sums by a different alpha expression
-    acc1, mag1 = ops.blend_backward(*args, variant=ops.BLEND_BACKWARD_V1)
-    for c, nme in enumerate(names):
-        _check_acc(f"blend_backward.v1_vs_v2.{nme}", acc1.cpu().numpy()[:, c], acc[:, c])
+
 
 
 def test_point_backward(ops, scene, ofwd, obwd):
@@ -378,7 +441,7 @@ def test_point_backward_sh_band_clearing(ops, scene, ofwd, obwd, band, keep):
 
 
 # ------------------------------------------------------------------------------- whole operator
-def _run_operator(scene, grad_image, band=3, hook=None, row=(0, 1), op=None):
+def _run_operator(scene, grad_image, band=3, hook=None, row=(0, 1), op=None, row_end=None, bin_shift=None):
     from taichi_3d_gaussian_splatting_amd import CameraInfo, GaussianPointCloudRasterisation as Op
     s = scene.to("cuda")
     xyz = s.point_cloud.clone().requires_grad_(True)
@@ -388,6 +451,10 @@ def _run_operator(scene, grad_image, band=3, hook=None, row=(0, 1), op=None):
                                                          depth_to_sort_key_scale=s.depth_to_sort_key_scale),
                 backward_valid_point_hook=hook)
         op.tile_row_begin, op.tile_row_step = row
+        if row_end is not None:
+            op.tile_row_end = row_end
+        if bin_shift is not None:
+            op.bin_shift = bin_shift
     inp = Op.GaussianPointCloudRasterisationInput(
         point_cloud=xyz, point_cloud_features=feat, point_object_id=s.point_object_id,
         point_invalid_mask=s.point_invalid_mask,
@@ -464,19 +531,20 @@ def _stages_to_ranges(ops, s):
                                              s.camera_intrinsics, q_cp, t_cp, s.near_plane, s.far_plane, s.width,
                                              s.height)
     feat = s.point_cloud_features.clone()
+    layout = ops.ListLayout()
     attrs, ntiles, nowned, bsums, bsums_full = ops.preprocess(
-        s.point_cloud, feat, s.point_object_id, s.camera_intrinsics, q_cp, t_cp, ids, s.width, s.height,
+        s.point_cloud, feat, s.point_object_id, s.camera_intrinsics, q_cp, t_cp, ids, s.width, s.height, layout,
         depth_to_sort_key_scale=s.depth_to_sort_key_scale, counters=counters)
     k, n_slots, max_dq, _ = ops.scan_block_sums(bsums, counters, bsums_full)
-    num_tiles = (s.width // 16) * (s.height // 16)
-    kdb, db, tb = ops.key_layout(s.near_plane, s.far_plane, s.depth_to_sort_key_scale, num_tiles, max_dq)
+    num_bins = layout.num_bins(s.width, s.height)
+    kdb, db, tb = ops.key_layout(s.near_plane, s.far_plane, s.depth_to_sort_key_scale, num_bins, max_dq)
     keys, payload, slot_offsets = ops.make_keys(attrs, nowned, bsums, k, s.width, s.height, s.depth_to_sort_key_scale,
-                                                key_depth_bits=kdb, num_overlap_tiles=ntiles,
+                                                layout, key_depth_bits=kdb, num_overlap_tiles=ntiles,
                                                 block_offsets_full=bsums_full)
     ops.sort_pairs(keys, payload, db, tb, kdb)
-    start, end = ops.tile_ranges(keys, num_tiles, kdb)
+    start, end = ops.tile_ranges(keys, num_bins, kdb)
     return dict(attrs=attrs, ntiles=ntiles, payload=payload, start=start, end=end, slot_offsets=slot_offsets,
-                n_slots=n_slots, k=k)
+                n_slots=n_slots, k=k, layout=layout)
 
 
 @pytest.mark.parametrize("workload", ["cfg2_100k_800", "headline_1m_1080p", "cfg3_400k_1080p"])
@@ -488,20 +556,20 @@ def test_forward_and_backward_blend_the_same_pairs(ops, workload):
     s = make_config_scene(workload).to("cuda")
     st = _stages_to_ranges(ops, s)
     image, depth, acc_alpha, last_eff, count, dbg_f = ops.blend_forward(
-        st["start"], st["end"], st["payload"], st["attrs"], s.width, s.height, debug_hits=True)
+        st["start"], st["end"], st["payload"], st["attrs"], s.width, s.height, st["layout"], debug_hits=True)
     assert torch.equal(dbg_f[:, :, 0], count)
     g = make_grad_image(s.height, s.width).cuda()
     partials, flags, mag, dbg_b = ops.blend_backward_partials(
-        st["start"], st["end"], st["payload"], st["attrs"], g, acc_alpha, last_eff, st["slot_offsets"], st["n_slots"],
-        s.width, s.height, debug_hits=True)
+        st["start"], st["payload"], st["attrs"], g, acc_alpha, last_eff, st["slot_offsets"], st["n_slots"],
+        s.width, s.height, st["layout"], debug_hits=True)
     differing = int((dbg_f != dbg_b).any(dim=2).sum())
     report(f"hit_sets.{workload}", pixels=s.height * s.width, blended_pairs=int(count.sum()),
            pixels_with_different_sets=differing)
     assert differing == 0
     # and the debug build changes nothing: same partial sums as the production kernel, bit for bit
     partials2, flags2, mag2 = ops.blend_backward_partials(
-        st["start"], st["end"], st["payload"], st["attrs"], g, acc_alpha, last_eff, st["slot_offsets"], st["n_slots"],
-        s.width, s.height)
+        st["start"], st["payload"], st["attrs"], g, acc_alpha, last_eff, st["slot_offsets"], st["n_slots"],
+        s.width, s.height, st["layout"])
     raised = flags.bool()
     assert torch.equal(flags, flags2) and torch.equal(mag, mag2)
     assert torch.equal(partials[raised].view(torch.int32), partials2[raised].view(torch.int32))
@@ -529,11 +597,11 @@ def test_rgb_only_and_inference_paths(ops, scene):
     assert torch.equal(inf_rgb[0], full[0]) and not inf_rgb[1].any()
     # stage level: every flag combination writes the same image
     st = _stages_to_ranges(ops, scene.to("cuda"))
-    ref = ops.blend_forward(st["start"], st["end"], st["payload"], st["attrs"], scene.width, scene.height)
+    ref = ops.blend_forward(st["start"], st["end"], st["payload"], st["attrs"], scene.width, scene.height, st["layout"])
     for rgb_only in (False, True):
         for need_state in (False, True):
             out = ops.blend_forward(st["start"], st["end"], st["payload"], st["attrs"], scene.width, scene.height,
-                                    rgb_only=rgb_only, need_state=need_state)
+                                    st["layout"], rgb_only=rgb_only, need_state=need_state)
             assert torch.equal(out[0], ref[0])
             assert (out[1] is None) == rgb_only and (out[2] is None) == (not need_state)
             if not rgb_only:
@@ -633,8 +701,9 @@ def test_headline_size_properties(ops):
                                              s.height)
     assert torch.equal(ids.long(), torch.nonzero(mask).flatten())  # ordered compaction
     feat = s.point_cloud_features.clone()
+    layout = ops.ListLayout()
     attrs, ntiles, nowned, block_sums, block_sums_full = ops.preprocess(
-        s.point_cloud, feat, s.point_object_id, s.camera_intrinsics, q_cp, t_cp, ids, s.width, s.height,
+        s.point_cloud, feat, s.point_object_id, s.camera_intrinsics, q_cp, t_cp, ids, s.width, s.height, layout,
         depth_to_sort_key_scale=s.depth_to_sort_key_scale, counters=counters)
     max_dq = ops.read_counters(counters)[ops.COUNTER_MAX_DEPTH_KEY]
     assert max_dq == int((attrs[:, 2] * s.depth_to_sort_key_scale).int().max().item())
@@ -644,11 +713,12 @@ def test_headline_size_properties(ops):
     k, n_slots, _, m_dev = ops.scan_block_sums(block_sums, counters, block_sums_full)
     assert m_dev == ids.shape[0]
     assert k == total and n_slots == int(ntiles.sum().item())
-    num_tiles = (s.width // 16) * (s.height // 16)
+    num_tiles = layout.num_bins(s.width, s.height)   # lists are per 64 x 64-pixel bin
+    assert num_tiles == 30 * 17
     kdb, db, tb = ops.key_layout(s.near_plane, s.far_plane, s.depth_to_sort_key_scale, num_tiles, max_dq)
     assert 0 < kdb < 17  # production layout at this size: compressed keys, depth field sized to the bits in use
     keys, payload, slot_offsets = ops.make_keys(attrs, nowned, block_sums, k, s.width, s.height,
-                                                s.depth_to_sort_key_scale, key_depth_bits=kdb,
+                                                s.depth_to_sort_key_scale, layout, key_depth_bits=kdb,
                                                 num_overlap_tiles=ntiles, block_offsets_full=block_sums_full)
     assert torch.equal(slot_offsets.long(), torch.cumsum(ntiles.long(), 0) - ntiles.long())
     # histogram of payload = key counts (every point emits exactly its count)
@@ -661,15 +731,15 @@ def test_headline_size_properties(ops):
     tile_of = ((keys.long() & 0xffffffff) >> kdb).int()
     cnt = torch.bincount(tile_of.long(), minlength=num_tiles).int()
     assert torch.equal(end - start, cnt)
-    image, depth, acc_alpha, last_eff, count = ops.blend_forward(start, end, payload, attrs, s.width, s.height)
+    image, depth, acc_alpha, last_eff, count = ops.blend_forward(start, end, payload, attrs, s.width, s.height, layout)
     assert torch.isfinite(image).all() and image.min() >= 0 and image.max() <= 1.0 + 1e-5
     assert acc_alpha.min() >= 0 and acc_alpha.max() <= 1.0 - 1e-4 + 1e-6  # T never drops below 1e-4
-    tiles_v = torch.arange(s.height, device="cuda") // 16
-    tiles_u = torch.arange(s.width, device="cuda") // 16
-    tid = tiles_v[:, None] * (s.width // 16) + tiles_u[None, :]
+    bins_v = torch.arange(s.height, device="cuda") // 64
+    bins_u = torch.arange(s.width, device="cuda") // 64
+    tid = bins_v[:, None] * 30 + bins_u[None, :]
     assert (last_eff >= start[tid]).all() and (last_eff <= end[tid]).all()
     assert (count <= last_eff - start[tid]).all()
-    report("headline.sizes", M=ids.shape[0], K_reference=int(ntiles.sum().item()), K_after_cull=k)
+    report("headline.sizes", M=ids.shape[0], K_reference=int(ntiles.sum().item()), K_bin_keys=k)
 
 
 def test_rccl_collectives_on_device_world1():

@@ -18,6 +18,7 @@ g = make_grad_image(s.height, s.width).to("cuda")
 times = {}
 CULL = os.environ.get('GS_CULL', '1') == '1'
 AB = os.environ.get('GS_AB', '0') == '1'
+LAYOUT = hip_ops.ListLayout(bin_shift=int(os.environ.get('GS_BIN_SHIFT', '2')), exact_cull=CULL)
 
 
 def timed(name, fn):
@@ -27,7 +28,7 @@ def timed(name, fn):
     return out
 
 
-num_tiles = (s.width // 16) * (s.height // 16)
+num_tiles = LAYOUT.num_bins(s.width, s.height)
 kdb, db, tb = hip_ops.key_layout(s.near_plane, s.far_plane, s.depth_to_sort_key_scale, num_tiles)
 q_cp, t_cp = hip_ops.pose_inverse(s.q_pointcloud_camera, s.t_pointcloud_camera)
 feat = s.point_cloud_features.clone()
@@ -36,29 +37,27 @@ for _ in range(reps + 2):
         s.point_cloud, s.point_invalid_mask, s.point_object_id, s.camera_intrinsics, q_cp, t_cp, s.near_plane,
         s.far_plane, s.width, s.height))
     attrs, ntiles, nowned, bsums, bsums_full = timed("preprocess", lambda: hip_ops.preprocess(
-        s.point_cloud, feat, s.point_object_id, s.camera_intrinsics, q_cp, t_cp, ids, s.width, s.height, 0, 1, CULL, s.depth_to_sort_key_scale, counters))
+        s.point_cloud, feat, s.point_object_id, s.camera_intrinsics, q_cp, t_cp, ids, s.width, s.height, LAYOUT,
+        s.depth_to_sort_key_scale, counters))
     k, n_slots, max_dq, _m = timed("scan_block_sums", lambda: hip_ops.scan_block_sums(bsums, counters, bsums_full))
     kdb, db, tb = hip_ops.key_layout(s.near_plane, s.far_plane, s.depth_to_sort_key_scale, num_tiles, max_dq)
     keys, payload, slot_off = timed("make_keys", lambda: hip_ops.make_keys(attrs, nowned, bsums, k, s.width, s.height,
-                                                                 s.depth_to_sort_key_scale, 0, 1, CULL, kdb, ntiles, bsums_full))
+                                                                 s.depth_to_sort_key_scale, LAYOUT, kdb, ntiles, bsums_full))
     keys, payload = timed("sort_pairs", lambda: hip_ops.sort_pairs(keys, payload, db, tb, kdb, in_place=False))
     start, end = timed("tile_ranges", lambda: hip_ops.tile_ranges(keys, num_tiles, kdb))
     image, depth, acc_alpha, last_eff, count = timed("blend_forward", lambda: hip_ops.blend_forward(
-        start, end, payload, attrs, s.width, s.height))
-    if AB:   # A/B arms: inference forward (image only) and the round-1 backward kernel
+        start, end, payload, attrs, s.width, s.height, LAYOUT))
+    if AB:   # A/B arm: inference forward (image only)
         timed("blend_forward_rgb_nostate", lambda: hip_ops.blend_forward(
-            start, end, payload, attrs, s.width, s.height, rgb_only=True, need_state=False))
-        timed("blend_backward_v1", lambda: hip_ops.blend_backward_partials(
-            start, end, payload, attrs, g, acc_alpha, last_eff, slot_off, n_slots, s.width, s.height,
-            variant=hip_ops.BLEND_BACKWARD_V1))
+            start, end, payload, attrs, s.width, s.height, LAYOUT, rgb_only=True, need_state=False))
     partials, flags, mag = timed("blend_backward", lambda: hip_ops.blend_backward_partials(
-        start, end, payload, attrs, g, acc_alpha, last_eff, slot_off, n_slots, s.width, s.height))
+        start, payload, attrs, g, acc_alpha, last_eff, slot_off, n_slots, s.width, s.height, LAYOUT))
     acc = timed("reduce_partials", lambda: hip_ops.reduce_partials(slot_off, ntiles, flags, partials))
     timed("point_backward", lambda: hip_ops.point_backward(
         s.point_cloud, feat, s.point_object_id, s.camera_intrinsics, q_cp, t_cp, s.t_pointcloud_camera, ids, acc, attrs, 3,
         1.0, 0.5, 20.0, 5.0, 1.0, False, vmask, nowned))
 torch.cuda.synchronize()
-print(f"workload={workload} M={ids.shape[0]} K={k} cull={CULL}")
+print(f"workload={workload} M={ids.shape[0]} K={k} cull={CULL} bin_shift={LAYOUT.bin_shift}")
 tot = 0.0
 for name, pairs in times.items():
     ms = sum(a.elapsed_time(b) for a, b in pairs[2:]) / len(pairs[2:])
@@ -66,10 +65,10 @@ for name, pairs in times.items():
     print(f"  {name:16s} {ms:8.4f} ms")
 print(f"  {'sum':16s} {tot:8.4f} ms")
 lens = (end - start).float()
-eff = (last_eff.view(s.height // 16, 16, s.width // 16, 16).amax(dim=(1, 3)).flatten() - start).float()
-print(f"  tile list mean={lens.mean():.1f} max={lens.max():.0f}; effective (to max last) mean={eff.mean():.1f}; "
-      f"count mean={count.float().mean():.2f}")
-vals = eff.sort(descending=True).values
-print("  effective list percentiles: max=%d p99.9=%d p99=%d p90=%d p50=%d" % (
-    vals[0], vals[int(0.001 * len(vals))], vals[int(0.01 * len(vals))], vals[int(0.1 * len(vals))], vals[len(vals) // 2]))
-print("  sum(eff)=%d; blocks=%d" % (int(eff.sum()), len(vals)))
+side = 16 << LAYOUT.bin_shift
+bins_u = (s.width + side - 1) // side
+tile_bin = (torch.arange(s.height // 16, device="cuda")[:, None] >> LAYOUT.bin_shift) * bins_u + \
+    (torch.arange(s.width // 16, device="cuda")[None, :] >> LAYOUT.bin_shift)
+walked = (last_eff.view(s.height // 16, 16, s.width // 16, 16).amax(dim=(1, 3)) - start[tile_bin.long()]).float().flatten()
+print(f"  bin list mean={lens.mean():.1f} max={lens.max():.0f}; list positions walked per tile (to max last) "
+      f"mean={walked.mean():.1f} max={walked.max():.0f}; blended per pixel mean={count.float().mean():.2f}")
