@@ -152,9 +152,11 @@ class GaussianPointCloudRasterisation(torch.nn.Module):
         self.tile_row_end = hip_ops._NO_ROW_LIMIT
         # drop (bin | tile, Gaussian) pairs that cannot reach alpha >= 1/255 anywhere in the bin | tile (output-identical)
         self.exact_tile_cull = True
-        # sort keys per bin of (1 << bin_shift)^2 tiles (2: 64 x 64 pixels; 0: per tile as the reference); the blend
-        # kernels recover each tile's list from its bin's list, in order (hip_ops.ListLayout)
-        self.bin_shift = 2
+        # sort keys per bin of (1 << bin_shift)^2 tiles: 0 = per tile as the reference (fastest when Gaussians cover few
+        # tiles), 2 = 64 x 64 pixels (the blend kernels recover each tile's list from its bin's list, in order; fastest
+        # when Gaussians cover many tiles), None = chosen per frame from the previous frame's tiles-per-Gaussian ratio
+        self.bin_shift: Optional[int] = None
+        self._auto_bin_shift = 0
         outer = self
 
         class _module_function(torch.autograd.Function):
@@ -178,7 +180,8 @@ class GaussianPointCloudRasterisation(torch.nn.Module):
                          q_pointcloud_camera, t_pointcloud_camera, camera_info, color_max_sh_band, need_state):
                 cfg = outer.config
                 width, height = camera_info.camera_width, camera_info.camera_height
-                layout = hip_ops.ListLayout(bin_shift=outer.bin_shift, exact_cull=outer.exact_tile_cull,
+                bin_shift = outer._auto_bin_shift if outer.bin_shift is None else outer.bin_shift
+                layout = hip_ops.ListLayout(bin_shift=bin_shift, exact_cull=outer.exact_tile_cull,
                                             row_begin=outer.tile_row_begin, row_step=outer.tile_row_step,
                                             row_end=outer.tile_row_end)
                 if not pointcloud_features.is_contiguous():
@@ -206,6 +209,9 @@ class GaussianPointCloudRasterisation(torch.nn.Module):
                 # (the reference syncs twice: RAS:870 and RAS:916)
                 n_keys, n_slots, max_depth_key, m = hip_ops.scan_block_sums(block_sums, counters, block_sums_full)
                 nb = (m + 255) // 256
+                # next frame's list layout: bins once a Gaussian covers >= 64 tiles on average (hysteresis: back at < 32)
+                ratio = n_slots / max(m, 1)
+                outer._auto_bin_shift = 2 if ratio >= (32.0 if outer._auto_bin_shift else 64.0) else 0
                 ids, attrs, num_overlap_tiles, num_owned_tiles = ids[:m], attrs[:m], num_overlap_tiles[:m], \
                     num_owned_tiles[:m]
                 block_sums, block_sums_full = block_sums[:nb], block_sums_full[:nb]

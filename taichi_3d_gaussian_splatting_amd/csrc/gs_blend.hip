@@ -142,11 +142,30 @@ __device__ __forceinline__ void gs_fill_step(const int32_t *__restrict__ payload
     nbuf = min(before, BATCH);
 }
 
+// Per-tile lists (bin_shift 0: the key generator already emitted exactly the tile's entries): the next <= BATCH
+// positions are staged as they are -- no test, no compaction, one barrier (the caller's).
+template <int DIR, typename Store>
+__device__ __forceinline__ void gs_direct_step(const int32_t *__restrict__ payload, const float4 *__restrict__ attrs,
+                                               int &pos, int limit, int &nbuf, Store store) {
+    const int tid = threadIdx.x;
+    const int j = pos + DIR * tid;
+    if (DIR > 0 ? j < limit : j >= limit) {
+        const int o = payload[j];
+        const float4 *g = attrs + 4 * (size_t)o;
+        const float4 r[4] = {g[0], g[1], g[2], g[3]};
+        store(tid, j, o, r);
+    }
+    nbuf = min(BATCH, DIR > 0 ? limit - pos : pos - limit + 1);
+    pos += DIR * BATCH;
+}
+
 // ------------------------------------------------------------------------------- forward
+// STAGED: lists cover a bin of several tiles and are filtered while they are staged (gs_fill_step); otherwise they are
+//         the tile's own list (gs_direct_step)
 // AUX:   depth and per-pixel count are produced (off with rgb_only, RAS:464-469,478-484)
 // STATE: acc_alpha / last_effective are produced (what the backward pass needs; off for inference)
 // DEBUG: per-pixel {number of blended Gaussians, wrap-around sum of (payload+1)*GS_HASH_MUL} -> debug_hits (tests)
-template <bool AUX, bool STATE, bool DEBUG>
+template <bool STAGED, bool AUX, bool STATE, bool DEBUG>
 __global__ __launch_bounds__(BLEND_THREADS) void blend_forward_kernel(
     const int32_t *__restrict__ bin_start, const int32_t *__restrict__ bin_end,
     const int32_t *__restrict__ payload, const float4 *__restrict__ attrs, int width, int height, int row_begin,
@@ -189,7 +208,10 @@ __global__ __launch_bounds__(BLEND_THREADS) void blend_forward_kernel(
         // barrier (protects the staged batch) + whole-tile early exit vote
         if (__syncthreads_and((alive.x + alive.y == 0.f) ? 1 : 0)) break;
         int nbuf = 0;
-        while (nbuf < BATCH && pos < end) gs_fill_step<+1>(payload, attrs, pos, end, nbuf, s_cnt, s_next, keep, store);
+        if (STAGED)
+            while (nbuf < BATCH && pos < end) gs_fill_step<+1>(payload, attrs, pos, end, nbuf, s_cnt, s_next, keep, store);
+        else
+            gs_direct_step<+1>(payload, attrs, pos, end, nbuf, store);
         {   // pad to a multiple of GROUP with inert records (amplitude 0 -> alpha 0, never blended)
             const int padded = (nbuf + GROUP - 1) & ~(GROUP - 1);
             if (tid < padded - nbuf) {
@@ -284,7 +306,7 @@ __global__ __launch_bounds__(BLEND_THREADS) void blend_forward_kernel(
 // UTL:343), and the twelve-value reduce-scatter carries the pixel count as a float (exact below 2^24).  Per round of up
 // to 128 staged entries the two waves combine their partial sums in LDS (ds_add_f32), then thread k stores entry k's
 // 48-B record into its (Gaussian, tile) slot (plain stores).
-template <bool DEBUG>
+template <bool STAGED, bool DEBUG>
 __global__ __launch_bounds__(BLEND_THREADS) void blend_backward_kernel(
     const int32_t *__restrict__ bin_start, const int32_t *__restrict__ payload,
     const float4 *__restrict__ attrs, const float *__restrict__ grad_image, const float *__restrict__ acc_alpha,
@@ -343,8 +365,11 @@ __global__ __launch_bounds__(BLEND_THREADS) void blend_backward_kernel(
     while (pos >= start) {
         __syncthreads();  // previous round fully flushed before its LDS is reused
         int nbuf = 0;
-        while (nbuf < BATCH && pos >= start)
-            gs_fill_step<-1>(payload, attrs, pos, start, nbuf, s_cnt, s_next, keep, store);
+        if (STAGED)
+            while (nbuf < BATCH && pos >= start)
+                gs_fill_step<-1>(payload, attrs, pos, start, nbuf, s_cnt, s_next, keep, store);
+        else
+            gs_direct_step<-1>(payload, attrs, pos, start, nbuf, store);
         {
             const int padded = (nbuf + GROUP - 1) & ~(GROUP - 1);
             if (tid < padded - nbuf) {   // inert padding: amplitude 0 -> alpha 0, never a hit
@@ -481,19 +506,35 @@ __global__ __launch_bounds__(GS_BLOCK) void reduce_partials_kernel(
     acc[3 * (size_t)i + 2] = make_float4(gl, nv, __builtin_bit_cast(float, npix), 0.f);
 }
 
-template <bool AUX, bool STATE>
+template <bool STAGED, bool AUX, bool STATE>
 static void launch_forward(bool debug, dim3 grid, hipStream_t s, const int32_t *bin_start, const int32_t *bin_end,
                            const int32_t *payload, const float4 *attrs, int width, int height, int rb, int rs,
                            int bin_shift, int filter, float *image, float *depth, float *acc_alpha,
                            int32_t *last_effective, int32_t *valid_count, uint32_t *debug_hits) {
     if (debug)
-        hipLaunchKernelGGL((blend_forward_kernel<AUX, STATE, true>), grid, dim3(BLEND_THREADS), 0, s, bin_start, bin_end,
-                           payload, attrs, width, height, rb, rs, bin_shift, filter, image, depth, acc_alpha,
+        hipLaunchKernelGGL((blend_forward_kernel<STAGED, AUX, STATE, true>), grid, dim3(BLEND_THREADS), 0, s, bin_start,
+                           bin_end, payload, attrs, width, height, rb, rs, bin_shift, filter, image, depth, acc_alpha,
                            last_effective, valid_count, debug_hits);
     else
-        hipLaunchKernelGGL((blend_forward_kernel<AUX, STATE, false>), grid, dim3(BLEND_THREADS), 0, s, bin_start, bin_end,
-                           payload, attrs, width, height, rb, rs, bin_shift, filter, image, depth, acc_alpha,
+        hipLaunchKernelGGL((blend_forward_kernel<STAGED, AUX, STATE, false>), grid, dim3(BLEND_THREADS), 0, s, bin_start,
+                           bin_end, payload, attrs, width, height, rb, rs, bin_shift, filter, image, depth, acc_alpha,
                            last_effective, valid_count, debug_hits);
+}
+
+template <bool STAGED>
+static void launch_backward(bool debug, dim3 grid, hipStream_t s, const int32_t *bin_start, const int32_t *payload,
+                            const float4 *attrs, const float *grad_image, const float *acc_alpha,
+                            const int32_t *last_effective, int width, int height, int rb, int rs, int bin_shift,
+                            int filter, const int32_t *slot_offsets, float4 *partials, uint8_t *slot_flags,
+                            float *magnitude_image, uint32_t *debug_hits) {
+    if (debug)
+        hipLaunchKernelGGL((blend_backward_kernel<STAGED, true>), grid, dim3(BLEND_THREADS), 0, s, bin_start, payload,
+                           attrs, grad_image, acc_alpha, last_effective, width, height, rb, rs, bin_shift, filter,
+                           slot_offsets, partials, slot_flags, magnitude_image, debug_hits);
+    else
+        hipLaunchKernelGGL((blend_backward_kernel<STAGED, false>), grid, dim3(BLEND_THREADS), 0, s, bin_start, payload,
+                           attrs, grad_image, acc_alpha, last_effective, width, height, rb, rs, bin_shift, filter,
+                           slot_offsets, partials, slot_flags, magnitude_image, debug_hits);
 }
 
 }  // namespace
@@ -513,6 +554,7 @@ int gs_blend_forward(const int32_t *bin_start, const int32_t *bin_end, const int
     GS_REQUIRE(tile_row_step >= 1 && tile_row_begin >= 0 && tile_row_end >= 0, "tile row ownership");
     GS_REQUIRE(bin_shift >= 0 && bin_shift <= 4, "bin_shift");
     GS_REQUIRE(bin_shift == 0 || (filter & GS_FILTER_BOX), "lists that cover several tiles need the box filter");
+    const bool staged = bin_shift > 0 || filter != 0;   // per-tile lists taken as they are go the direct way
     const bool aux = !(flags & GS_BLEND_RGB_ONLY), state = !(flags & GS_BLEND_NO_STATE);
     GS_REQUIRE(image != nullptr, "image");
     GS_REQUIRE(!aux || (depth != nullptr && valid_count != nullptr), "depth / valid_count (or pass GS_BLEND_RGB_ONLY)");
@@ -525,14 +567,19 @@ int gs_blend_forward(const int32_t *bin_start, const int32_t *bin_end, const int
     const float4 *a4 = reinterpret_cast<const float4 *>(attrs);
     hipStream_t s = (hipStream_t)stream;
     const bool dbg = debug_pixel_hits != nullptr;
-#define GS_FWD(AUX, STATE)                                                                                          \
-    launch_forward<AUX, STATE>(dbg, grid, s, bin_start, bin_end, payload, a4, width, height, tile_row_begin,        \
-                               tile_row_step, bin_shift, filter, image, depth, acc_alpha, last_effective,           \
-                               valid_count, debug_pixel_hits)
-    if (aux && state) GS_FWD(true, true);
-    else if (aux) GS_FWD(true, false);
-    else if (state) GS_FWD(false, true);
-    else GS_FWD(false, false);
+#define GS_FWD(STAGED, AUX, STATE)                                                                                  \
+    launch_forward<STAGED, AUX, STATE>(dbg, grid, s, bin_start, bin_end, payload, a4, width, height, tile_row_begin, \
+                                       tile_row_step, bin_shift, filter, image, depth, acc_alpha, last_effective,   \
+                                       valid_count, debug_pixel_hits)
+#define GS_FWD2(STAGED)                                                                                             \
+    do {                                                                                                            \
+        if (aux && state) GS_FWD(STAGED, true, true);                                                               \
+        else if (aux) GS_FWD(STAGED, true, false);                                                                  \
+        else if (state) GS_FWD(STAGED, false, true);                                                                \
+        else GS_FWD(STAGED, false, false);                                                                          \
+    } while (0)
+    if (staged) GS_FWD2(true); else GS_FWD2(false);
+#undef GS_FWD2
 #undef GS_FWD
     GS_CHECK_LAUNCH();
     return 0;
@@ -553,17 +600,18 @@ int gs_blend_backward(const int32_t *bin_start, const int32_t *payload, const fl
     const int tw = width / GS_TILE_WIDTH;
     const int rows = owned_row_count(height / GS_TILE_HEIGHT, tile_row_begin, tile_row_step, tile_row_end);
     if (rows == 0 || tw == 0) return 0;
-    const dim3 grid(tw * rows), block(BLEND_THREADS);
+    const dim3 grid(tw * rows);
     const float4 *a4 = reinterpret_cast<const float4 *>(attrs);
     float4 *p4 = reinterpret_cast<float4 *>(partials);
-    if (debug_pixel_hits != nullptr)
-        hipLaunchKernelGGL(blend_backward_kernel<true>, grid, block, 0, s, bin_start, payload, a4, grad_image,
-                           acc_alpha, last_effective, width, height, tile_row_begin, tile_row_step, bin_shift, filter,
-                           slot_offsets, p4, slot_flags, magnitude_image, debug_pixel_hits);
+    const bool staged = bin_shift > 0 || filter != 0;
+    if (staged)
+        launch_backward<true>(debug_pixel_hits != nullptr, grid, s, bin_start, payload, a4, grad_image, acc_alpha,
+                              last_effective, width, height, tile_row_begin, tile_row_step, bin_shift, filter,
+                              slot_offsets, p4, slot_flags, magnitude_image, debug_pixel_hits);
     else
-        hipLaunchKernelGGL(blend_backward_kernel<false>, grid, block, 0, s, bin_start, payload, a4, grad_image,
-                           acc_alpha, last_effective, width, height, tile_row_begin, tile_row_step, bin_shift, filter,
-                           slot_offsets, p4, slot_flags, magnitude_image, debug_pixel_hits);
+        launch_backward<false>(debug_pixel_hits != nullptr, grid, s, bin_start, payload, a4, grad_image, acc_alpha,
+                               last_effective, width, height, tile_row_begin, tile_row_step, bin_shift, filter,
+                               slot_offsets, p4, slot_flags, magnitude_image, debug_pixel_hits);
     GS_CHECK_LAUNCH();
     return 0;
 }

@@ -36,24 +36,25 @@ _NO_ROW_LIMIT = 1 << 30
 class ListLayout:
     """How the sorted lists of one frame are organised (the same object goes to preprocess, make_keys, tile_ranges and
     both blend passes -- they must agree):
-      bin_shift   : sort keys are emitted per bin of (1 << bin_shift)^2 tiles; 2 = 64 x 64 pixels (default), 0 = per
-                    tile as in the reference (RAS:131-172)
+      bin_shift   : sort keys are emitted per bin of (1 << bin_shift)^2 tiles.  0 (default) = one key per tile as in
+                    the reference (RAS:131-172): the blend kernels stage their tile's list as it is.  > 0 (2 = 64 x 64
+                    pixels): 3-16x fewer keys to generate and sort; the blend kernels then walk their bin's list and
+                    keep, in order, the entries of their own tile (box + exact contribution test) -- pays when a
+                    Gaussian covers many tiles (the reference's stress test: 5760 tiles per Gaussian), costs 10-25 %
+                    on scenes of small Gaussians where the sort is a small part of the frame
       exact_cull  : drop (bin | tile, Gaussian) pairs that cannot reach alpha >= 1/255 (output-identical)
-      row_begin / row_step / row_end : the tile rows {row_begin + k*row_step} < row_end this GPU renders
-      prefiltered : the lists hold exactly the entries of each tile already (bin_shift 0 only; e.g. the oracle's lists
-                    fed to a blend kernel in a test): no staging filter at all."""
-    bin_shift: int = 2
+      row_begin / row_step / row_end : the tile rows {row_begin + k*row_step} < row_end this GPU renders."""
+    bin_shift: int = 0
     exact_cull: bool = True
     row_begin: int = 0
     row_step: int = 1
     row_end: int = _NO_ROW_LIMIT
-    prefiltered: bool = False
 
     @property
     def filter(self) -> int:
-        if self.prefiltered:
-            if self.bin_shift != 0:
-                raise ValueError("prefiltered lists are per-tile lists (bin_shift 0)")
+        """Staging filter of the blend kernels: none for per-tile lists (the key generator emitted exactly the tile's
+        entries), tile box (+ exact contribution test) for bin lists."""
+        if self.bin_shift == 0:
             return 0
         return FILTER_BOX | (FILTER_CULL if self.exact_cull else 0)
 
@@ -69,7 +70,7 @@ class ListLayout:
         return range(self.row_begin, min(height // TILE_HEIGHT, self.row_end), self.row_step)
 
 
-PER_TILE_LISTS = ListLayout(bin_shift=0, exact_cull=False, prefiltered=True)   # the reference's lists, taken as given
+PER_TILE_LISTS = ListLayout(bin_shift=0, exact_cull=False)   # the reference's lists
 
 
 def _require_device(t: torch.Tensor, name: str) -> None:

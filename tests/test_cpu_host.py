@@ -142,12 +142,11 @@ def test_synthetic_scene_is_deterministic_and_matches_survey_sizes():
 def test_list_layout_object():
     from taichi_3d_gaussian_splatting_amd.hip_ops import FILTER_BOX, FILTER_CULL, PER_TILE_LISTS, ListLayout
     d = ListLayout()
-    assert (d.bin_shift, d.exact_cull, d.filter, d.sharded) == (2, True, FILTER_BOX | FILTER_CULL, False)
-    assert d.num_bins(1920, 1072) == 30 * 17 and ListLayout(bin_shift=0).num_bins(1920, 1072) == 120 * 67
-    assert ListLayout(exact_cull=False).filter == FILTER_BOX
-    assert PER_TILE_LISTS.filter == 0 and PER_TILE_LISTS.bin_shift == 0
-    with pytest.raises(ValueError):
-        ListLayout(bin_shift=2, prefiltered=True).filter
+    assert (d.bin_shift, d.exact_cull, d.filter, d.sharded) == (0, True, 0, False)   # per-tile lists, staged as they are
+    b = ListLayout(bin_shift=2)
+    assert b.filter == FILTER_BOX | FILTER_CULL and ListLayout(bin_shift=2, exact_cull=False).filter == FILTER_BOX
+    assert b.num_bins(1920, 1072) == 30 * 17 and d.num_bins(1920, 1072) == 120 * 67
+    assert PER_TILE_LISTS.filter == 0 and PER_TILE_LISTS.bin_shift == 0 and not PER_TILE_LISTS.exact_cull
     band = ListLayout(row_begin=8, row_end=20)
     assert band.sharded and list(band.owned_rows(1072)) == list(range(8, 20))
     assert list(ListLayout(row_begin=1, row_step=3).owned_rows(160)) == [1, 4, 7]

@@ -98,12 +98,12 @@ def test_preprocess(ops, scene, ofwd):
     sums = np.add.reduceat(ntiles.cpu().numpy(), np.arange(0, len(ofwd["ids"]), 256))
     assert np.array_equal(block_sums.cpu().numpy(), sums)
     assert np.array_equal(block_sums_full.cpu().numpy(), sums)
-    # production layout: keys per 64 x 64-pixel bin, exact cull on: the box count (hook output) is unchanged, the key
+    # bin layout (heavy scenes): keys per 64 x 64-pixel bin, exact cull on: the box count (hook output) is unchanged, the key
     # count is the number of bins of the box (at most), the cull bound is stored
     feat2 = dev(s.point_cloud_features).clone()
     attrs2, ntiles2, nkeys2, bs2, bsf2 = ops.preprocess(
         dev(s.point_cloud), feat2, dev(s.point_object_id), dev(s.camera_intrinsics), dev(ofwd["q_cp"]),
-        dev(ofwd["t_cp"]), dev(ofwd["ids"]), s.width, s.height, ops.ListLayout())
+        dev(ofwd["t_cp"]), dev(ofwd["ids"]), s.width, s.height, ops.ListLayout(bin_shift=2))
     assert torch.equal(ntiles2, ntiles) and torch.equal(bsf2, block_sums_full)
     assert (nkeys2 <= ntiles2).all() and int(nkeys2.sum()) < int(ntiles2.sum())
     a2 = attrs2.cpu().numpy()
@@ -212,16 +212,16 @@ def _pipeline(ops, s, ofwd, layout, g=None):
 
 
 def test_list_layouts_are_output_identical(ops, scene, ofwd, obwd):
-    """The reference sorts one key per (tile, Gaussian) of the tile box (RAS:131-172).  The production layout sorts one
-    key per (64 x 64-pixel bin, Gaussian), drops pairs that cannot reach alpha >= 1/255, and lets every tile recover its
-    own list from its bin's list.  Every combination blends the SAME Gaussians into every pixel in the same order:
+    """The reference sorts one key per (tile, Gaussian) of the tile box (RAS:131-172).  The default layout drops the
+    pairs that cannot reach alpha >= 1/255; the bin layouts sort one key per (32 | 64 | 128-pixel bin, Gaussian) and let
+    every tile recover its own list from its bin's list.  Every combination blends the SAME Gaussians into every pixel in the same order:
     image, depth, accumulated alpha, counts and the per-pixel {count, hash} of blended Gaussians are bit-identical,
     and so are the backward sums."""
     s = scene
     g = dev(obwd[0])
     layouts = {"tile": ops.ListLayout(bin_shift=0, exact_cull=False), "tile+cull": ops.ListLayout(bin_shift=0),
-               "bin": ops.ListLayout(bin_shift=2, exact_cull=False), "bin+cull": ops.ListLayout(),
-               "bin8+cull": ops.ListLayout(bin_shift=3)}
+               "bin": ops.ListLayout(bin_shift=2, exact_cull=False), "bin+cull": ops.ListLayout(bin_shift=2),
+               "bin8+cull": ops.ListLayout(bin_shift=3), "bin2+cull": ops.ListLayout(bin_shift=1)}
     outs = {name: _pipeline(ops, s, ofwd, lay, g) for name, lay in layouts.items()}
     ref = outs["tile"]
     assert np.array_equal(ref["keys"], ofwd["keys"]) and np.array_equal(ref["payload"], ofwd["payload"])
@@ -524,14 +524,14 @@ def test_operator_is_as_close_to_the_f64_spec_as_the_fp32_oracle(scene, ofwd):
         assert e_hip <= 3.0 * e_o32 + 1e-6
 
 
-def _stages_to_ranges(ops, s):
+def _stages_to_ranges(ops, s, layout=None):
     """HIP front end on a device scene -> everything the two blend kernels need."""
     q_cp, t_cp = ops.pose_inverse(s.q_pointcloud_camera, s.t_pointcloud_camera)
     mask, ids, counters = ops.filter_compact(s.point_cloud, s.point_invalid_mask, s.point_object_id,
                                              s.camera_intrinsics, q_cp, t_cp, s.near_plane, s.far_plane, s.width,
                                              s.height)
     feat = s.point_cloud_features.clone()
-    layout = ops.ListLayout()
+    layout = layout or ops.ListLayout()
     attrs, ntiles, nowned, bsums, bsums_full = ops.preprocess(
         s.point_cloud, feat, s.point_object_id, s.camera_intrinsics, q_cp, t_cp, ids, s.width, s.height, layout,
         depth_to_sort_key_scale=s.depth_to_sort_key_scale, counters=counters)
@@ -547,14 +547,15 @@ def _stages_to_ranges(ops, s):
                 n_slots=n_slots, k=k, layout=layout)
 
 
-@pytest.mark.parametrize("workload", ["cfg2_100k_800", "headline_1m_1080p", "cfg3_400k_1080p"])
-def test_forward_and_backward_blend_the_same_pairs(ops, workload):
+@pytest.mark.parametrize("workload,bin_shift", [("cfg2_100k_800", 0), ("headline_1m_1080p", 0), ("headline_1m_1080p", 2),
+                                                ("cfg3_400k_1080p", 0)])
+def test_forward_and_backward_blend_the_same_pairs(ops, workload, bin_shift):
     """a (pixel, Gaussian) pair must be treated as blended by the backward pass iff the forward
     pass blended it.  Both kernels evaluate alpha through the same device function; here every pixel's blended set is
     compared through {count, hash of the blended Gaussians' list offsets}: identical on EVERY pixel, at full size."""
     from taichi_3d_gaussian_splatting_amd.synthetic import make_config_scene, make_grad_image
     s = make_config_scene(workload).to("cuda")
-    st = _stages_to_ranges(ops, s)
+    st = _stages_to_ranges(ops, s, ops.ListLayout(bin_shift=bin_shift))
     image, depth, acc_alpha, last_eff, count, dbg_f = ops.blend_forward(
         st["start"], st["end"], st["payload"], st["attrs"], s.width, s.height, st["layout"], debug_hits=True)
     assert torch.equal(dbg_f[:, :, 0], count)
@@ -563,7 +564,7 @@ def test_forward_and_backward_blend_the_same_pairs(ops, workload):
         st["start"], st["payload"], st["attrs"], g, acc_alpha, last_eff, st["slot_offsets"], st["n_slots"],
         s.width, s.height, st["layout"], debug_hits=True)
     differing = int((dbg_f != dbg_b).any(dim=2).sum())
-    report(f"hit_sets.{workload}", pixels=s.height * s.width, blended_pairs=int(count.sum()),
+    report(f"hit_sets.{workload}.bin_shift{bin_shift}", pixels=s.height * s.width, keys=st["k"], blended_pairs=int(count.sum()),
            pixels_with_different_sets=differing)
     assert differing == 0
     # and the debug build changes nothing: same partial sums as the production kernel, bit for bit
@@ -713,8 +714,8 @@ def test_headline_size_properties(ops):
     k, n_slots, _, m_dev = ops.scan_block_sums(block_sums, counters, block_sums_full)
     assert m_dev == ids.shape[0]
     assert k == total and n_slots == int(ntiles.sum().item())
-    num_tiles = layout.num_bins(s.width, s.height)   # lists are per 64 x 64-pixel bin
-    assert num_tiles == 30 * 17
+    num_tiles = layout.num_bins(s.width, s.height)   # per-tile lists (default layout)
+    assert num_tiles == 120 * 67
     kdb, db, tb = ops.key_layout(s.near_plane, s.far_plane, s.depth_to_sort_key_scale, num_tiles, max_dq)
     assert 0 < kdb < 17  # production layout at this size: compressed keys, depth field sized to the bits in use
     keys, payload, slot_offsets = ops.make_keys(attrs, nowned, block_sums, k, s.width, s.height,
@@ -734,12 +735,12 @@ def test_headline_size_properties(ops):
     image, depth, acc_alpha, last_eff, count = ops.blend_forward(start, end, payload, attrs, s.width, s.height, layout)
     assert torch.isfinite(image).all() and image.min() >= 0 and image.max() <= 1.0 + 1e-5
     assert acc_alpha.min() >= 0 and acc_alpha.max() <= 1.0 - 1e-4 + 1e-6  # T never drops below 1e-4
-    bins_v = torch.arange(s.height, device="cuda") // 64
-    bins_u = torch.arange(s.width, device="cuda") // 64
-    tid = bins_v[:, None] * 30 + bins_u[None, :]
+    bins_v = torch.arange(s.height, device="cuda") // 16
+    bins_u = torch.arange(s.width, device="cuda") // 16
+    tid = bins_v[:, None] * 120 + bins_u[None, :]
     assert (last_eff >= start[tid]).all() and (last_eff <= end[tid]).all()
     assert (count <= last_eff - start[tid]).all()
-    report("headline.sizes", M=ids.shape[0], K_reference=int(ntiles.sum().item()), K_bin_keys=k)
+    report("headline.sizes", M=ids.shape[0], K_reference=int(ntiles.sum().item()), K_after_cull=k)
 
 
 def test_rccl_collectives_on_device_world1():
@@ -809,34 +810,36 @@ def test_operator_full_size_forward_backward(workload, tag):
 def test_reference_stress_distribution_runs():
     """The reference's own stress test (T_RAS:111-150): 1e5 rows of U[0,1) data, only the first 8000 valid,
     1920x1088, f = 500, camera 0.5 behind the cloud -> every Gaussian covers every tile (4.6e7 (tile, Gaussian)
-    pairs in the reference's binning).  The reference only checks that it runs; we also check finiteness, the
-    exact-cull invariance and run-to-run reproducibility of the gradients."""
+    pairs in the reference's binning).  The reference only checks that it runs; we also check finiteness, that the
+    exact cull and the bin layout (the one the operator switches to on such scenes) leave the image bit-identical, and
+    run-to-run reproducibility of the gradients."""
     from taichi_3d_gaussian_splatting_amd import CameraInfo, GaussianPointCloudRasterisation as Op
-    g = torch.Generator().manual_seed(0)
-    n = 100_000
-    xyz0 = torch.rand(n, 3, generator=g).cuda()
-    feat0 = torch.rand(n, 56, generator=g).cuda()
-    invalid = torch.zeros(n, dtype=torch.int8, device="cuda"); invalid[8000:] = 1
-    obj = torch.zeros(n, dtype=torch.int32, device="cuda")
-    cam = CameraInfo(torch.tensor([[500., 0, 960], [0, 500., 540], [0, 0, 1]], device="cuda"), 1088, 1920, 0)
-    q = torch.tensor([[0., 0., 0., 1.]], device="cuda"); t = torch.tensor([[0., 0., -0.5]], device="cuda")
+    from taichi_3d_gaussian_splatting_amd.synthetic import make_config_scene
+    s = make_config_scene("stress_t_ras").to("cuda")
+    cam = CameraInfo(s.camera_intrinsics, s.height, s.width, 0)
     outs = []
-    for cull in (True, False, True):
-        xyz = xyz0.clone().requires_grad_(True); feat = feat0.clone().requires_grad_(True)
-        op = Op(Op.GaussianPointCloudRasterisationConfig())
-        op.exact_tile_cull = cull
+    for cull, bin_shift in ((True, 0), (False, 0), (True, 0), (True, 2), (True, None), (True, None)):
+        xyz = s.point_cloud.clone().requires_grad_(True); feat = s.point_cloud_features.clone().requires_grad_(True)
+        if bin_shift is not None or len(outs) == 4:
+            op = Op(Op.GaussianPointCloudRasterisationConfig())   # the two `None` runs share one operator
+        op.exact_tile_cull, op.bin_shift = cull, bin_shift
         image, depth, count = op(Op.GaussianPointCloudRasterisationInput(
-            point_cloud=xyz, point_cloud_features=feat, point_object_id=obj, point_invalid_mask=invalid,
-            camera_info=cam, q_pointcloud_camera=q, t_pointcloud_camera=t))
+            point_cloud=xyz, point_cloud_features=feat, point_object_id=s.point_object_id,
+            point_invalid_mask=s.point_invalid_mask, camera_info=cam, q_pointcloud_camera=s.q_pointcloud_camera,
+            t_pointcloud_camera=s.t_pointcloud_camera))
         image.sum().backward()  # as T_RAS:149-150
-        outs.append((image.detach(), count, feat.grad.clone(), xyz.grad.clone()))
-    img, cnt, gf, gx = outs[0]
+        outs.append((image.detach(), count, feat.grad.clone(), xyz.grad.clone(), op._auto_bin_shift))
+    img, cnt, gf, gx, _ = outs[0]
     assert torch.isfinite(img).all() and torch.isfinite(gf).all() and torch.isfinite(gx).all()
     assert img.max() > 0.1 and cnt.max() > 0
     assert not gf[8000:].any() and not gx[8000:].any()          # invalid rows get no gradient
     assert torch.equal(img, outs[1][0]) and torch.equal(cnt, outs[1][1])   # exact cull: bit-identical image
     assert rel_l2(gf.cpu().numpy(), outs[1][2].cpu().numpy()) < 1e-5
     assert torch.equal(gf, outs[2][2]) and torch.equal(gx, outs[2][3])     # reproducible gradients
+    for k in (3, 4, 5):   # bin layout (forced, then chosen by the operator after its first frame): same bits
+        assert torch.equal(img, outs[k][0]) and torch.equal(cnt, outs[k][1])
+        assert torch.equal(gf, outs[k][2]) and torch.equal(gx, outs[k][3])
+    assert outs[4][4] == 2 and outs[5][4] == 2   # after one frame of this scene the operator picks 64-pixel bins
     report("stress.sizes", max_count=int(cnt.max()), mean_count=float(cnt.float().mean()))
 
 

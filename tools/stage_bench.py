@@ -18,7 +18,7 @@ g = make_grad_image(s.height, s.width).to("cuda")
 times = {}
 CULL = os.environ.get('GS_CULL', '1') == '1'
 AB = os.environ.get('GS_AB', '0') == '1'
-LAYOUT = hip_ops.ListLayout(bin_shift=int(os.environ.get('GS_BIN_SHIFT', '2')), exact_cull=CULL)
+LAYOUT = hip_ops.ListLayout(bin_shift=int(os.environ.get('GS_BIN_SHIFT', '0')), exact_cull=CULL)
 
 
 def timed(name, fn):
