@@ -132,9 +132,14 @@ int gs_scan_block_sums2(int32_t *block_sums, int32_t *block_sums_full, int n_blo
  * the values passed to gs_preprocess.
  * Optionally (slot_offsets may be NULL: inference) writes slot_offsets int32[M] = exclusive scan of num_overlap_tiles (block_offsets_full = scanned
  * block_sums_full): slot_offsets[i] + (t1v-t0v)*(tile_u-t0u) + (tile_v-t0v) is the reference's key index
- * of the (Gaussian i, tile) pair (RAS:163-166) and addresses its partial-gradient slot in the backward. */
+ * of the (Gaussian i, tile) pair (RAS:163-166) and addresses its partial-gradient slot in the backward.
+ * Sizes that are still on their way to the host: with counters != NULL (the array of gs_filter_compact /
+ * gs_scan_block_sums2, same stream) n_visible is only the CAPACITY of the per-point arrays and the kernel takes the
+ * count from counters[GS_COUNTER_NUM_VISIBLE]; at most n_keys_capacity keys are written (the host compares
+ * counters[GS_COUNTER_NUM_KEYS] with it once the read-back has arrived and redoes the frame if it did not fit). */
 int gs_make_keys(const float *attrs, const int32_t *num_keys, const int32_t *block_offsets,
-                 int n_visible, int width, int height, int tile_row_begin, int tile_row_step,
+                 int n_visible, const int32_t *counters, int64_t n_keys_capacity, int width,
+                 int height, int tile_row_begin, int tile_row_step,
                  int tile_row_end, int bin_shift, int exact_tile_cull, int key_depth_bits,
                  float depth_scale, void *keys,
                  int32_t *payload, const int32_t *num_overlap_tiles,
@@ -146,16 +151,23 @@ int gs_make_keys(const float *attrs, const int32_t *num_keys, const int32_t *blo
  * whole key as a signed int64.  32-bit layout: bits [0, key_depth_bits+tile_bits).
  * keys_alt/payload_alt are ping-pong buffers of the same size.  Returns 0 when the sorted pairs are in
  * keys/payload, or -- only if allow_result_in_alt != 0 -- 1 when they are in keys_alt/payload_alt (odd
- * number of passes; saves the copy back).  Negative on error. */
+ * number of passes; saves the copy back).  Negative on error.
+ * n_keys_device (may be NULL): device address of the actual number of pairs (e.g. counters + GS_COUNTER_NUM_KEYS);
+ * n_keys is then the capacity that sizes grids and workspace, and min(*n_keys_device, n_keys) pairs are sorted. */
 size_t gs_sort_workspace_bytes(int64_t n_keys);
 int gs_sort_pairs(void *keys, int32_t *payload, void *keys_alt, int32_t *payload_alt,
-                  int64_t n_keys, int key_depth_bits, int depth_bits, int tile_bits,
-                  int allow_result_in_alt, void *workspace, void *stream);
+                  int64_t n_keys, const int32_t *n_keys_device, int key_depth_bits, int depth_bits,
+                  int tile_bits, int allow_result_in_alt, void *workspace, void *stream);
 
 /* Per-bin [start,end) ranges (n_tiles = number of bins; per tile with bin_shift = 0).  Replaces
  * find_tile_start_and_end (RAS:175-193) including the zero-initialisation of RAS:954-957. */
-int gs_tile_ranges(const void *keys_sorted, int64_t n_keys, int key_depth_bits,
-                   int32_t *tile_start, int32_t *tile_end, int n_tiles, void *stream);
+int gs_tile_ranges(const void *keys_sorted, int64_t n_keys, const int32_t *n_keys_device,
+                   int key_depth_bits, int32_t *tile_start, int32_t *tile_end, int n_tiles,
+                   void *stream);
+
+/* Enqueues a copy of the device counters into PINNED host memory (no synchronisation): the host keeps launching
+ * and waits for its own event when it needs the sizes. */
+int gs_read_counters_async(const int32_t *counters, int32_t *host_counters_pinned, int n, void *stream);
 
 /* Front-to-back alpha blending.  Replaces gaussian_point_rasterisation (RAS:318-485).
  * bin_start/bin_end: the ranges of gs_tile_ranges; bin_shift/filter: see "Lists" above.

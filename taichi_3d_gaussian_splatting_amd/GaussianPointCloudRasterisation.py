@@ -157,6 +157,11 @@ class GaussianPointCloudRasterisation(torch.nn.Module):
         # when Gaussians cover many tiles), None = chosen per frame from the previous frame's tiles-per-Gaussian ratio
         self.bin_shift: Optional[int] = None
         self._auto_bin_shift = 0
+        # launch the list stages from device-side counts with the previous frame's capacities instead of waiting for
+        # this frame's sizes (see _forward); False = wait for the sizes first (two dependent halves, as round 1)
+        self.speculative_sizes = True
+        self._size_guess, self._size_guess_key, self._readbacks = None, None, {}
+        self.speculation_stats = {"frames": 0, "redone": 0}
         outer = self
 
         class _module_function(torch.autograd.Function):
@@ -205,37 +210,69 @@ class GaussianPointCloudRasterisation(torch.nn.Module):
                 attrs, num_overlap_tiles, num_owned_tiles, block_sums, block_sums_full = hip_ops.preprocess(
                     xyz, pointcloud_features, obj, intrinsics, q_cp, t_cp, ids, width, height, layout,
                     cfg.depth_to_sort_key_scale, counters, n_visible_on_device=True)
-                # RAS:913-922  scans; ONE host read-back for M, K, the slot count and the depth range
-                # (the reference syncs twice: RAS:870 and RAS:916)
-                n_keys, n_slots, max_depth_key, m = hip_ops.scan_block_sums(block_sums, counters, block_sums_full)
+                # RAS:913-922  scans.  The reference blocks twice on sizes (RAS:870,916); here the one read-back of
+                # M, K, the slot count and the depth range travels to pinned memory while the host keeps launching:
+                # key generation, sort, ranges and the blend run SPECULATIVELY from the device-side counts with the
+                # capacities learnt from the previous frame, and are redone with exact sizes in the rare frame that
+                # does not fit (first frame, jump in the number of keys or in the depth range).
+                hip_ops.scan_block_sums_async(block_sums, counters, block_sums_full)
+                readback = outer._counter_readback(xyz.device)
+                readback.start(counters)
+                num_bins = layout.num_bins(width, height)
+                rgb_only = bool(cfg.rgb_only)
+
+                def lists_and_blend(attrs_, nkeys_, bsums_, bsums_full_, ntiles_, n_keys_, max_depth_key_, counters_):
+                    # RAS:927-945 keys (one per (bin, Gaussian)), RAS:947-950 stable sort, RAS:952-964 list ranges,
+                    # RAS:967-997 blend.  rgb_only (RAS:464-469,478-484): depth and count are not computed -- the
+                    # reference returns uninitialised memory for them, this operator zeros.  The state the backward
+                    # pass reads (acc_alpha, last_effective) is produced whenever a gradient can be asked for -- also
+                    # with rgb_only, where the reference's backward would read garbage -- and skipped otherwise.
+                    kdb, depth_bits, tile_bits = hip_ops.key_layout(
+                        cfg.near_plane, cfg.far_plane, cfg.depth_to_sort_key_scale, num_bins, max_depth_key_)
+                    n_dev = None if counters_ is None else counters_[hip_ops.COUNTER_NUM_KEYS:hip_ops.COUNTER_NUM_KEYS + 1]
+                    keys, payload_, slot_offsets_ = hip_ops.make_keys(
+                        attrs_, nkeys_, bsums_, n_keys_, width, height, cfg.depth_to_sort_key_scale, layout, kdb,
+                        ntiles_ if need_state else None, bsums_full_ if need_state else None, counters=counters_)
+                    keys, payload_ = hip_ops.sort_pairs(keys, payload_, depth_bits, tile_bits, kdb, in_place=False,
+                                                        n_keys_device=n_dev)
+                    start_, end_ = hip_ops.tile_ranges(keys, num_bins, kdb, n_keys_device=n_dev)
+                    del keys
+                    blended = hip_ops.blend_forward(start_, end_, payload_, attrs_, width, height, layout,
+                                                    rgb_only=rgb_only, need_state=need_state)
+                    return payload_, slot_offsets_, start_, blended
+
+                guess_key = (width, height, layout, cfg.near_plane, cfg.far_plane, cfg.depth_to_sort_key_scale)
+                guess = outer._size_guess if outer.speculative_sizes and outer._size_guess_key == guess_key else None
+                result = None
+                if guess is not None:
+                    result = lists_and_blend(attrs, num_owned_tiles, block_sums, block_sums_full, num_overlap_tiles,
+                                             guess[0], guess[1], counters)
+                host = readback.wait()
+                m, n_keys, n_slots = (host[hip_ops.COUNTER_NUM_VISIBLE], host[hip_ops.COUNTER_NUM_KEYS],
+                                      host[hip_ops.COUNTER_NUM_SLOTS])
+                max_depth_key = host[hip_ops.COUNTER_MAX_DEPTH_KEY]
+                if n_keys >= 0x7fffffff or n_slots >= 0x7fffffff:
+                    raise RuntimeError("more than 2^31-1 (tile, Gaussian) pairs: key offsets are int32 as in the reference")
                 nb = (m + 255) // 256
                 # next frame's list layout: bins once a Gaussian covers >= 64 tiles on average (hysteresis: back at < 32)
                 ratio = n_slots / max(m, 1)
                 outer._auto_bin_shift = 2 if ratio >= (32.0 if outer._auto_bin_shift else 64.0) else 0
+                fits = guess is not None and n_keys <= guess[0] and max_depth_key <= guess[1]
+                outer.speculation_stats["frames"] += 1
+                outer.speculation_stats["redone"] += 0 if (fits or guess is None) else 1
+                # capacities for the next frame: 25 % head-room over this frame, decaying slowly from the high-water mark;
+                # the depth range as the largest value with the same number of bits
+                depth_bound = (1 << max(int(max_depth_key), 1).bit_length()) - 1
+                outer._size_guess = (max(int(1.25 * n_keys) + 4096, int(0.95 * guess[0]) if guess else 0), depth_bound)
+                outer._size_guess_key = guess_key
                 ids, attrs, num_overlap_tiles, num_owned_tiles = ids[:m], attrs[:m], num_overlap_tiles[:m], \
                     num_owned_tiles[:m]
-                block_sums, block_sums_full = block_sums[:nb], block_sums_full[:nb]
-                # RAS:927-945  keys: one per (bin, Gaussian)
-                num_bins = layout.num_bins(width, height)
-                key_depth_bits, depth_bits, tile_bits = hip_ops.key_layout(
-                    cfg.near_plane, cfg.far_plane, cfg.depth_to_sort_key_scale, num_bins, max_depth_key)
-                keys, payload, slot_offsets = hip_ops.make_keys(
-                    attrs, num_owned_tiles, block_sums, n_keys, width, height, cfg.depth_to_sort_key_scale,
-                    layout, key_depth_bits, num_overlap_tiles, block_sums_full)
-                # RAS:947-950  sort (stable)
-                keys, payload = hip_ops.sort_pairs(keys, payload, depth_bits, tile_bits, key_depth_bits,
-                                                   in_place=False)
-                # RAS:952-964  list ranges (per bin)
-                tile_start, tile_end = hip_ops.tile_ranges(keys, num_bins, key_depth_bits)
-                del keys
-                # RAS:967-997  blend.  rgb_only (RAS:464-469,478-484): depth and count are not computed -- the reference
-                # returns uninitialised memory for them, this operator zeros.  The state the backward pass reads
-                # (acc_alpha, last_effective) is produced whenever a gradient can be asked for -- also with rgb_only,
-                # where the reference's backward would read garbage -- and skipped otherwise (inference).
-                rgb_only = bool(cfg.rgb_only)
-                image, depth, acc_alpha, last_eff, count = hip_ops.blend_forward(
-                    tile_start, tile_end, payload, attrs, width, height, layout,
-                    rgb_only=rgb_only, need_state=need_state)
+                if not fits:
+                    result = lists_and_blend(attrs, num_owned_tiles, block_sums[:nb], block_sums_full[:nb],
+                                             num_overlap_tiles, n_keys, max_depth_key, None)
+                payload, slot_offsets, tile_start, (image, depth, acc_alpha, last_eff, count) = result
+                if slot_offsets is not None:
+                    slot_offsets = slot_offsets[:m]
                 if rgb_only:
                     depth = torch.zeros((height, width), dtype=torch.float32, device=xyz.device)
                     count = torch.zeros((height, width), dtype=torch.int32, device=xyz.device)
@@ -304,6 +341,12 @@ class GaussianPointCloudRasterisation(torch.nn.Module):
         self.hook_feature_gradients: bool = True
         self.grad_accumulator_reduce: Optional[Callable[[torch.Tensor], None]] = None
         self.image_gather: Optional[Callable[[list], None]] = None
+
+    def _counter_readback(self, device):
+        rb = self._readbacks.get(device)
+        if rb is None:
+            rb = self._readbacks[device] = hip_ops.CounterReadback(device)
+        return rb
 
     def forward(self, input_data: "GaussianPointCloudRasterisation.GaussianPointCloudRasterisationInput"):
         camera_info = input_data.camera_info

@@ -16,7 +16,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgsplat_hip.so")
-ABI_VERSION = 17
+ABI_VERSION = 18
 
 _c = ctypes
 _P = _c.c_void_p
@@ -35,10 +35,11 @@ _SIGNATURES = {
     "gs_preprocess": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _P, _P, _P, _P, _P, _P, _P]),
     "gs_scan_block_sums": (_I, [_P, _I, _P, _I, _P]),
     "gs_scan_block_sums2": (_I, [_P, _P, _I, _P, _P]),
-    "gs_make_keys": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _P, _P, _P, _P, _P, _P]),
+    "gs_make_keys": (_I, [_P, _P, _P, _I, _P, _I64, _I, _I, _I, _I, _I, _I, _I, _I, _F, _P, _P, _P, _P, _P, _P]),
     "gs_sort_workspace_bytes": (_c.c_size_t, [_I64]),
-    "gs_sort_pairs": (_I, [_P, _P, _P, _P, _I64, _I, _I, _I, _I, _P, _P]),
-    "gs_tile_ranges": (_I, [_P, _I64, _I, _P, _P, _I, _P]),
+    "gs_sort_pairs": (_I, [_P, _P, _P, _P, _I64, _P, _I, _I, _I, _I, _P, _P]),
+    "gs_tile_ranges": (_I, [_P, _I64, _P, _I, _P, _P, _I, _P]),
+    "gs_read_counters_async": (_I, [_P, _P, _I, _P]),
     "gs_blend_forward": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _I, _P, _P]),
     "gs_blend_backward": (_I, [_P, _P, _P, _P, _P, _P, _P, _I64, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P]),
     "gs_reduce_partials": (_I, [_P, _P, _P, _P, _I, _P, _P]),

@@ -70,9 +70,10 @@ __device__ __forceinline__ void gs_tile_box(float u, float v, float r, int tw, i
 // nothing.
 __device__ __forceinline__ float gs_cull_qmax(float amp) { return 2.0f * logf(255.0f * amp) + 1e-2f; }
 
-// [x0, x1] x [y0, y1]: pixel-CENTRE coordinates of the rectangle's corner pixels.
-__device__ __forceinline__ bool gs_rect_may_contribute(float ux, float uy, float A, float B, float C, float qmax,
-                                                       float x0, float x1, float y0, float y1) {
+// [x0, x1] x [y0, y1]: pixel-CENTRE coordinates of the rectangle's corner pixels.  sx = -B/A, sy = -B/C: the slopes
+// of the conic's conjugate diameters (per-Gaussian constants; an approximate reciprocal is enough, see above).
+__device__ __forceinline__ bool gs_rect_may_contribute(float ux, float uy, float A, float B, float C, float sx,
+                                                       float sy, float qmax, float x0, float x1, float y0, float y1) {
 #pragma clang fp contract(off)
     const float dxc = fminf(fmaxf(ux, x0), x1) - ux;  // x offset of the closest point, 0 if inside the span
     const float dyc = fminf(fmaxf(uy, y0), y1) - uy;
@@ -80,11 +81,11 @@ __device__ __forceinline__ bool gs_rect_may_contribute(float ux, float uy, float
     if (dxc != 0.f || dyc != 0.f) {
         qmin = 3.0e38f;
         if (dxc != 0.f) {  // edge x = const facing the centre: minimise over dy along the edge (slope -B/C)
-            const float dy = fminf(fmaxf((-B * __builtin_amdgcn_rcpf(C)) * dxc, y0 - uy), y1 - uy);
+            const float dy = fminf(fmaxf(sy * dxc, y0 - uy), y1 - uy);
             qmin = A * dxc * dxc + 2.f * B * dxc * dy + C * dy * dy;
         }
         if (dyc != 0.f) {
-            const float dx = fminf(fmaxf((-B * __builtin_amdgcn_rcpf(A)) * dyc, x0 - ux), x1 - ux);
+            const float dx = fminf(fmaxf(sx * dyc, x0 - ux), x1 - ux);
             qmin = fminf(qmin, A * dx * dx + 2.f * B * dx * dyc + C * dyc * dyc);
         }
     }
@@ -105,8 +106,9 @@ __device__ __forceinline__ bool gs_entry_in_tile(const float4 r0, const float4 r
     }
     if (filter & GS_FILTER_CULL) {
         const float x0 = (float)(tile_u * GS_TILE_WIDTH) + 0.5f, y0 = (float)(tile_v * GS_TILE_HEIGHT) + 0.5f;
-        keep = keep && gs_rect_may_contribute(r0.x, r0.y, r1.x, r1.y, r1.z, r0.w, x0, x0 + (float)(GS_TILE_WIDTH - 1),
-                                              y0, y0 + (float)(GS_TILE_HEIGHT - 1));
+        keep = keep && gs_rect_may_contribute(r0.x, r0.y, r1.x, r1.y, r1.z, -r1.y * __builtin_amdgcn_rcpf(r1.x),
+                                              -r1.y * __builtin_amdgcn_rcpf(r1.z), r0.w, x0,
+                                              x0 + (float)(GS_TILE_WIDTH - 1), y0, y0 + (float)(GS_TILE_HEIGHT - 1));
     }
     return keep;
 }

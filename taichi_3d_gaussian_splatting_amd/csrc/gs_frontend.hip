@@ -60,34 +60,43 @@ struct RowOwner { int begin, step, end; };
 // number of owned tile rows in [lo, hi)
 __device__ __forceinline__ int owned_rows(int lo, int hi, RowOwner ow) {
     hi = min(hi, ow.end);
+    if (ow.step == 1) return max(hi - max(lo, ow.begin), 0);   // contiguous band (and the single-GPU case): no division
     int f = ow.begin;
     if (lo > ow.begin) f = ow.begin + ((lo - ow.begin + ow.step - 1) / ow.step) * ow.step;
     return f < hi ? (hi - 1 - f) / ow.step + 1 : 0;
 }
 
-// Sort keys are emitted per BIN = (1 << bin_shift)^2 tiles (default 4 x 4 tiles = 64 x 64 pixels), not per tile: the
-// blend kernels walk their bin's depth-sorted list and stage the entries that belong to their own tile (box test + exact
-// contribution test, gs_entry_in_tile).  The per-tile sequence is unchanged -- the bin list filtered by tile membership
-// is the tile's list in the same (depth, index) order -- but 3-16x fewer keys are generated, sorted and ranged.
-// A Gaussian emits a key for bin (bu, bv) iff the bin holds a tile of its box (RAS:81-103) in a tile row this GPU owns
-// and (with the exact cull) the Gaussian can reach alpha >= 1/255 somewhere on those tiles.
-struct BinBox { int b0u, b1u, b0v, b1v; };
-__device__ __forceinline__ BinBox bin_box(int t0u, int t1u, int t0v, int t1v, int bin_shift) {
-    BinBox b;
-    b.b0u = t0u >> bin_shift; b.b1u = t1u > t0u ? ((t1u - 1) >> bin_shift) + 1 : b.b0u;
-    b.b0v = t0v >> bin_shift; b.b1v = t1v > t0v ? ((t1v - 1) >> bin_shift) + 1 : b.b0v;
-    return b;
-}
-__device__ __forceinline__ bool bin_emits(int bu, int bv, int t0u, int t1u, int t0v, int t1v, int bin_shift,
-                                          RowOwner ow, int cull, float ux, float uy, float A, float B, float C,
-                                          float qmax) {
-    const int u_lo = max(t0u, bu << bin_shift), u_hi = min(t1u, (bu + 1) << bin_shift);   // tiles of the box in this bin
-    const int v_lo = max(t0v, bv << bin_shift), v_hi = min(t1v, (bv + 1) << bin_shift);
-    if (owned_rows(v_lo, v_hi, ow) == 0) return false;
-    if (!cull) return true;
-    return gs_rect_may_contribute(ux, uy, A, B, C, qmax, (float)(u_lo * GS_TILE_WIDTH) + 0.5f,
-                                  (float)(u_hi * GS_TILE_WIDTH) - 0.5f, (float)(v_lo * GS_TILE_HEIGHT) + 0.5f,
-                                  (float)(v_hi * GS_TILE_HEIGHT) - 0.5f);
+// Sort keys are emitted per BIN = (1 << bin_shift)^2 tiles; bin_shift 0 (default) = per tile as the reference
+// (RAS:131-172).  With bin_shift > 0 the blend kernels walk their bin's depth-sorted list and stage the entries that
+// belong to their own tile (box test + exact contribution test, gs_entry_in_tile): the per-tile sequence is unchanged --
+// the bin list filtered by tile membership is the tile's list in the same (depth, index) order -- but 3-16x fewer keys
+// are generated, sorted and ranged.  A Gaussian emits a key for bin (bu, bv) iff the bin holds a tile of its box
+// (RAS:81-103) in a tile row this GPU owns and (with the exact cull) the Gaussian can reach alpha >= 1/255 somewhere
+// on those tiles.  for_each_emitting_bin visits exactly those bins; gs_preprocess counts them, gs_make_keys writes them:
+// the same function on the same stored values, so count and keys agree.
+template <typename Emit>
+__device__ __forceinline__ void for_each_emitting_bin(int t0u, int t1u, int t0v, int t1v, int bin_shift, RowOwner ow,
+                                                      int cull, float ux, float uy, float A, float B, float C, float qmax,
+                                                      Emit emit) {
+    if (t1u <= t0u || t1v <= t0v) return;
+    const int b0u = t0u >> bin_shift, b1u = ((t1u - 1) >> bin_shift) + 1;
+    const int b0v = t0v >> bin_shift, b1v = ((t1v - 1) >> bin_shift) + 1;
+    // slopes of the conic's conjugate diameters: per-Gaussian constants of the contribution test
+    const float sy = -B * __builtin_amdgcn_rcpf(C), sx = -B * __builtin_amdgcn_rcpf(A);
+    for (int bv = b0v; bv < b1v; ++bv) {
+        const int v_lo = max(t0v, bv << bin_shift), v_hi = min(t1v, (bv + 1) << bin_shift);   // box rows in this bin row
+        if (owned_rows(v_lo, v_hi, ow) == 0) continue;
+        const float y0 = (float)(v_lo * GS_TILE_HEIGHT) + 0.5f, y1 = (float)(v_hi * GS_TILE_HEIGHT) - 0.5f;
+        for (int bu = b0u; bu < b1u; ++bu) {
+            if (cull) {
+                const int u_lo = max(t0u, bu << bin_shift), u_hi = min(t1u, (bu + 1) << bin_shift);
+                if (!gs_rect_may_contribute(ux, uy, A, B, C, sx, sy, qmax, (float)(u_lo * GS_TILE_WIDTH) + 0.5f,
+                                            (float)(u_hi * GS_TILE_WIDTH) - 0.5f, y0, y1))
+                    continue;
+            }
+            emit(bu, bv);
+        }
+    }
 }
 
 // ------------------------------------------------------------------ pose inverse
@@ -323,13 +332,9 @@ __global__ __launch_bounds__(GS_BLOCK) void preprocess_kernel(
         // blend kernels apply the same test per tile.
         const float amp = opacity * rescale;
         const float qmax = cull ? gs_cull_qmax(amp) : __builtin_inff();
-        if (full > 0 && owned_rows(t0v, t1v, ow) > 0) {   // number of sort keys = bins reached on this GPU
-            const BinBox bb = bin_box(t0u, t1u, t0v, t1v, bin_shift);
-            for (int bu = bb.b0u; bu < bb.b1u; ++bu)
-                for (int bv = bb.b0v; bv < bb.b1v; ++bv)
-                    owned += bin_emits(bu, bv, t0u, t1u, t0v, t1v, bin_shift, ow, cull, uv[0], uv[1], cA, cB, cC, qmax)
-                                 ? 1 : 0;
-        }
+        // number of sort keys = bins reached on this GPU
+        for_each_emitting_bin(t0u, t1u, t0v, t1v, bin_shift, ow, cull, uv[0], uv[1], cA, cB, cC, qmax,
+                              [&](int, int) { ++owned; });
 
         float4 *out = reinterpret_cast<float4 *>(attrs + (size_t)GS_ATTR_STRIDE * i);
         out[0] = make_float4(uv[0], uv[1], c[2], qmax);  // always: the hook exposes uv and depth of every
@@ -383,11 +388,14 @@ __global__ __launch_bounds__(GS_BLOCK) void preprocess_kernel(
 template <typename KeyT>
 __global__ __launch_bounds__(GS_BLOCK) void make_keys_kernel(
     const float *__restrict__ attrs, const int32_t *__restrict__ nkeys,
-    const int32_t *__restrict__ block_offsets, int m, int width, int height, RowOwner ow, int bin_shift,
+    const int32_t *__restrict__ block_offsets, int m_capacity, const int32_t *__restrict__ counters,
+    long long n_keys_capacity, int width, int height, RowOwner ow, int bin_shift,
     int cull, int key_depth_bits, float depth_scale, KeyT *__restrict__ keys, int32_t *__restrict__ payload,
     const int32_t *__restrict__ ntiles_full, const int32_t *__restrict__ block_offsets_full,
     int32_t *__restrict__ slot_offsets) {
     __shared__ int lds[4];
+    // sizes may still be on their way to the host: the visible count is read on the device, writes stop at the capacity
+    const int m = counters ? min(counters[GS_COUNTER_NUM_VISIBLE], m_capacity) : m_capacity;
     const int i = blockIdx.x * GS_BLOCK + threadIdx.x;
     int cnt = i < m ? nkeys[i] : 0;
     int total;
@@ -404,21 +412,21 @@ __global__ __launch_bounds__(GS_BLOCK) void make_keys_kernel(
     const int bins_u = (tw + (1 << bin_shift) - 1) >> bin_shift;
     int t0u, t1u, t0v, t1v;
     tile_box(a0.x, a0.y, a1.w, tw, height / GS_TILE_HEIGHT, t0u, t1u, t0v, t1v);
-    const BinBox bb = bin_box(t0u, t1u, t0v, t1v, bin_shift);
     const int32_t dq = (int32_t)(a0.z * depth_scale);  // truncation toward zero, RAS:159-160
     int k = offset;
-    for (int bu = bb.b0u; bu < bb.b1u; ++bu)
-        for (int bv = bb.b0v; bv < bb.b1v; ++bv) {
-            // the same expression on the same stored values as gs_preprocess: the two kernels agree on the count
-            if (!bin_emits(bu, bv, t0u, t1u, t0v, t1v, bin_shift, ow, cull, a0.x, a0.y, a1.x, a1.y, a1.z, a0.w)) continue;
-            const int32_t bin = bu + bv * bins_u;
+    // the same walk on the same stored values as gs_preprocess: the two kernels agree on the count
+    for_each_emitting_bin(t0u, t1u, t0v, t1v, bin_shift, ow, cull, a0.x, a0.y, a1.x, a1.y, a1.z, a0.w,
+                          [&](int bu, int bv) {
+        const int32_t bin = bu + bv * bins_u;
+        if (k < n_keys_capacity) {   // (an overflowing frame is detected by the host from the counters and redone)
             if (sizeof(KeyT) == 8)
                 keys[k] = (KeyT)((int64_t)dq + ((int64_t)bin << 32));
             else
                 keys[k] = (KeyT)(((uint32_t)bin << key_depth_bits) | (uint32_t)dq);
             payload[k] = i;
-            ++k;
         }
+        ++k;
+    });
 }
 
 // RAS:175-193 find_tile_start_and_end (arrays pre-zeroed by the caller entry point)
@@ -428,8 +436,10 @@ __device__ __forceinline__ int32_t tile_of_key(KeyT key, int key_depth_bits) {
     return (int32_t)((uint32_t)key >> key_depth_bits);
 }
 template <typename KeyT>
-__global__ void tile_ranges_kernel(const KeyT *__restrict__ keys, long long n, int key_depth_bits,
-                                   int32_t *__restrict__ tile_start, int32_t *__restrict__ tile_end) {
+__global__ void tile_ranges_kernel(const KeyT *__restrict__ keys, long long n, const int32_t *__restrict__ n_device,
+                                   int key_depth_bits, int32_t *__restrict__ tile_start,
+                                   int32_t *__restrict__ tile_end) {
+    if (n_device) n = min((long long)*n_device, n);
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     int32_t t = tile_of_key<KeyT>(keys[i], key_depth_bits);
@@ -491,6 +501,13 @@ int gs_read_counters(const int32_t *counters, int32_t *host_counters, int n, voi
     return 0;
 }
 
+int gs_read_counters_async(const int32_t *counters, int32_t *host_counters_pinned, int n, void *stream) {
+    GS_REQUIRE(n > 0 && n <= GS_NUM_COUNTERS, "n");
+    GS_CHECK_HIP(hipMemcpyAsync(host_counters_pinned, counters, sizeof(int32_t) * n, hipMemcpyDeviceToHost,
+                                (hipStream_t)stream));
+    return 0;
+}
+
 int gs_preprocess(const float *xyz, float *features, const int32_t *object_id, const float *intrinsics,
                   const float *q_cp, const float *t_cp, const int32_t *ids, int n_visible, int n_visible_on_device,
                   int width, int height, int tile_row_begin, int tile_row_step, int tile_row_end, int bin_shift,
@@ -539,11 +556,11 @@ int gs_scan_block_sums2(int32_t *block_sums, int32_t *block_sums_full, int n_blo
 }
 
 int gs_make_keys(const float *attrs, const int32_t *num_keys, const int32_t *block_offsets, int n_visible,
-                 int width, int height, int tile_row_begin, int tile_row_step, int tile_row_end, int bin_shift,
-                 int exact_tile_cull, int key_depth_bits, float depth_scale, void *keys, int32_t *payload,
-                 const int32_t *num_overlap_tiles, const int32_t *block_offsets_full, int32_t *slot_offsets,
-                 void *stream) {
-    GS_REQUIRE(n_visible >= 0, "n_visible");
+                 const int32_t *counters, int64_t n_keys_capacity, int width, int height, int tile_row_begin,
+                 int tile_row_step, int tile_row_end, int bin_shift, int exact_tile_cull, int key_depth_bits,
+                 float depth_scale, void *keys, int32_t *payload, const int32_t *num_overlap_tiles,
+                 const int32_t *block_offsets_full, int32_t *slot_offsets, void *stream) {
+    GS_REQUIRE(n_visible >= 0 && n_keys_capacity >= 0, "n_visible / n_keys_capacity");
     GS_REQUIRE(tile_row_step >= 1 && tile_row_begin >= 0 && tile_row_end >= 0, "tile row ownership");
     GS_REQUIRE(bin_shift >= 0 && bin_shift <= 4, "bin_shift");
     GS_REQUIRE(key_depth_bits >= 0 && key_depth_bits < 32, "key_depth_bits");
@@ -554,18 +571,20 @@ int gs_make_keys(const float *attrs, const int32_t *num_keys, const int32_t *blo
     const RowOwner ow{tile_row_begin, tile_row_step, tile_row_end};
     if (key_depth_bits == 0)
         hipLaunchKernelGGL(make_keys_kernel<uint64_t>, grid, block, 0, (hipStream_t)stream, attrs, num_keys,
-                           block_offsets, n_visible, width, height, ow, bin_shift, exact_tile_cull, 0, depth_scale,
-                           (uint64_t *)keys, payload, num_overlap_tiles, block_offsets_full, slot_offsets);
+                           block_offsets, n_visible, counters, (long long)n_keys_capacity, width, height, ow, bin_shift,
+                           exact_tile_cull, 0, depth_scale, (uint64_t *)keys, payload, num_overlap_tiles,
+                           block_offsets_full, slot_offsets);
     else
         hipLaunchKernelGGL(make_keys_kernel<uint32_t>, grid, block, 0, (hipStream_t)stream, attrs, num_keys,
-                           block_offsets, n_visible, width, height, ow, bin_shift, exact_tile_cull, key_depth_bits,
-                           depth_scale, (uint32_t *)keys, payload, num_overlap_tiles, block_offsets_full, slot_offsets);
+                           block_offsets, n_visible, counters, (long long)n_keys_capacity, width, height, ow, bin_shift,
+                           exact_tile_cull, key_depth_bits, depth_scale, (uint32_t *)keys, payload, num_overlap_tiles,
+                           block_offsets_full, slot_offsets);
     GS_CHECK_LAUNCH();
     return 0;
 }
 
-int gs_tile_ranges(const void *keys_sorted, int64_t n_keys, int key_depth_bits, int32_t *tile_start,
-                   int32_t *tile_end, int n_tiles /* number of bins */, void *stream) {
+int gs_tile_ranges(const void *keys_sorted, int64_t n_keys, const int32_t *n_keys_device, int key_depth_bits,
+                   int32_t *tile_start, int32_t *tile_end, int n_tiles /* number of bins */, void *stream) {
     GS_REQUIRE(n_keys >= 0 && n_tiles > 0, "sizes");
     GS_REQUIRE(key_depth_bits >= 0 && key_depth_bits < 32, "key_depth_bits");
     hipStream_t s = (hipStream_t)stream;
@@ -579,10 +598,10 @@ int gs_tile_ranges(const void *keys_sorted, int64_t n_keys, int key_depth_bits, 
     const dim3 grid(gs_div_up(n_keys, GS_BLOCK)), block(GS_BLOCK);
     if (key_depth_bits == 0)
         hipLaunchKernelGGL(tile_ranges_kernel<uint64_t>, grid, block, 0, s, (const uint64_t *)keys_sorted,
-                           (long long)n_keys, 0, tile_start, tile_end);
+                           (long long)n_keys, n_keys_device, 0, tile_start, tile_end);
     else
         hipLaunchKernelGGL(tile_ranges_kernel<uint32_t>, grid, block, 0, s, (const uint32_t *)keys_sorted,
-                           (long long)n_keys, key_depth_bits, tile_start, tile_end);
+                           (long long)n_keys, n_keys_device, key_depth_bits, tile_start, tile_end);
     GS_CHECK_LAUNCH();
     return 0;
 }

@@ -26,9 +26,10 @@ __device__ __forceinline__ unsigned digit_of(KeyT key, int shift, KeyT flip) {
 
 template <typename KeyT>
 __global__ __launch_bounds__(GS_BLOCK) void sort_hist_kernel(const KeyT *__restrict__ keys, long long n,
-                                                            int shift, KeyT flip, int nblk,
-                                                            int32_t *__restrict__ counts) {
-    __shared__ int hist[WAVES][RADIX];   // one histogram per wave: a quarter of the same-address LDS atomics
+                                                            const int32_t *__restrict__ n_device, int shift,
+                                                            KeyT flip, int nblk, int32_t *__restrict__ counts) {
+    __shared__ int hist[WAVES][RADIX];
+    if (n_device) n = min((long long)*n_device, n);   // grid and workspace are sized by the capacity n   // one histogram per wave: a quarter of the same-address LDS atomics
 #pragma unroll
     for (int k = 0; k < WAVES; ++k) hist[k][threadIdx.x] = 0;
     __syncthreads();
@@ -73,9 +74,10 @@ __global__ __launch_bounds__(GS_BLOCK) void sort_scan_rows_kernel(int32_t *__res
 //      the output: rocprofv3 showed 2.8x the algorithmic HBM write bytes.)
 template <typename KeyT>
 __global__ __launch_bounds__(GS_BLOCK) void sort_scatter_kernel(
-    const KeyT *__restrict__ keys_in, const int32_t *__restrict__ payload_in, long long n, int shift,
-    KeyT flip, int nblk, const int32_t *__restrict__ row_offsets, const int32_t *__restrict__ totals,
-    KeyT *__restrict__ keys_out, int32_t *__restrict__ payload_out) {
+    const KeyT *__restrict__ keys_in, const int32_t *__restrict__ payload_in, long long n,
+    const int32_t *__restrict__ n_device, int shift, KeyT flip, int nblk, const int32_t *__restrict__ row_offsets,
+    const int32_t *__restrict__ totals, KeyT *__restrict__ keys_out, int32_t *__restrict__ payload_out) {
+    if (n_device) n = min((long long)*n_device, n);
     __shared__ int s_cnt[WAVES][RADIX];   // running per-wave digit counts, later exclusive prefix over waves
     __shared__ int s_local[RADIX];        // block-local start of each digit's run
     __shared__ int s_gbase[RADIX];        // global position of the block's first key of each digit
@@ -154,21 +156,21 @@ __global__ __launch_bounds__(GS_BLOCK) void sort_scatter_kernel(
 
 template <typename KeyT>
 static int sort_pairs_impl(KeyT *keys, int32_t *payload, KeyT *keys_alt, int32_t *payload_alt, int64_t n_keys,
-                           const int *shifts, int n_pass, KeyT flip, int allow_result_in_alt, void *workspace,
-                           hipStream_t s) {
+                           const int32_t *n_dev, const int *shifts, int n_pass, KeyT flip, int allow_result_in_alt,
+                           void *workspace, hipStream_t s) {
     const int nblk = gs_div_up(n_keys, SORT_ITEMS);
     int32_t *counts = (int32_t *)workspace;
     int32_t *totals = counts + (size_t)RADIX * nblk;
     KeyT *kin = keys, *kout = keys_alt;
     int32_t *pin = payload, *pout = payload_alt;
     for (int p = 0; p < n_pass; ++p) {
-        hipLaunchKernelGGL(sort_hist_kernel<KeyT>, dim3(nblk), dim3(GS_BLOCK), 0, s, kin, (long long)n_keys,
+        hipLaunchKernelGGL(sort_hist_kernel<KeyT>, dim3(nblk), dim3(GS_BLOCK), 0, s, kin, (long long)n_keys, n_dev,
                            shifts[p], flip, nblk, counts);
         GS_CHECK_LAUNCH();
         hipLaunchKernelGGL(sort_scan_rows_kernel, dim3(RADIX), dim3(GS_BLOCK), 0, s, counts, nblk, totals);
         GS_CHECK_LAUNCH();
         hipLaunchKernelGGL(sort_scatter_kernel<KeyT>, dim3(nblk), dim3(GS_BLOCK), 0, s, kin, pin, (long long)n_keys,
-                           shifts[p], flip, nblk, counts, totals, kout, pout);
+                           n_dev, shifts[p], flip, nblk, counts, totals, kout, pout);
         GS_CHECK_LAUNCH();
         KeyT *tk = kin; kin = kout; kout = tk;
         int32_t *tp = pin; pin = pout; pout = tp;
@@ -189,8 +191,8 @@ size_t gs_sort_workspace_bytes(int64_t n_keys) {
 }
 
 int gs_sort_pairs(void *keys, int32_t *payload, void *keys_alt, int32_t *payload_alt, int64_t n_keys,
-                  int key_depth_bits, int depth_bits, int tile_bits, int allow_result_in_alt, void *workspace,
-                  void *stream) {
+                  const int32_t *n_keys_device, int key_depth_bits, int depth_bits, int tile_bits,
+                  int allow_result_in_alt, void *workspace, void *stream) {
     GS_REQUIRE(n_keys >= 0 && n_keys < 0x7fffffffLL, "n_keys must fit int32");
     GS_REQUIRE(depth_bits >= 0 && depth_bits <= 64 && tile_bits >= 0 && tile_bits <= 31, "bit ranges");
     GS_REQUIRE(key_depth_bits >= 0 && key_depth_bits < 32, "key_depth_bits");
@@ -200,8 +202,8 @@ int gs_sort_pairs(void *keys, int32_t *payload, void *keys_alt, int32_t *payload
     if (key_depth_bits > 0) {  // compressed 32-bit keys: one contiguous field
         GS_REQUIRE(key_depth_bits + tile_bits <= 32, "compressed key does not fit 32 bits");
         for (int sh = 0; sh < key_depth_bits + tile_bits; sh += RADIX_BITS) shifts[n_pass++] = sh;
-        return sort_pairs_impl<uint32_t>((uint32_t *)keys, payload, (uint32_t *)keys_alt, payload_alt, n_keys, shifts,
-                                         n_pass, 0u, allow_result_in_alt, workspace, s);
+        return sort_pairs_impl<uint32_t>((uint32_t *)keys, payload, (uint32_t *)keys_alt, payload_alt, n_keys,
+                                         n_keys_device, shifts, n_pass, 0u, allow_result_in_alt, workspace, s);
     }
     uint64_t flip = 0;
     if (depth_bits >= 64) {  // full signed 64-bit order
@@ -211,8 +213,8 @@ int gs_sort_pairs(void *keys, int32_t *payload, void *keys_alt, int32_t *payload
         for (int sh = 0; sh < depth_bits && sh < 32; sh += RADIX_BITS) shifts[n_pass++] = sh;
         for (int sh = 32; sh < 32 + tile_bits; sh += RADIX_BITS) shifts[n_pass++] = sh;
     }
-    return sort_pairs_impl<uint64_t>((uint64_t *)keys, payload, (uint64_t *)keys_alt, payload_alt, n_keys, shifts,
-                                     n_pass, flip, allow_result_in_alt, workspace, s);
+    return sort_pairs_impl<uint64_t>((uint64_t *)keys, payload, (uint64_t *)keys_alt, payload_alt, n_keys,
+                                     n_keys_device, shifts, n_pass, flip, allow_result_in_alt, workspace, s);
 }
 
 }  // extern "C"

@@ -93,6 +93,31 @@ def read_counters(counters: torch.Tensor) -> Tuple[int, ...]:
     return tuple(host)
 
 
+class CounterReadback:
+    """The frame's sizes (M, K, slot count, depth range) on their way to the host WITHOUT stalling the launch queue:
+    ``start`` enqueues the scans' counters into pinned memory and records an event; the host keeps launching the
+    kernels that can work from the device-side counts and calls ``wait`` when it needs the numbers."""
+
+    def __init__(self, device):
+        self.host = torch.empty(NUM_COUNTERS, dtype=torch.int32).pin_memory()
+        self.event = torch.cuda.Event()
+        self.device = device
+
+    def start(self, counters: torch.Tensor) -> None:
+        call("gs_read_counters_async", ptr(counters), self.host.data_ptr(), NUM_COUNTERS, current_stream(self.device))
+        self.event.record(torch.cuda.current_stream(self.device))
+
+    def wait(self) -> Tuple[int, ...]:
+        self.event.synchronize()
+        return tuple(self.host.tolist())
+
+
+def scan_block_sums_async(block_sums: torch.Tensor, counters: torch.Tensor, block_sums_full: torch.Tensor) -> None:
+    """The two in-place scans of ``scan_block_sums`` without its size read-back."""
+    call("gs_scan_block_sums2", ptr(block_sums), ptr(block_sums_full), block_sums.shape[0], ptr(counters),
+         current_stream(counters.device))
+
+
 def pose_inverse(q_pointcloud_camera: torch.Tensor, t_pointcloud_camera: torch.Tensor):
     q = _f32(q_pointcloud_camera, "q_pointcloud_camera").reshape(-1, 4)
     t = _f32(t_pointcloud_camera, "t_pointcloud_camera").reshape(-1, 3)
@@ -164,19 +189,22 @@ def scan_block_sums(block_sums: torch.Tensor, counters: torch.Tensor,
 
 
 def make_keys(attrs, num_keys, block_offsets, n_keys, width, height, depth_to_sort_key_scale,
-              layout: ListLayout = ListLayout(), key_depth_bits=0, num_overlap_tiles=None, block_offsets_full=None):
+              layout: ListLayout = ListLayout(), key_depth_bits=0, num_overlap_tiles=None, block_offsets_full=None,
+              counters=None):
     """-> (keys, payload, slot_offsets).  key_depth_bits == 0: int64 keys in the reference layout
     (bin << 32) + depth; key_depth_bits > 0: 32-bit keys (bin << key_depth_bits) | depth, stored in an int32
     tensor.  slot_offsets i32[M] = exclusive scan of num_overlap_tiles (base of every Gaussian's backward
-    slots) when num_overlap_tiles + its scanned block sums are given, else None (inference)."""
+    slots) when num_overlap_tiles + its scanned block sums are given, else None (inference).
+    counters given: the sizes are still on the device -- attrs/num_keys are capacity-sized, n_keys is the CAPACITY of
+    the key arrays (see include/gsplat_hip.h)."""
     dev = attrs.device
     m = attrs.shape[0]
     keys = torch.empty(n_keys, dtype=torch.int64 if key_depth_bits == 0 else torch.int32, device=dev)
     payload = torch.empty(n_keys, dtype=torch.int32, device=dev)
     slot_offsets = torch.empty(m, dtype=torch.int32, device=dev) if num_overlap_tiles is not None else None
     if m > 0:
-        call("gs_make_keys", ptr(attrs), ptr(num_keys), ptr(block_offsets), m, int(width), int(height),
-             layout.row_begin, layout.row_step, layout.row_end, layout.bin_shift, int(layout.exact_cull),
+        call("gs_make_keys", ptr(attrs), ptr(num_keys), ptr(block_offsets), m, ptr(counters), int(n_keys),
+             int(width), int(height), layout.row_begin, layout.row_step, layout.row_end, layout.bin_shift, int(layout.exact_cull),
              int(key_depth_bits), float(depth_to_sort_key_scale), ptr(keys), ptr(payload), ptr(num_overlap_tiles),
              ptr(block_offsets_full), ptr(slot_offsets), current_stream(dev))
     return keys, payload, slot_offsets
@@ -210,7 +238,7 @@ def sort_pairs(keys: torch.Tensor, payload: torch.Tensor, depth_bits: int, tile_
     """Stable sort of (keys, payload).  in_place=True: the inputs hold the result.  in_place=False: returns the
     (keys, payload) tensors that hold the result (the inputs or the ping-pong buffers: no copy back after an
     odd number of passes); the other pair is scratch."""
-    n = keys.shape[0]
+    n = keys.shape[0]   # capacity when n_keys_device (an int32 device scalar holding the actual count) is given
     if n <= 1:
         return None if in_place else (keys, payload)
     if keys.dtype != (torch.int64 if key_depth_bits == 0 else torch.int32):
@@ -219,7 +247,7 @@ def sort_pairs(keys: torch.Tensor, payload: torch.Tensor, depth_bits: int, tile_
     keys_alt, payload_alt = torch.empty_like(keys), torch.empty_like(payload)
     ws = torch.empty(_lib.load().gs_sort_workspace_bytes(n), dtype=torch.uint8, device=dev)
     status = _lib.load().gs_sort_pairs(ptr(keys), ptr(payload), ptr(keys_alt), ptr(payload_alt), n,
-                                       int(key_depth_bits), int(depth_bits), int(tile_bits), 0 if in_place else 1,
+                                       ptr(n_keys_device), int(key_depth_bits), int(depth_bits), int(tile_bits), 0 if in_place else 1,
                                        ptr(ws), current_stream(dev))
     if status < 0:
         _lib.check(status, "gs_sort_pairs")
@@ -228,14 +256,15 @@ def sort_pairs(keys: torch.Tensor, payload: torch.Tensor, depth_bits: int, tile_
     return None
 
 
-def tile_ranges(keys_sorted: torch.Tensor, num_tiles: int, key_depth_bits: int = 0):
+def tile_ranges(keys_sorted: torch.Tensor, num_tiles: int, key_depth_bits: int = 0,
+                n_keys_device: Optional[torch.Tensor] = None):
     """Per-bin [start, end) ranges of the sorted keys (num_tiles = number of bins; tiles with bin_shift 0)."""
     if keys_sorted.dtype != (torch.int64 if key_depth_bits == 0 else torch.int32):
         raise TypeError("key dtype does not match the key layout")
     dev = keys_sorted.device
     both = torch.empty((2, num_tiles), dtype=torch.int32, device=dev)  # one buffer -> one fill in the library
     start, end = both[0], both[1]
-    call("gs_tile_ranges", ptr(keys_sorted), keys_sorted.shape[0], int(key_depth_bits), ptr(start), ptr(end),
+    call("gs_tile_ranges", ptr(keys_sorted), keys_sorted.shape[0], ptr(n_keys_device), int(key_depth_bits), ptr(start), ptr(end),
          int(num_tiles), current_stream(dev))
     return start, end
 

@@ -611,6 +611,32 @@ def test_rgb_only_and_inference_paths(ops, scene):
                 assert torch.equal(out[2], ref[2]) and torch.equal(out[3], ref[3])
 
 
+def test_speculative_sizes_overflow_is_redone(scene):
+    """The list stages are launched from device-side counts with the previous frame's capacities (no blocking size
+    read-back in the steady state).  A frame that does not fit -- many more keys, or a deeper depth range than the
+    previous frame -- is detected when the sizes arrive and redone: its outputs equal those of a fresh operator."""
+    from taichi_3d_gaussian_splatting_amd import GaussianPointCloudRasterisation as Op
+    from taichi_3d_gaussian_splatting_amd.synthetic import make_grad_image
+    g = make_grad_image(scene.height, scene.width)
+    few = small_scene(n=500, size=scene.height, seed=3)           # 20x fewer keys, same image size and planes
+    far = small_scene(n=3000, size=scene.height, seed=4)
+    far.point_cloud[:, 2] += 40.0                                # quantised depths ~4300: more bits than the ~400 before
+    cfg = Op.GaussianPointCloudRasterisationConfig()
+    op = Op(cfg)
+    fresh = lambda sc: _run_operator(sc, g, op=Op(cfg))           # noqa: E731
+    seq = [few, few, scene, scene, far, far, few]
+    expect_redone = [0, 0, 1, 1, 2, 2, 2]                         # frame 0 has nothing to speculate from
+    for sc, redone in zip(seq, expect_redone):
+        got, ref = _run_operator(sc, g, op=op), fresh(sc)
+        assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1]) and torch.equal(got[2], ref[2])
+        assert torch.equal(got[3].grad, ref[3].grad) and torch.equal(got[4].grad, ref[4].grad)
+        assert op.speculation_stats["redone"] == redone, (op.speculation_stats, redone)
+    assert op.speculation_stats["frames"] == len(seq)
+    op.speculative_sizes = False                                  # the two-halves path still works
+    got, ref = _run_operator(scene, g, op=op), fresh(scene)
+    assert torch.equal(got[0], ref[0]) and torch.equal(got[4].grad, ref[4].grad)
+
+
 def test_hook_feature_gradients_can_be_switched_off(scene):
     from taichi_3d_gaussian_splatting_amd import GaussianPointCloudRasterisation as Op
     from taichi_3d_gaussian_splatting_amd.synthetic import make_grad_image
