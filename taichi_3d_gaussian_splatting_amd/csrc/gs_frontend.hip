@@ -83,17 +83,18 @@ __device__ __forceinline__ void for_each_emitting_bin(int t0u, int t1u, int t0v,
     const int b0v = t0v >> bin_shift, b1v = ((t1v - 1) >> bin_shift) + 1;
     // slopes of the conic's conjugate diameters: per-Gaussian constants of the contribution test
     const float sy = -B * __builtin_amdgcn_rcpf(C), sx = -B * __builtin_amdgcn_rcpf(A);
-    for (int bv = b0v; bv < b1v; ++bv) {
-        const int v_lo = max(t0v, bv << bin_shift), v_hi = min(t1v, (bv + 1) << bin_shift);   // box rows in this bin row
-        if (owned_rows(v_lo, v_hi, ow) == 0) continue;
-        const float y0 = (float)(v_lo * GS_TILE_HEIGHT) + 0.5f, y1 = (float)(v_hi * GS_TILE_HEIGHT) - 0.5f;
-        for (int bu = b0u; bu < b1u; ++bu) {
-            if (cull) {
-                const int u_lo = max(t0u, bu << bin_shift), u_hi = min(t1u, (bu + 1) << bin_shift);
-                if (!gs_rect_may_contribute(ux, uy, A, B, C, sx, sy, qmax, (float)(u_lo * GS_TILE_WIDTH) + 0.5f,
-                                            (float)(u_hi * GS_TILE_WIDTH) - 0.5f, y0, y1))
-                    continue;
-            }
+    // tile_u outer, tile_v inner: the generation order of RAS:161-166 (with bin_shift 0 the unsorted keys are the
+    // reference's, position by position)
+    for (int bu = b0u; bu < b1u; ++bu) {
+        const int u_lo = max(t0u, bu << bin_shift), u_hi = min(t1u, (bu + 1) << bin_shift);   // box columns in this bin
+        const float x0 = (float)(u_lo * GS_TILE_WIDTH) + 0.5f, x1 = (float)(u_hi * GS_TILE_WIDTH) - 0.5f;
+        for (int bv = b0v; bv < b1v; ++bv) {
+            const int v_lo = max(t0v, bv << bin_shift), v_hi = min(t1v, (bv + 1) << bin_shift);
+            if (owned_rows(v_lo, v_hi, ow) == 0) continue;
+            if (cull && !gs_rect_may_contribute(ux, uy, A, B, C, sx, sy, qmax, x0, x1,
+                                                (float)(v_lo * GS_TILE_HEIGHT) + 0.5f,
+                                                (float)(v_hi * GS_TILE_HEIGHT) - 0.5f))
+                continue;
             emit(bu, bv);
         }
     }

@@ -234,7 +234,7 @@ def key_layout(near_plane: float, far_plane: float, depth_to_sort_key_scale: flo
 
 
 def sort_pairs(keys: torch.Tensor, payload: torch.Tensor, depth_bits: int, tile_bits: int,
-               key_depth_bits: int = 0, in_place: bool = True):
+               key_depth_bits: int = 0, in_place: bool = True, n_keys_device: Optional[torch.Tensor] = None):
     """Stable sort of (keys, payload).  in_place=True: the inputs hold the result.  in_place=False: returns the
     (keys, payload) tensors that hold the result (the inputs or the ping-pong buffers: no copy back after an
     odd number of passes); the other pair is scratch."""
