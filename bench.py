@@ -158,8 +158,7 @@ def main() -> None:
     n = s.point_cloud.shape[0]
     roofline, stages_ms, sizes = None, {}, {}
     if not args.no_stage_profile:
-        layout = hip_ops.ListLayout(bin_shift=op.bin_shift, exact_cull=op.exact_tile_cull, row_begin=op.tile_row_begin,
-                                    row_step=op.tile_row_step, row_end=op.tile_row_end)
+        layout = op.list_layout()
         ev = lambda: torch.cuda.Event(enable_timing=True)  # noqa: E731  (events on torch's current stream,
         reps = max(3, min(args.steps, 10))                 #  the stream every kernel is launched on)
         acc_ms = {}

@@ -185,10 +185,7 @@ class GaussianPointCloudRasterisation(torch.nn.Module):
                          q_pointcloud_camera, t_pointcloud_camera, camera_info, color_max_sh_band, need_state):
                 cfg = outer.config
                 width, height = camera_info.camera_width, camera_info.camera_height
-                bin_shift = outer._auto_bin_shift if outer.bin_shift is None else outer.bin_shift
-                layout = hip_ops.ListLayout(bin_shift=bin_shift, exact_cull=outer.exact_tile_cull,
-                                            row_begin=outer.tile_row_begin, row_step=outer.tile_row_step,
-                                            row_end=outer.tile_row_end)
+                layout = outer.list_layout()
                 if not pointcloud_features.is_contiguous():
                     raise ValueError("point_cloud_features must be contiguous (it is normalised in place)")
                 if pointcloud_features.dtype != torch.float32 or pointcloud_features.shape[1] != 56:
@@ -341,6 +338,12 @@ class GaussianPointCloudRasterisation(torch.nn.Module):
         self.hook_feature_gradients: bool = True
         self.grad_accumulator_reduce: Optional[Callable[[torch.Tensor], None]] = None
         self.image_gather: Optional[Callable[[list], None]] = None
+
+    def list_layout(self) -> "hip_ops.ListLayout":
+        """The list layout the next forward pass will use."""
+        return hip_ops.ListLayout(bin_shift=self._auto_bin_shift if self.bin_shift is None else self.bin_shift,
+                                  exact_cull=self.exact_tile_cull, row_begin=self.tile_row_begin,
+                                  row_step=self.tile_row_step, row_end=self.tile_row_end)
 
     def _counter_readback(self, device):
         rb = self._readbacks.get(device)

@@ -474,43 +474,63 @@ __global__ __launch_bounds__(BLEND_THREADS) void blend_backward_kernel(
 }
 
 // Sums the flagged (Gaussian, tile) slots of every visible Gaussian into the accumulator record acc[i] that
-// gs_point_backward consumes.  Sixteen lanes share a Gaussian: lane l takes the slot groups l, l + 16, ... (four
-// consecutive slots each) in ascending order, then the sixteen partial records are added in a fixed DPP order -- a
-// deterministic summation order whatever the launch, so gradients are bitwise reproducible.  (One thread per Gaussian
-// scanned the flags serially: 2.2 ms on the reference's stress scene, where every one of 5,628 Gaussians owns 8,160
-// slots.)  Value 10 (pixel count) is summed as an integer.
-constexpr int RP_LANES = 16;
+// gs_point_backward consumes.  One lane per Gaussian walks its slots in ascending order (typically ~10); a Gaussian
+// with more than RP_HEAVY slots (the reference's stress scene: 8,160 each, 2.2 ms when a single lane scanned them) is
+// handed to the whole wave instead: lane l takes the slot groups l, l + 64, ... (four consecutive slots each) in
+// ascending order and the 64 partial records are added in a fixed DPP order.  Either way the summation order depends
+// only on the slot layout, so gradients are bitwise reproducible.  Value 10 (pixel count) is summed as an integer.
+constexpr int RP_HEAVY = 128;
+struct SlotSum { float v[10]; int npix; };
+__device__ __forceinline__ void rp_add_group(const uint8_t *__restrict__ flags, const float4 *__restrict__ partials,
+                                             int first, int cnt, SlotSum &a) {
+    unsigned mask = 0u;   // gather the flags of up to 32 consecutive slots (independent byte loads), then visit the
+                          // raised ones (independent 48-B loads): many loads in flight instead of one at a time
+    for (int r = 0; r < cnt; ++r) mask |= (flags[first + r] != 0 ? 1u : 0u) << r;
+    while (mask) {
+        const int r = __builtin_ctz(mask);
+        mask &= mask - 1;
+        const float4 *src = partials + 3 * (size_t)(first + r);
+        const float4 p0 = src[0], p1 = src[1], p2 = src[2];
+        a.v[0] += p0.x; a.v[1] += p0.y; a.v[2] += p0.z; a.v[3] += p0.w;
+        a.v[4] += p1.x; a.v[5] += p1.y; a.v[6] += p1.z; a.v[7] += p1.w;
+        a.v[8] += p2.x; a.v[9] += p2.y;
+        a.npix += __builtin_bit_cast(int, p2.z);
+    }
+}
 __global__ __launch_bounds__(GS_BLOCK) void reduce_partials_kernel(
     const int32_t *__restrict__ slot_offsets, const int32_t *__restrict__ ntiles_full,
     const uint8_t *__restrict__ slot_flags, const float4 *__restrict__ partials, int m, float4 *__restrict__ acc) {
-    const int i = (int)(((long long)blockIdx.x * GS_BLOCK + threadIdx.x) / RP_LANES), sub = threadIdx.x & (RP_LANES - 1);
+    const int i = blockIdx.x * GS_BLOCK + threadIdx.x, lane = gs_lane();
     const bool live = i < m;
     const int base = live ? slot_offsets[i] : 0, n = live ? ntiles_full[i] : 0;
-    float v[10] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    int npix = 0;
-    for (int r0 = 4 * sub; r0 < n; r0 += 4 * RP_LANES) {
-        const int cnt = min(4, n - r0);
-        unsigned mask = 0u;   // (slot_flags + base is not 4-byte aligned in general: byte loads, one cache line)
-        for (int r = 0; r < cnt; ++r) mask |= (slot_flags[base + r0 + r] != 0 ? 1u : 0u) << r;
-        while (mask) {
-            const int r = __builtin_ctz(mask);
-            mask &= mask - 1;
-            const float4 *src = partials + 3 * (size_t)(base + r0 + r);
-            const float4 p0 = src[0], p1 = src[1], p2 = src[2];
-            v[0] += p0.x; v[1] += p0.y; v[2] += p0.z; v[3] += p0.w;
-            v[4] += p1.x; v[5] += p1.y; v[6] += p1.z; v[7] += p1.w;
-            v[8] += p2.x; v[9] += p2.y;
-            npix += __builtin_bit_cast(int, p2.z);
-        }
-    }
-    // the sixteen lanes of a Gaussian are one DPP row: totals land in lane 15 of the row
+    SlotSum a;
 #pragma unroll
-    for (int k = 0; k < 10; ++k) v[k] = gs_row_sum_to_lane15(v[k]);
-    const float npf = gs_row_sum_to_lane15((float)npix);   // < 2^24: exact as a float
-    if (live && sub == RP_LANES - 1) {
-        acc[3 * (size_t)i] = make_float4(v[0], v[1], v[2], v[3]);
-        acc[3 * (size_t)i + 1] = make_float4(v[4], v[5], v[6], v[7]);
-        acc[3 * (size_t)i + 2] = make_float4(v[8], v[9], __builtin_bit_cast(float, (int)npf), 0.f);
+    for (int k = 0; k < 10; ++k) a.v[k] = 0.f;
+    a.npix = 0;
+    if (n <= RP_HEAVY)
+        for (int r0 = 0; r0 < n; r0 += 32) rp_add_group(slot_flags, partials, base + r0, min(32, n - r0), a);
+    unsigned long long heavy = __builtin_amdgcn_ballot_w64(n > RP_HEAVY);
+    while (heavy) {   // wave-uniform loop over the heavy Gaussians of this wave
+        const int L = __builtin_ctzll(heavy);
+        heavy &= heavy - 1;
+        const int bL = __builtin_amdgcn_readlane(base, L), nL = __builtin_amdgcn_readlane(n, L);
+        SlotSum h;
+#pragma unroll
+        for (int k = 0; k < 10; ++k) h.v[k] = 0.f;
+        h.npix = 0;
+        for (int r0 = 4 * lane; r0 < nL; r0 += 4 * GS_WAVE) rp_add_group(slot_flags, partials, bL + r0, min(4, nL - r0), h);
+#pragma unroll
+        for (int k = 0; k < 10; ++k) {
+            const float t = gs_readlane63(gs_wave_sum_to_lane63(h.v[k]));
+            if (lane == L) a.v[k] = t;
+        }
+        const float np = gs_readlane63(gs_wave_sum_to_lane63((float)h.npix));   // < 2^24: exact as a float
+        if (lane == L) a.npix = (int)np;
+    }
+    if (live) {
+        acc[3 * (size_t)i] = make_float4(a.v[0], a.v[1], a.v[2], a.v[3]);
+        acc[3 * (size_t)i + 1] = make_float4(a.v[4], a.v[5], a.v[6], a.v[7]);
+        acc[3 * (size_t)i + 2] = make_float4(a.v[8], a.v[9], __builtin_bit_cast(float, a.npix), 0.f);
     }
 }
 
@@ -628,7 +648,7 @@ int gs_reduce_partials(const int32_t *slot_offsets, const int32_t *num_overlap_t
                        const float *partials, int n_visible, float *acc, void *stream) {
     GS_REQUIRE(n_visible >= 0, "n_visible");
     if (n_visible == 0) return 0;
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3(gs_div_up((long long)n_visible * RP_LANES, GS_BLOCK)), dim3(GS_BLOCK), 0,
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(gs_div_up(n_visible, GS_BLOCK)), dim3(GS_BLOCK), 0,
                        (hipStream_t)stream, slot_offsets, num_overlap_tiles, slot_flags,
                        reinterpret_cast<const float4 *>(partials), n_visible, reinterpret_cast<float4 *>(acc));
     GS_CHECK_LAUNCH();
