@@ -158,7 +158,7 @@ def main() -> None:
     n = s.point_cloud.shape[0]
     roofline, stages_ms, sizes = None, {}, {}
     if not args.no_stage_profile:
-        layout = op.list_layout()
+        layout = op.list_layout(s.height)
         ev = lambda: torch.cuda.Event(enable_timing=True)  # noqa: E731  (events on torch's current stream,
         reps = max(3, min(args.steps, 10))                 #  the stream every kernel is launched on)
         acc_ms = {}

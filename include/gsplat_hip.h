@@ -206,6 +206,7 @@ int gs_blend_backward(const int32_t *bin_start, const int32_t *payload, const fl
  * Replaces the accumulation side of the reference's atomics (RAS:674-696). */
 int gs_reduce_partials(const int32_t *slot_offsets, const int32_t *num_overlap_tiles,
                        const uint8_t *slot_flags, const float *partials, int n_visible, float *acc,
+                       const int32_t *num_keys /* may be NULL; num_keys[i] == 0: nothing to sum */,
                        void *stream);
 
 /* Backward per-point pass + gradient post-processing.  Replaces the per-point loop of

@@ -146,10 +146,15 @@ class GaussianPointCloudRasterisation(torch.nn.Module):
     ):
         super().__init__()
         self.config = config
-        # image-space sharding (multi-GPU): this instance renders tile rows begin, begin+step, ... below end
+        # image-space sharding (multi-GPU): this instance renders tile rows begin, begin+step, ... below end; either set
+        # directly or derived per frame from `shard` = (rank, world, "bands" | "interleaved") by
+        # distributed.shard_rasteriser_across_tile_rows (`shard_row_weights`: optional per-tile-row weights, the same on
+        # every rank, that balance the bands)
         self.tile_row_begin = 0
         self.tile_row_step = 1
         self.tile_row_end = hip_ops._NO_ROW_LIMIT
+        self.shard = None
+        self.shard_row_weights = None
         # drop (bin | tile, Gaussian) pairs that cannot reach alpha >= 1/255 anywhere in the bin | tile (output-identical)
         self.exact_tile_cull = True
         # sort keys per bin of (1 << bin_shift)^2 tiles: 0 = per tile as the reference (fastest when Gaussians cover few
@@ -185,7 +190,7 @@ class GaussianPointCloudRasterisation(torch.nn.Module):
                          q_pointcloud_camera, t_pointcloud_camera, camera_info, color_max_sh_band, need_state):
                 cfg = outer.config
                 width, height = camera_info.camera_width, camera_info.camera_height
-                layout = outer.list_layout()
+                layout = outer.list_layout(height)
                 if not pointcloud_features.is_contiguous():
                     raise ValueError("point_cloud_features must be contiguous (it is normalised in place)")
                 if pointcloud_features.dtype != torch.float32 or pointcloud_features.shape[1] != 56:
@@ -308,7 +313,8 @@ class GaussianPointCloudRasterisation(torch.nn.Module):
                     # RAS:531-705  per-pixel pass
                     acc, magnitude_image = hip_ops.blend_backward(
                         tile_start, payload, attrs, grad_rasterized_image, acc_alpha, last_eff,
-                        slot_offsets, num_overlap_tiles, ctx.n_slots, width, height, ctx.layout)
+                        slot_offsets, num_overlap_tiles, ctx.n_slots, width, height, ctx.layout,
+                        num_keys=num_owned_tiles if ctx.layout.sharded else None)
                     if outer.grad_accumulator_reduce is not None:  # multi-GPU: sum partial tile gradients
                         outer.grad_accumulator_reduce(acc)
                     # RAS:707-772 + 1102-1125  per-point pass, band clearing and factors fused
@@ -339,11 +345,18 @@ class GaussianPointCloudRasterisation(torch.nn.Module):
         self.grad_accumulator_reduce: Optional[Callable[[torch.Tensor], None]] = None
         self.image_gather: Optional[Callable[[list], None]] = None
 
-    def list_layout(self) -> "hip_ops.ListLayout":
-        """The list layout the next forward pass will use."""
+    def list_layout(self, height: Optional[int] = None) -> "hip_ops.ListLayout":
+        """The list layout the next forward pass will use (for an image of ``height`` pixels when sharded)."""
+        begin, step, end = self.tile_row_begin, self.tile_row_step, self.tile_row_end
+        if self.shard is not None:
+            from .distributed import owned_tile_rows
+            if height is None:
+                raise ValueError("a sharded layout depends on the image height")
+            rank, world, mode = self.shard
+            rows = owned_tile_rows(height // TILE_HEIGHT, rank, world, mode, self.shard_row_weights)
+            begin, step, end = rows.start, rows.step, rows.stop
         return hip_ops.ListLayout(bin_shift=self._auto_bin_shift if self.bin_shift is None else self.bin_shift,
-                                  exact_cull=self.exact_tile_cull, row_begin=self.tile_row_begin,
-                                  row_step=self.tile_row_step, row_end=self.tile_row_end)
+                                  exact_cull=self.exact_tile_cull, row_begin=begin, row_step=step, row_end=end)
 
     def _counter_readback(self, device):
         rb = self._readbacks.get(device)

@@ -499,10 +499,12 @@ __device__ __forceinline__ void rp_add_group(const uint8_t *__restrict__ flags, 
 }
 __global__ __launch_bounds__(GS_BLOCK) void reduce_partials_kernel(
     const int32_t *__restrict__ slot_offsets, const int32_t *__restrict__ ntiles_full,
-    const uint8_t *__restrict__ slot_flags, const float4 *__restrict__ partials, int m, float4 *__restrict__ acc) {
+    const uint8_t *__restrict__ slot_flags, const float4 *__restrict__ partials, int m, float4 *__restrict__ acc,
+    const int32_t *__restrict__ nkeys) {
     const int i = blockIdx.x * GS_BLOCK + threadIdx.x, lane = gs_lane();
     const bool live = i < m;
-    const int base = live ? slot_offsets[i] : 0, n = live ? ntiles_full[i] : 0;
+    // a Gaussian that emitted no sort key on this GPU (tile-row sharding) was blended nowhere: no slot to look at
+    const int base = live ? slot_offsets[i] : 0, n = live && (nkeys == nullptr || nkeys[i] > 0) ? ntiles_full[i] : 0;
     SlotSum a;
 #pragma unroll
     for (int k = 0; k < 10; ++k) a.v[k] = 0.f;
@@ -645,12 +647,12 @@ int gs_blend_backward(const int32_t *bin_start, const int32_t *payload, const fl
 }
 
 int gs_reduce_partials(const int32_t *slot_offsets, const int32_t *num_overlap_tiles, const uint8_t *slot_flags,
-                       const float *partials, int n_visible, float *acc, void *stream) {
+                       const float *partials, int n_visible, float *acc, const int32_t *num_keys, void *stream) {
     GS_REQUIRE(n_visible >= 0, "n_visible");
     if (n_visible == 0) return 0;
     hipLaunchKernelGGL(reduce_partials_kernel, dim3(gs_div_up(n_visible, GS_BLOCK)), dim3(GS_BLOCK), 0,
                        (hipStream_t)stream, slot_offsets, num_overlap_tiles, slot_flags,
-                       reinterpret_cast<const float4 *>(partials), n_visible, reinterpret_cast<float4 *>(acc));
+                       reinterpret_cast<const float4 *>(partials), n_visible, reinterpret_cast<float4 *>(acc), num_keys);
     GS_CHECK_LAUNCH();
     return 0;
 }

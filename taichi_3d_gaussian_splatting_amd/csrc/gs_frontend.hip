@@ -262,9 +262,11 @@ __global__ __launch_bounds__(GS_BLOCK) void preprocess_kernel(
     if (i < m) {
         const int id = ids[i];
         float4 *row4 = reinterpret_cast<float4 *>(feat + (size_t)GS_FEATURE_DIM * id);
-        float f[GS_FEATURE_DIM];
+        // q, log-scale and the opacity logit now (32 B); the 192 B of SH coefficients only if this Gaussian emits a key on
+        // this GPU (under tile-row sharding most visible Gaussians do not)
+        float f[8];
 #pragma unroll
-        for (int k = 0; k < GS_FEATURE_DIM / 4; ++k) {
+        for (int k = 0; k < 2; ++k) {
             float4 v = row4[k];
             f[4 * k] = v.x; f[4 * k + 1] = v.y; f[4 * k + 2] = v.z; f[4 * k + 3] = v.w;
         }
@@ -345,8 +347,14 @@ __global__ __launch_bounds__(GS_BLOCK) void preprocess_kernel(
             // the SH colour (the most expensive part) and the rest of the record are skipped otherwise
             // (tile-row sharding: most Gaussians touch the rows of only one or two of the G GPUs).
             // colour: RAS:280-282,302-310; ray origin = (-R^T) t (UTL:495-510)
+            float sh[48];
+#pragma unroll
+            for (int k = 0; k < 12; ++k) {
+                float4 v = row4[2 + k];
+                sh[4 * k] = v.x; sh[4 * k + 1] = v.y; sh[4 * k + 2] = v.z; sh[4 * k + 3] = v.w;
+            }
             float rgb[3];   // shared source with the per-point backward (gs_common.h): bit-identical there
-            gs_view_colour(W.m, t, p, [&](int ch, int k) { return f[8 + 16 * ch + k]; }, rgb);
+            gs_view_colour(W.m, t, p, [&](int ch, int k) { return sh[16 * ch + k]; }, rgb);
             out[1] = make_float4(cA, cB, cC, radius);
             out[2] = make_float4(rgb[0], rgb[1], rgb[2], opacity);
             // the weight UTL:275-284 in the log2 domain: amp * 2^(dx*(A'dx + B'dy) + C'dy^2)

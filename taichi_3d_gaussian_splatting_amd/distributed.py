@@ -22,12 +22,43 @@ import torch.distributed as dist
 TILE_HEIGHT = 16
 
 
-def owned_tile_rows(num_tile_rows: int, rank: int, world: int) -> range:
-    return range(rank, num_tile_rows, world)
+def owned_tile_rows(num_tile_rows: int, rank: int, world: int, mode: str = "bands",
+                    row_weights: Optional[Sequence[float]] = None) -> range:
+    """Tile rows rendered by ``rank``.
+    "bands" (default): one contiguous band per rank, so that a Gaussian is binned, sorted and blended by one rank
+    (two if it straddles a boundary) and the per-rank list work scales with 1/world; the boundaries split
+    ``row_weights`` (e.g. the previous frame's sort keys per tile row) evenly, or the rows when no weights are given.
+    "interleaved": rows rank, rank + world, ... (balances any scene, but every rank meets every Gaussian)."""
+    if mode == "interleaved":
+        return range(rank, num_tile_rows, world)
+    if mode != "bands":
+        raise ValueError(mode)
+    bounds = band_boundaries(num_tile_rows, world, row_weights)
+    return range(bounds[rank], bounds[rank + 1])
+
+
+def band_boundaries(num_tile_rows: int, world: int, row_weights: Optional[Sequence[float]] = None) -> list:
+    """world + 1 non-decreasing row indices, 0 .. num_tile_rows: band g = rows [b[g], b[g+1]).  With weights, band g
+    ends at the first row where the running weight reaches (g+1)/world of the total (deterministic: every rank
+    computes the same boundaries from the same replicated weights)."""
+    if row_weights is None or len(row_weights) != num_tile_rows or float(sum(row_weights)) <= 0.0:
+        return [(g * num_tile_rows) // world for g in range(world + 1)]
+    total = float(sum(row_weights))
+    bounds, run, g = [0], 0.0, 1
+    for r, w in enumerate(row_weights):
+        run += float(w)
+        while g < world and run >= total * g / world:
+            bounds.append(r + 1)
+            g += 1
+    while len(bounds) < world + 1:
+        bounds.append(num_tile_rows)
+    bounds[-1] = num_tile_rows
+    return bounds
 
 
 def all_gather_tile_rows(tensors: Sequence[torch.Tensor], rank: int, world: int,
-                         group: Optional[dist.ProcessGroup] = None, force: bool = False) -> None:
+                         group: Optional[dist.ProcessGroup] = None, force: bool = False, mode: str = "bands",
+                         row_weights: Optional[Sequence[float]] = None) -> None:
     """In place: every tensor is [H, W, ...] with only this rank's tile rows valid; after the call all
     rows are valid on every rank.  One collective per call: the per-rank blocks of all tensors are
     packed into one byte buffer (fewer, larger collectives)."""
@@ -35,8 +66,9 @@ def all_gather_tile_rows(tensors: Sequence[torch.Tensor], rank: int, world: int,
         return
     height = tensors[0].shape[0]
     th = height // TILE_HEIGHT
-    max_rows = (th + world - 1) // world
-    rows_mine = len(owned_tile_rows(th, rank, world))
+    rows = [owned_tile_rows(th, g, world, mode, row_weights) for g in range(world)]
+    max_rows = max(len(r) for r in rows)
+    mine = rows[rank]
     views, spans, total = [], [], 0
     for t in tensors:
         assert t.shape[0] == height and t.is_contiguous()
@@ -47,14 +79,17 @@ def all_gather_tile_rows(tensors: Sequence[torch.Tensor], rank: int, world: int,
         total += nbytes
     dev = tensors[0].device
     send = torch.empty(total, dtype=torch.uint8, device=dev)
-    for v, (off, nbytes) in zip(views, spans):  # one strided copy per tensor into the packed send buffer
-        send[off: off + nbytes].view(v.dtype).view(max_rows, v.shape[1])[:rows_mine].copy_(v[rank::world])
+    for v, (off, nbytes) in zip(views, spans):  # one (strided or contiguous) copy per tensor into the packed send buffer
+        send[off: off + nbytes].view(v.dtype).view(max_rows, v.shape[1])[:len(mine)].copy_(
+            v[mine.start:mine.stop:mine.step])
     recv = torch.empty(world * total, dtype=torch.uint8, device=dev)
     dist.all_gather_into_tensor(recv, send, group=group)
     recv2d = recv.view(world, total)
-    for v, (off, nbytes) in zip(views, spans):  # one copy per tensor: [G, rows, len] -> interleaved rows
-        block = recv2d[:, off: off + nbytes].view(v.dtype).unflatten(1, (max_rows, v.shape[1]))
-        v.copy_(block.permute(1, 0, 2).reshape(max_rows * world, v.shape[1])[:th])
+    for v, (off, nbytes) in zip(views, spans):
+        block = recv2d[:, off: off + nbytes].view(v.dtype).unflatten(1, (max_rows, v.shape[1]))   # [G, rows, len]
+        for g, r in enumerate(rows):
+            if g != rank and len(r) > 0:
+                v[r.start:r.stop:r.step].copy_(block[g, :len(r)])
 
 
 _replica_checks = {"calls": 0}
@@ -86,11 +121,15 @@ def all_reduce_accumulators(acc: torch.Tensor, group: Optional[dist.ProcessGroup
     col.view(torch.int32).copy_(col.round().to(torch.int32))
 
 
-def shard_rasteriser_across_tile_rows(rasteriser, group: Optional[dist.ProcessGroup] = None, force: bool = False):
-    """Configure a ``GaussianPointCloudRasterisation`` instance for tile-row sharding over ``group``."""
+def shard_rasteriser_across_tile_rows(rasteriser, group: Optional[dist.ProcessGroup] = None, force: bool = False,
+                                      mode: str = "bands"):
+    """Configure a ``GaussianPointCloudRasterisation`` instance for tile-row sharding over ``group`` (see
+    ``owned_tile_rows`` for the two modes; ``rasteriser.shard_row_weights`` may be set to per-tile-row weights --
+    identical on every rank -- to balance the bands)."""
     rank, world = dist.get_rank(group), dist.get_world_size(group)
-    rasteriser.tile_row_begin, rasteriser.tile_row_step = rank, world
+    rasteriser.shard = (rank, world, mode)
     if world > 1 or force:
-        rasteriser.image_gather = lambda tensors: all_gather_tile_rows(tensors, rank, world, group, force)
+        rasteriser.image_gather = lambda tensors: all_gather_tile_rows(
+            tensors, rank, world, group, force, mode, rasteriser.shard_row_weights)
         rasteriser.grad_accumulator_reduce = lambda acc: all_reduce_accumulators(acc, group)
     return rasteriser

@@ -14,7 +14,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, height, width):
+def _worker(rank, world, port, height, width, mode, weights):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -28,12 +28,12 @@ def _worker(rank, world, port, height, width):
     # each rank holds only its own tile rows (others are zero, as hip_ops.blend_forward leaves them)
     rows = torch.arange(height) // 16
     own = torch.zeros(height, dtype=torch.bool)
-    for r in owned_tile_rows(th, rank, world):
+    for r in owned_tile_rows(th, rank, world, mode, weights):
         own |= rows == r
     image = torch.where(own[:, None, None], full_image, torch.zeros_like(full_image)).contiguous()
     depth = torch.where(own[:, None], full_depth, torch.zeros_like(full_depth)).contiguous()
     count = torch.where(own[:, None], full_count, torch.zeros_like(full_count)).contiguous()
-    all_gather_tile_rows([image, depth, count], rank, world)
+    all_gather_tile_rows([image, depth, count], rank, world, mode=mode, row_weights=weights)
     assert torch.equal(image, full_image) and torch.equal(depth, full_depth) and torch.equal(count, full_count)
 
     # gradient accumulators: float columns summed, column 10 summed as int32 bits
@@ -50,21 +50,38 @@ def _worker(rank, world, port, height, width):
     dist.destroy_process_group()
 
 
-def _run(world, height, width):
-    mp.spawn(_worker, args=(world, _free_port(), height, width), nprocs=world, join=True)
+def _run(world, height, width, mode="bands", weights=None):
+    mp.spawn(_worker, args=(world, _free_port(), height, width, mode, weights), nprocs=world, join=True)
 
 
 def test_all_gather_tile_rows_and_grad_reduce_world2():
-    _run(2, 1072 // 4 // 16 * 16 + 16, 64)   # 17 tile rows: uneven split (9 + 8)
+    _run(2, 1072 // 4 // 16 * 16 + 16, 64)   # 17 tile rows: uneven bands (8 + 9)
+
+
+def test_all_gather_tile_rows_world2_interleaved():
+    _run(2, 1072 // 4 // 16 * 16 + 16, 64, mode="interleaved")   # rows 0,2,.. / 1,3,..
 
 
 def test_all_gather_tile_rows_world3_uneven():
-    _run(3, 80, 32)   # 5 tile rows over 3 ranks: 2 + 2 + 1
+    _run(3, 80, 32)   # 5 tile rows over 3 ranks: 1 + 2 + 2
+
+
+def test_all_gather_tile_rows_world3_weighted_bands_with_an_empty_band():
+    _run(3, 80, 32, weights=[0.0, 0.0, 10.0, 0.5, 0.5])   # bands [0,3) [3,3) [3,5): rank 1 owns nothing
 
 
 def test_owned_rows_partition():
-    from taichi_3d_gaussian_splatting_amd.distributed import owned_tile_rows
+    from taichi_3d_gaussian_splatting_amd.distributed import band_boundaries, owned_tile_rows
     for th in (1, 5, 67):
         for world in (1, 2, 4, 8):
-            got = sorted(r for g in range(world) for r in owned_tile_rows(th, g, world))
-            assert got == list(range(th))
+            for mode in ("bands", "interleaved"):
+                got = sorted(r for g in range(world) for r in owned_tile_rows(th, g, world, mode))
+                assert got == list(range(th))
+    # K-balanced bands: boundaries follow the weights, stay a partition, are contiguous
+    w = [1.0] * 10 + [9.0] * 10 + [1.0] * 47
+    b = band_boundaries(67, 4, w)
+    assert b[0] == 0 and b[-1] == 67 and b == sorted(b)
+    loads = [sum(w[b[g]:b[g + 1]]) for g in range(4)]
+    assert max(loads) <= 1.35 * sum(w) / 4
+    assert band_boundaries(67, 8) == [(g * 67) // 8 for g in range(9)]
+    assert band_boundaries(5, 3, [0.0, 0.0, 10.0, 0.5, 0.5]) == [0, 3, 3, 5]   # the heavy row fills two shares

@@ -1,6 +1,6 @@
 """Tile-row sharding with REAL ranks on the device: two (and three) processes share the box's single GPU and talk
 through gloo (RCCL refuses two ranks on one device; the RCCL call path itself is covered by the world-size-1 test in
-test_hip_parity.py).  Every rank renders only its interleaved tile rows with the HIP kernels, the collectives of
+test_hip_parity.py).  Every rank renders only its band of tile rows (or its interleaved rows) with the HIP kernels, the collectives of
 ``distributed.py`` assemble image / depth / count and sum the backward accumulators, and every rank must end with
 the image and the dense gradients of the un-sharded operator -- bit for bit for everything that is not a sum over
 ranks, and to fp32 summation-order noise for the gradients of Gaussians that straddle rows of different ranks."""
@@ -21,7 +21,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, n, height, width):
+def _worker(rank, world, port, n, height, width, mode):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -39,8 +39,13 @@ def _worker(rank, world, port, n, height, width):
             op = Op(Op.GaussianPointCloudRasterisationConfig(),
                     backward_valid_point_hook=lambda h: hooks.__setitem__(sharded, h))
             if sharded:
-                shard_rasteriser_across_tile_rows(op)
-                assert (op.tile_row_begin, op.tile_row_step) == (rank, world)
+                shard_rasteriser_across_tile_rows(op, mode=mode)
+                lay = op.list_layout(height)
+                th = height // 16
+                if mode == "interleaved":
+                    assert (lay.row_begin, lay.row_step) == (rank, world)
+                else:
+                    assert (lay.row_begin, lay.row_step, lay.row_end) == ((rank * th) // world, 1, ((rank + 1) * th) // world)
             image, depth, count = op(Op.GaussianPointCloudRasterisationInput(
                 point_cloud=xyz, point_cloud_features=feat, point_object_id=s.point_object_id,
                 point_invalid_mask=s.point_invalid_mask,
@@ -71,9 +76,9 @@ def _worker(rank, world, port, n, height, width):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,height", [(2, 144), (3, 80)])
-def test_sharded_operator_with_real_ranks(world, height):
-    mp.spawn(_worker, args=(world, _free_port(), 6000, height, 160), nprocs=world, join=True)
+@pytest.mark.parametrize("world,height,mode", [(2, 144, "bands"), (3, 80, "bands"), (2, 144, "interleaved")])
+def test_sharded_operator_with_real_ranks(world, height, mode):
+    mp.spawn(_worker, args=(world, _free_port(), 6000, height, 160, mode), nprocs=world, join=True)
 
 
 def _train_worker(rank, world, port, root):
@@ -93,7 +98,7 @@ def _train_worker(rank, world, port, root):
         cfg.gaussian_point_cloud_scene_config.max_num_points_ratio = 2.0
         cfg.gaussian_point_cloud_scene_config.initial_alpha = 0.5
         trainer = TRN(cfg)
-        assert trainer.rasterisation.tile_row_step == world and trainer.rasterisation.tile_row_begin == rank
+        assert trainer.rasterisation.shard == (rank, world, "bands")
         n_before = int((trainer.scene.point_invalid_mask == 0).sum())
         trainer.train()
         live = trainer.scene.point_invalid_mask == 0

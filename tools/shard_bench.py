@@ -2,10 +2,12 @@ import os, sys, time, torch
 sys.path.insert(0, os.getcwd())
 from taichi_3d_gaussian_splatting_amd import CameraInfo, GaussianPointCloudRasterisation as Op
 from taichi_3d_gaussian_splatting_amd.synthetic import make_config_scene, make_grad_image
-s = make_config_scene("headline_1m_1080p").to("cuda"); g = make_grad_image(s.height, s.width).to("cuda")
+s = make_config_scene(sys.argv[1] if len(sys.argv) > 1 else "headline_1m_1080p").to("cuda"); g = make_grad_image(s.height, s.width).to("cuda")
+MODE = os.environ.get("GS_SHARD_MODE", "bands")
+RANK = int(os.environ.get("GS_SHARD_RANK", "-1"))   # -1: the middle band (the heaviest one under perspective)
 for G in (1, 2, 4, 8):
     op = Op(Op.GaussianPointCloudRasterisationConfig())
-    op.tile_row_begin, op.tile_row_step = 0, G
+    op.shard = (G // 2 if RANK < 0 else min(RANK, G - 1), G, MODE)
     xyz = s.point_cloud.clone().requires_grad_(True); feat = s.point_cloud_features.clone().requires_grad_(True)
     inp = Op.GaussianPointCloudRasterisationInput(point_cloud=xyz, point_cloud_features=feat, point_object_id=s.point_object_id,
         point_invalid_mask=s.point_invalid_mask, camera_info=CameraInfo(s.camera_intrinsics, s.height, s.width, 0),
@@ -17,4 +19,4 @@ for G in (1, 2, 4, 8):
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(20): step()
     torch.cuda.synchronize()
-    print(f"G={G}: rank-0 compute per step (no collectives) {(time.perf_counter()-t0)/20*1e3:.3f} ms")
+    print(f"G={G} {MODE} rank {op.shard[0]}: compute per step (no collectives) {(time.perf_counter()-t0)/20*1e3:.3f} ms")
