@@ -6,23 +6,35 @@
         --master-port P bench.py --gpus N --steps K --warmup W
 
 A "step" is one forward + backward pass of the drop-in operator over one synthetic frame with the
-inputs already resident in HBM.  Default workload = the configuration BASELINE.json's metric is
-quoted on: 1e6 random-init Gaussians, 1920x1080 -> rendered at 1920x1072 (the reference asserts
-H % 16 == 0 and its data path crops, RAS:1193-1194, ImagePoseDataset.py:86-88), SH degree 3.
-N > 1: the same frame is sharded over interleaved 16-pixel tile rows (one process per GPU,
+inputs already resident in HBM, INCLUDING the backward hook every training iteration installs (a
+no-op consumer: the operator still produces the hook's compact copies; --no-hook removes it).
+Default workload = the configuration BASELINE.json's metric is quoted on: 1e6 random-init Gaussians,
+1920x1080 -> rendered at 1920x1072 (the reference asserts H % 16 == 0 and its data path crops,
+RAS:1193-1194, ImagePoseDataset.py:86-88), SH degree 3.
+N > 1: the same frame is sharded over contiguous bands of 16-pixel tile rows (one process per GPU,
 RCCL all-gather of the rendered rows + all-reduce of the per-Gaussian gradient accumulators), so the
 scaling is STRONG: total work is fixed, value = frame pixels / max-over-ranks step time.
 
 Rank 0 prints ONE JSON line.  Besides the contract fields it carries
-  roofline     : achieved algorithmic HBM GB/s of the dominant kernel vs the 8 TB/s peak, measured
-                 live with HIP events on the launch stream (plus all stage times and the whole-path figure)
+  step_ms      : per-step GPU time from HIP events on the launch stream: median, p90, min (ms_per_step stays the
+                 wall-clock mean over the K steps between two barriers + synchronisations)
+  roofline     : achieved algorithmic HBM GB/s of the dominant kernel vs the 8 TB/s peak, measured live with HIP
+                 events on the launch stream (plus all stage times and the whole-path figure); `traffic` = PMC HBM
+                 bytes per launch from the committed profile -- only while the kernel sources are the profiled ones
+                 (hash recorded next to the profile), else null; `valu` = the VALU-issue view of the same kernel
+                 (the blend kernels are bound by VALU issue, not HBM: DESIGN.md section 5)
   cpu_baseline : the CPU oracle (a from-source port of the reference kernels; the reference itself
                  cannot run here -- taichi is absent and its kernels are CUDA-only) timed on this
                  box's host cores on one full frame of the same workload.
+
+Other lines (not the driver's): --forward-only (inference: no_grad, with --rgb-only the reference's rgb_only
+configuration; metric "rendered Mpixels/s (fwd)"), --workload {cfg1_10k_256, cfg2_100k_800, cfg3_400k_1080p,
+cfg4_2m_1080p, stress_t_ras}.
 """
 from __future__ import annotations
 
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -35,6 +47,9 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+# VALU issue ceiling: 256 CUs x 4 SIMD-32, one wave64 fp32 instruction per 2 cycles per SIMD at 2.4 GHz
+VALU_PEAK_WAVE_INSTR_PER_S = 256 * 4 * 2.4e9 / 2.0
+PROFILE_TAG = "r02"
 
 
 def algorithmic_bytes(n, m, k, p, key_bytes=8):
@@ -56,30 +71,60 @@ def algorithmic_bytes(n, m, k, p, key_bytes=8):
     }
 
 
-def profiled_traffic_bytes(kernel: str):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC summary (profiles/r01_hbm_traffic.csv:
-    separate --pmc FETCH_SIZE / WRITE_SIZE passes over this same command, tools/profile.sh), with the gfx950
-    correction of the MI355X guide (FETCH_SIZE counts 128-B requests as 64 B -> doubled).  None if absent."""
-    path = os.path.join(ROOT, "profiles", "r01_hbm_traffic.csv")
+def kernel_source_hash() -> str:
+    """sha256 over the HIP sources (the profile summaries record the hash they were taken with)."""
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, "taichi_3d_gaussian_splatting_amd", "csrc")
+    for name in sorted(os.listdir(csrc)):
+        if name.endswith((".hip", ".h")):
+            with open(os.path.join(csrc, name), "rb") as fh:
+                h.update(name.encode() + b"\0" + fh.read())
+    return h.hexdigest()[:16]
+
+
+def profiled_counters(kernel: str):
+    """(HBM bytes per launch, VALU wave-instructions per launch) of `kernel` from the committed rocprofv3 PMC
+    summaries (profiles/<tag>_hbm_traffic.csv: separate --pmc FETCH_SIZE / WRITE_SIZE passes over this same command,
+    tools/profile.sh, with the gfx950 correction of the MI355X guide -- FETCH_SIZE counts 128-B requests as 64 B ->
+    doubled; profiles/<tag>_sq_counters.csv: SQ_INSTS_VALU).  (None, None) when the profile is absent or was taken
+    with other kernel sources than the ones in the tree (profiles/<tag>_source_hash.txt)."""
     try:
-        import csv
-        with open(path) as fh:
+        with open(os.path.join(ROOT, "profiles", f"{PROFILE_TAG}_source_hash.txt")) as fh:
+            if fh.read().split()[0] != kernel_source_hash():
+                return None, None
+    except (OSError, IndexError):
+        return None, None
+    import csv
+    traffic = valu = None
+    try:
+        with open(os.path.join(ROOT, "profiles", f"{PROFILE_TAG}_hbm_traffic.csv")) as fh:
             for row in csv.DictReader(fh):
-                if row[""] == kernel + "_kernel":
-                    return int((float(row["hbm_read_MB_gfx950_corrected"]) + float(row["hbm_write_MB"])) * 1e6)
+                if row[""].startswith(kernel + "_kernel"):
+                    traffic = int((float(row["hbm_read_MB_gfx950_corrected"]) + float(row["hbm_write_MB"])) * 1e6)
     except (OSError, KeyError, ValueError):
         pass
-    return None
+    try:
+        with open(os.path.join(ROOT, "profiles", f"{PROFILE_TAG}_sq_counters.csv")) as fh:
+            for row in csv.DictReader(fh):
+                if row["kernel"].startswith(kernel + "_kernel"):
+                    valu = float(row["SQ_INSTS_VALU"])
+    except (OSError, KeyError, ValueError):
+        pass
+    return traffic, valu
 
 
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="headline_1m_1080p")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-stage-profile", action="store_true")
+    ap.add_argument("--no-hook", action="store_true", help="time the backward without a backward hook")
+    ap.add_argument("--forward-only", action="store_true", help="inference line: forward under no_grad")
+    ap.add_argument("--rgb-only", action="store_true", help="with --forward-only: the reference's rgb_only config")
+    ap.add_argument("--shard-mode", default="bands", choices=["bands", "interleaved"])
     args = ap.parse_args()
 
     import torch.distributed as dist
@@ -114,10 +159,13 @@ def main() -> None:
     s = host_scene.to(device)
     grad_image = make_grad_image(s.height, s.width).to(device)
     cfg = Op.GaussianPointCloudRasterisationConfig(near_plane=s.near_plane, far_plane=s.far_plane,
-                                                   depth_to_sort_key_scale=s.depth_to_sort_key_scale)
-    op = Op(cfg)
+                                                   depth_to_sort_key_scale=s.depth_to_sort_key_scale,
+                                                   rgb_only=bool(args.rgb_only and args.forward_only))
+    hook_calls = []
+    hook = None if (args.no_hook or args.forward_only) else (lambda h: hook_calls.append(1))
+    op = Op(cfg, backward_valid_point_hook=hook)
     if world > 1:
-        shard_rasteriser_across_tile_rows(op)
+        shard_rasteriser_across_tile_rows(op, mode=args.shard_mode)
     xyz = s.point_cloud.clone().requires_grad_(True)
     feat = s.point_cloud_features.clone().requires_grad_(True)
     cam = CameraInfo(camera_intrinsics=s.camera_intrinsics, camera_height=s.height, camera_width=s.width, camera_id=0)
@@ -127,6 +175,9 @@ def main() -> None:
         t_pointcloud_camera=s.t_pointcloud_camera, color_max_sh_band=3)
 
     def step():
+        if args.forward_only:
+            with torch.no_grad():
+                return op(inp)[0]
         xyz.grad = None
         feat.grad = None
         image, depth, count = op(inp)
@@ -141,9 +192,12 @@ def main() -> None:
     for _ in range(args.warmup):
         step()
     fence()
+    events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for a, b in events:      # events on torch's current stream = the stream every kernel is launched on
+        a.record()
         step()
+        b.record()
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -151,6 +205,9 @@ def main() -> None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     ms_per_step = 1e3 * elapsed / args.steps
+    per_step = sorted(a.elapsed_time(b) for a, b in events)
+    step_ms = {"median": round(per_step[len(per_step) // 2], 4),
+               "p90": round(per_step[int(0.9 * (len(per_step) - 1))], 4), "min": round(per_step[0], 4)}
     pixels = s.height * s.width
     value = pixels / 1e6 / (ms_per_step / 1e3)
 
@@ -159,8 +216,8 @@ def main() -> None:
     roofline, stages_ms, sizes = None, {}, {}
     if not args.no_stage_profile:
         layout = op.list_layout(s.height)
-        ev = lambda: torch.cuda.Event(enable_timing=True)  # noqa: E731  (events on torch's current stream,
-        reps = max(3, min(args.steps, 10))                 #  the stream every kernel is launched on)
+        ev = lambda: torch.cuda.Event(enable_timing=True)  # noqa: E731
+        reps = max(3, min(args.steps, 10))
         acc_ms = {}
 
         def timed(name, fn):
@@ -171,7 +228,6 @@ def main() -> None:
             acc_ms.setdefault(name, []).append((a, b))
             return out
 
-        num_tiles = (s.width // 16) * (s.height // 16)
         num_bins = layout.num_bins(s.width, s.height)
         kdb, db, tb = hip_ops.key_layout(s.near_plane, s.far_plane, s.depth_to_sort_key_scale, num_bins)
         q_cp, t_cp = hip_ops.pose_inverse(s.q_pointcloud_camera, s.t_pointcloud_camera)
@@ -197,10 +253,13 @@ def main() -> None:
             timed("point_backward", lambda: hip_ops.point_backward(
                 s.point_cloud, f, s.point_object_id, s.camera_intrinsics, q_cp, t_cp, s.t_pointcloud_camera, ids,
                 acc, attrs, 3, cfg.grad_q_factor, cfg.grad_s_factor, cfg.grad_alpha_factor, cfg.grad_color_factor,
-                cfg.grad_high_order_color_factor, False, vmask, nowned))
+                cfg.grad_high_order_color_factor, hook is not None, vmask, nowned,
+                want_visible_features=hook is not None and op.hook_feature_gradients,
+                want_hook_fields=hook is not None))
         torch.cuda.synchronize()
         m = int(ids.shape[0])
-        sizes = {"N": n, "M": m, "K": int(k), "P": pixels, "tiles": num_tiles}
+        sizes = {"N": n, "M": m, "K": int(k), "P": pixels, "tiles": (s.width // 16) * (s.height // 16),
+                 "bin_shift": layout.bin_shift}
         stages_ms = {name: sum(a.elapsed_time(b) for a, b in pairs[1:]) / max(len(pairs) - 1, 1)
                      for name, pairs in acc_ms.items()}
         p_owned = pixels if world == 1 else pixels * len(layout.owned_rows(s.height)) / (s.height // 16)
@@ -208,22 +267,33 @@ def main() -> None:
         dominant = max(stages_ms, key=stages_ms.get)
         achieved = bytes_per[dominant] / (stages_ms[dominant] * 1e-3) / 1e9
         path_bytes = sum(bytes_per.values())
+        traffic, valu_instr = (None, None)
+        if world == 1 and args.workload == "headline_1m_1080p":
+            traffic, valu_instr = profiled_counters(dominant)
+        valu = None
+        if valu_instr is not None:
+            rate = valu_instr / (stages_ms[dominant] * 1e-3)
+            valu = {"wave_instructions_per_launch": valu_instr, "achieved_per_s": rate,
+                    "peak_per_s": VALU_PEAK_WAVE_INSTR_PER_S, "frac": round(rate / VALU_PEAK_WAVE_INSTR_PER_S, 4),
+                    "note": "peak = one plain fp32 wave64 instruction per 2 cycles per SIMD-32; packed, compare, DPP "
+                            "and transcendental instructions issue at 1/2 .. 1/4 of it (profiles/r02_pmc_blend.md)"}
         roofline = {
             "bound": "hbm", "kernel": dominant, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-            "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
-            "traffic": profiled_traffic_bytes(dominant) if world == 1 and args.workload == "headline_1m_1080p" else None,
+            "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
             "kernel_ms": round(stages_ms[dominant], 4),
             "algorithmic_bytes": int(bytes_per[dominant]),
+            "valu": valu,
             "path": {"algorithmic_bytes": int(path_bytes),
                      "achieved": round(path_bytes / (ms_per_step * 1e-3) / 1e9, 2),
                      "frac": round(path_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)},
             "stages_ms": {k_: round(v, 4) for k_, v in stages_ms.items()},
-            "note": "blend kernels are VALU/LDS/atomic-bound by construction (DESIGN.md section 5)",
+            "kernel_source_hash": kernel_source_hash(),
+            "note": "blend kernels are VALU-issue-bound by construction (DESIGN.md section 5)",
         }
 
     # ---------------------------------------------------------------- CPU baseline (rank 0, N == 1)
     cpu_baseline = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.forward_only:
         from oracle import gs_oracle as O
         O.build()
         hs = host_scene
@@ -239,19 +309,24 @@ def main() -> None:
             "value": round(pixels / 1e6 / (t2 - t0), 4), "unit": "Mpixels/s", "cores": O.num_threads(),
             "kind": "port",
             "sample": f"1 full frame of the same workload ({args.workload}): forward {t1 - t0:.2f} s + "
-                      f"backward {t2 - t1:.2f} s, OpenMP fp32 C oracle",
+                      f"backward {t2 - t1:.2f} s, OpenMP fp32 C oracle (tile-local accumulation, no atomics)",
             "host_cpus": os.cpu_count(),
         }
 
     if rank == 0:
+        what = "fwd" if args.forward_only else "fwd+bwd"
+        metric = (f"rendered Mpixels/s ({what}), 1e6 Gaussians @1920x1080" if args.workload == "headline_1m_1080p"
+                  else f"rendered Mpixels/s ({what}), {args.workload}")
         out = {
-            "metric": "rendered Mpixels/s (fwd+bwd), 1e6 Gaussians @1920x1080",
+            "metric": metric,
             "value": round(value, 3), "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": args.workload, "gaussians": n, "image": f"{s.width}x{s.height}",
-                       "sh_degree": 3, "sharding": "none" if world == 1 else f"tile-rows/{world}",
-                       **sizes},
+                       "sh_degree": 3, "sharding": "none" if world == 1 else f"tile-row {args.shard_mode}/{world}",
+                       "backward_hook": hook is not None, "forward_only": args.forward_only,
+                       "rgb_only": bool(cfg.rgb_only), "speculation": dict(op.speculation_stats), **sizes},
+            "step_ms": step_ms,
             "roofline": roofline, "cpu_baseline": cpu_baseline,
         }
         print(json.dumps(out), flush=True)

@@ -207,6 +207,7 @@ int gs_blend_backward(const int32_t *bin_start, const int32_t *payload, const fl
 int gs_reduce_partials(const int32_t *slot_offsets, const int32_t *num_overlap_tiles,
                        const uint8_t *slot_flags, const float *partials, int n_visible, float *acc,
                        const int32_t *num_keys /* may be NULL; num_keys[i] == 0: nothing to sum */,
+                       int64_t n_slots_hint /* total number of slots (picks the lanes-per-Gaussian variant; 0 = default) */,
                        void *stream);
 
 /* Backward per-point pass + gradient post-processing.  Replaces the per-point loop of

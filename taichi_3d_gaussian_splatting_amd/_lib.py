@@ -16,7 +16,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgsplat_hip.so")
-ABI_VERSION = 19
+ABI_VERSION = 20
 
 _c = ctypes
 _P = _c.c_void_p
@@ -42,7 +42,7 @@ _SIGNATURES = {
     "gs_read_counters_async": (_I, [_P, _P, _I, _P]),
     "gs_blend_forward": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _I, _P, _P]),
     "gs_blend_backward": (_I, [_P, _P, _P, _P, _P, _P, _P, _I64, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P]),
-    "gs_reduce_partials": (_I, [_P, _P, _P, _P, _I, _P, _P, _P]),
+    "gs_reduce_partials": (_I, [_P, _P, _P, _P, _I, _P, _P, _I64, _P]),
     "gs_loss_workspace_floats": (_c.c_longlong, [_I, _I]),
     "gs_loss_forward": (_I, [_P, _I, _I, _P, _I, _I, _F, _P, _P, _P, _P]),
     "gs_loss_backward": (_I, [_P, _I, _I, _P, _P, _I, _I, _F, _P, _P, _P, _P, _P]),

@@ -199,7 +199,7 @@ __global__ __launch_bounds__(BLEND_THREADS) void blend_forward_kernel(
     };
     auto store = [&](int slot, int j, int o, const float4 *r) {
         s_p[slot] = r[0]; s_c[slot] = r[2]; s_q[slot] = r[3];
-        s_j[slot] = j;
+        if (STAGED) s_j[slot] = j;
         if (DEBUG) s_o[slot] = o;
     };
 
@@ -208,6 +208,7 @@ __global__ __launch_bounds__(BLEND_THREADS) void blend_forward_kernel(
         // barrier (protects the staged batch) + whole-tile early exit vote
         if (__syncthreads_and((alive.x + alive.y == 0.f) ? 1 : 0)) break;
         int nbuf = 0;
+        const int batch_first = pos;   // direct path: staged entry k sits at list position batch_first + k
         if (STAGED)
             while (nbuf < BATCH && pos < end) gs_fill_step<+1>(payload, attrs, pos, end, nbuf, s_cnt, s_next, keep, store);
         else
@@ -265,7 +266,7 @@ __global__ __launch_bounds__(BLEND_THREADS) void blend_forward_kernel(
                 }
                 T = Tn;
                 if (STATE) {
-                    const int idx = s_j[k + i] + 1;
+                    const int idx = (STAGED ? s_j[k + i] : batch_first + k + i) + 1;
                     last0 = ok0 ? idx : last0;
                     last1 = ok1 ? idx : last1;
                 }
@@ -358,13 +359,15 @@ __global__ __launch_bounds__(BLEND_THREADS) void blend_backward_kernel(
     };
     auto store = [&](int slot_, int j, int o, const float4 *r) {
         s_p[slot_] = r[0]; s_b[slot_] = r[1]; s_c[slot_] = r[2]; s_q[slot_] = r[3];
-        s_j[slot_] = j; s_o[slot_] = o;
+        if (STAGED) s_j[slot_] = j;
+        s_o[slot_] = o;
     };
 
     int pos = end - 1;   // next list position to examine, walking down to `start`
     while (pos >= start) {
         __syncthreads();  // previous round fully flushed before its LDS is reused
         int nbuf = 0;
+        const int batch_first = pos;   // direct path: staged entry k sits at list position batch_first - k
         if (STAGED)
             while (nbuf < BATCH && pos >= start)
                 gs_fill_step<-1>(payload, attrs, pos, start, nbuf, s_cnt, s_next, keep, store);
@@ -384,7 +387,8 @@ __global__ __launch_bounds__(BLEND_THREADS) void blend_backward_kernel(
         }
         __syncthreads();
         for (int k = 0; k < nbuf; k += GROUP) {
-            if (s_j[k + GROUP - 1] >= wave_end) continue;  // descending positions: the whole group lies behind this wave's pixels
+            // descending positions: the whole group lies behind this wave's pixels
+            if ((STAGED ? s_j[k + GROUP - 1] : batch_first - (k + GROUP - 1)) >= wave_end) continue;
             // group evaluation: LDS reads + exp of GROUP entries are independent and overlap
             v2f alpha[GROUP], dx[GROUP];
             float dy[GROUP];
@@ -394,7 +398,7 @@ __global__ __launch_bounds__(BLEND_THREADS) void blend_backward_kernel(
             for (int i = 0; i < GROUP; ++i) {
                 const bool a0 = alpha[i].x >= EPS_ALPHA, a1 = alpha[i].y >= EPS_ALPHA;  // RAS:631, as RAS:451
                 if (gs_ballot(a0 || a1) == 0ull) continue;  // wave-uniform skip: no pixel of this wave is touched
-                const int jj = s_j[k + i];
+                const int jj = STAGED ? s_j[k + i] : batch_first - (k + i);
                 const bool hit0 = a0 && (jj < last0), hit1 = a1 && (jj < last1);  // RAS:618 (effective range)
                 if ((gs_ballot(hit0) | gs_ballot(hit1)) == 0ull) continue;
                 // alpha = 0 for a pixel that is not hit makes its whole update an exact no-op
@@ -497,11 +501,16 @@ __device__ __forceinline__ void rp_add_group(const uint8_t *__restrict__ flags, 
         a.npix += __builtin_bit_cast(int, p2.z);
     }
 }
+// LANES = 1: one lane per Gaussian (+ whole-wave help for the rare heavy one); LANES = 16: sixteen lanes (one DPP
+// row) per Gaussian, lane l taking the slot groups l, l + 16, ... -- chosen by the host when Gaussians own many slots
+// on average (a wave full of heavy Gaussians would otherwise serialise them).
+template <int LANES>
 __global__ __launch_bounds__(GS_BLOCK) void reduce_partials_kernel(
     const int32_t *__restrict__ slot_offsets, const int32_t *__restrict__ ntiles_full,
     const uint8_t *__restrict__ slot_flags, const float4 *__restrict__ partials, int m, float4 *__restrict__ acc,
     const int32_t *__restrict__ nkeys) {
-    const int i = blockIdx.x * GS_BLOCK + threadIdx.x, lane = gs_lane();
+    const int i = (int)(((long long)blockIdx.x * GS_BLOCK + threadIdx.x) / LANES), lane = gs_lane();
+    const int sub = threadIdx.x & (LANES - 1);
     const bool live = i < m;
     // a Gaussian that emitted no sort key on this GPU (tile-row sharding) was blended nowhere: no slot to look at
     const int base = live ? slot_offsets[i] : 0, n = live && (nkeys == nullptr || nkeys[i] > 0) ? ntiles_full[i] : 0;
@@ -509,27 +518,36 @@ __global__ __launch_bounds__(GS_BLOCK) void reduce_partials_kernel(
 #pragma unroll
     for (int k = 0; k < 10; ++k) a.v[k] = 0.f;
     a.npix = 0;
-    if (n <= RP_HEAVY)
-        for (int r0 = 0; r0 < n; r0 += 32) rp_add_group(slot_flags, partials, base + r0, min(32, n - r0), a);
-    unsigned long long heavy = __builtin_amdgcn_ballot_w64(n > RP_HEAVY);
-    while (heavy) {   // wave-uniform loop over the heavy Gaussians of this wave
-        const int L = __builtin_ctzll(heavy);
-        heavy &= heavy - 1;
-        const int bL = __builtin_amdgcn_readlane(base, L), nL = __builtin_amdgcn_readlane(n, L);
-        SlotSum h;
+    if (LANES > 1) {
+        for (int r0 = 4 * sub; r0 < n; r0 += 4 * LANES) rp_add_group(slot_flags, partials, base + r0, min(4, n - r0), a);
+        // the LANES lanes of a Gaussian are one DPP row: totals land in lane 15 of the row
 #pragma unroll
-        for (int k = 0; k < 10; ++k) h.v[k] = 0.f;
-        h.npix = 0;
-        for (int r0 = 4 * lane; r0 < nL; r0 += 4 * GS_WAVE) rp_add_group(slot_flags, partials, bL + r0, min(4, nL - r0), h);
+        for (int k = 0; k < 10; ++k) a.v[k] = gs_row_sum_to_lane15(a.v[k]);
+        a.npix = (int)gs_row_sum_to_lane15((float)a.npix);   // < 2^24: exact as a float
+    } else {
+        if (n <= RP_HEAVY)
+            for (int r0 = 0; r0 < n; r0 += 32) rp_add_group(slot_flags, partials, base + r0, min(32, n - r0), a);
+        unsigned long long heavy = __builtin_amdgcn_ballot_w64(n > RP_HEAVY);
+        while (heavy) {   // wave-uniform loop over the heavy Gaussians of this wave
+            const int L = __builtin_ctzll(heavy);
+            heavy &= heavy - 1;
+            const int bL = __builtin_amdgcn_readlane(base, L), nL = __builtin_amdgcn_readlane(n, L);
+            SlotSum h;
 #pragma unroll
-        for (int k = 0; k < 10; ++k) {
-            const float t = gs_readlane63(gs_wave_sum_to_lane63(h.v[k]));
-            if (lane == L) a.v[k] = t;
+            for (int k = 0; k < 10; ++k) h.v[k] = 0.f;
+            h.npix = 0;
+            for (int r0 = 4 * lane; r0 < nL; r0 += 4 * GS_WAVE)
+                rp_add_group(slot_flags, partials, bL + r0, min(4, nL - r0), h);
+#pragma unroll
+            for (int k = 0; k < 10; ++k) {
+                const float t = gs_readlane63(gs_wave_sum_to_lane63(h.v[k]));
+                if (lane == L) a.v[k] = t;
+            }
+            const float np = gs_readlane63(gs_wave_sum_to_lane63((float)h.npix));   // < 2^24: exact as a float
+            if (lane == L) a.npix = (int)np;
         }
-        const float np = gs_readlane63(gs_wave_sum_to_lane63((float)h.npix));   // < 2^24: exact as a float
-        if (lane == L) a.npix = (int)np;
     }
-    if (live) {
+    if (live && sub == LANES - 1) {
         acc[3 * (size_t)i] = make_float4(a.v[0], a.v[1], a.v[2], a.v[3]);
         acc[3 * (size_t)i + 1] = make_float4(a.v[4], a.v[5], a.v[6], a.v[7]);
         acc[3 * (size_t)i + 2] = make_float4(a.v[8], a.v[9], __builtin_bit_cast(float, a.npix), 0.f);
@@ -647,12 +665,18 @@ int gs_blend_backward(const int32_t *bin_start, const int32_t *payload, const fl
 }
 
 int gs_reduce_partials(const int32_t *slot_offsets, const int32_t *num_overlap_tiles, const uint8_t *slot_flags,
-                       const float *partials, int n_visible, float *acc, const int32_t *num_keys, void *stream) {
+                       const float *partials, int n_visible, float *acc, const int32_t *num_keys,
+                       int64_t n_slots_hint, void *stream) {
     GS_REQUIRE(n_visible >= 0, "n_visible");
     if (n_visible == 0) return 0;
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3(gs_div_up(n_visible, GS_BLOCK)), dim3(GS_BLOCK), 0,
-                       (hipStream_t)stream, slot_offsets, num_overlap_tiles, slot_flags,
-                       reinterpret_cast<const float4 *>(partials), n_visible, reinterpret_cast<float4 *>(acc), num_keys);
+    const float4 *p4 = reinterpret_cast<const float4 *>(partials);
+    float4 *a4 = reinterpret_cast<float4 *>(acc);
+    if (n_slots_hint > 32 * (int64_t)n_visible)   // many slots per Gaussian on average: sixteen lanes each
+        hipLaunchKernelGGL(reduce_partials_kernel<16>, dim3(gs_div_up(16LL * n_visible, GS_BLOCK)), dim3(GS_BLOCK), 0,
+                           (hipStream_t)stream, slot_offsets, num_overlap_tiles, slot_flags, p4, n_visible, a4, num_keys);
+    else
+        hipLaunchKernelGGL(reduce_partials_kernel<1>, dim3(gs_div_up(n_visible, GS_BLOCK)), dim3(GS_BLOCK), 0,
+                           (hipStream_t)stream, slot_offsets, num_overlap_tiles, slot_flags, p4, n_visible, a4, num_keys);
     GS_CHECK_LAUNCH();
     return 0;
 }

@@ -320,7 +320,7 @@ def reduce_partials(slot_offsets, num_overlap_tiles, flags, partials, num_keys=N
     m = slot_offsets.shape[0]
     acc = torch.empty((m, ACC_STRIDE), dtype=torch.float32, device=partials.device)
     call("gs_reduce_partials", ptr(slot_offsets), ptr(num_overlap_tiles), ptr(flags), ptr(partials), m, ptr(acc),
-         ptr(num_keys), current_stream(partials.device))
+         ptr(num_keys), int(partials.shape[0]), current_stream(partials.device))
     return acc
 
 

@@ -48,13 +48,27 @@ t["hbm_read_MB_gfx950_corrected"] = 2 * t["hbm_read_MB_raw"]
 t["hbm_write_MB"] = t["WRITE_SIZE"] * 1024 / 1e6
 t = t.sort_values("fetch_pass_mean_us", ascending=False)
 t.round(3).to_csv(os.path.join(dst, f"{name}_hbm_traffic.csv"))
+# SQ counters (tools/profile.sh fourth pass): mean per launch and kernel
+sq_path = os.path.join(src, "sq", "sq_counter_collection.csv")
+if os.path.exists(sq_path):
+    d = pd.read_csv(sq_path)
+    d["kernel"] = d.Kernel_Name.map(short)
+    sq = d.pivot_table(index="kernel", columns="Counter_Name", values="Counter_Value", aggfunc="mean")
+    sq["launches"] = d[d.Counter_Name == "SQ_WAVES"].groupby("kernel").size()
+    sq.round(1).to_csv(os.path.join(dst, f"{name}_sq_counters.csv"))
+    print(sq.round(0).to_string())
 bench = {}
-for pas in ("trace", "fetch", "write"):
+for pas in ("trace", "fetch", "write", "sq"):
     log = open(os.path.join(src, f"{pas}.log")).read()
     m = re.search(r'^\{"metric".*$', log, flags=re.M)
     if m:
         bench[pas] = json.loads(m.group(0))
 json.dump(bench, open(os.path.join(dst, f"{name}_bench_lines.json"), "w"), indent=1)
+# the kernel sources the profile was taken with (bench.py only quotes `traffic` / `valu` while they are the tree's)
+hashes = {b.get("roofline", {}).get("kernel_source_hash") for b in bench.values()}
+if len(hashes) == 1 and None not in hashes:
+    with open(os.path.join(dst, f"{name}_source_hash.txt"), "w") as fh:
+        fh.write(hashes.pop() + "  # sha256[:16] of csrc/*.hip,*.h at profile time (bench.py kernel_source_hash)\n")
 pd.set_option("display.width", 200)
 print(stats.head(14).to_string())
 print(t.round(2).head(14).to_string())
