@@ -262,10 +262,13 @@ class GaussianPointCloudRasterisation(torch.nn.Module):
                 fits = guess is not None and n_keys <= guess[0] and max_depth_key <= guess[1]
                 outer.speculation_stats["frames"] += 1
                 outer.speculation_stats["redone"] += 0 if (fits or guess is None) else 1
-                # capacities for the next frame: 25 % head-room over this frame, decaying slowly from the high-water mark;
-                # the depth range as the largest value with the same number of bits
+                # capacities for the next frame: 30 % head-room over this frame, decaying slowly (1 % per frame) from the
+                # high-water mark -- training alternates between views whose key counts differ; the depth range as the
+                # largest value with the same number of bits, never less than the previous bound while it still fits
                 depth_bound = (1 << max(int(max_depth_key), 1).bit_length()) - 1
-                outer._size_guess = (max(int(1.25 * n_keys) + 4096, int(0.95 * guess[0]) if guess else 0), depth_bound)
+                if guess is not None and depth_bound <= guess[1] <= 4 * depth_bound + 3:
+                    depth_bound = guess[1]
+                outer._size_guess = (max(int(1.3 * n_keys) + 4096, int(0.99 * guess[0]) if guess else 0), depth_bound)
                 outer._size_guess_key = guess_key
                 ids, attrs, num_overlap_tiles, num_owned_tiles = ids[:m], attrs[:m], num_overlap_tiles[:m], \
                     num_owned_tiles[:m]

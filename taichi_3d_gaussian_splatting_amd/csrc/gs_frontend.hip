@@ -7,6 +7,7 @@
 // discrete decisions derived from it (frustum test, depth quantisation, tile boxes) agree
 // bit-for-bit with the oracle.
 #include "gs_common.h"
+#include <stdlib.h>
 
 #pragma clang fp contract(off)
 
@@ -74,6 +75,8 @@ __device__ __forceinline__ int owned_rows(int lo, int hi, RowOwner ow) {
 // (RAS:81-103) in a tile row this GPU owns and (with the exact cull) the Gaussian can reach alpha >= 1/255 somewhere
 // on those tiles.  for_each_emitting_bin visits exactly those bins; gs_preprocess counts them, gs_make_keys writes them:
 // the same function on the same stored values, so count and keys agree.
+// (a) per-lane walk: every lane visits the bins of its own Gaussian.  Cheapest per pair (~45 instructions), but a wave
+//     waits for its largest box.
 template <typename Emit>
 __device__ __forceinline__ void for_each_emitting_bin(int t0u, int t1u, int t0v, int t1v, int bin_shift, RowOwner ow,
                                                       int cull, float ux, float uy, float A, float B, float C, float qmax,
@@ -97,6 +100,74 @@ __device__ __forceinline__ void for_each_emitting_bin(int t0u, int t1u, int t0v,
                 continue;
             emit(bu, bv);
         }
+    }
+}
+
+// (b) balanced walk.
+// A Gaussian's box holds 1 .. several thousand bins: a lane that walks its own box alone makes the other 63 lanes wait for
+// the largest box of the wave (measured: 2,700 VALU instructions per wave in gs_preprocess, most of them in this loop).
+// The walk is therefore BALANCED: the (bin, Gaussian) pairs of the 64 Gaussians of a wave are numbered consecutively --
+// Gaussians in lane order, a Gaussian's bins in the generation order of RAS:161-166 (tile_u outer, tile_v inner) -- and
+// dealt to the lanes 64 at a time.  gs_preprocess counts the surviving pairs per Gaussian, gs_make_keys writes them;
+// because surviving pairs are visited in exactly the order in which their keys are laid out, key generation becomes a
+// stream compaction with consecutive lanes writing consecutive keys (the per-lane loops scattered 8-B stores).
+struct BinWalkRec {           // one Gaussian, 64 B in LDS
+    float u, v, A, B;
+    float C, qmax, sx, sy;    // sx = -B/A, sy = -B/C: slopes of the conic's conjugate diameters (contribution test)
+    int t0u, t1u, t0v, t1v;   // tile box (RAS:81-103)
+    int b0u, b0v, nbv;        // first bin column / row of the walk, bin rows per column
+    unsigned magic;           // floor(2^32 / nbv) + 1: pair index -> (column, row) without an integer division
+};
+// -> number of (bin, Gaussian) pairs to visit.  Bin rows without a tile row of this GPU are left out up front when the
+// GPU owns a contiguous band (row_step 1), so that a Gaussian outside the band costs nothing.
+__device__ __forceinline__ int make_walk_rec(BinWalkRec &r, bool active, float u, float v, float A, float B, float C,
+                                             float qmax, int t0u, int t1u, int t0v, int t1v, int bin_shift, RowOwner ow) {
+    r.u = u; r.v = v; r.A = A; r.B = B; r.C = C; r.qmax = qmax;
+    r.sx = -B * __builtin_amdgcn_rcpf(A); r.sy = -B * __builtin_amdgcn_rcpf(C);
+    r.t0u = t0u; r.t1u = t1u; r.t0v = t0v; r.t1v = t1v;
+    int b0u = 0, b1u = 0, b0v = 0, b1v = 0;
+    if (active && t1u > t0u && t1v > t0v) {
+        b0u = t0u >> bin_shift; b1u = ((t1u - 1) >> bin_shift) + 1;
+        int v_lo = t0v, v_hi = t1v;
+        if (ow.step == 1) { v_lo = max(v_lo, ow.begin); v_hi = min(v_hi, ow.end); }
+        if (v_hi > v_lo) { b0v = v_lo >> bin_shift; b1v = ((v_hi - 1) >> bin_shift) + 1; }
+    }
+    r.b0u = b0u; r.b0v = b0v; r.nbv = b1v - b0v;
+    r.magic = r.nbv > 1 ? 0xffffffffu / (unsigned)r.nbv + 1u : 0u;
+    return (b1u - b0u) * (b1v - b0v);
+}
+// visit(owner_lane, bin_u, bin_v, survives) is called by every lane once per round of 64 pairs (wave-convergent, so that
+// it may use ballots); `survives` is false for the padding lanes of the last round.  recs: the 64 records of this wave.
+template <typename Visit>
+__device__ __forceinline__ void walk_bins_balanced(const BinWalkRec *__restrict__ recs, int npairs, int bin_shift,
+                                                   RowOwner ow, int cull, Visit visit) {
+    const int incl = gs_wave_incl_scan(npairs), excl = incl - npairs;
+    const int total = __builtin_amdgcn_readlane(incl, GS_WAVE - 1), lane = gs_lane();
+    for (int base = 0; base < total; base += GS_WAVE) {
+        const int q = base + lane;
+        const bool valid = q < total;
+        int owner = 0;   // number of lanes whose pairs all lie before q: binary search over the inclusive scan
+#pragma unroll
+        for (int step = GS_WAVE / 2; step > 0; step >>= 1)
+            if (__shfl(incl, owner + step - 1, GS_WAVE) <= q) owner += step;
+        owner = min(owner, GS_WAVE - 1);
+        const int p = q - __shfl(excl, owner, GS_WAVE);
+        const BinWalkRec r = recs[owner];
+        bool survives = false;
+        int bu = 0, bv = 0;
+        if (valid) {
+            const int col = r.nbv > 1 ? (int)__umulhi((unsigned)p, r.magic) : p;
+            bu = r.b0u + col;
+            bv = r.b0v + (p - col * r.nbv);
+            const int u_lo = max(r.t0u, bu << bin_shift), u_hi = min(r.t1u, (bu + 1) << bin_shift);   // box tiles in the bin
+            const int v_lo = max(r.t0v, bv << bin_shift), v_hi = min(r.t1v, (bv + 1) << bin_shift);
+            survives = owned_rows(v_lo, v_hi, ow) > 0;
+            if (survives && cull)
+                survives = gs_rect_may_contribute(r.u, r.v, r.A, r.B, r.C, r.sx, r.sy, r.qmax,
+                                                  (float)(u_lo * GS_TILE_WIDTH) + 0.5f, (float)(u_hi * GS_TILE_WIDTH) - 0.5f,
+                                                  (float)(v_lo * GS_TILE_HEIGHT) + 0.5f, (float)(v_hi * GS_TILE_HEIGHT) - 0.5f);
+        }
+        visit(owner, bu, bv, survives);
     }
 }
 
@@ -245,6 +316,7 @@ __global__ __launch_bounds__(GS_BLOCK) void compact_kernel(const int8_t *__restr
 // One lane per visible point; the 224-B feature row is read as 14 x 16-B loads (the lines are reused by
 // the 14 loads out of L1; measured: the kernel is bound by its ~2.7 k VALU instructions per wave -- IEEE
 // divisions, expf, the cull loop -- and an LDS-staged coalesced gather was 6 % slower: lower occupancy).
+template <bool BALANCED>
 __global__ __launch_bounds__(GS_BLOCK) void preprocess_kernel(
     const float *__restrict__ xyz, float *__restrict__ feat, const int32_t *__restrict__ obj,
     const float *__restrict__ Kmat, const float *__restrict__ q_cp, const float *__restrict__ t_cp,
@@ -253,14 +325,21 @@ __global__ __launch_bounds__(GS_BLOCK) void preprocess_kernel(
     int32_t *__restrict__ ntiles_full, int32_t *__restrict__ nkeys, int32_t *__restrict__ block_sums,
     int32_t *__restrict__ block_sums_full) {
     __shared__ int s_sum, s_sum_full, s_dq;
+    __shared__ BinWalkRec s_rec[BALANCED ? GS_BLOCK : 1];
+    __shared__ int s_cnt[BALANCED ? GS_BLOCK : 1];
     if (threadIdx.x == 0) { s_sum = 0; s_sum_full = 0; s_dq = 0; }
+    if (BALANCED) s_cnt[threadIdx.x] = 0;
     __syncthreads();
     // the number of visible points may still be on its way to the host: read it on the device
     const int m = use_device_count ? min(counters[GS_COUNTER_NUM_VISIBLE], m_capacity) : m_capacity;
     const int i = blockIdx.x * GS_BLOCK + threadIdx.x;
     int owned = 0, full = 0, dq = 0;
-    if (i < m) {
-        const int id = ids[i];
+    const bool live = i < m;
+    // quantities that outlive the geometry phase (the count phase below runs wave-convergent, outside any branch)
+    float u_ = 0.f, v_ = 0.f, z_ = 0.f, cA = 0.f, cB = 0.f, cC = 0.f, radius = 0.f, opacity = 0.f, amp = 0.f, qmax = 0.f;
+    int t0u = 0, t1u = 0, t0v = 0, t1v = 0, id = 0;
+    if (live) {
+        id = ids[i];
         float4 *row4 = reinterpret_cast<float4 *>(feat + (size_t)GS_FEATURE_DIM * id);
         // q, log-scale and the opacity logit now (32 B); the 192 B of SH coefficients only if this Gaussian emits a key on
         // this GPU (under tile-row sharding most visible Gaussians do not)
@@ -323,30 +402,48 @@ __global__ __launch_bounds__(GS_BLOCK) void preprocess_kernel(
         // RAS:311-315 radius from the un-filtered covariance
         float dd = cov[0] - cov[3];
         float lam = (cov[0] + cov[3] + sqrtf(dd * dd + 4.0f * cov[1] * cov[2])) / 2.0f;
-        float radius = sqrtf(lam) * 3.0f;
-        const float opacity = 1.f / (1.f + expf(-f[7]));  // RAS:299-300
-        const float cA = inv * cd, cB = inv * (-cov[1]), cC = inv * ca;
+        radius = sqrtf(lam) * 3.0f;
+        opacity = 1.f / (1.f + expf(-f[7]));  // RAS:299-300
+        cA = inv * cd; cB = inv * (-cov[1]); cC = inv * ca;
+        u_ = uv[0]; v_ = uv[1]; z_ = c[2];
 
-        int t0u, t1u, t0v, t1v;
         tile_box(uv[0], uv[1], radius, width / GS_TILE_WIDTH, height / GS_TILE_HEIGHT, t0u, t1u, t0v, t1v);
         full = (t1u - t0u) * (t1v - t0v);
         ntiles_full[i] = full;
         // the exact-cull bound of this Gaussian; +inf (never culled) when the cull is off.  Stored in the record: the
         // blend kernels apply the same test per tile.
-        const float amp = opacity * rescale;
-        const float qmax = cull ? gs_cull_qmax(amp) : __builtin_inff();
-        // number of sort keys = bins reached on this GPU
-        for_each_emitting_bin(t0u, t1u, t0v, t1v, bin_shift, ow, cull, uv[0], uv[1], cA, cB, cC, qmax,
-                              [&](int, int) { ++owned; });
-
+        amp = opacity * rescale;
+        qmax = cull ? gs_cull_qmax(amp) : __builtin_inff();
+    }
+    if (!BALANCED) {   // number of sort keys = bins reached on this GPU
+        if (live)
+            for_each_emitting_bin(t0u, t1u, t0v, t1v, bin_shift, ow, cull, u_, v_, cA, cB, cC, qmax,
+                                  [&](int, int) { ++owned; });
+    } else {   // the same count by the balanced walk over the wave's (bin, Gaussian) pairs
+        BinWalkRec *recs = s_rec + (threadIdx.x & ~(GS_WAVE - 1));
+        int *cnts = s_cnt + (threadIdx.x & ~(GS_WAVE - 1));
+        const int npairs = make_walk_rec(s_rec[threadIdx.x], live && full > 0, u_, v_, cA, cB, cC, qmax, t0u, t1u, t0v,
+                                         t1v, bin_shift, ow);
+        walk_bins_balanced(recs, npairs, bin_shift, ow, cull, [&](int owner, int, int, bool survives) {
+            if (survives) atomicAdd(&cnts[owner], 1);
+        });
+        __syncthreads();
+        owned = s_cnt[threadIdx.x];
+    }
+    if (live) {
         float4 *out = reinterpret_cast<float4 *>(attrs + (size_t)GS_ATTR_STRIDE * i);
-        out[0] = make_float4(uv[0], uv[1], c[2], qmax);  // always: the hook exposes uv and depth of every
-                                                         // visible point (RAS:1138-1139)
+        out[0] = make_float4(u_, v_, z_, qmax);  // always: the hook exposes uv and depth of every
+                                                 // visible point (RAS:1138-1139)
         if (owned > 0) {
             // Only Gaussians that emit at least one key on this GPU are ever gathered by the blend kernels:
             // the SH colour (the most expensive part) and the rest of the record are skipped otherwise
             // (tile-row sharding: most Gaussians touch the rows of only one or two of the G GPUs).
             // colour: RAS:280-282,302-310; ray origin = (-R^T) t (UTL:495-510)
+            const float4 *row4 = reinterpret_cast<const float4 *>(feat + (size_t)GS_FEATURE_DIM * id);
+            const int o = obj[id];
+            const Mat3 W = rotmat_from_q(q_cp[4 * o], q_cp[4 * o + 1], q_cp[4 * o + 2], q_cp[4 * o + 3]);
+            const float t[3] = {t_cp[3 * o], t_cp[3 * o + 1], t_cp[3 * o + 2]};
+            const float p[3] = {xyz[3 * (size_t)id], xyz[3 * (size_t)id + 1], xyz[3 * (size_t)id + 2]};
             float sh[48];
 #pragma unroll
             for (int k = 0; k < 12; ++k) {
@@ -394,7 +491,7 @@ __global__ __launch_bounds__(GS_BLOCK) void preprocess_kernel(
 // KeyT = uint64_t: reference layout (tile << 32) + int32 depth.  KeyT = uint32_t: compressed layout
 // (tile << key_depth_bits) | depth, used when the quantised depth is known to be non-negative and
 // tile and depth fit 32 bits together (same order, half the sort traffic).
-template <typename KeyT>
+template <typename KeyT, bool BALANCED>
 __global__ __launch_bounds__(GS_BLOCK) void make_keys_kernel(
     const float *__restrict__ attrs, const int32_t *__restrict__ nkeys,
     const int32_t *__restrict__ block_offsets, int m_capacity, const int32_t *__restrict__ counters,
@@ -403,6 +500,8 @@ __global__ __launch_bounds__(GS_BLOCK) void make_keys_kernel(
     const int32_t *__restrict__ ntiles_full, const int32_t *__restrict__ block_offsets_full,
     int32_t *__restrict__ slot_offsets) {
     __shared__ int lds[4];
+    __shared__ BinWalkRec s_rec[BALANCED ? GS_BLOCK : 1];
+    __shared__ int s_dq[BALANCED ? GS_BLOCK : 1];
     // sizes may still be on their way to the host: the visible count is read on the device, writes stop at the capacity
     const int m = counters ? min(counters[GS_COUNTER_NUM_VISIBLE], m_capacity) : m_capacity;
     const int i = blockIdx.x * GS_BLOCK + threadIdx.x;
@@ -414,27 +513,54 @@ __global__ __launch_bounds__(GS_BLOCK) void make_keys_kernel(
         const int so = block_offsets_full[blockIdx.x] + gs_block_excl_scan(full, &total, lds);
         if (i < m) slot_offsets[i] = so;
     }
-    if (i >= m || cnt == 0) return;
-    const float4 a0 = reinterpret_cast<const float4 *>(attrs + (size_t)GS_ATTR_STRIDE * i)[0];
-    const float4 a1 = reinterpret_cast<const float4 *>(attrs + (size_t)GS_ATTR_STRIDE * i)[1];
     const int tw = width / GS_TILE_WIDTH;
     const int bins_u = (tw + (1 << bin_shift) - 1) >> bin_shift;
-    int t0u, t1u, t0v, t1v;
-    tile_box(a0.x, a0.y, a1.w, tw, height / GS_TILE_HEIGHT, t0u, t1u, t0v, t1v);
-    const int32_t dq = (int32_t)(a0.z * depth_scale);  // truncation toward zero, RAS:159-160
-    int k = offset;
-    // the same walk on the same stored values as gs_preprocess: the two kernels agree on the count
-    for_each_emitting_bin(t0u, t1u, t0v, t1v, bin_shift, ow, cull, a0.x, a0.y, a1.x, a1.y, a1.z, a0.w,
-                          [&](int bu, int bv) {
-        const int32_t bin = bu + bv * bins_u;
-        if (k < n_keys_capacity) {   // (an overflowing frame is detected by the host from the counters and redone)
+    float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0;
+    int t0u = 0, t1u = 0, t0v = 0, t1v = 0;
+    if (cnt > 0) {
+        a0 = reinterpret_cast<const float4 *>(attrs + (size_t)GS_ATTR_STRIDE * i)[0];
+        a1 = reinterpret_cast<const float4 *>(attrs + (size_t)GS_ATTR_STRIDE * i)[1];
+        tile_box(a0.x, a0.y, a1.w, tw, height / GS_TILE_HEIGHT, t0u, t1u, t0v, t1v);
+    }
+    if (!BALANCED) {   // per-lane walk: every lane writes its own keys from its own offset
+        if (cnt == 0) return;
+        const int32_t dq = (int32_t)(a0.z * depth_scale);  // truncation toward zero, RAS:159-160
+        long long k = offset;
+        for_each_emitting_bin(t0u, t1u, t0v, t1v, bin_shift, ow, cull, a0.x, a0.y, a1.x, a1.y, a1.z, a0.w,
+                              [&](int bu, int bv) {
+            const int32_t bin = bu + bv * bins_u;
+            if (k < n_keys_capacity) {   // (an overflowing frame is detected by the host from the counters and redone)
+                if (sizeof(KeyT) == 8)
+                    keys[k] = (KeyT)((int64_t)dq + ((int64_t)bin << 32));
+                else
+                    keys[k] = (KeyT)(((uint32_t)bin << key_depth_bits) | (uint32_t)dq);
+                payload[k] = i;
+            }
+            ++k;
+        });
+        return;
+    }
+    // the same walk on the same stored values as gs_preprocess: both kernels agree on which pairs survive, and the
+    // survivors are met in the order of their keys -- the wave's first key sits at its lane 0's offset
+    BinWalkRec *recs = s_rec + (threadIdx.x & ~(GS_WAVE - 1));
+    int *dqs = s_dq + (threadIdx.x & ~(GS_WAVE - 1));
+    s_dq[threadIdx.x] = (int32_t)(a0.z * depth_scale);  // truncation toward zero, RAS:159-160
+    const int npairs = make_walk_rec(s_rec[threadIdx.x], cnt > 0, a0.x, a0.y, a1.x, a1.y, a1.z, a0.w, t0u, t1u, t0v, t1v,
+                                     bin_shift, ow);
+    long long next = __builtin_amdgcn_readfirstlane(offset);
+    const int first_point = blockIdx.x * GS_BLOCK + (threadIdx.x & ~(GS_WAVE - 1));
+    walk_bins_balanced(recs, npairs, bin_shift, ow, cull, [&](int owner, int bu, int bv, bool survives) {
+        const unsigned long long alive = __builtin_amdgcn_ballot_w64(survives);
+        const long long k = next + gs_mbcnt(alive);
+        if (survives && k < n_keys_capacity) {   // (an overflowing frame is detected by the host from the counters and redone)
+            const int32_t bin = bu + bv * bins_u, dq = dqs[owner];
             if (sizeof(KeyT) == 8)
                 keys[k] = (KeyT)((int64_t)dq + ((int64_t)bin << 32));
             else
                 keys[k] = (KeyT)(((uint32_t)bin << key_depth_bits) | (uint32_t)dq);
-            payload[k] = i;
+            payload[k] = first_point + owner;
         }
-        ++k;
+        next += __popcll(alive);
     });
 }
 
@@ -464,6 +590,13 @@ __global__ void tile_ranges_kernel(const KeyT *__restrict__ keys, long long n, c
 }
 
 }  // namespace
+
+// GS_BALANCED_WALK=1 selects the balanced (bin, Gaussian) walk in gs_preprocess / gs_make_keys (A/B switch; both walks
+// visit the same pairs in the same order, so every output is identical)
+static bool gs_balanced_walk() {
+    static const bool on = [] { const char *e = getenv("GS_BALANCED_WALK"); return e != nullptr && e[0] == '1'; }();
+    return on;
+}
 
 // =================================================================== C ABI
 extern "C" {
@@ -529,11 +662,18 @@ int gs_preprocess(const float *xyz, float *features, const int32_t *object_id, c
     GS_REQUIRE(width % GS_TILE_WIDTH == 0 && height % GS_TILE_HEIGHT == 0, "image size must be a multiple of 16");
     GS_REQUIRE(!n_visible_on_device || counters != nullptr, "device-side count needs counters");
     if (n_visible == 0) return 0;
-    hipLaunchKernelGGL(preprocess_kernel, dim3(gs_div_up(n_visible, GS_BLOCK)), dim3(GS_BLOCK), 0,
-                       (hipStream_t)stream, xyz, features, object_id, intrinsics, q_cp, t_cp, ids, n_visible,
-                       n_visible_on_device, width, height, RowOwner{tile_row_begin, tile_row_step, tile_row_end},
-                       bin_shift, exact_tile_cull, depth_scale, counters, attrs, num_overlap_tiles, num_keys,
-                       block_sums, block_sums_full);
+    const dim3 grid(gs_div_up(n_visible, GS_BLOCK)), block(GS_BLOCK);
+    const RowOwner ow{tile_row_begin, tile_row_step, tile_row_end};
+    if (gs_balanced_walk())
+        hipLaunchKernelGGL(preprocess_kernel<true>, grid, block, 0, (hipStream_t)stream, xyz, features, object_id,
+                           intrinsics, q_cp, t_cp, ids, n_visible, n_visible_on_device, width, height, ow, bin_shift,
+                           exact_tile_cull, depth_scale, counters, attrs, num_overlap_tiles, num_keys, block_sums,
+                           block_sums_full);
+    else
+        hipLaunchKernelGGL(preprocess_kernel<false>, grid, block, 0, (hipStream_t)stream, xyz, features, object_id,
+                           intrinsics, q_cp, t_cp, ids, n_visible, n_visible_on_device, width, height, ow, bin_shift,
+                           exact_tile_cull, depth_scale, counters, attrs, num_overlap_tiles, num_keys, block_sums,
+                           block_sums_full);
     GS_CHECK_LAUNCH();
     return 0;
 }
@@ -578,16 +718,15 @@ int gs_make_keys(const float *attrs, const int32_t *num_keys, const int32_t *blo
     if (n_visible == 0) return 0;
     const dim3 grid(gs_div_up(n_visible, GS_BLOCK)), block(GS_BLOCK);
     const RowOwner ow{tile_row_begin, tile_row_step, tile_row_end};
-    if (key_depth_bits == 0)
-        hipLaunchKernelGGL(make_keys_kernel<uint64_t>, grid, block, 0, (hipStream_t)stream, attrs, num_keys,
-                           block_offsets, n_visible, counters, (long long)n_keys_capacity, width, height, ow, bin_shift,
-                           exact_tile_cull, 0, depth_scale, (uint64_t *)keys, payload, num_overlap_tiles,
-                           block_offsets_full, slot_offsets);
-    else
-        hipLaunchKernelGGL(make_keys_kernel<uint32_t>, grid, block, 0, (hipStream_t)stream, attrs, num_keys,
-                           block_offsets, n_visible, counters, (long long)n_keys_capacity, width, height, ow, bin_shift,
-                           exact_tile_cull, key_depth_bits, depth_scale, (uint32_t *)keys, payload, num_overlap_tiles,
-                           block_offsets_full, slot_offsets);
+#define GS_KEYS(KeyT, BAL, KDB, PTR)                                                                               \
+    hipLaunchKernelGGL((make_keys_kernel<KeyT, BAL>), grid, block, 0, (hipStream_t)stream, attrs, num_keys,          \
+                       block_offsets, n_visible, counters, (long long)n_keys_capacity, width, height, ow, bin_shift, \
+                       exact_tile_cull, KDB, depth_scale, (KeyT *)PTR, payload, num_overlap_tiles,                   \
+                       block_offsets_full, slot_offsets)
+    const bool bal = gs_balanced_walk();
+    if (key_depth_bits == 0) { if (bal) GS_KEYS(uint64_t, true, 0, keys); else GS_KEYS(uint64_t, false, 0, keys); }
+    else { if (bal) GS_KEYS(uint32_t, true, key_depth_bits, keys); else GS_KEYS(uint32_t, false, key_depth_bits, keys); }
+#undef GS_KEYS
     GS_CHECK_LAUNCH();
     return 0;
 }

@@ -81,7 +81,8 @@ def make_config(tag, iterations):
         train_dataset_json_path=os.path.join(data, "train.json"), val_dataset_json_path=os.path.join(data, "val.json"),
         pointcloud_parquet_path=os.path.join(data, "points.parquet"), num_iterations=iterations + 1,
         val_interval=1000, log_loss_interval=10, log_metrics_interval=100, log_image_interval=10 ** 9,
-        log_validation_image=False, summary_writer_log_dir=os.path.join(out_dir, tag), num_data_loader_workers=0)
+        log_validation_image=False, summary_writer_log_dir=os.path.join(out_dir, tag), num_data_loader_workers=0,
+        output_model_dir=os.path.join(data, f"checkpoints_{tag}"))     # parquet checkpoints (19 MB each): scratch
     # everything else is the reference's default schedule (TRN:31-58, ADC:44-83): 4 -> 2 -> 1 down-sampling every 250
     # iterations, SH band + 1 every 1000, position lr decay 0.97 / 100, densify every 100 after 500, alpha reset 3000
     cfg.gaussian_point_cloud_scene_config.max_num_points_ratio = 8.0
