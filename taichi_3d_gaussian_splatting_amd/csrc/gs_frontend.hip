@@ -103,14 +103,13 @@ __device__ __forceinline__ void for_each_emitting_bin(int t0u, int t1u, int t0v,
     }
 }
 
-// (b) balanced walk.
-// A Gaussian's box holds 1 .. several thousand bins: a lane that walks its own box alone makes the other 63 lanes wait for
-// the largest box of the wave (measured: 2,700 VALU instructions per wave in gs_preprocess, most of them in this loop).
-// The walk is therefore BALANCED: the (bin, Gaussian) pairs of the 64 Gaussians of a wave are numbered consecutively --
-// Gaussians in lane order, a Gaussian's bins in the generation order of RAS:161-166 (tile_u outer, tile_v inner) -- and
-// dealt to the lanes 64 at a time.  gs_preprocess counts the surviving pairs per Gaussian, gs_make_keys writes them;
-// because surviving pairs are visited in exactly the order in which their keys are laid out, key generation becomes a
-// stream compaction with consecutive lanes writing consecutive keys (the per-lane loops scattered 8-B stores).
+// (b) balanced walk (gs_make_keys).  A Gaussian's box holds 1 .. several thousand bins: a lane that walks its own box
+// alone makes the other 63 lanes wait for the largest box of the wave, and writes its keys with scattered 8-B stores.
+// Here the (bin, Gaussian) pairs of the 64 Gaussians of a wave are numbered consecutively -- Gaussians in lane order, a
+// Gaussian's bins in the generation order of RAS:161-166 (tile_u outer, tile_v inner) -- and dealt to the lanes 64 at a
+// time.  Surviving pairs are then visited in exactly the order in which their keys are laid out, so key generation
+// becomes a stream compaction with consecutive lanes writing consecutive keys.  Both walks visit the same pairs in the
+// same order and take the same decisions.
 struct BinWalkRec {           // one Gaussian, 64 B in LDS
     float u, v, A, B;
     float C, qmax, sx, sy;    // sx = -B/A, sy = -B/C: slopes of the conic's conjugate diameters (contribution test)
@@ -316,7 +315,6 @@ __global__ __launch_bounds__(GS_BLOCK) void compact_kernel(const int8_t *__restr
 // One lane per visible point; the 224-B feature row is read as 14 x 16-B loads (the lines are reused by
 // the 14 loads out of L1; measured: the kernel is bound by its ~2.7 k VALU instructions per wave -- IEEE
 // divisions, expf, the cull loop -- and an LDS-staged coalesced gather was 6 % slower: lower occupancy).
-template <bool BALANCED>
 __global__ __launch_bounds__(GS_BLOCK) void preprocess_kernel(
     const float *__restrict__ xyz, float *__restrict__ feat, const int32_t *__restrict__ obj,
     const float *__restrict__ Kmat, const float *__restrict__ q_cp, const float *__restrict__ t_cp,
@@ -325,10 +323,7 @@ __global__ __launch_bounds__(GS_BLOCK) void preprocess_kernel(
     int32_t *__restrict__ ntiles_full, int32_t *__restrict__ nkeys, int32_t *__restrict__ block_sums,
     int32_t *__restrict__ block_sums_full) {
     __shared__ int s_sum, s_sum_full, s_dq;
-    __shared__ BinWalkRec s_rec[BALANCED ? GS_BLOCK : 1];
-    __shared__ int s_cnt[BALANCED ? GS_BLOCK : 1];
     if (threadIdx.x == 0) { s_sum = 0; s_sum_full = 0; s_dq = 0; }
-    if (BALANCED) s_cnt[threadIdx.x] = 0;
     __syncthreads();
     // the number of visible points may still be on its way to the host: read it on the device
     const int m = use_device_count ? min(counters[GS_COUNTER_NUM_VISIBLE], m_capacity) : m_capacity;
@@ -415,21 +410,12 @@ __global__ __launch_bounds__(GS_BLOCK) void preprocess_kernel(
         amp = opacity * rescale;
         qmax = cull ? gs_cull_qmax(amp) : __builtin_inff();
     }
-    if (!BALANCED) {   // number of sort keys = bins reached on this GPU
-        if (live)
-            for_each_emitting_bin(t0u, t1u, t0v, t1v, bin_shift, ow, cull, u_, v_, cA, cB, cC, qmax,
-                                  [&](int, int) { ++owned; });
-    } else {   // the same count by the balanced walk over the wave's (bin, Gaussian) pairs
-        BinWalkRec *recs = s_rec + (threadIdx.x & ~(GS_WAVE - 1));
-        int *cnts = s_cnt + (threadIdx.x & ~(GS_WAVE - 1));
-        const int npairs = make_walk_rec(s_rec[threadIdx.x], live && full > 0, u_, v_, cA, cB, cC, qmax, t0u, t1u, t0v,
-                                         t1v, bin_shift, ow);
-        walk_bins_balanced(recs, npairs, bin_shift, ow, cull, [&](int owner, int, int, bool survives) {
-            if (survives) atomicAdd(&cnts[owner], 1);
-        });
-        __syncthreads();
-        owned = s_cnt[threadIdx.x];
-    }
+    // number of sort keys = bins reached on this GPU.  (Per-lane walk: measured, the count is not what bounds this kernel --
+    // 0.139 ms with the exact cull, 0.144 without, 0.143 with the balanced walk of gs_make_keys; the IEEE divisions,
+    // expf and sqrtf of the projection chain are, and they have to stay: the tile boxes must match the reference's.)
+    if (live)
+        for_each_emitting_bin(t0u, t1u, t0v, t1v, bin_shift, ow, cull, u_, v_, cA, cB, cC, qmax,
+                              [&](int, int) { ++owned; });
     if (live) {
         float4 *out = reinterpret_cast<float4 *>(attrs + (size_t)GS_ATTR_STRIDE * i);
         out[0] = make_float4(u_, v_, z_, qmax);  // always: the hook exposes uv and depth of every
@@ -491,7 +477,7 @@ __global__ __launch_bounds__(GS_BLOCK) void preprocess_kernel(
 // KeyT = uint64_t: reference layout (tile << 32) + int32 depth.  KeyT = uint32_t: compressed layout
 // (tile << key_depth_bits) | depth, used when the quantised depth is known to be non-negative and
 // tile and depth fit 32 bits together (same order, half the sort traffic).
-template <typename KeyT, bool BALANCED>
+template <typename KeyT>
 __global__ __launch_bounds__(GS_BLOCK) void make_keys_kernel(
     const float *__restrict__ attrs, const int32_t *__restrict__ nkeys,
     const int32_t *__restrict__ block_offsets, int m_capacity, const int32_t *__restrict__ counters,
@@ -500,8 +486,8 @@ __global__ __launch_bounds__(GS_BLOCK) void make_keys_kernel(
     const int32_t *__restrict__ ntiles_full, const int32_t *__restrict__ block_offsets_full,
     int32_t *__restrict__ slot_offsets) {
     __shared__ int lds[4];
-    __shared__ BinWalkRec s_rec[BALANCED ? GS_BLOCK : 1];
-    __shared__ int s_dq[BALANCED ? GS_BLOCK : 1];
+    __shared__ BinWalkRec s_rec[GS_BLOCK];
+    __shared__ int s_dq[GS_BLOCK];
     // sizes may still be on their way to the host: the visible count is read on the device, writes stop at the capacity
     const int m = counters ? min(counters[GS_COUNTER_NUM_VISIBLE], m_capacity) : m_capacity;
     const int i = blockIdx.x * GS_BLOCK + threadIdx.x;
@@ -522,9 +508,20 @@ __global__ __launch_bounds__(GS_BLOCK) void make_keys_kernel(
         a1 = reinterpret_cast<const float4 *>(attrs + (size_t)GS_ATTR_STRIDE * i)[1];
         tile_box(a0.x, a0.y, a1.w, tw, height / GS_TILE_HEIGHT, t0u, t1u, t0v, t1v);
     }
-    if (!BALANCED) {   // per-lane walk: every lane writes its own keys from its own offset
+    // The same walk on the same stored values as gs_preprocess: both kernels agree on which pairs survive.  A wave of
+    // ordinary Gaussians (a few dozen bins each) deals its pairs to its lanes 64 at a time -- survivors are then met in
+    // the order of their keys, the wave's first key sits at its lane 0's offset, and consecutive lanes write consecutive
+    // keys (0.070 -> 0.056 ms at the headline size against one scattered-store loop per lane).  A wave that holds a
+    // Gaussian of more than 256 bins keeps the per-lane loop: the balanced walk costs ~2.5x per pair (owner search,
+    // record fetch) and such waves are uniform anyway (the reference's stress scene: 0.15 vs 0.34 ms).
+    BinWalkRec *recs = s_rec + (threadIdx.x & ~(GS_WAVE - 1));
+    int *dqs = s_dq + (threadIdx.x & ~(GS_WAVE - 1));
+    s_dq[threadIdx.x] = (int32_t)(a0.z * depth_scale);  // truncation toward zero, RAS:159-160
+    const int npairs = make_walk_rec(s_rec[threadIdx.x], cnt > 0, a0.x, a0.y, a1.x, a1.y, a1.z, a0.w, t0u, t1u, t0v, t1v,
+                                     bin_shift, ow);
+    if (__builtin_amdgcn_ballot_w64(npairs > 256) != 0ull) {   // per-lane walk: every lane writes its own keys from its own offset
         if (cnt == 0) return;
-        const int32_t dq = (int32_t)(a0.z * depth_scale);  // truncation toward zero, RAS:159-160
+        const int32_t dq = (int32_t)(a0.z * depth_scale);
         long long k = offset;
         for_each_emitting_bin(t0u, t1u, t0v, t1v, bin_shift, ow, cull, a0.x, a0.y, a1.x, a1.y, a1.z, a0.w,
                               [&](int bu, int bv) {
@@ -540,13 +537,6 @@ __global__ __launch_bounds__(GS_BLOCK) void make_keys_kernel(
         });
         return;
     }
-    // the same walk on the same stored values as gs_preprocess: both kernels agree on which pairs survive, and the
-    // survivors are met in the order of their keys -- the wave's first key sits at its lane 0's offset
-    BinWalkRec *recs = s_rec + (threadIdx.x & ~(GS_WAVE - 1));
-    int *dqs = s_dq + (threadIdx.x & ~(GS_WAVE - 1));
-    s_dq[threadIdx.x] = (int32_t)(a0.z * depth_scale);  // truncation toward zero, RAS:159-160
-    const int npairs = make_walk_rec(s_rec[threadIdx.x], cnt > 0, a0.x, a0.y, a1.x, a1.y, a1.z, a0.w, t0u, t1u, t0v, t1v,
-                                     bin_shift, ow);
     long long next = __builtin_amdgcn_readfirstlane(offset);
     const int first_point = blockIdx.x * GS_BLOCK + (threadIdx.x & ~(GS_WAVE - 1));
     walk_bins_balanced(recs, npairs, bin_shift, ow, cull, [&](int owner, int bu, int bv, bool survives) {
@@ -590,13 +580,6 @@ __global__ void tile_ranges_kernel(const KeyT *__restrict__ keys, long long n, c
 }
 
 }  // namespace
-
-// GS_BALANCED_WALK=1 selects the balanced (bin, Gaussian) walk in gs_preprocess / gs_make_keys (A/B switch; both walks
-// visit the same pairs in the same order, so every output is identical)
-static bool gs_balanced_walk() {
-    static const bool on = [] { const char *e = getenv("GS_BALANCED_WALK"); return e != nullptr && e[0] == '1'; }();
-    return on;
-}
 
 // =================================================================== C ABI
 extern "C" {
@@ -662,18 +645,11 @@ int gs_preprocess(const float *xyz, float *features, const int32_t *object_id, c
     GS_REQUIRE(width % GS_TILE_WIDTH == 0 && height % GS_TILE_HEIGHT == 0, "image size must be a multiple of 16");
     GS_REQUIRE(!n_visible_on_device || counters != nullptr, "device-side count needs counters");
     if (n_visible == 0) return 0;
-    const dim3 grid(gs_div_up(n_visible, GS_BLOCK)), block(GS_BLOCK);
-    const RowOwner ow{tile_row_begin, tile_row_step, tile_row_end};
-    if (gs_balanced_walk())
-        hipLaunchKernelGGL(preprocess_kernel<true>, grid, block, 0, (hipStream_t)stream, xyz, features, object_id,
-                           intrinsics, q_cp, t_cp, ids, n_visible, n_visible_on_device, width, height, ow, bin_shift,
-                           exact_tile_cull, depth_scale, counters, attrs, num_overlap_tiles, num_keys, block_sums,
-                           block_sums_full);
-    else
-        hipLaunchKernelGGL(preprocess_kernel<false>, grid, block, 0, (hipStream_t)stream, xyz, features, object_id,
-                           intrinsics, q_cp, t_cp, ids, n_visible, n_visible_on_device, width, height, ow, bin_shift,
-                           exact_tile_cull, depth_scale, counters, attrs, num_overlap_tiles, num_keys, block_sums,
-                           block_sums_full);
+    hipLaunchKernelGGL(preprocess_kernel, dim3(gs_div_up(n_visible, GS_BLOCK)), dim3(GS_BLOCK), 0,
+                       (hipStream_t)stream, xyz, features, object_id, intrinsics, q_cp, t_cp, ids, n_visible,
+                       n_visible_on_device, width, height, RowOwner{tile_row_begin, tile_row_step, tile_row_end},
+                       bin_shift, exact_tile_cull, depth_scale, counters, attrs, num_overlap_tiles, num_keys,
+                       block_sums, block_sums_full);
     GS_CHECK_LAUNCH();
     return 0;
 }
@@ -718,15 +694,16 @@ int gs_make_keys(const float *attrs, const int32_t *num_keys, const int32_t *blo
     if (n_visible == 0) return 0;
     const dim3 grid(gs_div_up(n_visible, GS_BLOCK)), block(GS_BLOCK);
     const RowOwner ow{tile_row_begin, tile_row_step, tile_row_end};
-#define GS_KEYS(KeyT, BAL, KDB, PTR)                                                                               \
-    hipLaunchKernelGGL((make_keys_kernel<KeyT, BAL>), grid, block, 0, (hipStream_t)stream, attrs, num_keys,          \
-                       block_offsets, n_visible, counters, (long long)n_keys_capacity, width, height, ow, bin_shift, \
-                       exact_tile_cull, KDB, depth_scale, (KeyT *)PTR, payload, num_overlap_tiles,                   \
-                       block_offsets_full, slot_offsets)
-    const bool bal = gs_balanced_walk();
-    if (key_depth_bits == 0) { if (bal) GS_KEYS(uint64_t, true, 0, keys); else GS_KEYS(uint64_t, false, 0, keys); }
-    else { if (bal) GS_KEYS(uint32_t, true, key_depth_bits, keys); else GS_KEYS(uint32_t, false, key_depth_bits, keys); }
-#undef GS_KEYS
+    if (key_depth_bits == 0)
+        hipLaunchKernelGGL(make_keys_kernel<uint64_t>, grid, block, 0, (hipStream_t)stream, attrs, num_keys,
+                           block_offsets, n_visible, counters, (long long)n_keys_capacity, width, height, ow, bin_shift,
+                           exact_tile_cull, 0, depth_scale, (uint64_t *)keys, payload, num_overlap_tiles,
+                           block_offsets_full, slot_offsets);
+    else
+        hipLaunchKernelGGL(make_keys_kernel<uint32_t>, grid, block, 0, (hipStream_t)stream, attrs, num_keys,
+                           block_offsets, n_visible, counters, (long long)n_keys_capacity, width, height, ow, bin_shift,
+                           exact_tile_cull, key_depth_bits, depth_scale, (uint32_t *)keys, payload, num_overlap_tiles,
+                           block_offsets_full, slot_offsets);
     GS_CHECK_LAUNCH();
     return 0;
 }

@@ -144,5 +144,5 @@ def test_bench_multi_rank_contract(tmp_path):
     assert len(lines) == 1, out.stdout[-2000:]
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == 2 and rec["steps"] == 3 and rec["warmup"] == 1 and rec["scaling"] == "strong"
-    assert rec["config"]["sharding"] == "tile-rows/2" and rec["value"] > 0 and rec["unit"] == "Mpixels/s"
+    assert rec["config"]["sharding"] == "tile-row bands/2" and rec["value"] > 0 and rec["unit"] == "Mpixels/s"
     assert rec["roofline"]["bound"] == "hbm" and 0 < rec["roofline"]["frac"] < 1
