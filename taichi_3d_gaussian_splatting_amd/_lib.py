@@ -15,7 +15,8 @@ from typing import Optional
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libgsplat_hip.so")
+# GS_LIB_PATH: development knob (tuning sweeps load differently built variants of the library); default = in-tree build
+LIB_PATH = os.environ.get("GS_LIB_PATH") or os.path.join(_HERE, "libgsplat_hip.so")
 ABI_VERSION = 20
 
 _c = ctypes

@@ -29,7 +29,19 @@ namespace {
 constexpr float EPS_ALPHA = (float)(1.0 / 255.0);  // RAS:451
 constexpr float CLAMP_ALPHA = 0.99f;               // RAS:453
 constexpr float STOP_T = 0.0001f;                  // RAS:458
-constexpr int GROUP = 4;  // list entries evaluated together in the blend loops (GS_BLOCK % GROUP == 0)
+#ifndef GS_GROUP_FWD
+#define GS_GROUP_FWD 4
+#endif
+#ifndef GS_GROUP_BWD
+#define GS_GROUP_BWD 4
+#endif
+#ifndef GS_BWD_MIN_WAVES
+#define GS_BWD_MIN_WAVES 1   // second argument of __launch_bounds__ (minimum waves per SIMD) of the backward kernel
+#endif
+constexpr int GROUP = GS_GROUP_FWD > GS_GROUP_BWD ? (GS_GROUP_FWD > 4 ? GS_GROUP_FWD : 4) : (GS_GROUP_BWD > 4 ? GS_GROUP_BWD : 4);
+                              // padding granularity of a staged batch (BATCH % GROUP == 0; covers both group sizes)
+constexpr int GROUP_FWD = GS_GROUP_FWD;  // list entries evaluated together in the forward blend loop
+constexpr int GROUP_BWD = GS_GROUP_BWD;  // ... in the backward loop
 
 struct TileCoord { int tile_u, tile_v, tile_id; };
 
@@ -223,12 +235,12 @@ __global__ __launch_bounds__(BLEND_THREADS) void blend_forward_kernel(
         __syncthreads();
         // Entries are evaluated in groups of GROUP: the LDS reads and the exp of a group are independent
         // and overlap (the per-pixel blend recurrence is the only serial part), which hides their latency.
-        for (int k = 0; k < nbuf; k += GROUP) {
+        for (int k = 0; k < nbuf; k += GROUP_FWD) {
             if (gs_ballot(alive.x + alive.y != 0.f) == 0ull) break;  // every pixel of this wave is saturated
-            v2f alpha[GROUP];
-            float z[GROUP];
+            v2f alpha[GROUP_FWD];
+            float z[GROUP_FWD];
 #pragma unroll
-            for (int i = 0; i < GROUP; ++i) {
+            for (int i = 0; i < GROUP_FWD; ++i) {
                 v2f dx;
                 float dy;
                 const float4 p = s_p[k + i];
@@ -236,7 +248,7 @@ __global__ __launch_bounds__(BLEND_THREADS) void blend_forward_kernel(
                 z[i] = p.z;
             }
 #pragma unroll
-            for (int i = 0; i < GROUP; ++i) {
+            for (int i = 0; i < GROUP_FWD; ++i) {
                 // a = alpha for a live pixel (x * 1.0f is exact), 0 for a saturated one
                 const v2f a = alpha[i] * alive;
                 bool ok0 = a.x >= EPS_ALPHA, ok1 = a.y >= EPS_ALPHA;  // RAS:451
@@ -308,7 +320,7 @@ __global__ __launch_bounds__(BLEND_THREADS) void blend_forward_kernel(
 // to 128 staged entries the two waves combine their partial sums in LDS (ds_add_f32), then thread k stores entry k's
 // 48-B record into its (Gaussian, tile) slot (plain stores).
 template <bool STAGED, bool DEBUG>
-__global__ __launch_bounds__(BLEND_THREADS) void blend_backward_kernel(
+__global__ __launch_bounds__(BLEND_THREADS, GS_BWD_MIN_WAVES) void blend_backward_kernel(
     const int32_t *__restrict__ bin_start, const int32_t *__restrict__ payload,
     const float4 *__restrict__ attrs, const float *__restrict__ grad_image, const float *__restrict__ acc_alpha,
     const int32_t *__restrict__ last_effective, int width, int height, int row_begin, int row_step, int bin_shift,
@@ -386,16 +398,16 @@ __global__ __launch_bounds__(BLEND_THREADS) void blend_backward_kernel(
             z[2] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
         __syncthreads();
-        for (int k = 0; k < nbuf; k += GROUP) {
+        for (int k = 0; k < nbuf; k += GROUP_BWD) {
             // descending positions: the whole group lies behind this wave's pixels
-            if ((STAGED ? s_j[k + GROUP - 1] : batch_first - (k + GROUP - 1)) >= wave_end) continue;
+            if ((STAGED ? s_j[k + GROUP_BWD - 1] : batch_first - (k + GROUP_BWD - 1)) >= wave_end) continue;
             // group evaluation: LDS reads + exp of GROUP entries are independent and overlap
-            v2f alpha[GROUP], dx[GROUP];
-            float dy[GROUP];
+            v2f alpha[GROUP_BWD], dx[GROUP_BWD];
+            float dy[GROUP_BWD];
 #pragma unroll
-            for (int i = 0; i < GROUP; ++i) alpha[i] = gs_pair_alpha(s_p[k + i], s_q[k + i], px, py, dx[i], dy[i]);
+            for (int i = 0; i < GROUP_BWD; ++i) alpha[i] = gs_pair_alpha(s_p[k + i], s_q[k + i], px, py, dx[i], dy[i]);
 #pragma unroll
-            for (int i = 0; i < GROUP; ++i) {
+            for (int i = 0; i < GROUP_BWD; ++i) {
                 const bool a0 = alpha[i].x >= EPS_ALPHA, a1 = alpha[i].y >= EPS_ALPHA;  // RAS:631, as RAS:451
                 if (gs_ballot(a0 || a1) == 0ull) continue;  // wave-uniform skip: no pixel of this wave is touched
                 const int jj = STAGED ? s_j[k + i] : batch_first - (k + i);

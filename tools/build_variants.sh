@@ -1,0 +1,20 @@
+#!/bin/bash
+# Builds differently tuned variants of libgsplat_hip.so into variants/ (development tool for tuning sweeps:
+# GS_LIB_PATH=variants/libgsplat_hip_<tag>.so python tools/stage_bench.py ...).  usage: tools/build_variants.sh "tag:-DFLAG=.. -DFLAG2=.." ...
+set -e
+ROOT=$(cd "$(dirname "$0")/.." && pwd)
+SRC=$ROOT/taichi_3d_gaussian_splatting_amd/csrc
+OUT=$ROOT/variants
+mkdir -p $OUT
+for spec in "$@"; do
+    tag=${spec%%:*}; flags=${spec#*:}
+    tmp=$(mktemp -d)
+    for f in gs_api gs_frontend gs_sort gs_blend gs_point_backward gs_controller gs_loss gs_optim; do
+        extra=""; [ $f = gs_blend ] && extra="$flags"
+        /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -fPIC -munsafe-fp-atomics -Wno-unused-function $extra -c $SRC/$f.hip -o $tmp/$f.o &
+    done
+    wait
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $tmp/*.o -o $OUT/libgsplat_hip_$tag.so
+    rm -rf $tmp
+    echo "built $tag ($flags)"
+done
