@@ -35,6 +35,9 @@ constexpr float STOP_T = 0.0001f;                  // RAS:458
 #ifndef GS_GROUP_BWD
 #define GS_GROUP_BWD 4
 #endif
+#ifndef GS_MFMA_REDUCE
+#define GS_MFMA_REDUCE 0     // 1: the backward's cross-lane sums go through the matrix pipe (gs_wave_reduce12_mfma)
+#endif
 #ifndef GS_BWD_MIN_WAVES
 #define GS_BWD_MIN_WAVES 1   // second argument of __launch_bounds__ (minimum waves per SIMD) of the backward kernel
 #endif
@@ -365,6 +368,9 @@ __global__ __launch_bounds__(BLEND_THREADS, GS_BWD_MIN_WAVES) void blend_backwar
     const int row = lane >> 4;
     const int slot = ((row & 1) << 1) | (row >> 1);  // rows (0,1,2,3) -> values (0,2,1,3) of each result register
     const bool row_tail = (lane & 15) == 15;
+#if GS_MFMA_REDUCE
+    const GsMfmaReduceConsts mfma_consts = gs_mfma_reduce_consts();
+#endif
 
     auto keep = [&](const float4 r0, const float4 r1) {
         return gs_entry_in_tile(r0, r1, tc.tile_u, tc.tile_v, tw, th, filter);
@@ -447,6 +453,13 @@ __global__ __launch_bounds__(BLEND_THREADS, GS_BWD_MIN_WAVES) void blend_backwar
                 }
                 // in-lane pair sums, then the 12-value reduce-scatter over the 64 lanes (gs_common.h); row totals
                 // land in lane 15 of each row: t0 (v0, c00, v1, c01)  t1 (c11, gg, gr, gb)  t2 (w, count, |v|, 0)
+#if GS_MFMA_REDUCE
+                // matrix-pipe variant: lane n (< 11) ends up with the wave total of value n
+                const float tot = gs_wave_reduce12_mfma(v0.x + v0.y, v1.x + v1.y, c00.x + c00.y, c01.x + c01.y,
+                                                        c11.x + c11.y, gr.x + gr.y, gg.x + gg.y, gb.x + gb.y,
+                                                        w.x + w.y, nv.x + nv.y, h.x + h.y, 0.f, mfma_consts);
+                if (lane < 11) atomicAdd(&s_acc[k + i][lane], tot);
+#else
                 float t0, t1, t2;
                 gs_wave_reduce12(v0.x + v0.y, v1.x + v1.y, c00.x + c00.y, c01.x + c01.y, c11.x + c11.y, gr.x + gr.y,
                                  gg.x + gg.y, gb.x + gb.y, w.x + w.y, nv.x + nv.y, h.x + h.y, 0.f, t0, t1, t2);
@@ -456,6 +469,7 @@ __global__ __launch_bounds__(BLEND_THREADS, GS_BWD_MIN_WAVES) void blend_backwar
                     atomicAdd(A + 4, t1);
                     atomicAdd(A + 8, t2);
                 }
+#endif
             }
         }
         __syncthreads();
