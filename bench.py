@@ -6,8 +6,10 @@
         --master-port P bench.py --gpus N --steps K --warmup W
 
 A "step" is one forward + backward pass of the drop-in operator over one synthetic frame with the
-inputs already resident in HBM, INCLUDING the backward hook every training iteration installs (a
-no-op consumer: the operator still produces the hook's compact copies; --no-hook removes it).
+inputs already resident in HBM, INCLUDING the backward hook every training iteration installs, as the
+trainer configures it between densifications (a no-op consumer; the operator produces the hook's nine compact
+M-indexed fields, the tenth -- the [M,56] copy of the feature gradients, which the trainer only asks for on the
+iteration of a densification -- with --hook-feature-copy; --no-hook removes the hook).
 Default workload = the configuration BASELINE.json's metric is quoted on: 1e6 random-init Gaussians,
 1920x1080 -> rendered at 1920x1072 (the reference asserts H % 16 == 0 and its data path crops,
 RAS:1193-1194, ImagePoseDataset.py:86-88), SH degree 3.
@@ -122,6 +124,8 @@ def main() -> None:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-stage-profile", action="store_true")
     ap.add_argument("--no-hook", action="store_true", help="time the backward without a backward hook")
+    ap.add_argument("--hook-feature-copy", action="store_true",
+                    help="the hook also receives the [M,56] compact copy of the feature gradients (RAS:1132)")
     ap.add_argument("--forward-only", action="store_true", help="inference line: forward under no_grad")
     ap.add_argument("--rgb-only", action="store_true", help="with --forward-only: the reference's rgb_only config")
     ap.add_argument("--shard-mode", default="bands", choices=["bands", "interleaved"])
@@ -164,6 +168,7 @@ def main() -> None:
     hook_calls = []
     hook = None if (args.no_hook or args.forward_only) else (lambda h: hook_calls.append(1))
     op = Op(cfg, backward_valid_point_hook=hook)
+    op.hook_feature_gradients = bool(args.hook_feature_copy)   # GaussianPointTrainer: only on densification iterations
     if world > 1:
         shard_rasteriser_across_tile_rows(op, mode=args.shard_mode)
     xyz = s.point_cloud.clone().requires_grad_(True)
@@ -192,12 +197,13 @@ def main() -> None:
     for _ in range(args.warmup):
         step()
     fence()
-    events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    # one event per step boundary on torch's current stream (= the stream every kernel is launched on)
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
-    for a, b in events:      # events on torch's current stream = the stream every kernel is launched on
-        a.record()
+    marks[0].record()
+    for i in range(args.steps):
         step()
-        b.record()
+        marks[i + 1].record()
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -205,7 +211,7 @@ def main() -> None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     ms_per_step = 1e3 * elapsed / args.steps
-    per_step = sorted(a.elapsed_time(b) for a, b in events)
+    per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
     step_ms = {"median": round(per_step[len(per_step) // 2], 4),
                "p90": round(per_step[int(0.9 * (len(per_step) - 1))], 4), "min": round(per_step[0], 4)}
     pixels = s.height * s.width
@@ -324,7 +330,8 @@ def main() -> None:
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": args.workload, "gaussians": n, "image": f"{s.width}x{s.height}",
                        "sh_degree": 3, "sharding": "none" if world == 1 else f"tile-row {args.shard_mode}/{world}",
-                       "backward_hook": hook is not None, "forward_only": args.forward_only,
+                       "backward_hook": hook is not None, "hook_feature_copy": bool(hook is not None and args.hook_feature_copy),
+                       "forward_only": args.forward_only,
                        "rgb_only": bool(cfg.rgb_only), "speculation": dict(op.speculation_stats), **sizes},
             "step_ms": step_ms,
             "roofline": roofline, "cpu_baseline": cpu_baseline,
