@@ -54,11 +54,13 @@ VALU_PEAK_WAVE_INSTR_PER_S = 256 * 4 * 2.4e9 / 2.0
 PROFILE_TAG = "r02"
 
 
-def algorithmic_bytes(n, m, k, p, key_bytes=8):
+def algorithmic_bytes(n, m, k, p, key_bytes=8, k_tile=None):
     """Compulsory HBM bytes per launch of each stage: every
-    stage input read once, every output written once; N points, M visible, K (tile,Gaussian) pairs
-    that are sorted and blended, P pixels; key_bytes = 4 (compressed keys) or 8 (reference layout)."""
+    stage input read once, every output written once; N points, M visible, K sort keys, k_tile (tile, Gaussian) pairs
+    that are blended (= K with per-tile keys; with binned lists fewer keys are sorted but the same pairs are
+    blended), P pixels; key_bytes = 4 (compressed keys) or 8 (reference layout)."""
     pair = key_bytes + 4
+    k_tile = k if k_tile is None else k_tile
     return {
         "filter_compact": 18 * n + 4 * m,
         "preprocess": 244 * m + 16 * m + 48 * m + 8 * m + 4 * m,   # row+xyz+ids+obj, q write, attrs, counts
@@ -66,8 +68,8 @@ def algorithmic_bytes(n, m, k, p, key_bytes=8):
         "make_keys": 32 * m + pair * k,
         "sort_pairs": 2 * pair * k,
         "tile_ranges": key_bytes * k,
-        "blend_forward": 48 * k + 28 * p,
-        "blend_backward": 44 * k + 28 * p + 48 * m,   # list re-gather, per-pixel in/out, one record per Gaussian
+        "blend_forward": 48 * k_tile + 28 * p,
+        "blend_backward": 44 * k_tile + 28 * p + 48 * m,   # list re-gather, per-pixel in/out, one record per Gaussian
         "reduce_partials": 48 * m + 8 * m,            # (the slot records themselves are blend_backward's output)
         "point_backward": 244 * m + 48 * m + 248 * n,
     }
@@ -264,12 +266,22 @@ def main() -> None:
                 want_hook_fields=hook is not None))
         torch.cuda.synchronize()
         m = int(ids.shape[0])
-        sizes = {"N": n, "M": m, "K": int(k), "P": pixels, "tiles": (s.width // 16) * (s.height // 16),
-                 "bin_shift": layout.bin_shift}
+        k_tile = int(k)
+        if layout.bin_shift:   # the (tile, Gaussian) pairs the blend kernels recover from the bin lists: count them once
+            import dataclasses
+            per_tile = dataclasses.replace(layout, bin_shift=0)
+            counters_t = torch.zeros_like(counters)
+            counters_t[hip_ops.COUNTER_NUM_VISIBLE] = m
+            _, _, _, bs_t, bsf_t = hip_ops.preprocess(
+                s.point_cloud, feat.detach(), s.point_object_id, s.camera_intrinsics, q_cp, t_cp, ids, s.width,
+                s.height, per_tile, s.depth_to_sort_key_scale, counters_t)
+            k_tile = int(hip_ops.scan_block_sums(bs_t, counters_t, bsf_t)[0])
+        sizes = {"N": n, "M": m, "K": int(k), "K_tile": k_tile, "P": pixels,
+                 "tiles": (s.width // 16) * (s.height // 16), "bin_shift": layout.bin_shift}
         stages_ms = {name: sum(a.elapsed_time(b) for a, b in pairs[1:]) / max(len(pairs) - 1, 1)
                      for name, pairs in acc_ms.items()}
         p_owned = pixels if world == 1 else pixels * len(layout.owned_rows(s.height)) / (s.height // 16)
-        bytes_per = algorithmic_bytes(n, m, int(k), p_owned, 4 if kdb > 0 else 8)
+        bytes_per = algorithmic_bytes(n, m, int(k), p_owned, 4 if kdb > 0 else 8, k_tile)
         dominant = max(stages_ms, key=stages_ms.get)
         achieved = bytes_per[dominant] / (stages_ms[dominant] * 1e-3) / 1e9
         path_bytes = sum(bytes_per.values())

@@ -157,9 +157,9 @@ class GaussianPointCloudRasterisation(torch.nn.Module):
         self.shard_row_weights = None
         # drop (bin | tile, Gaussian) pairs that cannot reach alpha >= 1/255 anywhere in the bin | tile (output-identical)
         self.exact_tile_cull = True
-        # sort keys per bin of (1 << bin_shift)^2 tiles: 0 = per tile as the reference (fastest when Gaussians cover few
-        # tiles), 2 = 64 x 64 pixels (the blend kernels recover each tile's list from its bin's list, in order; fastest
-        # when Gaussians cover many tiles), None = chosen per frame from the previous frame's tiles-per-Gaussian ratio
+        # sort keys per bin of (1 << bin_shift)^2 tiles: 0 = per tile as the reference (fastest on small frames), 1 = 32 x 32
+        # pixels, 2 = 64 x 64 pixels (the blend kernels recover each tile's list from its bin's list, in order; the more
+        # tiles a Gaussian covers the larger the bin that pays), None = chosen per frame from the previous frame's sizes
         self.bin_shift: Optional[int] = None
         self._auto_bin_shift = 0
         # launch the list stages from device-side counts with the previous frame's capacities instead of waiting for
@@ -256,9 +256,19 @@ class GaussianPointCloudRasterisation(torch.nn.Module):
                 if n_keys >= 0x7fffffff or n_slots >= 0x7fffffff:
                     raise RuntimeError("more than 2^31-1 (tile, Gaussian) pairs: key offsets are int32 as in the reference")
                 nb = (m + 255) // 256
-                # next frame's list layout: bins once a Gaussian covers >= 64 tiles on average (hysteresis: back at < 32)
+                # next frame's list layout, from this frame's sizes (with hysteresis): 4x4-tile bins once a Gaussian
+                # covers >= 64 tiles on average (the lists would be dominated by pairs that never blend); 2x2-tile bins
+                # once there are >= 3e6 (tile, Gaussian) pairs (key generation + three radix passes then cost more than
+                # the blend kernels pay for filtering twice as many list entries: -2.3 % at the headline size); per-tile
+                # keys, as the reference, otherwise (small frames: the filter costs more than the sort saves)
                 ratio = n_slots / max(m, 1)
-                outer._auto_bin_shift = 2 if ratio >= (32.0 if outer._auto_bin_shift else 64.0) else 0
+                previous = outer._auto_bin_shift
+                if ratio >= (32.0 if previous == 2 else 64.0):
+                    outer._auto_bin_shift = 2
+                elif n_slots >= (2_000_000 if previous == 1 else 3_000_000):
+                    outer._auto_bin_shift = 1
+                else:
+                    outer._auto_bin_shift = 0
                 fits = guess is not None and n_keys <= guess[0] and max_depth_key <= guess[1]
                 outer.speculation_stats["frames"] += 1
                 outer.speculation_stats["redone"] += 0 if (fits or guess is None) else 1

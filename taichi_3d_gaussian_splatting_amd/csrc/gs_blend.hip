@@ -109,7 +109,7 @@ constexpr unsigned GS_HASH_MUL = 2654435761u;
 // (ascending from `pos` when DIR = +1, descending from `pos` when DIR = -1, bounded by `limit`), keeps the entries that
 // belong to the tile and appends them IN LIST ORDER behind the `nbuf` entries already staged; at most BATCH - nbuf are
 // accepted and the walk resumes at the first entry that did not fit.  Returns through `pos` / `nbuf` (uniform).
-// keep(row0, row1) is the membership test; store(slot, j, o, rows) writes a kept entry to the kernel's LDS arrays.
+// keep(row0, row1) is the membership test; store(slot, j, o, row0..row3) writes a kept entry to the kernel's LDS arrays.
 // Two barriers per step.  s_cnt: int[4], s_next: int[1] in LDS.
 template <int DIR, typename Keep, typename Store>
 __device__ __forceinline__ void gs_fill_step(const int32_t *__restrict__ payload, const float4 *__restrict__ attrs,
@@ -145,7 +145,7 @@ __device__ __forceinline__ void gs_fill_step(const int32_t *__restrict__ payload
         const int c0 = s_cnt[2 * h], c1 = s_cnt[2 * h + 1];
         const int slot = before + (w ? c0 : 0) + gs_mbcnt(bal[h]);
         if (kept[h]) {
-            if (slot < BATCH) store(slot, j[h], o[h], r[h]);
+            if (slot < BATCH) store(slot, j[h], o[h], r[h][0], r[h][1], r[h][2], r[h][3]);
             else if (slot == BATCH) *s_next = j[h];   // first entry that does not fit: the walk resumes here
         }
         before += c0 + c1;
@@ -164,12 +164,14 @@ __device__ __forceinline__ void gs_direct_step(const int32_t *__restrict__ paylo
                                                int &pos, int limit, int &nbuf, Store store) {
     const int tid = threadIdx.x;
     const int j = pos + DIR * tid;
-    if (DIR > 0 ? j < limit : j >= limit) {
-        const int o = payload[j];
+    const bool valid = DIR > 0 ? j < limit : j >= limit;
+    const int o = valid ? payload[j] : 0;
+    float4 r0, r1, r2, r3;   // (scalars, not an array: an array handed to `store` by pointer ends up in scratch memory)
+    if (valid) {
         const float4 *g = attrs + 4 * (size_t)o;
-        const float4 r[4] = {g[0], g[1], g[2], g[3]};
-        store(tid, j, o, r);
+        r0 = g[0]; r1 = g[1]; r2 = g[2]; r3 = g[3];
     }
+    if (valid) store(tid, j, o, r0, r1, r2, r3);
     nbuf = min(BATCH, DIR > 0 ? limit - pos : pos - limit + 1);
     pos += DIR * BATCH;
 }
@@ -212,8 +214,8 @@ __global__ __launch_bounds__(BLEND_THREADS) void blend_forward_kernel(
     auto keep = [&](const float4 r0, const float4 r1) {
         return gs_entry_in_tile(r0, r1, tc.tile_u, tc.tile_v, tw, th, filter);
     };
-    auto store = [&](int slot, int j, int o, const float4 *r) {
-        s_p[slot] = r[0]; s_c[slot] = r[2]; s_q[slot] = r[3];
+    auto store = [&](int slot, int j, int o, const float4 r0, const float4, const float4 r2, const float4 r3) {
+        s_p[slot] = r0; s_c[slot] = r2; s_q[slot] = r3;
         if (STAGED) s_j[slot] = j;
         if (DEBUG) s_o[slot] = o;
     };
@@ -225,7 +227,8 @@ __global__ __launch_bounds__(BLEND_THREADS) void blend_forward_kernel(
         int nbuf = 0;
         const int batch_first = pos;   // direct path: staged entry k sits at list position batch_first + k
         if (STAGED)
-            while (nbuf < BATCH && pos < end) gs_fill_step<+1>(payload, attrs, pos, end, nbuf, s_cnt, s_next, keep, store);
+            while (nbuf < BATCH && pos < end)
+                gs_fill_step<+1>(payload, attrs, pos, end, nbuf, s_cnt, s_next, keep, store);
         else
             gs_direct_step<+1>(payload, attrs, pos, end, nbuf, store);
         {   // pad to a multiple of GROUP with inert records (amplitude 0 -> alpha 0, never blended)
@@ -375,8 +378,8 @@ __global__ __launch_bounds__(BLEND_THREADS, GS_BWD_MIN_WAVES) void blend_backwar
     auto keep = [&](const float4 r0, const float4 r1) {
         return gs_entry_in_tile(r0, r1, tc.tile_u, tc.tile_v, tw, th, filter);
     };
-    auto store = [&](int slot_, int j, int o, const float4 *r) {
-        s_p[slot_] = r[0]; s_b[slot_] = r[1]; s_c[slot_] = r[2]; s_q[slot_] = r[3];
+    auto store = [&](int slot_, int j, int o, const float4 r0, const float4 r1, const float4 r2, const float4 r3) {
+        s_p[slot_] = r0; s_b[slot_] = r1; s_c[slot_] = r2; s_q[slot_] = r3;
         if (STAGED) s_j[slot_] = j;
         s_o[slot_] = o;
     };
