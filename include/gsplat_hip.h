@@ -73,7 +73,9 @@ int gs_pose_inverse(const float *q_pointcloud_camera, const float *t_pointcloud_
 
 /* Frustum test + order-preserving stream compaction.  Replaces filter_point_in_camera
  * (RAS:31-78) and the mask -> index torch glue (RAS:841-870).
- * out: mask int8[N], ids int32[N] (first M valid, ascending), counters[GS_COUNTER_NUM_VISIBLE]=M. */
+ * out: mask int8[N], ids int32[N] (first M valid, ascending), counters[GS_COUNTER_NUM_VISIBLE]=M.
+ * counters: int32[GS_NUM_COUNTERS]; ALL of them are reset to zero here (the first stage of a frame), so the caller
+ * need not clear the buffer between frames. */
 size_t gs_filter_workspace_bytes(int n_points);
 int gs_filter_compact(const float *xyz, const int8_t *invalid_mask, const int32_t *object_id,
                       const float *intrinsics, const float *q_camera_pointcloud,
@@ -99,7 +101,7 @@ int gs_read_counters(const int32_t *counters, int32_t *host_counters, int n, voi
  * n_visible_on_device != 0: n_visible is only the CAPACITY of ids/outputs (e.g. N) and the kernel takes
  * the actual count from counters[GS_COUNTER_NUM_VISIBLE] as written by gs_filter_compact on the same
  * stream -- the host then needs a single size read-back (M, K, slots together) instead of two.
- * counters (may be NULL; must be zero-initialised by the caller): counters[GS_COUNTER_MAX_DEPTH_KEY]
+ * counters (may be NULL; zeroed by gs_filter_compact, else by the caller): counters[GS_COUNTER_MAX_DEPTH_KEY]
  * receives the largest quantised depth int32(z*depth_scale) on screen, so that the host can size the
  * key's depth field to the bits in use (fewer radix passes than the far_plane*depth_scale bound). */
 int gs_preprocess(const float *xyz, float *features, const int32_t *object_id,
@@ -190,7 +192,8 @@ int gs_blend_forward(const int32_t *bin_start, const int32_t *bin_end, const int
 /* Backward per-pixel pass.  Replaces the pixel loop of gaussian_point_rasterisation_backward
  * (RAS:531-705) WITHOUT its global atomics (RAS:674-696): the partial sums of a (Gaussian, tile) pair
  * are stored as one 48-B record (layout of `acc`) in partials[slot] and slot_flags[slot] is raised
- * (slot: see gs_make_keys; n_slots = counters[GS_COUNTER_NUM_SLOTS]; slot_flags is zeroed by the library).
+ * (slot: see gs_make_keys; n_slots = counters[GS_COUNTER_NUM_SLOTS]; slot_flags is zeroed by the library and must be
+ * allocated with n_slots rounded UP to a multiple of 16 bytes -- the fill is issued as one aligned memset).
  * The walk starts at the tile-wide maximum of last_effective and runs down to bin_start; bin_shift and filter
  * must be the forward's.  alpha is evaluated by the same device function as in gs_blend_forward and the staging
  * filter is the same function on the same records, so both passes treat exactly the same (pixel, Gaussian)

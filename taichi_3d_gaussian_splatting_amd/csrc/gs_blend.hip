@@ -673,7 +673,9 @@ int gs_blend_backward(const int32_t *bin_start, const int32_t *payload, const fl
     GS_REQUIRE(bin_shift == 0 || (filter & GS_FILTER_BOX), "lists that cover several tiles need the box filter");
     GS_REQUIRE(n_slots >= 0, "n_slots");
     hipStream_t s = (hipStream_t)stream;
-    if (n_slots > 0) GS_CHECK_HIP(hipMemsetAsync(slot_flags, 0, (size_t)n_slots, s));
+    // the flag buffer is padded to a multiple of 16 bytes (header): one aligned fill instead of an aligned fill plus a
+    // second launch for the odd tail
+    if (n_slots > 0) GS_CHECK_HIP(hipMemsetAsync(slot_flags, 0, ((size_t)n_slots + 15) & ~(size_t)15, s));
     const int tw = width / GS_TILE_WIDTH;
     const int rows = owned_row_count(height / GS_TILE_HEIGHT, tile_row_begin, tile_row_step, tile_row_end);
     if (rows == 0 || tw == 0) return 0;

@@ -211,9 +211,11 @@ __global__ __launch_bounds__(GS_BLOCK) void filter_kernel(
     const float *__restrict__ xyz, const int8_t *__restrict__ invalid, const int32_t *__restrict__ obj,
     const float *__restrict__ Kmat, const float *__restrict__ q_cp, const float *__restrict__ t_cp, int n,
     float near_plane, float far_plane, int width, int height, int8_t *__restrict__ mask,
-    int32_t *__restrict__ block_counts) {
+    int32_t *__restrict__ block_counts, int32_t *__restrict__ counters) {
     __shared__ int s_count;
     if (threadIdx.x == 0) s_count = 0;
+    // the frame's counters start at zero (the first kernel of a frame does it: no separate fill launch)
+    if (blockIdx.x == 0 && threadIdx.x < GS_NUM_COUNTERS) counters[threadIdx.x] = 0;
     __syncthreads();
     float K[9];
 #pragma unroll
@@ -253,16 +255,43 @@ __global__ __launch_bounds__(GS_BLOCK) void scan_single_block_kernel(int32_t *__
                                                                     int32_t *__restrict__ total_out,
                                                                     int32_t *__restrict__ data2,
                                                                     int32_t *__restrict__ total_out2) {
-    __shared__ int lds[4];
+    __shared__ long long lds[GS_BLOCK / GS_WAVE];
     if (blockIdx.x == 1) { data = data2; total_out = total_out2; }
+    // every thread owns SCAN_ITEMS consecutive values: all loads of a 4096-value chunk are in flight together (the
+    // one-value-per-thread form paid one L2 round trip per 256 values: 12 us for the 3.9 k block sums of 1e6 points)
+    constexpr int SCAN_ITEMS = 16;
     long long carry = 0;
-    for (int base = 0; base < n; base += GS_BLOCK) {
-        int i = base + threadIdx.x;
-        int v = i < n ? data[i] : 0;
-        int total;
-        int ex = gs_block_excl_scan(v, &total, lds);
-        long long out = carry + ex;
-        if (i < n) data[i] = out > 0x7fffffffLL ? 0x7fffffff : (int)out;
+    for (int base = 0; base < n; base += GS_BLOCK * SCAN_ITEMS) {
+        const int first = base + threadIdx.x * SCAN_ITEMS;
+        int v[SCAN_ITEMS];
+#pragma unroll
+        for (int k = 0; k < SCAN_ITEMS; ++k) v[k] = first + k < n ? data[first + k] : 0;
+        long long mine = 0;   // 64-bit throughout: the total saturates at INT32_MAX instead of wrapping
+#pragma unroll
+        for (int k = 0; k < SCAN_ITEMS; ++k) mine += v[k];
+        long long incl = mine;
+#pragma unroll
+        for (int d = 1; d < GS_WAVE; d <<= 1) {
+            const long long o = __shfl_up(incl, d, GS_WAVE);
+            if (gs_lane() >= d) incl += o;
+        }
+        const int w = threadIdx.x >> 6;
+        if (gs_lane() == GS_WAVE - 1) lds[w] = incl;
+        __syncthreads();
+        long long before = 0, total = 0;
+#pragma unroll
+        for (int i = 0; i < GS_BLOCK / GS_WAVE; ++i) {
+            const long long t = lds[i];
+            if (i < w) before += t;
+            total += t;
+        }
+        __syncthreads();
+        long long run = carry + before + incl - mine;
+#pragma unroll
+        for (int k = 0; k < SCAN_ITEMS; ++k) {
+            if (first + k < n) data[first + k] = run > 0x7fffffffLL ? 0x7fffffff : (int)run;
+            run += v[k];
+        }
         carry += total;
     }
     if (threadIdx.x == 0) *total_out = carry > 0x7fffffffLL ? 0x7fffffff : (int)carry;
@@ -616,12 +645,12 @@ int gs_filter_compact(const float *xyz, const int8_t *invalid_mask, const int32_
     hipStream_t s = (hipStream_t)stream;
     int32_t *block_counts = (int32_t *)workspace;
     if (n_points == 0) {
-        GS_CHECK_HIP(hipMemsetAsync(counters + GS_COUNTER_NUM_VISIBLE, 0, sizeof(int32_t), s));
+        GS_CHECK_HIP(hipMemsetAsync(counters, 0, sizeof(int32_t) * GS_NUM_COUNTERS, s));
         return 0;
     }
     const int nblk = gs_div_up(n_points, FILTER_ITEMS);
     hipLaunchKernelGGL(filter_kernel, dim3(nblk), dim3(GS_BLOCK), 0, s, xyz, invalid_mask, object_id, intrinsics,
-                       q_cp, t_cp, n_points, near_plane, far_plane, width, height, mask, block_counts);
+                       q_cp, t_cp, n_points, near_plane, far_plane, width, height, mask, block_counts, counters);
     GS_CHECK_LAUNCH();
     hipLaunchKernelGGL(compact_kernel, dim3(nblk), dim3(GS_BLOCK), 0, s, mask, n_points, block_counts, ids,
                        counters + GS_COUNTER_NUM_VISIBLE);

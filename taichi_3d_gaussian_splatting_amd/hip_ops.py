@@ -139,7 +139,7 @@ def filter_compact(xyz, invalid_mask, object_id, intrinsics, q_cp, t_cp, near_pl
     mask = torch.empty(n, dtype=torch.int8, device=dev)
     ids = torch.empty(n, dtype=torch.int32, device=dev)
     if counters is None:
-        counters = torch.zeros(NUM_COUNTERS, dtype=torch.int32, device=dev)
+        counters = torch.empty(NUM_COUNTERS, dtype=torch.int32, device=dev)   # zeroed by gs_filter_compact
     ws = torch.empty(_lib.load().gs_filter_workspace_bytes(n), dtype=torch.uint8, device=dev)
     call("gs_filter_compact", ptr(xyz), ptr(invalid_mask), ptr(object_id), ptr(intrinsics), ptr(q_cp), ptr(t_cp),
          n, float(near_plane), float(far_plane), int(width), int(height), ptr(mask), ptr(ids), ptr(counters),
@@ -303,7 +303,8 @@ def blend_backward_partials(bin_start, payload, attrs, grad_image, acc_alpha, la
     dev = attrs.device
     grad_image = _f32(grad_image, "grad_rasterized_image")
     partials = torch.empty((max(int(n_slots), 1), ACC_STRIDE), dtype=torch.float32, device=dev)
-    flags = torch.empty(max(int(n_slots), 1), dtype=torch.uint8, device=dev)
+    # the flag buffer is allocated padded to 16 bytes (gsplat_hip.h: one aligned fill); callers see the n_slots flags
+    flags = torch.empty((max(int(n_slots), 1) + 15) & ~15, dtype=torch.uint8, device=dev)[:max(int(n_slots), 1)]
     alloc = torch.zeros if layout.sharded else torch.empty
     mag = alloc((height, width, 2), dtype=torch.float32, device=dev)
     dbg = torch.zeros((height, width, 2), dtype=torch.int32, device=dev) if debug_hits else None
