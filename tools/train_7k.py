@@ -100,7 +100,14 @@ summary = dict(iterations=ITERS, oracle_iterations=ORACLE_ITERS, image=f"{SIZE}x
 # ---------------------------------------------------------------- HIP back end, full length
 t0 = time.perf_counter()
 trainer = TRN(make_config("hip", ITERS))
-trainer.train()
+if os.environ.get("GS_CPROFILE"):      # host-side profile of the loop (cProfile inflates the wall time)
+    import cProfile
+    import pstats
+    prof = cProfile.Profile()
+    prof.runcall(trainer.train)
+    pstats.Stats(prof).sort_stats("tottime").print_stats(45)
+else:
+    trainer.train()
 torch.cuda.synchronize()
 summary["hip_seconds"] = round(time.perf_counter() - t0, 1)
 summary["hip_it_per_s"] = round(ITERS / summary["hip_seconds"], 1)
