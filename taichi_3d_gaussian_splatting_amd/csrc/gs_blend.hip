@@ -513,6 +513,10 @@ __global__ __launch_bounds__(BLEND_THREADS, GS_BWD_MIN_WAVES) void blend_backwar
 // ascending order and the 64 partial records are added in a fixed DPP order.  Either way the summation order depends
 // only on the slot layout, so gradients are bitwise reproducible.  Value 10 (pixel count) is summed as an integer.
 constexpr int RP_HEAVY = 128;
+#ifndef GS_RP_CHUNK
+#define GS_RP_CHUNK 4
+#endif
+constexpr int RP_CHUNK = GS_RP_CHUNK;   // raised slots fetched together (tools/build_variants.sh sweeps it)
 struct SlotSum { float v[10]; int npix; };
 __device__ __forceinline__ void rp_add_group(const uint8_t *__restrict__ flags, const float4 *__restrict__ partials,
                                              int first, int cnt, SlotSum &a) {
@@ -520,14 +524,29 @@ __device__ __forceinline__ void rp_add_group(const uint8_t *__restrict__ flags, 
                           // raised ones (independent 48-B loads): many loads in flight instead of one at a time
     for (int r = 0; r < cnt; ++r) mask |= (flags[first + r] != 0 ? 1u : 0u) << r;
     while (mask) {
-        const int r = __builtin_ctz(mask);
-        mask &= mask - 1;
-        const float4 *src = partials + 3 * (size_t)(first + r);
-        const float4 p0 = src[0], p1 = src[1], p2 = src[2];
-        a.v[0] += p0.x; a.v[1] += p0.y; a.v[2] += p0.z; a.v[3] += p0.w;
-        a.v[4] += p1.x; a.v[5] += p1.y; a.v[6] += p1.z; a.v[7] += p1.w;
-        a.v[8] += p2.x; a.v[9] += p2.y;
-        a.npix += __builtin_bit_cast(int, p2.z);
+        // up to RP_CHUNK raised slots per round: their 48-B records are all requested before the first one is added
+        // (one record per round left the kernel waiting on a full memory latency per slot); added in ascending order
+        int r[RP_CHUNK];
+        float4 p[RP_CHUNK][3];
+#pragma unroll
+        for (int q = 0; q < RP_CHUNK; ++q) {
+            r[q] = mask ? __builtin_ctz(mask) : -1;
+            mask &= mask - 1;   // (0 stays 0)
+        }
+#pragma unroll
+        for (int q = 0; q < RP_CHUNK; ++q)
+            if (r[q] >= 0) {
+                const float4 *src = partials + 3 * (size_t)(first + r[q]);
+                p[q][0] = src[0]; p[q][1] = src[1]; p[q][2] = src[2];
+            }
+#pragma unroll
+        for (int q = 0; q < RP_CHUNK; ++q)
+            if (r[q] >= 0) {
+                a.v[0] += p[q][0].x; a.v[1] += p[q][0].y; a.v[2] += p[q][0].z; a.v[3] += p[q][0].w;
+                a.v[4] += p[q][1].x; a.v[5] += p[q][1].y; a.v[6] += p[q][1].z; a.v[7] += p[q][1].w;
+                a.v[8] += p[q][2].x; a.v[9] += p[q][2].y;
+                a.npix += __builtin_bit_cast(int, p[q][2].z);
+            }
     }
 }
 // LANES = 1: one lane per Gaussian (+ whole-wave help for the rare heavy one); LANES = 16: sixteen lanes (one DPP
