@@ -655,20 +655,31 @@ def test_hook_feature_gradients_can_be_switched_off(scene):
     assert torch.equal(full[4].grad, lean[4].grad) and torch.equal(full[3].grad, lean[3].grad)
 
 
-def test_operator_tile_row_sharding_matches_single(scene):
-    """Image-space sharding: rendering tile rows {0,2,4,..} and {1,3,5,..} separately and merging
-    equals the un-sharded render bit-for-bit; partial gradients add up."""
+@pytest.mark.parametrize("bin_shift", [0, 1, 2])
+@pytest.mark.parametrize("split", ["interleaved", "bands"])
+def test_operator_tile_row_sharding_matches_single(scene, split, bin_shift):
+    """Image-space sharding: rendering two sets of tile rows separately -- rows {0,2,4,..} / {1,3,5,..}, or the bands
+    [0,7) / [7,16) whose boundary cuts through the 2x2- and 4x4-tile bins -- and merging equals the un-sharded render
+    bit-for-bit, with per-tile keys and with binned lists; partial gradients add up."""
     from taichi_3d_gaussian_splatting_amd.synthetic import make_grad_image
     g = make_grad_image(scene.height, scene.width)
-    image, depth, count, xyz, feat = _run_operator(scene, g)
-    parts = [_run_operator(scene, g, row=(r, 2)) for r in range(2)]
+    image, depth, count, xyz, feat = _run_operator(scene, g, bin_shift=0)
     rows = torch.arange(scene.height, device="cuda") // 16
-    merged = torch.where((rows % 2 == 0)[:, None, None], parts[0][0], parts[1][0])
+    if split == "interleaved":
+        parts = [_run_operator(scene, g, row=(r, 2), bin_shift=bin_shift) for r in range(2)]
+        first = rows % 2 == 0
+    else:
+        parts = [_run_operator(scene, g, row=(0, 1), row_end=7, bin_shift=bin_shift),
+                 _run_operator(scene, g, row=(7, 1), bin_shift=bin_shift)]
+        first = rows < 7
+    merged = torch.where(first[:, None, None], parts[0][0], parts[1][0])
     assert torch.equal(merged, image)
-    merged_count = torch.where((rows % 2 == 0)[:, None], parts[0][2], parts[1][2])
+    merged_count = torch.where(first[:, None], parts[0][2], parts[1][2])
     assert torch.equal(merged_count, count)
     gsum = parts[0][4].grad + parts[1][4].grad
     assert rel_l2(gsum.cpu().numpy(), feat.grad.cpu().numpy()) < 1e-4
+    gx = parts[0][3].grad + parts[1][3].grad
+    assert rel_l2(gx.cpu().numpy(), xyz.grad.cpu().numpy()) < 1e-4
 
 
 def test_operator_edge_cases():
