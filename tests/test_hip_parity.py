@@ -547,8 +547,8 @@ def _stages_to_ranges(ops, s, layout=None):
                 n_slots=n_slots, k=k, layout=layout)
 
 
-@pytest.mark.parametrize("workload,bin_shift", [("cfg2_100k_800", 0), ("headline_1m_1080p", 0), ("headline_1m_1080p", 2),
-                                                ("cfg3_400k_1080p", 0)])
+@pytest.mark.parametrize("workload,bin_shift", [("cfg2_100k_800", 0), ("headline_1m_1080p", 0), ("headline_1m_1080p", 1),
+                                                ("headline_1m_1080p", 2), ("cfg3_400k_1080p", 0)])
 def test_forward_and_backward_blend_the_same_pairs(ops, workload, bin_shift):
     """a (pixel, Gaussian) pair must be treated as blended by the backward pass iff the forward
     pass blended it.  Both kernels evaluate alpha through the same device function; here every pixel's blended set is

@@ -1,11 +1,12 @@
 import os, sys, time, torch
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from taichi_3d_gaussian_splatting_amd import CameraInfo, GaussianPointCloudRasterisation as Op
 from taichi_3d_gaussian_splatting_amd.synthetic import make_config_scene, make_grad_image
 s = make_config_scene(sys.argv[1] if len(sys.argv) > 1 else "headline_1m_1080p").to("cuda"); g = make_grad_image(s.height, s.width).to("cuda")
 MODE = os.environ.get("GS_SHARD_MODE", "bands")
 RANK = int(os.environ.get("GS_SHARD_RANK", "-1"))   # -1: the middle band (the heaviest one under perspective)
-for G in (1, 2, 4, 8):
+WORLDS = tuple(int(x) for x in os.environ.get("GS_SHARD_WORLDS", "1,2,4,8").split(","))
+for G in WORLDS:
     op = Op(Op.GaussianPointCloudRasterisationConfig())
     op.shard = (G // 2 if RANK < 0 else min(RANK, G - 1), G, MODE)
     xyz = s.point_cloud.clone().requires_grad_(True); feat = s.point_cloud_features.clone().requires_grad_(True)
