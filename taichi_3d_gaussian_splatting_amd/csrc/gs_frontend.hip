@@ -135,6 +135,13 @@ __device__ __forceinline__ int make_walk_rec(BinWalkRec &r, bool active, float u
     r.magic = r.nbv > 1 ? 0xffffffffu / (unsigned)r.nbv + 1u : 0u;
     return (b1u - b0u) * (b1v - b0v);
 }
+// Which walk a wave takes (gs_preprocess and gs_make_keys ask the same question of the same numbers): per lane when at
+// least half of its Gaussians are heavy (> 256 pairs: the wave is balanced as it is and the per-lane walk costs ~2.5x
+// less per pair), shared among the lanes otherwise.
+constexpr int HEAVY_PAIRS = 256;
+__device__ __forceinline__ bool gs_mostly_heavy_wave(int npairs) {
+    return __popcll(__builtin_amdgcn_ballot_w64(npairs > HEAVY_PAIRS)) >= GS_WAVE / 2;
+}
 // visit(owner_lane, bin_u, bin_v, survives) is called by every lane once per round of 64 pairs (wave-convergent, so that
 // it may use ballots); `survives` is false for the padding lanes of the last round.  recs: the 64 records of this wave.
 template <typename Visit>
@@ -352,7 +359,10 @@ __global__ __launch_bounds__(GS_BLOCK) void preprocess_kernel(
     int32_t *__restrict__ ntiles_full, int32_t *__restrict__ nkeys, int32_t *__restrict__ block_sums,
     int32_t *__restrict__ block_sums_full) {
     __shared__ int s_sum, s_sum_full, s_dq;
+    __shared__ BinWalkRec s_rec[GS_BLOCK];   // the key count shares its Gaussians' bins among the lanes of a wave
+    __shared__ int s_cnt[GS_BLOCK];
     if (threadIdx.x == 0) { s_sum = 0; s_sum_full = 0; s_dq = 0; }
+    s_cnt[threadIdx.x] = 0;
     __syncthreads();
     // the number of visible points may still be on its way to the host: read it on the device
     const int m = use_device_count ? min(counters[GS_COUNTER_NUM_VISIBLE], m_capacity) : m_capacity;
@@ -443,12 +453,28 @@ __global__ __launch_bounds__(GS_BLOCK) void preprocess_kernel(
         amp = opacity * rescale;
         qmax = cull ? gs_cull_qmax(amp) : __builtin_inff();
     }
-    // number of sort keys = bins reached on this GPU.  (Per-lane walk: measured, the count is not what bounds this kernel --
-    // 0.139 ms with the exact cull, 0.144 without, 0.143 with the balanced walk of gs_make_keys; the IEEE divisions,
-    // expf and sqrtf of the projection chain are, and they have to stay: the tile boxes must match the reference's.)
-    if (live)
-        for_each_emitting_bin(t0u, t1u, t0v, t1v, bin_shift, ow, cull, u_, v_, cA, cB, cC, qmax,
-                              [&](int, int) { ++owned; });
+    // number of sort keys = bins reached on this GPU: the walk of gs_make_keys on the same values (count and keys agree).
+    // The (bin, Gaussian) pairs of a wave's 64 Gaussians are dealt to its lanes 64 at a time, so that ONE screen-filling
+    // Gaussian (a floater close to the camera: thousands of bins) is counted by the whole wave instead of stalling the
+    // frame on a single lane (measured: +0.35 ms per frame here and +0.45 ms in gs_make_keys for one such Gaussian among
+    // the 1e6 of the headline scene; ordinary waves: 0.139 vs 0.143 ms, the row gathers hide the count).  A wave made
+    // of mostly heavy Gaussians (the reference's stress distribution) keeps the per-lane loop: it is already balanced.
+    {
+        BinWalkRec *recs = s_rec + (threadIdx.x & ~(GS_WAVE - 1));
+        int *cnts = s_cnt + (threadIdx.x & ~(GS_WAVE - 1));
+        const int npairs = make_walk_rec(s_rec[threadIdx.x], live, u_, v_, cA, cB, cC, qmax, t0u, t1u, t0v, t1v,
+                                         bin_shift, ow);
+        if (gs_mostly_heavy_wave(npairs)) {
+            if (live)
+                for_each_emitting_bin(t0u, t1u, t0v, t1v, bin_shift, ow, cull, u_, v_, cA, cB, cC, qmax,
+                                      [&](int, int) { ++owned; });
+        } else {
+            walk_bins_balanced(recs, npairs, bin_shift, ow, cull, [&](int owner, int, int, bool survives) {
+                if (survives) atomicAdd(&cnts[owner], 1);
+            });
+            owned = cnts[gs_lane()];
+        }
+    }
     if (live) {
         float4 *out = reinterpret_cast<float4 *>(attrs + (size_t)GS_ATTR_STRIDE * i);
         out[0] = make_float4(u_, v_, z_, qmax);  // always: the hook exposes uv and depth of every
@@ -544,15 +570,16 @@ __global__ __launch_bounds__(GS_BLOCK) void make_keys_kernel(
     // The same walk on the same stored values as gs_preprocess: both kernels agree on which pairs survive.  A wave of
     // ordinary Gaussians (a few dozen bins each) deals its pairs to its lanes 64 at a time -- survivors are then met in
     // the order of their keys, the wave's first key sits at its lane 0's offset, and consecutive lanes write consecutive
-    // keys (0.070 -> 0.056 ms at the headline size against one scattered-store loop per lane).  A wave that holds a
-    // Gaussian of more than 256 bins keeps the per-lane loop: the balanced walk costs ~2.5x per pair (owner search,
-    // record fetch) and such waves are uniform anyway (the reference's stress scene: 0.15 vs 0.34 ms).
+    // keys (0.070 -> 0.056 ms at the headline size against one scattered-store loop per lane) -- and a single
+    // screen-filling Gaussian is written by its whole wave.  A wave of mostly heavy Gaussians (> 256 bins each) keeps
+    // the per-lane loop: the balanced walk costs ~2.5x per pair (owner search, record fetch) and such waves are
+    // balanced as they are (the reference's stress scene: 0.15 vs 0.34 ms).
     BinWalkRec *recs = s_rec + (threadIdx.x & ~(GS_WAVE - 1));
     int *dqs = s_dq + (threadIdx.x & ~(GS_WAVE - 1));
     s_dq[threadIdx.x] = (int32_t)(a0.z * depth_scale);  // truncation toward zero, RAS:159-160
     const int npairs = make_walk_rec(s_rec[threadIdx.x], cnt > 0, a0.x, a0.y, a1.x, a1.y, a1.z, a0.w, t0u, t1u, t0v, t1v,
                                      bin_shift, ow);
-    if (__builtin_amdgcn_ballot_w64(npairs > 256) != 0ull) {   // per-lane walk: every lane writes its own keys from its own offset
+    if (gs_mostly_heavy_wave(npairs)) {   // per-lane walk: every lane writes its own keys from its own offset
         if (cnt == 0) return;
         const int32_t dq = (int32_t)(a0.z * depth_scale);
         long long k = offset;
