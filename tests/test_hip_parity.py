@@ -547,6 +547,37 @@ def _stages_to_ranges(ops, s, layout=None):
                 n_slots=n_slots, k=k, layout=layout)
 
 
+def test_screen_filling_gaussians_among_ordinary_ones(ops):
+    """A few Gaussians that cover the whole image (floaters close to the camera) among 1e4 ordinary ones: their wave
+    counts and writes its (bin, Gaussian) pairs through the lane-shared walk, every other wave as before.  Keys, payload,
+    tile counts and ranges stay bit-exact against the oracle (per-tile keys), the binned layouts blend the same pixels,
+    and the whole operator matches the oracle."""
+    s = small_scene(n=10_000, size=256, seed=5, sh_degree=3)
+    heavy = torch.tensor([70, 4100, 4101, 9000])
+    s.point_cloud[heavy] = torch.tensor([[0.0, 0.0, 0.0], [0.1, -0.1, 0.2], [-0.2, 0.1, -0.1], [0.05, 0.05, 0.0]])
+    s.point_cloud_features[heavy, 4:7] = 1.0     # log-scale: sigma ~ 2.7, the whole view
+    s.point_cloud_features[heavy, 7] = -3.0      # faint: blended everywhere, saturates nothing
+    f = oracle_forward(s)
+    assert (f["num_overlap_tiles"][np.isin(f["ids"], heavy.numpy())] == 256).all()   # every tile of the 16 x 16 grid
+    d = s.to("cuda")
+    per_tile = _stages_to_ranges(ops, d, ops.ListLayout(bin_shift=0, exact_cull=False))
+    assert per_tile["k"] == len(f["keys"])
+    assert np.array_equal(per_tile["ntiles"].cpu().numpy(), f["num_overlap_tiles"])
+    assert np.array_equal(per_tile["payload"].cpu().numpy(), f["payload"])            # sorted order incl. stable ties
+    assert np.array_equal(per_tile["start"].cpu().numpy(), f["tile_start"])
+    assert np.array_equal(per_tile["end"].cpu().numpy(), f["tile_end"])
+    outs = {}
+    for name, layout in (("tile", ops.ListLayout(bin_shift=0)), ("bin2", ops.ListLayout(bin_shift=1)),
+                         ("bin4", ops.ListLayout(bin_shift=2))):
+        st = _stages_to_ranges(ops, d, layout)
+        outs[name] = ops.blend_forward(st["start"], st["end"], st["payload"], st["attrs"], d.width, d.height, layout)
+        report(f"screen_filling.{name}", keys=st["k"])
+    for name in ("bin2", "bin4"):
+        for i in (0, 1, 2, 4):   # image, depth, acc_alpha, count (last_effective is a list position)
+            assert torch.equal(outs[name][i], outs["tile"][i]), (name, i)
+    _operator_vs_oracle("screen_filling", s, f)
+
+
 @pytest.mark.parametrize("workload,bin_shift", [("cfg2_100k_800", 0), ("headline_1m_1080p", 0), ("headline_1m_1080p", 1),
                                                 ("headline_1m_1080p", 2), ("cfg3_400k_1080p", 0)])
 def test_forward_and_backward_blend_the_same_pairs(ops, workload, bin_shift):
