@@ -165,7 +165,7 @@ class GaussianPointCloudRasterisation(torch.nn.Module):
         # launch the list stages from device-side counts with the previous frame's capacities instead of waiting for
         # this frame's sizes (see _forward); False = wait for the sizes first (two dependent halves, as round 1)
         self.speculative_sizes = True
-        self._size_guess, self._size_guess_key, self._readbacks = None, None, {}
+        self._size_guesses, self._readbacks = {}, {}   # (image size, list layout, planes) -> (key capacity, depth bound)
         self.speculation_stats = {"frames": 0, "redone": 0}
         outer = self
 
@@ -244,7 +244,8 @@ class GaussianPointCloudRasterisation(torch.nn.Module):
                     return payload_, slot_offsets_, start_, blended
 
                 guess_key = (width, height, layout, cfg.near_plane, cfg.far_plane, cfg.depth_to_sort_key_scale)
-                guess = outer._size_guess if outer.speculative_sizes and outer._size_guess_key == guess_key else None
+                # one guess per (image size, layout, planes): data sets that mix resolutions keep speculating
+                guess = outer._size_guesses.get(guess_key) if outer.speculative_sizes else None
                 result = None
                 if guess is not None:
                     result = lists_and_blend(attrs, num_owned_tiles, block_sums, block_sums_full, num_overlap_tiles,
@@ -278,8 +279,10 @@ class GaussianPointCloudRasterisation(torch.nn.Module):
                 depth_bound = (1 << max(int(max_depth_key), 1).bit_length()) - 1
                 if guess is not None and depth_bound <= guess[1] <= 4 * depth_bound + 3:
                     depth_bound = guess[1]
-                outer._size_guess = (max(int(1.3 * n_keys) + 4096, int(0.99 * guess[0]) if guess else 0), depth_bound)
-                outer._size_guess_key = guess_key
+                if len(outer._size_guesses) >= 16 and guess_key not in outer._size_guesses:
+                    outer._size_guesses.pop(next(iter(outer._size_guesses)))   # bounded: forget the oldest configuration
+                outer._size_guesses[guess_key] = (max(int(1.3 * n_keys) + 4096, int(0.99 * guess[0]) if guess else 0),
+                                                  depth_bound)
                 ids, attrs, num_overlap_tiles, num_owned_tiles = ids[:m], attrs[:m], num_overlap_tiles[:m], \
                     num_owned_tiles[:m]
                 if not fits:

@@ -666,6 +666,14 @@ def test_speculative_sizes_overflow_is_redone(scene):
     op.speculative_sizes = False                                  # the two-halves path still works
     got, ref = _run_operator(scene, g, op=op), fresh(scene)
     assert torch.equal(got[0], ref[0]) and torch.equal(got[4].grad, ref[4].grad)
+    # a data set that mixes image sizes keeps speculating: one size guess per (image size, layout, planes)
+    small = small_scene(n=2000, size=128, seed=6)
+    g_small = make_grad_image(small.height, small.width)
+    op2 = Op(cfg)
+    for sc, gi in ((scene, g), (small, g_small)) * 3:
+        got, ref = _run_operator(sc, gi, op=op2), _run_operator(sc, gi, op=Op(cfg))
+        assert torch.equal(got[0], ref[0]) and torch.equal(got[4].grad, ref[4].grad)
+    assert len(op2._size_guesses) == 2 and op2.speculation_stats == {"frames": 6, "redone": 0}
 
 
 def test_hook_feature_gradients_can_be_switched_off(scene):
