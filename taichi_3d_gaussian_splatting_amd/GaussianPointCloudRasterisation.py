@@ -162,6 +162,7 @@ class GaussianPointCloudRasterisation(torch.nn.Module):
         # tiles a Gaussian covers the larger the bin that pays), None = chosen per frame from the previous frame's sizes
         self.bin_shift: Optional[int] = None
         self._auto_bin_shift = 0
+        self._auto_bin_shift_by_size = {}
         # launch the list stages from device-side counts with the previous frame's capacities instead of waiting for
         # this frame's sizes (see _forward); False = wait for the sizes first (two dependent halves, as round 1)
         self.speculative_sizes = True
@@ -190,7 +191,7 @@ class GaussianPointCloudRasterisation(torch.nn.Module):
                          q_pointcloud_camera, t_pointcloud_camera, camera_info, color_max_sh_band, need_state):
                 cfg = outer.config
                 width, height = camera_info.camera_width, camera_info.camera_height
-                layout = outer.list_layout(height)
+                layout = outer.list_layout(height, width)
                 if not pointcloud_features.is_contiguous():
                     raise ValueError("point_cloud_features must be contiguous (it is normalised in place)")
                 if pointcloud_features.dtype != torch.float32 or pointcloud_features.shape[1] != 56:
@@ -263,13 +264,14 @@ class GaussianPointCloudRasterisation(torch.nn.Module):
                 # the blend kernels pay for filtering twice as many list entries: -2.3 % at the headline size); per-tile
                 # keys, as the reference, otherwise (small frames: the filter costs more than the sort saves)
                 ratio = n_slots / max(m, 1)
-                previous = outer._auto_bin_shift
+                previous = layout.bin_shift if outer.bin_shift is None else outer._auto_bin_shift
                 if ratio >= (32.0 if previous == 2 else 64.0):
                     outer._auto_bin_shift = 2
                 elif n_slots >= (2_000_000 if previous == 1 else 3_000_000):
                     outer._auto_bin_shift = 1
                 else:
                     outer._auto_bin_shift = 0
+                outer._auto_bin_shift_by_size[(width, height)] = outer._auto_bin_shift   # cameras of several sizes
                 fits = guess is not None and n_keys <= guess[0] and max_depth_key <= guess[1]
                 outer.speculation_stats["frames"] += 1
                 outer.speculation_stats["redone"] += 0 if (fits or guess is None) else 1
@@ -361,8 +363,9 @@ class GaussianPointCloudRasterisation(torch.nn.Module):
         self.grad_accumulator_reduce: Optional[Callable[[torch.Tensor], None]] = None
         self.image_gather: Optional[Callable[[list], None]] = None
 
-    def list_layout(self, height: Optional[int] = None) -> "hip_ops.ListLayout":
-        """The list layout the next forward pass will use (for an image of ``height`` pixels when sharded)."""
+    def list_layout(self, height: Optional[int] = None, width: Optional[int] = None) -> "hip_ops.ListLayout":
+        """The list layout the next forward pass will use (for an image of ``height`` pixels when sharded; with
+        ``width`` too, the automatic bin size is the one learnt for that image size, else the last frame's)."""
         begin, step, end = self.tile_row_begin, self.tile_row_step, self.tile_row_end
         if self.shard is not None:
             from .distributed import owned_tile_rows
@@ -371,7 +374,9 @@ class GaussianPointCloudRasterisation(torch.nn.Module):
             rank, world, mode = self.shard
             rows = owned_tile_rows(height // TILE_HEIGHT, rank, world, mode, self.shard_row_weights)
             begin, step, end = rows.start, rows.step, rows.stop
-        return hip_ops.ListLayout(bin_shift=self._auto_bin_shift if self.bin_shift is None else self.bin_shift,
+        auto = self._auto_bin_shift if width is None else self._auto_bin_shift_by_size.get((width, height),
+                                                                                              self._auto_bin_shift)
+        return hip_ops.ListLayout(bin_shift=auto if self.bin_shift is None else self.bin_shift,
                                   exact_cull=self.exact_tile_cull, row_begin=begin, row_step=step, row_end=end)
 
     def _counter_readback(self, device):
