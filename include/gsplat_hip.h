@@ -206,12 +206,15 @@ int gs_blend_backward(const int32_t *bin_start, const int32_t *payload, const fl
                       uint32_t *debug_pixel_hits, void *stream);
 
 /* Per-Gaussian sum of its flagged slots, in slot order (bitwise reproducible), into acc float[M][12].
- * Replaces the accumulation side of the reference's atomics (RAS:674-696). */
+ * Replaces the accumulation side of the reference's atomics (RAS:674-696).
+ * attrs (may be NULL) + width/height: the packed records of gs_preprocess; with them a Gaussian of many slots is only
+ * looked at where its alpha >= 1/255 level set can reach (a needle's tile box is mostly empty) -- same sums, fewer
+ * flags read.  Records written with exact_tile_cull = 0 (attrs[3] = +inf) switch this off by themselves. */
 int gs_reduce_partials(const int32_t *slot_offsets, const int32_t *num_overlap_tiles,
                        const uint8_t *slot_flags, const float *partials, int n_visible, float *acc,
                        const int32_t *num_keys /* may be NULL; num_keys[i] == 0: nothing to sum */,
                        int64_t n_slots_hint /* total number of slots (picks the lanes-per-Gaussian variant; 0 = default) */,
-                       void *stream);
+                       const float *attrs, int width, int height, void *stream);
 
 /* Backward per-point pass + gradient post-processing.  Replaces the per-point loop of
  * gaussian_point_rasterisation_backward (RAS:707-772), the dense zero-initialisation

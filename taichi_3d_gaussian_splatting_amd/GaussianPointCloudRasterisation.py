@@ -258,19 +258,27 @@ class GaussianPointCloudRasterisation(torch.nn.Module):
                 if n_keys >= 0x7fffffff or n_slots >= 0x7fffffff:
                     raise RuntimeError("more than 2^31-1 (tile, Gaussian) pairs: key offsets are int32 as in the reference")
                 nb = (m + 255) // 256
-                # next frame's list layout, from this frame's sizes (with hysteresis): 4x4-tile bins once a Gaussian
-                # covers >= 64 tiles on average (the lists would be dominated by pairs that never blend); 2x2-tile bins
-                # once there are >= 3e6 (tile, Gaussian) pairs (key generation + three radix passes then cost more than
-                # the blend kernels pay for filtering twice as many list entries: -2.3 % at the headline size); per-tile
-                # keys, as the reference, otherwise (small frames: the filter costs more than the sort saves)
-                ratio = n_slots / max(m, 1)
-                previous = layout.bin_shift if outer.bin_shift is None else outer._auto_bin_shift
-                if ratio >= (32.0 if previous == 2 else 64.0):
-                    outer._auto_bin_shift = 2
-                elif n_slots >= (2_000_000 if previous == 1 else 3_000_000):
-                    outer._auto_bin_shift = 1
+                # next frame's list layout, from this frame's key count K (after the exact cull, in the layout this frame
+                # used; scaled to the whole image when sharded) and M, with hysteresis:
+                #   per-tile keys -> 2x2-tile bins once K >= 2e6: key generation + three radix passes then cost more than
+                #     the blend kernels pay for filtering twice as many list entries (-4 % at the headline size); back
+                #     below 0.7e6 bin keys (small frames: the filter costs more than the sort saves);
+                #   -> 4x4-tile bins once a Gaussian emits >= 64 tile keys / >= 16 bin keys on average (lists dominated
+                #     by pairs that are never blended: the reference's stress distribution, 8.3 -> 0.64 ms); back below 3.
+                # Counting emitted keys rather than tile-box areas keeps needle-shaped Gaussians (huge boxes that the cull
+                # empties) from pushing an ordinary frame into the coarse bins.
+                owned = len(layout.owned_rows(height))
+                k_frame = n_keys * ((height // TILE_HEIGHT) / owned if owned else 1.0)
+                used = layout.bin_shift
+                if m == 0:
+                    choice = used       # nothing on screen: no information
+                elif used == 0:
+                    choice = 2 if k_frame >= 64 * m else (1 if k_frame >= 2_000_000 else 0)
+                elif used == 1:
+                    choice = 2 if k_frame >= 16 * m else (0 if k_frame < 700_000 else 1)
                 else:
-                    outer._auto_bin_shift = 0
+                    choice = 1 if k_frame < 3 * m else used
+                outer._auto_bin_shift = choice
                 outer._auto_bin_shift_by_size[(width, height)] = outer._auto_bin_shift   # cameras of several sizes
                 fits = guess is not None and n_keys <= guess[0] and max_depth_key <= guess[1]
                 outer.speculation_stats["frames"] += 1

@@ -556,7 +556,7 @@ template <int LANES>
 __global__ __launch_bounds__(GS_BLOCK) void reduce_partials_kernel(
     const int32_t *__restrict__ slot_offsets, const int32_t *__restrict__ ntiles_full,
     const uint8_t *__restrict__ slot_flags, const float4 *__restrict__ partials, int m, float4 *__restrict__ acc,
-    const int32_t *__restrict__ nkeys) {
+    const int32_t *__restrict__ nkeys, const float4 *__restrict__ attrs, int tw, int th) {
     const int i = (int)(((long long)blockIdx.x * GS_BLOCK + threadIdx.x) / LANES), lane = gs_lane();
     const int sub = threadIdx.x & (LANES - 1);
     const bool live = i < m;
@@ -575,7 +575,22 @@ __global__ __launch_bounds__(GS_BLOCK) void reduce_partials_kernel(
     } else {
         if (n <= RP_HEAVY)
             for (int r0 = 0; r0 < n; r0 += 32) rp_add_group(slot_flags, partials, base + r0, min(32, n - r0), a);
+        // A heavy Gaussian's slots are the tiles of its reference box (column-major, gs_make_keys), but only tiles the
+        // level set q <= qmax reaches can have been blended -- for a needle a thin diagonal of a huge square (10,000
+        // screen-long needles: 6,000 slots each, 0.45 ms of flag scanning).  With the packed records at hand the wave
+        // visits, one tile column of the cull box per lane, only the rows the level set crosses (gs_common.h, conservative).
         unsigned long long heavy = __builtin_amdgcn_ballot_w64(n > RP_HEAVY);
+        int t0u = 0, t1u = 0, t0v = 0, t1v = 0, c0u = 0, c1u = 0, c0v = 0, c1v = 0;
+        float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0;
+        bool narrow = false;
+        if (attrs != nullptr && n > RP_HEAVY) {
+            r0 = attrs[4 * (size_t)i]; r1 = attrs[4 * (size_t)i + 1];
+            gs_tile_box(r0.x, r0.y, r1.w, tw, th, t0u, t1u, t0v, t1v);
+            c0u = t0u; c1u = t1u; c0v = t0v; c1v = t1v;
+            const float det = r1.x * r1.z - r1.y * r1.y;
+            narrow = r0.w < 1e30f && r0.w >= 0.f && det > 0.f && (t1u - t0u) * (t1v - t0v) == n;
+            if (narrow) gs_cull_box(r0.x, r0.y, r1.x, r1.y, r1.z, r0.w, c0u, c1u, c0v, c1v);
+        }
         while (heavy) {   // wave-uniform loop over the heavy Gaussians of this wave
             const int L = __builtin_ctzll(heavy);
             heavy &= heavy - 1;
@@ -584,8 +599,25 @@ __global__ __launch_bounds__(GS_BLOCK) void reduce_partials_kernel(
 #pragma unroll
             for (int k = 0; k < 10; ++k) h.v[k] = 0.f;
             h.npix = 0;
-            for (int r0 = 4 * lane; r0 < nL; r0 += 4 * GS_WAVE)
-                rp_add_group(slot_flags, partials, bL + r0, min(4, nL - r0), h);
+            if (__builtin_amdgcn_readlane((int)narrow, L)) {
+                const float u = gs_readlane_f(r0.x, L), v = gs_readlane_f(r0.y, L), qm = gs_readlane_f(r0.w, L);
+                const float A = gs_readlane_f(r1.x, L), B = gs_readlane_f(r1.y, L), C = gs_readlane_f(r1.z, L);
+                const int b0u = __builtin_amdgcn_readlane(t0u, L), b0v = __builtin_amdgcn_readlane(t0v, L);
+                const int nv = __builtin_amdgcn_readlane(t1v, L) - b0v;
+                const int k0u = __builtin_amdgcn_readlane(c0u, L), k1u = __builtin_amdgcn_readlane(c1u, L);
+                const int k0v = __builtin_amdgcn_readlane(c0v, L), k1v = __builtin_amdgcn_readlane(c1v, L);
+                for (int cu = k0u + lane; cu < k1u; cu += GS_WAVE) {   // one tile column per lane and round
+                    int ra, rb;
+                    gs_cull_rows_in_column(u, v, A, B, C, qm, cu, ra, rb);
+                    ra = max(ra, k0v); rb = min(rb, k1v);
+                    const int first = bL + nv * (cu - b0u) - b0v;   // slot of (cu, row) = first + row
+                    for (int row = ra; row < rb; row += 4)
+                        rp_add_group(slot_flags, partials, first + row, min(4, rb - row), h);
+                }
+            } else {
+                for (int r0_ = 4 * lane; r0_ < nL; r0_ += 4 * GS_WAVE)
+                    rp_add_group(slot_flags, partials, bL + r0_, min(4, nL - r0_), h);
+            }
 #pragma unroll
             for (int k = 0; k < 10; ++k) {
                 const float t = gs_readlane63(gs_wave_sum_to_lane63(h.v[k]));
@@ -716,17 +748,27 @@ int gs_blend_backward(const int32_t *bin_start, const int32_t *payload, const fl
 
 int gs_reduce_partials(const int32_t *slot_offsets, const int32_t *num_overlap_tiles, const uint8_t *slot_flags,
                        const float *partials, int n_visible, float *acc, const int32_t *num_keys,
-                       int64_t n_slots_hint, void *stream) {
+                       int64_t n_slots_hint, const float *attrs, int width, int height, void *stream) {
     GS_REQUIRE(n_visible >= 0, "n_visible");
+    GS_REQUIRE(attrs == nullptr || (width > 0 && height > 0 && width % GS_TILE_WIDTH == 0 && height % GS_TILE_HEIGHT == 0),
+               "image size (needed with attrs)");
     if (n_visible == 0) return 0;
     const float4 *p4 = reinterpret_cast<const float4 *>(partials);
     float4 *a4 = reinterpret_cast<float4 *>(acc);
-    if (n_slots_hint > 32 * (int64_t)n_visible)   // many slots per Gaussian on average: sixteen lanes each
+    const float4 *r4 = reinterpret_cast<const float4 *>(attrs);
+    const int tw = width / GS_TILE_WIDTH, th = height / GS_TILE_HEIGHT;
+    // hundreds of slots per Gaussian on average (every Gaussian is large: the reference's stress distribution): sixteen
+    // lanes each.  Otherwise one lane each, the few large ones handed to their whole wave -- which also skips the empty
+    // part of a needle's box, so a frame whose average is inflated by needles (72 slots per Gaussian with 1 % of screen-
+    // long needles) belongs here too
+    if (n_slots_hint > 512 * (int64_t)n_visible)
         hipLaunchKernelGGL(reduce_partials_kernel<16>, dim3(gs_div_up(16LL * n_visible, GS_BLOCK)), dim3(GS_BLOCK), 0,
-                           (hipStream_t)stream, slot_offsets, num_overlap_tiles, slot_flags, p4, n_visible, a4, num_keys);
+                           (hipStream_t)stream, slot_offsets, num_overlap_tiles, slot_flags, p4, n_visible, a4, num_keys,
+                           r4, tw, th);
     else
         hipLaunchKernelGGL(reduce_partials_kernel<1>, dim3(gs_div_up(n_visible, GS_BLOCK)), dim3(GS_BLOCK), 0,
-                           (hipStream_t)stream, slot_offsets, num_overlap_tiles, slot_flags, p4, n_visible, a4, num_keys);
+                           (hipStream_t)stream, slot_offsets, num_overlap_tiles, slot_flags, p4, n_visible, a4, num_keys,
+                           r4, tw, th);
     GS_CHECK_LAUNCH();
     return 0;
 }

@@ -70,6 +70,51 @@ __device__ __forceinline__ void gs_tile_box(float u, float v, float r, int tw, i
 // nothing.
 __device__ __forceinline__ float gs_cull_qmax(float amp) { return 2.0f * logf(255.0f * amp) + 1e-2f; }
 
+// The tile box a bin walk has to look at: the reference's box (a square around the 3-sigma circle, RAS:81-103)
+// intersected with the axis-aligned bounding box of the level set q <= qmax -- half-widths sqrt(qmax C / det) and
+// sqrt(qmax A / det), taken 0.01 % and one pixel wider than computed, so that no tile with a contributing pixel is lost.
+// A needle-shaped Gaussian's square is mostly empty (the test below rejects those bins one by one: 10,000 screen-long
+// needles cost +0.7 ms per frame in the two walks); its bounding box is not, unless the needle is diagonal.  qmax = +inf
+// (cull off) or a degenerate conic leave the box as it is; qmax < 0 (never visible) empties it.
+__device__ __forceinline__ void gs_cull_box(float u, float v, float A, float B, float C, float qmax, int &t0u, int &t1u,
+                                            int &t0v, int &t1v) {
+#pragma clang fp contract(off)
+    const float det = A * C - B * B;
+    if (!(qmax < 1e30f) || !(det > 0.f)) return;
+    if (qmax < 0.f) { t1u = t0u; t1v = t0v; return; }
+    const float s = qmax / det;
+    const float wx = sqrtf(s * C) * 1.0001f + 1.0f, wy = sqrtf(s * A) * 1.0001f + 1.0f;
+    // tile column t holds pixel centres 16 t + 0.5 .. 16 t + 15.5: it matters only if that span meets [u - wx, u + wx]
+    const float lim = 1.0e6f;
+    const int c0u = (int)ceilf(fminf(fmaxf((u - wx - ((float)GS_TILE_WIDTH - 0.5f)) / (float)GS_TILE_WIDTH, -lim), lim));
+    const int c1u = (int)floorf(fminf(fmaxf((u + wx - 0.5f) / (float)GS_TILE_WIDTH, -lim), lim)) + 1;
+    const int c0v = (int)ceilf(fminf(fmaxf((v - wy - ((float)GS_TILE_HEIGHT - 0.5f)) / (float)GS_TILE_HEIGHT, -lim), lim));
+    const int c1v = (int)floorf(fminf(fmaxf((v + wy - 0.5f) / (float)GS_TILE_HEIGHT, -lim), lim)) + 1;
+    t0u = max(t0u, c0u); t1u = max(min(t1u, c1u), t0u);
+    t0v = max(t0v, c0v); t1v = max(min(t1v, c1v), t0v);
+}
+
+// Rows of tile column `cu` that can hold a pixel with q <= qmax: the level set cut by the strip of the column's pixel
+// centres (one pixel wider on both sides) is convex, so its y-extent is an interval -- the upper boundary
+// y(dx) = (-B dx + sqrt(C qmax - det dx^2)) / C is concave and peaks at dx = -B sqrt(qmax / (A det)), the lower one is
+// its mirror image.  Conservative by construction (wider strip, interval taken 0.01 % + one pixel wider, negative
+// discriminants clamped); callers intersect with the box rows.  Requires det > 0, 0 <= qmax < inf (as gs_cull_box).
+__device__ __forceinline__ void gs_cull_rows_in_column(float u, float v, float A, float B, float C, float qmax, int cu,
+                                                       int &r0, int &r1) {
+#pragma clang fp contract(off)
+    const float det = A * C - B * B;
+    const float a = ((float)(cu * GS_TILE_WIDTH) + 0.5f - 1.0f) - u, b = ((float)(cu * GS_TILE_WIDTH + GS_TILE_WIDTH) - 0.5f + 1.0f) - u;
+    const float peak = B * sqrtf(qmax / (A * det));            // |dx| of the two extreme points
+    const float dxu = fminf(fmaxf(-peak, a), b), dxl = fminf(fmaxf(peak, a), b);
+    const float inv_c = 1.0f / C;
+    const float up = (-B * dxu + sqrtf(fmaxf(C * qmax - det * dxu * dxu, 0.f))) * inv_c;
+    const float lo = (-B * dxl - sqrtf(fmaxf(C * qmax - det * dxl * dxl, 0.f))) * inv_c;
+    const float slack = 1.0f + 1.0e-4f * (fabsf(up) + fabsf(lo));
+    const float lim = 1.0e6f;
+    r0 = (int)ceilf(fminf(fmaxf((v + lo - slack - ((float)GS_TILE_HEIGHT - 0.5f)) / (float)GS_TILE_HEIGHT, -lim), lim));
+    r1 = (int)floorf(fminf(fmaxf((v + up + slack - 0.5f) / (float)GS_TILE_HEIGHT, -lim), lim)) + 1;
+}
+
 // [x0, x1] x [y0, y1]: pixel-CENTRE coordinates of the rectangle's corner pixels.  sx = -B/A, sy = -B/C: the slopes
 // of the conic's conjugate diameters (per-Gaussian constants; an approximate reciprocal is enough, see above).
 __device__ __forceinline__ bool gs_rect_may_contribute(float ux, float uy, float A, float B, float C, float sx,
@@ -114,6 +159,10 @@ __device__ __forceinline__ bool gs_entry_in_tile(const float4 r0, const float4 r
 }
 
 __device__ __forceinline__ int gs_lane() { return threadIdx.x & (GS_WAVE - 1); }
+// value of lane `l` (wave-uniform index) for every lane
+__device__ __forceinline__ float gs_readlane_f(float x, int l) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), l));
+}
 
 // number of set bits of `mask` strictly below the calling lane
 __device__ __forceinline__ int gs_mbcnt(unsigned long long mask) {

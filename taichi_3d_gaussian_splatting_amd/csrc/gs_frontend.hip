@@ -462,11 +462,13 @@ __global__ __launch_bounds__(GS_BLOCK) void preprocess_kernel(
     {
         BinWalkRec *recs = s_rec + (threadIdx.x & ~(GS_WAVE - 1));
         int *cnts = s_cnt + (threadIdx.x & ~(GS_WAVE - 1));
-        const int npairs = make_walk_rec(s_rec[threadIdx.x], live, u_, v_, cA, cB, cC, qmax, t0u, t1u, t0v, t1v,
+        int w0u = t0u, w1u = t1u, w0v = t0v, w1v = t1v;   // the part of the box the walk looks at (gs_common.h)
+        if (live && cull) gs_cull_box(u_, v_, cA, cB, cC, qmax, w0u, w1u, w0v, w1v);
+        const int npairs = make_walk_rec(s_rec[threadIdx.x], live, u_, v_, cA, cB, cC, qmax, w0u, w1u, w0v, w1v,
                                          bin_shift, ow);
         if (gs_mostly_heavy_wave(npairs)) {
             if (live)
-                for_each_emitting_bin(t0u, t1u, t0v, t1v, bin_shift, ow, cull, u_, v_, cA, cB, cC, qmax,
+                for_each_emitting_bin(w0u, w1u, w0v, w1v, bin_shift, ow, cull, u_, v_, cA, cB, cC, qmax,
                                       [&](int, int) { ++owned; });
         } else {
             walk_bins_balanced(recs, npairs, bin_shift, ow, cull, [&](int owner, int, int, bool survives) {
@@ -566,6 +568,7 @@ __global__ __launch_bounds__(GS_BLOCK) void make_keys_kernel(
         a0 = reinterpret_cast<const float4 *>(attrs + (size_t)GS_ATTR_STRIDE * i)[0];
         a1 = reinterpret_cast<const float4 *>(attrs + (size_t)GS_ATTR_STRIDE * i)[1];
         tile_box(a0.x, a0.y, a1.w, tw, height / GS_TILE_HEIGHT, t0u, t1u, t0v, t1v);
+        if (cull) gs_cull_box(a0.x, a0.y, a1.x, a1.y, a1.z, a0.w, t0u, t1u, t0v, t1v);   // as gs_preprocess
     }
     // The same walk on the same stored values as gs_preprocess: both kernels agree on which pairs survive.  A wave of
     // ordinary Gaussians (a few dozen bins each) deals its pairs to its lanes 64 at a time -- survivors are then met in

@@ -315,13 +315,14 @@ def blend_backward_partials(bin_start, payload, attrs, grad_image, acc_alpha, la
     return (partials, flags, mag, dbg) if debug_hits else (partials, flags, mag)
 
 
-def reduce_partials(slot_offsets, num_overlap_tiles, flags, partials, num_keys=None):
+def reduce_partials(slot_offsets, num_overlap_tiles, flags, partials, num_keys=None, attrs=None, width=0, height=0):
     """Per-Gaussian sum of its flagged slots, in slot order -> acc f32[M,12].  num_keys (optional): Gaussians with
-    no sort key on this GPU are written as zeros without looking at their slots."""
+    no sort key on this GPU are written as zeros without looking at their slots.  attrs + image size (optional): a
+    Gaussian with many slots is only looked at where it can have been blended (same sums, fewer flags read)."""
     m = slot_offsets.shape[0]
     acc = torch.empty((m, ACC_STRIDE), dtype=torch.float32, device=partials.device)
     call("gs_reduce_partials", ptr(slot_offsets), ptr(num_overlap_tiles), ptr(flags), ptr(partials), m, ptr(acc),
-         ptr(num_keys), int(partials.shape[0]), current_stream(partials.device))
+         ptr(num_keys), int(partials.shape[0]), ptr(attrs), int(width), int(height), current_stream(partials.device))
     return acc
 
 
@@ -330,7 +331,7 @@ def blend_backward(bin_start, payload, attrs, grad_image, acc_alpha, last_eff, s
     """-> (acc f32[M,12], magnitude_grad_viewspace_on_image f32[H,W,2]): blend_backward_partials + reduce_partials."""
     partials, flags, mag = blend_backward_partials(bin_start, payload, attrs, grad_image, acc_alpha, last_eff,
                                                    slot_offsets, n_slots, width, height, layout)
-    return reduce_partials(slot_offsets, num_overlap_tiles, flags, partials, num_keys), mag
+    return reduce_partials(slot_offsets, num_overlap_tiles, flags, partials, num_keys, attrs, width, height), mag
 
 
 def point_backward(xyz, features, object_id, intrinsics, q_cp, t_cp, t_pc, ids, acc, attrs, color_max_sh_band,
