@@ -26,7 +26,11 @@ def variant(name):
     elif name == "cluster_200k_faint":  # 200,000 faint Gaussians inside a 0.02-wide ball: ~2 x 2 tiles
         idx = torch.randperm(xyz.shape[0], device="cuda", generator=gen)[:200_000]
         xyz[idx] = 0.01 * torch.randn(len(idx), 3, device="cuda", generator=gen)
-        feat[idx, 7] = -6.0
+        feat[idx, 7] = -5.0           # opacity 0.0067: just above the 1/255 threshold, so that every one is blended
+    elif name == "cluster_200k_tiny":   # 200,000 pixel-sized Gaussians in a 0.02-wide ball: a few tiles with 1e5-entry
+        idx = torch.randperm(xyz.shape[0], device="cuda", generator=gen)[:200_000]   # lists that never saturate
+        xyz[idx] = 0.01 * torch.randn(len(idx), 3, device="cuda", generator=gen)
+        feat[idx, 4:7] = -7.5
     elif name == "invalid_87pct":      # trainer capacity: 7 of 8 rows free
         invalid[torch.rand(xyz.shape[0], device="cuda", generator=gen) < 0.875] = 1
     return xyz, feat, invalid
@@ -44,7 +48,8 @@ for name in os.environ.get("GS_CASES", "baseline,baseline,needles_10k,cluster_20
 
     def step():
         xyz.grad = None; feat.grad = None
-        image, _, _ = op(inp)
+        global count
+        image, _, count = op(inp)
         image.backward(g)
         return image
     for _ in range(6):
@@ -56,4 +61,5 @@ for name in os.environ.get("GS_CASES", "baseline,baseline,needles_10k,cluster_20
     torch.cuda.synchronize()
     ok = bool(torch.isfinite(image).all() and torch.isfinite(feat.grad).all())
     print(f"{name:22s} {(time.perf_counter() - t0) / 20 * 1e3:7.3f} ms per frame  (bin_shift "
-          f"{op.list_layout(s.height, s.width).bin_shift}, finite {ok}, {op.speculation_stats})")
+          f"{op.list_layout(s.height, s.width).bin_shift}, finite {ok}, {op.speculation_stats}, "
+          f"key capacity {max(v[0] for v in op._size_guesses.values())}, max blended per pixel {int(count.max())})")
