@@ -513,34 +513,36 @@ __global__ __launch_bounds__(BLEND_THREADS, GS_BWD_MIN_WAVES) void blend_backwar
 // ascending order and the 64 partial records are added in a fixed DPP order.  Either way the summation order depends
 // only on the slot layout, so gradients are bitwise reproducible.  Value 10 (pixel count) is summed as an integer.
 constexpr int RP_HEAVY = 128;
-#ifndef GS_RP_CHUNK
-#define GS_RP_CHUNK 4
+#ifndef GS_RP_MIN_BLOCKS
+#define GS_RP_MIN_BLOCKS 6   // workgroups per CU = waves per SIMD: the kernel lives on memory-level parallelism
 #endif
-constexpr int RP_CHUNK = GS_RP_CHUNK;   // raised slots fetched together (tools/build_variants.sh sweeps it)
+// raised slots fetched together by rp_add_group: 4 where the kernel has registers to spare (sixteen lanes per Gaussian:
+// stress scene 0.198 -> 0.146 ms), 2 in the one-lane-per-Gaussian kernel (4 costs it a wave per SIMD: 55 -> 62 us)
 struct SlotSum { float v[10]; int npix; };
+template <int CHUNK>
 __device__ __forceinline__ void rp_add_group(const uint8_t *__restrict__ flags, const float4 *__restrict__ partials,
                                              int first, int cnt, SlotSum &a) {
     unsigned mask = 0u;   // gather the flags of up to 32 consecutive slots (independent byte loads), then visit the
                           // raised ones (independent 48-B loads): many loads in flight instead of one at a time
     for (int r = 0; r < cnt; ++r) mask |= (flags[first + r] != 0 ? 1u : 0u) << r;
     while (mask) {
-        // up to RP_CHUNK raised slots per round: their 48-B records are all requested before the first one is added
+        // up to CHUNK raised slots per round: their 48-B records are all requested before the first one is added
         // (one record per round left the kernel waiting on a full memory latency per slot); added in ascending order
-        int r[RP_CHUNK];
-        float4 p[RP_CHUNK][3];
+        int r[CHUNK];
+        float4 p[CHUNK][3];
 #pragma unroll
-        for (int q = 0; q < RP_CHUNK; ++q) {
+        for (int q = 0; q < CHUNK; ++q) {
             r[q] = mask ? __builtin_ctz(mask) : -1;
             mask &= mask - 1;   // (0 stays 0)
         }
 #pragma unroll
-        for (int q = 0; q < RP_CHUNK; ++q)
+        for (int q = 0; q < CHUNK; ++q)
             if (r[q] >= 0) {
                 const float4 *src = partials + 3 * (size_t)(first + r[q]);
                 p[q][0] = src[0]; p[q][1] = src[1]; p[q][2] = src[2];
             }
 #pragma unroll
-        for (int q = 0; q < RP_CHUNK; ++q)
+        for (int q = 0; q < CHUNK; ++q)
             if (r[q] >= 0) {
                 a.v[0] += p[q][0].x; a.v[1] += p[q][0].y; a.v[2] += p[q][0].z; a.v[3] += p[q][0].w;
                 a.v[4] += p[q][1].x; a.v[5] += p[q][1].y; a.v[6] += p[q][1].z; a.v[7] += p[q][1].w;
@@ -553,7 +555,7 @@ __device__ __forceinline__ void rp_add_group(const uint8_t *__restrict__ flags, 
 // row) per Gaussian, lane l taking the slot groups l, l + 16, ... -- chosen by the host when Gaussians own many slots
 // on average (a wave full of heavy Gaussians would otherwise serialise them).
 template <int LANES>
-__global__ __launch_bounds__(GS_BLOCK) void reduce_partials_kernel(
+__global__ __launch_bounds__(GS_BLOCK, GS_RP_MIN_BLOCKS) void reduce_partials_kernel(
     const int32_t *__restrict__ slot_offsets, const int32_t *__restrict__ ntiles_full,
     const uint8_t *__restrict__ slot_flags, const float4 *__restrict__ partials, int m, float4 *__restrict__ acc,
     const int32_t *__restrict__ nkeys, const float4 *__restrict__ attrs, int tw, int th) {
@@ -567,14 +569,14 @@ __global__ __launch_bounds__(GS_BLOCK) void reduce_partials_kernel(
     for (int k = 0; k < 10; ++k) a.v[k] = 0.f;
     a.npix = 0;
     if (LANES > 1) {
-        for (int r0 = 4 * sub; r0 < n; r0 += 4 * LANES) rp_add_group(slot_flags, partials, base + r0, min(4, n - r0), a);
+        for (int r0 = 4 * sub; r0 < n; r0 += 4 * LANES) rp_add_group<(LANES > 1 ? 4 : 2)>(slot_flags, partials, base + r0, min(4, n - r0), a);
         // the LANES lanes of a Gaussian are one DPP row: totals land in lane 15 of the row
 #pragma unroll
         for (int k = 0; k < 10; ++k) a.v[k] = gs_row_sum_to_lane15(a.v[k]);
         a.npix = (int)gs_row_sum_to_lane15((float)a.npix);   // < 2^24: exact as a float
     } else {
         if (n <= RP_HEAVY)
-            for (int r0 = 0; r0 < n; r0 += 32) rp_add_group(slot_flags, partials, base + r0, min(32, n - r0), a);
+            for (int r0 = 0; r0 < n; r0 += 32) rp_add_group<2>(slot_flags, partials, base + r0, min(32, n - r0), a);
         // A heavy Gaussian's slots are the tiles of its reference box (column-major, gs_make_keys), but only tiles the
         // level set q <= qmax reaches can have been blended -- for a needle a thin diagonal of a huge square (10,000
         // screen-long needles: 6,000 slots each, 0.45 ms of flag scanning).  With the packed records at hand the wave
@@ -612,11 +614,11 @@ __global__ __launch_bounds__(GS_BLOCK) void reduce_partials_kernel(
                     ra = max(ra, k0v); rb = min(rb, k1v);
                     const int first = bL + nv * (cu - b0u) - b0v;   // slot of (cu, row) = first + row
                     for (int row = ra; row < rb; row += 4)
-                        rp_add_group(slot_flags, partials, first + row, min(4, rb - row), h);
+                        rp_add_group<2>(slot_flags, partials, first + row, min(4, rb - row), h);
                 }
             } else {
                 for (int r0_ = 4 * lane; r0_ < nL; r0_ += 4 * GS_WAVE)
-                    rp_add_group(slot_flags, partials, bL + r0_, min(4, nL - r0_), h);
+                    rp_add_group<2>(slot_flags, partials, bL + r0_, min(4, nL - r0_), h);
             }
 #pragma unroll
             for (int k = 0; k < 10; ++k) {
