@@ -15,7 +15,10 @@ namespace {
 
 constexpr int RADIX_BITS = 8;
 constexpr int RADIX = 1 << RADIX_BITS;
-constexpr int SORT_ROUNDS = 16;
+#ifndef GS_SORT_ROUNDS
+#define GS_SORT_ROUNDS 16   // (tuning variants: tools/build_variants.sh)
+#endif
+constexpr int SORT_ROUNDS = GS_SORT_ROUNDS;
 constexpr int SORT_ITEMS = GS_BLOCK * SORT_ROUNDS;  // keys per workgroup
 constexpr int WAVES = GS_BLOCK / GS_WAVE;
 
