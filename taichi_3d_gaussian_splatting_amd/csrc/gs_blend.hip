@@ -29,6 +29,9 @@ namespace {
 constexpr float EPS_ALPHA = (float)(1.0 / 255.0);  // RAS:451
 constexpr float CLAMP_ALPHA = 0.99f;               // RAS:453
 constexpr float STOP_T = 0.0001f;                  // RAS:458
+#ifndef GS_ABLATE_FWD
+#define GS_ABLATE_FWD 0   // 1: forward evaluates alpha but blends nothing (tools/build_variants.sh, measurements only)
+#endif
 #ifndef GS_GROUP_FWD
 #define GS_GROUP_FWD 4
 #endif
@@ -253,6 +256,11 @@ __global__ __launch_bounds__(BLEND_THREADS) void blend_forward_kernel(
                 alpha[i] = gs_pair_alpha(p, s_q[k + i], px, py, dx, dy);
                 z[i] = p.z;
             }
+#if GS_ABLATE_FWD == 1   // tuning only: evaluation without the blend (what the alpha evaluation of every visited entry costs)
+#pragma unroll
+            for (int i = 0; i < GROUP_FWD; ++i) { Cr = Cr + alpha[i]; last0 += (int)z[i]; }
+            continue;
+#endif
 #pragma unroll
             for (int i = 0; i < GROUP_FWD; ++i) {
                 // a = alpha for a live pixel (x * 1.0f is exact), 0 for a saturated one
