@@ -936,6 +936,19 @@ def test_operator_full_size_forward_backward(workload, tag):
     f = oracle_forward(s)
     report(f"{tag}.full_size", M=len(f["ids"]), K=len(f["keys"]))
     _operator_vs_oracle(tag, s, f)
+    # the comparisons above use a fresh operator per call: first frames, i.e. sizes read before the lists are built and
+    # per-tile keys.  A long-lived operator at this size switches to 2x2-tile bins after its first frame and launches the
+    # list stages speculatively from its third: same bits, whatever the frame's history
+    from taichi_3d_gaussian_splatting_amd import GaussianPointCloudRasterisation as Op
+    g = make_grad_image(s.height, s.width)
+    op = Op(Op.GaussianPointCloudRasterisationConfig(near_plane=s.near_plane, far_plane=s.far_plane,
+                                                     depth_to_sort_key_scale=s.depth_to_sort_key_scale))
+    frames = [_run_operator(s, g, op=op) for _ in range(4)]
+    layouts = [op._auto_bin_shift]   # (after the last frame)
+    assert op.list_layout(s.height, s.width).bin_shift == 1 and op.speculation_stats == {"frames": 4, "redone": 0}
+    for image, depth, count, xyz, feat in frames[1:]:
+        assert torch.equal(image, frames[0][0]) and torch.equal(depth, frames[0][1]) and torch.equal(count, frames[0][2])
+        assert torch.equal(feat.grad, frames[0][4].grad) and torch.equal(xyz.grad, frames[0][3].grad)
 
 
 def test_reference_stress_distribution_runs():
