@@ -223,6 +223,13 @@ class GaussianPointCloudRasterisation(torch.nn.Module):
                 readback.start(counters)
                 num_bins = layout.num_bins(width, height)
                 rgb_only = bool(cfg.rgb_only)
+                # multi-GPU with the default (un-weighted) bands: outputs are allocated so that the all-gather of the
+                # other ranks' rows runs in place (distributed.all_gather_tile_rows)
+                gathered_rows = 0
+                if outer.image_gather is not None and outer.shard is not None and outer.shard[2] == "bands" and \
+                        outer.shard_row_weights is None:
+                    from .distributed import padded_image_rows
+                    gathered_rows = padded_image_rows(height, outer.shard[1])
 
                 def lists_and_blend(attrs_, nkeys_, bsums_, bsums_full_, ntiles_, n_keys_, max_depth_key_, counters_):
                     # RAS:927-945 keys (one per (bin, Gaussian)), RAS:947-950 stable sort, RAS:952-964 list ranges,
@@ -241,7 +248,8 @@ class GaussianPointCloudRasterisation(torch.nn.Module):
                     start_, end_ = hip_ops.tile_ranges(keys, num_bins, kdb, n_keys_device=n_dev)
                     del keys
                     blended = hip_ops.blend_forward(start_, end_, payload_, attrs_, width, height, layout,
-                                                    rgb_only=rgb_only, need_state=need_state)
+                                                    rgb_only=rgb_only, need_state=need_state,
+                                                    gathered_rows=gathered_rows)
                     return payload_, slot_offsets_, start_, blended
 
                 guess_key = (width, height, layout, cfg.near_plane, cfg.far_plane, cfg.depth_to_sort_key_scale)

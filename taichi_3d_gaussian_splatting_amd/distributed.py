@@ -2,12 +2,13 @@
 
 The reference is single-GPU (no collective anywhere); this is the
 multi-GPU path BASELINE.json's north_star defines: the point cloud is replicated, GPU ``g`` of ``G``
-owns the interleaved 16-pixel tile rows ``g, g+G, g+2G, ...`` (interleaving balances the load), runs
-binning/sort/blend only for its rows, and ONE all-gather (RCCL over xGMI; ``backend="nccl"`` is
-RCCL on ROCm) assembles the full image on every rank.  In the backward pass every rank
-back-propagates its own tiles and the per-Gaussian accumulators (48 B x M, not the 236 B x N dense
-gradients) are summed with one all-reduce before the per-point chain rule, so every rank ends up
-with the full gradient of its replicated parameters.
+owns a contiguous band of 16-pixel tile rows (default; interleaved rows ``g, g+G, ...`` as the alternative), runs
+binning/sort/blend only for its rows, and the full image is assembled on every rank by all-gathers (RCCL over xGMI;
+``backend="nccl"`` is RCCL on ROCm): with the default bands each output tensor is gathered IN PLACE (the rasteriser
+allocates it so that every band is an equal slice), otherwise the bands are packed into one buffer and gathered with
+one collective.  In the backward pass every rank back-propagates its own tiles and the per-Gaussian accumulators
+(48 B x M, not the 236 B x N dense gradients) are summed with one all-reduce before the per-point chain rule, so every
+rank ends up with the full gradient of its replicated parameters.
 
 One process per GPU (``torch.distributed``); works unchanged on ``gloo`` for the CPU tests of the
 collective logic (tests/test_distributed_cpu.py).
@@ -37,12 +38,27 @@ def owned_tile_rows(num_tile_rows: int, rank: int, world: int, mode: str = "band
     return range(bounds[rank], bounds[rank + 1])
 
 
+def uniform_band_rows(num_tile_rows: int, world: int) -> int:
+    """Tile rows per band of the un-weighted band split."""
+    return -(-num_tile_rows // world)
+
+
+def padded_image_rows(height: int, world: int) -> int:
+    """Pixel rows an output tensor needs so that the un-weighted bands of all ``world`` ranks are equally long slices of
+    it (the last ones reaching past the image): the rasteriser allocates its outputs with that many rows and returns the
+    first ``height`` -- ``all_gather_tile_rows`` then gathers straight into them."""
+    return uniform_band_rows(height // TILE_HEIGHT, world) * world * TILE_HEIGHT
+
+
 def band_boundaries(num_tile_rows: int, world: int, row_weights: Optional[Sequence[float]] = None) -> list:
     """world + 1 non-decreasing row indices, 0 .. num_tile_rows: band g = rows [b[g], b[g+1]).  With weights, band g
     ends at the first row where the running weight reaches (g+1)/world of the total (deterministic: every rank
     computes the same boundaries from the same replicated weights)."""
     if row_weights is None or len(row_weights) != num_tile_rows or float(sum(row_weights)) <= 0.0:
-        return [(g * num_tile_rows) // world for g in range(world + 1)]
+        # equal blocks of ceil(rows / world) rows, the last band(s) shorter: the longest band is as long as in any other
+        # even split, and every band sits at a multiple of the block size -- what lets the all-gather run in place
+        block = uniform_band_rows(num_tile_rows, world)
+        return [min(g * block, num_tile_rows) for g in range(world + 1)]
     total = float(sum(row_weights))
     bounds, run, g = [0], 0.0, 1
     for r, w in enumerate(row_weights):
@@ -66,6 +82,16 @@ def all_gather_tile_rows(tensors: Sequence[torch.Tensor], rank: int, world: int,
         return
     height = tensors[0].shape[0]
     th = height // TILE_HEIGHT
+    if mode == "bands" and row_weights is None and all(_padded_base(t, height, world) is not None for t in tensors):
+        # un-weighted bands in outputs allocated with padded_image_rows(): band g IS the g-th equal slice of the padded
+        # tensor, so each tensor is gathered where it lies -- no packing, no unpacking (the packed path below costs
+        # 3 + 3 (G - 1) small copy kernels per frame).  RCCL/NCCL gather in place when the send buffer is the rank's own
+        # slice of the receive buffer; other back ends (gloo on the CPU tests) get a copy of the slice.
+        in_place = dist.get_backend(group) == "nccl"
+        for t in tensors:
+            slices = _padded_base(t, height, world).view(world, -1)
+            dist.all_gather_into_tensor(slices.view(-1), slices[rank] if in_place else slices[rank].clone(), group=group)
+        return
     rows = [owned_tile_rows(th, g, world, mode, row_weights) for g in range(world)]
     max_rows = max(len(r) for r in rows)
     mine = rows[rank]
@@ -90,6 +116,15 @@ def all_gather_tile_rows(tensors: Sequence[torch.Tensor], rank: int, world: int,
         for g, r in enumerate(rows):
             if g != rank and len(r) > 0:
                 v[r.start:r.stop:r.step].copy_(block[g, :len(r)])
+
+
+def _padded_base(t: torch.Tensor, height: int, world: int):
+    """The padded allocation ``t`` is the first ``height`` rows of (see padded_image_rows), or None."""
+    base = t._base
+    if base is None or not t.is_contiguous() or not base.is_contiguous() or base.data_ptr() != t.data_ptr() or \
+            base.dim() != t.dim() or base.shape[1:] != t.shape[1:] or base.shape[0] != padded_image_rows(height, world):
+        return None
+    return base
 
 
 _replica_checks = {"calls": 0}

@@ -274,7 +274,7 @@ BLEND_NO_STATE = 2      # GS_BLEND_NO_STATE: no acc_alpha / last_effective (noth
 
 
 def blend_forward(bin_start, bin_end, payload, attrs, width, height, layout: ListLayout = ListLayout(),
-                  out=None, rgb_only=False, need_state=True, debug_hits=False):
+                  out=None, rgb_only=False, need_state=True, debug_hits=False, gathered_rows: int = 0):
     """-> (image, depth, acc_alpha, last_effective, count).  rgb_only: depth and count are not computed (returned
     as None); need_state=False: acc_alpha / last_effective are not computed (None) -- the inference path.
     debug_hits=True appends a uint32-as-int32 [H,W,2] tensor {blended count, hash of blended payloads} per pixel."""
@@ -284,9 +284,19 @@ def blend_forward(bin_start, bin_end, payload, attrs, width, height, layout: Lis
         alloc = torch.zeros if layout.sharded else torch.empty  # un-owned tiles are left untouched
         f32 = lambda *shape: alloc(shape, dtype=torch.float32, device=dev)   # noqa: E731
         i32 = lambda *shape: alloc(shape, dtype=torch.int32, device=dev)     # noqa: E731
-        out = (f32(height, width, 3), None if rgb_only else f32(height, width),
-               f32(height, width) if need_state else None, i32(height, width) if need_state else None,
-               None if rgb_only else i32(height, width))
+        if gathered_rows >= height:
+            # the caller all-gathers image / depth / count over the ranks of a tile-row sharding: allocated with
+            # `gathered_rows` rows (distributed.padded_image_rows) so that the gather runs in place, returned as their
+            # first `height` rows, and not zero-filled -- every row is either rendered here or received
+            g32 = lambda dt, *shape: torch.empty((gathered_rows,) + shape[1:], dtype=dt, device=dev)[:height]   # noqa: E731
+            out = (g32(torch.float32, height, width, 3), None if rgb_only else g32(torch.float32, height, width),
+                   torch.empty((height, width), dtype=torch.float32, device=dev) if need_state else None,
+                   torch.empty((height, width), dtype=torch.int32, device=dev) if need_state else None,
+                   None if rgb_only else g32(torch.int32, height, width))
+        else:
+            out = (f32(height, width, 3), None if rgb_only else f32(height, width),
+                   f32(height, width) if need_state else None, i32(height, width) if need_state else None,
+                   None if rgb_only else i32(height, width))
     image, depth, acc_alpha, last_eff, count = out
     dbg = torch.zeros((height, width, 2), dtype=torch.int32, device=dev) if debug_hits else None
     call("gs_blend_forward", ptr(bin_start), ptr(bin_end), ptr(payload), ptr(attrs), int(width), int(height),

@@ -14,7 +14,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, height, width, mode, weights):
+def _worker(rank, world, port, height, width, mode, weights, padded=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -33,6 +33,15 @@ def _worker(rank, world, port, height, width, mode, weights):
     image = torch.where(own[:, None, None], full_image, torch.zeros_like(full_image)).contiguous()
     depth = torch.where(own[:, None], full_depth, torch.zeros_like(full_depth)).contiguous()
     count = torch.where(own[:, None], full_count, torch.zeros_like(full_count)).contiguous()
+    if padded:   # outputs as the sharded rasteriser allocates them: first rows of a padded tensor, un-owned rows garbage
+        from taichi_3d_gaussian_splatting_amd.distributed import _padded_base, padded_image_rows
+
+        def as_padded(t):
+            base = torch.full((padded_image_rows(height, world),) + t.shape[1:], 77, dtype=t.dtype)
+            base[:height][own] = t[own]
+            return base[:height]
+        image, depth, count = as_padded(image), as_padded(depth), as_padded(count)
+        assert all(_padded_base(t, height, world) is not None for t in (image, depth, count))
     all_gather_tile_rows([image, depth, count], rank, world, mode=mode, row_weights=weights)
     assert torch.equal(image, full_image) and torch.equal(depth, full_depth) and torch.equal(count, full_count)
 
@@ -50,8 +59,14 @@ def _worker(rank, world, port, height, width, mode, weights):
     dist.destroy_process_group()
 
 
-def _run(world, height, width, mode="bands", weights=None):
-    mp.spawn(_worker, args=(world, _free_port(), height, width, mode, weights), nprocs=world, join=True)
+def _run(world, height, width, mode="bands", weights=None, padded=False):
+    mp.spawn(_worker, args=(world, _free_port(), height, width, mode, weights, padded), nprocs=world, join=True)
+
+
+def test_all_gather_in_place_for_padded_outputs_world2_and_3():
+    """Un-weighted bands in outputs allocated with padded_image_rows(): every tensor is gathered where it lies."""
+    _run(2, 17 * 16, 64, padded=True)    # 17 tile rows: bands of 9 + 8 rows, padded to 18
+    _run(3, 16 * 16, 48, padded=True)    # 16 tile rows: 6 + 6 + 4, padded to 18
 
 
 def test_all_gather_tile_rows_and_grad_reduce_world2():
@@ -83,5 +98,6 @@ def test_owned_rows_partition():
     assert b[0] == 0 and b[-1] == 67 and b == sorted(b)
     loads = [sum(w[b[g]:b[g + 1]]) for g in range(4)]
     assert max(loads) <= 1.35 * sum(w) / 4
-    assert band_boundaries(67, 8) == [(g * 67) // 8 for g in range(9)]
+    assert band_boundaries(67, 8) == [0, 9, 18, 27, 36, 45, 54, 63, 67]   # equal blocks of ceil(67 / 8), last one shorter
+    assert band_boundaries(16, 3) == [0, 6, 12, 16] and band_boundaries(2, 4) == [0, 1, 2, 2, 2]
     assert band_boundaries(5, 3, [0.0, 0.0, 10.0, 0.5, 0.5]) == [0, 3, 3, 5]   # the heavy row fills two shares

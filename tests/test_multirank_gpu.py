@@ -45,7 +45,8 @@ def _worker(rank, world, port, n, height, width, mode):
                 if mode == "interleaved":
                     assert (lay.row_begin, lay.row_step) == (rank, world)
                 else:
-                    assert (lay.row_begin, lay.row_step, lay.row_end) == ((rank * th) // world, 1, ((rank + 1) * th) // world)
+                    block = -(-th // world)   # equal blocks of ceil(rows / world): the all-gather runs in place
+                    assert (lay.row_begin, lay.row_step, lay.row_end) == (min(rank * block, th), 1, min((rank + 1) * block, th))
             image, depth, count = op(Op.GaussianPointCloudRasterisationInput(
                 point_cloud=xyz, point_cloud_features=feat, point_object_id=s.point_object_id,
                 point_invalid_mask=s.point_invalid_mask,
