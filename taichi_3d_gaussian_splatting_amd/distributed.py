@@ -151,9 +151,9 @@ def all_reduce_accumulators(acc: torch.Tensor, group: Optional[dist.ProcessGroup
     pixel count is < 2^24, so the float sum is exact in any order) and back to integer bits afterwards."""
     _check_replicas_agree(acc.shape[0], acc.device, group)
     col = acc[:, 10]
-    col.copy_(col.view(torch.int32).to(torch.float32))
+    col.copy_(col.view(torch.int32))            # int32 bits -> float value, one converting copy over the same memory
     dist.all_reduce(acc, op=dist.ReduceOp.SUM, group=group)
-    col.view(torch.int32).copy_(col.round().to(torch.int32))
+    col.view(torch.int32).copy_(col)            # the sum of integers below 2^24 is an integer: exact conversion back
 
 
 def shard_rasteriser_across_tile_rows(rasteriser, group: Optional[dist.ProcessGroup] = None, force: bool = False,
