@@ -721,6 +721,15 @@ def test_speculative_sizes_overflow_is_redone(scene):
     op.speculative_sizes = False                                  # the two-halves path still works
     got, ref = _run_operator(scene, g, op=op), fresh(scene)
     assert torch.equal(got[0], ref[0]) and torch.equal(got[4].grad, ref[4].grad)
+    # frames with nothing on screen in between (every point invalid): zero keys under a non-zero capacity and back
+    import copy
+    nothing = copy.deepcopy(scene)
+    nothing.point_invalid_mask = torch.ones_like(scene.point_invalid_mask)
+    op3 = Op(cfg)
+    for sc in (scene, nothing, scene, nothing, nothing, scene, scene):
+        got, ref = _run_operator(sc, g, op=op3), fresh(sc)
+        assert torch.equal(got[0], ref[0]) and torch.equal(got[2], ref[2]) and torch.equal(got[4].grad, ref[4].grad)
+    assert not _run_operator(nothing, g, op=op3)[0].any()
     # a data set that mixes image sizes keeps speculating: one size guess per (image size, layout, planes)
     small = small_scene(n=2000, size=128, seed=6)
     g_small = make_grad_image(small.height, small.width)
