@@ -287,6 +287,8 @@ class GaussianPointCloudRasterisation(torch.nn.Module):
                 else:
                     choice = 1 if k_frame < 3 * m else used
                 outer._auto_bin_shift = choice
+                if len(outer._auto_bin_shift_by_size) >= 64 and (width, height) not in outer._auto_bin_shift_by_size:
+                    outer._auto_bin_shift_by_size.pop(next(iter(outer._auto_bin_shift_by_size)))   # bounded
                 outer._auto_bin_shift_by_size[(width, height)] = outer._auto_bin_shift   # cameras of several sizes
                 fits = guess is not None and n_keys <= guess[0] and max_depth_key <= guess[1]
                 outer.speculation_stats["frames"] += 1
