@@ -310,6 +310,17 @@ int gs_adam_step_features(float *features, const float *grad, float *exp_avg, fl
                           const int8_t *point_invalid_mask, double scale_regulariser_weight, int32_t *workspace,
                           void *stream);
 
+/* Adam over the rows of a fixed-capacity tensor ([N,3] positions or [N,56] features) that skips the rows of invalid
+ * points: they are neither read nor written.  The moments of a skipped row decay lazily -- last_step[row] (int32[N],
+ * zero-initialised, owned by the caller next to the moments) is the last step that updated the row, and the first update
+ * after a gap of d steps starts from exp_avg * beta1^d, exp_avg_sq * beta2^d, what d zero-gradient steps of
+ * torch.optim.Adam leave behind (TRN:126-129 runs torch.optim.Adam over the full capacity, 10x the points in the
+ * reference's Truck configuration).  scale_regulariser_weight != 0 (56-float rows only): as gs_adam_step_features;
+ * workspace: int32[256] then. */
+int gs_adam_step_rows(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, long long n_rows, int row_len,
+                      double lr, double beta1, double beta2, double eps, int step, const int8_t *point_invalid_mask,
+                      int32_t *last_step, double scale_regulariser_weight, int32_t *workspace, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -284,6 +284,9 @@ class GaussianPointCloudTrainer:
         batches = cycle(train_loader)
         feature_optimizer = Adam([self.scene.point_cloud_features], lr=cfg.feature_learning_rate, betas=(0.9, 0.999))
         position_optimizer = Adam([self.scene.point_cloud], lr=cfg.position_learning_rate, betas=(0.9, 0.999))
+        # fixed-capacity tensors (max_num_points_ratio): the rows without a point are not stepped
+        feature_optimizer.set_row_mask(self.scene.point_cloud_features, self.scene.point_invalid_mask)
+        position_optimizer.set_row_mask(self.scene.point_cloud, self.scene.point_invalid_mask)
         regularised = self.loss_function.config.enable_regularization
         if regularised:
             feature_optimizer.set_scale_regulariser(self.scene.point_cloud_features,

@@ -17,7 +17,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # GS_LIB_PATH: development knob (tuning sweeps load differently built variants of the library); default = in-tree build
 LIB_PATH = os.environ.get("GS_LIB_PATH") or os.path.join(_HERE, "libgsplat_hip.so")
-ABI_VERSION = 22
+ABI_VERSION = 23
 
 _c = ctypes
 _P = _c.c_void_p
@@ -52,6 +52,8 @@ _SIGNATURES = {
     "gs_adam_step": (_I, [_P, _P, _P, _P, _c.c_longlong, _c.c_double, _c.c_double, _c.c_double, _c.c_double, _I, _P]),
     "gs_adam_step_features": (_I, [_P, _P, _P, _P, _c.c_longlong, _c.c_double, _c.c_double, _c.c_double, _c.c_double,
                                    _I, _P, _c.c_double, _P, _P]),
+    "gs_adam_step_rows": (_I, [_P, _P, _P, _P, _c.c_longlong, _I, _c.c_double, _c.c_double, _c.c_double, _c.c_double, _I,
+                           _P, _P, _c.c_double, _P, _P]),
     "gs_controller_accumulate": (_I, [_P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P]),
     "gs_ellipsoid_offsets": (_I, [_P, _I, _P, _P]),
     "gs_sample_from_points": (_I, [_P, _P, _P, _I, _P, _P]),

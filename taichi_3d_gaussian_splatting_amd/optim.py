@@ -18,6 +18,21 @@ class Adam(torch.optim.Optimizer):
             raise ValueError("invalid Adam hyper-parameters")
         super().__init__(params, dict(lr=lr, betas=tuple(betas), eps=eps))
         self._scale_regulariser = {}   # id(param) -> (weight, point_invalid_mask)
+        self._row_mask = {}            # id(param) -> point_invalid_mask: rows of invalid points are skipped
+
+    def set_row_mask(self, param: torch.Tensor, point_invalid_mask: torch.Tensor) -> None:
+        """``param`` is a fixed-capacity [N,3] or [N,56] tensor with one row per point and ``point_invalid_mask`` (int8 [N],
+        the live tensor -- it is read at every step) marks the rows without a point: those rows are not touched by the
+        step.  Their gradient is zero, so ``torch.optim.Adam`` would only decay their moments and move parameters that
+        are overwritten before they are read again; the decay is applied lazily when a row comes back to life
+        (``state["last_step"]``), so a row's moments are what ``torch.optim.Adam`` would hold.  With the reference's
+        capacity of 10x the initial points (config/tat_truck_every_8_test.yaml:20) most rows are free for most of a
+        run."""
+        if param.dim() != 2 or param.shape[1] not in (3, 56) or point_invalid_mask.shape != (param.shape[0],):
+            raise ValueError("set_row_mask: [N,3] or [N,56] parameter and an [N] mask")
+        if point_invalid_mask.dtype != torch.int8:
+            raise TypeError("point_invalid_mask must be int8")
+        self._row_mask[id(param)] = point_invalid_mask
 
     def set_scale_regulariser(self, features: torch.Tensor, weight: float, point_invalid_mask: torch.Tensor) -> None:
         """Fuse the gradient of ``weight * mean_live ||exp(features[:, 4:7])||`` (the trainer's scale regulariser,
@@ -52,6 +67,17 @@ class Adam(torch.optim.Optimizer):
                     state["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
                 state["step"] = int(state["step"]) + 1
                 reg = self._scale_regulariser.get(id(p))
+                mask = self._row_mask.get(id(p))
+                if mask is not None:
+                    if "last_step" not in state:
+                        state["last_step"] = torch.zeros(p.shape[0], dtype=torch.int32, device=p.device)
+                    weight = reg[0] if reg is not None else 0.0
+                    ws = torch.empty(256, dtype=torch.int32, device=p.device) if weight else None
+                    call("gs_adam_step_rows", ptr(p), ptr(grad), ptr(state["exp_avg"]), ptr(state["exp_avg_sq"]),
+                         p.shape[0], p.shape[1], float(group["lr"]), float(beta1), float(beta2), float(group["eps"]),
+                         state["step"], ptr(mask), ptr(state["last_step"]), float(weight), ptr(ws),
+                         current_stream(p.device))
+                    continue
                 if reg is not None:
                     weight, mask = reg
                     ws = torch.empty(256, dtype=torch.int32, device=p.device)

@@ -387,6 +387,56 @@ def test_controller_statistics_kernel_matches_eager_update():
     assert torch.isfinite(b.accumulated_view_space_position_gradients_avg).all()
 
 
+def test_adam_skipping_rows_of_invalid_points_matches_torch_adam_on_the_live_rows():
+    """optim.Adam.set_row_mask: the rows of invalid points are not stepped; their moments decay lazily.  Against
+    torch.optim.Adam stepping EVERY row (zero gradient on the invalid ones) through 90 steps in which points die and
+    rows are re-used with new parameters (as the controller does): parameters and moments of the live rows agree, and an
+    invalid row is left untouched."""
+    from taichi_3d_gaussian_splatting_amd.optim import Adam
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(9)
+    n = 3000
+    invalid = (torch.rand(n, device=dev, generator=g) < 0.6).to(torch.int8)     # capacity mostly free, as in training
+    mine = [torch.nn.Parameter(torch.randn(n, 56, device=dev, generator=g)),
+            torch.nn.Parameter(torch.randn(n, 3, device=dev, generator=g))]
+    ref = [torch.nn.Parameter(p.detach().clone()) for p in mine]
+    opt_a = Adam(mine, lr=5e-3)
+    for p in mine:
+        opt_a.set_row_mask(p, invalid)
+    opt_b = torch.optim.Adam(ref, lr=5e-3, foreach=False, fused=False)
+    frozen = None
+    for it in range(90):
+        live = (invalid == 0)
+        for a, b in zip(mine, ref):
+            grad = torch.randn(a.shape, device=dev, generator=g) * live[:, None]   # invalid points receive no gradient
+            grad[::5] = 0.0                                                         # (nor do invisible live ones)
+            a.grad, b.grad = grad.clone(), grad.clone()
+        if it == 40:
+            frozen = (int(torch.nonzero(invalid)[0]), [p.detach()[int(torch.nonzero(invalid)[0])].clone() for p in mine])
+        opt_a.step(); opt_b.step()
+        if it == 40:
+            row, before = frozen
+            assert all(torch.equal(p.detach()[row], q) for p, q in zip(mine, before)), "an invalid row was stepped"
+        if it % 9 == 4:   # "refinement": some points die, some free rows are re-used with fresh parameters
+            die = live & (torch.rand(n, device=dev, generator=g) < 0.15)
+            revive = (~live) & (torch.rand(n, device=dev, generator=g) < 0.2)
+            invalid[die] = 1
+            invalid[revive] = 0
+            with torch.no_grad():
+                for a, b in zip(mine, ref):
+                    fresh = torch.randn(int(revive.sum()), a.shape[1], device=dev, generator=g)
+                    a[revive] = fresh
+                    b[revive] = fresh
+    live = invalid == 0
+    sa, sb = opt_a.state_dict()["state"], opt_b.state_dict()["state"]
+    for k, (a, b) in enumerate(zip(mine, ref)):
+        assert torch.allclose(a[live], b[live], rtol=1e-5, atol=1e-6), (a[live] - b[live]).abs().max()
+        for name in ("exp_avg", "exp_avg_sq"):
+            ma, mb = sa[k][name][live], sb[k][name][live]
+            assert (ma - mb).abs().max() <= 2e-5 * mb.abs().max(), (name, float((ma - mb).abs().max()), float(mb.abs().max()))
+    assert int(live.sum()) > 300 and int((~live).sum()) > 300
+
+
 def test_adam_with_fused_scale_regulariser_matches_explicit_gradient():
     """optim.Adam.set_scale_regulariser (gradient added inside the Adam kernel) vs the explicit path
     (LossFunction.add_regularization_gradient_ then a plain step): same parameters after several steps."""
