@@ -280,24 +280,14 @@ __device__ __forceinline__ void gs_view_colour(const float W[9], const float t[3
 }
 
 // ------------------------------------------------------------------ coalesced access to 224-B feature rows
-// The feature matrix is AoS (56 floats = 14 x 16 B per Gaussian, owned by the caller).  A lane reading its own
-// row with 16-B loads makes every load instruction touch 64 different cache lines.  Instead the wave moves its
-// 64 rows cooperatively: 14 consecutive lanes handle the 14 float4 of one row (4 rows = 56 lanes per
-// instruction, 16 instructions per wave), staged through LDS so that each lane then owns its whole row.
+// The feature matrix is AoS (56 floats = 14 x 16 B per Gaussian, owned by the caller).  A lane writing its own
+// row with 16-B stores makes every store instruction touch 64 different cache lines.  Instead the wave moves its
+// 64 rows cooperatively: every lane puts its row into LDS, then 14 consecutive lanes write the 14 float4 of one row
+// (4 rows = 56 lanes per instruction, 16 instructions per wave).  (The reading direction was measured 6 % slower in
+// gs_preprocess -- it lowers the occupancy of a kernel that lives on memory-level parallelism -- and is not kept.)
 // rows = this wave's LDS staging area: 64 rows x GS_ROW_F4 float4 (the 15th float4 pads the row to 240 B,
 // which keeps the per-lane ds_read_b128 of one 16-lane group on distinct banks).
 #define GS_ROW_F4 15
-__device__ __forceinline__ void gs_rows_global_to_lds(const float4 *__restrict__ base, int my_row_id,
-                                                      float4 *__restrict__ rows) {
-    const int lane = gs_lane(), sub = lane / 14, c = lane - 14 * sub;
-#pragma unroll 4
-    for (int it = 0; it < 16; ++it) {
-        const int rr = it * 4 + sub;                        // row of this wave handled by my 14-lane group
-        const int rid = __shfl(my_row_id, rr & 63, GS_WAVE);  // its global row index (-1: no row)
-        if (lane < 56 && rid >= 0) rows[rr * GS_ROW_F4 + c] = base[(size_t)rid * 14 + c];
-    }
-    __builtin_amdgcn_wave_barrier();
-}
 __device__ __forceinline__ void gs_rows_lds_to_global(float4 *__restrict__ base, int my_row_id,
                                                       const float4 *__restrict__ rows) {
     __builtin_amdgcn_wave_barrier();
@@ -310,59 +300,18 @@ __device__ __forceinline__ void gs_rows_lds_to_global(float4 *__restrict__ base,
     }
 }
 
-// ------------------------------------------------------------------ 10-value wave reduce-scatter
-// Sums ten per-lane partials over the 64 lanes of a wave in 30 VALU instructions (6 x 10 = 60 with
+// ------------------------------------------------------------------ 12-value wave reduce-scatter
+// Sums twelve per-lane partials over the 64 lanes of a wave in 34 VALU instructions (6 x 12 = 72 with
 // the plain DPP ladder): two swap+add levels use gfx950's v_permlane32_swap / v_permlane16_swap to
-// halve the number of live registers (10 -> 5 -> 3), then four DPP row steps finish each register.
+// halve the number of live registers (12 -> 6 -> 3), then four DPP row steps finish each register.
 // On return the totals sit in lane 15 of each 16-lane row:
-//   t0: rows 0..3 = (x0, x2, x1, x3)   t1: rows = (x4, x6, x5, x7)   t2: rows = (x8, x8, x9, x9)
+//   t0: rows 0..3 = (x0, x2, x1, x3)   t1: rows = (x4, x6, x5, x7)   t2: rows = (x8, x10, x9, x11)
 // Hand-scheduled inline asm because (a) ROCm 7.2's clang returns element 0 for BOTH results of the
 // __builtin_amdgcn_permlane*_swap builtins and (b) hazards are not visible through an asm statement:
 // the leading s_nop covers "VALU write -> permlane read"; every other dependent pair below is separated
 // by >= 2 independent instructions (DPP / permlane reads of a just-written VGPR need 2 wait states).
 // Swap semantics verified on hardware: v_permlane32_swap exchanges vdst[63:32] with src0[31:0];
 // v_permlane16_swap exchanges the odd rows of vdst with the even rows of src0.
-__device__ __forceinline__ void gs_wave_reduce10(float x0, float x1, float x2, float x3, float x4, float x5,
-                                                 float x6, float x7, float x8, float x9, float &t0, float &t1,
-                                                 float &t2) {
-    float x10;
-    asm("s_nop 1\n\t"
-        "v_permlane32_swap_b32 %0, %1\n\t"   // (x0,x1): lanes<32 of x0+x1 -> sum x0, lanes>=32 -> sum x1
-        "v_permlane32_swap_b32 %2, %3\n\t"
-        "v_permlane32_swap_b32 %4, %5\n\t"
-        "v_permlane32_swap_b32 %6, %7\n\t"
-        "v_permlane32_swap_b32 %8, %9\n\t"
-        "v_add_f32 %0, %0, %1\n\t"
-        "v_add_f32 %2, %2, %3\n\t"
-        "v_add_f32 %4, %4, %5\n\t"
-        "v_add_f32 %6, %6, %7\n\t"
-        "v_add_f32 %8, %8, %9\n\t"
-        "v_mov_b32 %10, %8\n\t"
-        "v_permlane16_swap_b32 %0, %2\n\t"   // even rows: x0|x1 sums, odd rows: x2|x3 sums
-        "v_permlane16_swap_b32 %4, %6\n\t"
-        "v_permlane16_swap_b32 %8, %10\n\t"
-        "v_add_f32 %0, %0, %2\n\t"
-        "v_add_f32 %4, %4, %6\n\t"
-        "v_add_f32 %8, %8, %10\n\t"
-        "v_add_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-        "v_add_f32_dpp %4, %4, %4 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-        "v_add_f32_dpp %8, %8, %8 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-        "v_add_f32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-        "v_add_f32_dpp %4, %4, %4 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-        "v_add_f32_dpp %8, %8, %8 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-        "v_add_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xe\n\t"
-        "v_add_f32_dpp %4, %4, %4 row_shr:4 row_mask:0xf bank_mask:0xe\n\t"
-        "v_add_f32_dpp %8, %8, %8 row_shr:4 row_mask:0xf bank_mask:0xe\n\t"
-        "v_add_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xc\n\t"
-        "v_add_f32_dpp %4, %4, %4 row_shr:8 row_mask:0xf bank_mask:0xc\n\t"
-        "v_add_f32_dpp %8, %8, %8 row_shr:8 row_mask:0xf bank_mask:0xc\n\t"
-        "s_nop 1"
-        : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7), "+v"(x8), "+v"(x9),
-          "=&v"(x10));
-    t0 = x0; t1 = x4; t2 = x8;
-}
-// Twelve-value variant (same scheme, no odd register to duplicate: 12 -> 6 -> 3, then four DPP row steps each):
-//   t0: rows 0..3 = (x0, x2, x1, x3)   t1: rows = (x4, x6, x5, x7)   t2: rows = (x8, x10, x9, x11)
 __device__ __forceinline__ void gs_wave_reduce12(float x0, float x1, float x2, float x3, float x4, float x5,
                                                  float x6, float x7, float x8, float x9, float x10, float x11,
                                                  float &t0, float &t1, float &t2) {

@@ -49,8 +49,6 @@ __device__ __forceinline__ void matmul(const float *A, const float *B, float *C)
         }
 }
 
-__device__ __forceinline__ float sigmoidf(float x) { return 1.f / (1.f + expf(-x)); }
-
 __device__ __forceinline__ void tile_box(float u, float v, float r, int tw, int th, int &t0u, int &t1u,
                                          int &t0v, int &t1v) {
     gs_tile_box(u, v, r, tw, th, t0u, t1u, t0v, t1v);
