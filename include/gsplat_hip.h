@@ -197,13 +197,16 @@ int gs_blend_forward(const int32_t *bin_start, const int32_t *bin_end, const int
  * The walk starts at the tile-wide maximum of last_effective and runs down to bin_start; bin_shift and filter
  * must be the forward's.  alpha is evaluated by the same device function as in gs_blend_forward and the staging
  * filter is the same function on the same records, so both passes treat exactly the same (pixel, Gaussian)
- * pairs as blended.  debug_pixel_hits: see gs_blend_forward. */
+ * pairs as blended.  debug_pixel_hits: see gs_blend_forward.
+ * tile_order (may be NULL): int32[number of owned tiles], a permutation of 0 .. n-1 (n-th owned tile in row-major
+ * order over the owned rows): the order in which tiles are handed to the hardware dispatcher -- longest walks first
+ * shortens the tail of the launch; results do not depend on it. */
 int gs_blend_backward(const int32_t *bin_start, const int32_t *payload, const float *attrs,
                       const float *grad_image, const float *acc_alpha, const int32_t *last_effective,
                       const int32_t *slot_offsets, int64_t n_slots, int width, int height,
                       int tile_row_begin, int tile_row_step, int tile_row_end, int bin_shift,
                       int filter, float *partials, uint8_t *slot_flags, float *magnitude_image,
-                      uint32_t *debug_pixel_hits, void *stream);
+                      uint32_t *debug_pixel_hits, const int32_t *tile_order, void *stream);
 
 /* Per-Gaussian sum of its flagged slots, in slot order (bitwise reproducible), into acc float[M][12].
  * Replaces the accumulation side of the reference's atomics (RAS:674-696).

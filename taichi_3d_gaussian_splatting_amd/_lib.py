@@ -17,7 +17,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # GS_LIB_PATH: development knob (tuning sweeps load differently built variants of the library); default = in-tree build
 LIB_PATH = os.environ.get("GS_LIB_PATH") or os.path.join(_HERE, "libgsplat_hip.so")
-ABI_VERSION = 23
+ABI_VERSION = 24
 
 _c = ctypes
 _P = _c.c_void_p
@@ -42,7 +42,7 @@ _SIGNATURES = {
     "gs_tile_ranges": (_I, [_P, _I64, _P, _I, _P, _P, _I, _P]),
     "gs_read_counters_async": (_I, [_P, _P, _I, _P]),
     "gs_blend_forward": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _I, _P, _P]),
-    "gs_blend_backward": (_I, [_P, _P, _P, _P, _P, _P, _P, _I64, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P]),
+    "gs_blend_backward": (_I, [_P, _P, _P, _P, _P, _P, _P, _I64, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P]),
     "gs_reduce_partials": (_I, [_P, _P, _P, _P, _I, _P, _P, _I64, _P, _I, _I, _P]),
     "gs_loss_workspace_floats": (_c.c_longlong, [_I, _I]),
     "gs_loss_forward": (_I, [_P, _I, _I, _P, _I, _I, _F, _P, _P, _P, _P]),

@@ -44,6 +44,15 @@ constexpr float STOP_T = 0.0001f;                  // RAS:458
 #ifndef GS_BWD_MIN_WAVES
 #define GS_BWD_MIN_WAVES 1   // second argument of __launch_bounds__ (minimum waves per SIMD) of the backward kernel
 #endif
+#ifndef GS_BWD_REDUCE
+#define GS_BWD_REDUCE 1      // cross-lane sums of the backward: 1 = per hit entry (gs_wave_reduce12, 34 instructions), 2 = two hit
+                             // entries at a time (gs_wave_reduce12_pair, 50 per pair; one entry stays pending in registers),
+                             // 0 = none (measurement only: the partials are thrown away, gradients are wrong)
+#endif
+#ifndef GS_BWD_TRIM
+#define GS_BWD_TRIM 1        // 1: hit masks combined on the scalar unit, |v| accumulated with the VOP3 abs modifier, the four
+                             // list positions of a group read with one ds_read_b128
+#endif
 constexpr int GROUP = GS_GROUP_FWD > GS_GROUP_BWD ? (GS_GROUP_FWD > 4 ? GS_GROUP_FWD : 4) : (GS_GROUP_BWD > 4 ? GS_GROUP_BWD : 4);
                               // padding granularity of a staged batch (BATCH % GROUP == 0; covers both group sizes)
 constexpr int GROUP_FWD = GS_GROUP_FWD;  // list entries evaluated together in the forward blend loop
@@ -59,10 +68,13 @@ struct TileCoord { int tile_u, tile_v, tile_id; };
                          // Measured (tools/xcd_sweep.sh): C = 8, 120, 480 equal the default within 1 %; C = 30 (a fixed
                          // quarter of every tile row per XCD) is 25 % slower -- XCD load balance matters, L2 locality less.
 #endif
-__device__ __forceinline__ TileCoord owned_tile(int tw, int row_begin, int row_step) {
+__device__ __forceinline__ TileCoord owned_tile(int tw, int row_begin, int row_step,
+                                                const int32_t *__restrict__ tile_order = nullptr) {
     const int nb = gridDim.x;
     int b = blockIdx.x;
-    if (GS_XCD_CHUNK > 0) {
+    if (tile_order != nullptr) {
+        b = tile_order[b];   // caller-given dispatch order (longest lists first): a permutation of the owned tiles
+    } else if (GS_XCD_CHUNK > 0) {
         const int group = 8 * GS_XCD_CHUNK, full = (nb / group) * group;
         if (b < full) {
             const int x = b % 8, j = b / 8;   // XCD, position in that XCD's dispatch order
@@ -339,14 +351,16 @@ __global__ __launch_bounds__(BLEND_THREADS, GS_BWD_MIN_WAVES) void blend_backwar
     const float4 *__restrict__ attrs, const float *__restrict__ grad_image, const float *__restrict__ acc_alpha,
     const int32_t *__restrict__ last_effective, int width, int height, int row_begin, int row_step, int bin_shift,
     int filter, const int32_t *__restrict__ slot_offsets, float4 *__restrict__ partials,
-    uint8_t *__restrict__ slot_flags, float *__restrict__ magnitude_image, uint32_t *__restrict__ debug_hits) {
+    uint8_t *__restrict__ slot_flags, float *__restrict__ magnitude_image, uint32_t *__restrict__ debug_hits,
+    const int32_t *__restrict__ tile_order) {
     __shared__ float4 s_p[BATCH], s_b[BATCH], s_c[BATCH], s_q[BATCH];  // rows 0..3 of the kept records
-    __shared__ int s_j[BATCH], s_o[BATCH];
+    __shared__ __attribute__((aligned(16))) int s_j[BATCH];
+    __shared__ int s_o[BATCH];
     __shared__ float s_acc[BATCH][GS_ACC_STRIDE];  // [entry][value]; value 10 = pixel count (as a float)
     __shared__ int s_max[BLEND_THREADS / GS_WAVE];
     __shared__ int s_cnt[2 * FILL_PER_THREAD], s_next[1];
     const int tw = width / GS_TILE_WIDTH, th = height / GS_TILE_HEIGHT;
-    const TileCoord tc = owned_tile(tw, row_begin, row_step);
+    const TileCoord tc = owned_tile(tw, row_begin, row_step, tile_order);
     const int tid = threadIdx.x, lane = tid & 63;
     const int pu = tc.tile_u * GS_TILE_WIDTH + 2 * (tid & 7);  // left pixel of the pair
     const int pv = tc.tile_v * GS_TILE_HEIGHT + (tid >> 3);
@@ -379,6 +393,17 @@ __global__ __launch_bounds__(BLEND_THREADS, GS_BWD_MIN_WAVES) void blend_backwar
     const int row = lane >> 4;
     const int slot = ((row & 1) << 1) | (row >> 1);  // rows (0,1,2,3) -> values (0,2,1,3) of each result register
     const bool row_tail = (lane & 15) == 15;
+#if GS_BWD_REDUCE == 2
+    // destination of this lane's pair-reduce results (gs_wave_reduce12_pair): lanes 7 and 15 of each row
+    const bool pair_tail = (lane & 7) == 7, pair_b_sel = (row >> 1) != 0;
+    const int pair_vi = 2 * ((lane >> 3) & 1) + (row & 1);
+    float pend_x[12];
+    int pend_k = 0;
+    int pend = 0;   // wave-uniform: 1 while a hit entry's partials are waiting in pend_x
+#endif
+#if GS_BWD_REDUCE == 0
+    float sink = 0.f;
+#endif
 #if GS_MFMA_REDUCE
     const GsMfmaReduceConsts mfma_consts = gs_mfma_reduce_consts();
 #endif
@@ -417,7 +442,23 @@ __global__ __launch_bounds__(BLEND_THREADS, GS_BWD_MIN_WAVES) void blend_backwar
         __syncthreads();
         for (int k = 0; k < nbuf; k += GROUP_BWD) {
             // descending positions: the whole group lies behind this wave's pixels
+#if GS_BWD_TRIM
+            int jg[GROUP_BWD];
+            if (STAGED) {
+                static_assert(GROUP_BWD % 4 == 0, "list positions are read four at a time");
+#pragma unroll
+                for (int i = 0; i < GROUP_BWD; i += 4) {
+                    const int4 j4 = *reinterpret_cast<const int4 *>(&s_j[k + i]);
+                    jg[i] = j4.x; jg[i + 1] = j4.y; jg[i + 2] = j4.z; jg[i + 3] = j4.w;
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < GROUP_BWD; ++i) jg[i] = batch_first - (k + i);
+            }
+            if (jg[GROUP_BWD - 1] >= wave_end) continue;
+#else
             if ((STAGED ? s_j[k + GROUP_BWD - 1] : batch_first - (k + GROUP_BWD - 1)) >= wave_end) continue;
+#endif
             // group evaluation: LDS reads + exp of GROUP entries are independent and overlap
             v2f alpha[GROUP_BWD], dx[GROUP_BWD];
             float dy[GROUP_BWD];
@@ -426,54 +467,118 @@ __global__ __launch_bounds__(BLEND_THREADS, GS_BWD_MIN_WAVES) void blend_backwar
 #pragma unroll
             for (int i = 0; i < GROUP_BWD; ++i) {
                 const bool a0 = alpha[i].x >= EPS_ALPHA, a1 = alpha[i].y >= EPS_ALPHA;  // RAS:631, as RAS:451
+#if GS_BWD_TRIM
+                const unsigned long long ma0 = gs_ballot(a0), ma1 = gs_ballot(a1);
+                if ((ma0 | ma1) == 0ull) continue;  // wave-uniform skip: no pixel of this wave is touched
+                const int jj = jg[i];
+                const bool l0 = jj < last0, l1 = jj < last1;                            // RAS:618 (effective range)
+                const bool hit0 = a0 && l0, hit1 = a1 && l1;
+                if (((ma0 & gs_ballot(l0)) | (ma1 & gs_ballot(l1))) == 0ull) continue;
+#else
                 if (gs_ballot(a0 || a1) == 0ull) continue;  // wave-uniform skip: no pixel of this wave is touched
                 const int jj = STAGED ? s_j[k + i] : batch_first - (k + i);
                 const bool hit0 = a0 && (jj < last0), hit1 = a1 && (jj < last1);  // RAS:618 (effective range)
                 if ((gs_ballot(hit0) | gs_ballot(hit1)) == 0ull) continue;
-                // alpha = 0 for a pixel that is not hit makes its whole update an exact no-op
-                // (1/(1-0) = 1, a*T = 0); only dL/dalpha needs an explicit mask.
-                const v2f h = {hit0 ? 1.f : 0.f, hit1 ? 1.f : 0.f};
-                const v2f al = {hit0 ? __builtin_amdgcn_fmed3f(alpha[i].x, 0.f, CLAMP_ALPHA) : 0.f,
-                                hit1 ? __builtin_amdgcn_fmed3f(alpha[i].y, 0.f, CLAMP_ALPHA) : 0.f};
-                const v2f one_m = splat(1.f) - al;
-                const v2f inv1m = {__builtin_amdgcn_rcpf(one_m.x), __builtin_amdgcn_rcpf(one_m.y)};
-                T = T * inv1m;  // RAS:643, T_i = T_{i+1} / (1 - alpha_i)
-                const v2f aT = al * T;
-                const float4 c = s_c[k + i], b = s_b[k + i];
-                const v2f gr = aT * Gr, gg = aT * Gg, gb = aT * Gb;
-                // dL/dalpha = sum_c (c_c T - w_c/(1-alpha)) G_c = T (c.G) - S/(1-alpha)       (RAS:652-657)
-                const v2f cg = fma2(splat(c.z), Gb, fma2(splat(c.y), Gg, splat(c.x) * Gr));
-                const v2f dLda = fma2(T, cg, -(S * inv1m)) * h;
-                S = fma2(cg, aT, S);
-                // w = dL/dg * g = dL/dalpha * opacity * g = dL/dalpha * alpha (unclamped).  dL/dlogit = (1-o) w and the
-                // factor 1/2 of dg/dcov are per-Gaussian constants: applied once per (tile, Gaussian) in the flush.
-                const v2f w = dLda * alpha[i];
-                // UTL:331-348: m = conic @ d
-                const v2f m0 = fma2(dx[i], splat(b.x), splat(b.y * dy[i]));
-                const v2f m1 = fma2(dx[i], splat(b.y), splat(b.z * dy[i]));
-                const v2f v0 = w * m0, v1 = w * m1;  // dL/dmu = dL/dg * g * (conic @ d)   (UTL:343)
-                mag_u = mag_u + (v2f){fabsf(v0.x), fabsf(v0.y)};
-                mag_v = mag_v + (v2f){fabsf(v1.x), fabsf(v1.y)};
-                const v2f c00 = v0 * m0, c01 = v0 * m1, c11 = v1 * m1;  // 2 dL/dcov (UTL:345-346)
-                const v2f n2 = fma2(v1, v1, v0 * v0);
-                const v2f nv = {__builtin_amdgcn_sqrtf(n2.x), __builtin_amdgcn_sqrtf(n2.y)};  // v_sqrt_f32, 1 ulp
-                if (DEBUG) {
-                    const unsigned hv = (unsigned)(s_o[k + i] + 1) * GS_HASH_MUL;
-                    dc0 += hit0 ? 1u : 0u; dh0 += hit0 ? hv : 0u;
-                    dc1 += hit1 ? 1u : 0u; dh1 += hit1 ? hv : 0u;
+#endif
+                // The twelve per-lane partial sums of this entry (in-lane sums over the lane's two pixels), in the order of
+                // the accumulator record: v0, v1 (dL/dmu), c00, c01, c11 (2 dL/dcov), gr, gg, gb (dL/drgb), w, |v|, count, 0.
+                v2f pq[11];   // the eleven packed (two-pixel) partials of this entry
+                {
+                    // alpha = 0 for a pixel that is not hit makes its whole update an exact no-op
+                    // (1/(1-0) = 1, a*T = 0); only dL/dalpha needs an explicit mask.
+                    const v2f h = {hit0 ? 1.f : 0.f, hit1 ? 1.f : 0.f};
+                    const v2f al = {hit0 ? __builtin_amdgcn_fmed3f(alpha[i].x, 0.f, CLAMP_ALPHA) : 0.f,
+                                    hit1 ? __builtin_amdgcn_fmed3f(alpha[i].y, 0.f, CLAMP_ALPHA) : 0.f};
+                    const v2f one_m = splat(1.f) - al;
+                    const v2f inv1m = {__builtin_amdgcn_rcpf(one_m.x), __builtin_amdgcn_rcpf(one_m.y)};
+                    T = T * inv1m;  // RAS:643, T_i = T_{i+1} / (1 - alpha_i)
+                    const v2f aT = al * T;
+                    const float4 c = s_c[k + i], b = s_b[k + i];
+                    const v2f gr = aT * Gr, gg = aT * Gg, gb = aT * Gb;
+                    // dL/dalpha = sum_c (c_c T - w_c/(1-alpha)) G_c = T (c.G) - S/(1-alpha)       (RAS:652-657)
+                    const v2f cg = fma2(splat(c.z), Gb, fma2(splat(c.y), Gg, splat(c.x) * Gr));
+                    const v2f dLda = fma2(T, cg, -(S * inv1m)) * h;
+                    S = fma2(cg, aT, S);
+                    // w = dL/dg * g = dL/dalpha * opacity * g = dL/dalpha * alpha (unclamped).  dL/dlogit = (1-o) w and the
+                    // factor 1/2 of dg/dcov are per-Gaussian constants: applied once per (tile, Gaussian) in the flush.
+                    const v2f w = dLda * alpha[i];
+                    // UTL:331-348: m = conic @ d
+                    const v2f m0 = fma2(dx[i], splat(b.x), splat(b.y * dy[i]));
+                    const v2f m1 = fma2(dx[i], splat(b.y), splat(b.z * dy[i]));
+                    const v2f v0 = w * m0, v1 = w * m1;  // dL/dmu = dL/dg * g * (conic @ d)   (UTL:343)
+#if GS_BWD_TRIM
+                    asm("v_add_f32 %0, |%1|, %0" : "+v"(mag_u.x) : "v"(v0.x));
+                    asm("v_add_f32 %0, |%1|, %0" : "+v"(mag_u.y) : "v"(v0.y));
+                    asm("v_add_f32 %0, |%1|, %0" : "+v"(mag_v.x) : "v"(v1.x));
+                    asm("v_add_f32 %0, |%1|, %0" : "+v"(mag_v.y) : "v"(v1.y));
+#else
+                    mag_u = mag_u + (v2f){fabsf(v0.x), fabsf(v0.y)};
+                    mag_v = mag_v + (v2f){fabsf(v1.x), fabsf(v1.y)};
+#endif
+                    const v2f c00 = v0 * m0, c01 = v0 * m1, c11 = v1 * m1;  // 2 dL/dcov (UTL:345-346)
+                    const v2f n2 = fma2(v1, v1, v0 * v0);
+                    const v2f nv = {__builtin_amdgcn_sqrtf(n2.x), __builtin_amdgcn_sqrtf(n2.y)};  // v_sqrt_f32, 1 ulp
+                    if (DEBUG) {
+                        const unsigned hv = (unsigned)(s_o[k + i] + 1) * GS_HASH_MUL;
+                        dc0 += hit0 ? 1u : 0u; dh0 += hit0 ? hv : 0u;
+                        dc1 += hit1 ? 1u : 0u; dh1 += hit1 ? hv : 0u;
+                    }
+                    pq[0] = v0; pq[1] = v1; pq[2] = c00; pq[3] = c01; pq[4] = c11; pq[5] = gr; pq[6] = gg; pq[7] = gb;
+                    pq[8] = w; pq[9] = nv; pq[10] = h;
                 }
-                // in-lane pair sums, then the 12-value reduce-scatter over the 64 lanes (gs_common.h); row totals
-                // land in lane 15 of each row: t0 (v0, c00, v1, c01)  t1 (c11, gg, gr, gb)  t2 (w, count, |v|, 0)
+                // in-lane sums over the lane's two pixels (inline asm: the vectoriser would otherwise shuffle the operands
+                // into v_pk_add_f32 pairs with more moves than it saves adds)
+                auto partials_of_entry = [&](float (&x)[12]) {
+#pragma unroll
+                    for (int n = 0; n < 11; ++n) asm("v_add_f32 %0, %1, %2" : "=v"(x[n]) : "v"(pq[n].x), "v"(pq[n].y));
+                    x[11] = 0.f;
+                };
+#if GS_BWD_REDUCE == 0
+                {   // measurement only: what the kernel costs without the cross-lane sums
+                    float x[12];
+                    partials_of_entry(x);
+#pragma unroll
+                    for (int n = 0; n < 11; ++n) sink += x[n];
+                }
+#elif GS_BWD_REDUCE == 2
+                // Two hit entries share one reduce-scatter: the first one's partials wait in registers (pend_x) until the
+                // wave meets its next hit entry of this round; a leftover is reduced alone before the flush.  Both
+                // reduce-scatters add a value's 64 lanes in the same tree (gs_common.h), so an entry's sums are the same
+                // bits whether it found a partner or not.
+                // (the two arms are kept apart by distinct asm markers: merged, the compiler computes into scratch registers
+                // and copies twelve values into pend_x)
+                if (__builtin_amdgcn_readfirstlane(pend)) {
+                    asm volatile("; pair: second entry");
+                    float x[12];
+                    partials_of_entry(x);
+                    float w0, w1, w2;
+                    gs_wave_reduce12_pair(pend_x, x, w0, w1, w2);
+                    if (pair_tail) {
+                        float *A = &s_acc[pair_b_sel ? k + i : pend_k][pair_vi];
+                        atomicAdd(A, w0);
+                        atomicAdd(A + 4, w1);
+                        atomicAdd(A + 8, w2);
+                    }
+                    pend = 0;
+                } else {
+                    asm volatile("; pair: first entry");
+                    partials_of_entry(pend_x);
+                    pend_k = k + i;
+                    pend = 1;
+                }
+#else
+                float x[12];
+                partials_of_entry(x);
+                // the 12-value reduce-scatter over the 64 lanes (gs_common.h); row totals land in lane 15 of each row:
+                // t0 (v0, c00, v1, c01)  t1 (c11, gg, gr, gb)  t2 (w, count, |v|, 0)
 #if GS_MFMA_REDUCE
                 // matrix-pipe variant: lane n (< 11) ends up with the wave total of value n
-                const float tot = gs_wave_reduce12_mfma(v0.x + v0.y, v1.x + v1.y, c00.x + c00.y, c01.x + c01.y,
-                                                        c11.x + c11.y, gr.x + gr.y, gg.x + gg.y, gb.x + gb.y,
-                                                        w.x + w.y, nv.x + nv.y, h.x + h.y, 0.f, mfma_consts);
+                const float tot = gs_wave_reduce12_mfma(x[0], x[1], x[2], x[3], x[4], x[5], x[6], x[7], x[8], x[9], x[10],
+                                                        0.f, mfma_consts);
                 if (lane < 11) atomicAdd(&s_acc[k + i][lane], tot);
 #else
                 float t0, t1, t2;
-                gs_wave_reduce12(v0.x + v0.y, v1.x + v1.y, c00.x + c00.y, c01.x + c01.y, c11.x + c11.y, gr.x + gr.y,
-                                 gg.x + gg.y, gb.x + gb.y, w.x + w.y, nv.x + nv.y, h.x + h.y, 0.f, t0, t1, t2);
+                gs_wave_reduce12(x[0], x[1], x[2], x[3], x[4], x[5], x[6], x[7], x[8], x[9], x[10], 0.f, t0, t1, t2);
                 if (row_tail) {
                     float *A = &s_acc[k + i][slot];
                     atomicAdd(A, t0);
@@ -481,8 +586,23 @@ __global__ __launch_bounds__(BLEND_THREADS, GS_BWD_MIN_WAVES) void blend_backwar
                     atomicAdd(A + 8, t2);
                 }
 #endif
+#endif
             }
         }
+#if GS_BWD_REDUCE == 2
+        if (__builtin_amdgcn_readfirstlane(pend)) {   // the round's odd hit entry
+            float t0, t1, t2;
+            gs_wave_reduce12(pend_x[0], pend_x[1], pend_x[2], pend_x[3], pend_x[4], pend_x[5], pend_x[6], pend_x[7],
+                             pend_x[8], pend_x[9], pend_x[10], 0.f, t0, t1, t2);
+            if (row_tail) {
+                float *A = &s_acc[pend_k][slot];
+                atomicAdd(A, t0);
+                atomicAdd(A + 4, t1);
+                atomicAdd(A + 8, t2);
+            }
+            pend = 0;
+        }
+#endif
         __syncthreads();
         // flush: thread k owns staged entry k -> one 48-B store into the (Gaussian, tile) slot
         if (tid < nbuf) {
@@ -504,6 +624,9 @@ __global__ __launch_bounds__(BLEND_THREADS, GS_BWD_MIN_WAVES) void blend_backwar
             }
         }
     }
+#if GS_BWD_REDUCE == 0
+    mag_u.x += 1e-30f * sink;
+#endif
     magnitude_image[2 * p] = mag_u.x;
     magnitude_image[2 * p + 1] = mag_v.x;
     magnitude_image[2 * p + 2] = mag_u.y;
@@ -664,15 +787,15 @@ static void launch_backward(bool debug, dim3 grid, hipStream_t s, const int32_t 
                             const float4 *attrs, const float *grad_image, const float *acc_alpha,
                             const int32_t *last_effective, int width, int height, int rb, int rs, int bin_shift,
                             int filter, const int32_t *slot_offsets, float4 *partials, uint8_t *slot_flags,
-                            float *magnitude_image, uint32_t *debug_hits) {
+                            float *magnitude_image, uint32_t *debug_hits, const int32_t *tile_order) {
     if (debug)
         hipLaunchKernelGGL((blend_backward_kernel<STAGED, true>), grid, dim3(BLEND_THREADS), 0, s, bin_start, payload,
                            attrs, grad_image, acc_alpha, last_effective, width, height, rb, rs, bin_shift, filter,
-                           slot_offsets, partials, slot_flags, magnitude_image, debug_hits);
+                           slot_offsets, partials, slot_flags, magnitude_image, debug_hits, tile_order);
     else
         hipLaunchKernelGGL((blend_backward_kernel<STAGED, false>), grid, dim3(BLEND_THREADS), 0, s, bin_start, payload,
                            attrs, grad_image, acc_alpha, last_effective, width, height, rb, rs, bin_shift, filter,
-                           slot_offsets, partials, slot_flags, magnitude_image, debug_hits);
+                           slot_offsets, partials, slot_flags, magnitude_image, debug_hits, tile_order);
 }
 
 }  // namespace
@@ -727,7 +850,8 @@ int gs_blend_backward(const int32_t *bin_start, const int32_t *payload, const fl
                       const float *grad_image, const float *acc_alpha, const int32_t *last_effective,
                       const int32_t *slot_offsets, int64_t n_slots, int width, int height, int tile_row_begin,
                       int tile_row_step, int tile_row_end, int bin_shift, int filter, float *partials,
-                      uint8_t *slot_flags, float *magnitude_image, uint32_t *debug_pixel_hits, void *stream) {
+                      uint8_t *slot_flags, float *magnitude_image, uint32_t *debug_pixel_hits,
+                      const int32_t *tile_order, void *stream) {
     GS_REQUIRE(width % GS_TILE_WIDTH == 0 && height % GS_TILE_HEIGHT == 0, "image size must be a multiple of 16");
     GS_REQUIRE(tile_row_step >= 1 && tile_row_begin >= 0 && tile_row_end >= 0, "tile row ownership");
     GS_REQUIRE(bin_shift >= 0 && bin_shift <= 4, "bin_shift");
@@ -747,11 +871,11 @@ int gs_blend_backward(const int32_t *bin_start, const int32_t *payload, const fl
     if (staged)
         launch_backward<true>(debug_pixel_hits != nullptr, grid, s, bin_start, payload, a4, grad_image, acc_alpha,
                               last_effective, width, height, tile_row_begin, tile_row_step, bin_shift, filter,
-                              slot_offsets, p4, slot_flags, magnitude_image, debug_pixel_hits);
+                              slot_offsets, p4, slot_flags, magnitude_image, debug_pixel_hits, tile_order);
     else
         launch_backward<false>(debug_pixel_hits != nullptr, grid, s, bin_start, payload, a4, grad_image, acc_alpha,
                                last_effective, width, height, tile_row_begin, tile_row_step, bin_shift, filter,
-                               slot_offsets, p4, slot_flags, magnitude_image, debug_pixel_hits);
+                               slot_offsets, p4, slot_flags, magnitude_image, debug_pixel_hits, tile_order);
     GS_CHECK_LAUNCH();
     return 0;
 }

@@ -303,7 +303,9 @@ __device__ __forceinline__ void gs_rows_lds_to_global(float4 *__restrict__ base,
 // ------------------------------------------------------------------ 12-value wave reduce-scatter
 // Sums twelve per-lane partials over the 64 lanes of a wave in 34 VALU instructions (6 x 12 = 72 with
 // the plain DPP ladder): two swap+add levels use gfx950's v_permlane32_swap / v_permlane16_swap to
-// halve the number of live registers (12 -> 6 -> 3), then four DPP row steps finish each register.
+// halve the number of live registers (12 -> 6 -> 3), then four DPP row steps finish each register (row_ror:8 first, then
+// row_shr:1/2/4 over the 8-lane halves: the SAME addition tree as gs_wave_reduce12_pair below, so an entry's sums do
+// not depend on which of the two functions reduced it).
 // On return the totals sit in lane 15 of each 16-lane row:
 //   t0: rows 0..3 = (x0, x2, x1, x3)   t1: rows = (x4, x6, x5, x7)   t2: rows = (x8, x10, x9, x11)
 // Hand-scheduled inline asm because (a) ROCm 7.2's clang returns element 0 for BOTH results of the
@@ -334,22 +336,87 @@ __device__ __forceinline__ void gs_wave_reduce12(float x0, float x1, float x2, f
         "v_add_f32 %0, %0, %2\n\t"
         "v_add_f32 %4, %4, %6\n\t"
         "v_add_f32 %8, %8, %10\n\t"
+        "v_add_f32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %4, %4, %4 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %8, %8, %8 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
         "v_add_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
         "v_add_f32_dpp %4, %4, %4 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
         "v_add_f32_dpp %8, %8, %8 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
         "v_add_f32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
         "v_add_f32_dpp %4, %4, %4 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
         "v_add_f32_dpp %8, %8, %8 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-        "v_add_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xe\n\t"
-        "v_add_f32_dpp %4, %4, %4 row_shr:4 row_mask:0xf bank_mask:0xe\n\t"
-        "v_add_f32_dpp %8, %8, %8 row_shr:4 row_mask:0xf bank_mask:0xe\n\t"
-        "v_add_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xc\n\t"
-        "v_add_f32_dpp %4, %4, %4 row_shr:8 row_mask:0xf bank_mask:0xc\n\t"
-        "v_add_f32_dpp %8, %8, %8 row_shr:8 row_mask:0xf bank_mask:0xc\n\t"
+        "v_add_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %4, %4, %4 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %8, %8, %8 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
         "s_nop 1"
         : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7), "+v"(x8), "+v"(x9),
           "+v"(x10), "+v"(x11));
     t0 = x0; t1 = x4; t2 = x8;
+}
+// Two list entries at once (the backward blend keeps one hit entry pending): 2 x 12 per-lane partials P (entry A) and
+// Q (entry B) -> 50 VALU instructions instead of 2 x 34.  Level 1 swaps ACROSS the entries (v_permlane32_swap P[j],
+// Q[j]: lanes 0-31 then carry entry A, lanes 32-63 entry B), level 2 pairs values with v_permlane16_swap, level 3
+// packs two registers into one with bank-masked row_ror:8 adds, then three row_shr steps finish the 8-lane groups.
+// Value 11 of both entries must be 0 (it is never moved).  On return, for lane l with (l & 7) == 7, row r = l >> 4,
+// half h = (l >> 3) & 1:   w_k (k = 0, 1, 2) holds the wave total of value 4 k + 2 h + (r & 1) of entry (r >> 1).
+// Hazards as in gs_wave_reduce12: every DPP / permlane read of a freshly written VGPR is >= 2 instructions away.
+__device__ __forceinline__ void gs_wave_reduce12_pair(float (&P)[12], float (&Q)[12], float &w0, float &w1, float &w2) {
+    float zero = 0.f;
+    asm("s_nop 1\n\t"
+        "v_permlane32_swap_b32 %0, %12\n\t"
+        "v_permlane32_swap_b32 %1, %13\n\t"
+        "v_permlane32_swap_b32 %2, %14\n\t"
+        "v_permlane32_swap_b32 %3, %15\n\t"
+        "v_permlane32_swap_b32 %4, %16\n\t"
+        "v_permlane32_swap_b32 %5, %17\n\t"
+        "v_permlane32_swap_b32 %6, %18\n\t"
+        "v_permlane32_swap_b32 %7, %19\n\t"
+        "v_permlane32_swap_b32 %8, %20\n\t"
+        "v_permlane32_swap_b32 %9, %21\n\t"
+        "v_permlane32_swap_b32 %10, %22\n\t"
+        "v_add_f32 %0, %0, %12\n\t"
+        "v_add_f32 %1, %1, %13\n\t"
+        "v_add_f32 %2, %2, %14\n\t"
+        "v_add_f32 %3, %3, %15\n\t"
+        "v_add_f32 %4, %4, %16\n\t"
+        "v_add_f32 %5, %5, %17\n\t"
+        "v_add_f32 %6, %6, %18\n\t"
+        "v_add_f32 %7, %7, %19\n\t"
+        "v_add_f32 %8, %8, %20\n\t"
+        "v_add_f32 %9, %9, %21\n\t"
+        "v_add_f32 %10, %10, %22\n\t"
+        "v_permlane16_swap_b32 %0, %1\n\t"
+        "v_permlane16_swap_b32 %2, %3\n\t"
+        "v_permlane16_swap_b32 %4, %5\n\t"
+        "v_permlane16_swap_b32 %6, %7\n\t"
+        "v_permlane16_swap_b32 %8, %9\n\t"
+        "v_permlane16_swap_b32 %10, %11\n\t"
+        "v_add_f32 %0, %0, %1\n\t"
+        "v_add_f32 %2, %2, %3\n\t"
+        "v_add_f32 %4, %4, %5\n\t"
+        "v_add_f32 %6, %6, %7\n\t"
+        "v_add_f32 %8, %8, %9\n\t"
+        "v_add_f32 %10, %10, %11\n\t"
+        "v_add_f32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %4, %4, %4 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %8, %8, %8 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %0, %2, %2 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+        "v_add_f32_dpp %4, %6, %6 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+        "v_add_f32_dpp %8, %10, %10 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+        "v_add_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %4, %4, %4 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %8, %8, %8 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %4, %4, %4 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %8, %8, %8 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %4, %4, %4 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %8, %8, %8 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "s_nop 1"
+        : "+v"(P[0]), "+v"(P[1]), "+v"(P[2]), "+v"(P[3]), "+v"(P[4]), "+v"(P[5]), "+v"(P[6]), "+v"(P[7]), "+v"(P[8]),
+          "+v"(P[9]), "+v"(P[10]), "+v"(zero), "+v"(Q[0]), "+v"(Q[1]), "+v"(Q[2]), "+v"(Q[3]), "+v"(Q[4]), "+v"(Q[5]),
+          "+v"(Q[6]), "+v"(Q[7]), "+v"(Q[8]), "+v"(Q[9]), "+v"(Q[10]));
+    w0 = P[0]; w1 = P[4]; w2 = P[8];
 }
 // The same twelve sums with the matrix pipe doing most of the cross-lane work (the pipe is otherwise idle in the blend
 // kernels; f32-input MFMA is exact: a k-ordered fmaf chain).  One permlane32-swap level leaves six registers that hold

@@ -560,6 +560,7 @@ __global__ __launch_bounds__(GS_BLOCK) void make_keys_kernel(
     }
     const int tw = width / GS_TILE_WIDTH;
     const int bins_u = (tw + (1 << bin_shift) - 1) >> bin_shift;
+    const uint32_t depth_mask = key_depth_bits > 0 ? (1u << key_depth_bits) - 1u : 0xffffffffu;
     float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0;
     int t0u = 0, t1u = 0, t0v = 0, t1v = 0;
     if (cnt > 0) {
@@ -590,8 +591,9 @@ __global__ __launch_bounds__(GS_BLOCK) void make_keys_kernel(
             if (k < n_keys_capacity) {   // (an overflowing frame is detected by the host from the counters and redone)
                 if (sizeof(KeyT) == 8)
                     keys[k] = (KeyT)((int64_t)dq + ((int64_t)bin << 32));
-                else
-                    keys[k] = (KeyT)(((uint32_t)bin << key_depth_bits) | (uint32_t)dq);
+                else   // (a speculative frame whose depth range outgrew the field is redone by the host: the masked bits only
+                       //  keep its discarded keys inside the bin range, so that gs_tile_ranges stays inside its arrays)
+                    keys[k] = (KeyT)(((uint32_t)bin << key_depth_bits) | ((uint32_t)dq & depth_mask));
                 payload[k] = i;
             }
             ++k;
@@ -608,7 +610,7 @@ __global__ __launch_bounds__(GS_BLOCK) void make_keys_kernel(
             if (sizeof(KeyT) == 8)
                 keys[k] = (KeyT)((int64_t)dq + ((int64_t)bin << 32));
             else
-                keys[k] = (KeyT)(((uint32_t)bin << key_depth_bits) | (uint32_t)dq);
+                keys[k] = (KeyT)(((uint32_t)bin << key_depth_bits) | ((uint32_t)dq & depth_mask));
             payload[k] = first_point + owner;
         }
         next += __popcll(alive);
@@ -624,7 +626,7 @@ __device__ __forceinline__ int32_t tile_of_key(KeyT key, int key_depth_bits) {
 constexpr int RANGES_PER_THREAD = 4;   // consecutive keys per thread (one 16-B / 32-B run): 4x fewer, fatter waves
 template <typename KeyT>
 __global__ void tile_ranges_kernel(const KeyT *__restrict__ keys, long long n, const int32_t *__restrict__ n_device,
-                                   int key_depth_bits, int32_t *__restrict__ tile_start,
+                                   int key_depth_bits, int n_tiles, int32_t *__restrict__ tile_start,
                                    int32_t *__restrict__ tile_end) {
     if (n_device) n = min((long long)*n_device, n);
     const long long first = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * RANGES_PER_THREAD;
@@ -636,12 +638,12 @@ __global__ void tile_ranges_kernel(const KeyT *__restrict__ keys, long long n, c
         if (i >= n) break;
         if (i + 1 < n) {
             const int32_t tn = tile_of_key<KeyT>(keys[i + 1], key_depth_bits);
-            if (t != tn) {
-                tile_start[tn] = (int32_t)(i + 1);
-                tile_end[t] = (int32_t)(i + 1);
+            if (t != tn) {   // (bin ids outside the arrays -- keys the caller did not generate -- are never written)
+                if ((unsigned)tn < (unsigned)n_tiles) tile_start[tn] = (int32_t)(i + 1);
+                if ((unsigned)t < (unsigned)n_tiles) tile_end[t] = (int32_t)(i + 1);
             }
             t = tn;
-        } else {
+        } else if ((unsigned)t < (unsigned)n_tiles) {
             tile_end[t] = (int32_t)n;
         }
     }
@@ -791,10 +793,10 @@ int gs_tile_ranges(const void *keys_sorted, int64_t n_keys, const int32_t *n_key
     const dim3 grid(gs_div_up(n_keys, (int64_t)GS_BLOCK * RANGES_PER_THREAD)), block(GS_BLOCK);
     if (key_depth_bits == 0)
         hipLaunchKernelGGL(tile_ranges_kernel<uint64_t>, grid, block, 0, s, (const uint64_t *)keys_sorted,
-                           (long long)n_keys, n_keys_device, 0, tile_start, tile_end);
+                           (long long)n_keys, n_keys_device, 0, n_tiles, tile_start, tile_end);
     else
         hipLaunchKernelGGL(tile_ranges_kernel<uint32_t>, grid, block, 0, s, (const uint32_t *)keys_sorted,
-                           (long long)n_keys, n_keys_device, key_depth_bits, tile_start, tile_end);
+                           (long long)n_keys, n_keys_device, key_depth_bits, n_tiles, tile_start, tile_end);
     GS_CHECK_LAUNCH();
     return 0;
 }

@@ -306,7 +306,7 @@ def blend_forward(bin_start, bin_end, payload, attrs, width, height, layout: Lis
 
 
 def blend_backward_partials(bin_start, payload, attrs, grad_image, acc_alpha, last_eff, slot_offsets, n_slots,
-                            width, height, layout: ListLayout = ListLayout(), debug_hits=False):
+                            width, height, layout: ListLayout = ListLayout(), debug_hits=False, tile_order=None):
     """Per-pixel backward pass -> (partials f32[S,12], slot_flags u8[S], magnitude image f32[H,W,2]): one partial
     record per (Gaussian, tile) slot, plain stores, no atomics.  debug_hits=True appends the per-pixel
     {count, hash} record of the pairs the backward treated as blended (see blend_forward)."""
@@ -321,7 +321,7 @@ def blend_backward_partials(bin_start, payload, attrs, grad_image, acc_alpha, la
     call("gs_blend_backward", ptr(bin_start), ptr(payload), ptr(attrs), ptr(grad_image), ptr(acc_alpha),
          ptr(last_eff), ptr(slot_offsets), int(n_slots), int(width), int(height), layout.row_begin, layout.row_step,
          layout.row_end, layout.bin_shift, layout.filter, ptr(partials), ptr(flags), ptr(mag), ptr(dbg),
-         current_stream(dev))
+         ptr(tile_order), current_stream(dev))
     return (partials, flags, mag, dbg) if debug_hits else (partials, flags, mag)
 
 

@@ -78,22 +78,25 @@ def make_scene(n: int, height: int, width: int, s_min: float, s_max: float, sh_d
         depth_to_sort_key_scale=depth_to_sort_key_scale)
 
 
-def make_reference_stress_scene(seed: int = 0) -> SyntheticScene:
+def make_reference_stress_scene(seed: int = 0, n: int = 100_000, n_valid: int = 8000, height: int = 1088,
+                                width: int = 1920) -> SyntheticScene:
     """The reference's own stress test (tests/GaussianPointCloudRasterisation_test.py:111-150): 1e5 rows of U[0,1)
     data of which only the first 8000 are valid, 1920 x 1088, f = 500, camera 0.5 behind the cloud: every Gaussian
-    covers (nearly) every tile -- 4.6e7 (tile, Gaussian) pairs in the reference's binning.  SURVEY 8(d) secondary scene."""
+    covers (nearly) every tile -- 4.6e7 (tile, Gaussian) pairs in the reference's binning.  SURVEY 8(d) secondary scene.
+    Other sizes keep the distribution and the field of view (focal length and principal point scale with the width):
+    a version the CPU oracle can check."""
     g = torch.Generator().manual_seed(seed)
-    n = 100_000
     xyz = torch.rand(n, 3, generator=g)
     feat = torch.rand(n, 56, generator=g)
     invalid = torch.zeros(n, dtype=torch.int8)
-    invalid[8000:] = 1
+    invalid[n_valid:] = 1
+    f = 500.0 * width / 1920.0
     return SyntheticScene(
         point_cloud=xyz, point_cloud_features=feat, point_invalid_mask=invalid,
         point_object_id=torch.zeros(n, dtype=torch.int32),
-        camera_intrinsics=torch.tensor([[500.0, 0.0, 960.0], [0.0, 500.0, 540.0], [0.0, 0.0, 1.0]]),
+        camera_intrinsics=torch.tensor([[f, 0.0, width / 2.0], [0.0, f, 540.0 * height / 1088.0], [0.0, 0.0, 1.0]]),
         q_pointcloud_camera=torch.tensor([[0.0, 0.0, 0.0, 1.0]]), t_pointcloud_camera=torch.tensor([[0.0, 0.0, -0.5]]),
-        height=1088, width=1920)
+        height=height, width=width)
 
 
 def make_config_scene(name: str, seed: int = 0) -> SyntheticScene:

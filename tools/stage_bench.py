@@ -18,6 +18,7 @@ g = make_grad_image(s.height, s.width).to("cuda")
 times = {}
 CULL = os.environ.get('GS_CULL', '1') == '1'
 AB = os.environ.get('GS_AB', '0') == '1'
+ORDERED = os.environ.get('GS_TILE_ORDER', '0') == '1'
 LAYOUT = hip_ops.ListLayout(bin_shift=int(os.environ.get('GS_BIN_SHIFT', '0')), exact_cull=CULL)
 
 
@@ -52,6 +53,15 @@ for _ in range(reps + 2):
             start, end, payload, attrs, s.width, s.height, LAYOUT, rgb_only=True, need_state=False))
     partials, flags, mag = timed("blend_backward", lambda: hip_ops.blend_backward_partials(
         start, payload, attrs, g, acc_alpha, last_eff, slot_off, n_slots, s.width, s.height, LAYOUT))
+    if ORDERED:   # A/B arm: tiles dispatched longest walk first (order computed with torch, outside the timed region)
+        tw_, th_ = s.width // 16, s.height // 16
+        side_ = 1 << LAYOUT.bin_shift
+        bins_u_ = (tw_ + side_ - 1) // side_
+        tb_ = (torch.arange(th_, device="cuda")[:, None] // side_) * bins_u_ + (torch.arange(tw_, device="cuda")[None, :] // side_)
+        walked_ = last_eff.view(th_, 16, tw_, 16).amax(dim=(1, 3)) - start[tb_.long()]
+        order = torch.argsort(walked_.flatten(), descending=True, stable=True).to(torch.int32)
+        partials2, flags2, mag2 = timed("blend_backward_lpt", lambda: hip_ops.blend_backward_partials(
+            start, payload, attrs, g, acc_alpha, last_eff, slot_off, n_slots, s.width, s.height, LAYOUT, tile_order=order))
     acc = timed("reduce_partials", lambda: hip_ops.reduce_partials(slot_off, ntiles, flags, partials))
     timed("point_backward", lambda: hip_ops.point_backward(
         s.point_cloud, feat, s.point_object_id, s.camera_intrinsics, q_cp, t_cp, s.t_pointcloud_camera, ids, acc, attrs, 3,
@@ -61,7 +71,7 @@ print(f"workload={workload} M={ids.shape[0]} K={k} cull={CULL} bin_shift={LAYOUT
 tot = 0.0
 for name, pairs in times.items():
     ms = sum(a.elapsed_time(b) for a, b in pairs[2:]) / len(pairs[2:])
-    tot += 0.0 if name in ("blend_forward_rgb_nostate", "blend_backward_v1") else ms
+    tot += 0.0 if name in ("blend_forward_rgb_nostate", "blend_backward_lpt") else ms
     print(f"  {name:16s} {ms:8.4f} ms")
 print(f"  {'sum':16s} {tot:8.4f} ms")
 lens = (end - start).float()
@@ -70,5 +80,11 @@ bins_u = (s.width + side - 1) // side
 tile_bin = (torch.arange(s.height // 16, device="cuda")[:, None] >> LAYOUT.bin_shift) * bins_u + \
     (torch.arange(s.width // 16, device="cuda")[None, :] >> LAYOUT.bin_shift)
 walked = (last_eff.view(s.height // 16, 16, s.width // 16, 16).amax(dim=(1, 3)) - start[tile_bin.long()]).float().flatten()
+hits = acc[:, 10].contiguous().view(torch.int32).double().sum().item()
+print(f"  checksums: acc.sum={acc[:, :10].double().sum().item():.9e} acc.abs={acc[:, :10].double().abs().sum().item():.9e} "
+      f"mag.sum={mag.double().sum().item():.9e}; (pixel, Gaussian) hits={hits:.0f} = "
+      f"{hits / max(walked.sum().item() * 256.0, 1.0):.4f} of the visited (tile entry x 256 pixel) pairs")
+if ORDERED:
+    print(f"  lpt arm identical: {bool(torch.equal(partials2[flags2.bool()], partials[flags.bool()]) and torch.equal(mag2, mag))}")
 print(f"  bin list mean={lens.mean():.1f} max={lens.max():.0f}; list positions walked per tile (to max last) "
       f"mean={walked.mean():.1f} max={walked.max():.0f}; blended per pixel mean={count.float().mean():.2f}")
