@@ -18,8 +18,8 @@ RCCL all-gather of the rendered rows + all-reduce of the per-Gaussian gradient a
 scaling is STRONG: total work is fixed, value = frame pixels / max-over-ranks step time.
 
 Rank 0 prints ONE JSON line.  Besides the contract fields it carries
-  step_ms      : per-step GPU time from HIP events on the launch stream: median, p90, min (ms_per_step stays the
-                 wall-clock mean over the K steps between two barriers + synchronisations)
+  step_ms      : per-step GPU time from HIP events on the launch stream around each step: median, p90, min (ms_per_step
+                 stays the wall-clock mean over the K steps between two barriers + synchronisations)
   roofline     : achieved algorithmic HBM GB/s of the dominant kernel vs the 8 TB/s peak, measured live with HIP
                  events on the launch stream (plus all stage times and the whole-path figure); `traffic` = PMC HBM
                  bytes per launch from the committed profile -- only while the kernel sources are the profiled ones
@@ -71,7 +71,7 @@ def algorithmic_bytes(n, m, k, p, key_bytes=8, k_tile=None):
         "blend_forward": 48 * k_tile + 28 * p,
         "blend_backward": 44 * k_tile + 28 * p + 48 * m,   # list re-gather, per-pixel in/out, one record per Gaussian
         "reduce_partials": 48 * m + 8 * m,            # (the slot records themselves are blend_backward's output)
-        "point_backward": 244 * m + 48 * m + 248 * n,
+        "point_backward": 244 * m + 48 * m + 248 * n,  # (fused form, 1 GPU: the 48 m are one slot record per Gaussian)
     }
 
 
@@ -131,6 +131,9 @@ def main() -> None:
     ap.add_argument("--forward-only", action="store_true", help="inference line: forward under no_grad")
     ap.add_argument("--rgb-only", action="store_true", help="with --forward-only: the reference's rgb_only config")
     ap.add_argument("--shard-mode", default="bands", choices=["bands", "interleaved"])
+    ap.add_argument("--static-scene", action="store_true",
+                    help="let the forward skip the write-back of quaternions that are already normalised (default: "
+                         "training-like -- the in-place normalisation RAS:196-205 writes every visible row, every frame)")
     args = ap.parse_args()
 
     import torch.distributed as dist
@@ -196,16 +199,23 @@ def main() -> None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    # Training-like steady state: an optimiser step leaves every quaternion off unit length, so every forward's in-place
+    # normalisation (RAS:196-205) writes the visible rows back.  On this static scene the operator would skip that write
+    # after the first frame (the stored quaternions are already normalised); `always_store_normalised_rotation` makes it
+    # pay the write every frame, as training does (same memory contents).  --static-scene: the skip stays.
+    op.always_store_normalised_rotation = not args.static_scene
+
+    for i in range(args.warmup):
         step()
     fence()
-    # one event per step boundary on torch's current stream (= the stream every kernel is launched on)
-    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    # two events per step on torch's current stream (= the stream every kernel is launched on)
+    begins = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    ends = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
     t0 = time.perf_counter()
-    marks[0].record()
     for i in range(args.steps):
+        begins[i].record()
         step()
-        marks[i + 1].record()
+        ends[i].record()
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -213,7 +223,7 @@ def main() -> None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     ms_per_step = 1e3 * elapsed / args.steps
-    per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
+    per_step = sorted(begins[i].elapsed_time(ends[i]) for i in range(args.steps))
     step_ms = {"median": round(per_step[len(per_step) // 2], 4),
                "p90": round(per_step[int(0.9 * (len(per_step) - 1))], 4), "min": round(per_step[0], 4)}
     pixels = s.height * s.width
@@ -246,24 +256,32 @@ def main() -> None:
                 s.near_plane, s.far_plane, s.width, s.height))
             attrs, ntiles, nowned, bsums, bsums_full = timed("preprocess", lambda: hip_ops.preprocess(
                 s.point_cloud, f, s.point_object_id, s.camera_intrinsics, q_cp, t_cp, ids, s.width, s.height, layout,
-                s.depth_to_sort_key_scale, counters))
+                s.depth_to_sort_key_scale, counters, always_store_rotation=op.always_store_normalised_rotation))
             k, n_slots, max_dq, _m = timed("scan_block_sums", lambda: hip_ops.scan_block_sums(bsums, counters, bsums_full))
             kdb, db, tb = hip_ops.key_layout(s.near_plane, s.far_plane, s.depth_to_sort_key_scale, num_bins, max_dq)
             keys, payload, slot_off = timed("make_keys", lambda: hip_ops.make_keys(
                 attrs, nowned, bsums, k, s.width, s.height, s.depth_to_sort_key_scale, layout, kdb, ntiles, bsums_full))
             keys, payload = timed("sort_pairs", lambda: hip_ops.sort_pairs(keys, payload, db, tb, kdb, in_place=False))
             start, end = timed("tile_ranges", lambda: hip_ops.tile_ranges(keys, num_bins, kdb))
+            # as the operator runs them: tiles dispatched longest first, slot sums inside the per-point kernel (1 GPU)
+            tile_work = torch.empty(hip_ops.num_owned_tiles(s.width, s.height, layout), dtype=torch.int32, device=device)
             image, depth, acc_alpha, last_eff, count = timed("blend_forward", lambda: hip_ops.blend_forward(
-                start, end, payload, attrs, s.width, s.height, layout))
+                start, end, payload, attrs, s.width, s.height, layout, ordered=op.ordered_dispatch,
+                tile_work=tile_work if op.ordered_dispatch else None))
             partials, flags, mag = timed("blend_backward", lambda: hip_ops.blend_backward_partials(
-                start, payload, attrs, grad_image, acc_alpha, last_eff, slot_off, n_slots, s.width, s.height, layout))
-            acc = timed("reduce_partials", lambda: hip_ops.reduce_partials(slot_off, ntiles, flags, partials))
+                start, payload, attrs, grad_image, acc_alpha, last_eff, slot_off, n_slots, s.width, s.height, layout,
+                tile_work=tile_work if op.ordered_dispatch else None))
+            acc = None
+            if world > 1 or not op.fused_slot_reduction:
+                acc = timed("reduce_partials", lambda: hip_ops.reduce_partials(slot_off, ntiles, flags, partials, None, attrs,
+                                                                               s.width, s.height))
             timed("point_backward", lambda: hip_ops.point_backward(
                 s.point_cloud, f, s.point_object_id, s.camera_intrinsics, q_cp, t_cp, s.t_pointcloud_camera, ids,
                 acc, attrs, 3, cfg.grad_q_factor, cfg.grad_s_factor, cfg.grad_alpha_factor, cfg.grad_color_factor,
                 cfg.grad_high_order_color_factor, hook is not None, vmask, nowned,
                 want_visible_features=hook is not None and op.hook_feature_gradients,
-                want_hook_fields=hook is not None))
+                want_hook_fields=hook is not None, slots=None if acc is not None else (slot_off, ntiles, flags, partials),
+                width=s.width, height=s.height))
         torch.cuda.synchronize()
         m = int(ids.shape[0])
         k_tile = int(k)
@@ -283,6 +301,7 @@ def main() -> None:
         p_owned = pixels if world == 1 else pixels * len(layout.owned_rows(s.height)) / (s.height // 16)
         bytes_per = algorithmic_bytes(n, m, int(k), p_owned, 4 if kdb > 0 else 8, k_tile)
         backward_stages = ("blend_backward", "reduce_partials", "point_backward")
+        bytes_per = {k_: v for k_, v in bytes_per.items() if k_ in stages_ms}
         timed_stages = [k_ for k_ in stages_ms if not (args.forward_only and k_ in backward_stages)]
         dominant = max(timed_stages, key=stages_ms.get)
         achieved = bytes_per[dominant] / (stages_ms[dominant] * 1e-3) / 1e9
@@ -293,6 +312,13 @@ def main() -> None:
         traffic, valu_instr = (None, None)
         if world == 1 and args.workload == "headline_1m_1080p":
             traffic, valu_instr = profiled_counters(dominant)
+        # the HBM-class stage (streaming / sort / scan: everything but the two VALU-bound blend kernels) furthest from
+        # its bound, among the stages that take at least 2 % of the step
+        hbm_class = [k_ for k_ in timed_stages if k_ not in ("blend_forward", "blend_backward")
+                     and stages_ms[k_] >= 0.02 * ms_per_step]
+        worst = min(hbm_class, key=lambda k_: bytes_per[k_] / stages_ms[k_]) if hbm_class else None
+        worst_traffic = profiled_counters({"sort_pairs": "sort_scatter"}.get(worst, worst))[0] \
+            if (worst and world == 1 and args.workload == "headline_1m_1080p") else None
         valu = None
         if valu_instr is not None:
             rate = valu_instr / (stages_ms[dominant] * 1e-3)
@@ -310,6 +336,11 @@ def main() -> None:
                      "achieved": round(path_bytes / (ms_per_step * 1e-3) / 1e9, 2),
                      "frac": round(path_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)} if path_meaningful
             else None,
+            "hbm_stage_furthest_from_bound": None if worst is None else {
+                "stage": worst, "stage_ms": round(stages_ms[worst], 4), "algorithmic_bytes": int(bytes_per[worst]),
+                "achieved": round(bytes_per[worst] / (stages_ms[worst] * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": round(bytes_per[worst] / (stages_ms[worst] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                "traffic_of_its_main_kernel": worst_traffic},
             "stages_ms": {k_: round(v, 4) for k_, v in stages_ms.items()},
             "kernel_source_hash": kernel_source_hash(),
             "note": "blend kernels are VALU-issue-bound by construction (DESIGN.md section 5)",
@@ -349,7 +380,7 @@ def main() -> None:
             "config": {"workload": args.workload, "gaussians": n, "image": f"{s.width}x{s.height}",
                        "sh_degree": 3, "sharding": "none" if world == 1 else f"tile-row {args.shard_mode}/{world}",
                        "backward_hook": hook is not None, "hook_feature_copy": bool(hook is not None and args.hook_feature_copy),
-                       "forward_only": args.forward_only,
+                       "forward_only": args.forward_only, "training_like": not args.static_scene,
                        "rgb_only": bool(cfg.rgb_only), "speculation": dict(op.speculation_stats), **sizes},
             "step_ms": step_ms,
             "roofline": roofline, "cpu_baseline": cpu_baseline,

@@ -103,13 +103,16 @@ int gs_read_counters(const int32_t *counters, int32_t *host_counters, int n, voi
  * stream -- the host then needs a single size read-back (M, K, slots together) instead of two.
  * counters (may be NULL; zeroed by gs_filter_compact, else by the caller): counters[GS_COUNTER_MAX_DEPTH_KEY]
  * receives the largest quantised depth int32(z*depth_scale) on screen, so that the host can size the
- * key's depth field to the bits in use (fewer radix passes than the far_plane*depth_scale bound). */
+ * key's depth field to the bits in use (fewer radix passes than the far_plane*depth_scale bound).
+ * always_store_rotation: the normalised quaternion is written back only when it differs from what is stored (the
+ * contents of `features` are the same either way); != 0 writes it always -- what every training iteration pays, since
+ * the optimiser has just moved q: lets a benchmark on a static scene include that traffic. */
 int gs_preprocess(const float *xyz, float *features, const int32_t *object_id,
                   const float *intrinsics, const float *q_camera_pointcloud,
                   const float *t_camera_pointcloud, const int32_t *ids, int n_visible,
                   int n_visible_on_device, int width, int height, int tile_row_begin,
                   int tile_row_step, int tile_row_end, int bin_shift, int exact_tile_cull,
-                  float depth_scale, int32_t *counters, float *attrs,
+                  int always_store_rotation, float depth_scale, int32_t *counters, float *attrs,
                   int32_t *num_overlap_tiles, int32_t *num_keys, int32_t *block_sums,
                   int32_t *block_sums_full, void *stream);
 
@@ -180,14 +183,21 @@ int gs_read_counters_async(const int32_t *counters, int32_t *host_counters_pinne
  *   reads -- are neither tracked nor written (may be NULL): the inference path.  The two flags combine.
  * last_effective = 1 + list position of the last Gaussian blended into the pixel (bin_start of its bin if none).
  * debug_pixel_hits (may be NULL; tests): uint32[H][W][2] = per pixel {number of blended Gaussians, wrap-around sum
- *   of (payload + 1) * 2654435761}; gs_blend_backward fills the same record for the pairs IT treats as blended. */
+ *   of (payload + 1) * 2654435761}; gs_blend_backward fills the same record for the pairs IT treats as blended.
+ * Dispatch order.  Tiles differ in work by an order of magnitude; handed to the hardware in image order the launch ends
+ * in a long tail of half-empty CUs.  tile_order (may be NULL): int32[number of owned tiles] scratch; when given, the
+ * library fills it with the owned tiles sorted by list length, longest first (one small launch), and dispatches the
+ * tiles in that order.  tile_work (may be NULL; needs the state outputs): int32[number of owned tiles], receives per
+ * owned tile (n-th in row-major order over the owned rows) the number of list positions gs_blend_backward will walk
+ * for it -- pass it on to gs_blend_backward.  Results never depend on the order. */
 #define GS_BLEND_RGB_ONLY 1
 #define GS_BLEND_NO_STATE 2
 int gs_blend_forward(const int32_t *bin_start, const int32_t *bin_end, const int32_t *payload,
                      const float *attrs, int width, int height, int tile_row_begin,
                      int tile_row_step, int tile_row_end, int bin_shift, int filter, float *image,
                      float *depth, float *acc_alpha, int32_t *last_effective, int32_t *valid_count,
-                     int flags, uint32_t *debug_pixel_hits, void *stream);
+                     int flags, uint32_t *debug_pixel_hits, int32_t *tile_order, int32_t *tile_work,
+                     void *stream);
 
 /* Backward per-pixel pass.  Replaces the pixel loop of gaussian_point_rasterisation_backward
  * (RAS:531-705) WITHOUT its global atomics (RAS:674-696): the partial sums of a (Gaussian, tile) pair
@@ -198,15 +208,16 @@ int gs_blend_forward(const int32_t *bin_start, const int32_t *bin_end, const int
  * must be the forward's.  alpha is evaluated by the same device function as in gs_blend_forward and the staging
  * filter is the same function on the same records, so both passes treat exactly the same (pixel, Gaussian)
  * pairs as blended.  debug_pixel_hits: see gs_blend_forward.
- * tile_order (may be NULL): int32[number of owned tiles], a permutation of 0 .. n-1 (n-th owned tile in row-major
- * order over the owned rows): the order in which tiles are handed to the hardware dispatcher -- longest walks first
- * shortens the tail of the launch; results do not depend on it. */
+ * tile_work / tile_order (may be NULL): dispatch order, see gs_blend_forward.  tile_work (the forward's record) given:
+ * tile_order is scratch of the same size and is filled with the tiles sorted by walk length, longest first.  Only
+ * tile_order given: it is taken as the caller's permutation of 0 .. n-1 (n-th owned tile in row-major order). */
 int gs_blend_backward(const int32_t *bin_start, const int32_t *payload, const float *attrs,
                       const float *grad_image, const float *acc_alpha, const int32_t *last_effective,
                       const int32_t *slot_offsets, int64_t n_slots, int width, int height,
                       int tile_row_begin, int tile_row_step, int tile_row_end, int bin_shift,
                       int filter, float *partials, uint8_t *slot_flags, float *magnitude_image,
-                      uint32_t *debug_pixel_hits, const int32_t *tile_order, void *stream);
+                      uint32_t *debug_pixel_hits, const int32_t *tile_work, int32_t *tile_order,
+                      void *stream);
 
 /* Per-Gaussian sum of its flagged slots, in slot order (bitwise reproducible), into acc float[M][12].
  * Replaces the accumulation side of the reference's atomics (RAS:674-696).
@@ -233,7 +244,12 @@ int gs_reduce_partials(const int32_t *slot_offsets, const int32_t *num_overlap_t
  * from the features, and only if their accumulated colour gradient is non-zero (tile-row sharding).
  * hook_compact (may be NULL): float[7*M], the remaining M-indexed hook fields as consecutive planes --
  * grad_viewspace [M][2] | magnitude_grad_viewspace [M] | num_affected_pixels [M] (int32 bits) | point_depth [M] |
- * point_uv_in_camera [M][2] (RAS:1130-1139) -- written here instead of five strided column copies of acc / attrs. */
+ * point_uv_in_camera [M][2] (RAS:1130-1139) -- written here instead of five strided column copies of acc / attrs.
+ * Fused slot reduction: with acc == NULL the accumulator record of every Gaussian is summed here from the slot records
+ * of gs_blend_backward (slot_offsets, num_overlap_tiles, slot_flags, partials, image size -- the arguments of
+ * gs_reduce_partials; num_owned_tiles doubles as its num_keys): the same code in the same order as gs_reduce_partials,
+ * hence the same bits, without the launch and without writing and re-reading acc.  With acc != NULL (a multi-GPU run
+ * all-reduces it first) the six trailing arguments are ignored. */
 int gs_point_backward(const float *xyz, const float *features, const int32_t *object_id,
                       const float *intrinsics, const float *q_camera_pointcloud,
                       const float *t_camera_pointcloud, const float *t_pointcloud_camera,
@@ -242,7 +258,9 @@ int gs_point_backward(const float *xyz, const float *features, const int32_t *ob
                       int color_max_sh_band, float grad_q_factor, float grad_s_factor,
                       float grad_alpha_factor, float grad_color_factor,
                       float grad_high_order_color_factor, float *grad_xyz, float *grad_features,
-                      float *grad_xyz_visible, float *grad_features_visible, float *hook_compact, void *stream);
+                      float *grad_xyz_visible, float *grad_features_visible, float *hook_compact,
+                      const int32_t *slot_offsets, const int32_t *num_overlap_tiles, const uint8_t *slot_flags,
+                      const float *partials, int width, int height, void *stream);
 
 /* ---- adaptive-controller kernels (not on the per-frame hot path) ---------------- */
 

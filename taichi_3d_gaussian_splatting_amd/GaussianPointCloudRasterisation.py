@@ -166,6 +166,17 @@ class GaussianPointCloudRasterisation(torch.nn.Module):
         # launch the list stages from device-side counts with the previous frame's capacities instead of waiting for
         # this frame's sizes (see _forward); False = wait for the sizes first (two dependent halves, as round 1)
         self.speculative_sizes = True
+        # tiles are handed to the hardware longest list / longest backward walk first instead of in image order (same
+        # results; the launches lose their tail of half-empty CUs)
+        self.ordered_dispatch = True
+        # sum the backward's (Gaussian, tile) slot records inside the per-point kernel instead of a launch of their own
+        # (same bits).  Measured slower at the headline size (0.186 vs 0.069 + 0.101 ms: the gather wants more waves in
+        # flight than the per-point kernel can hold), so off by default
+        self.fused_slot_reduction = False
+        # the forward writes a normalised quaternion back only when the stored one differs (RAS:196-205: same memory
+        # contents).  True = always write: what a training iteration pays -- the optimiser has just moved q -- for
+        # benchmarks that time a static scene (bench.py)
+        self.always_store_normalised_rotation = False
         self._size_guesses, self._readbacks = {}, {}   # (image size, list layout, planes) -> (key capacity, depth bound)
         self.speculation_stats = {"frames": 0, "redone": 0}
         outer = self
@@ -212,7 +223,8 @@ class GaussianPointCloudRasterisation(torch.nn.Module):
                 # RAS:887-911  per-point projection + tile counts (launched for the capacity N)
                 attrs, num_overlap_tiles, num_owned_tiles, block_sums, block_sums_full = hip_ops.preprocess(
                     xyz, pointcloud_features, obj, intrinsics, q_cp, t_cp, ids, width, height, layout,
-                    cfg.depth_to_sort_key_scale, counters, n_visible_on_device=True)
+                    cfg.depth_to_sort_key_scale, counters, n_visible_on_device=True,
+                    always_store_rotation=outer.always_store_normalised_rotation)
                 # RAS:913-922  scans.  The reference blocks twice on sizes (RAS:870,916); here the one read-back of
                 # M, K, the slot count and the depth range travels to pinned memory while the host keeps launching:
                 # key generation, sort, ranges and the blend run SPECULATIVELY from the device-side counts with the
@@ -247,10 +259,15 @@ class GaussianPointCloudRasterisation(torch.nn.Module):
                                                         n_keys_device=n_dev)
                     start_, end_ = hip_ops.tile_ranges(keys, num_bins, kdb, n_keys_device=n_dev)
                     del keys
+                    work_ = None
+                    if need_state and outer.ordered_dispatch:
+                        work_ = torch.empty(hip_ops.num_owned_tiles(width, height, layout), dtype=torch.int32,
+                                            device=attrs_.device)
                     blended = hip_ops.blend_forward(start_, end_, payload_, attrs_, width, height, layout,
                                                     rgb_only=rgb_only, need_state=need_state,
-                                                    gathered_rows=gathered_rows)
-                    return payload_, slot_offsets_, start_, blended
+                                                    gathered_rows=gathered_rows, ordered=outer.ordered_dispatch,
+                                                    tile_work=work_)
+                    return payload_, slot_offsets_, start_, blended, work_
 
                 guess_key = (width, height, layout, cfg.near_plane, cfg.far_plane, cfg.depth_to_sort_key_scale)
                 # one guess per (image size, layout, planes): data sets that mix resolutions keep speculating
@@ -275,6 +292,10 @@ class GaussianPointCloudRasterisation(torch.nn.Module):
                 #     by pairs that are never blended: the reference's stress distribution, 8.3 -> 0.64 ms); back below 3.
                 # Counting emitted keys rather than tile-box areas keeps needle-shaped Gaussians (huge boxes that the cull
                 # empties) from pushing an ordinary frame into the coarse bins.
+                # Sharded runs: every rank decides from its OWN key count (scaled to the whole image), so ranks may pick
+                # different layouts for the same frame.  That is correct by construction -- image, depth, count and
+                # gradients are bit-identical across layouts (tests: test_list_layouts_are_output_identical, the sharded
+                # x binned tests) -- and costs at most some load imbalance; set `bin_shift` to pin one layout everywhere.
                 owned = len(layout.owned_rows(height))
                 k_frame = n_keys * ((height // TILE_HEIGHT) / owned if owned else 1.0)
                 used = layout.bin_shift
@@ -308,7 +329,7 @@ class GaussianPointCloudRasterisation(torch.nn.Module):
                 if not fits:
                     result = lists_and_blend(attrs, num_owned_tiles, block_sums[:nb], block_sums_full[:nb],
                                              num_overlap_tiles, n_keys, max_depth_key, None)
-                payload, slot_offsets, tile_start, (image, depth, acc_alpha, last_eff, count) = result
+                payload, slot_offsets, tile_start, (image, depth, acc_alpha, last_eff, count), tile_work = result
                 if slot_offsets is not None:
                     slot_offsets = slot_offsets[:m]
                 if rgb_only:
@@ -323,6 +344,7 @@ class GaussianPointCloudRasterisation(torch.nn.Module):
                 ctx.save_for_backward(xyz, pointcloud_features, payload, ids, tile_start, acc_alpha,
                                       last_eff, num_overlap_tiles, obj, q_cp, t_cp, t_pc, attrs, intrinsics,
                                       slot_offsets, visible_mask, num_owned_tiles)
+                ctx.tile_work = tile_work
                 ctx.n_slots = n_slots
                 ctx.camera_info = camera_info
                 ctx.color_max_sh_band = color_max_sh_band
@@ -346,13 +368,19 @@ class GaussianPointCloudRasterisation(torch.nn.Module):
                     camera_info = ctx.camera_info
                     width, height = camera_info.camera_width, camera_info.camera_height
                     hook = backward_valid_point_hook
-                    # RAS:531-705  per-pixel pass
-                    acc, magnitude_image = hip_ops.blend_backward(
-                        tile_start, payload, attrs, grad_rasterized_image, acc_alpha, last_eff,
-                        slot_offsets, num_overlap_tiles, ctx.n_slots, width, height, ctx.layout,
-                        num_keys=num_owned_tiles if ctx.layout.sharded else None)
-                    if outer.grad_accumulator_reduce is not None:  # multi-GPU: sum partial tile gradients
-                        outer.grad_accumulator_reduce(acc)
+                    # RAS:531-705  per-pixel pass: one 48-B record per (Gaussian, tile) slot, no atomics
+                    partials, slot_flags, magnitude_image = hip_ops.blend_backward_partials(
+                        tile_start, payload, attrs, grad_rasterized_image, acc_alpha, last_eff, slot_offsets,
+                        ctx.n_slots, width, height, ctx.layout, tile_work=ctx.tile_work)
+                    acc = slots = None
+                    if outer.grad_accumulator_reduce is None and outer.fused_slot_reduction:
+                        # the slot sums are formed inside the per-point kernel and stay in registers
+                        slots = (slot_offsets, num_overlap_tiles, slot_flags, partials)
+                    else:   # the per-Gaussian sums go through memory (multi-GPU: they are summed over the ranks)
+                        acc = hip_ops.reduce_partials(slot_offsets, num_overlap_tiles, slot_flags, partials,
+                                                      num_owned_tiles if ctx.layout.sharded else None, attrs, width, height)
+                        if outer.grad_accumulator_reduce is not None:
+                            outer.grad_accumulator_reduce(acc)
                     # RAS:707-772 + 1102-1125  per-point pass, band clearing and factors fused
                     out = hip_ops.point_backward(
                         xyz, features, obj, intrinsics, q_cp, t_cp, t_pc, ids, acc, attrs, ctx.color_max_sh_band,
@@ -360,7 +388,7 @@ class GaussianPointCloudRasterisation(torch.nn.Module):
                         cfg.grad_high_order_color_factor, want_visible=hook is not None,
                         visible_mask=visible_mask, num_owned_tiles=num_owned_tiles,
                         want_visible_features=hook is not None and outer.hook_feature_gradients,
-                        want_hook_fields=hook is not None)
+                        want_hook_fields=hook is not None, slots=slots, width=width, height=height)
                     grad_pointcloud, grad_pointcloud_features, gx_vis, gf_vis = out[:4]
                     if hook is not None:  # RAS:1127-1142; the column fields come compact out of the same kernel
                         hook(GaussianPointCloudRasterisation.BackwardValidPointHookInput(

@@ -33,7 +33,7 @@ _SIGNATURES = {
     "gs_filter_workspace_bytes": (_c.c_size_t, [_I]),
     "gs_filter_compact": (_I, [_P, _P, _P, _P, _P, _P, _I, _F, _F, _I, _I, _P, _P, _P, _P, _P]),
     "gs_read_counters": (_I, [_P, _P, _I, _P]),
-    "gs_preprocess": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _P, _P, _P, _P, _P, _P, _P]),
+    "gs_preprocess": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _P, _P, _P, _P, _P, _P, _P]),
     "gs_scan_block_sums": (_I, [_P, _I, _P, _I, _P]),
     "gs_scan_block_sums2": (_I, [_P, _P, _I, _P, _P]),
     "gs_make_keys": (_I, [_P, _P, _P, _I, _P, _I64, _I, _I, _I, _I, _I, _I, _I, _I, _F, _P, _P, _P, _P, _P, _P]),
@@ -41,8 +41,8 @@ _SIGNATURES = {
     "gs_sort_pairs": (_I, [_P, _P, _P, _P, _I64, _P, _I, _I, _I, _I, _P, _P]),
     "gs_tile_ranges": (_I, [_P, _I64, _P, _I, _P, _P, _I, _P]),
     "gs_read_counters_async": (_I, [_P, _P, _I, _P]),
-    "gs_blend_forward": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _I, _P, _P]),
-    "gs_blend_backward": (_I, [_P, _P, _P, _P, _P, _P, _P, _I64, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P]),
+    "gs_blend_forward": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P]),
+    "gs_blend_backward": (_I, [_P, _P, _P, _P, _P, _P, _P, _I64, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P]),
     "gs_reduce_partials": (_I, [_P, _P, _P, _P, _I, _P, _P, _I64, _P, _I, _I, _P]),
     "gs_loss_workspace_floats": (_c.c_longlong, [_I, _I]),
     "gs_loss_forward": (_I, [_P, _I, _I, _P, _I, _I, _F, _P, _P, _P, _P]),
@@ -58,7 +58,7 @@ _SIGNATURES = {
     "gs_ellipsoid_offsets": (_I, [_P, _I, _P, _P]),
     "gs_sample_from_points": (_I, [_P, _P, _P, _I, _P, _P]),
     "gs_point_backward": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _I, _F, _F, _F, _F, _F,
-                               _P, _P, _P, _P, _P, _P]),
+                               _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P]),
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)

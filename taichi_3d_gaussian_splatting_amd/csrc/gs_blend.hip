@@ -17,6 +17,7 @@
 //            eleven per (pixel, Gaussian), RAS:674-696); the slots of a Gaussian are summed in a fixed order by
 //            reduce_partials_kernel, so gradients are bitwise reproducible.
 #include "gs_common.h"
+#include "gs_slots.h"
 
 // Automatic FMA contraction is off in this file and every fused multiply-add is written explicitly:
 // the unrolled copies of the inner loops then execute the same instruction sequence for a Gaussian
@@ -58,7 +59,7 @@ constexpr int GROUP = GS_GROUP_FWD > GS_GROUP_BWD ? (GS_GROUP_FWD > 4 ? GS_GROUP
 constexpr int GROUP_FWD = GS_GROUP_FWD;  // list entries evaluated together in the forward blend loop
 constexpr int GROUP_BWD = GS_GROUP_BWD;  // ... in the backward loop
 
-struct TileCoord { int tile_u, tile_v, tile_id; };
+struct TileCoord { int tile_u, tile_v, tile_id, index; };   // index: n-th owned tile (row-major over the owned rows)
 
 // blockIdx -> owned tile.  Consecutive workgroups are dispatched round-robin over the 8 XCDs
 // (block b -> XCD b%8); the remap gives every XCD a contiguous run of tiles so that neighbouring
@@ -73,7 +74,7 @@ __device__ __forceinline__ TileCoord owned_tile(int tw, int row_begin, int row_s
     const int nb = gridDim.x;
     int b = blockIdx.x;
     if (tile_order != nullptr) {
-        b = tile_order[b];   // caller-given dispatch order (longest lists first): a permutation of the owned tiles
+        b = tile_order[b];   // dispatch order (longest walks first, tile_order_kernel): a permutation of the owned tiles
     } else if (GS_XCD_CHUNK > 0) {
         const int group = 8 * GS_XCD_CHUNK, full = (nb / group) * group;
         if (b < full) {
@@ -85,6 +86,7 @@ __device__ __forceinline__ TileCoord owned_tile(int tw, int row_begin, int row_s
         if (b < chunk * 8) b = (b % 8) * chunk + b / 8;
     }
     TileCoord t;
+    t.index = b;
     t.tile_u = b % tw;
     t.tile_v = row_begin + (b / tw) * row_step;
     t.tile_id = t.tile_u + t.tile_v * tw;
@@ -191,6 +193,78 @@ __device__ __forceinline__ void gs_direct_step(const int32_t *__restrict__ paylo
     pos += DIR * BATCH;
 }
 
+// ------------------------------------------------------------------------------- dispatch order
+// The hardware hands workgroups to the CUs in blockIdx order as slots free up.  Tiles differ in work by an order of
+// magnitude (list positions walked: mean 158, max 383 per-tile / 292 and 749 binned at the headline scene), so with
+// tiles in image order the launch ends with a long tail of half-empty CUs: VALU busy 80 %, 3.4 of 5 waves resident on
+// average.  Longest-first (LPT) order fixes most of it (backward 0.46 -> 0.40 ms measured with an order computed by
+// torch).  This kernel is that order on the device: ONE workgroup, counting sort of the owned tiles by 1024 classes of
+// their work estimate, descending (LDS atomics; the order inside a class is arbitrary and irrelevant -- a tile's
+// results do not depend on when it runs).  work[e] given: the estimate of tile e (the forward kernel records the walk
+// length the backward will see); work == nullptr: the length of the tile's (bin's) sorted list.
+constexpr int ORDER_THREADS = 1024, ORDER_CLASSES = 1024, ORDER_ITEMS = 8;   // (one class per thread)
+__global__ __launch_bounds__(ORDER_THREADS) void tile_order_kernel(
+    const int32_t *__restrict__ work, const int32_t *__restrict__ bin_start, const int32_t *__restrict__ bin_end, int n,
+    int tw, int row_begin, int row_step, int bin_shift, int32_t *__restrict__ order) {
+    __shared__ int s_hist[ORDER_CLASSES], s_cur[ORDER_CLASSES], s_red[ORDER_THREADS / GS_WAVE];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int bins_u = (tw + (1 << bin_shift) - 1) >> bin_shift;
+    auto work_of = [&](int e) {
+        if (work != nullptr) return max(work[e], 0);
+        const int tu = e % tw, tv = row_begin + (e / tw) * row_step;
+        const int bin = (tu >> bin_shift) + (tv >> bin_shift) * bins_u;
+        return max(bin_end[bin] - bin_start[bin], 0);
+    };
+    // up to ORDER_ITEMS x 1024 tiles (8192: a 1920 x 1088 frame) live in registers: one read of the estimates; larger frames
+    // re-read them in the later passes
+    int w[ORDER_ITEMS];
+    int mx = 1;
+#pragma unroll
+    for (int k = 0; k < ORDER_ITEMS; ++k) {
+        const int e = k * ORDER_THREADS + tid;
+        w[k] = e < n ? work_of(e) : -1;
+        mx = max(mx, w[k]);
+    }
+    for (int e = ORDER_ITEMS * ORDER_THREADS + tid; e < n; e += ORDER_THREADS) mx = max(mx, work_of(e));
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) mx = max(mx, __shfl_xor(mx, d, GS_WAVE));
+    if (lane == 0) s_red[wv] = mx;
+    s_hist[tid] = 0;
+    s_cur[tid] = 0;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < ORDER_THREADS / GS_WAVE; ++k) mx = max(mx, s_red[k]);
+    // class 0 = heaviest: the counting sort below is then ascending in the class
+    const float scale = (float)(ORDER_CLASSES - 1) / (float)mx;
+    auto class_of = [&](int x) { return ORDER_CLASSES - 1 - min((int)((float)x * scale), ORDER_CLASSES - 1); };
+#pragma unroll
+    for (int k = 0; k < ORDER_ITEMS; ++k)
+        if (w[k] >= 0) atomicAdd(&s_hist[class_of(w[k])], 1);
+    for (int e = ORDER_ITEMS * ORDER_THREADS + tid; e < n; e += ORDER_THREADS) atomicAdd(&s_hist[class_of(work_of(e))], 1);
+    __syncthreads();
+    // exclusive scan of the 1024 class counts, one class per thread
+    const int cnt = s_hist[tid];
+    const int incl = gs_wave_incl_scan(cnt);
+    __syncthreads();                       // (s_red is reused)
+    if (lane == GS_WAVE - 1) s_red[wv] = incl;
+    __syncthreads();
+    int before = 0;
+#pragma unroll
+    for (int k = 0; k < ORDER_THREADS / GS_WAVE; ++k) before += k < wv ? s_red[k] : 0;
+    s_hist[tid] = before + incl - cnt;     // first position of class `tid`
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < ORDER_ITEMS; ++k)
+        if (w[k] >= 0) {
+            const int c = class_of(w[k]);
+            order[s_hist[c] + atomicAdd(&s_cur[c], 1)] = k * ORDER_THREADS + tid;
+        }
+    for (int e = ORDER_ITEMS * ORDER_THREADS + tid; e < n; e += ORDER_THREADS) {
+        const int c = class_of(work_of(e));
+        order[s_hist[c] + atomicAdd(&s_cur[c], 1)] = e;
+    }
+}
+
 // ------------------------------------------------------------------------------- forward
 // STAGED: lists cover a bin of several tiles and are filtered while they are staged (gs_fill_step); otherwise they are
 //         the tile's own list (gs_direct_step)
@@ -203,13 +277,13 @@ __global__ __launch_bounds__(BLEND_THREADS) void blend_forward_kernel(
     const int32_t *__restrict__ payload, const float4 *__restrict__ attrs, int width, int height, int row_begin,
     int row_step, int bin_shift, int filter, float *__restrict__ image, float *__restrict__ depth,
     float *__restrict__ acc_alpha, int32_t *__restrict__ last_effective, int32_t *__restrict__ valid_count,
-    uint32_t *__restrict__ debug_hits) {
+    uint32_t *__restrict__ debug_hits, const int32_t *__restrict__ tile_order, int32_t *__restrict__ tile_work) {
     __shared__ float4 s_p[BATCH], s_c[BATCH], s_q[BATCH];  // rows 0, 2, 3 of the kept records
     __shared__ int s_j[BATCH];                             // their list positions (last_effective is one of them + 1)
     __shared__ int s_o[DEBUG ? BATCH : 1];
     __shared__ int s_cnt[2 * FILL_PER_THREAD], s_next[1];
     const int tw = width / GS_TILE_WIDTH, th = height / GS_TILE_HEIGHT;
-    const TileCoord tc = owned_tile(tw, row_begin, row_step);
+    const TileCoord tc = owned_tile(tw, row_begin, row_step, tile_order);
     const int tid = threadIdx.x;
     const int pu = tc.tile_u * GS_TILE_WIDTH + 2 * (tid & 7);   // left pixel of the pair
     const int pv = tc.tile_v * GS_TILE_HEIGHT + (tid >> 3);
@@ -330,6 +404,15 @@ __global__ __launch_bounds__(BLEND_THREADS) void blend_forward_kernel(
         acc_alpha[p + 1] = 1.f - T.y;
         last_effective[p] = last0;
         last_effective[p + 1] = last1;
+        if (tile_work != nullptr) {   // list positions the backward pass will walk for this tile: its dispatch-order estimate
+            int mx = max(last0, last1);
+#pragma unroll
+            for (int d = 32; d > 0; d >>= 1) mx = max(mx, __shfl_xor(mx, d, GS_WAVE));
+            __syncthreads();          // (all waves are past their last use of s_cnt)
+            if ((tid & 63) == 0) s_cnt[tid >> 6] = mx;
+            __syncthreads();
+            if (tid == 0) tile_work[tc.index] = max(s_cnt[0], s_cnt[1]) - start;
+        }
     }
     if (DEBUG) {
         debug_hits[2 * p] = dc0; debug_hits[2 * p + 1] = dh0;
@@ -637,51 +720,13 @@ __global__ __launch_bounds__(BLEND_THREADS, GS_BWD_MIN_WAVES) void blend_backwar
     }
 }
 
-// Sums the flagged (Gaussian, tile) slots of every visible Gaussian into the accumulator record acc[i] that
-// gs_point_backward consumes.  One lane per Gaussian walks its slots in ascending order (typically ~10); a Gaussian
-// with more than RP_HEAVY slots (the reference's stress scene: 8,160 each, 2.2 ms when a single lane scanned them) is
-// handed to the whole wave instead: lane l takes the slot groups l, l + 64, ... (four consecutive slots each) in
-// ascending order and the 64 partial records are added in a fixed DPP order.  Either way the summation order depends
-// only on the slot layout, so gradients are bitwise reproducible.  Value 10 (pixel count) is summed as an integer.
-constexpr int RP_HEAVY = 128;
+// Sums the flagged (Gaussian, tile) slots of every visible Gaussian into the accumulator record acc[i] (gs_slots.h: the
+// code is shared with the fused per-point backward, which keeps the sums in registers; this kernel serves the callers
+// that need acc in memory -- a multi-GPU run all-reduces it, tests compare it).
 #ifndef GS_RP_MIN_BLOCKS
-#define GS_RP_MIN_BLOCKS 6   // workgroups per CU = waves per SIMD: the kernel lives on memory-level parallelism
+#define GS_RP_MIN_BLOCKS 6   // workgroups per CU = waves per SIMD: the kernel lives on memory-level parallelism (5: 63 -> 69 us
+                             // at the headline size); 77 registers with one record in flight in the whole-wave path
 #endif
-// raised slots fetched together by rp_add_group: 4 where the kernel has registers to spare (sixteen lanes per Gaussian:
-// stress scene 0.198 -> 0.146 ms), 2 in the one-lane-per-Gaussian kernel (4 costs it a wave per SIMD: 55 -> 62 us)
-struct SlotSum { float v[10]; int npix; };
-template <int CHUNK>
-__device__ __forceinline__ void rp_add_group(const uint8_t *__restrict__ flags, const float4 *__restrict__ partials,
-                                             int first, int cnt, SlotSum &a) {
-    unsigned mask = 0u;   // gather the flags of up to 32 consecutive slots (independent byte loads), then visit the
-                          // raised ones (independent 48-B loads): many loads in flight instead of one at a time
-    for (int r = 0; r < cnt; ++r) mask |= (flags[first + r] != 0 ? 1u : 0u) << r;
-    while (mask) {
-        // up to CHUNK raised slots per round: their 48-B records are all requested before the first one is added
-        // (one record per round left the kernel waiting on a full memory latency per slot); added in ascending order
-        int r[CHUNK];
-        float4 p[CHUNK][3];
-#pragma unroll
-        for (int q = 0; q < CHUNK; ++q) {
-            r[q] = mask ? __builtin_ctz(mask) : -1;
-            mask &= mask - 1;   // (0 stays 0)
-        }
-#pragma unroll
-        for (int q = 0; q < CHUNK; ++q)
-            if (r[q] >= 0) {
-                const float4 *src = partials + 3 * (size_t)(first + r[q]);
-                p[q][0] = src[0]; p[q][1] = src[1]; p[q][2] = src[2];
-            }
-#pragma unroll
-        for (int q = 0; q < CHUNK; ++q)
-            if (r[q] >= 0) {
-                a.v[0] += p[q][0].x; a.v[1] += p[q][0].y; a.v[2] += p[q][0].z; a.v[3] += p[q][0].w;
-                a.v[4] += p[q][1].x; a.v[5] += p[q][1].y; a.v[6] += p[q][1].z; a.v[7] += p[q][1].w;
-                a.v[8] += p[q][2].x; a.v[9] += p[q][2].y;
-                a.npix += __builtin_bit_cast(int, p[q][2].z);
-            }
-    }
-}
 // LANES = 1: one lane per Gaussian (+ whole-wave help for the rare heavy one); LANES = 16: sixteen lanes (one DPP
 // row) per Gaussian, lane l taking the slot groups l, l + 16, ... -- chosen by the host when Gaussians own many slots
 // on average (a wave full of heavy Gaussians would otherwise serialise them).
@@ -690,75 +735,22 @@ __global__ __launch_bounds__(GS_BLOCK, GS_RP_MIN_BLOCKS) void reduce_partials_ke
     const int32_t *__restrict__ slot_offsets, const int32_t *__restrict__ ntiles_full,
     const uint8_t *__restrict__ slot_flags, const float4 *__restrict__ partials, int m, float4 *__restrict__ acc,
     const int32_t *__restrict__ nkeys, const float4 *__restrict__ attrs, int tw, int th) {
-    const int i = (int)(((long long)blockIdx.x * GS_BLOCK + threadIdx.x) / LANES), lane = gs_lane();
+    const int i = (int)(((long long)blockIdx.x * GS_BLOCK + threadIdx.x) / LANES);
     const int sub = threadIdx.x & (LANES - 1);
     const bool live = i < m;
-    // a Gaussian that emitted no sort key on this GPU (tile-row sharding) was blended nowhere: no slot to look at
-    const int base = live ? slot_offsets[i] : 0, n = live && (nkeys == nullptr || nkeys[i] > 0) ? ntiles_full[i] : 0;
     SlotSum a;
-#pragma unroll
-    for (int k = 0; k < 10; ++k) a.v[k] = 0.f;
-    a.npix = 0;
     if (LANES > 1) {
-        for (int r0 = 4 * sub; r0 < n; r0 += 4 * LANES) rp_add_group<(LANES > 1 ? 4 : 2)>(slot_flags, partials, base + r0, min(4, n - r0), a);
+        const int base = live ? slot_offsets[i] : 0, n = live && (nkeys == nullptr || nkeys[i] > 0) ? ntiles_full[i] : 0;
+#pragma unroll
+        for (int k = 0; k < 10; ++k) a.v[k] = 0.f;
+        a.npix = 0;
+        for (int r0 = 4 * sub; r0 < n; r0 += 4 * LANES) rp_add_group<4>(slot_flags, partials, base + r0, min(4, n - r0), a);
         // the LANES lanes of a Gaussian are one DPP row: totals land in lane 15 of the row
 #pragma unroll
         for (int k = 0; k < 10; ++k) a.v[k] = gs_row_sum_to_lane15(a.v[k]);
         a.npix = (int)gs_row_sum_to_lane15((float)a.npix);   // < 2^24: exact as a float
     } else {
-        if (n <= RP_HEAVY)
-            for (int r0 = 0; r0 < n; r0 += 32) rp_add_group<2>(slot_flags, partials, base + r0, min(32, n - r0), a);
-        // A heavy Gaussian's slots are the tiles of its reference box (column-major, gs_make_keys), but only tiles the
-        // level set q <= qmax reaches can have been blended -- for a needle a thin diagonal of a huge square (10,000
-        // screen-long needles: 6,000 slots each, 0.45 ms of flag scanning).  With the packed records at hand the wave
-        // visits, one tile column of the cull box per lane, only the rows the level set crosses (gs_common.h, conservative).
-        unsigned long long heavy = __builtin_amdgcn_ballot_w64(n > RP_HEAVY);
-        int t0u = 0, t1u = 0, t0v = 0, t1v = 0, c0u = 0, c1u = 0, c0v = 0, c1v = 0;
-        float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0;
-        bool narrow = false;
-        if (attrs != nullptr && n > RP_HEAVY) {
-            r0 = attrs[4 * (size_t)i]; r1 = attrs[4 * (size_t)i + 1];
-            gs_tile_box(r0.x, r0.y, r1.w, tw, th, t0u, t1u, t0v, t1v);
-            c0u = t0u; c1u = t1u; c0v = t0v; c1v = t1v;
-            const float det = r1.x * r1.z - r1.y * r1.y;
-            narrow = r0.w < 1e30f && r0.w >= 0.f && det > 0.f && (t1u - t0u) * (t1v - t0v) == n;
-            if (narrow) gs_cull_box(r0.x, r0.y, r1.x, r1.y, r1.z, r0.w, c0u, c1u, c0v, c1v);
-        }
-        while (heavy) {   // wave-uniform loop over the heavy Gaussians of this wave
-            const int L = __builtin_ctzll(heavy);
-            heavy &= heavy - 1;
-            const int bL = __builtin_amdgcn_readlane(base, L), nL = __builtin_amdgcn_readlane(n, L);
-            SlotSum h;
-#pragma unroll
-            for (int k = 0; k < 10; ++k) h.v[k] = 0.f;
-            h.npix = 0;
-            if (__builtin_amdgcn_readlane((int)narrow, L)) {
-                const float u = gs_readlane_f(r0.x, L), v = gs_readlane_f(r0.y, L), qm = gs_readlane_f(r0.w, L);
-                const float A = gs_readlane_f(r1.x, L), B = gs_readlane_f(r1.y, L), C = gs_readlane_f(r1.z, L);
-                const int b0u = __builtin_amdgcn_readlane(t0u, L), b0v = __builtin_amdgcn_readlane(t0v, L);
-                const int nv = __builtin_amdgcn_readlane(t1v, L) - b0v;
-                const int k0u = __builtin_amdgcn_readlane(c0u, L), k1u = __builtin_amdgcn_readlane(c1u, L);
-                const int k0v = __builtin_amdgcn_readlane(c0v, L), k1v = __builtin_amdgcn_readlane(c1v, L);
-                for (int cu = k0u + lane; cu < k1u; cu += GS_WAVE) {   // one tile column per lane and round
-                    int ra, rb;
-                    gs_cull_rows_in_column(u, v, A, B, C, qm, cu, ra, rb);
-                    ra = max(ra, k0v); rb = min(rb, k1v);
-                    const int first = bL + nv * (cu - b0u) - b0v;   // slot of (cu, row) = first + row
-                    for (int row = ra; row < rb; row += 4)
-                        rp_add_group<2>(slot_flags, partials, first + row, min(4, rb - row), h);
-                }
-            } else {
-                for (int r0_ = 4 * lane; r0_ < nL; r0_ += 4 * GS_WAVE)
-                    rp_add_group<2>(slot_flags, partials, bL + r0_, min(4, nL - r0_), h);
-            }
-#pragma unroll
-            for (int k = 0; k < 10; ++k) {
-                const float t = gs_readlane63(gs_wave_sum_to_lane63(h.v[k]));
-                if (lane == L) a.v[k] = t;
-            }
-            const float np = gs_readlane63(gs_wave_sum_to_lane63((float)h.npix));   // < 2^24: exact as a float
-            if (lane == L) a.npix = (int)np;
-        }
+        gs_sum_slots_of_lane<2, 1>(live, i, slot_offsets, ntiles_full, slot_flags, partials, nkeys, attrs, tw, th, a);
     }
     if (live && sub == LANES - 1) {
         acc[3 * (size_t)i] = make_float4(a.v[0], a.v[1], a.v[2], a.v[3]);
@@ -771,15 +763,16 @@ template <bool STAGED, bool AUX, bool STATE>
 static void launch_forward(bool debug, dim3 grid, hipStream_t s, const int32_t *bin_start, const int32_t *bin_end,
                            const int32_t *payload, const float4 *attrs, int width, int height, int rb, int rs,
                            int bin_shift, int filter, float *image, float *depth, float *acc_alpha,
-                           int32_t *last_effective, int32_t *valid_count, uint32_t *debug_hits) {
+                           int32_t *last_effective, int32_t *valid_count, uint32_t *debug_hits,
+                           const int32_t *tile_order, int32_t *tile_work) {
     if (debug)
         hipLaunchKernelGGL((blend_forward_kernel<STAGED, AUX, STATE, true>), grid, dim3(BLEND_THREADS), 0, s, bin_start,
                            bin_end, payload, attrs, width, height, rb, rs, bin_shift, filter, image, depth, acc_alpha,
-                           last_effective, valid_count, debug_hits);
+                           last_effective, valid_count, debug_hits, tile_order, tile_work);
     else
         hipLaunchKernelGGL((blend_forward_kernel<STAGED, AUX, STATE, false>), grid, dim3(BLEND_THREADS), 0, s, bin_start,
                            bin_end, payload, attrs, width, height, rb, rs, bin_shift, filter, image, depth, acc_alpha,
-                           last_effective, valid_count, debug_hits);
+                           last_effective, valid_count, debug_hits, tile_order, tile_work);
 }
 
 template <bool STAGED>
@@ -810,7 +803,8 @@ static int owned_row_count(int th, int begin, int step, int end) {
 int gs_blend_forward(const int32_t *bin_start, const int32_t *bin_end, const int32_t *payload, const float *attrs,
                      int width, int height, int tile_row_begin, int tile_row_step, int tile_row_end, int bin_shift,
                      int filter, float *image, float *depth, float *acc_alpha, int32_t *last_effective,
-                     int32_t *valid_count, int flags, uint32_t *debug_pixel_hits, void *stream) {
+                     int32_t *valid_count, int flags, uint32_t *debug_pixel_hits, int32_t *tile_order,
+                     int32_t *tile_work, void *stream) {
     GS_REQUIRE(width % GS_TILE_WIDTH == 0 && height % GS_TILE_HEIGHT == 0, "image size must be a multiple of 16");
     GS_REQUIRE(tile_row_step >= 1 && tile_row_begin >= 0 && tile_row_end >= 0, "tile row ownership");
     GS_REQUIRE(bin_shift >= 0 && bin_shift <= 4, "bin_shift");
@@ -828,10 +822,16 @@ int gs_blend_forward(const int32_t *bin_start, const int32_t *bin_end, const int
     const float4 *a4 = reinterpret_cast<const float4 *>(attrs);
     hipStream_t s = (hipStream_t)stream;
     const bool dbg = debug_pixel_hits != nullptr;
+    GS_REQUIRE(tile_work == nullptr || state, "tile_work is the backward's walk length: it needs the state outputs");
+    if (tile_order != nullptr) {   // longest lists first
+        hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(ORDER_THREADS), 0, s, (const int32_t *)nullptr, bin_start,
+                           bin_end, tw * rows, tw, tile_row_begin, tile_row_step, bin_shift, tile_order);
+        GS_CHECK_LAUNCH();
+    }
 #define GS_FWD(STAGED, AUX, STATE)                                                                                  \
     launch_forward<STAGED, AUX, STATE>(dbg, grid, s, bin_start, bin_end, payload, a4, width, height, tile_row_begin, \
                                        tile_row_step, bin_shift, filter, image, depth, acc_alpha, last_effective,   \
-                                       valid_count, debug_pixel_hits)
+                                       valid_count, debug_pixel_hits, tile_order, tile_work)
 #define GS_FWD2(STAGED)                                                                                             \
     do {                                                                                                            \
         if (aux && state) GS_FWD(STAGED, true, true);                                                               \
@@ -851,7 +851,7 @@ int gs_blend_backward(const int32_t *bin_start, const int32_t *payload, const fl
                       const int32_t *slot_offsets, int64_t n_slots, int width, int height, int tile_row_begin,
                       int tile_row_step, int tile_row_end, int bin_shift, int filter, float *partials,
                       uint8_t *slot_flags, float *magnitude_image, uint32_t *debug_pixel_hits,
-                      const int32_t *tile_order, void *stream) {
+                      const int32_t *tile_work, int32_t *tile_order, void *stream) {
     GS_REQUIRE(width % GS_TILE_WIDTH == 0 && height % GS_TILE_HEIGHT == 0, "image size must be a multiple of 16");
     GS_REQUIRE(tile_row_step >= 1 && tile_row_begin >= 0 && tile_row_end >= 0, "tile row ownership");
     GS_REQUIRE(bin_shift >= 0 && bin_shift <= 4, "bin_shift");
@@ -868,6 +868,12 @@ int gs_blend_backward(const int32_t *bin_start, const int32_t *payload, const fl
     const float4 *a4 = reinterpret_cast<const float4 *>(attrs);
     float4 *p4 = reinterpret_cast<float4 *>(partials);
     const bool staged = bin_shift > 0 || filter != 0;
+    GS_REQUIRE(tile_work == nullptr || tile_order != nullptr, "tile_work needs the tile_order buffer");
+    if (tile_work != nullptr) {   // longest walks first, from the lengths the forward pass recorded
+        hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(ORDER_THREADS), 0, s, tile_work, (const int32_t *)nullptr,
+                           (const int32_t *)nullptr, tw * rows, tw, tile_row_begin, tile_row_step, bin_shift, tile_order);
+        GS_CHECK_LAUNCH();
+    }
     if (staged)
         launch_backward<true>(debug_pixel_hits != nullptr, grid, s, bin_start, payload, a4, grad_image, acc_alpha,
                               last_effective, width, height, tile_row_begin, tile_row_step, bin_shift, filter,

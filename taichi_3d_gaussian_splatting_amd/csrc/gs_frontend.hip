@@ -353,9 +353,9 @@ __global__ __launch_bounds__(GS_BLOCK) void preprocess_kernel(
     const float *__restrict__ xyz, float *__restrict__ feat, const int32_t *__restrict__ obj,
     const float *__restrict__ Kmat, const float *__restrict__ q_cp, const float *__restrict__ t_cp,
     const int32_t *__restrict__ ids, int m_capacity, int use_device_count, int width, int height, RowOwner ow,
-    int bin_shift, int cull, float depth_scale, int32_t *__restrict__ counters, float *__restrict__ attrs,
-    int32_t *__restrict__ ntiles_full, int32_t *__restrict__ nkeys, int32_t *__restrict__ block_sums,
-    int32_t *__restrict__ block_sums_full) {
+    int bin_shift, int cull, int always_store_q, float depth_scale, int32_t *__restrict__ counters,
+    float *__restrict__ attrs, int32_t *__restrict__ ntiles_full, int32_t *__restrict__ nkeys,
+    int32_t *__restrict__ block_sums, int32_t *__restrict__ block_sums_full) {
     __shared__ int s_sum, s_sum_full, s_dq;
     __shared__ BinWalkRec s_rec[GS_BLOCK];   // the key count shares its Gaussians' bins among the lanes of a wave
     __shared__ int s_cnt[GS_BLOCK];
@@ -386,8 +386,9 @@ __global__ __launch_bounds__(GS_BLOCK) void preprocess_kernel(
         const float4 q_in = make_float4(f[0], f[1], f[2], f[3]);
         f[0] = f[0] / nrm; f[1] = f[1] / nrm; f[2] = f[2] / nrm; f[3] = f[3] / nrm;
         // the store is skipped when it would not change the row (an already normalised quaternion: every frame but
-        // the first of a static scene) -- same memory contents, 64 B of HBM write granule per Gaussian less
-        if (f[0] != q_in.x || f[1] != q_in.y || f[2] != q_in.z || f[3] != q_in.w)
+        // the first of a static scene) -- same memory contents, 64 B of HBM write granule per Gaussian less.  A training
+        // iteration always pays it (the optimiser has moved q); always_store_q lets a benchmark on a static scene pay it too
+        if (always_store_q || f[0] != q_in.x || f[1] != q_in.y || f[2] != q_in.z || f[3] != q_in.w)
             row4[0] = make_float4(f[0], f[1], f[2], f[3]);
 
         float K[9];
@@ -706,7 +707,7 @@ int gs_read_counters_async(const int32_t *counters, int32_t *host_counters_pinne
 int gs_preprocess(const float *xyz, float *features, const int32_t *object_id, const float *intrinsics,
                   const float *q_cp, const float *t_cp, const int32_t *ids, int n_visible, int n_visible_on_device,
                   int width, int height, int tile_row_begin, int tile_row_step, int tile_row_end, int bin_shift,
-                  int exact_tile_cull, float depth_scale, int32_t *counters,
+                  int exact_tile_cull, int always_store_rotation, float depth_scale, int32_t *counters,
                   float *attrs, int32_t *num_overlap_tiles, int32_t *num_keys, int32_t *block_sums,
                   int32_t *block_sums_full, void *stream) {
     GS_REQUIRE(n_visible >= 0, "n_visible");
@@ -718,8 +719,8 @@ int gs_preprocess(const float *xyz, float *features, const int32_t *object_id, c
     hipLaunchKernelGGL(preprocess_kernel, dim3(gs_div_up(n_visible, GS_BLOCK)), dim3(GS_BLOCK), 0,
                        (hipStream_t)stream, xyz, features, object_id, intrinsics, q_cp, t_cp, ids, n_visible,
                        n_visible_on_device, width, height, RowOwner{tile_row_begin, tile_row_step, tile_row_end},
-                       bin_shift, exact_tile_cull, depth_scale, counters, attrs, num_overlap_tiles, num_keys,
-                       block_sums, block_sums_full);
+                       bin_shift, exact_tile_cull, always_store_rotation, depth_scale, counters, attrs, num_overlap_tiles,
+                       num_keys, block_sums, block_sums_full);
     GS_CHECK_LAUNCH();
     return 0;
 }

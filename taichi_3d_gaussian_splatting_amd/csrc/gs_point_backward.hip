@@ -10,6 +10,7 @@
 //   dL/ds_c = (sum_a dL/dM[a][c] R[a][c]) exp(s_c),   dL/dq = sum_ab dL/dM[a][b] dM[a][b]/dq
 // which is the same linear map as GP3:270-330 evaluated in a cheaper association order.
 #include "gs_common.h"
+#include "gs_slots.h"
 
 namespace {
 
@@ -44,6 +45,22 @@ __device__ __forceinline__ void sh_basis(const float d[3], float Y[16]) {  // SP
 }
 
 struct Factors { float q, s, alpha, color, color_hi; int keep; /* SH coefficients kept per channel */ };
+// Where a Gaussian's accumulator record comes from when it is not read from `acc`: the slot records of gs_blend_backward,
+// summed here (gs_slots.h) -- the fused form of gs_reduce_partials + gs_point_backward: one launch less and the 48 B x M
+// accumulator array is neither written nor read back.  MEASURED SLOWER at the headline size (0.186 ms against 0.069 +
+// 0.101 ms for the two kernels): the slot gather is latency-bound and lives on waves in flight, and this kernel runs two
+// waves per SIMD (61 KB of row staging per workgroup) where gs_reduce_partials runs six.  Kept as an option of the entry
+// point (small frames, where a launch costs more than the gather), not the operator's default.
+struct SlotSource {
+    const int32_t *slot_offsets, *ntiles_full;
+    const uint8_t *slot_flags;
+    const float4 *partials;
+    int tw, th;
+};
+#ifndef GS_PB_CHUNK
+#define GS_PB_CHUNK 6   // slot records in flight per lane: the kernel runs two waves per SIMD (61 KB of row staging per
+                        // workgroup), so memory-level parallelism has to come from the lane, and registers are plentiful
+#endif
 
 __global__ __launch_bounds__(GS_BLOCK) void point_backward_kernel(
     const float *__restrict__ xyz, const float *__restrict__ feat, const int32_t *__restrict__ obj,
@@ -51,7 +68,7 @@ __global__ __launch_bounds__(GS_BLOCK) void point_backward_kernel(
     const float *__restrict__ t_pc, const int32_t *__restrict__ ids, int m, const float4 *__restrict__ acc,
     const float4 *__restrict__ attrs, const int32_t *__restrict__ ntiles_owned, Factors fac,
     float *__restrict__ grad_xyz, float *__restrict__ grad_feat, float *__restrict__ grad_xyz_vis,
-    float *__restrict__ grad_feat_vis, float *__restrict__ hook_compact) {
+    float *__restrict__ grad_feat_vis, float *__restrict__ hook_compact, SlotSource slots) {
     extern __shared__ __attribute__((aligned(16))) float4 s_rows[];  // [4 waves][64 rows][GS_ROW_F4]
     const int i = blockIdx.x * GS_BLOCK + threadIdx.x;
     const int id = i < m ? ids[i] : -1;
@@ -63,7 +80,17 @@ __global__ __launch_bounds__(GS_BLOCK) void point_backward_kernel(
     const float4 *frow = reinterpret_cast<const float4 *>(feat) + 14 * (size_t)idc;
     const float4 f0 = frow[0], f1 = frow[1];
     const float f[8] = {f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z, f1.w};
-    const float4 A0 = acc[3 * (size_t)ic], A1 = acc[3 * (size_t)ic + 1], A2 = acc[3 * (size_t)ic + 2];
+    float4 A0, A1, A2;
+    if (acc != nullptr) {
+        A0 = acc[3 * (size_t)ic]; A1 = acc[3 * (size_t)ic + 1]; A2 = acc[3 * (size_t)ic + 2];
+    } else {   // fused slot reduction (wave-convergent: every lane takes part in the sums of a heavy Gaussian)
+        SlotSum a;
+        gs_sum_slots_of_lane<GS_PB_CHUNK, 2>(i < m, ic, slots.slot_offsets, slots.ntiles_full, slots.slot_flags, slots.partials,
+                                          ntiles_owned, attrs, slots.tw, slots.th, a);
+        A0 = make_float4(a.v[0], a.v[1], a.v[2], a.v[3]);
+        A1 = make_float4(a.v[4], a.v[5], a.v[6], a.v[7]);
+        A2 = make_float4(a.v[8], a.v[9], __builtin_bit_cast(float, a.npix), 0.f);
+    }
     const float g_uv[2] = {A0.x, A0.y};
     const float g00 = A0.z, g01 = A0.w, g11 = A1.x;
     const float g_rgb[3] = {A1.y, A1.z, A1.w};
@@ -224,8 +251,14 @@ extern "C" int gs_point_backward(const float *xyz, const float *features, const 
                                  float grad_alpha_factor, float grad_color_factor,
                                  float grad_high_order_color_factor, float *grad_xyz, float *grad_features,
                                  float *grad_xyz_visible, float *grad_features_visible, float *hook_compact,
+                                 const int32_t *slot_offsets, const int32_t *num_overlap_tiles,
+                                 const uint8_t *slot_flags, const float *partials, int width, int height,
                                  void *stream) {
     GS_REQUIRE(n_visible >= 0 && n_points >= n_visible, "sizes");
+    GS_REQUIRE(n_visible == 0 || acc != nullptr ||
+                   (slot_offsets != nullptr && num_overlap_tiles != nullptr && slot_flags != nullptr && partials != nullptr &&
+                    width > 0 && height > 0 && width % GS_TILE_WIDTH == 0 && height % GS_TILE_HEIGHT == 0),
+               "gs_point_backward: either acc or the slot records of gs_blend_backward (+ image size)");
     GS_REQUIRE(n_visible == 0 || attrs != nullptr, "gs_point_backward: attrs (the packed records of the forward pass) is required");
     hipStream_t s = (hipStream_t)stream;
     if (n_points > 0 && visible_mask != nullptr && n_visible > 0) {
@@ -245,7 +278,9 @@ extern "C" int gs_point_backward(const float *xyz, const float *features, const 
                        sizeof(float4) * GS_BLOCK * GS_ROW_F4, s, xyz,
                        features, object_id, intrinsics, q_cp, t_cp, t_pc, ids, n_visible,
                        reinterpret_cast<const float4 *>(acc), reinterpret_cast<const float4 *>(attrs), num_owned_tiles,
-                       fac, grad_xyz, grad_features, grad_xyz_visible, grad_features_visible, hook_compact);
+                       fac, grad_xyz, grad_features, grad_xyz_visible, grad_features_visible, hook_compact,
+                       SlotSource{slot_offsets, num_overlap_tiles, slot_flags, reinterpret_cast<const float4 *>(partials),
+                                  width / GS_TILE_WIDTH, height / GS_TILE_HEIGHT});
     GS_CHECK_LAUNCH();
     return 0;
 }

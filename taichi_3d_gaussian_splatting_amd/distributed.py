@@ -54,7 +54,9 @@ def band_boundaries(num_tile_rows: int, world: int, row_weights: Optional[Sequen
     """world + 1 non-decreasing row indices, 0 .. num_tile_rows: band g = rows [b[g], b[g+1]).  With weights, band g
     ends at the first row where the running weight reaches (g+1)/world of the total (deterministic: every rank
     computes the same boundaries from the same replicated weights)."""
-    if row_weights is None or len(row_weights) != num_tile_rows or float(sum(row_weights)) <= 0.0:
+    if row_weights is not None and len(row_weights) != num_tile_rows:
+        raise ValueError(f"row_weights has {len(row_weights)} entries for {num_tile_rows} tile rows")
+    if row_weights is None or float(sum(row_weights)) <= 0.0:
         # equal blocks of ceil(rows / world) rows, the last band(s) shorter: the longest band is as long as in any other
         # even split, and every band sits at a multiple of the block size -- what lets the all-gather run in place
         block = uniform_band_rows(num_tile_rows, world)
@@ -127,17 +129,11 @@ def _padded_base(t: torch.Tensor, height: int, world: int):
     return base
 
 
-_replica_checks = {"calls": 0}
-
-
 def _check_replicas_agree(m: int, device, group) -> None:
     """The accumulators are [M,12] with M = number of Gaussians in the frustum: the replicated point clouds must agree
-    or the all-reduce below would add rows of different Gaussians (or hang on unequal sizes).  Checked with one tiny
-    collective on the first call and then every 1000th (replicas that start identical stay identical: the optimiser
-    and the controller are deterministic under identical seeds)."""
-    _replica_checks["calls"] += 1
-    if _replica_checks["calls"] % 1000 != 1:
-        return
+    or the exchange below would add rows of different Gaussians (or hang on unequal sizes).  One 16-byte collective per
+    backward pass -- small next to the accumulator exchange it protects (a replica that diverges between two sparse
+    checks, e.g. a nondeterministic densification on one rank, would otherwise go unnoticed)."""
     sizes = torch.tensor([m, -m], dtype=torch.int64, device=device)
     dist.all_reduce(sizes, op=dist.ReduceOp.MAX, group=group)
     if int(sizes[0]) != m or int(sizes[1]) != -m:

@@ -151,7 +151,8 @@ def filter_compact(xyz, invalid_mask, object_id, intrinsics, q_cp, t_cp, near_pl
 
 
 def preprocess(xyz, features, object_id, intrinsics, q_cp, t_cp, ids, width, height, layout: ListLayout = ListLayout(),
-               depth_to_sort_key_scale=100.0, counters=None, n_visible_on_device=False):
+               depth_to_sort_key_scale=100.0, counters=None, n_visible_on_device=False,
+               always_store_rotation: bool = False):
     """-> (attrs f32[M,16], num_overlap_tiles i32[M], num_keys i32[M], block_sums, block_sums_full).
     Normalises features[ids, 0:4] IN PLACE (RAS:196-205).  num_overlap_tiles is the reference's box count
     (hook output; its scan gives the backward slots); num_keys is the number of sort keys emitted (bins reached in
@@ -165,7 +166,8 @@ def preprocess(xyz, features, object_id, intrinsics, q_cp, t_cp, ids, width, hei
     block_sums_full = torch.empty_like(block_sums)
     call("gs_preprocess", ptr(xyz), ptr(features), ptr(object_id), ptr(intrinsics), ptr(q_cp), ptr(t_cp), ptr(ids),
          m, int(bool(n_visible_on_device)), int(width), int(height), layout.row_begin, layout.row_step, layout.row_end,
-         layout.bin_shift, int(layout.exact_cull), float(depth_to_sort_key_scale), ptr(counters), ptr(attrs),
+         layout.bin_shift, int(layout.exact_cull), int(bool(always_store_rotation)), float(depth_to_sort_key_scale),
+         ptr(counters), ptr(attrs),
          ptr(ntiles), ptr(nkeys), ptr(block_sums), ptr(block_sums_full), current_stream(dev))
     return attrs, ntiles, nkeys, block_sums, block_sums_full
 
@@ -274,10 +276,13 @@ BLEND_NO_STATE = 2      # GS_BLEND_NO_STATE: no acc_alpha / last_effective (noth
 
 
 def blend_forward(bin_start, bin_end, payload, attrs, width, height, layout: ListLayout = ListLayout(),
-                  out=None, rgb_only=False, need_state=True, debug_hits=False, gathered_rows: int = 0):
+                  out=None, rgb_only=False, need_state=True, debug_hits=False, gathered_rows: int = 0,
+                  ordered: bool = False, tile_work: Optional[torch.Tensor] = None):
     """-> (image, depth, acc_alpha, last_effective, count).  rgb_only: depth and count are not computed (returned
     as None); need_state=False: acc_alpha / last_effective are not computed (None) -- the inference path.
-    debug_hits=True appends a uint32-as-int32 [H,W,2] tensor {blended count, hash of blended payloads} per pixel."""
+    debug_hits=True appends a uint32-as-int32 [H,W,2] tensor {blended count, hash of blended payloads} per pixel.
+    ordered: tiles are dispatched longest list first (same results, shorter tail of the launch); tile_work (int32[owned
+    tiles], needs the state): receives the walk lengths the backward pass will see (blend_backward_partials)."""
     dev = bin_start.device
     flags = (BLEND_RGB_ONLY if rgb_only else 0) | (0 if need_state else BLEND_NO_STATE)
     if out is None:
@@ -299,14 +304,20 @@ def blend_forward(bin_start, bin_end, payload, attrs, width, height, layout: Lis
                    None if rgb_only else i32(height, width))
     image, depth, acc_alpha, last_eff, count = out
     dbg = torch.zeros((height, width, 2), dtype=torch.int32, device=dev) if debug_hits else None
+    order = torch.empty(num_owned_tiles(width, height, layout), dtype=torch.int32, device=dev) if ordered else None
     call("gs_blend_forward", ptr(bin_start), ptr(bin_end), ptr(payload), ptr(attrs), int(width), int(height),
          layout.row_begin, layout.row_step, layout.row_end, layout.bin_shift, layout.filter, ptr(image), ptr(depth),
-         ptr(acc_alpha), ptr(last_eff), ptr(count), flags, ptr(dbg), current_stream(dev))
+         ptr(acc_alpha), ptr(last_eff), ptr(count), flags, ptr(dbg), ptr(order), ptr(tile_work), current_stream(dev))
     return out + (dbg,) if debug_hits else out
 
 
+def num_owned_tiles(width: int, height: int, layout: ListLayout) -> int:
+    return (width // TILE_WIDTH) * len(layout.owned_rows(height))
+
+
 def blend_backward_partials(bin_start, payload, attrs, grad_image, acc_alpha, last_eff, slot_offsets, n_slots,
-                            width, height, layout: ListLayout = ListLayout(), debug_hits=False, tile_order=None):
+                            width, height, layout: ListLayout = ListLayout(), debug_hits=False, tile_order=None,
+                            tile_work=None):
     """Per-pixel backward pass -> (partials f32[S,12], slot_flags u8[S], magnitude image f32[H,W,2]): one partial
     record per (Gaussian, tile) slot, plain stores, no atomics.  debug_hits=True appends the per-pixel
     {count, hash} record of the pairs the backward treated as blended (see blend_forward)."""
@@ -318,10 +329,12 @@ def blend_backward_partials(bin_start, payload, attrs, grad_image, acc_alpha, la
     alloc = torch.zeros if layout.sharded else torch.empty
     mag = alloc((height, width, 2), dtype=torch.float32, device=dev)
     dbg = torch.zeros((height, width, 2), dtype=torch.int32, device=dev) if debug_hits else None
+    if tile_work is not None:   # the forward's walk lengths: the library sorts the tiles by them (longest first)
+        tile_order = torch.empty_like(tile_work)
     call("gs_blend_backward", ptr(bin_start), ptr(payload), ptr(attrs), ptr(grad_image), ptr(acc_alpha),
          ptr(last_eff), ptr(slot_offsets), int(n_slots), int(width), int(height), layout.row_begin, layout.row_step,
          layout.row_end, layout.bin_shift, layout.filter, ptr(partials), ptr(flags), ptr(mag), ptr(dbg),
-         ptr(tile_order), current_stream(dev))
+         ptr(tile_work), ptr(tile_order), current_stream(dev))
     return (partials, flags, mag, dbg) if debug_hits else (partials, flags, mag)
 
 
@@ -337,19 +350,23 @@ def reduce_partials(slot_offsets, num_overlap_tiles, flags, partials, num_keys=N
 
 
 def blend_backward(bin_start, payload, attrs, grad_image, acc_alpha, last_eff, slot_offsets, num_overlap_tiles,
-                   n_slots, width, height, layout: ListLayout = ListLayout(), num_keys=None):
+                   n_slots, width, height, layout: ListLayout = ListLayout(), num_keys=None, tile_work=None):
     """-> (acc f32[M,12], magnitude_grad_viewspace_on_image f32[H,W,2]): blend_backward_partials + reduce_partials."""
     partials, flags, mag = blend_backward_partials(bin_start, payload, attrs, grad_image, acc_alpha, last_eff,
-                                                   slot_offsets, n_slots, width, height, layout)
+                                                   slot_offsets, n_slots, width, height, layout, tile_work=tile_work)
     return reduce_partials(slot_offsets, num_overlap_tiles, flags, partials, num_keys, attrs, width, height), mag
 
 
 def point_backward(xyz, features, object_id, intrinsics, q_cp, t_cp, t_pc, ids, acc, attrs, color_max_sh_band,
                    grad_q_factor, grad_s_factor, grad_alpha_factor, grad_color_factor,
                    grad_high_order_color_factor, want_visible: bool, visible_mask=None, num_owned_tiles=None,
-                   want_visible_features: Optional[bool] = None, want_hook_fields: bool = False):
+                   want_visible_features: Optional[bool] = None, want_hook_fields: bool = False, slots=None,
+                   width: int = 0, height: int = 0):
     """attrs: the packed records of ``preprocess`` (the colour chain reads sigmoid(SH.Y) from them);
-    num_owned_tiles (optional): records with 0 owned tiles are incomplete, their colour is re-evaluated on demand."""
+    num_owned_tiles (optional): records with 0 owned tiles are incomplete, their colour is re-evaluated on demand.
+    acc=None + slots=(slot_offsets, num_overlap_tiles, slot_flags, partials) + image size: the fused form -- the
+    accumulators are summed from the slot records of ``blend_backward_partials`` inside the kernel (same bits as
+    ``reduce_partials``, no [M,12] array in memory)."""
     dev = xyz.device
     n, m = xyz.shape[0], ids.shape[0]
     grad_xyz = torch.empty((n, 3), dtype=torch.float32, device=dev)
@@ -359,11 +376,15 @@ def point_backward(xyz, features, object_id, intrinsics, q_cp, t_cp, t_pc, ids, 
     gx_vis = torch.empty((m, 3), dtype=torch.float32, device=dev) if want_visible else None
     gf_vis = torch.empty((m, FEATURE_DIM), dtype=torch.float32, device=dev) if want_visible_features else None
     hook = torch.empty(7 * m, dtype=torch.float32, device=dev) if want_hook_fields else None
+    so, nt, fl, pa = slots if slots is not None else (None, None, None, None)
+    if acc is None and slots is None:
+        raise ValueError("point_backward needs either acc or the slot records")
     call("gs_point_backward", ptr(xyz), ptr(features), ptr(object_id), ptr(intrinsics), ptr(q_cp), ptr(t_cp),
          ptr(t_pc), ptr(ids), ptr(visible_mask), m, n, ptr(acc), ptr(attrs), ptr(num_owned_tiles), int(color_max_sh_band),
          float(grad_q_factor), float(grad_s_factor),
          float(grad_alpha_factor), float(grad_color_factor), float(grad_high_order_color_factor), ptr(grad_xyz),
-         ptr(grad_feat), ptr(gx_vis), ptr(gf_vis), ptr(hook), current_stream(dev))
+         ptr(grad_feat), ptr(gx_vis), ptr(gf_vis), ptr(hook), ptr(so), ptr(nt), ptr(fl), ptr(pa), int(width), int(height),
+         current_stream(dev))
     if want_hook_fields:   # views of the planes: viewspace [M,2], magnitude [M], pixels i32[M], depth [M], uv [M,2]
         fields = dict(grad_viewspace=hook[0:2 * m].view(m, 2), magnitude_grad_viewspace=hook[2 * m:3 * m],
                       num_affected_pixels=hook[3 * m:4 * m].view(torch.int32), point_depth=hook[4 * m:5 * m],

@@ -69,8 +69,13 @@ class Adam(torch.optim.Optimizer):
                 reg = self._scale_regulariser.get(id(p))
                 mask = self._row_mask.get(id(p))
                 if mask is not None:
+                    if reg is not None and reg[1] is not mask:
+                        raise RuntimeError("set_row_mask and set_scale_regulariser were given different masks")
                     if "last_step" not in state:
-                        state["last_step"] = torch.zeros(p.shape[0], dtype=torch.int32, device=p.device)
+                        # moments restored from a state_dict written without row masks (or by torch.optim.Adam) are
+                        # current as of the previous step: no lazy decay is owed for them
+                        state["last_step"] = torch.full((p.shape[0],), int(state["step"]) - 1, dtype=torch.int32,
+                                                        device=p.device)
                     weight = reg[0] if reg is not None else 0.0
                     ws = torch.empty(256, dtype=torch.int32, device=p.device) if weight else None
                     call("gs_adam_step_rows", ptr(p), ptr(grad), ptr(state["exp_avg"]), ptr(state["exp_avg_sq"]),

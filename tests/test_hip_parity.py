@@ -679,8 +679,10 @@ def test_needles_against_the_f64_spec():
     assert d["image"] <= NEEDLE_IMAGE_TOL and d["grad_feat"] <= NEEDLE_GRAD_TOL and d["grad_xyz"] <= NEEDLE_GRAD_TOL
 
 
-NEEDLE_IMAGE_TOL = 3e-3   # placeholder until measured (set to <= 10x observed)
-NEEDLE_GRAD_TOL = 1e-2    # placeholder until measured (set to <= 10x observed)
+# HIP operator vs fp32 oracle on the kept pixels, round 3: image 1.7e-4, grad_feat 2.3e-4, grad_xyz 5.0e-5 (relative L2);
+# against the f64 spec the operator sits at 2.8e-4 / 4.6e-4 / 1.8e-4 where the fp32 oracle sits at 3.2e-4 / 4.0e-4 / 1.8e-4
+NEEDLE_IMAGE_TOL = 1e-3
+NEEDLE_GRAD_TOL = 2e-3
 
 
 def _chain_scene(n=600, size=96, seed=21):
@@ -705,7 +707,7 @@ def test_long_saturating_chains_against_the_f64_spec():
     assert d["image"] <= REGRESSION_PIXEL_TOL and d["grad_feat"] <= CHAIN_GRAD_TOL and d["grad_xyz"] <= CHAIN_GRAD_TOL
 
 
-CHAIN_GRAD_TOL = 1e-3     # placeholder until measured (set to <= 10x observed)
+CHAIN_GRAD_TOL = 5e-5     # observed 5.3e-6 (features) / 8.2e-6 (positions) against the fp32 oracle, round 3
 
 
 @pytest.mark.parametrize("workload,bin_shift", [("cfg2_100k_800", 0), ("headline_1m_1080p", 0), ("headline_1m_1080p", 1),

@@ -48,6 +48,10 @@ for _ in range(reps + 2):
     start, end = timed("tile_ranges", lambda: hip_ops.tile_ranges(keys, num_tiles, kdb))
     image, depth, acc_alpha, last_eff, count = timed("blend_forward", lambda: hip_ops.blend_forward(
         start, end, payload, attrs, s.width, s.height, LAYOUT))
+    if ORDERED:   # the library's own dispatch order (longest list first) + the walk lengths for the backward
+        tile_work = torch.empty(hip_ops.num_owned_tiles(s.width, s.height, LAYOUT), dtype=torch.int32, device="cuda")
+        out_o = timed("blend_forward_ordered", lambda: hip_ops.blend_forward(
+            start, end, payload, attrs, s.width, s.height, LAYOUT, ordered=True, tile_work=tile_work))
     if AB:   # A/B arm: inference forward (image only)
         timed("blend_forward_rgb_nostate", lambda: hip_ops.blend_forward(
             start, end, payload, attrs, s.width, s.height, LAYOUT, rgb_only=True, need_state=False))
@@ -62,16 +66,24 @@ for _ in range(reps + 2):
         order = torch.argsort(walked_.flatten(), descending=True, stable=True).to(torch.int32)
         partials2, flags2, mag2 = timed("blend_backward_lpt", lambda: hip_ops.blend_backward_partials(
             start, payload, attrs, g, acc_alpha, last_eff, slot_off, n_slots, s.width, s.height, LAYOUT, tile_order=order))
+        partials3, flags3, mag3 = timed("blend_backward_ordered", lambda: hip_ops.blend_backward_partials(
+            start, payload, attrs, g, acc_alpha, last_eff, slot_off, n_slots, s.width, s.height, LAYOUT, tile_work=tile_work))
     acc = timed("reduce_partials", lambda: hip_ops.reduce_partials(slot_off, ntiles, flags, partials))
-    timed("point_backward", lambda: hip_ops.point_backward(
+    unfused = timed("point_backward", lambda: hip_ops.point_backward(
         s.point_cloud, feat, s.point_object_id, s.camera_intrinsics, q_cp, t_cp, s.t_pointcloud_camera, ids, acc, attrs, 3,
         1.0, 0.5, 20.0, 5.0, 1.0, False, vmask, nowned))
+    if AB:   # A/B arm: slot reduction fused into the per-point kernel
+        fused = timed("point_backward_fused", lambda: hip_ops.point_backward(
+            s.point_cloud, feat, s.point_object_id, s.camera_intrinsics, q_cp, t_cp, s.t_pointcloud_camera, ids, None, attrs, 3,
+            1.0, 0.5, 20.0, 5.0, 1.0, False, vmask, nowned, slots=(slot_off, ntiles, flags, partials), width=s.width,
+            height=s.height))
 torch.cuda.synchronize()
 print(f"workload={workload} M={ids.shape[0]} K={k} cull={CULL} bin_shift={LAYOUT.bin_shift}")
 tot = 0.0
 for name, pairs in times.items():
     ms = sum(a.elapsed_time(b) for a, b in pairs[2:]) / len(pairs[2:])
-    tot += 0.0 if name in ("blend_forward_rgb_nostate", "blend_backward_lpt") else ms
+    tot += 0.0 if name in ("blend_forward_rgb_nostate", "blend_backward_lpt", "blend_forward_ordered",
+                           "blend_backward_ordered", "point_backward_fused") else ms
     print(f"  {name:16s} {ms:8.4f} ms")
 print(f"  {'sum':16s} {tot:8.4f} ms")
 lens = (end - start).float()
@@ -84,7 +96,13 @@ hits = acc[:, 10].contiguous().view(torch.int32).double().sum().item()
 print(f"  checksums: acc.sum={acc[:, :10].double().sum().item():.9e} acc.abs={acc[:, :10].double().abs().sum().item():.9e} "
       f"mag.sum={mag.double().sum().item():.9e}; (pixel, Gaussian) hits={hits:.0f} = "
       f"{hits / max(walked.sum().item() * 256.0, 1.0):.4f} of the visited (tile entry x 256 pixel) pairs")
+if AB:
+    print(f"  fused slot reduction identical: {all(torch.equal(a, b) for a, b in zip(fused[:2], unfused[:2]))}")
 if ORDERED:
-    print(f"  lpt arm identical: {bool(torch.equal(partials2[flags2.bool()], partials[flags.bool()]) and torch.equal(mag2, mag))}")
+    print(f"  lpt arm identical: {bool(torch.equal(partials2[flags2.bool()], partials[flags.bool()]) and torch.equal(mag2, mag))}"
+          f"; library-ordered arms identical: backward "
+          f"{bool(torch.equal(partials3[flags3.bool()], partials[flags.bool()]) and torch.equal(mag3, mag))}, forward "
+          f"{all(torch.equal(a, b) for a, b in zip(out_o, (image, depth, acc_alpha, last_eff, count)))}; "
+          f"tile_work == walked: {bool(torch.equal(tile_work.long(), walked.long()))}")
 print(f"  bin list mean={lens.mean():.1f} max={lens.max():.0f}; list positions walked per tile (to max last) "
       f"mean={walked.mean():.1f} max={walked.max():.0f}; blended per pixel mean={count.float().mean():.2f}")
