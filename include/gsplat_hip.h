@@ -230,6 +230,21 @@ int gs_reduce_partials(const int32_t *slot_offsets, const int32_t *num_overlap_t
                        int64_t n_slots_hint /* total number of slots (picks the lanes-per-Gaussian variant; 0 = default) */,
                        const float *attrs, int width, int height, void *stream);
 
+/* Multi-GPU (tile-row sharding): sparse exchange of the accumulators.  The reference has no counterpart (single GPU);
+ * the stage sits between gs_reduce_partials and gs_point_backward when the frame is sharded over several GPUs.
+ * gs_compact_rows: the rows of acc this GPU produced (num_keys[i] > 0: it emitted a sort key for Gaussian i) as an
+ *   ascending list -- ids int32[capacity], rows float[capacity][12]; *count = number of produced rows (entries past
+ *   `capacity` are dropped, the caller compares).  workspace: gs_compact_rows_workspace_bytes(n_visible).
+ * gs_merge_rows: `world` such lists, gathered from all ranks into one buffer -- list g starts at word g * list_stride_words
+ *   and holds `capacity` ids followed by `capacity` rows (capacity % 4 == 0) with counts[g] valid entries -- are summed
+ *   into the dense acc float[n_visible][12] (rows no list mentions: zeros): the lists are added in rank order, the same
+ *   additions in the same order on every rank, so replicated gradients stay bit-identical across ranks. */
+size_t gs_compact_rows_workspace_bytes(int n_visible);
+int gs_compact_rows(const float *acc, const int32_t *num_keys, int n_visible, int capacity, int32_t *ids,
+                    float *rows, int32_t *count, void *workspace, void *stream);
+int gs_merge_rows(const int32_t *lists, int64_t list_stride_words, int capacity, const int32_t *counts, int world,
+                  int n_visible, float *acc, void *stream);
+
 /* Backward per-point pass + gradient post-processing.  Replaces the per-point loop of
  * gaussian_point_rasterisation_backward (RAS:707-772), the dense zero-initialisation
  * (RAS:1051-1053), _clear_grad_by_color_max_sh_band (RAS:1167-1182) and the factor scaling

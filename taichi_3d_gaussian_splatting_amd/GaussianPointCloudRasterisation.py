@@ -380,7 +380,7 @@ class GaussianPointCloudRasterisation(torch.nn.Module):
                         acc = hip_ops.reduce_partials(slot_offsets, num_overlap_tiles, slot_flags, partials,
                                                       num_owned_tiles if ctx.layout.sharded else None, attrs, width, height)
                         if outer.grad_accumulator_reduce is not None:
-                            outer.grad_accumulator_reduce(acc)
+                            acc = outer.grad_accumulator_reduce(acc, num_owned_tiles)
                     # RAS:707-772 + 1102-1125  per-point pass, band clearing and factors fused
                     out = hip_ops.point_backward(
                         xyz, features, obj, intrinsics, q_cp, t_cp, t_pc, ids, acc, attrs, ctx.color_max_sh_band,
@@ -406,7 +406,7 @@ class GaussianPointCloudRasterisation(torch.nn.Module):
         # that does not read it on every iteration (the trainer: only when the controller densifies) may switch it
         # off, ``grad_pointfeatures_in_camera`` is then None
         self.hook_feature_gradients: bool = True
-        self.grad_accumulator_reduce: Optional[Callable[[torch.Tensor], None]] = None
+        self.grad_accumulator_reduce: Optional[Callable[[torch.Tensor, torch.Tensor], torch.Tensor]] = None
         self.image_gather: Optional[Callable[[list], None]] = None
 
     def list_layout(self, height: Optional[int] = None, width: Optional[int] = None) -> "hip_ops.ListLayout":

@@ -44,6 +44,9 @@ _SIGNATURES = {
     "gs_blend_forward": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P]),
     "gs_blend_backward": (_I, [_P, _P, _P, _P, _P, _P, _P, _I64, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P]),
     "gs_reduce_partials": (_I, [_P, _P, _P, _P, _I, _P, _P, _I64, _P, _I, _I, _P]),
+    "gs_compact_rows_workspace_bytes": (_c.c_size_t, [_I]),
+    "gs_compact_rows": (_I, [_P, _P, _I, _I, _P, _P, _P, _P, _P]),
+    "gs_merge_rows": (_I, [_P, _I64, _I, _P, _I, _I, _P, _P]),
     "gs_loss_workspace_floats": (_c.c_longlong, [_I, _I]),
     "gs_loss_forward": (_I, [_P, _I, _I, _P, _I, _I, _F, _P, _P, _P, _P]),
     "gs_loss_backward": (_I, [_P, _I, _I, _P, _P, _I, _I, _F, _P, _P, _P, _P, _P]),

@@ -45,10 +45,22 @@ constexpr float STOP_T = 0.0001f;                  // RAS:458
 #ifndef GS_BWD_MIN_WAVES
 #define GS_BWD_MIN_WAVES 1   // second argument of __launch_bounds__ (minimum waves per SIMD) of the backward kernel
 #endif
-#ifndef GS_BWD_REDUCE
-#define GS_BWD_REDUCE 1      // cross-lane sums of the backward: 1 = per hit entry (gs_wave_reduce12, 34 instructions), 2 = two hit
-                             // entries at a time (gs_wave_reduce12_pair, 50 per pair; one entry stays pending in registers),
-                             // 0 = none (measurement only: the partials are thrown away, gradients are wrong)
+// Cross-lane sums of the backward: 1 = per hit entry (gs_wave_reduce12, 34 instructions), 2 = two hit entries at a time
+// (gs_wave_reduce12_pair, 50 per pair; one entry stays pending in registers: +15 VGPRs, four waves per SIMD instead of
+// five), 0 = none (measurement only: the partials are thrown away, gradients are wrong).  Same bits either way.  Measured
+// at the headline size (profiles/r03_exp1_backward_arms.txt): binned lists 0.489 -> 0.468 ms with pairs, per-tile lists
+// 0.460 -> 0.457 (the lost wave costs what the shorter reduction saves) -- hence pairs for the staged kernel only.
+#ifndef GS_BWD_REDUCE_STAGED
+#define GS_BWD_REDUCE_STAGED 2
+#endif
+#ifndef GS_BWD_REDUCE_DIRECT
+#define GS_BWD_REDUCE_DIRECT 1
+#endif
+#ifdef GS_BWD_REDUCE          // (one switch for both kernels: tools/build_variants.sh)
+#undef GS_BWD_REDUCE_STAGED
+#undef GS_BWD_REDUCE_DIRECT
+#define GS_BWD_REDUCE_STAGED GS_BWD_REDUCE
+#define GS_BWD_REDUCE_DIRECT GS_BWD_REDUCE
 #endif
 #ifndef GS_BWD_TRIM
 #define GS_BWD_TRIM 1        // 1: hit masks combined on the scalar unit, |v| accumulated with the VOP3 abs modifier, the four
@@ -476,17 +488,14 @@ __global__ __launch_bounds__(BLEND_THREADS, GS_BWD_MIN_WAVES) void blend_backwar
     const int row = lane >> 4;
     const int slot = ((row & 1) << 1) | (row >> 1);  // rows (0,1,2,3) -> values (0,2,1,3) of each result register
     const bool row_tail = (lane & 15) == 15;
-#if GS_BWD_REDUCE == 2
+    constexpr int REDUCE = STAGED ? GS_BWD_REDUCE_STAGED : GS_BWD_REDUCE_DIRECT;
     // destination of this lane's pair-reduce results (gs_wave_reduce12_pair): lanes 7 and 15 of each row
     const bool pair_tail = (lane & 7) == 7, pair_b_sel = (row >> 1) != 0;
     const int pair_vi = 2 * ((lane >> 3) & 1) + (row & 1);
     float pend_x[12];
     int pend_k = 0;
-    int pend = 0;   // wave-uniform: 1 while a hit entry's partials are waiting in pend_x
-#endif
-#if GS_BWD_REDUCE == 0
+    int pend = 0;   // wave-uniform: 1 while a hit entry's partials are waiting in pend_x (REDUCE == 2)
     float sink = 0.f;
-#endif
 #if GS_MFMA_REDUCE
     const GsMfmaReduceConsts mfma_consts = gs_mfma_reduce_consts();
 #endif
@@ -616,64 +625,61 @@ __global__ __launch_bounds__(BLEND_THREADS, GS_BWD_MIN_WAVES) void blend_backwar
                     for (int n = 0; n < 11; ++n) asm("v_add_f32 %0, %1, %2" : "=v"(x[n]) : "v"(pq[n].x), "v"(pq[n].y));
                     x[11] = 0.f;
                 };
-#if GS_BWD_REDUCE == 0
-                {   // measurement only: what the kernel costs without the cross-lane sums
+                if constexpr (REDUCE == 0) {   // measurement only: what the kernel costs without the cross-lane sums
                     float x[12];
                     partials_of_entry(x);
 #pragma unroll
                     for (int n = 0; n < 11; ++n) sink += x[n];
-                }
-#elif GS_BWD_REDUCE == 2
-                // Two hit entries share one reduce-scatter: the first one's partials wait in registers (pend_x) until the
-                // wave meets its next hit entry of this round; a leftover is reduced alone before the flush.  Both
-                // reduce-scatters add a value's 64 lanes in the same tree (gs_common.h), so an entry's sums are the same
-                // bits whether it found a partner or not.
-                // (the two arms are kept apart by distinct asm markers: merged, the compiler computes into scratch registers
-                // and copies twelve values into pend_x)
-                if (__builtin_amdgcn_readfirstlane(pend)) {
-                    asm volatile("; pair: second entry");
+                } else if constexpr (REDUCE == 2) {
+                    // Two hit entries share one reduce-scatter: the first one's partials wait in registers (pend_x) until the
+                    // wave meets its next hit entry of this round; a leftover is reduced alone before the flush.  Both
+                    // reduce-scatters add a value's 64 lanes in the same tree (gs_common.h), so an entry's sums are the same
+                    // bits whether it found a partner or not.
+                    // (the two arms are kept apart by distinct asm markers: merged, the compiler computes into scratch
+                    // registers and copies twelve values into pend_x)
+                    if (__builtin_amdgcn_readfirstlane(pend)) {
+                        asm volatile("; pair: second entry");
+                        float x[12];
+                        partials_of_entry(x);
+                        float w0, w1, w2;
+                        gs_wave_reduce12_pair(pend_x, x, w0, w1, w2);
+                        if (pair_tail) {
+                            float *A = &s_acc[pair_b_sel ? k + i : pend_k][pair_vi];
+                            atomicAdd(A, w0);
+                            atomicAdd(A + 4, w1);
+                            atomicAdd(A + 8, w2);
+                        }
+                        pend = 0;
+                    } else {
+                        asm volatile("; pair: first entry");
+                        partials_of_entry(pend_x);
+                        pend_k = k + i;
+                        pend = 1;
+                    }
+                } else {
                     float x[12];
                     partials_of_entry(x);
-                    float w0, w1, w2;
-                    gs_wave_reduce12_pair(pend_x, x, w0, w1, w2);
-                    if (pair_tail) {
-                        float *A = &s_acc[pair_b_sel ? k + i : pend_k][pair_vi];
-                        atomicAdd(A, w0);
-                        atomicAdd(A + 4, w1);
-                        atomicAdd(A + 8, w2);
-                    }
-                    pend = 0;
-                } else {
-                    asm volatile("; pair: first entry");
-                    partials_of_entry(pend_x);
-                    pend_k = k + i;
-                    pend = 1;
-                }
-#else
-                float x[12];
-                partials_of_entry(x);
-                // the 12-value reduce-scatter over the 64 lanes (gs_common.h); row totals land in lane 15 of each row:
-                // t0 (v0, c00, v1, c01)  t1 (c11, gg, gr, gb)  t2 (w, count, |v|, 0)
+                    // the 12-value reduce-scatter over the 64 lanes (gs_common.h); row totals land in lane 15 of each row:
+                    // t0 (v0, c00, v1, c01)  t1 (c11, gg, gr, gb)  t2 (w, count, |v|, 0)
 #if GS_MFMA_REDUCE
-                // matrix-pipe variant: lane n (< 11) ends up with the wave total of value n
-                const float tot = gs_wave_reduce12_mfma(x[0], x[1], x[2], x[3], x[4], x[5], x[6], x[7], x[8], x[9], x[10],
-                                                        0.f, mfma_consts);
-                if (lane < 11) atomicAdd(&s_acc[k + i][lane], tot);
+                    // matrix-pipe variant: lane n (< 11) ends up with the wave total of value n
+                    const float tot = gs_wave_reduce12_mfma(x[0], x[1], x[2], x[3], x[4], x[5], x[6], x[7], x[8], x[9], x[10],
+                                                            0.f, mfma_consts);
+                    if (lane < 11) atomicAdd(&s_acc[k + i][lane], tot);
 #else
-                float t0, t1, t2;
-                gs_wave_reduce12(x[0], x[1], x[2], x[3], x[4], x[5], x[6], x[7], x[8], x[9], x[10], 0.f, t0, t1, t2);
-                if (row_tail) {
-                    float *A = &s_acc[k + i][slot];
-                    atomicAdd(A, t0);
-                    atomicAdd(A + 4, t1);
-                    atomicAdd(A + 8, t2);
+                    float t0, t1, t2;
+                    gs_wave_reduce12(x[0], x[1], x[2], x[3], x[4], x[5], x[6], x[7], x[8], x[9], x[10], 0.f, t0, t1, t2);
+                    if (row_tail) {
+                        float *A = &s_acc[k + i][slot];
+                        atomicAdd(A, t0);
+                        atomicAdd(A + 4, t1);
+                        atomicAdd(A + 8, t2);
+                    }
+#endif
                 }
-#endif
-#endif
             }
         }
-#if GS_BWD_REDUCE == 2
-        if (__builtin_amdgcn_readfirstlane(pend)) {   // the round's odd hit entry
+        if (REDUCE == 2 && __builtin_amdgcn_readfirstlane(pend)) {   // the round's odd hit entry
             float t0, t1, t2;
             gs_wave_reduce12(pend_x[0], pend_x[1], pend_x[2], pend_x[3], pend_x[4], pend_x[5], pend_x[6], pend_x[7],
                              pend_x[8], pend_x[9], pend_x[10], 0.f, t0, t1, t2);
@@ -685,7 +691,6 @@ __global__ __launch_bounds__(BLEND_THREADS, GS_BWD_MIN_WAVES) void blend_backwar
             }
             pend = 0;
         }
-#endif
         __syncthreads();
         // flush: thread k owns staged entry k -> one 48-B store into the (Gaussian, tile) slot
         if (tid < nbuf) {
@@ -707,9 +712,7 @@ __global__ __launch_bounds__(BLEND_THREADS, GS_BWD_MIN_WAVES) void blend_backwar
             }
         }
     }
-#if GS_BWD_REDUCE == 0
-    mag_u.x += 1e-30f * sink;
-#endif
+    if (REDUCE == 0) mag_u.x += 1e-30f * sink;
     magnitude_image[2 * p] = mag_u.x;
     magnitude_image[2 * p + 1] = mag_v.x;
     magnitude_image[2 * p + 2] = mag_u.y;

@@ -7,8 +7,10 @@ binning/sort/blend only for its rows, and the full image is assembled on every r
 ``backend="nccl"`` is RCCL on ROCm): with the default bands each output tensor is gathered IN PLACE (the rasteriser
 allocates it so that every band is an equal slice), otherwise the bands are packed into one buffer and gathered with
 one collective.  In the backward pass every rank back-propagates its own tiles and the per-Gaussian accumulators
-(48 B x M, not the 236 B x N dense gradients) are summed with one all-reduce before the per-point chain rule, so every
-rank ends up with the full gradient of its replicated parameters.
+(48 B x M, not the 236 B x N dense gradients) are summed over the ranks before the per-point chain rule, so every rank ends
+up with the full gradient of its replicated parameters: with bands by a SPARSE exchange -- a rank sends only the rows it
+produced (~M/G + the Gaussians that straddle its band boundaries), all-gathered and added in rank order, bit-identical on
+every rank (``exchange_accumulators_sparse``) --, with interleaved rows by one dense all-reduce.
 
 One process per GPU (``torch.distributed``); works unchanged on ``gloo`` for the CPU tests of the
 collective logic (tests/test_distributed_cpu.py).
@@ -141,26 +143,75 @@ def _check_replicas_agree(m: int, device, group) -> None:
                            f"{-int(sizes[1])} and {int(sizes[0])}: the replicated point clouds have diverged")
 
 
-def all_reduce_accumulators(acc: torch.Tensor, group: Optional[dist.ProcessGroup] = None) -> None:
-    """Sum the [M,12] backward accumulators over ranks with ONE collective.  Column 10 holds an int32 pixel
-    count in the float's bits (include/gsplat_hip.h): it is converted to a float value for the reduction (a
-    pixel count is < 2^24, so the float sum is exact in any order) and back to integer bits afterwards."""
+def all_reduce_accumulators(acc: torch.Tensor, group: Optional[dist.ProcessGroup] = None) -> torch.Tensor:
+    """Sum the [M,12] backward accumulators over ranks with ONE dense collective (in place; returns acc).  Column 10
+    holds an int32 pixel count in the float's bits (include/gsplat_hip.h): it is converted to a float value for the
+    reduction (a pixel count is < 2^24, so the float sum is exact in any order) and back to integer bits afterwards."""
     _check_replicas_agree(acc.shape[0], acc.device, group)
     col = acc[:, 10]
     col.copy_(col.view(torch.int32))            # int32 bits -> float value, one converting copy over the same memory
     dist.all_reduce(acc, op=dist.ReduceOp.SUM, group=group)
     col.view(torch.int32).copy_(col)            # the sum of integers below 2^24 is an integer: exact conversion back
+    return acc
+
+
+def exchange_accumulators_sparse(acc: torch.Tensor, num_keys: torch.Tensor, group: Optional[dist.ProcessGroup] = None,
+                                 compact=None, merge=None, stats: Optional[dict] = None) -> torch.Tensor:
+    """Sum of the [M,12] accumulators over ranks WITHOUT moving the rows a rank did not produce.  With bands a Gaussian
+    is blended by one rank (two when it straddles a band boundary), so a rank's accumulator array is ~(1 - 1/G) zeros:
+    each rank compacts the rows it produced (``num_keys > 0``) into an ascending (row id, 48-B record) list, the lists
+    are all-gathered (one collective; the list lengths -- and the replica check -- travel in a 16-byte one before it)
+    and every rank adds them in rank order: identical additions in identical order everywhere, so the replicated
+    gradients are bit-identical across ranks and from run to run.  At G = 8 a rank sends ~M/8 + straddlers rows of 52 B
+    instead of taking part in a 48 B x M all-reduce.  ``compact`` / ``merge``: the two device stages
+    (``hip_ops.compact_rows`` / ``hip_ops.merge_rows``; the CPU tests of the collective logic inject stand-ins)."""
+    if compact is None or merge is None:
+        from . import hip_ops
+        compact, merge = compact or hip_ops.compact_rows, merge or hip_ops.merge_rows
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    m, dev = acc.shape[0], acc.device
+    ids, rows, count = compact(acc, num_keys)
+    mine = torch.stack([count.reshape(()).to(torch.int64), torch.full((), m, dtype=torch.int64, device=dev)])
+    sizes = torch.empty((world, 2), dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(sizes.view(-1), mine, group=group)
+    host = sizes.tolist()                       # the one host synchronisation of the exchange (list lengths)
+    if any(row[1] != m for row in host):
+        raise RuntimeError(f"rank {rank}: {m} Gaussians in the frustum, other ranks {[row[1] for row in host]}: the "
+                           f"replicated point clouds have diverged")
+    counts = [row[0] for row in host]
+    cap = max(4, -(-max(counts) // 4) * 4)      # 16-B aligned rows behind the ids
+    stride = 13 * cap
+    send = torch.empty(stride, dtype=torch.int32, device=dev)
+    n_mine = counts[rank]
+    send[:n_mine].copy_(ids[:n_mine])
+    send[cap:cap + 12 * n_mine].view(torch.float32).copy_(rows[:n_mine].reshape(-1))
+    recv = torch.empty(world * stride, dtype=torch.int32, device=dev)
+    dist.all_gather_into_tensor(recv, send, group=group)
+    if stats is not None:
+        stats.update(rows_sent=n_mine, rows_total=sum(counts), capacity=cap, bytes_sent=4 * stride,
+                     dense_bytes=48 * m)
+    return merge(recv, stride, cap, sizes[:, 0].to(torch.int32).contiguous(), world, m)
 
 
 def shard_rasteriser_across_tile_rows(rasteriser, group: Optional[dist.ProcessGroup] = None, force: bool = False,
-                                      mode: str = "bands"):
+                                      mode: str = "bands", accumulator_exchange: Optional[str] = None):
     """Configure a ``GaussianPointCloudRasterisation`` instance for tile-row sharding over ``group`` (see
     ``owned_tile_rows`` for the two modes; ``rasteriser.shard_row_weights`` may be set to per-tile-row weights --
-    identical on every rank -- to balance the bands)."""
+    identical on every rank -- to balance the bands).  accumulator_exchange: "sparse" (default with bands: every rank
+    sends only the accumulator rows it produced, ``exchange_accumulators_sparse``) or "dense" (one all-reduce of the
+    whole [M,12] array; default with interleaved rows, where every rank meets nearly every Gaussian)."""
     rank, world = dist.get_rank(group), dist.get_world_size(group)
     rasteriser.shard = (rank, world, mode)
+    exchange = accumulator_exchange or ("sparse" if mode == "bands" else "dense")
+    if exchange not in ("sparse", "dense"):
+        raise ValueError(exchange)
     if world > 1 or force:
         rasteriser.image_gather = lambda tensors: all_gather_tile_rows(
             tensors, rank, world, group, force, mode, rasteriser.shard_row_weights)
-        rasteriser.grad_accumulator_reduce = lambda acc: all_reduce_accumulators(acc, group)
+        rasteriser.exchange_stats = {}
+        if exchange == "sparse":
+            rasteriser.grad_accumulator_reduce = lambda acc, num_keys: exchange_accumulators_sparse(
+                acc, num_keys, group, stats=rasteriser.exchange_stats)
+        else:
+            rasteriser.grad_accumulator_reduce = lambda acc, num_keys: all_reduce_accumulators(acc, group)
     return rasteriser

@@ -357,6 +357,27 @@ def blend_backward(bin_start, payload, attrs, grad_image, acc_alpha, last_eff, s
     return reduce_partials(slot_offsets, num_overlap_tiles, flags, partials, num_keys, attrs, width, height), mag
 
 
+def compact_rows(acc: torch.Tensor, num_keys: torch.Tensor):
+    """Multi-GPU: the accumulator rows this GPU produced (num_keys > 0), ascending -> (ids i32[M], rows f32[M,12],
+    count i32[1] on the device); the first `count` entries are valid."""
+    m, dev = acc.shape[0], acc.device
+    ids = torch.empty(m, dtype=torch.int32, device=dev)
+    rows = torch.empty((m, ACC_STRIDE), dtype=torch.float32, device=dev)
+    count = torch.empty(1, dtype=torch.int32, device=dev)
+    ws = torch.empty(_lib.load().gs_compact_rows_workspace_bytes(m), dtype=torch.uint8, device=dev)
+    call("gs_compact_rows", ptr(acc), ptr(num_keys), m, m, ptr(ids), ptr(rows), ptr(count), ptr(ws), current_stream(dev))
+    return ids, rows, count
+
+
+def merge_rows(lists: torch.Tensor, stride_words: int, capacity: int, counts: torch.Tensor, world: int, m: int):
+    """Multi-GPU: `world` gathered row lists (int32 words: per rank `capacity` ids, then `capacity` 48-B rows) summed in
+    rank order -> dense acc f32[M,12]."""
+    acc = torch.empty((m, ACC_STRIDE), dtype=torch.float32, device=lists.device)
+    call("gs_merge_rows", ptr(lists), int(stride_words), int(capacity), ptr(counts), int(world), int(m), ptr(acc),
+         current_stream(lists.device))
+    return acc
+
+
 def point_backward(xyz, features, object_id, intrinsics, q_cp, t_cp, t_pc, ids, acc, attrs, color_max_sh_band,
                    grad_q_factor, grad_s_factor, grad_alpha_factor, grad_color_factor,
                    grad_high_order_color_factor, want_visible: bool, visible_mask=None, num_owned_tiles=None,

@@ -85,6 +85,85 @@ def test_all_gather_tile_rows_world3_weighted_bands_with_an_empty_band():
     _run(3, 80, 32, weights=[0.0, 0.0, 10.0, 0.5, 0.5])   # bands [0,3) [3,3) [3,5): rank 1 owns nothing
 
 
+def _compact_stand_in(acc, num_keys):
+    """What hip_ops.compact_rows does, in torch (CPU test double of the device stage)."""
+    keep = torch.nonzero(num_keys > 0).flatten()
+    m = acc.shape[0]
+    ids = torch.full((m,), -7, dtype=torch.int32)
+    rows = torch.full((m, 12), float("nan"))
+    ids[:len(keep)] = keep.to(torch.int32)
+    rows[:len(keep)] = acc[keep]
+    return ids, rows, torch.tensor([len(keep)], dtype=torch.int32)
+
+
+def _merge_stand_in(lists, stride, cap, counts, world, m):
+    """What hip_ops.merge_rows does: the gathered lists added in rank order (column 10: int32 bits summed as integers)."""
+    acc = torch.zeros(m, 12)
+    npix = torch.zeros(m, dtype=torch.int32)
+    for g in range(world):
+        block = lists[g * stride:(g + 1) * stride]
+        n = int(counts[g])
+        ids = block[:n].long()
+        rows = block[cap:cap + 12 * cap].view(torch.float32).view(cap, 12)[:n]
+        acc[ids] += rows                      # ids are distinct within a list
+        npix[ids] += rows[:, 10].contiguous().view(torch.int32)
+    acc[:, 10] = npix.view(torch.float32)
+    return acc
+
+
+def _sparse_worker(rank, world, port, m):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from taichi_3d_gaussian_splatting_amd.distributed import exchange_accumulators_sparse
+    # band-like ownership: rank g produced rows of a contiguous id range plus a few "straddlers" of its neighbours
+    gens = [torch.Generator().manual_seed(300 + r) for r in range(world)]
+    accs, keys = [], []
+    for r in range(world):
+        lo, hi = r * m // world, (r + 1) * m // world
+        nk = torch.zeros(m, dtype=torch.int32)
+        nk[max(lo - 5, 0):min(hi + 5, m)] = 1 + torch.randint(0, 9, (min(hi + 5, m) - max(lo - 5, 0),), generator=gens[r],
+                                                              dtype=torch.int32)
+        nk[torch.randint(0, m, (7,), generator=gens[r])] = 3          # a few large Gaussians seen by several ranks
+        a = torch.rand(m, 12, generator=gens[r]) * (nk > 0)[:, None]
+        a[:, 10] = (torch.randint(0, 5000, (m,), generator=gens[r], dtype=torch.int32) * (nk > 0)).view(torch.float32)
+        a[:, 11] = 0.0
+        accs.append(a); keys.append(nk)
+    stats = {}
+    got = exchange_accumulators_sparse(accs[rank].clone(), keys[rank], compact=_compact_stand_in, merge=_merge_stand_in,
+                                       stats=stats)
+    expect = torch.zeros(m, 12)
+    for r in range(world):                      # rank order
+        expect[:, :10] += accs[r][:, :10]
+    assert torch.equal(got[:, :10], expect[:, :10])                   # same additions in the same order: bit-exact
+    assert torch.equal(got[:, 10].contiguous().view(torch.int32),
+                       sum(a[:, 10].contiguous().view(torch.int32) for a in accs))
+    assert stats["rows_sent"] == int((keys[rank] > 0).sum()) and stats["rows_sent"] < 0.7 * m
+    assert stats["bytes_sent"] < stats["dense_bytes"]
+    # every rank ends with the same bits
+    digest = got.view(torch.int32).long().sum().view(1)
+    everyone = [torch.zeros_like(digest) for _ in range(world)]
+    dist.all_gather(everyone, digest)
+    assert all(torch.equal(everyone[0], e) for e in everyone)
+    # diverged replicas are reported, not summed
+    if world > 1:
+        try:
+            exchange_accumulators_sparse(accs[rank][:m - rank].clone(), keys[rank][:m - rank], compact=_compact_stand_in,
+                                         merge=_merge_stand_in)
+        except RuntimeError as e:
+            assert "diverged" in str(e)
+        else:
+            raise AssertionError("replicas with different M went unnoticed")
+    dist.destroy_process_group()
+
+
+def test_sparse_accumulator_exchange_world2_and_3():
+    """Collective logic of the sparse accumulator exchange (device stages replaced by torch stand-ins): the sum over ranks in
+    rank order, bit-identical on every rank, fewer bytes than the dense all-reduce, diverged replicas detected."""
+    for world in (2, 3):
+        mp.spawn(_sparse_worker, args=(world, _free_port(), 1000), nprocs=world, join=True)
+
+
 def test_owned_rows_partition():
     from taichi_3d_gaussian_splatting_amd.distributed import band_boundaries, owned_tile_rows
     for th in (1, 5, 67):

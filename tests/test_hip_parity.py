@@ -986,6 +986,15 @@ def test_rccl_collectives_on_device_world1():
         ref_acc = acc.clone()
         D.all_reduce_accumulators(acc)
         assert torch.equal(acc.view(torch.int32), ref_acc.view(torch.int32))
+        # the sparse exchange through RCCL with the device stages (compact -> all-gather -> merge in rank order)
+        nk = (torch.rand(1000, device="cuda") < 0.3).to(torch.int32)
+        masked = ref_acc * (nk > 0)[:, None]
+        masked[:, 10] = (ref_acc[:, 10].contiguous().view(torch.int32) * nk).view(torch.float32)
+        stats = {}
+        got = D.exchange_accumulators_sparse(masked.clone(), nk, stats=stats)
+        assert torch.equal(got[:, :10], masked[:, :10]) and not got[:, 11].any()
+        assert torch.equal(got[:, 10].contiguous().view(torch.int32), masked[:, 10].contiguous().view(torch.int32))
+        assert stats["rows_sent"] == int(nk.sum())
         # the sharded operator end to end under a (trivial) process group
         s = small_scene(n=2000, size=128, seed=9)
         g = make_grad_image(128, 128)

@@ -55,10 +55,19 @@ def _worker(rank, world, port, n, height, width, mode):
                 q_pointcloud_camera=s.q_pointcloud_camera, t_pointcloud_camera=s.t_pointcloud_camera,
                 color_max_sh_band=3))
             (image * g).sum().backward()
+            if sharded:
+                hooks["stats"] = dict(op.exchange_stats)
             return image.detach(), depth.detach(), count, xyz.grad, feat.grad
 
         base = run(False)
         shard = run(True)
+        again = run(True)
+        # the accumulator exchange adds the ranks' contributions in a fixed order: run-to-run bitwise reproducible
+        assert torch.equal(shard[3].view(torch.int32), again[3].view(torch.int32))
+        assert torch.equal(shard[4].view(torch.int32), again[4].view(torch.int32))
+        if mode == "bands":   # sparse exchange: a rank sends the rows it produced, not all M
+            st = hooks["stats"]
+            assert 0 < st["rows_sent"] < hooks[True].point_id_in_camera_list.shape[0] and st["bytes_sent"] < st["dense_bytes"]
         assert torch.equal(base[0], shard[0]) and torch.equal(base[1], shard[1]) and torch.equal(base[2], shard[2])
         for a, b in ((base[3], shard[3]), (base[4], shard[4])):
             assert (a - b).abs().max() <= 2e-5 * a.abs().max()           # sums over ranks: order differs
@@ -68,8 +77,9 @@ def _worker(rank, world, port, n, height, width, mode):
         assert torch.equal(hb.num_affected_pixels, hs.num_affected_pixels)          # integer sum: exact
         assert torch.equal(hb.num_overlap_tiles, hs.num_overlap_tiles)
         assert torch.allclose(hb.magnitude_grad_viewspace, hs.magnitude_grad_viewspace, rtol=1e-5, atol=1e-12)
-        # every rank holds the same result
-        mine = torch.stack([shard[3].double().sum(), shard[4].double().sum(), shard[0].double().sum()]).cpu()
+        # every rank holds the same result, bit for bit (digest: wrap-around sums of the gradients' bit patterns)
+        mine = torch.stack([shard[3].view(torch.int32).long().sum(), shard[4].view(torch.int32).long().sum(),
+                            shard[0].view(torch.int32).long().sum()]).cpu()
         everyone = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(everyone, mine)
         assert all(torch.equal(everyone[0], e) for e in everyone)
