@@ -45,6 +45,7 @@ __device__ __forceinline__ void sh_basis(const float d[3], float Y[16]) {  // SP
 }
 
 struct Factors { float q, s, alpha, color, color_hi; int keep; /* SH coefficients kept per channel */ };
+constexpr int ZERO_ROUNDS = 8;   // rows per thread of the workgroups that zero the rows of invisible points
 // Where a Gaussian's accumulator record comes from when it is not read from `acc`: the slot records of gs_blend_backward,
 // summed here (gs_slots.h) -- the fused form of gs_reduce_partials + gs_point_backward: one launch less and the 48 B x M
 // accumulator array is neither written nor read back.  MEASURED SLOWER at the headline size (0.186 ms against 0.069 +
@@ -68,9 +69,27 @@ __global__ __launch_bounds__(GS_BLOCK) void point_backward_kernel(
     const float *__restrict__ t_pc, const int32_t *__restrict__ ids, int m, const float4 *__restrict__ acc,
     const float4 *__restrict__ attrs, const int32_t *__restrict__ ntiles_owned, Factors fac,
     float *__restrict__ grad_xyz, float *__restrict__ grad_feat, float *__restrict__ grad_xyz_vis,
-    float *__restrict__ grad_feat_vis, float *__restrict__ hook_compact, SlotSource slots) {
+    float *__restrict__ grad_feat_vis, float *__restrict__ hook_compact, SlotSource slots,
+    const int8_t *__restrict__ visible_mask, int n_points, int n_zero_blocks) {
     extern __shared__ __attribute__((aligned(16))) float4 s_rows[];  // [4 waves][64 rows][GS_ROW_F4]
-    const int i = blockIdx.x * GS_BLOCK + threadIdx.x;
+    if ((int)blockIdx.x < n_zero_blocks) {
+        // The leading workgroups zero the rows of the dense gradients that belong to points NOT in the frustum (RAS:1051-1053
+        // zero-initialises everything; the visible rows are fully written by the other workgroups): formerly a launch of its
+        // own for a few per cent of the rows.
+        float4 *gf4 = reinterpret_cast<float4 *>(grad_feat);
+        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int r = 0; r < ZERO_ROUNDS; ++r) {
+            const int row = (int)blockIdx.x * (GS_BLOCK * ZERO_ROUNDS) + r * GS_BLOCK + threadIdx.x;
+            if (row < n_points && visible_mask[row] == 0) {
+#pragma unroll
+                for (int c = 0; c < 14; ++c) gf4[(size_t)row * 14 + c] = z;
+                grad_xyz[3 * (size_t)row] = 0.f; grad_xyz[3 * (size_t)row + 1] = 0.f; grad_xyz[3 * (size_t)row + 2] = 0.f;
+            }
+        }
+        return;
+    }
+    const int i = ((int)blockIdx.x - n_zero_blocks) * GS_BLOCK + threadIdx.x;
     const int id = i < m ? ids[i] : -1;
     float4 *wave_rows = s_rows + (threadIdx.x >> 6) * (GS_WAVE * GS_ROW_F4);
     float4 *my_row = wave_rows + gs_lane() * GS_ROW_F4;   // this lane's gradient row, assembled in LDS
@@ -228,19 +247,6 @@ __global__ __launch_bounds__(GS_BLOCK) void point_backward_kernel(
     }
 }
 
-// Zero rows of the dense gradients for points that are NOT visible (RAS:1051-1053 zero-initialises
-// everything; the visible rows are fully written by point_backward_kernel, so only the others need zeros).
-__global__ __launch_bounds__(GS_BLOCK) void zero_invisible_rows_kernel(const int8_t *__restrict__ mask, int n,
-                                                                      float4 *__restrict__ grad_feat4,
-                                                                      float *__restrict__ grad_xyz) {
-    const int row = blockIdx.x * GS_BLOCK + threadIdx.x;
-    if (row >= n || mask[row] != 0) return;
-    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-    for (int c = 0; c < 14; ++c) grad_feat4[(size_t)row * 14 + c] = z;
-    grad_xyz[3 * (size_t)row] = 0.f; grad_xyz[3 * (size_t)row + 1] = 0.f; grad_xyz[3 * (size_t)row + 2] = 0.f;
-}
-
 }  // namespace
 
 extern "C" int gs_point_backward(const float *xyz, const float *features, const int32_t *object_id,
@@ -261,11 +267,10 @@ extern "C" int gs_point_backward(const float *xyz, const float *features, const 
                "gs_point_backward: either acc or the slot records of gs_blend_backward (+ image size)");
     GS_REQUIRE(n_visible == 0 || attrs != nullptr, "gs_point_backward: attrs (the packed records of the forward pass) is required");
     hipStream_t s = (hipStream_t)stream;
-    if (n_points > 0 && visible_mask != nullptr && n_visible > 0) {
-        hipLaunchKernelGGL(zero_invisible_rows_kernel, dim3(gs_div_up(n_points, GS_BLOCK)), dim3(GS_BLOCK), 0, s,
-                           visible_mask, n_points, reinterpret_cast<float4 *>(grad_features), grad_xyz);
-        GS_CHECK_LAUNCH();
-    } else if (n_points > 0) {
+    // rows of points outside the frustum: zeroed by the leading workgroups of the per-point kernel when the mask is known,
+    // else both arrays are cleared first
+    const bool zero_in_kernel = n_points > 0 && visible_mask != nullptr && n_visible > 0;
+    if (!zero_in_kernel && n_points > 0) {
         GS_CHECK_HIP(hipMemsetAsync(grad_xyz, 0, sizeof(float) * 3 * (size_t)n_points, s));
         GS_CHECK_HIP(hipMemsetAsync(grad_features, 0, sizeof(float) * GS_FEATURE_DIM * (size_t)n_points, s));
     }
@@ -274,13 +279,16 @@ extern "C" int gs_point_backward(const float *xyz, const float *features, const 
     fac.q = grad_q_factor; fac.s = grad_s_factor; fac.alpha = grad_alpha_factor;
     fac.color = grad_color_factor; fac.color_hi = grad_high_order_color_factor;
     fac.keep = color_max_sh_band <= 0 ? 1 : color_max_sh_band == 1 ? 4 : color_max_sh_band == 2 ? 9 : 16;
-    hipLaunchKernelGGL(point_backward_kernel, dim3(gs_div_up(n_visible, GS_BLOCK)), dim3(GS_BLOCK),
+    const int nblk = gs_div_up(n_visible, GS_BLOCK);
+    const int nzero = zero_in_kernel ? gs_div_up(n_points, GS_BLOCK * ZERO_ROUNDS) : 0;
+    hipLaunchKernelGGL(point_backward_kernel, dim3(nblk + nzero), dim3(GS_BLOCK),
                        sizeof(float4) * GS_BLOCK * GS_ROW_F4, s, xyz,
                        features, object_id, intrinsics, q_cp, t_cp, t_pc, ids, n_visible,
                        reinterpret_cast<const float4 *>(acc), reinterpret_cast<const float4 *>(attrs), num_owned_tiles,
                        fac, grad_xyz, grad_features, grad_xyz_visible, grad_features_visible, hook_compact,
                        SlotSource{slot_offsets, num_overlap_tiles, slot_flags, reinterpret_cast<const float4 *>(partials),
-                                  width / GS_TILE_WIDTH, height / GS_TILE_HEIGHT});
+                                  width / GS_TILE_WIDTH, height / GS_TILE_HEIGHT},
+                       visible_mask, n_points, nzero);
     GS_CHECK_LAUNCH();
     return 0;
 }
