@@ -192,6 +192,13 @@ int gs_read_counters_async(const int32_t *counters, int32_t *host_counters_pinne
  * for it -- pass it on to gs_blend_backward.  Results never depend on the order. */
 #define GS_BLEND_RGB_ONLY 1
 #define GS_BLEND_NO_STATE 2
+#define GS_BLEND_TWO_WAVES 4    /* both blend passes: always the two-waves-per-tile kernels (two pixels per lane) */
+#define GS_BLEND_ONE_WAVE 16    /* gs_blend_backward only, per-tile lists: the measurement arm with one wave per tile and four
+                                   pixels per lane (slower; profiles/r03_pmc_blend.md) */
+#define GS_BLEND_FOUR_WAVES 8   /* both blend passes: the four-waves-per-tile kernels (one pixel per lane) whenever the lists
+                                   are per-tile lists taken as they are (bin_shift 0, filter 0).  Default (neither flag):
+                                   four waves when at most 1024 tiles are rendered -- a grid that cannot fill the chip with two.
+                                   Image, depth, counts, state and hit sets are bit-identical between the two forms. */
 int gs_blend_forward(const int32_t *bin_start, const int32_t *bin_end, const int32_t *payload,
                      const float *attrs, int width, int height, int tile_row_begin,
                      int tile_row_step, int tile_row_end, int bin_shift, int filter, float *image,
@@ -207,7 +214,8 @@ int gs_blend_forward(const int32_t *bin_start, const int32_t *bin_end, const int
  * The walk starts at the tile-wide maximum of last_effective and runs down to bin_start; bin_shift and filter
  * must be the forward's.  alpha is evaluated by the same device function as in gs_blend_forward and the staging
  * filter is the same function on the same records, so both passes treat exactly the same (pixel, Gaussian)
- * pairs as blended.  debug_pixel_hits: see gs_blend_forward.
+ * pairs as blended.  debug_pixel_hits: see gs_blend_forward.  flags: GS_BLEND_TWO_WAVES / GS_BLEND_FOUR_WAVES or 0
+ * (see above; the slot sums of the two forms add the same per-pixel terms in a different order).
  * tile_work / tile_order (may be NULL): dispatch order, see gs_blend_forward.  tile_work (the forward's record) given:
  * tile_order is scratch of the same size and is filled with the tiles sorted by walk length, longest first.  Only
  * tile_order given: it is taken as the caller's permutation of 0 .. n-1 (n-th owned tile in row-major order). */
@@ -216,7 +224,7 @@ int gs_blend_backward(const int32_t *bin_start, const int32_t *payload, const fl
                       const int32_t *slot_offsets, int64_t n_slots, int width, int height,
                       int tile_row_begin, int tile_row_step, int tile_row_end, int bin_shift,
                       int filter, float *partials, uint8_t *slot_flags, float *magnitude_image,
-                      uint32_t *debug_pixel_hits, const int32_t *tile_work, int32_t *tile_order,
+                      uint32_t *debug_pixel_hits, int flags, const int32_t *tile_work, int32_t *tile_order,
                       void *stream);
 
 /* Per-Gaussian sum of its flagged slots, in slot order (bitwise reproducible), into acc float[M][12].

@@ -177,6 +177,7 @@ class GaussianPointCloudRasterisation(torch.nn.Module):
         # contents).  True = always write: what a training iteration pays -- the optimiser has just moved q -- for
         # benchmarks that time a static scene (bench.py)
         self.always_store_normalised_rotation = False
+        self._scratch = hip_ops.Workspaces()   # buffers that do not outlive a call, kept between frames
         self._size_guesses, self._readbacks = {}, {}   # (image size, list layout, planes) -> (key capacity, depth bound)
         self.speculation_stats = {"frames": 0, "redone": 0}
         outer = self
@@ -219,12 +220,12 @@ class GaussianPointCloudRasterisation(torch.nn.Module):
                 # RAS:848-870  frustum filter + ordered compaction; M stays on the device
                 visible_mask, ids, counters = hip_ops.filter_compact(
                     xyz, invalid, obj, intrinsics, q_cp, t_cp, cfg.near_plane, cfg.far_plane, width, height,
-                    sync=False)
+                    sync=False, ws=outer._scratch)
                 # RAS:887-911  per-point projection + tile counts (launched for the capacity N)
                 attrs, num_overlap_tiles, num_owned_tiles, block_sums, block_sums_full = hip_ops.preprocess(
                     xyz, pointcloud_features, obj, intrinsics, q_cp, t_cp, ids, width, height, layout,
                     cfg.depth_to_sort_key_scale, counters, n_visible_on_device=True,
-                    always_store_rotation=outer.always_store_normalised_rotation)
+                    always_store_rotation=outer.always_store_normalised_rotation, ws=outer._scratch)
                 # RAS:913-922  scans.  The reference blocks twice on sizes (RAS:870,916); here the one read-back of
                 # M, K, the slot count and the depth range travels to pinned memory while the host keeps launching:
                 # key generation, sort, ranges and the blend run SPECULATIVELY from the device-side counts with the
@@ -254,9 +255,10 @@ class GaussianPointCloudRasterisation(torch.nn.Module):
                     n_dev = None if counters_ is None else counters_[hip_ops.COUNTER_NUM_KEYS:hip_ops.COUNTER_NUM_KEYS + 1]
                     keys, payload_, slot_offsets_ = hip_ops.make_keys(
                         attrs_, nkeys_, bsums_, n_keys_, width, height, cfg.depth_to_sort_key_scale, layout, kdb,
-                        ntiles_ if need_state else None, bsums_full_ if need_state else None, counters=counters_)
+                        ntiles_ if need_state else None, bsums_full_ if need_state else None, counters=counters_,
+                        ws=outer._scratch)
                     keys, payload_ = hip_ops.sort_pairs(keys, payload_, depth_bits, tile_bits, kdb, in_place=False,
-                                                        n_keys_device=n_dev)
+                                                        n_keys_device=n_dev, ws=outer._scratch)
                     start_, end_ = hip_ops.tile_ranges(keys, num_bins, kdb, n_keys_device=n_dev)
                     del keys
                     work_ = None
@@ -266,7 +268,7 @@ class GaussianPointCloudRasterisation(torch.nn.Module):
                     blended = hip_ops.blend_forward(start_, end_, payload_, attrs_, width, height, layout,
                                                     rgb_only=rgb_only, need_state=need_state,
                                                     gathered_rows=gathered_rows, ordered=outer.ordered_dispatch,
-                                                    tile_work=work_)
+                                                    tile_work=work_, ws=outer._scratch)
                     return payload_, slot_offsets_, start_, blended, work_
 
                 guess_key = (width, height, layout, cfg.near_plane, cfg.far_plane, cfg.depth_to_sort_key_scale)
@@ -371,14 +373,15 @@ class GaussianPointCloudRasterisation(torch.nn.Module):
                     # RAS:531-705  per-pixel pass: one 48-B record per (Gaussian, tile) slot, no atomics
                     partials, slot_flags, magnitude_image = hip_ops.blend_backward_partials(
                         tile_start, payload, attrs, grad_rasterized_image, acc_alpha, last_eff, slot_offsets,
-                        ctx.n_slots, width, height, ctx.layout, tile_work=ctx.tile_work)
+                        ctx.n_slots, width, height, ctx.layout, tile_work=ctx.tile_work, ws=outer._scratch)
                     acc = slots = None
                     if outer.grad_accumulator_reduce is None and outer.fused_slot_reduction:
                         # the slot sums are formed inside the per-point kernel and stay in registers
                         slots = (slot_offsets, num_overlap_tiles, slot_flags, partials)
                     else:   # the per-Gaussian sums go through memory (multi-GPU: they are summed over the ranks)
                         acc = hip_ops.reduce_partials(slot_offsets, num_overlap_tiles, slot_flags, partials,
-                                                      num_owned_tiles if ctx.layout.sharded else None, attrs, width, height)
+                                                      num_owned_tiles if ctx.layout.sharded else None, attrs, width, height,
+                                                      ws=outer._scratch)
                         if outer.grad_accumulator_reduce is not None:
                             acc = outer.grad_accumulator_reduce(acc, num_owned_tiles)
                     # RAS:707-772 + 1102-1125  per-point pass, band clearing and factors fused

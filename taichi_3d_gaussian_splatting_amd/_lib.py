@@ -42,7 +42,7 @@ _SIGNATURES = {
     "gs_tile_ranges": (_I, [_P, _I64, _P, _I, _P, _P, _I, _P]),
     "gs_read_counters_async": (_I, [_P, _P, _I, _P]),
     "gs_blend_forward": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P]),
-    "gs_blend_backward": (_I, [_P, _P, _P, _P, _P, _P, _P, _I64, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P]),
+    "gs_blend_backward": (_I, [_P, _P, _P, _P, _P, _P, _P, _I64, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P, _P]),
     "gs_reduce_partials": (_I, [_P, _P, _P, _P, _I, _P, _P, _I64, _P, _I, _I, _P]),
     "gs_compact_rows_workspace_bytes": (_c.c_size_t, [_I]),
     "gs_compact_rows": (_I, [_P, _P, _I, _I, _P, _P, _P, _P, _P]),

@@ -215,10 +215,14 @@ __device__ __forceinline__ void gs_direct_step(const int32_t *__restrict__ paylo
 // results do not depend on when it runs).  work[e] given: the estimate of tile e (the forward kernel records the walk
 // length the backward will see); work == nullptr: the length of the tile's (bin's) sorted list.
 constexpr int ORDER_THREADS = 1024, ORDER_CLASSES = 1024, ORDER_ITEMS = 8;   // (one class per thread)
+constexpr int ORDER_WAVES = ORDER_THREADS / GS_WAVE;
 __global__ __launch_bounds__(ORDER_THREADS) void tile_order_kernel(
     const int32_t *__restrict__ work, const int32_t *__restrict__ bin_start, const int32_t *__restrict__ bin_end, int n,
     int tw, int row_begin, int row_step, int bin_shift, int32_t *__restrict__ order) {
-    __shared__ int s_hist[ORDER_CLASSES], s_cur[ORDER_CLASSES], s_red[ORDER_THREADS / GS_WAVE];
+    // one histogram PER WAVE (64 KB of LDS): the tiles of a frame crowd into few classes, and a shared histogram turned
+    // every LDS atomic into a 20-way same-address conflict (13 us per call; 10 us of it the atomics)
+    __shared__ int s_hist[ORDER_WAVES][ORDER_CLASSES];
+    __shared__ int s_red[ORDER_WAVES];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int bins_u = (tw + (1 << bin_shift) - 1) >> bin_shift;
     auto work_of = [&](int e) {
@@ -227,8 +231,8 @@ __global__ __launch_bounds__(ORDER_THREADS) void tile_order_kernel(
         const int bin = (tu >> bin_shift) + (tv >> bin_shift) * bins_u;
         return max(bin_end[bin] - bin_start[bin], 0);
     };
-    // up to ORDER_ITEMS x 1024 tiles (8192: a 1920 x 1088 frame) live in registers: one read of the estimates; larger frames
-    // re-read them in the later passes
+    // wave w owns the tiles e = (k * 16 + w) * 64 + lane, k = 0, 1, ...: up to ORDER_ITEMS x 1024 tiles (8192: a 1920 x 1088
+    // frame) live in registers -- one read of the estimates; larger frames re-read them in the later passes
     int w[ORDER_ITEMS];
     int mx = 1;
 #pragma unroll
@@ -241,40 +245,43 @@ __global__ __launch_bounds__(ORDER_THREADS) void tile_order_kernel(
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) mx = max(mx, __shfl_xor(mx, d, GS_WAVE));
     if (lane == 0) s_red[wv] = mx;
-    s_hist[tid] = 0;
-    s_cur[tid] = 0;
+#pragma unroll
+    for (int k = 0; k < ORDER_WAVES; ++k) s_hist[k][tid] = 0;
     __syncthreads();
 #pragma unroll
-    for (int k = 0; k < ORDER_THREADS / GS_WAVE; ++k) mx = max(mx, s_red[k]);
+    for (int k = 0; k < ORDER_WAVES; ++k) mx = max(mx, s_red[k]);
     // class 0 = heaviest: the counting sort below is then ascending in the class
     const float scale = (float)(ORDER_CLASSES - 1) / (float)mx;
     auto class_of = [&](int x) { return ORDER_CLASSES - 1 - min((int)((float)x * scale), ORDER_CLASSES - 1); };
 #pragma unroll
     for (int k = 0; k < ORDER_ITEMS; ++k)
-        if (w[k] >= 0) atomicAdd(&s_hist[class_of(w[k])], 1);
-    for (int e = ORDER_ITEMS * ORDER_THREADS + tid; e < n; e += ORDER_THREADS) atomicAdd(&s_hist[class_of(work_of(e))], 1);
+        if (w[k] >= 0) atomicAdd(&s_hist[wv][class_of(w[k])], 1);
+    for (int e = ORDER_ITEMS * ORDER_THREADS + tid; e < n; e += ORDER_THREADS) atomicAdd(&s_hist[wv][class_of(work_of(e))], 1);
     __syncthreads();
-    // exclusive scan of the 1024 class counts, one class per thread
-    const int cnt = s_hist[tid];
+    // class `tid`: exclusive prefix of its counts over the waves (in place), total -> scanned over the classes
+    int cnt = 0;
+#pragma unroll
+    for (int k = 0; k < ORDER_WAVES; ++k) {
+        const int c = s_hist[k][tid];
+        s_hist[k][tid] = cnt;
+        cnt += c;
+    }
     const int incl = gs_wave_incl_scan(cnt);
     __syncthreads();                       // (s_red is reused)
     if (lane == GS_WAVE - 1) s_red[wv] = incl;
     __syncthreads();
     int before = 0;
 #pragma unroll
-    for (int k = 0; k < ORDER_THREADS / GS_WAVE; ++k) before += k < wv ? s_red[k] : 0;
-    s_hist[tid] = before + incl - cnt;     // first position of class `tid`
+    for (int k = 0; k < ORDER_WAVES; ++k) before += k < wv ? s_red[k] : 0;
+    const int first = before + incl - cnt;   // first position of class `tid`
+#pragma unroll
+    for (int k = 0; k < ORDER_WAVES; ++k) s_hist[k][tid] += first;   // -> running cursor of (wave k, class tid)
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < ORDER_ITEMS; ++k)
-        if (w[k] >= 0) {
-            const int c = class_of(w[k]);
-            order[s_hist[c] + atomicAdd(&s_cur[c], 1)] = k * ORDER_THREADS + tid;
-        }
-    for (int e = ORDER_ITEMS * ORDER_THREADS + tid; e < n; e += ORDER_THREADS) {
-        const int c = class_of(work_of(e));
-        order[s_hist[c] + atomicAdd(&s_cur[c], 1)] = e;
-    }
+        if (w[k] >= 0) order[atomicAdd(&s_hist[wv][class_of(w[k])], 1)] = k * ORDER_THREADS + tid;
+    for (int e = ORDER_ITEMS * ORDER_THREADS + tid; e < n; e += ORDER_THREADS)
+        order[atomicAdd(&s_hist[wv][class_of(work_of(e))], 1)] = e;
 }
 
 // ------------------------------------------------------------------------------- forward
@@ -723,6 +730,405 @@ __global__ __launch_bounds__(BLEND_THREADS, GS_BWD_MIN_WAVES) void blend_backwar
     }
 }
 
+// ------------------------------------------------------------------------------- small grids: four waves per tile
+// A frame of a few hundred tiles (the 4x / 2x down-sampled first iterations of every training run, TRN:133-148; a 256 x 256
+// view; one rank's band of a sharded frame) cannot fill 256 CUs with two waves per tile: every tile walks its list alone on
+// two of its CU's four SIMDs and the launch lasts as long as the longest list (10k Gaussians at 256 x 256: 256 tiles, 96 +
+// 146 us in the two kernels above).  These arms give a tile FOUR waves -- one pixel per lane, so a list entry costs a wave
+// about half the issue slots of the two-pixel form -- for per-tile lists taken as they are (bin_shift 0, no filter: what
+// small frames use).  Per pixel they execute the same IEEE operations in the same order as the two-pixel kernels (packed
+// instructions are per-component), so image, depth, counts, state and hit decisions are bit-identical; the backward's slot
+// sums add the same per-pixel terms in another order (four waves of 64 pixels instead of two of 128).
+constexpr int SMALL_THREADS = 256;
+constexpr int GS_SMALL_GRID_TILES = 1024;   // at most this many owned tiles: four waves per tile (4 x the 256 CUs)
+
+__device__ __forceinline__ float gs_pixel_alpha(const float4 p, const float4 q, float px, float py, float &dx, float &dy) {
+    // gs_pair_alpha for one pixel: the same operations (the packed form computes each component exactly like this)
+    dx = px - p.x;
+    dy = py - p.y;
+    const float e = __builtin_fmaf(dx, __builtin_fmaf(dx, q.x, q.y * dy), q.z * dy * dy);
+    return __builtin_amdgcn_exp2f(e) * q.w;
+}
+
+template <bool AUX, bool STATE, bool DEBUG>
+__global__ __launch_bounds__(SMALL_THREADS) void blend_forward_small_kernel(
+    const int32_t *__restrict__ tile_start, const int32_t *__restrict__ tile_end,
+    const int32_t *__restrict__ payload, const float4 *__restrict__ attrs, int width, int height, int row_begin,
+    int row_step, float *__restrict__ image, float *__restrict__ depth, float *__restrict__ acc_alpha,
+    int32_t *__restrict__ last_effective, int32_t *__restrict__ valid_count, uint32_t *__restrict__ debug_hits,
+    const int32_t *__restrict__ tile_order, int32_t *__restrict__ tile_work) {
+    __shared__ float4 s_p[BATCH], s_c[BATCH], s_q[BATCH];
+    __shared__ int s_o[DEBUG ? BATCH : 1];
+    __shared__ int s_red[SMALL_THREADS / GS_WAVE];
+    const int tw = width / GS_TILE_WIDTH;
+    const TileCoord tc = owned_tile(tw, row_begin, row_step, tile_order);
+    const int tid = threadIdx.x;
+    const int pu = tc.tile_u * GS_TILE_WIDTH + (tid & 15), pv = tc.tile_v * GS_TILE_HEIGHT + (tid >> 4);
+    const int start = tile_start[tc.tile_id], end = tile_end[tc.tile_id];
+    const float px = (float)pu + 0.5f, py = (float)pv + 0.5f;
+    float T = 1.0f, alive = 1.0f, Cr = 0.f, Cg = 0.f, Cb = 0.f, D = 0.f, Wd = 0.f;
+    int last = start, cnt = 0;
+    unsigned dh = 0u, dc = 0u;
+    int pos = start;
+    while (pos < end) {
+        if (__syncthreads_and(alive == 0.f ? 1 : 0)) break;   // barrier (protects the staged batch) + whole-tile early exit
+        const int batch_first = pos;
+        {
+            const int j = pos + tid;
+            if (tid < BATCH && j < end) {
+                const int o = payload[j];
+                const float4 *g = attrs + 4 * (size_t)o;
+                s_p[tid] = g[0]; s_c[tid] = g[2]; s_q[tid] = g[3];
+                if (DEBUG) s_o[tid] = o;
+            }
+        }
+        const int nbuf = min(BATCH, end - pos);
+        pos += BATCH;
+        {
+            const int padded = (nbuf + GROUP - 1) & ~(GROUP - 1);
+            if (tid < padded - nbuf) {
+                s_p[nbuf + tid] = make_float4(0.f, 0.f, 0.f, 0.f);
+                s_q[nbuf + tid] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+        __syncthreads();
+        for (int k = 0; k < nbuf; k += GROUP_FWD) {
+            if (gs_ballot(alive != 0.f) == 0ull) break;   // every pixel of this wave is saturated
+            float alpha[GROUP_FWD], z[GROUP_FWD];
+#pragma unroll
+            for (int i = 0; i < GROUP_FWD; ++i) {
+                float dx, dy;
+                const float4 p = s_p[k + i];
+                alpha[i] = gs_pixel_alpha(p, s_q[k + i], px, py, dx, dy);
+                z[i] = p.z;
+            }
+#pragma unroll
+            for (int i = 0; i < GROUP_FWD; ++i) {
+                const float a = alpha[i] * alive;
+                bool ok = a >= EPS_ALPHA;                               // RAS:451
+                if (gs_ballot(ok) == 0ull) continue;
+                float al = ok ? __builtin_amdgcn_fmed3f(a, 0.f, CLAMP_ALPHA) : 0.f;
+                float Tn = T * (1.f - al);
+                const bool sat = ok && Tn < STOP_T;
+                if (gs_ballot(sat) != 0ull) {                           // RAS:458-460: saturates the pixel, NOT blended
+                    if (sat) { al = 0.f; alive = 0.f; ok = false; }
+                    Tn = T * (1.f - al);
+                }
+                const float wgt = al * T;
+                const float4 c = s_c[k + i];
+                Cr = __builtin_fmaf(c.x, wgt, Cr);
+                Cg = __builtin_fmaf(c.y, wgt, Cg);
+                Cb = __builtin_fmaf(c.z, wgt, Cb);
+                if (AUX) {
+                    D = __builtin_fmaf(z[i], wgt, D);
+                    Wd = Wd + wgt;
+                    cnt += ok ? 1 : 0;
+                }
+                T = Tn;
+                if (STATE) last = ok ? batch_first + k + i + 1 : last;
+                if (DEBUG) {
+                    const unsigned hv = (unsigned)(s_o[k + i] + 1) * GS_HASH_MUL;
+                    dc += ok ? 1u : 0u; dh += ok ? hv : 0u;
+                }
+            }
+        }
+    }
+    const size_t p = (size_t)pv * width + pu;
+    image[3 * p] = Cr; image[3 * p + 1] = Cg; image[3 * p + 2] = Cb;
+    if (AUX) {
+        depth[p] = D / fmaxf(Wd, 1e-6f);  // RAS:479-480
+        valid_count[p] = cnt;
+    }
+    if (STATE) {
+        acc_alpha[p] = 1.f - T;
+        last_effective[p] = last;
+        if (tile_work != nullptr) {
+            int mx = last;
+#pragma unroll
+            for (int d = 32; d > 0; d >>= 1) mx = max(mx, __shfl_xor(mx, d, GS_WAVE));
+            if ((tid & 63) == 0) s_red[tid >> 6] = mx;
+            __syncthreads();
+            if (tid == 0) tile_work[tc.index] = max(max(s_red[0], s_red[1]), max(s_red[2], s_red[3])) - start;
+        }
+    }
+    if (DEBUG) { debug_hits[2 * p] = dc; debug_hits[2 * p + 1] = dh; }
+}
+
+template <bool DEBUG>
+__global__ __launch_bounds__(SMALL_THREADS) void blend_backward_small_kernel(
+    const int32_t *__restrict__ tile_start, const int32_t *__restrict__ payload, const float4 *__restrict__ attrs,
+    const float *__restrict__ grad_image, const float *__restrict__ acc_alpha, const int32_t *__restrict__ last_effective,
+    int width, int height, int row_begin, int row_step, const int32_t *__restrict__ slot_offsets,
+    float4 *__restrict__ partials, uint8_t *__restrict__ slot_flags, float *__restrict__ magnitude_image,
+    uint32_t *__restrict__ debug_hits, const int32_t *__restrict__ tile_order) {
+    __shared__ float4 s_p[BATCH], s_b[BATCH], s_c[BATCH], s_q[BATCH];
+    __shared__ int s_o[BATCH];
+    __shared__ float s_acc[BATCH][GS_ACC_STRIDE];
+    __shared__ int s_max[SMALL_THREADS / GS_WAVE];
+    const int tw = width / GS_TILE_WIDTH, th = height / GS_TILE_HEIGHT;
+    const TileCoord tc = owned_tile(tw, row_begin, row_step, tile_order);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int pu = tc.tile_u * GS_TILE_WIDTH + (tid & 15), pv = tc.tile_v * GS_TILE_HEIGHT + (tid >> 4);
+    const size_t p = (size_t)pv * width + pu;
+    const int start = tile_start[tc.tile_id];
+    const float px = (float)pu + 0.5f, py = (float)pv + 0.5f;
+    const int last = last_effective[p];
+    float T = 1.0f - acc_alpha[p], S = 0.f;
+    const float Gr = grad_image[3 * p], Gg = grad_image[3 * p + 1], Gb = grad_image[3 * p + 2];
+    float mag_u = 0.f, mag_v = 0.f;
+    unsigned dh = 0u, dc = 0u;
+    int mx = last;
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) mx = max(mx, __shfl_xor(mx, d, GS_WAVE));
+    const int wave_end = mx;
+    if (lane == 0) s_max[tid >> 6] = mx;
+    __syncthreads();
+    const int end = max(max(s_max[0], s_max[1]), max(s_max[2], s_max[3]));
+    const int row = lane >> 4;
+    const int slot = ((row & 1) << 1) | (row >> 1);
+    const bool row_tail = (lane & 15) == 15;
+    int pos = end - 1;
+    while (pos >= start) {
+        __syncthreads();   // previous round fully flushed before its LDS is reused
+        const int batch_first = pos;
+        {
+            const int j = pos - tid;
+            if (tid < BATCH && j >= start) {
+                const int o = payload[j];
+                const float4 *g = attrs + 4 * (size_t)o;
+                s_p[tid] = g[0]; s_b[tid] = g[1]; s_c[tid] = g[2]; s_q[tid] = g[3];
+                s_o[tid] = o;
+            }
+        }
+        const int nbuf = min(BATCH, pos - start + 1);
+        pos -= BATCH;
+        {
+            const int padded = (nbuf + GROUP - 1) & ~(GROUP - 1);
+            if (tid < padded - nbuf) {
+                s_p[nbuf + tid] = make_float4(0.f, 0.f, 0.f, 0.f);
+                s_q[nbuf + tid] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            if (tid < BATCH) {
+                float4 *z = reinterpret_cast<float4 *>(&s_acc[tid][0]);
+                z[0] = make_float4(0.f, 0.f, 0.f, 0.f);
+                z[1] = make_float4(0.f, 0.f, 0.f, 0.f);
+                z[2] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+        __syncthreads();
+        for (int k = 0; k < nbuf; k += GROUP_BWD) {
+            if (batch_first - (k + GROUP_BWD - 1) >= wave_end) continue;   // the whole group lies behind this wave's pixels
+            float alpha[GROUP_BWD], dx[GROUP_BWD], dy[GROUP_BWD];
+#pragma unroll
+            for (int i = 0; i < GROUP_BWD; ++i) alpha[i] = gs_pixel_alpha(s_p[k + i], s_q[k + i], px, py, dx[i], dy[i]);
+#pragma unroll
+            for (int i = 0; i < GROUP_BWD; ++i) {
+                const bool a0 = alpha[i] >= EPS_ALPHA;                   // RAS:631, as RAS:451
+                const unsigned long long ma = gs_ballot(a0);
+                if (ma == 0ull) continue;
+                const int jj = batch_first - (k + i);
+                const bool l0 = jj < last;                               // RAS:618 (effective range)
+                const bool hit = a0 && l0;
+                if ((ma & gs_ballot(l0)) == 0ull) continue;
+                const float h = hit ? 1.f : 0.f;
+                const float al = hit ? __builtin_amdgcn_fmed3f(alpha[i], 0.f, CLAMP_ALPHA) : 0.f;
+                const float inv1m = __builtin_amdgcn_rcpf(1.f - al);
+                T = T * inv1m;                                           // RAS:643
+                const float aT = al * T;
+                const float4 c = s_c[k + i], b = s_b[k + i];
+                const float gr = aT * Gr, gg = aT * Gg, gb = aT * Gb;
+                const float cg = __builtin_fmaf(c.z, Gb, __builtin_fmaf(c.y, Gg, c.x * Gr));
+                const float dLda = __builtin_fmaf(T, cg, -(S * inv1m)) * h;   // RAS:652-657
+                S = __builtin_fmaf(cg, aT, S);
+                const float w = dLda * alpha[i];
+                const float m0 = __builtin_fmaf(dx[i], b.x, b.y * dy[i]);    // UTL:331-348: m = conic @ d
+                const float m1 = __builtin_fmaf(dx[i], b.y, b.z * dy[i]);
+                const float v0 = w * m0, v1 = w * m1;
+                mag_u += fabsf(v0);
+                mag_v += fabsf(v1);
+                const float c00 = v0 * m0, c01 = v0 * m1, c11 = v1 * m1;
+                const float nv = __builtin_amdgcn_sqrtf(__builtin_fmaf(v1, v1, v0 * v0));
+                if (DEBUG) {
+                    const unsigned hv = (unsigned)(s_o[k + i] + 1) * GS_HASH_MUL;
+                    dc += hit ? 1u : 0u; dh += hit ? hv : 0u;
+                }
+                float t0, t1, t2;
+                gs_wave_reduce12(v0, v1, c00, c01, c11, gr, gg, gb, w, nv, h, 0.f, t0, t1, t2);
+                if (row_tail) {
+                    float *A = &s_acc[k + i][slot];
+                    atomicAdd(A, t0);
+                    atomicAdd(A + 4, t1);
+                    atomicAdd(A + 8, t2);
+                }
+            }
+        }
+        __syncthreads();
+        if (tid < nbuf) {   // flush: thread k owns staged entry k -> one 48-B store into the (Gaussian, tile) slot
+            const float4 *Sa = reinterpret_cast<const float4 *>(&s_acc[tid][0]);
+            float4 r0 = Sa[0], r1 = Sa[1], r2 = Sa[2];
+            if (r2.z > 0.f) {
+                const float4 a = s_p[tid];
+                int t0u, t1u, t0v, t1v;
+                gs_tile_box(a.x, a.y, s_b[tid].w, tw, th, t0u, t1u, t0v, t1v);
+                const int dst_slot = slot_offsets[s_o[tid]] + (t1v - t0v) * (tc.tile_u - t0u) + (tc.tile_v - t0v);
+                float4 *dst = partials + 3 * (size_t)dst_slot;
+                r0.z *= 0.5f; r0.w *= 0.5f; r1.x *= 0.5f;
+                r2.x *= (1.f - s_c[tid].w);
+                r2.z = __builtin_bit_cast(float, (int)r2.z);
+                dst[0] = r0;
+                dst[1] = r1;
+                dst[2] = r2;
+                slot_flags[dst_slot] = 1;
+            }
+        }
+    }
+    magnitude_image[2 * p] = mag_u;
+    magnitude_image[2 * p + 1] = mag_v;
+    if (DEBUG) { debug_hits[2 * p] = dc; debug_hits[2 * p + 1] = dh; }
+}
+
+// ------------------------------------------------------------------------------- measurement arm: one wave per tile
+// FOUR pixels per lane, one wave per tile -- one 34-instruction reduce-scatter per (tile, entry)
+// instead of two plus the LDS combine, at the price of 33 in-lane additions instead of 11 and of the half-tile skip (a
+// wave now covers the whole tile, so "no pixel of this wave is hit" is rarer).  Per-tile lists taken as they are; selected
+// with GS_BLEND_ONE_WAVE.  Measured slower than the two-wave kernel (profiles/r03_pmc_blend.md), kept for the record.
+constexpr int WIDE_THREADS = 64;
+template <bool DEBUG>
+__global__ __launch_bounds__(WIDE_THREADS) void blend_backward_wide_kernel(
+    const int32_t *__restrict__ tile_start, const int32_t *__restrict__ payload, const float4 *__restrict__ attrs,
+    const float *__restrict__ grad_image, const float *__restrict__ acc_alpha, const int32_t *__restrict__ last_effective,
+    int width, int height, int row_begin, int row_step, const int32_t *__restrict__ slot_offsets,
+    float4 *__restrict__ partials, uint8_t *__restrict__ slot_flags, float *__restrict__ magnitude_image,
+    uint32_t *__restrict__ debug_hits, const int32_t *__restrict__ tile_order) {
+    __shared__ float4 s_p[BATCH], s_b[BATCH], s_c[BATCH], s_q[BATCH];
+    __shared__ int s_o[BATCH];
+    __shared__ float s_acc[BATCH][GS_ACC_STRIDE];
+    const int tw = width / GS_TILE_WIDTH, th = height / GS_TILE_HEIGHT;
+    const TileCoord tc = owned_tile(tw, row_begin, row_step, tile_order);
+    const int lane = threadIdx.x;
+    const int pu0 = tc.tile_u * GS_TILE_WIDTH + 4 * (lane & 3), pv = tc.tile_v * GS_TILE_HEIGHT + (lane >> 2);
+    const size_t p0 = (size_t)pv * width + pu0;
+    const int start = tile_start[tc.tile_id];
+    const float py = (float)pv + 0.5f;
+    float px[4], T[4], S[4], Gr[4], Gg[4], Gb[4], mag_u[4], mag_v[4];
+    int last[4];
+    unsigned dh[4], dc[4];
+    int mx = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        px[q] = (float)(pu0 + q) + 0.5f;
+        last[q] = last_effective[p0 + q];
+        T[q] = 1.0f - acc_alpha[p0 + q];
+        S[q] = 0.f;
+        Gr[q] = grad_image[3 * (p0 + q)]; Gg[q] = grad_image[3 * (p0 + q) + 1]; Gb[q] = grad_image[3 * (p0 + q) + 2];
+        mag_u[q] = 0.f; mag_v[q] = 0.f; dh[q] = 0u; dc[q] = 0u;
+        mx = max(mx, last[q]);
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) mx = max(mx, __shfl_xor(mx, d, GS_WAVE));
+    const int end = mx;
+    const int row = lane >> 4;
+    const int slot = ((row & 1) << 1) | (row >> 1);
+    const bool row_tail = (lane & 15) == 15;
+    int pos = end - 1;
+    while (pos >= start) {
+        __builtin_amdgcn_wave_barrier();
+        const int batch_first = pos;
+#pragma unroll
+        for (int h = 0; h < BATCH / WIDE_THREADS; ++h) {
+            const int e = h * WIDE_THREADS + lane, j = pos - e;
+            if (j >= start) {
+                const int o = payload[j];
+                const float4 *g = attrs + 4 * (size_t)o;
+                s_p[e] = g[0]; s_b[e] = g[1]; s_c[e] = g[2]; s_q[e] = g[3];
+                s_o[e] = o;
+            } else {   // inert padding: amplitude 0 -> alpha 0, never a hit
+                s_p[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+                s_q[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+        const int nbuf = min(BATCH, pos - start + 1);
+        pos -= BATCH;
+        __builtin_amdgcn_wave_barrier();
+        for (int k = 0; k < nbuf; ++k) {
+            const float4 P = s_p[k], Q = s_q[k];
+            float alpha[4], dx[4], dy;
+            bool hit[4];
+            const int jj = batch_first - k;
+            bool any = false;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                alpha[q] = gs_pixel_alpha(P, Q, px[q], py, dx[q], dy);
+                hit[q] = alpha[q] >= EPS_ALPHA && jj < last[q];
+                any = any || hit[q];
+            }
+            if (gs_ballot(any) == 0ull) continue;
+            const float4 c = s_c[k], b = s_b[k];
+            float x[11];
+#pragma unroll
+            for (int n = 0; n < 11; ++n) x[n] = 0.f;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float h = hit[q] ? 1.f : 0.f;
+                const float al = hit[q] ? __builtin_amdgcn_fmed3f(alpha[q], 0.f, CLAMP_ALPHA) : 0.f;
+                const float inv1m = __builtin_amdgcn_rcpf(1.f - al);
+                T[q] = T[q] * inv1m;
+                const float aT = al * T[q];
+                const float cg = __builtin_fmaf(c.z, Gb[q], __builtin_fmaf(c.y, Gg[q], c.x * Gr[q]));
+                const float dLda = __builtin_fmaf(T[q], cg, -(S[q] * inv1m)) * h;
+                S[q] = __builtin_fmaf(cg, aT, S[q]);
+                const float w = dLda * alpha[q];
+                const float m0 = __builtin_fmaf(dx[q], b.x, b.y * dy), m1 = __builtin_fmaf(dx[q], b.y, b.z * dy);
+                const float v0 = w * m0, v1 = w * m1;
+                mag_u[q] += fabsf(v0);
+                mag_v[q] += fabsf(v1);
+                x[0] += v0; x[1] += v1; x[2] += v0 * m0; x[3] += v0 * m1; x[4] += v1 * m1;
+                x[5] += aT * Gr[q]; x[6] += aT * Gg[q]; x[7] += aT * Gb[q]; x[8] += w;
+                x[9] += __builtin_amdgcn_sqrtf(__builtin_fmaf(v1, v1, v0 * v0)); x[10] += h;
+                if (DEBUG) {
+                    const unsigned hv = (unsigned)(s_o[k] + 1) * GS_HASH_MUL;
+                    dc[q] += hit[q] ? 1u : 0u; dh[q] += hit[q] ? hv : 0u;
+                }
+            }
+            float t0, t1, t2;
+            gs_wave_reduce12(x[0], x[1], x[2], x[3], x[4], x[5], x[6], x[7], x[8], x[9], x[10], 0.f, t0, t1, t2);
+            if (row_tail) {   // one wave per tile: plain stores, every entry of the round is written at most once
+                float *A = &s_acc[k][slot];
+                A[0] = t0; A[4] = t1; A[8] = t2;
+            }
+            if (lane == 0) s_o[k] |= 0x40000000;   // entry k was hit this round: its s_acc row is valid
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int h = 0; h < BATCH / WIDE_THREADS; ++h) {
+            const int e = h * WIDE_THREADS + lane;
+            if (e < nbuf && (s_o[e] & 0x40000000)) {
+                const int o = s_o[e] & 0x3fffffff;
+                const float4 *Sa = reinterpret_cast<const float4 *>(&s_acc[e][0]);
+                float4 r0 = Sa[0], r1 = Sa[1], r2 = Sa[2];
+                if (r2.z > 0.f) {
+                    const float4 a = s_p[e];
+                    int t0u, t1u, t0v, t1v;
+                    gs_tile_box(a.x, a.y, s_b[e].w, tw, th, t0u, t1u, t0v, t1v);
+                    const int dst_slot = slot_offsets[o] + (t1v - t0v) * (tc.tile_u - t0u) + (tc.tile_v - t0v);
+                    float4 *dst = partials + 3 * (size_t)dst_slot;
+                    r0.z *= 0.5f; r0.w *= 0.5f; r1.x *= 0.5f;
+                    r2.x *= (1.f - s_c[e].w);
+                    r2.z = __builtin_bit_cast(float, (int)r2.z);
+                    dst[0] = r0; dst[1] = r1; dst[2] = r2;
+                    slot_flags[dst_slot] = 1;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        magnitude_image[2 * (p0 + q)] = mag_u[q];
+        magnitude_image[2 * (p0 + q) + 1] = mag_v[q];
+        if (DEBUG) { debug_hits[2 * (p0 + q)] = dc[q]; debug_hits[2 * (p0 + q) + 1] = dh[q]; }
+    }
+}
+
 // Sums the flagged (Gaussian, tile) slots of every visible Gaussian into the accumulator record acc[i] (gs_slots.h: the
 // code is shared with the fused per-point backward, which keeps the sums in registers; this kernel serves the callers
 // that need acc in memory -- a multi-GPU run all-reduces it, tests compare it).
@@ -831,6 +1237,13 @@ int gs_blend_forward(const int32_t *bin_start, const int32_t *bin_end, const int
                            bin_end, tw * rows, tw, tile_row_begin, tile_row_step, bin_shift, tile_order);
         GS_CHECK_LAUNCH();
     }
+    const bool four_waves = !staged && !(flags & GS_BLEND_TWO_WAVES) &&
+                            ((flags & GS_BLEND_FOUR_WAVES) || tw * rows <= GS_SMALL_GRID_TILES);
+#define GS_FWD_SMALL(AUX, STATE, DBG)                                                                                \
+    hipLaunchKernelGGL((blend_forward_small_kernel<AUX, STATE, DBG>), grid, dim3(SMALL_THREADS), 0, s, bin_start,     \
+                       bin_end, payload, a4, width, height, tile_row_begin, tile_row_step, image, depth, acc_alpha,   \
+                       last_effective, valid_count, debug_pixel_hits, tile_order, tile_work)
+#define GS_FWD_SMALL2(AUX, STATE) do { if (dbg) GS_FWD_SMALL(AUX, STATE, true); else GS_FWD_SMALL(AUX, STATE, false); } while (0)
 #define GS_FWD(STAGED, AUX, STATE)                                                                                  \
     launch_forward<STAGED, AUX, STATE>(dbg, grid, s, bin_start, bin_end, payload, a4, width, height, tile_row_begin, \
                                        tile_row_step, bin_shift, filter, image, depth, acc_alpha, last_effective,   \
@@ -842,7 +1255,14 @@ int gs_blend_forward(const int32_t *bin_start, const int32_t *bin_end, const int
         else if (state) GS_FWD(STAGED, false, true);                                                                \
         else GS_FWD(STAGED, false, false);                                                                          \
     } while (0)
-    if (staged) GS_FWD2(true); else GS_FWD2(false);
+    if (four_waves) {
+        if (aux && state) GS_FWD_SMALL2(true, true);
+        else if (aux) GS_FWD_SMALL2(true, false);
+        else if (state) GS_FWD_SMALL2(false, true);
+        else GS_FWD_SMALL2(false, false);
+    } else if (staged) GS_FWD2(true); else GS_FWD2(false);
+#undef GS_FWD_SMALL2
+#undef GS_FWD_SMALL
 #undef GS_FWD2
 #undef GS_FWD
     GS_CHECK_LAUNCH();
@@ -853,7 +1273,7 @@ int gs_blend_backward(const int32_t *bin_start, const int32_t *payload, const fl
                       const float *grad_image, const float *acc_alpha, const int32_t *last_effective,
                       const int32_t *slot_offsets, int64_t n_slots, int width, int height, int tile_row_begin,
                       int tile_row_step, int tile_row_end, int bin_shift, int filter, float *partials,
-                      uint8_t *slot_flags, float *magnitude_image, uint32_t *debug_pixel_hits,
+                      uint8_t *slot_flags, float *magnitude_image, uint32_t *debug_pixel_hits, int flags,
                       const int32_t *tile_work, int32_t *tile_order, void *stream) {
     GS_REQUIRE(width % GS_TILE_WIDTH == 0 && height % GS_TILE_HEIGHT == 0, "image size must be a multiple of 16");
     GS_REQUIRE(tile_row_step >= 1 && tile_row_begin >= 0 && tile_row_end >= 0, "tile row ownership");
@@ -877,7 +1297,27 @@ int gs_blend_backward(const int32_t *bin_start, const int32_t *payload, const fl
                            (const int32_t *)nullptr, tw * rows, tw, tile_row_begin, tile_row_step, bin_shift, tile_order);
         GS_CHECK_LAUNCH();
     }
-    if (staged)
+    const bool four_waves = !staged && !(flags & GS_BLEND_TWO_WAVES) &&
+                            ((flags & GS_BLEND_FOUR_WAVES) || tw * rows <= GS_SMALL_GRID_TILES);
+    if (!staged && (flags & GS_BLEND_ONE_WAVE)) {   // measurement arm (four pixels per lane)
+        if (debug_pixel_hits != nullptr)
+            hipLaunchKernelGGL(blend_backward_wide_kernel<true>, grid, dim3(WIDE_THREADS), 0, s, bin_start, payload, a4,
+                               grad_image, acc_alpha, last_effective, width, height, tile_row_begin, tile_row_step,
+                               slot_offsets, p4, slot_flags, magnitude_image, debug_pixel_hits, tile_order);
+        else
+            hipLaunchKernelGGL(blend_backward_wide_kernel<false>, grid, dim3(WIDE_THREADS), 0, s, bin_start, payload, a4,
+                               grad_image, acc_alpha, last_effective, width, height, tile_row_begin, tile_row_step,
+                               slot_offsets, p4, slot_flags, magnitude_image, debug_pixel_hits, tile_order);
+    } else if (four_waves) {
+        if (debug_pixel_hits != nullptr)
+            hipLaunchKernelGGL(blend_backward_small_kernel<true>, grid, dim3(SMALL_THREADS), 0, s, bin_start, payload, a4,
+                               grad_image, acc_alpha, last_effective, width, height, tile_row_begin, tile_row_step,
+                               slot_offsets, p4, slot_flags, magnitude_image, debug_pixel_hits, tile_order);
+        else
+            hipLaunchKernelGGL(blend_backward_small_kernel<false>, grid, dim3(SMALL_THREADS), 0, s, bin_start, payload, a4,
+                               grad_image, acc_alpha, last_effective, width, height, tile_row_begin, tile_row_step,
+                               slot_offsets, p4, slot_flags, magnitude_image, debug_pixel_hits, tile_order);
+    } else if (staged)
         launch_backward<true>(debug_pixel_hits != nullptr, grid, s, bin_start, payload, a4, grad_image, acc_alpha,
                               last_effective, width, height, tile_row_begin, tile_row_step, bin_shift, filter,
                               slot_offsets, p4, slot_flags, magnitude_image, debug_pixel_hits, tile_order);

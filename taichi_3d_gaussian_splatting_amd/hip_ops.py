@@ -73,6 +73,31 @@ class ListLayout:
 PER_TILE_LISTS = ListLayout(bin_shift=0, exact_cull=False)   # the reference's lists
 
 
+class Workspaces:
+    """Scratch buffers of one operator instance that are dead when the call that uses them returns (sort ping-pong keys,
+    histograms, block sums, slot records, ...): kept between frames instead of ~10 ``torch.empty`` calls per frame (host
+    time that small frames cannot hide behind the GPU).  Buffers only grow.  Nothing that is returned to the caller or
+    saved for the backward pass lives here, so frames may interleave (two forwards, then two backwards) on one stream."""
+
+    def __init__(self):
+        self._bufs = {}
+
+    def get(self, name: str, shape, dtype: torch.dtype, device) -> torch.Tensor:
+        numel = 1
+        for d in (shape if isinstance(shape, (tuple, list)) else (shape,)):
+            numel *= int(d)
+        t = self._bufs.get(name)
+        if t is None or t.numel() < numel or t.dtype != dtype or t.device != device:
+            grow = numel if t is None else max(numel, (t.numel() * 5) // 4)
+            t = torch.empty(max(grow, 1), dtype=dtype, device=device)
+            self._bufs[name] = t
+        return t[:numel].view(shape)
+
+
+def _scratch(ws: Optional["Workspaces"], name: str, shape, dtype, device) -> torch.Tensor:
+    return torch.empty(shape, dtype=dtype, device=device) if ws is None else ws.get(name, shape, dtype, device)
+
+
 def _require_device(t: torch.Tensor, name: str) -> None:
     if not t.is_cuda:
         raise RuntimeError(
@@ -129,7 +154,7 @@ def pose_inverse(q_pointcloud_camera: torch.Tensor, t_pointcloud_camera: torch.T
 
 
 def filter_compact(xyz, invalid_mask, object_id, intrinsics, q_cp, t_cp, near_plane, far_plane, width, height,
-                   counters: Optional[torch.Tensor] = None, sync: bool = True):
+                   counters: Optional[torch.Tensor] = None, sync: bool = True, ws: Optional[Workspaces] = None):
     """-> (mask int8[N], ids, counters).  sync=True: blocks on the size read-back (RAS:870) and returns
     ids int32[M]; sync=False: returns the int32[N] buffer whose first M entries are valid, M staying on the
     device in counters[COUNTER_NUM_VISIBLE] (pass it on with preprocess(..., n_visible_on_device=True))."""
@@ -140,10 +165,10 @@ def filter_compact(xyz, invalid_mask, object_id, intrinsics, q_cp, t_cp, near_pl
     ids = torch.empty(n, dtype=torch.int32, device=dev)
     if counters is None:
         counters = torch.empty(NUM_COUNTERS, dtype=torch.int32, device=dev)   # zeroed by gs_filter_compact
-    ws = torch.empty(_lib.load().gs_filter_workspace_bytes(n), dtype=torch.uint8, device=dev)
+    scratch = _scratch(ws, "filter", _lib.load().gs_filter_workspace_bytes(n), torch.uint8, dev)
     call("gs_filter_compact", ptr(xyz), ptr(invalid_mask), ptr(object_id), ptr(intrinsics), ptr(q_cp), ptr(t_cp),
          n, float(near_plane), float(far_plane), int(width), int(height), ptr(mask), ptr(ids), ptr(counters),
-         ptr(ws), current_stream(dev))
+         ptr(scratch), current_stream(dev))
     if not sync:
         return mask, ids, counters
     m = read_counters(counters)[COUNTER_NUM_VISIBLE]
@@ -152,7 +177,7 @@ def filter_compact(xyz, invalid_mask, object_id, intrinsics, q_cp, t_cp, near_pl
 
 def preprocess(xyz, features, object_id, intrinsics, q_cp, t_cp, ids, width, height, layout: ListLayout = ListLayout(),
                depth_to_sort_key_scale=100.0, counters=None, n_visible_on_device=False,
-               always_store_rotation: bool = False):
+               always_store_rotation: bool = False, ws: Optional[Workspaces] = None):
     """-> (attrs f32[M,16], num_overlap_tiles i32[M], num_keys i32[M], block_sums, block_sums_full).
     Normalises features[ids, 0:4] IN PLACE (RAS:196-205).  num_overlap_tiles is the reference's box count
     (hook output; its scan gives the backward slots); num_keys is the number of sort keys emitted (bins reached in
@@ -162,8 +187,9 @@ def preprocess(xyz, features, object_id, intrinsics, q_cp, t_cp, ids, width, hei
     attrs = torch.empty((m, ATTR_STRIDE), dtype=torch.float32, device=dev)
     ntiles = torch.empty(m, dtype=torch.int32, device=dev)
     nkeys = torch.empty(m, dtype=torch.int32, device=dev)
-    block_sums = torch.empty((m + _PRE_BLOCK - 1) // _PRE_BLOCK, dtype=torch.int32, device=dev)
-    block_sums_full = torch.empty_like(block_sums)
+    nblk = (m + _PRE_BLOCK - 1) // _PRE_BLOCK
+    block_sums = _scratch(ws, "block_sums", nblk, torch.int32, dev)
+    block_sums_full = _scratch(ws, "block_sums_full", nblk, torch.int32, dev)
     call("gs_preprocess", ptr(xyz), ptr(features), ptr(object_id), ptr(intrinsics), ptr(q_cp), ptr(t_cp), ptr(ids),
          m, int(bool(n_visible_on_device)), int(width), int(height), layout.row_begin, layout.row_step, layout.row_end,
          layout.bin_shift, int(layout.exact_cull), int(bool(always_store_rotation)), float(depth_to_sort_key_scale),
@@ -192,7 +218,7 @@ def scan_block_sums(block_sums: torch.Tensor, counters: torch.Tensor,
 
 def make_keys(attrs, num_keys, block_offsets, n_keys, width, height, depth_to_sort_key_scale,
               layout: ListLayout = ListLayout(), key_depth_bits=0, num_overlap_tiles=None, block_offsets_full=None,
-              counters=None):
+              counters=None, ws: Optional[Workspaces] = None):
     """-> (keys, payload, slot_offsets).  key_depth_bits == 0: int64 keys in the reference layout
     (bin << 32) + depth; key_depth_bits > 0: 32-bit keys (bin << key_depth_bits) | depth, stored in an int32
     tensor.  slot_offsets i32[M] = exclusive scan of num_overlap_tiles (base of every Gaussian's backward
@@ -201,7 +227,7 @@ def make_keys(attrs, num_keys, block_offsets, n_keys, width, height, depth_to_so
     the key arrays (see include/gsplat_hip.h)."""
     dev = attrs.device
     m = attrs.shape[0]
-    keys = torch.empty(n_keys, dtype=torch.int64 if key_depth_bits == 0 else torch.int32, device=dev)
+    keys = _scratch(ws, "keys", n_keys, torch.int64 if key_depth_bits == 0 else torch.int32, dev)
     payload = torch.empty(n_keys, dtype=torch.int32, device=dev)
     slot_offsets = torch.empty(m, dtype=torch.int32, device=dev) if num_overlap_tiles is not None else None
     if m > 0:
@@ -236,7 +262,8 @@ def key_layout(near_plane: float, far_plane: float, depth_to_sort_key_scale: flo
 
 
 def sort_pairs(keys: torch.Tensor, payload: torch.Tensor, depth_bits: int, tile_bits: int,
-               key_depth_bits: int = 0, in_place: bool = True, n_keys_device: Optional[torch.Tensor] = None):
+               key_depth_bits: int = 0, in_place: bool = True, n_keys_device: Optional[torch.Tensor] = None,
+               ws: Optional[Workspaces] = None):
     """Stable sort of (keys, payload).  in_place=True: the inputs hold the result.  in_place=False: returns the
     (keys, payload) tensors that hold the result (the inputs or the ping-pong buffers: no copy back after an
     odd number of passes); the other pair is scratch."""
@@ -246,11 +273,12 @@ def sort_pairs(keys: torch.Tensor, payload: torch.Tensor, depth_bits: int, tile_
     if keys.dtype != (torch.int64 if key_depth_bits == 0 else torch.int32):
         raise TypeError("key dtype does not match the key layout")
     dev = keys.device
-    keys_alt, payload_alt = torch.empty_like(keys), torch.empty_like(payload)
-    ws = torch.empty(_lib.load().gs_sort_workspace_bytes(n), dtype=torch.uint8, device=dev)
+    keys_alt = _scratch(ws, "keys_alt", n, keys.dtype, dev)
+    payload_alt = torch.empty_like(payload)   # (either payload buffer may end up holding the result: not scratch)
+    scratch = _scratch(ws, "sort", _lib.load().gs_sort_workspace_bytes(n), torch.uint8, dev)
     status = _lib.load().gs_sort_pairs(ptr(keys), ptr(payload), ptr(keys_alt), ptr(payload_alt), n,
                                        ptr(n_keys_device), int(key_depth_bits), int(depth_bits), int(tile_bits), 0 if in_place else 1,
-                                       ptr(ws), current_stream(dev))
+                                       ptr(scratch), current_stream(dev))
     if status < 0:
         _lib.check(status, "gs_sort_pairs")
     if not in_place:
@@ -273,18 +301,20 @@ def tile_ranges(keys_sorted: torch.Tensor, num_tiles: int, key_depth_bits: int =
 
 BLEND_RGB_ONLY = 1      # include/gsplat_hip.h GS_BLEND_RGB_ONLY: no depth / per-pixel count (RAS:464-469,478-484)
 BLEND_NO_STATE = 2      # GS_BLEND_NO_STATE: no acc_alpha / last_effective (nothing will be back-propagated)
+BLEND_ARMS = {None: 0, "two_waves": 4, "four_waves": 8, "one_wave": 16}   # GS_BLEND_TWO_WAVES / GS_BLEND_FOUR_WAVES (None: by tile count)
 
 
 def blend_forward(bin_start, bin_end, payload, attrs, width, height, layout: ListLayout = ListLayout(),
                   out=None, rgb_only=False, need_state=True, debug_hits=False, gathered_rows: int = 0,
-                  ordered: bool = False, tile_work: Optional[torch.Tensor] = None):
+                  ordered: bool = False, tile_work: Optional[torch.Tensor] = None, arm: Optional[str] = None,
+                  ws: Optional[Workspaces] = None):
     """-> (image, depth, acc_alpha, last_effective, count).  rgb_only: depth and count are not computed (returned
     as None); need_state=False: acc_alpha / last_effective are not computed (None) -- the inference path.
     debug_hits=True appends a uint32-as-int32 [H,W,2] tensor {blended count, hash of blended payloads} per pixel.
     ordered: tiles are dispatched longest list first (same results, shorter tail of the launch); tile_work (int32[owned
     tiles], needs the state): receives the walk lengths the backward pass will see (blend_backward_partials)."""
     dev = bin_start.device
-    flags = (BLEND_RGB_ONLY if rgb_only else 0) | (0 if need_state else BLEND_NO_STATE)
+    flags = (BLEND_RGB_ONLY if rgb_only else 0) | (0 if need_state else BLEND_NO_STATE) | BLEND_ARMS[arm]
     if out is None:
         alloc = torch.zeros if layout.sharded else torch.empty  # un-owned tiles are left untouched
         f32 = lambda *shape: alloc(shape, dtype=torch.float32, device=dev)   # noqa: E731
@@ -304,7 +334,7 @@ def blend_forward(bin_start, bin_end, payload, attrs, width, height, layout: Lis
                    None if rgb_only else i32(height, width))
     image, depth, acc_alpha, last_eff, count = out
     dbg = torch.zeros((height, width, 2), dtype=torch.int32, device=dev) if debug_hits else None
-    order = torch.empty(num_owned_tiles(width, height, layout), dtype=torch.int32, device=dev) if ordered else None
+    order = _scratch(ws, "order_fwd", num_owned_tiles(width, height, layout), torch.int32, dev) if ordered else None
     call("gs_blend_forward", ptr(bin_start), ptr(bin_end), ptr(payload), ptr(attrs), int(width), int(height),
          layout.row_begin, layout.row_step, layout.row_end, layout.bin_shift, layout.filter, ptr(image), ptr(depth),
          ptr(acc_alpha), ptr(last_eff), ptr(count), flags, ptr(dbg), ptr(order), ptr(tile_work), current_stream(dev))
@@ -317,33 +347,34 @@ def num_owned_tiles(width: int, height: int, layout: ListLayout) -> int:
 
 def blend_backward_partials(bin_start, payload, attrs, grad_image, acc_alpha, last_eff, slot_offsets, n_slots,
                             width, height, layout: ListLayout = ListLayout(), debug_hits=False, tile_order=None,
-                            tile_work=None):
+                            tile_work=None, arm: Optional[str] = None, ws: Optional[Workspaces] = None):
     """Per-pixel backward pass -> (partials f32[S,12], slot_flags u8[S], magnitude image f32[H,W,2]): one partial
     record per (Gaussian, tile) slot, plain stores, no atomics.  debug_hits=True appends the per-pixel
     {count, hash} record of the pairs the backward treated as blended (see blend_forward)."""
     dev = attrs.device
     grad_image = _f32(grad_image, "grad_rasterized_image")
-    partials = torch.empty((max(int(n_slots), 1), ACC_STRIDE), dtype=torch.float32, device=dev)
+    partials = _scratch(ws, "partials", (max(int(n_slots), 1), ACC_STRIDE), torch.float32, dev)
     # the flag buffer is allocated padded to 16 bytes (gsplat_hip.h: one aligned fill); callers see the n_slots flags
-    flags = torch.empty((max(int(n_slots), 1) + 15) & ~15, dtype=torch.uint8, device=dev)[:max(int(n_slots), 1)]
+    flags = _scratch(ws, "slot_flags", (max(int(n_slots), 1) + 15) & ~15, torch.uint8, dev)[:max(int(n_slots), 1)]
     alloc = torch.zeros if layout.sharded else torch.empty
     mag = alloc((height, width, 2), dtype=torch.float32, device=dev)
     dbg = torch.zeros((height, width, 2), dtype=torch.int32, device=dev) if debug_hits else None
     if tile_work is not None:   # the forward's walk lengths: the library sorts the tiles by them (longest first)
-        tile_order = torch.empty_like(tile_work)
+        tile_order = _scratch(ws, "order_bwd", tile_work.shape[0], torch.int32, dev)
     call("gs_blend_backward", ptr(bin_start), ptr(payload), ptr(attrs), ptr(grad_image), ptr(acc_alpha),
          ptr(last_eff), ptr(slot_offsets), int(n_slots), int(width), int(height), layout.row_begin, layout.row_step,
-         layout.row_end, layout.bin_shift, layout.filter, ptr(partials), ptr(flags), ptr(mag), ptr(dbg),
+         layout.row_end, layout.bin_shift, layout.filter, ptr(partials), ptr(flags), ptr(mag), ptr(dbg), BLEND_ARMS[arm],
          ptr(tile_work), ptr(tile_order), current_stream(dev))
     return (partials, flags, mag, dbg) if debug_hits else (partials, flags, mag)
 
 
-def reduce_partials(slot_offsets, num_overlap_tiles, flags, partials, num_keys=None, attrs=None, width=0, height=0):
+def reduce_partials(slot_offsets, num_overlap_tiles, flags, partials, num_keys=None, attrs=None, width=0, height=0,
+                    ws: Optional[Workspaces] = None):
     """Per-Gaussian sum of its flagged slots, in slot order -> acc f32[M,12].  num_keys (optional): Gaussians with
     no sort key on this GPU are written as zeros without looking at their slots.  attrs + image size (optional): a
     Gaussian with many slots is only looked at where it can have been blended (same sums, fewer flags read)."""
     m = slot_offsets.shape[0]
-    acc = torch.empty((m, ACC_STRIDE), dtype=torch.float32, device=partials.device)
+    acc = _scratch(ws, "acc", (m, ACC_STRIDE), torch.float32, partials.device)
     call("gs_reduce_partials", ptr(slot_offsets), ptr(num_overlap_tiles), ptr(flags), ptr(partials), m, ptr(acc),
          ptr(num_keys), int(partials.shape[0]), ptr(attrs), int(width), int(height), current_stream(partials.device))
     return acc

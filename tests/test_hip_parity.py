@@ -184,9 +184,10 @@ def test_keys_sort_ranges_bit_exact(ops, scene, ofwd):
     assert np.array_equal(end32.cpu().numpy(), ofwd["tile_end"])
 
 
-def _pipeline(ops, s, ofwd, layout, g=None):
+def _pipeline(ops, s, ofwd, layout, g=None, arm="two_waves"):
     """HIP stages after the frustum filter under a list layout -> forward outputs (+ debug hit records), sorted keys,
-    and (with an upstream gradient g) the backward accumulators."""
+    and (with an upstream gradient g) the backward accumulators.  arm: the blend kernels' form (two waves per tile by
+    default here, so that layouts are compared like for like; None = the library's choice by tile count)."""
     feat = dev(s.point_cloud_features).clone()  # fresh copy: preprocess normalises q in place
     a, nfull, nkeys, bsums, bsums_full = ops.preprocess(
         dev(s.point_cloud), feat, dev(s.point_object_id), dev(s.camera_intrinsics), dev(ofwd["q_cp"]),
@@ -201,12 +202,12 @@ def _pipeline(ops, s, ofwd, layout, g=None):
     db, tb = ops.sort_key_bits(s.near_plane, s.far_plane, s.depth_to_sort_key_scale, nb)
     ops.sort_pairs(keys, payload, db, tb)
     start, end = ops.tile_ranges(keys, nb)
-    out = ops.blend_forward(start, end, payload, a, s.width, s.height, layout, debug_hits=True)
+    out = ops.blend_forward(start, end, payload, a, s.width, s.height, layout, debug_hits=True, arm=arm)
     res = dict(k=k, keys=keys.cpu().numpy(), payload=payload.cpu().numpy(), fwd=[t.cpu() for t in out])
     if g is not None:
         image, depth, acc_alpha, last_eff, count, _ = out
         partials, flags, mag, dbg = ops.blend_backward_partials(start, payload, a, g, acc_alpha, last_eff, slot_offsets,
-                                                                n_slots, s.width, s.height, layout, debug_hits=True)
+                                                                n_slots, s.width, s.height, layout, debug_hits=True, arm=arm)
         res.update(acc=ops.reduce_partials(slot_offsets, nfull, flags, partials).cpu(), mag=mag.cpu(), bwd_dbg=dbg.cpu())
     return res
 
@@ -234,6 +235,19 @@ def test_list_layouts_are_output_identical(ops, scene, ofwd, obwd):
         assert torch.equal(o["bwd_dbg"], ref["fwd"][5]), name            # backward treats the same pairs as blended
         assert torch.equal(o["acc"].view(torch.int32), ref["acc"].view(torch.int32)), name
         assert torch.equal(o["mag"], ref["mag"]), name
+    # the four-waves-per-tile form of the two blend kernels (small grids; per-tile lists taken as they are): every forward
+    # output and the hit sets bit-identical, the backward's slot sums equal up to the order of the per-pixel terms
+    for name in ("tile", "tile+cull"):
+        four = _pipeline(ops, s, ofwd, layouts[name], g, arm="four_waves")
+        for i in range(6):
+            assert torch.equal(four["fwd"][i], outs[name]["fwd"][i]), (name, names[i])
+        assert torch.equal(four["bwd_dbg"], ref["fwd"][5]) and torch.equal(four["mag"], ref["mag"]), name
+        a4, a2 = four["acc"], outs[name]["acc"]
+        assert torch.equal(a4[:, 10].contiguous().view(torch.int32), a2[:, 10].contiguous().view(torch.int32))
+        scale = a2[:, :10].abs().amax(dim=0).clamp_min(1e-30)
+        worst = float(((a4[:, :10] - a2[:, :10]).abs() / scale).max())
+        report(f"four_waves.{name}", max_scaled_difference_of_slot_sums=worst)
+        assert worst < 2e-6
     # every (bin, Gaussian) key the cull dropped stays below 1/255 on all pixels of the bin (float64 check)
     full, kept = outs["bin"], outs["bin+cull"]
     pair = lambda o: (o["keys"] >> 32) * (1 << 32) + o["payload"]  # noqa: E731  (bin, point) identifier
@@ -740,6 +754,38 @@ def test_forward_and_backward_blend_the_same_pairs(ops, workload, bin_shift):
     # per-Gaussian pixel counts of the backward add up to the forward's per-pixel counts
     acc = ops.reduce_partials(st["slot_offsets"], st["ntiles"], flags, partials)
     assert int(acc[:, 10].contiguous().view(torch.int32).sum()) == int(count.sum())
+
+
+def test_four_waves_per_tile_arm_at_a_larger_size(ops):
+    """The small-grid arm of the two blend kernels (four waves per tile, one pixel per lane) forced on a 2,500-tile frame
+    and compared with the two-wave kernels on the same lists: every forward output bit-identical, identical hit sets in
+    both passes, slot sums equal up to the order of the per-pixel terms; the default picks it by tile count."""
+    from taichi_3d_gaussian_splatting_amd.synthetic import make_config_scene, make_grad_image
+    s = make_config_scene("cfg2_100k_800").to("cuda")
+    st = _stages_to_ranges(ops, s, ops.ListLayout(bin_shift=0))
+    g = make_grad_image(s.height, s.width).cuda()
+    out, part = {}, {}
+    for arm in ("two_waves", "four_waves", None):
+        out[arm] = ops.blend_forward(st["start"], st["end"], st["payload"], st["attrs"], s.width, s.height, st["layout"],
+                                     debug_hits=True, arm=arm)
+        part[arm] = ops.blend_backward_partials(st["start"], st["payload"], st["attrs"], g, out[arm][2], out[arm][3],
+                                                st["slot_offsets"], st["n_slots"], s.width, s.height, st["layout"],
+                                                debug_hits=True, arm=arm)
+    for i in range(6):
+        assert torch.equal(out["four_waves"][i], out["two_waves"][i]), i
+    p2, f2, m2, d2 = part["two_waves"]
+    p4, f4, m4, d4 = part["four_waves"]
+    assert torch.equal(d4, d2) and torch.equal(d4, out["two_waves"][5]) and torch.equal(f4, f2) and torch.equal(m4, m2)
+    raised = f2.bool()
+    assert torch.equal(p4[raised][:, 10].contiguous().view(torch.int32), p2[raised][:, 10].contiguous().view(torch.int32))
+    a2 = ops.reduce_partials(st["slot_offsets"], st["ntiles"], f2, p2)
+    a4 = ops.reduce_partials(st["slot_offsets"], st["ntiles"], f4, p4)
+    scale = a2[:, :10].abs().amax(dim=0).clamp_min(1e-30)
+    worst = float(((a4[:, :10] - a2[:, :10]).abs() / scale).max())
+    report("four_waves.cfg2", tiles=(s.width // 16) * (s.height // 16), max_scaled_difference_of_sums=worst)
+    assert worst < 2e-6
+    # 2,500 tiles > 1,024: the library's own choice here is the two-wave form, bit for bit
+    assert torch.equal(part[None][0][raised].view(torch.int32), p2[raised].view(torch.int32))
 
 
 def test_rgb_only_and_inference_paths(ops, scene):

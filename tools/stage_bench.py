@@ -19,6 +19,8 @@ times = {}
 CULL = os.environ.get('GS_CULL', '1') == '1'
 AB = os.environ.get('GS_AB', '0') == '1'
 ORDERED = os.environ.get('GS_TILE_ORDER', '0') == '1'
+ARMS = os.environ.get('GS_ARMS', '0') == '1'
+arm_out, arm_acc = {}, {}
 LAYOUT = hip_ops.ListLayout(bin_shift=int(os.environ.get('GS_BIN_SHIFT', '0')), exact_cull=CULL)
 
 
@@ -72,6 +74,15 @@ for _ in range(reps + 2):
     unfused = timed("point_backward", lambda: hip_ops.point_backward(
         s.point_cloud, feat, s.point_object_id, s.camera_intrinsics, q_cp, t_cp, s.t_pointcloud_camera, ids, acc, attrs, 3,
         1.0, 0.5, 20.0, 5.0, 1.0, False, vmask, nowned))
+    if ARMS and LAYOUT.bin_shift == 0:   # the forms of the blend kernels on the same per-tile lists
+        for arm_ in ("two_waves", "four_waves", "one_wave"):
+            arm_out[arm_] = timed(f"blend_backward[{arm_}]", lambda: hip_ops.blend_backward_partials(
+                start, payload, attrs, g, acc_alpha, last_eff, slot_off, n_slots, s.width, s.height, LAYOUT, arm=arm_,
+                tile_work=tile_work if ORDERED else None))
+            if arm_ != "one_wave":
+                timed(f"blend_forward[{arm_}]", lambda: hip_ops.blend_forward(
+                    start, end, payload, attrs, s.width, s.height, LAYOUT, arm=arm_, ordered=ORDERED))
+            arm_acc[arm_] = hip_ops.reduce_partials(slot_off, ntiles, arm_out[arm_][1], arm_out[arm_][0]).clone()
     if AB:   # A/B arm: slot reduction fused into the per-point kernel
         fused = timed("point_backward_fused", lambda: hip_ops.point_backward(
             s.point_cloud, feat, s.point_object_id, s.camera_intrinsics, q_cp, t_cp, s.t_pointcloud_camera, ids, None, attrs, 3,
@@ -83,7 +94,7 @@ tot = 0.0
 for name, pairs in times.items():
     ms = sum(a.elapsed_time(b) for a, b in pairs[2:]) / len(pairs[2:])
     tot += 0.0 if name in ("blend_forward_rgb_nostate", "blend_backward_lpt", "blend_forward_ordered",
-                           "blend_backward_ordered", "point_backward_fused") else ms
+                           "blend_backward_ordered", "point_backward_fused") or "[" in name else ms
     print(f"  {name:16s} {ms:8.4f} ms")
 print(f"  {'sum':16s} {tot:8.4f} ms")
 lens = (end - start).float()
@@ -96,6 +107,13 @@ hits = acc[:, 10].contiguous().view(torch.int32).double().sum().item()
 print(f"  checksums: acc.sum={acc[:, :10].double().sum().item():.9e} acc.abs={acc[:, :10].double().abs().sum().item():.9e} "
       f"mag.sum={mag.double().sum().item():.9e}; (pixel, Gaussian) hits={hits:.0f} = "
       f"{hits / max(walked.sum().item() * 256.0, 1.0):.4f} of the visited (tile entry x 256 pixel) pairs")
+for arm_, a_ in arm_acc.items():
+    ref_ = arm_acc["two_waves"]
+    scale_ = ref_[:, :10].abs().amax(dim=0).clamp_min(1e-30)
+    print(f"  arm {arm_}: max scaled difference of the slot sums vs two_waves "
+          f"{float(((a_[:, :10] - ref_[:, :10]).abs() / scale_).max()):.3e}, pixel counts equal "
+          f"{bool(torch.equal(a_[:, 10].contiguous().view(torch.int32), ref_[:, 10].contiguous().view(torch.int32)))}, "
+          f"magnitude image equal {bool(torch.equal(arm_out[arm_][2], arm_out['two_waves'][2]))}")
 if AB:
     print(f"  fused slot reduction identical: {all(torch.equal(a, b) for a, b in zip(fused[:2], unfused[:2]))}")
 if ORDERED:
