@@ -210,43 +210,52 @@ __device__ __forceinline__ void gs_direct_step(const int32_t *__restrict__ paylo
 // magnitude (list positions walked: mean 158, max 383 per-tile / 292 and 749 binned at the headline scene), so with
 // tiles in image order the launch ends with a long tail of half-empty CUs: VALU busy 80 %, 3.4 of 5 waves resident on
 // average.  Longest-first (LPT) order fixes most of it (backward 0.46 -> 0.40 ms measured with an order computed by
-// torch).  This kernel is that order on the device: ONE workgroup, counting sort of the owned tiles by 1024 classes of
-// their work estimate, descending (LDS atomics; the order inside a class is arbitrary and irrelevant -- a tile's
-// results do not depend on when it runs).  work[e] given: the estimate of tile e (the forward kernel records the walk
+// torch).  This kernel is that order on the device: a counting sort of the owned tiles by 1024 classes of their work
+// estimate, descending (LDS atomics; the order inside a class is arbitrary and irrelevant -- a tile's results do not
+// depend on when it runs).  work[e] given: the estimate of tile e (the forward kernel records the walk
 // length the backward will see); work == nullptr: the length of the tile's (bin's) sorted list.
-constexpr int ORDER_THREADS = 1024, ORDER_CLASSES = 1024, ORDER_ITEMS = 8;   // (one class per thread)
-constexpr int ORDER_WAVES = ORDER_THREADS / GS_WAVE;
+// Eight workgroups, one per residue of the tile number modulo 8: workgroup r sorts the tiles e = r (mod 8) among themselves
+// and stores its p-th heaviest at order[r + 8 p] -- block b of the blend launch (which the hardware places on XCD b mod 8)
+// simply takes order[b], i.e. the (b / 8)-th heaviest tile of list b mod 8: eight descending lists interleaved, no
+// communication between the workgroups, and each XCD works through its own list heaviest first.  (One workgroup sorting
+// all 8,040 tiles took 10-13 us per call, most of it fixed latency of a lone workgroup.)
+constexpr int ORDER_WGS = 8, ORDER_THREADS = 256, ORDER_CLASSES = 1024, ORDER_ITEMS = 4;
+constexpr int ORDER_WAVES = ORDER_THREADS / GS_WAVE, ORDER_CLASSES_PER_THREAD = ORDER_CLASSES / ORDER_THREADS;
 __global__ __launch_bounds__(ORDER_THREADS) void tile_order_kernel(
     const int32_t *__restrict__ work, const int32_t *__restrict__ bin_start, const int32_t *__restrict__ bin_end, int n,
     int tw, int row_begin, int row_step, int bin_shift, int32_t *__restrict__ order) {
-    // one histogram PER WAVE (64 KB of LDS): the tiles of a frame crowd into few classes, and a shared histogram turned
-    // every LDS atomic into a 20-way same-address conflict (13 us per call; 10 us of it the atomics)
+    // one histogram PER WAVE: the tiles of a frame crowd into few classes, and a shared histogram turns every LDS atomic
+    // into a many-way same-address conflict
     __shared__ int s_hist[ORDER_WAVES][ORDER_CLASSES];
     __shared__ int s_red[ORDER_WAVES];
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, r = blockIdx.x;
+    const int n_local = n > r ? (n - r + ORDER_WGS - 1) / ORDER_WGS : 0;   // tiles r, r + 8, ... below n
     const int bins_u = (tw + (1 << bin_shift) - 1) >> bin_shift;
-    auto work_of = [&](int e) {
+    auto work_of = [&](int j) {   // j-th tile of this workgroup's list
+        const int e = r + ORDER_WGS * j;
         if (work != nullptr) return max(work[e], 0);
         const int tu = e % tw, tv = row_begin + (e / tw) * row_step;
         const int bin = (tu >> bin_shift) + (tv >> bin_shift) * bins_u;
         return max(bin_end[bin] - bin_start[bin], 0);
     };
-    // wave w owns the tiles e = (k * 16 + w) * 64 + lane, k = 0, 1, ...: up to ORDER_ITEMS x 1024 tiles (8192: a 1920 x 1088
-    // frame) live in registers -- one read of the estimates; larger frames re-read them in the later passes
+    // up to ORDER_ITEMS x 256 tiles per list (8 x 1024 = 8192 tiles: a 1920 x 1088 frame) live in registers: one read of the
+    // estimates; larger frames re-read them in the later passes
     int w[ORDER_ITEMS];
     int mx = 1;
 #pragma unroll
     for (int k = 0; k < ORDER_ITEMS; ++k) {
-        const int e = k * ORDER_THREADS + tid;
-        w[k] = e < n ? work_of(e) : -1;
+        const int j = k * ORDER_THREADS + tid;
+        w[k] = j < n_local ? work_of(j) : -1;
         mx = max(mx, w[k]);
     }
-    for (int e = ORDER_ITEMS * ORDER_THREADS + tid; e < n; e += ORDER_THREADS) mx = max(mx, work_of(e));
+    for (int j = ORDER_ITEMS * ORDER_THREADS + tid; j < n_local; j += ORDER_THREADS) mx = max(mx, work_of(j));
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) mx = max(mx, __shfl_xor(mx, d, GS_WAVE));
     if (lane == 0) s_red[wv] = mx;
 #pragma unroll
-    for (int k = 0; k < ORDER_WAVES; ++k) s_hist[k][tid] = 0;
+    for (int k = 0; k < ORDER_WAVES; ++k)
+#pragma unroll
+        for (int c = 0; c < ORDER_CLASSES_PER_THREAD; ++c) s_hist[k][c * ORDER_THREADS + tid] = 0;
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < ORDER_WAVES; ++k) mx = max(mx, s_red[k]);
@@ -256,32 +265,43 @@ __global__ __launch_bounds__(ORDER_THREADS) void tile_order_kernel(
 #pragma unroll
     for (int k = 0; k < ORDER_ITEMS; ++k)
         if (w[k] >= 0) atomicAdd(&s_hist[wv][class_of(w[k])], 1);
-    for (int e = ORDER_ITEMS * ORDER_THREADS + tid; e < n; e += ORDER_THREADS) atomicAdd(&s_hist[wv][class_of(work_of(e))], 1);
+    for (int j = ORDER_ITEMS * ORDER_THREADS + tid; j < n_local; j += ORDER_THREADS) atomicAdd(&s_hist[wv][class_of(work_of(j))], 1);
     __syncthreads();
-    // class `tid`: exclusive prefix of its counts over the waves (in place), total -> scanned over the classes
-    int cnt = 0;
+    // thread t owns the consecutive classes 4 t .. 4 t + 3: exclusive prefix of every class over the waves (in place), class
+    // totals scanned over the classes
+    int first[ORDER_CLASSES_PER_THREAD], mine = 0;
 #pragma unroll
-    for (int k = 0; k < ORDER_WAVES; ++k) {
-        const int c = s_hist[k][tid];
-        s_hist[k][tid] = cnt;
-        cnt += c;
+    for (int c = 0; c < ORDER_CLASSES_PER_THREAD; ++c) {
+        const int cls = ORDER_CLASSES_PER_THREAD * tid + c;
+        int cnt = 0;
+#pragma unroll
+        for (int k = 0; k < ORDER_WAVES; ++k) {
+            const int v = s_hist[k][cls];
+            s_hist[k][cls] = cnt;
+            cnt += v;
+        }
+        first[c] = mine;      // (exclusive within the thread)
+        mine += cnt;
     }
-    const int incl = gs_wave_incl_scan(cnt);
+    const int incl = gs_wave_incl_scan(mine);
     __syncthreads();                       // (s_red is reused)
     if (lane == GS_WAVE - 1) s_red[wv] = incl;
     __syncthreads();
-    int before = 0;
+    int before = incl - mine;
 #pragma unroll
     for (int k = 0; k < ORDER_WAVES; ++k) before += k < wv ? s_red[k] : 0;
-    const int first = before + incl - cnt;   // first position of class `tid`
 #pragma unroll
-    for (int k = 0; k < ORDER_WAVES; ++k) s_hist[k][tid] += first;   // -> running cursor of (wave k, class tid)
+    for (int c = 0; c < ORDER_CLASSES_PER_THREAD; ++c)
+#pragma unroll
+        for (int k = 0; k < ORDER_WAVES; ++k)
+            s_hist[k][ORDER_CLASSES_PER_THREAD * tid + c] += before + first[c];   // -> running cursor of (wave, class)
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < ORDER_ITEMS; ++k)
-        if (w[k] >= 0) order[atomicAdd(&s_hist[wv][class_of(w[k])], 1)] = k * ORDER_THREADS + tid;
-    for (int e = ORDER_ITEMS * ORDER_THREADS + tid; e < n; e += ORDER_THREADS)
-        order[atomicAdd(&s_hist[wv][class_of(work_of(e))], 1)] = e;
+        if (w[k] >= 0)
+            order[r + ORDER_WGS * atomicAdd(&s_hist[wv][class_of(w[k])], 1)] = r + ORDER_WGS * (k * ORDER_THREADS + tid);
+    for (int j = ORDER_ITEMS * ORDER_THREADS + tid; j < n_local; j += ORDER_THREADS)
+        order[r + ORDER_WGS * atomicAdd(&s_hist[wv][class_of(work_of(j))], 1)] = r + ORDER_WGS * j;
 }
 
 // ------------------------------------------------------------------------------- forward
@@ -371,13 +391,16 @@ __global__ __launch_bounds__(BLEND_THREADS) void blend_forward_kernel(
                 // a = alpha for a live pixel (x * 1.0f is exact), 0 for a saturated one
                 const v2f a = alpha[i] * alive;
                 bool ok0 = a.x >= EPS_ALPHA, ok1 = a.y >= EPS_ALPHA;  // RAS:451
-                if (gs_ballot(ok0 || ok1) == 0ull) continue;          // wave-uniform skip
+                const unsigned long long mok0 = gs_ballot(ok0), mok1 = gs_ballot(ok1);
+                if ((mok0 | mok1) == 0ull) continue;                  // wave-uniform skip
                 // alpha = 0 for a skipped pixel makes the update below an exact no-op (T*(1-0) = T, C += c*0)
                 v2f al = {ok0 ? __builtin_amdgcn_fmed3f(a.x, 0.f, CLAMP_ALPHA) : 0.f,
                           ok1 ? __builtin_amdgcn_fmed3f(a.y, 0.f, CLAMP_ALPHA) : 0.f};
                 v2f Tn = T * (splat(1.f) - al);
-                const bool sat0 = ok0 && Tn.x < STOP_T, sat1 = ok1 && Tn.y < STOP_T;
-                if (gs_ballot(sat0 || sat1) != 0ull) {
+                const bool low0 = Tn.x < STOP_T, low1 = Tn.y < STOP_T;
+                const bool sat0 = ok0 && low0, sat1 = ok1 && low1;
+                // (masks combined on the scalar unit: a ballot of the AND would be materialised as select + compare)
+                if (((mok0 & gs_ballot(low0)) | (mok1 & gs_ballot(low1))) != 0ull) {
                     // rare: RAS:458-460 -- the first Gaussian that would push T below 1e-4 saturates the
                     // pixel and is NOT blended
                     if (sat0) { al.x = 0.f; alive.x = 0.f; ok0 = false; }
@@ -863,7 +886,10 @@ __global__ __launch_bounds__(SMALL_THREADS) void blend_backward_small_kernel(
     uint32_t *__restrict__ debug_hits, const int32_t *__restrict__ tile_order) {
     __shared__ float4 s_p[BATCH], s_b[BATCH], s_c[BATCH], s_q[BATCH];
     __shared__ int s_o[BATCH];
-    __shared__ float s_acc[BATCH][GS_ACC_STRIDE];
+    // one slice of partial sums PER WAVE, written with plain stores and added in a fixed order by the flush: four waves
+    // meeting in one row with ds_add_f32 would sum in arrival order (two waves are safe: a + b = b + a) and the gradients
+    // would no longer be bitwise reproducible
+    __shared__ float s_acc[SMALL_THREADS / GS_WAVE][BATCH][GS_ACC_STRIDE];
     __shared__ int s_max[SMALL_THREADS / GS_WAVE];
     const int tw = width / GS_TILE_WIDTH, th = height / GS_TILE_HEIGHT;
     const TileCoord tc = owned_tile(tw, row_begin, row_step, tile_order);
@@ -908,11 +934,13 @@ __global__ __launch_bounds__(SMALL_THREADS) void blend_backward_small_kernel(
                 s_p[nbuf + tid] = make_float4(0.f, 0.f, 0.f, 0.f);
                 s_q[nbuf + tid] = make_float4(0.f, 0.f, 0.f, 0.f);
             }
-            if (tid < BATCH) {
-                float4 *z = reinterpret_cast<float4 *>(&s_acc[tid][0]);
-                z[0] = make_float4(0.f, 0.f, 0.f, 0.f);
-                z[1] = make_float4(0.f, 0.f, 0.f, 0.f);
-                z[2] = make_float4(0.f, 0.f, 0.f, 0.f);
+            {   // thread t clears rows t & 127 of slices 2 (t >> 7) and 2 (t >> 7) + 1
+                const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    float4 *z = reinterpret_cast<float4 *>(&s_acc[2 * (tid >> 7) + h][tid & (BATCH - 1)][0]);
+                    z[0] = zero; z[1] = zero; z[2] = zero;
+                }
             }
         }
         __syncthreads();
@@ -954,18 +982,25 @@ __global__ __launch_bounds__(SMALL_THREADS) void blend_backward_small_kernel(
                 }
                 float t0, t1, t2;
                 gs_wave_reduce12(v0, v1, c00, c01, c11, gr, gg, gb, w, nv, h, 0.f, t0, t1, t2);
-                if (row_tail) {
-                    float *A = &s_acc[k + i][slot];
-                    atomicAdd(A, t0);
-                    atomicAdd(A + 4, t1);
-                    atomicAdd(A + 8, t2);
+                if (row_tail) {   // (every (wave, entry) row is written at most once per round)
+                    float *A = &s_acc[tid >> 6][k + i][slot];
+                    A[0] = t0; A[4] = t1; A[8] = t2;
                 }
             }
         }
         __syncthreads();
         if (tid < nbuf) {   // flush: thread k owns staged entry k -> one 48-B store into the (Gaussian, tile) slot
-            const float4 *Sa = reinterpret_cast<const float4 *>(&s_acc[tid][0]);
-            float4 r0 = Sa[0], r1 = Sa[1], r2 = Sa[2];
+            float4 r[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {   // (wave 0 + wave 1) + (wave 2 + wave 3)
+                const float4 a0 = reinterpret_cast<const float4 *>(&s_acc[0][tid][0])[c];
+                const float4 a1 = reinterpret_cast<const float4 *>(&s_acc[1][tid][0])[c];
+                const float4 a2 = reinterpret_cast<const float4 *>(&s_acc[2][tid][0])[c];
+                const float4 a3 = reinterpret_cast<const float4 *>(&s_acc[3][tid][0])[c];
+                r[c] = make_float4((a0.x + a1.x) + (a2.x + a3.x), (a0.y + a1.y) + (a2.y + a3.y),
+                                   (a0.z + a1.z) + (a2.z + a3.z), (a0.w + a1.w) + (a2.w + a3.w));
+            }
+            float4 r0 = r[0], r1 = r[1], r2 = r[2];
             if (r2.z > 0.f) {
                 const float4 a = s_p[tid];
                 int t0u, t1u, t0v, t1v;
@@ -1233,7 +1268,7 @@ int gs_blend_forward(const int32_t *bin_start, const int32_t *bin_end, const int
     const bool dbg = debug_pixel_hits != nullptr;
     GS_REQUIRE(tile_work == nullptr || state, "tile_work is the backward's walk length: it needs the state outputs");
     if (tile_order != nullptr) {   // longest lists first
-        hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(ORDER_THREADS), 0, s, (const int32_t *)nullptr, bin_start,
+        hipLaunchKernelGGL(tile_order_kernel, dim3(ORDER_WGS), dim3(ORDER_THREADS), 0, s, (const int32_t *)nullptr, bin_start,
                            bin_end, tw * rows, tw, tile_row_begin, tile_row_step, bin_shift, tile_order);
         GS_CHECK_LAUNCH();
     }
@@ -1293,7 +1328,7 @@ int gs_blend_backward(const int32_t *bin_start, const int32_t *payload, const fl
     const bool staged = bin_shift > 0 || filter != 0;
     GS_REQUIRE(tile_work == nullptr || tile_order != nullptr, "tile_work needs the tile_order buffer");
     if (tile_work != nullptr) {   // longest walks first, from the lengths the forward pass recorded
-        hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(ORDER_THREADS), 0, s, tile_work, (const int32_t *)nullptr,
+        hipLaunchKernelGGL(tile_order_kernel, dim3(ORDER_WGS), dim3(ORDER_THREADS), 0, s, tile_work, (const int32_t *)nullptr,
                            (const int32_t *)nullptr, tw * rows, tw, tile_row_begin, tile_row_step, bin_shift, tile_order);
         GS_CHECK_LAUNCH();
     }

@@ -788,6 +788,54 @@ def test_four_waves_per_tile_arm_at_a_larger_size(ops):
     assert torch.equal(part[None][0][raised].view(torch.int32), p2[raised].view(torch.int32))
 
 
+def test_ordered_dispatch_on_a_4k_grid(ops):
+    """Longest-first dispatch on a grid of 32,400 tiles (3840 x 2160: more tiles than the ordering kernel keeps in
+    registers, and not a multiple of its eight lists' length): every tile is still rendered exactly once -- outputs
+    pre-filled with NaN come back identical to the image-order launch -- in both passes."""
+    from taichi_3d_gaussian_splatting_amd.synthetic import make_grad_image, make_scene
+    s = make_scene(n=200_000, height=2160, width=3840, s_min=0.004, s_max=0.03, seed=13).to("cuda")
+    st = _stages_to_ranges(ops, s, ops.ListLayout(bin_shift=1))
+    args = (st["start"], st["end"], st["payload"], st["attrs"], s.width, s.height, st["layout"])
+    plain = ops.blend_forward(*args)
+    nan_f = lambda *shape: torch.full(shape, float("nan"), device="cuda")   # noqa: E731
+    out = (nan_f(s.height, s.width, 3), nan_f(s.height, s.width), nan_f(s.height, s.width),
+           torch.full((s.height, s.width), -7, dtype=torch.int32, device="cuda"),
+           torch.full((s.height, s.width), -7, dtype=torch.int32, device="cuda"))
+    work = torch.full((ops.num_owned_tiles(s.width, s.height, st["layout"]),), -1, dtype=torch.int32, device="cuda")
+    ordered = ops.blend_forward(*args, out=out, ordered=True, tile_work=work)
+    for a, b in zip(plain, ordered):
+        assert torch.equal(a, b)
+    assert int(work.min()) >= 0
+    g = make_grad_image(s.height, s.width).cuda()
+    bargs = (st["start"], st["payload"], st["attrs"], g, plain[2], plain[3], st["slot_offsets"], st["n_slots"], s.width,
+             s.height, st["layout"])
+    p0, f0, m0 = ops.blend_backward_partials(*bargs)
+    p1, f1, m1 = ops.blend_backward_partials(*bargs, tile_work=work)
+    assert torch.equal(f0, f1) and torch.equal(m0, m1) and torch.equal(p0[f0.bool()].view(torch.int32), p1[f1.bool()].view(torch.int32))
+
+
+def test_operator_options_that_must_not_change_a_bit(scene):
+    """`fused_slot_reduction` (slot sums inside the per-point kernel), `always_store_normalised_rotation` (the write-back a
+    training iteration pays, for benchmarks of static scenes) and `ordered_dispatch` off: same image, same gradients, same
+    in-place normalised quaternions, bit for bit."""
+    from taichi_3d_gaussian_splatting_amd import GaussianPointCloudRasterisation as Op
+    from taichi_3d_gaussian_splatting_amd.synthetic import make_grad_image
+    g = make_grad_image(scene.height, scene.width)
+    cfg = Op.GaussianPointCloudRasterisationConfig(near_plane=scene.near_plane, far_plane=scene.far_plane,
+                                                   depth_to_sort_key_scale=scene.depth_to_sort_key_scale)
+    ref = _run_operator(scene, g, op=Op(cfg))
+    for attr, value in (("fused_slot_reduction", True), ("always_store_normalised_rotation", True),
+                        ("ordered_dispatch", False)):
+        op = Op(cfg)
+        setattr(op, attr, value)
+        got = _run_operator(scene, g, op=op)
+        for i in range(3):
+            assert torch.equal(got[i], ref[i]), (attr, i)
+        assert torch.equal(got[3].grad.view(torch.int32), ref[3].grad.view(torch.int32)), attr
+        assert torch.equal(got[4].grad.view(torch.int32), ref[4].grad.view(torch.int32)), attr
+        assert torch.equal(got[4].detach(), ref[4].detach()), attr     # the caller's features after the in-place normalisation
+
+
 def test_rgb_only_and_inference_paths(ops, scene):
     """rgb_only (RAS:464-469,478-484) and the no-gradient path: the image is bit-identical to the full forward; depth and
     count are zeros under rgb_only; gradients under rgb_only equal those of the default configuration."""

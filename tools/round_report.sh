@@ -1,11 +1,14 @@
 #!/bin/bash
 # Everything the round's documents quote, in one gpurun call (see profiles/README.md).  usage: tools/round_report.sh <tag>
 set -u
-TAG=${1:-r02}
+TAG=${1:-r03}
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out/report_$TAG
 mkdir -p $OUT
 cd $ROOT
+# 0. the GPU test suite (with the [parity] / [record] lines the documents quote)
+timeout 1500 python -m pytest tests -m gpu -q -s > $OUT/pytest.log 2>&1
+grep -E "passed|failed|\[record\]" $OUT/pytest.log | tail -5
 # 1. rocprofv3: kernel trace + HBM counters + SQ counters over the bench command
 bash tools/profile.sh $TAG > $OUT/profile.log 2>&1
 # 2. bench lines of every workload (driver contract line first)
@@ -15,6 +18,7 @@ cat $OUT/bench_default.json >> $OUT/bench_all_configs.jsonl
 for w in cfg1_10k_256 cfg2_100k_800 cfg3_400k_1080p cfg4_2m_1080p stress_t_ras; do
     python bench.py --workload $w --no-cpu-baseline 2>> $OUT/bench.err >> $OUT/bench_all_configs.jsonl
 done
+python bench.py --static-scene --no-cpu-baseline 2>> $OUT/bench.err >> $OUT/bench_all_configs.jsonl
 python bench.py --no-hook --no-cpu-baseline 2>> $OUT/bench.err >> $OUT/bench_all_configs.jsonl
 python bench.py --hook-feature-copy --no-cpu-baseline 2>> $OUT/bench.err >> $OUT/bench_all_configs.jsonl
 for w in headline_1m_1080p cfg3_400k_1080p stress_t_ras; do
@@ -22,7 +26,7 @@ for w in headline_1m_1080p cfg3_400k_1080p stress_t_ras; do
     python bench.py --workload $w --forward-only --rgb-only --no-cpu-baseline 2>> $OUT/bench.err >> $OUT/bench_all_configs.jsonl
 done
 # 3. per-stage times and per-rank shard times (one GPU, no collectives)
-python tools/stage_bench.py headline_1m_1080p 30 > $OUT/stage_headline.log 2>&1
+for bs in 1 0; do GS_BIN_SHIFT=$bs GS_TILE_ORDER=1 GS_ARMS=1 GS_AB=1 python tools/stage_bench.py headline_1m_1080p 30; done > $OUT/stage_headline.log 2>&1
 for m in bands interleaved; do GS_SHARD_MODE=$m python tools/shard_bench.py headline_1m_1080p; done > $OUT/shard_headline.log 2>&1
 python tools/shard_bench.py cfg4_2m_1080p > $OUT/shard_cfg4.log 2>&1
 python tools/host_profile.py cfg1_10k_256 300 > $OUT/host_profile_cfg1.log 2>&1

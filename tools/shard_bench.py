@@ -9,6 +9,8 @@ WORLDS = tuple(int(x) for x in os.environ.get("GS_SHARD_WORLDS", "1,2,4,8").spli
 for G in WORLDS:
     op = Op(Op.GaussianPointCloudRasterisationConfig())
     op.shard = (G // 2 if RANK < 0 else min(RANK, G - 1), G, MODE)
+    if os.environ.get("GS_BIN_SHIFT"):
+        op.bin_shift = int(os.environ["GS_BIN_SHIFT"])
     xyz = s.point_cloud.clone().requires_grad_(True); feat = s.point_cloud_features.clone().requires_grad_(True)
     inp = Op.GaussianPointCloudRasterisationInput(point_cloud=xyz, point_cloud_features=feat, point_object_id=s.point_object_id,
         point_invalid_mask=s.point_invalid_mask, camera_info=CameraInfo(s.camera_intrinsics, s.height, s.width, 0),
@@ -20,4 +22,5 @@ for G in WORLDS:
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(20): step()
     torch.cuda.synchronize()
-    print(f"G={G} {MODE} rank {op.shard[0]}: compute per step (no collectives) {(time.perf_counter()-t0)/20*1e3:.3f} ms")
+    print(f"G={G} {MODE} rank {op.shard[0]} bin_shift {op.list_layout(s.height, s.width).bin_shift}: compute per step (no collectives) "
+          f"{(time.perf_counter()-t0)/20*1e3:.3f} ms")
