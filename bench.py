@@ -263,13 +263,17 @@ def main() -> None:
                 attrs, nowned, bsums, k, s.width, s.height, s.depth_to_sort_key_scale, layout, kdb, ntiles, bsums_full))
             keys, payload = timed("sort_pairs", lambda: hip_ops.sort_pairs(keys, payload, db, tb, kdb, in_place=False))
             start, end = timed("tile_ranges", lambda: hip_ops.tile_ranges(keys, num_bins, kdb))
-            # as the operator runs them: tiles dispatched longest first, slot sums inside the per-point kernel (1 GPU)
+            # as the operator runs them: tiles dispatched longest first, the backward on the per-tile lists the (binned)
+            # forward pass wrote out
             tile_work = torch.empty(hip_ops.num_owned_tiles(s.width, s.height, layout), dtype=torch.int32, device=device)
-            image, depth, acc_alpha, last_eff, count = timed("blend_forward", lambda: hip_ops.blend_forward(
+            emit = bool(op.backward_on_walked_lists and layout.filter != 0 and layout.bin_shift <= 2)
+            fwd = timed("blend_forward", lambda: hip_ops.blend_forward(
                 start, end, payload, attrs, s.width, s.height, layout, ordered=op.ordered_dispatch,
-                tile_work=tile_work if op.ordered_dispatch else None))
+                tile_work=tile_work if op.ordered_dispatch else None, emit_walked_lists=emit))
+            image, depth, acc_alpha, last_eff, count = fwd[:5]
+            b_start, b_list, b_layout = (fwd[5], fwd[6], hip_ops.walked_layout(layout)) if emit else (start, payload, layout)
             partials, flags, mag = timed("blend_backward", lambda: hip_ops.blend_backward_partials(
-                start, payload, attrs, grad_image, acc_alpha, last_eff, slot_off, n_slots, s.width, s.height, layout,
+                b_start, b_list, attrs, grad_image, acc_alpha, last_eff, slot_off, n_slots, s.width, s.height, b_layout,
                 tile_work=tile_work if op.ordered_dispatch else None))
             acc = None
             if world > 1 or not op.fused_slot_reduction:

@@ -189,7 +189,14 @@ int gs_read_counters_async(const int32_t *counters, int32_t *host_counters_pinne
  * library fills it with the owned tiles sorted by list length, longest first (one small launch), and dispatches the
  * tiles in that order.  tile_work (may be NULL; needs the state outputs): int32[number of owned tiles], receives per
  * owned tile (n-th in row-major order over the owned rows) the number of list positions gs_blend_backward will walk
- * for it -- pass it on to gs_blend_backward.  Results never depend on the order. */
+ * for it -- pass it on to gs_blend_backward.  Results never depend on the order.
+ * Walked lists (binned layouts with the state outputs; both NULL otherwise).  walked_list: int32[n_keys << 2 bin_shift],
+ * walked_start: int32[number of tiles of the image].  A tile of a binned layout keeps, while it stages its bin's list, the
+ * entries that belong to it; with these buffers it also writes them out -- tile t (0 .. 4^bin_shift - 1, row-major in the bin)
+ * of a bin with range [s, e) owns positions (s << 2 bin_shift) + t (e - s) onwards -- stores that first position in
+ * walked_start[tile] and reports last_effective as positions in walked_list.  gs_blend_backward is then called with
+ * (bin_start = walked_start, payload = walked_list, bin_shift = 0, filter = 0): it walks a plain per-tile list and never
+ * examines the bin's other entries again (it never goes beyond what the forward pass walked). */
 #define GS_BLEND_RGB_ONLY 1
 #define GS_BLEND_NO_STATE 2
 #define GS_BLEND_TWO_WAVES 4    /* both blend passes: always the two-waves-per-tile kernels (two pixels per lane) */
@@ -204,7 +211,7 @@ int gs_blend_forward(const int32_t *bin_start, const int32_t *bin_end, const int
                      int tile_row_step, int tile_row_end, int bin_shift, int filter, float *image,
                      float *depth, float *acc_alpha, int32_t *last_effective, int32_t *valid_count,
                      int flags, uint32_t *debug_pixel_hits, int32_t *tile_order, int32_t *tile_work,
-                     void *stream);
+                     int32_t *walked_list, int32_t *walked_start, void *stream);
 
 /* Backward per-pixel pass.  Replaces the pixel loop of gaussian_point_rasterisation_backward
  * (RAS:531-705) WITHOUT its global atomics (RAS:674-696): the partial sums of a (Gaussian, tile) pair

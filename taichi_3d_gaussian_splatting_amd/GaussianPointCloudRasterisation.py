@@ -173,6 +173,9 @@ class GaussianPointCloudRasterisation(torch.nn.Module):
         # (same bits).  Measured slower at the headline size (0.186 vs 0.069 + 0.101 ms: the gather wants more waves in
         # flight than the per-point kernel can hold), so off by default
         self.fused_slot_reduction = False
+        # binned layouts: the backward pass walks the per-tile lists the forward pass wrote out while filtering its bin's
+        # list, instead of filtering the bin's list a second time (same entries in the same order: same bits)
+        self.backward_on_walked_lists = True
         # the forward writes a normalised quaternion back only when the stored one differs (RAS:196-205: same memory
         # contents).  True = always write: what a training iteration pays -- the optimiser has just moved q -- for
         # benchmarks that time a static scene (bench.py)
@@ -265,11 +268,17 @@ class GaussianPointCloudRasterisation(torch.nn.Module):
                     if need_state and outer.ordered_dispatch:
                         work_ = torch.empty(hip_ops.num_owned_tiles(width, height, layout), dtype=torch.int32,
                                             device=attrs_.device)
+                    # binned layouts: the forward pass writes out every tile's own list as far as it walks it, and the
+                    # backward pass runs on those plain per-tile lists (no second filtering of the bin's entries)
+                    emit = bool(need_state and outer.backward_on_walked_lists and layout.filter != 0 and
+                                layout.bin_shift <= 2 and (payload_.shape[0] << (2 * layout.bin_shift)) < 2 ** 31)
                     blended = hip_ops.blend_forward(start_, end_, payload_, attrs_, width, height, layout,
                                                     rgb_only=rgb_only, need_state=need_state,
                                                     gathered_rows=gathered_rows, ordered=outer.ordered_dispatch,
-                                                    tile_work=work_, ws=outer._scratch)
-                    return payload_, slot_offsets_, start_, blended, work_
+                                                    tile_work=work_, ws=outer._scratch, emit_walked_lists=emit)
+                    if emit:   # what the backward pass walks: (list starts, list) of the emitted per-tile lists
+                        start_, payload_, blended = blended[5], blended[6], blended[:5]
+                    return payload_, slot_offsets_, start_, blended, work_, emit
 
                 guess_key = (width, height, layout, cfg.near_plane, cfg.far_plane, cfg.depth_to_sort_key_scale)
                 # one guess per (image size, layout, planes): data sets that mix resolutions keep speculating
@@ -331,7 +340,7 @@ class GaussianPointCloudRasterisation(torch.nn.Module):
                 if not fits:
                     result = lists_and_blend(attrs, num_owned_tiles, block_sums[:nb], block_sums_full[:nb],
                                              num_overlap_tiles, n_keys, max_depth_key, None)
-                payload, slot_offsets, tile_start, (image, depth, acc_alpha, last_eff, count), tile_work = result
+                payload, slot_offsets, tile_start, (image, depth, acc_alpha, last_eff, count), tile_work, walked = result
                 if slot_offsets is not None:
                     slot_offsets = slot_offsets[:m]
                 if rgb_only:
@@ -347,6 +356,7 @@ class GaussianPointCloudRasterisation(torch.nn.Module):
                                       last_eff, num_overlap_tiles, obj, q_cp, t_cp, t_pc, attrs, intrinsics,
                                       slot_offsets, visible_mask, num_owned_tiles)
                 ctx.tile_work = tile_work
+                ctx.layout_bwd = hip_ops.walked_layout(layout) if walked else layout
                 ctx.n_slots = n_slots
                 ctx.camera_info = camera_info
                 ctx.color_max_sh_band = color_max_sh_band
@@ -373,7 +383,7 @@ class GaussianPointCloudRasterisation(torch.nn.Module):
                     # RAS:531-705  per-pixel pass: one 48-B record per (Gaussian, tile) slot, no atomics
                     partials, slot_flags, magnitude_image = hip_ops.blend_backward_partials(
                         tile_start, payload, attrs, grad_rasterized_image, acc_alpha, last_eff, slot_offsets,
-                        ctx.n_slots, width, height, ctx.layout, tile_work=ctx.tile_work, ws=outer._scratch)
+                        ctx.n_slots, width, height, ctx.layout_bwd, tile_work=ctx.tile_work, ws=outer._scratch)
                     acc = slots = None
                     if outer.grad_accumulator_reduce is None and outer.fused_slot_reduction:
                         # the slot sums are formed inside the per-point kernel and stay in registers

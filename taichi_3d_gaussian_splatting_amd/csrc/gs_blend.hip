@@ -316,7 +316,8 @@ __global__ __launch_bounds__(BLEND_THREADS) void blend_forward_kernel(
     const int32_t *__restrict__ payload, const float4 *__restrict__ attrs, int width, int height, int row_begin,
     int row_step, int bin_shift, int filter, float *__restrict__ image, float *__restrict__ depth,
     float *__restrict__ acc_alpha, int32_t *__restrict__ last_effective, int32_t *__restrict__ valid_count,
-    uint32_t *__restrict__ debug_hits, const int32_t *__restrict__ tile_order, int32_t *__restrict__ tile_work) {
+    uint32_t *__restrict__ debug_hits, const int32_t *__restrict__ tile_order, int32_t *__restrict__ tile_work,
+    int32_t *__restrict__ walked_list, int32_t *__restrict__ walked_start) {
     __shared__ float4 s_p[BATCH], s_c[BATCH], s_q[BATCH];  // rows 0, 2, 3 of the kept records
     __shared__ int s_j[BATCH];                             // their list positions (last_effective is one of them + 1)
     __shared__ int s_o[DEBUG ? BATCH : 1];
@@ -331,12 +332,23 @@ __global__ __launch_bounds__(BLEND_THREADS) void blend_forward_kernel(
     const int start = bin_start[bin], end = bin_end[bin];
     const v2f px = {(float)pu + 0.5f, (float)pu + 1.5f};
     const float py = (float)pv + 0.5f;
+    // The tile's OWN list, as far as this pass walks it.  A tile of a binned layout filters its bin's list while staging it;
+    // the entries it keeps are written out here -- tile t of bin b owns the segment [(start_b << 2 s) + t len_b, + len_b) of
+    // walked_list -- so that the backward pass walks a plain per-tile list (no filter, no compaction, no second examination
+    // of the bin's entries: it never goes beyond what the forward pass walked).  last_effective then refers to positions
+    // in walked_list and walked_start[tile] holds the segment's first position.
+    const bool emit = STAGED && STATE && walked_list != nullptr;
+    const int bin_mask = (1 << bin_shift) - 1;
+    const int wbase = emit ? (start << (2 * bin_shift)) +
+                                 ((tc.tile_u & bin_mask) + ((tc.tile_v & bin_mask) << bin_shift)) * (end - start)
+                           : start;
+    int kept_base = 0;   // entries this tile kept in earlier rounds
 
     // alive = 1 until the pixel saturates, then 0: it multiplies alpha, so a dead pixel never passes the
     // 1/255 test again and needs no separate predicate in the hot loop.
     v2f T = splat(1.0f), alive = splat(1.0f);
     v2f Cr = splat(0.f), Cg = splat(0.f), Cb = splat(0.f), D = splat(0.f), Wd = splat(0.f);
-    int last0 = start, last1 = start, cnt0 = 0, cnt1 = 0;
+    int last0 = wbase, last1 = wbase, cnt0 = 0, cnt1 = 0;
     unsigned dh0 = 0u, dh1 = 0u, dc0 = 0u, dc1 = 0u;
 
     auto keep = [&](const float4 r0, const float4 r1) {
@@ -346,6 +358,7 @@ __global__ __launch_bounds__(BLEND_THREADS) void blend_forward_kernel(
         s_p[slot] = r0; s_c[slot] = r2; s_q[slot] = r3;
         if (STAGED) s_j[slot] = j;
         if (DEBUG) s_o[slot] = o;
+        if (emit) walked_list[wbase + kept_base + slot] = o;
     };
 
     int pos = start;
@@ -420,7 +433,7 @@ __global__ __launch_bounds__(BLEND_THREADS) void blend_forward_kernel(
                 }
                 T = Tn;
                 if (STATE) {
-                    const int idx = (STAGED ? s_j[k + i] : batch_first + k + i) + 1;
+                    const int idx = (emit ? wbase + kept_base + k + i : STAGED ? s_j[k + i] : batch_first + k + i) + 1;
                     last0 = ok0 ? idx : last0;
                     last1 = ok1 ? idx : last1;
                 }
@@ -431,6 +444,7 @@ __global__ __launch_bounds__(BLEND_THREADS) void blend_forward_kernel(
                 }
             }
         }
+        kept_base += nbuf;
     }
     const size_t p = (size_t)pv * width + pu;
     float *img = image + 3 * p;
@@ -453,8 +467,9 @@ __global__ __launch_bounds__(BLEND_THREADS) void blend_forward_kernel(
             __syncthreads();          // (all waves are past their last use of s_cnt)
             if ((tid & 63) == 0) s_cnt[tid >> 6] = mx;
             __syncthreads();
-            if (tid == 0) tile_work[tc.index] = max(s_cnt[0], s_cnt[1]) - start;
+            if (tid == 0) tile_work[tc.index] = max(s_cnt[0], s_cnt[1]) - wbase;
         }
+        if (emit && tid == 0) walked_start[tc.tile_id] = wbase;
     }
     if (DEBUG) {
         debug_hits[2 * p] = dc0; debug_hits[2 * p + 1] = dh0;
@@ -1208,15 +1223,15 @@ static void launch_forward(bool debug, dim3 grid, hipStream_t s, const int32_t *
                            const int32_t *payload, const float4 *attrs, int width, int height, int rb, int rs,
                            int bin_shift, int filter, float *image, float *depth, float *acc_alpha,
                            int32_t *last_effective, int32_t *valid_count, uint32_t *debug_hits,
-                           const int32_t *tile_order, int32_t *tile_work) {
+                           const int32_t *tile_order, int32_t *tile_work, int32_t *walked_list, int32_t *walked_start) {
     if (debug)
         hipLaunchKernelGGL((blend_forward_kernel<STAGED, AUX, STATE, true>), grid, dim3(BLEND_THREADS), 0, s, bin_start,
                            bin_end, payload, attrs, width, height, rb, rs, bin_shift, filter, image, depth, acc_alpha,
-                           last_effective, valid_count, debug_hits, tile_order, tile_work);
+                           last_effective, valid_count, debug_hits, tile_order, tile_work, walked_list, walked_start);
     else
         hipLaunchKernelGGL((blend_forward_kernel<STAGED, AUX, STATE, false>), grid, dim3(BLEND_THREADS), 0, s, bin_start,
                            bin_end, payload, attrs, width, height, rb, rs, bin_shift, filter, image, depth, acc_alpha,
-                           last_effective, valid_count, debug_hits, tile_order, tile_work);
+                           last_effective, valid_count, debug_hits, tile_order, tile_work, walked_list, walked_start);
 }
 
 template <bool STAGED>
@@ -1248,7 +1263,7 @@ int gs_blend_forward(const int32_t *bin_start, const int32_t *bin_end, const int
                      int width, int height, int tile_row_begin, int tile_row_step, int tile_row_end, int bin_shift,
                      int filter, float *image, float *depth, float *acc_alpha, int32_t *last_effective,
                      int32_t *valid_count, int flags, uint32_t *debug_pixel_hits, int32_t *tile_order,
-                     int32_t *tile_work, void *stream) {
+                     int32_t *tile_work, int32_t *walked_list, int32_t *walked_start, void *stream) {
     GS_REQUIRE(width % GS_TILE_WIDTH == 0 && height % GS_TILE_HEIGHT == 0, "image size must be a multiple of 16");
     GS_REQUIRE(tile_row_step >= 1 && tile_row_begin >= 0 && tile_row_end >= 0, "tile row ownership");
     GS_REQUIRE(bin_shift >= 0 && bin_shift <= 4, "bin_shift");
@@ -1267,6 +1282,8 @@ int gs_blend_forward(const int32_t *bin_start, const int32_t *bin_end, const int
     hipStream_t s = (hipStream_t)stream;
     const bool dbg = debug_pixel_hits != nullptr;
     GS_REQUIRE(tile_work == nullptr || state, "tile_work is the backward's walk length: it needs the state outputs");
+    GS_REQUIRE((walked_list == nullptr) == (walked_start == nullptr), "walked_list and walked_start go together");
+    GS_REQUIRE(walked_list == nullptr || (staged && state), "walked lists are emitted by the filtering (binned) forward with state");
     if (tile_order != nullptr) {   // longest lists first
         hipLaunchKernelGGL(tile_order_kernel, dim3(ORDER_WGS), dim3(ORDER_THREADS), 0, s, (const int32_t *)nullptr, bin_start,
                            bin_end, tw * rows, tw, tile_row_begin, tile_row_step, bin_shift, tile_order);
@@ -1282,7 +1299,7 @@ int gs_blend_forward(const int32_t *bin_start, const int32_t *bin_end, const int
 #define GS_FWD(STAGED, AUX, STATE)                                                                                  \
     launch_forward<STAGED, AUX, STATE>(dbg, grid, s, bin_start, bin_end, payload, a4, width, height, tile_row_begin, \
                                        tile_row_step, bin_shift, filter, image, depth, acc_alpha, last_effective,   \
-                                       valid_count, debug_pixel_hits, tile_order, tile_work)
+                                       valid_count, debug_pixel_hits, tile_order, tile_work, walked_list, walked_start)
 #define GS_FWD2(STAGED)                                                                                             \
     do {                                                                                                            \
         if (aux && state) GS_FWD(STAGED, true, true);                                                               \

@@ -307,12 +307,15 @@ BLEND_ARMS = {None: 0, "two_waves": 4, "four_waves": 8, "one_wave": 16}   # GS_B
 def blend_forward(bin_start, bin_end, payload, attrs, width, height, layout: ListLayout = ListLayout(),
                   out=None, rgb_only=False, need_state=True, debug_hits=False, gathered_rows: int = 0,
                   ordered: bool = False, tile_work: Optional[torch.Tensor] = None, arm: Optional[str] = None,
-                  ws: Optional[Workspaces] = None):
+                  ws: Optional[Workspaces] = None, emit_walked_lists: bool = False):
     """-> (image, depth, acc_alpha, last_effective, count).  rgb_only: depth and count are not computed (returned
     as None); need_state=False: acc_alpha / last_effective are not computed (None) -- the inference path.
     debug_hits=True appends a uint32-as-int32 [H,W,2] tensor {blended count, hash of blended payloads} per pixel.
     ordered: tiles are dispatched longest list first (same results, shorter tail of the launch); tile_work (int32[owned
-    tiles], needs the state): receives the walk lengths the backward pass will see (blend_backward_partials)."""
+    tiles], needs the state): receives the walk lengths the backward pass will see (blend_backward_partials).
+    emit_walked_lists (binned layouts with state): appends (walked_start i32[tiles], walked_list i32[K << 2 bin_shift]) --
+    every tile's own list as far as it was walked; last_effective then refers to positions in walked_list and the
+    backward pass is run on (walked_start, walked_list) with ``walked_layout(layout)``."""
     dev = bin_start.device
     flags = (BLEND_RGB_ONLY if rgb_only else 0) | (0 if need_state else BLEND_NO_STATE) | BLEND_ARMS[arm]
     if out is None:
@@ -335,10 +338,26 @@ def blend_forward(bin_start, bin_end, payload, attrs, width, height, layout: Lis
     image, depth, acc_alpha, last_eff, count = out
     dbg = torch.zeros((height, width, 2), dtype=torch.int32, device=dev) if debug_hits else None
     order = _scratch(ws, "order_fwd", num_owned_tiles(width, height, layout), torch.int32, dev) if ordered else None
+    walked_list = walked_start = None
+    if emit_walked_lists:
+        if not (need_state and layout.filter != 0 and (payload.shape[0] << (2 * layout.bin_shift)) < 2 ** 31):
+            raise ValueError("walked lists: binned layout with state, and K << 2 bin_shift must fit int32")
+        walked_list = torch.empty(max(payload.shape[0], 1) << (2 * layout.bin_shift), dtype=torch.int32, device=dev)
+        walked_start = torch.empty((width // TILE_WIDTH) * (height // TILE_HEIGHT), dtype=torch.int32, device=dev)
     call("gs_blend_forward", ptr(bin_start), ptr(bin_end), ptr(payload), ptr(attrs), int(width), int(height),
          layout.row_begin, layout.row_step, layout.row_end, layout.bin_shift, layout.filter, ptr(image), ptr(depth),
-         ptr(acc_alpha), ptr(last_eff), ptr(count), flags, ptr(dbg), ptr(order), ptr(tile_work), current_stream(dev))
+         ptr(acc_alpha), ptr(last_eff), ptr(count), flags, ptr(dbg), ptr(order), ptr(tile_work), ptr(walked_list),
+         ptr(walked_start), current_stream(dev))
+    if emit_walked_lists:
+        out = out + (walked_start, walked_list)
     return out + (dbg,) if debug_hits else out
+
+
+def walked_layout(layout: ListLayout) -> ListLayout:
+    """The layout under which the backward pass walks the per-tile lists a binned forward pass emitted: plain per-tile
+    lists, same tile-row ownership."""
+    return ListLayout(bin_shift=0, exact_cull=False, row_begin=layout.row_begin, row_step=layout.row_step,
+                      row_end=layout.row_end)
 
 
 def num_owned_tiles(width: int, height: int, layout: ListLayout) -> int:

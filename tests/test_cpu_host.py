@@ -41,10 +41,10 @@ def test_argument_validation_without_gpu(lib):
     assert l.gs_pose_inverse(None, None, None, None, 0, None) == -1
     assert b"n_obj" in l.gs_last_error()
     assert l.gs_sort_pairs(None, None, None, None, 10, None, 0, 70, 3, 0, None, None) == -1
-    assert l.gs_blend_forward(None, None, None, None, 100, 64, 0, 1, 4, 2, 3, None, None, None, None, None, 0, None, None, None, None) == -1
+    assert l.gs_blend_forward(None, None, None, None, 100, 64, 0, 1, 4, 2, 3, None, None, None, None, None, 0, None, None, None, None, None, None) == -1
     assert b"multiple of 16" in l.gs_last_error()
     # lists that cover several tiles (bins) cannot be blended without the tile-box filter
-    assert l.gs_blend_forward(None, None, None, None, 128, 64, 0, 1, 4, 2, 0, None, None, None, None, None, 0, None, None, None, None) == -1
+    assert l.gs_blend_forward(None, None, None, None, 128, 64, 0, 1, 4, 2, 0, None, None, None, None, None, 0, None, None, None, None, None, None) == -1
     assert b"box filter" in l.gs_last_error()
     assert l.gs_sort_pairs(None, None, None, None, 1, None, 0, 17, 13, 0, None, None) == 0  # n <= 1: nothing to do
     assert l.gs_sort_pairs(None, None, None, None, 10, None, 25, 25, 13, 0, None, None) == -1  # 25+13 bits > 32

@@ -836,6 +836,54 @@ def test_operator_options_that_must_not_change_a_bit(scene):
         assert torch.equal(got[4].detach(), ref[4].detach()), attr     # the caller's features after the in-place normalisation
 
 
+def test_backward_on_walked_lists_is_bit_identical(ops):
+    """Binned layouts: the forward pass writes out every tile's own list as far as it walks it and the backward pass runs on
+    those per-tile lists.  Same entries in the same order through the same arithmetic: gradients, hook fields and the
+    magnitude image equal the ones of the backward pass that filters the bin lists again, bit for bit (2,500 tiles: both
+    run the two-wave kernels), for 2x2- and 4x4-tile bins; and the emitted lists are the tiles' lists of the per-tile
+    layout, truncated where the forward pass stopped."""
+    from taichi_3d_gaussian_splatting_amd import GaussianPointCloudRasterisation as Op
+    from taichi_3d_gaussian_splatting_amd.synthetic import make_config_scene, make_grad_image
+    s = make_config_scene("cfg2_100k_800")
+    g = make_grad_image(s.height, s.width)
+    cfg = Op.GaussianPointCloudRasterisationConfig(near_plane=s.near_plane, far_plane=s.far_plane,
+                                                   depth_to_sort_key_scale=s.depth_to_sort_key_scale)
+    for bin_shift in (1, 2):
+        res = {}
+        for walked in (True, False):
+            got = {}
+            op = Op(cfg, backward_valid_point_hook=lambda h: got.__setitem__("h", h))
+            op.bin_shift, op.backward_on_walked_lists = bin_shift, walked
+            out = _run_operator(s, g, op=op)
+            res[walked] = (out, got["h"])
+        (a, ha), (b, hb) = res[True], res[False]
+        for i in range(3):
+            assert torch.equal(a[i], b[i])
+        assert torch.equal(a[3].grad.view(torch.int32), b[3].grad.view(torch.int32)), bin_shift
+        assert torch.equal(a[4].grad.view(torch.int32), b[4].grad.view(torch.int32)), bin_shift
+        assert torch.equal(ha.magnitude_grad_viewspace_on_image, hb.magnitude_grad_viewspace_on_image)
+        assert torch.equal(ha.num_affected_pixels, hb.num_affected_pixels)
+    # the emitted lists themselves, against the per-tile layout's sorted lists
+    d = s.to("cuda")
+    tile = _stages_to_ranges(ops, d, ops.ListLayout(bin_shift=0))
+    binned = _stages_to_ranges(ops, d, ops.ListLayout(bin_shift=1))
+    ft = ops.blend_forward(tile["start"], tile["end"], tile["payload"], tile["attrs"], d.width, d.height, tile["layout"],
+                           arm="two_waves")
+    fb = ops.blend_forward(binned["start"], binned["end"], binned["payload"], binned["attrs"], d.width, d.height,
+                           binned["layout"], emit_walked_lists=True)
+    walked_start, walked_list = fb[5], fb[6]
+    for i in (0, 1, 2, 4):
+        assert torch.equal(fb[i], ft[i])
+    tw = d.width // 16
+    reach_t = (ft[3].view(d.height // 16, 16, tw, 16).amax(dim=(1, 3)).flatten() - tile["start"]).cpu()
+    reach_b = (fb[3].view(d.height // 16, 16, tw, 16).amax(dim=(1, 3)).flatten() - walked_start).cpu()
+    assert torch.equal(reach_t, reach_b)      # last blended entry at the same position of the tile's list
+    ts, ws_, pl, wl = tile["start"].cpu(), walked_start.cpu(), tile["payload"].cpu(), walked_list.cpu()
+    for t in torch.randperm(ts.shape[0], generator=torch.Generator().manual_seed(0))[:200].tolist():
+        n = int(reach_t[t])
+        assert torch.equal(pl[ts[t]:ts[t] + n], wl[ws_[t]:ws_[t] + n]), t
+
+
 def test_rgb_only_and_inference_paths(ops, scene):
     """rgb_only (RAS:464-469,478-484) and the no-gradient path: the image is bit-identical to the full forward; depth and
     count are zeros under rgb_only; gradients under rgb_only equal those of the default configuration."""

@@ -70,6 +70,14 @@ for _ in range(reps + 2):
             start, payload, attrs, g, acc_alpha, last_eff, slot_off, n_slots, s.width, s.height, LAYOUT, tile_order=order))
         partials3, flags3, mag3 = timed("blend_backward_ordered", lambda: hip_ops.blend_backward_partials(
             start, payload, attrs, g, acc_alpha, last_eff, slot_off, n_slots, s.width, s.height, LAYOUT, tile_work=tile_work))
+        if LAYOUT.filter != 0:   # the operator's path on binned layouts: forward emits the walked per-tile lists
+            work_w = torch.empty_like(tile_work)
+            out_w = timed("blend_forward_ordered_emitting", lambda: hip_ops.blend_forward(
+                start, end, payload, attrs, s.width, s.height, LAYOUT, ordered=True, tile_work=work_w, emit_walked_lists=True))
+            partials4, flags4, mag4 = timed("blend_backward_ordered_walked", lambda: hip_ops.blend_backward_partials(
+                out_w[5], out_w[6], attrs, g, out_w[2], out_w[3], slot_off, n_slots, s.width, s.height,
+                hip_ops.walked_layout(LAYOUT), tile_work=work_w))
+            walked_same = bool(torch.equal(partials4[flags4.bool()], partials[flags.bool()]) and torch.equal(mag4, mag))
     acc = timed("reduce_partials", lambda: hip_ops.reduce_partials(slot_off, ntiles, flags, partials))
     unfused = timed("point_backward", lambda: hip_ops.point_backward(
         s.point_cloud, feat, s.point_object_id, s.camera_intrinsics, q_cp, t_cp, s.t_pointcloud_camera, ids, acc, attrs, 3,
@@ -121,6 +129,7 @@ if ORDERED:
           f"; library-ordered arms identical: backward "
           f"{bool(torch.equal(partials3[flags3.bool()], partials[flags.bool()]) and torch.equal(mag3, mag))}, forward "
           f"{all(torch.equal(a, b) for a, b in zip(out_o, (image, depth, acc_alpha, last_eff, count)))}; "
-          f"tile_work == walked: {bool(torch.equal(tile_work.long(), walked.long()))}")
+          f"tile_work == walked: {bool(torch.equal(tile_work.long(), walked.long()))}"
+          + (f"; backward on walked lists identical: {walked_same}" if LAYOUT.filter != 0 else ""))
 print(f"  bin list mean={lens.mean():.1f} max={lens.max():.0f}; list positions walked per tile (to max last) "
       f"mean={walked.mean():.1f} max={walked.max():.0f}; blended per pixel mean={count.float().mean():.2f}")
