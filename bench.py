@@ -318,7 +318,10 @@ def main() -> None:
             traffic, valu_instr = profiled_counters(dominant)
         # the HBM-class stage (streaming / sort / scan: everything but the two VALU-bound blend kernels) furthest from
         # its bound, among the stages that take at least 2 % of the step
-        hbm_class = [k_ for k_ in timed_stages if k_ not in ("blend_forward", "blend_backward")
+        # (filter_compact and scan_block_sums are left out: in this stage-by-stage profile their times contain a blocking
+        # size read-back that the operator's speculative launches do not have)
+        hbm_class = [k_ for k_ in timed_stages
+                     if k_ not in ("blend_forward", "blend_backward", "filter_compact", "scan_block_sums")
                      and stages_ms[k_] >= 0.02 * ms_per_step]
         worst = min(hbm_class, key=lambda k_: bytes_per[k_] / stages_ms[k_]) if hbm_class else None
         worst_traffic = profiled_counters({"sort_pairs": "sort_scatter"}.get(worst, worst))[0] \

@@ -959,6 +959,46 @@ def test_speculative_sizes_overflow_is_redone(scene):
     assert len(op2._size_guesses) == 2 and op2.speculation_stats == {"frames": 6, "redone": 0}
 
 
+def test_speculative_depth_overflow_cannot_write_outside_the_ranges(ops):
+    """a speculative frame builds 32-bit keys with the PREVIOUS frame's depth width.  When this frame's
+    quantised depths need more bits, the excess used to spill into the bin field, and with a bin count that is not a power
+    of two `tile_ranges` wrote up to ~600 bytes past its arrays before the host noticed the overflow and redid the frame.
+    Now the depth field is masked and `tile_ranges` checks bin ids: keys of such a frame stay inside the bin range and a
+    guard region behind the ranges stays untouched."""
+    from taichi_3d_gaussian_splatting_amd import _lib
+    s = small_scene(n=3000, size=240, seed=4)          # 15 x 15 = 225 tiles: not a power of two
+    s.point_cloud[:, 2] += 40.0                        # quantised depths ~4300: 13 bits
+    d = s.to("cuda")
+    layout = ops.ListLayout(bin_shift=0)
+    q_cp, t_cp = ops.pose_inverse(d.q_pointcloud_camera, d.t_pointcloud_camera)
+    mask, ids, counters = ops.filter_compact(d.point_cloud, d.point_invalid_mask, d.point_object_id, d.camera_intrinsics,
+                                             q_cp, t_cp, d.near_plane, d.far_plane, d.width, d.height)
+    attrs, ntiles, nowned, bsums, bsums_full = ops.preprocess(
+        d.point_cloud, d.point_cloud_features.clone(), d.point_object_id, d.camera_intrinsics, q_cp, t_cp, ids, d.width,
+        d.height, layout, depth_to_sort_key_scale=d.depth_to_sort_key_scale, counters=counters)
+    k, n_slots, max_dq, _ = ops.scan_block_sums(bsums, counters, bsums_full)
+    num_bins = layout.num_bins(d.width, d.height)
+    assert num_bins == 225 and max_dq >= 8 * 400       # an 8x deeper range than the width the keys are built with
+    stale_kdb = 9                                       # what a frame with depths ~400 would have left behind
+    keys, payload, _ = ops.make_keys(attrs, nowned, bsums, k, d.width, d.height, d.depth_to_sort_key_scale, layout,
+                                     key_depth_bits=stale_kdb, num_overlap_tiles=ntiles, block_offsets_full=bsums_full)
+    assert k > 0 and int((keys.view(torch.int32).long() & 0xffffffff).max() >> stale_kdb) < num_bins
+    ops.sort_pairs(keys, payload, stale_kdb, 8, stale_kdb)
+    guard = 256
+    buf = torch.full((2 * num_bins + guard,), -12345, dtype=torch.int32, device="cuda")
+    _lib.call("gs_tile_ranges", _lib.ptr(keys), k, None, stale_kdb, _lib.ptr(buf[:num_bins]),
+              _lib.ptr(buf[num_bins:2 * num_bins]), num_bins, _lib.current_stream(buf.device))
+    torch.cuda.synchronize()
+    assert bool((buf[2 * num_bins:] == -12345).all()), "tile_ranges wrote behind its arrays"
+    # and a hand-made key with a bin id outside the range is ignored, not written
+    bad = torch.tensor([(3 << stale_kdb) | 5, (300 << stale_kdb) | 1, (301 << stale_kdb) | 1], dtype=torch.int32, device="cuda")
+    buf.fill_(-12345)
+    _lib.call("gs_tile_ranges", _lib.ptr(bad), 3, None, stale_kdb, _lib.ptr(buf[:num_bins]),
+              _lib.ptr(buf[num_bins:2 * num_bins]), num_bins, _lib.current_stream(buf.device))
+    torch.cuda.synchronize()
+    assert bool((buf[2 * num_bins:] == -12345).all()) and int(buf[num_bins + 3]) == 1
+
+
 def test_hook_feature_gradients_can_be_switched_off(scene):
     from taichi_3d_gaussian_splatting_amd import GaussianPointCloudRasterisation as Op
     from taichi_3d_gaussian_splatting_amd.synthetic import make_grad_image
