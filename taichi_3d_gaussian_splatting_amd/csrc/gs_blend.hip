@@ -7,15 +7,21 @@
 // (16-B gathers) in LDS per blend round -- the sequence a tile blends is exactly the reference's per-tile list.
 //  forward : front-to-back blend (RAS:318-485, weight UTL:275-284); 2 waves per tile, two pixels per lane
 //            on packed fp32 math; whole-tile early exit with a workgroup vote (the reference could not
-//            express it, RAS:387-394).
+//            express it, RAS:387-394).  With a binned layout it also writes out the entries each tile keeps
+//            (walked_list): the backward pass then walks plain per-tile lists and never filters a bin list again.
 //  backward: back-to-front traversal (RAS:531-705, gradients UTL:331-348) starting at the tile's last
 //            effective entry; 2 waves per tile, two pixels per lane; alpha is evaluated by the SAME expression as in
 //            the forward kernel (gs_pair_alpha below), so the hit test alpha >= 1/255 decides identically in both
 //            passes; the per-Gaussian partial sums (ten gradients + the pixel count) are reduced across the 64 lanes
-//            by a permlane-swap + DPP reduce-scatter, combined across the two waves in LDS (ds_add_f32), and stored
+//            by a permlane-swap + DPP reduce-scatter (one hit entry at a time, or two sharing one reduce-scatter in
+//            the kernel that still filters bin lists), combined across the two waves in LDS (ds_add_f32), and stored
 //            once per (tile, Gaussian) into that pair's private slot -- no global atomics at all (the reference issues
 //            eleven per (pixel, Gaussian), RAS:674-696); the slots of a Gaussian are summed in a fixed order by
 //            reduce_partials_kernel, so gradients are bitwise reproducible.
+//  order   : tiles are handed to the hardware longest list / longest backward walk first (tile_order_kernel), which
+//            removes the tail of half-empty CUs of a launch in image order.
+//  small   : grids of at most 1,280 tiles run both passes with FOUR waves per tile and one pixel per lane
+//            (blend_*_small_kernel): same per-pixel arithmetic, half the issue slots per wave and entry.
 #include "gs_common.h"
 #include "gs_slots.h"
 
@@ -778,7 +784,11 @@ __global__ __launch_bounds__(BLEND_THREADS, GS_BWD_MIN_WAVES) void blend_backwar
 // instructions are per-component), so image, depth, counts, state and hit decisions are bit-identical; the backward's slot
 // sums add the same per-pixel terms in another order (four waves of 64 pixels instead of two of 128).
 constexpr int SMALL_THREADS = 256;
-constexpr int GS_SMALL_GRID_TILES = 1024;   // at most this many owned tiles: four waves per tile (4 x the 256 CUs)
+#ifndef GS_SMALL_GRID_TILES
+#define GS_SMALL_GRID_TILES 1280   // at most this many owned tiles (5 x the 256 CUs): four waves per tile.  Measured at 256
+                                   // tiles (-21 %) and at the 1,080 tiles of one of eight bands of a 1920 x 1072 frame (-3 %);
+                                   // +19 % at 8,040 tiles
+#endif
 
 __device__ __forceinline__ float gs_pixel_alpha(const float4 p, const float4 q, float px, float py, float &dx, float &dy) {
     // gs_pair_alpha for one pixel: the same operations (the packed form computes each component exactly like this)

@@ -4,7 +4,7 @@
 //
 // Only the bits that can differ are sorted: the quantised-depth field [0, depth_bits) and the
 // tile field [32, 32+tile_bits); 8-bit digits.  Per pass:
-//   1. digit histogram per workgroup (SORT_ITEMS keys each)       -> counts[digit][block]
+//   1. digit histogram per workgroup (GS_BLOCK x rounds keys each) -> counts[digit][block]
 //   2. exclusive scan of every digit row + digit totals            (256 workgroups)
 //   3. stable scatter: wave-level digit matching with ballots (64-lane match-any), per-wave running digit
 //      counters in LDS, block-local permutation in LDS, coalesced write-out of each digit's run.
@@ -18,19 +18,34 @@ constexpr int RADIX = 1 << RADIX_BITS;
 #ifndef GS_SORT_ROUNDS
 #define GS_SORT_ROUNDS 16   // (tuning variants: tools/build_variants.sh)
 #endif
-constexpr int SORT_ROUNDS = GS_SORT_ROUNDS;
-constexpr int SORT_ITEMS = GS_BLOCK * SORT_ROUNDS;  // keys per workgroup
+#ifndef GS_SORT_SMALL_ROUNDS
+#define GS_SORT_SMALL_ROUNDS 4   // rounds per wave when the large workgroups would not fill the chip (see sort_rounds_for)
+#endif
+#ifndef GS_SORT_SMALL_BLOCKS
+#define GS_SORT_SMALL_BLOCKS 512   // fewer large workgroups than this: sort with the small ones
+#endif
 constexpr int WAVES = GS_BLOCK / GS_WAVE;
+
+// Keys per workgroup = GS_BLOCK x rounds.  16 rounds amortise the per-workgroup prefix work best, but a workgroup ranks its
+// rounds one after the other (a dependent chain of ballots and LDS counter updates): with few keys -- small frames, a
+// GPU's band of a sharded frame -- 4,096-key workgroups leave most of the 256 CUs idle and the launch lasts as long as
+// one workgroup's chain (17 us for 360k keys where 2.9M keys take 23).  Below GS_SORT_SMALL_BLOCKS large workgroups the
+// sort runs with a quarter of the chain per workgroup and four times the workgroups.
+static int sort_rounds_for(int64_t n_keys) {
+    return gs_div_up(n_keys > 0 ? n_keys : 1, GS_BLOCK * GS_SORT_ROUNDS) < GS_SORT_SMALL_BLOCKS ? GS_SORT_SMALL_ROUNDS
+                                                                                               : GS_SORT_ROUNDS;
+}
 
 template <typename KeyT>
 __device__ __forceinline__ unsigned digit_of(KeyT key, int shift, KeyT flip) {
     return (unsigned)(((key ^ flip) >> shift) & (RADIX - 1));
 }
 
-template <typename KeyT>
+template <typename KeyT, int SORT_ROUNDS>
 __global__ __launch_bounds__(GS_BLOCK) void sort_hist_kernel(const KeyT *__restrict__ keys, long long n,
                                                             const int32_t *__restrict__ n_device, int shift,
                                                             KeyT flip, int nblk, int32_t *__restrict__ counts) {
+    constexpr int SORT_ITEMS = GS_BLOCK * SORT_ROUNDS;
     __shared__ int hist[WAVES][RADIX];
     if (n_device) n = min((long long)*n_device, n);   // grid and workspace are sized by the capacity n   // one histogram per wave: a quarter of the same-address LDS atomics
 #pragma unroll
@@ -75,11 +90,12 @@ __global__ __launch_bounds__(GS_BLOCK) void sort_scan_rows_kernel(int32_t *__res
 //   3. keys and payloads are permuted into digit order IN LDS, then written out with consecutive threads writing
 //      consecutive addresses of a digit's run.  (Scattering straight from registers wrote 4-byte pieces all over
 //      the output: rocprofv3 showed 2.8x the algorithmic HBM write bytes.)
-template <typename KeyT>
+template <typename KeyT, int SORT_ROUNDS>
 __global__ __launch_bounds__(GS_BLOCK) void sort_scatter_kernel(
     const KeyT *__restrict__ keys_in, const int32_t *__restrict__ payload_in, long long n,
     const int32_t *__restrict__ n_device, int shift, KeyT flip, int nblk, const int32_t *__restrict__ row_offsets,
     const int32_t *__restrict__ totals, KeyT *__restrict__ keys_out, int32_t *__restrict__ payload_out) {
+    constexpr int SORT_ITEMS = GS_BLOCK * SORT_ROUNDS;
     if (n_device) n = min((long long)*n_device, n);
     __shared__ int s_cnt[WAVES][RADIX];   // running per-wave digit counts, later exclusive prefix over waves
     __shared__ int s_local[RADIX];        // block-local start of each digit's run
@@ -157,23 +173,23 @@ __global__ __launch_bounds__(GS_BLOCK) void sort_scatter_kernel(
 
 }  // namespace
 
-template <typename KeyT>
-static int sort_pairs_impl(KeyT *keys, int32_t *payload, KeyT *keys_alt, int32_t *payload_alt, int64_t n_keys,
-                           const int32_t *n_dev, const int *shifts, int n_pass, KeyT flip, int allow_result_in_alt,
-                           void *workspace, hipStream_t s) {
-    const int nblk = gs_div_up(n_keys, SORT_ITEMS);
+template <typename KeyT, int SORT_ROUNDS>
+static int sort_passes(KeyT *keys, int32_t *payload, KeyT *keys_alt, int32_t *payload_alt, int64_t n_keys,
+                       const int32_t *n_dev, const int *shifts, int n_pass, KeyT flip, int allow_result_in_alt,
+                       void *workspace, hipStream_t s) {
+    const int nblk = gs_div_up(n_keys, GS_BLOCK * SORT_ROUNDS);
     int32_t *counts = (int32_t *)workspace;
     int32_t *totals = counts + (size_t)RADIX * nblk;
     KeyT *kin = keys, *kout = keys_alt;
     int32_t *pin = payload, *pout = payload_alt;
     for (int p = 0; p < n_pass; ++p) {
-        hipLaunchKernelGGL(sort_hist_kernel<KeyT>, dim3(nblk), dim3(GS_BLOCK), 0, s, kin, (long long)n_keys, n_dev,
-                           shifts[p], flip, nblk, counts);
+        hipLaunchKernelGGL((sort_hist_kernel<KeyT, SORT_ROUNDS>), dim3(nblk), dim3(GS_BLOCK), 0, s, kin, (long long)n_keys,
+                           n_dev, shifts[p], flip, nblk, counts);
         GS_CHECK_LAUNCH();
         hipLaunchKernelGGL(sort_scan_rows_kernel, dim3(RADIX), dim3(GS_BLOCK), 0, s, counts, nblk, totals);
         GS_CHECK_LAUNCH();
-        hipLaunchKernelGGL(sort_scatter_kernel<KeyT>, dim3(nblk), dim3(GS_BLOCK), 0, s, kin, pin, (long long)n_keys,
-                           n_dev, shifts[p], flip, nblk, counts, totals, kout, pout);
+        hipLaunchKernelGGL((sort_scatter_kernel<KeyT, SORT_ROUNDS>), dim3(nblk), dim3(GS_BLOCK), 0, s, kin, pin,
+                           (long long)n_keys, n_dev, shifts[p], flip, nblk, counts, totals, kout, pout);
         GS_CHECK_LAUNCH();
         KeyT *tk = kin; kin = kout; kout = tk;
         int32_t *tp = pin; pin = pout; pout = tp;
@@ -186,10 +202,22 @@ static int sort_pairs_impl(KeyT *keys, int32_t *payload, KeyT *keys_alt, int32_t
     return 0;
 }
 
+template <typename KeyT>
+static int sort_pairs_impl(KeyT *keys, int32_t *payload, KeyT *keys_alt, int32_t *payload_alt, int64_t n_keys,
+                           const int32_t *n_dev, const int *shifts, int n_pass, KeyT flip, int allow_result_in_alt,
+                           void *workspace, hipStream_t s) {
+    // (n_keys is the capacity when the count lives on the device: the choice follows the capacity, as the grids do)
+    if (sort_rounds_for(n_keys) == GS_SORT_SMALL_ROUNDS)
+        return sort_passes<KeyT, GS_SORT_SMALL_ROUNDS>(keys, payload, keys_alt, payload_alt, n_keys, n_dev, shifts, n_pass,
+                                                       flip, allow_result_in_alt, workspace, s);
+    return sort_passes<KeyT, GS_SORT_ROUNDS>(keys, payload, keys_alt, payload_alt, n_keys, n_dev, shifts, n_pass, flip,
+                                             allow_result_in_alt, workspace, s);
+}
+
 extern "C" {
 
 size_t gs_sort_workspace_bytes(int64_t n_keys) {
-    const size_t nblk = (size_t)gs_div_up(n_keys > 0 ? n_keys : 1, SORT_ITEMS);
+    const size_t nblk = (size_t)gs_div_up(n_keys > 0 ? n_keys : 1, GS_BLOCK * sort_rounds_for(n_keys));
     return sizeof(int32_t) * (RADIX * nblk + RADIX + 64);
 }
 

@@ -29,6 +29,10 @@ done
 for bs in 1 0; do GS_BIN_SHIFT=$bs GS_TILE_ORDER=1 GS_ARMS=1 GS_AB=1 python tools/stage_bench.py headline_1m_1080p 30; done > $OUT/stage_headline.log 2>&1
 for m in bands interleaved; do GS_SHARD_MODE=$m python tools/shard_bench.py headline_1m_1080p; done > $OUT/shard_headline.log 2>&1
 python tools/shard_bench.py cfg4_2m_1080p > $OUT/shard_cfg4.log 2>&1
+# kernel trace of the middle rank of eight (what a rank's time is made of)
+(cd /tmp && export TMPDIR=/tmp && cd $ROOT && GS_SHARD_WORLDS=8 rocprofv3 --kernel-trace --stats -d $OUT/shard_g8_prof -o g8 --output-format csv -- \
+    python tools/shard_bench.py headline_1m_1080p) > $OUT/shard_g8_trace.log 2>&1
+cp $OUT/shard_g8_prof/g8_kernel_stats.csv $OUT/shard_g8_kernel_stats.csv 2>/dev/null
 python tools/host_profile.py cfg1_10k_256 300 > $OUT/host_profile_cfg1.log 2>&1
 # 4. multi-rank bench plumbing on this one GPU (gloo transport)
 GS_BENCH_DIST_BACKEND=gloo python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 \

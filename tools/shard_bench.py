@@ -9,6 +9,8 @@ WORLDS = tuple(int(x) for x in os.environ.get("GS_SHARD_WORLDS", "1,2,4,8").spli
 for G in WORLDS:
     op = Op(Op.GaussianPointCloudRasterisationConfig())
     op.shard = (G // 2 if RANK < 0 else min(RANK, G - 1), G, MODE)
+    if G > 1:   # as under torch.distributed: outputs allocated for an in-place gather, other ranks' rows not zero-filled
+        op.image_gather = lambda tensors: None
     if os.environ.get("GS_BIN_SHIFT"):
         op.bin_shift = int(os.environ["GS_BIN_SHIFT"])
     xyz = s.point_cloud.clone().requires_grad_(True); feat = s.point_cloud_features.clone().requires_grad_(True)
