@@ -250,7 +250,7 @@ int gs_reduce_partials(const int32_t *slot_offsets, const int32_t *num_overlap_t
  * gs_compact_rows: the rows of acc this GPU produced (num_keys[i] > 0: it emitted a sort key for Gaussian i) as an
  *   ascending list -- ids int32[capacity], rows float[capacity][12]; *count = number of produced rows (entries past
  *   `capacity` are dropped, the caller compares).  workspace: gs_compact_rows_workspace_bytes(n_visible).
- * gs_merge_rows: `world` such lists, gathered from all ranks into one buffer -- list g starts at word g * list_stride_words
+ * gs_merge_rows: `world` (<= 128) such lists, gathered from all ranks into one buffer -- list g starts at word g * list_stride_words
  *   and holds `capacity` ids followed by `capacity` rows (capacity % 4 == 0) with counts[g] valid entries -- are summed
  *   into the dense acc float[n_visible][12] (rows no list mentions: zeros): the lists are added in rank order, the same
  *   additions in the same order on every rank, so replicated gradients stay bit-identical across ranks. */

@@ -91,36 +91,59 @@ __device__ __forceinline__ int lower_bound(const int32_t *__restrict__ a, int n,
 }
 
 constexpr int MERGE_IDS = GS_BLOCK;   // row ids owned by one workgroup
-// lists: world blocks of `stride` 32-bit words each: [capacity] ids, then [capacity][12] rows; counts[g] = valid entries
+constexpr int MERGE_MAX_WORLD = GS_BLOCK / 2;   // one thread per (list, span end) in the search phase
+constexpr int MERGE_LISTS_IN_FLIGHT = 4;        // lists whose rows a thread holds in registers at a time
+// lists: world blocks of `stride` 32-bit words each: [capacity] ids, then [capacity][12] rows; counts[g] = valid entries.
+// A workgroup first finds its span in ALL lists at once (2 x world threads, one binary search each: one chain of ~log2(n)
+// dependent loads per workgroup instead of one per list -- with the searches inside the list loop the launch took 99 us at
+// G = 8, M = 1e6, four times what its 120 MB of traffic cost), then adds the lists in rank order, the rows of four lists in
+// flight at a time.
 __global__ __launch_bounds__(GS_BLOCK) void rows_merge_kernel(const int32_t *__restrict__ lists, long long stride,
                                                             int capacity, const int32_t *__restrict__ counts, int world,
                                                             int m, float4 *__restrict__ acc) {
     __shared__ float s_acc[MERGE_IDS][GS_ACC_STRIDE + 1];   // (+1: rows on different banks)
     __shared__ int s_npix[MERGE_IDS];
-    __shared__ int s_span[2];
+    __shared__ int s_span[2 * MERGE_MAX_WORLD];
     const int lo_id = blockIdx.x * MERGE_IDS, hi_id = min(lo_id + MERGE_IDS, m);
 #pragma unroll
     for (int k = 0; k < GS_ACC_STRIDE; ++k) s_acc[threadIdx.x][k] = 0.f;
     s_npix[threadIdx.x] = 0;
-    for (int g = 0; g < world; ++g) {   // rank order: the same additions in the same order on every rank
-        const int32_t *ids = lists + (size_t)g * stride;
-        const float4 *rows = reinterpret_cast<const float4 *>(ids + capacity);
-        const int n = min(counts[g], capacity);
-        __syncthreads();                // previous list fully added; s_span free
-        if (threadIdx.x < 2) s_span[threadIdx.x] = lower_bound(ids, n, threadIdx.x == 0 ? lo_id : hi_id);
-        __syncthreads();
-        const int first = s_span[0], cnt = s_span[1] - first;   // <= MERGE_IDS: ids are distinct within a list
-        if ((int)threadIdx.x < cnt) {
-            const int j = first + threadIdx.x, r = ids[j] - lo_id;
-            const float4 a = rows[3 * (size_t)j], b = rows[3 * (size_t)j + 1], c = rows[3 * (size_t)j + 2];
-            float *d = s_acc[r];        // one thread per row of this list: no two threads touch the same row
-            d[0] += a.x; d[1] += a.y; d[2] += a.z; d[3] += a.w;
-            d[4] += b.x; d[5] += b.y; d[6] += b.z; d[7] += b.w;
-            d[8] += c.x; d[9] += c.y;
-            s_npix[r] += __builtin_bit_cast(int, c.z);   // pixel count: int32 bits, summed as an integer
-        }
+    if ((int)threadIdx.x < 2 * world) {
+        const int g = threadIdx.x >> 1;
+        s_span[threadIdx.x] = lower_bound(lists + (size_t)g * stride, min(counts[g], capacity),
+                                          (threadIdx.x & 1) ? hi_id : lo_id);
     }
     __syncthreads();
+    for (int g0 = 0; g0 < world; g0 += MERGE_LISTS_IN_FLIGHT) {
+        int row[MERGE_LISTS_IN_FLIGHT];
+        float4 a[MERGE_LISTS_IN_FLIGHT], b[MERGE_LISTS_IN_FLIGHT], c[MERGE_LISTS_IN_FLIGHT];
+#pragma unroll
+        for (int k = 0; k < MERGE_LISTS_IN_FLIGHT; ++k) {
+            const int g = g0 + k;
+            row[k] = -1;
+            if (g < world) {
+                const int32_t *ids = lists + (size_t)g * stride;
+                const float4 *rows = reinterpret_cast<const float4 *>(ids + capacity);
+                const int first = s_span[2 * g], cnt = s_span[2 * g + 1] - first;   // <= MERGE_IDS: ids are distinct within a list
+                if ((int)threadIdx.x < cnt) {
+                    const int j = first + threadIdx.x;
+                    row[k] = ids[j] - lo_id;
+                    a[k] = rows[3 * (size_t)j]; b[k] = rows[3 * (size_t)j + 1]; c[k] = rows[3 * (size_t)j + 2];
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < MERGE_LISTS_IN_FLIGHT; ++k) {   // rank order: the same additions in the same order on every rank
+            if (row[k] >= 0) {
+                float *d = s_acc[row[k]];   // one thread per row of this list: no two threads touch the same row
+                d[0] += a[k].x; d[1] += a[k].y; d[2] += a[k].z; d[3] += a[k].w;
+                d[4] += b[k].x; d[5] += b[k].y; d[6] += b[k].z; d[7] += b[k].w;
+                d[8] += c[k].x; d[9] += c[k].y;
+                s_npix[row[k]] += __builtin_bit_cast(int, c[k].z);   // pixel count: int32 bits, summed as an integer
+            }
+            __syncthreads();                // this list fully added before another thread adds the next one into the same rows
+        }
+    }
     const int i = lo_id + threadIdx.x;
     if (i < hi_id) {
         const float *d = s_acc[threadIdx.x];
@@ -159,7 +182,7 @@ int gs_compact_rows(const float *acc, const int32_t *num_keys, int n_visible, in
 
 int gs_merge_rows(const int32_t *lists, int64_t list_stride_words, int capacity, const int32_t *counts, int world,
                   int n_visible, float *acc, void *stream) {
-    GS_REQUIRE(world >= 1 && n_visible >= 0 && capacity >= 0, "sizes");
+    GS_REQUIRE(world >= 1 && world <= MERGE_MAX_WORLD && n_visible >= 0 && capacity >= 0, "sizes (world <= 128)");
     GS_REQUIRE(list_stride_words >= 13LL * capacity && capacity % 4 == 0,
                "a list holds `capacity` ids followed by `capacity` 48-B rows; capacity must be a multiple of 4 (16-B rows)");
     if (n_visible == 0) return 0;

@@ -27,8 +27,8 @@ for w in headline_1m_1080p cfg3_400k_1080p stress_t_ras; do
 done
 # 3. per-stage times and per-rank shard times (one GPU, no collectives)
 for bs in 1 0; do GS_BIN_SHIFT=$bs GS_TILE_ORDER=1 GS_ARMS=1 GS_AB=1 python tools/stage_bench.py headline_1m_1080p 30; done > $OUT/stage_headline.log 2>&1
-for m in bands interleaved; do GS_SHARD_MODE=$m python tools/shard_bench.py headline_1m_1080p; done > $OUT/shard_headline.log 2>&1
-python tools/shard_bench.py cfg4_2m_1080p > $OUT/shard_cfg4.log 2>&1
+for m in bands interleaved; do GS_SHARD_EXCHANGE=1 GS_SHARD_MODE=$m python tools/shard_bench.py headline_1m_1080p; done > $OUT/shard_headline.log 2>&1
+GS_SHARD_EXCHANGE=1 python tools/shard_bench.py cfg4_2m_1080p > $OUT/shard_cfg4.log 2>&1
 # kernel trace of the middle rank of eight (what a rank's time is made of)
 (cd /tmp && export TMPDIR=/tmp && cd $ROOT && GS_SHARD_WORLDS=8 rocprofv3 --kernel-trace --stats -d $OUT/shard_g8_prof -o g8 --output-format csv -- \
     python tools/shard_bench.py headline_1m_1080p) > $OUT/shard_g8_trace.log 2>&1
