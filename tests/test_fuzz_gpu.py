@@ -1,0 +1,198 @@
+"""Randomised whole-operator parity on the GPU: random scenes, cameras, image sizes and operator options against the
+CPU oracle.  The fixed-scene tests of test_hip_parity.py pin each stage; this one looks for what nobody thought of:
+rotated and off-centre cameras, several objects with their own poses, Gaussians behind the camera and outside the
+frustum, needles, near-transparent and near-opaque mixtures, tiny and non-square images, every list layout and
+dispatch option, two consecutive frames through one operator (speculative sizes, automatic layout).
+
+GS_FUZZ_CASES (default 24) cases per run; GS_FUZZ_FIRST shifts the seeds (a failure prints its seed).
+"""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import gs_oracle as O
+from taichi_3d_gaussian_splatting_amd.synthetic import SyntheticScene
+from tests.helpers import FRAGILE_MARGIN, oracle_forward, rel_l2, report
+
+pytestmark = pytest.mark.gpu
+
+CASES = int(os.environ.get("GS_FUZZ_CASES", "24"))
+FIRST = int(os.environ.get("GS_FUZZ_FIRST", "0"))
+
+# Bars.  Observed over cases 0..799 (round 3, one MI355X; every case prints its distances as a [parity] line): 553 ordinary
+# scenes -- pixel 3.2e-6, depth 2.2e-5, grad_xyz 3.6e-5, grad_feat 3.4e-5; 247 needle scenes, against the fp32 oracle -- pixel
+# 3.6e-4, depth 7.1e-4, gradients 1.9e-4 / 7.8e-4, every one within 2x the fp32 oracle's own distance to the f64 spec.
+PIXEL_TOL = 1e-4            # north star, non-fragile pixels
+FRAGILE_PIXEL_BOUND = 1e-2  # one skipped / added Gaussian on a pixel whose decision sits on a threshold
+GRAD_TOL = 1e-4             # rel-L2 of the dense gradients, upstream gradient zeroed on the fragile pixels
+DEPTH_TOL = 2e-4            # depth image (alpha-weighted depths, values 1..10)
+NEEDLE_MARGIN = 4e-5        # needle scenes: decisions this close to a threshold differ between fp32 and f64 oracles
+SPEC_FACTOR = 2.0           # needle scenes: operator-to-f64 distance <= 2 x the fp32 oracle's own (as test_needles_against_the_f64_spec)
+
+
+def _quat(axis, angle):
+    axis = np.asarray(axis, np.float64)
+    axis = axis / np.linalg.norm(axis)
+    return np.concatenate([axis * math.sin(angle / 2), [math.cos(angle / 2)]]).astype(np.float32)   # x, y, z, w
+
+
+def _rot(q):
+    x, y, z, w = [float(v) for v in q]
+    return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)],
+                     [2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)],
+                     [2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)]])
+
+
+def random_scene(seed: int):
+    rng = np.random.default_rng(77_000 + seed)
+    height, width = 16 * int(rng.integers(1, 17)), 16 * int(rng.integers(1, 21))
+    n = int(10 ** rng.uniform(2.0, 4.0))
+    n_obj = int(rng.choice([1, 1, 1, 2, 3]))
+    spread = rng.uniform(0.5, 2.0)
+    xyz = (rng.uniform(-1, 1, size=(n, 3)) * spread).astype(np.float32)
+    feat = np.zeros((n, 56), np.float32)
+    q = rng.normal(size=(n, 4))
+    feat[:, 0:4] = q / np.linalg.norm(q, axis=1, keepdims=True) * rng.uniform(0.5, 2.0, size=(n, 1))   # un-normalised
+    s_min = 10 ** rng.uniform(-2.6, -1.3)
+    s_max = s_min * 10 ** rng.uniform(0.3, 1.5)
+    feat[:, 4:7] = rng.uniform(math.log(s_min), math.log(s_max), size=(n, 3))
+    needles = bool(rng.random() < 0.3)
+    if needles:   # a third of the Gaussians: two short axes and one 10-100 (x <= 1.65) times as long -- what trained scenes hold
+        rows = rng.random(n) < 0.33
+        axis = rng.integers(0, 3, size=n)
+        feat[rows, 4:7] = rng.uniform(math.log(s_min), math.log(s_min) + 0.5, size=(int(rows.sum()), 3))
+        feat[rows, 4 + axis[rows]] += np.log(rng.uniform(10, 100, size=int(rows.sum()))).astype(np.float32)
+    feat[:, 7] = rng.uniform(-3.0, 4.0, size=n)
+    band = int(rng.integers(0, 4))
+    for ch in range(3):
+        feat[:, 8 + 16 * ch] = rng.uniform(-2, 2, size=n) / 0.2820948
+        feat[:, 9 + 16 * ch: 24 + 16 * ch] = rng.normal(size=(n, 15)) * 0.3   # present even when the band ignores them
+    invalid = (rng.random(n) < float(rng.choice([0.0, 0.0, 0.1, 0.5]))).astype(np.int8)
+    obj = rng.integers(0, n_obj, size=n).astype(np.int32)
+    # camera <- pointcloud poses of the objects: a camera at distance d looking at the origin, rotated about a random
+    # axis, per object a small extra motion
+    d = rng.uniform(1.5, 4.0)
+    base = _quat(rng.normal(size=3), rng.uniform(0, math.radians(50)))
+    qs, ts = [], []
+    for _ in range(n_obj):
+        extra = _quat(rng.normal(size=3), rng.uniform(0, math.radians(10)))
+        R = _rot(base) @ _rot(extra)
+        qq = _quat_from_rot(R)
+        qs.append(qq)
+        ts.append((R @ np.array([0.0, 0.0, -d]) + rng.normal(size=3) * 0.1).astype(np.float32))
+    fx = width * rng.uniform(0.5, 1.5)
+    fy = fx * rng.uniform(0.8, 1.25)
+    K = np.array([[fx, 0.0, width / 2 + rng.uniform(-0.1, 0.1) * width],
+                  [0.0, fy, height / 2 + rng.uniform(-0.1, 0.1) * height], [0.0, 0.0, 1.0]], np.float32)
+    near, far, scale = [(0.8, 1000.0, 100.0), (0.1, 50.0, 1000.0), (2.0, 10.0, 10.0), (0.8, 1000.0, 100.0)][int(rng.integers(0, 4))]
+    scene = SyntheticScene(
+        point_cloud=torch.from_numpy(xyz), point_cloud_features=torch.from_numpy(feat),
+        point_invalid_mask=torch.from_numpy(invalid), point_object_id=torch.from_numpy(obj),
+        camera_intrinsics=torch.from_numpy(K), q_pointcloud_camera=torch.from_numpy(np.stack(qs)),
+        t_pointcloud_camera=torch.from_numpy(np.stack(ts)), height=height, width=width, near_plane=near,
+        far_plane=far, depth_to_sort_key_scale=scale)
+    options = dict(bin_shift=[None, 0, 1, 2][int(rng.integers(0, 4))], exact_tile_cull=bool(rng.random() < 0.7),
+                   ordered_dispatch=bool(rng.random() < 0.7), backward_on_walked_lists=bool(rng.random() < 0.7),
+                   fused_slot_reduction=bool(rng.random() < 0.3), speculative_sizes=bool(rng.random() < 0.7),
+                   hook=bool(rng.random() < 0.5))
+    return scene, band, needles, options
+
+
+def _quat_from_rot(R):
+    w = math.sqrt(max(0.0, 1 + R[0, 0] + R[1, 1] + R[2, 2])) / 2
+    if w > 1e-6:
+        x, y, z = (R[2, 1] - R[1, 2]) / (4 * w), (R[0, 2] - R[2, 0]) / (4 * w), (R[1, 0] - R[0, 1]) / (4 * w)
+    else:   # rotation by pi: not produced by the angles above, kept for completeness
+        x = math.sqrt(max(0.0, (1 + R[0, 0]) / 2)); y = math.sqrt(max(0.0, (1 + R[1, 1]) / 2))
+        z = math.sqrt(max(0.0, (1 + R[2, 2]) / 2))
+    v = np.array([x, y, z, w])
+    return (v / np.linalg.norm(v)).astype(np.float32)
+
+
+@pytest.mark.parametrize("case", range(FIRST, FIRST + CASES))
+def test_random_scene_against_the_oracle(case):
+    from taichi_3d_gaussian_splatting_amd import CameraInfo, GaussianPointCloudRasterisation as Op
+    scene, band, needles, opt = random_scene(case)
+    f = oracle_forward(scene)
+    rng = np.random.default_rng(5_000 + case)
+    # Pixels whose blend decisions sit on a threshold may legitimately differ between two correct implementations: they
+    # are compared with the loose per-pixel bound and get no upstream gradient (a flipped pair is a discrete change).
+    # Needle scenes are ill-conditioned in fp32 (the conic of an aspect-ratio-100 Gaussian loses most of its digits), so
+    # there the yardstick is the float64 build of the oracle: the operator may be as far from it as the fp32 oracle is
+    # (x SPEC_FACTOR), on the pixels where both oracle precisions take the same decisions with NEEDLE_MARGIN to spare.
+    spec = oracle_forward(scene, precision="f64") if needles else None
+    if needles:
+        keep = (f["count"] == spec["count"]) & (f["margin"] >= NEEDLE_MARGIN) & (spec["margin"] >= NEEDLE_MARGIN)
+    else:
+        keep = f["margin"] >= FRAGILE_MARGIN
+    g = (rng.random((scene.height, scene.width, 3)) * 2 - 1).astype(np.float32) * keep[:, :, None]
+    ob = O.backward(f, g, band)
+    ob64 = O.backward(spec, g.astype(np.float64), band) if needles else None
+
+    s = scene.to("cuda")
+    got = {}
+    hook = (lambda h: got.__setitem__("h", h)) if opt["hook"] else None
+    op = Op(Op.GaussianPointCloudRasterisationConfig(near_plane=s.near_plane, far_plane=s.far_plane,
+                                                     depth_to_sort_key_scale=s.depth_to_sort_key_scale),
+            backward_valid_point_hook=hook)
+    for name in ("bin_shift", "exact_tile_cull", "ordered_dispatch", "backward_on_walked_lists",
+                 "fused_slot_reduction", "speculative_sizes"):
+        setattr(op, name, opt[name])
+    worst = {}
+
+    def held(name, hip, ref32, ref64, tol, tag, reduce):
+        """Non-needle: distance to the fp32 oracle <= tol.  Needle: distance to the f64 spec <= SPEC_FACTOR x the fp32
+        oracle's own distance (+ tol as the floor for quantities both get right)."""
+        d = reduce(hip, ref32)
+        worst[name] = max(worst.get(name, 0.0), d)
+        if ref64 is None:
+            assert d <= tol, f"{tag}: {name} {d:.3e} > {tol:.1e}"
+        else:
+            d_hip, d_o32 = reduce(hip, ref64), reduce(ref32, ref64)
+            assert d_hip <= SPEC_FACTOR * d_o32 + tol, f"{tag}: {name} vs f64 {d_hip:.3e}, fp32 oracle {d_o32:.3e}"
+
+    def linf(a, b):
+        return float(np.abs(np.asarray(a, np.float64) - np.asarray(b, np.float64)).max()) if a.size else 0.0
+
+    for frame in range(2):   # the second frame runs on the sizes (and, with bin_shift None, the layout) learnt from the first
+        xyz = s.point_cloud.clone().requires_grad_(True)
+        feat = s.point_cloud_features.clone().requires_grad_(True)
+        inp = Op.GaussianPointCloudRasterisationInput(
+            point_cloud=xyz, point_cloud_features=feat, point_object_id=s.point_object_id,
+            point_invalid_mask=s.point_invalid_mask,
+            camera_info=CameraInfo(camera_intrinsics=s.camera_intrinsics, camera_height=s.height,
+                                   camera_width=s.width, camera_id=0),
+            q_pointcloud_camera=s.q_pointcloud_camera, t_pointcloud_camera=s.t_pointcloud_camera,
+            color_max_sh_band=band)
+        image, depth, count = op(inp)
+        (image * torch.from_numpy(g).cuda()).sum().backward()
+        tag = f"case {case} frame {frame} ({scene.width}x{scene.height}, n={xyz.shape[0]}, M={len(f['ids'])}, band {band}, " \
+              f"needles={needles}, {opt})"
+        img, dep = image.detach().cpu().numpy(), depth.detach().cpu().numpy()
+        if keep.any():
+            held("pixel", img[keep], f["image"][keep], spec["image"][keep] if needles else None, PIXEL_TOL, tag, linf)
+            held("depth", dep[keep], f["depth"][keep], spec["depth"][keep] if needles else None, DEPTH_TOL, tag, linf)
+            assert np.array_equal(count.cpu().numpy()[keep], f["count"][keep]), tag
+        assert linf(img, f["image"]) <= FRAGILE_PIXEL_BOUND, tag
+        # side effect: visible quaternions normalised in place
+        assert np.allclose(feat.detach().cpu().numpy()[:, :4], f["feat"][:, :4], atol=2e-7), tag
+        gx, gf = xyz.grad.cpu().numpy(), feat.grad.cpu().numpy()
+        assert np.isfinite(gx).all() and np.isfinite(gf).all(), tag
+        invisible = np.setdiff1d(np.arange(gx.shape[0]), f["ids"])
+        assert not gx[invisible].any() and not gf[invisible].any(), tag
+        for name, hip in (("grad_xyz", gx), ("grad_feat", gf)):
+            if np.abs(ob[name]).max() > 0:
+                held(name, hip, ob[name], ob64[name] if needles else None, GRAD_TOL, tag, rel_l2)
+        if hook is not None and len(f["ids"]) > 0:
+            h, ho = got["h"], ob["hook"]
+            assert np.array_equal(h.point_id_in_camera_list.cpu().numpy(), ho["point_id_in_camera_list"]), tag
+            assert np.array_equal(h.num_overlap_tiles.cpu().numpy(), ho["num_overlap_tiles"]), tag
+            assert np.array_equal(h.point_depth.cpu().numpy(), ho["point_depth"]), tag
+            assert np.array_equal(h.point_uv_in_camera.cpu().numpy(), ho["point_uv_in_camera"]), tag
+            npix = h.num_affected_pixels.cpu().numpy()
+            assert int(np.abs(npix - ho["num_affected_pixels"]).sum()) <= int((~keep).sum()), tag
+    report(f"fuzz.case{case}", size=f"{scene.width}x{scene.height}", n=scene.point_cloud.shape[0], m=len(f["ids"]),
+           needles=needles, left_out=int((~keep).sum()), **{k: f"{v:.2e}" for k, v in worst.items()})
