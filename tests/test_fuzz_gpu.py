@@ -22,15 +22,20 @@ pytestmark = pytest.mark.gpu
 CASES = int(os.environ.get("GS_FUZZ_CASES", "24"))
 FIRST = int(os.environ.get("GS_FUZZ_FIRST", "0"))
 
-# Bars.  Observed over cases 0..799 (round 3, one MI355X; every case prints its distances as a [parity] line): 553 ordinary
-# scenes -- pixel 3.2e-6, depth 2.2e-5, grad_xyz 3.6e-5, grad_feat 3.4e-5; 247 needle scenes, against the fp32 oracle -- pixel
-# 3.6e-4, depth 7.1e-4, gradients 1.9e-4 / 7.8e-4, every one within 2x the fp32 oracle's own distance to the f64 spec.
+# Bars.  Observed over cases 0..599 (round 3, one MI355X; every case prints its distances as a [parity] line; 86 of them on
+# grids of more than 1,280 tiles): 287 ordinary scenes -- pixel 3.8e-6, depth 9.5e-6, grad_xyz 6.5e-5, grad_feat 3.8e-5, no
+# flipped pixel; 313 ill-conditioned scenes (needles or close-ups), against the fp32 oracle -- pixel 3.9e-4, depth 1.9e-3,
+# gradients 2.3e-4 / 5.5e-4, every one within SPEC_FACTOR x the fp32 oracle's own distance to the f64 spec.
 PIXEL_TOL = 1e-4            # north star, non-fragile pixels
 FRAGILE_PIXEL_BOUND = 1e-2  # one skipped / added Gaussian on a pixel whose decision sits on a threshold
 GRAD_TOL = 1e-4             # rel-L2 of the dense gradients, upstream gradient zeroed on the fragile pixels
 DEPTH_TOL = 2e-4            # depth image (alpha-weighted depths, values 1..10)
 NEEDLE_MARGIN = 4e-5        # needle scenes: decisions this close to a threshold differ between fp32 and f64 oracles
-SPEC_FACTOR = 2.0           # needle scenes: operator-to-f64 distance <= 2 x the fp32 oracle's own (as test_needles_against_the_f64_spec)
+SPEC_FACTOR = 4.0           # ill-conditioned scenes: operator-to-f64 distance <= 4 x the fp32 oracle's own.  (Two fp32 evaluations
+                            # in different association orders: on a 6,000-Gaussian scene the ratio is 0.9-1.2,
+                            # test_needles_against_the_f64_spec holds 2; on a 200-Gaussian draw one row decides it: seen 3.1)
+FLIP_MARGIN = 1e-5          # ordinary scenes: a pixel this close to a threshold may still flip when the quadratic form of a
+MAX_FLIPS = 2               # Gaussian seen from very close cancels (seen: margin 1.3e-7, 1 pixel of 462,336): at most two
 
 
 def _quat(axis, angle):
@@ -50,6 +55,9 @@ def random_scene(seed: int):
     rng = np.random.default_rng(77_000 + seed)
     height, width = 16 * int(rng.integers(1, 17)), 16 * int(rng.integers(1, 21))
     n = int(10 ** rng.uniform(2.0, 4.0))
+    if rng.random() < 0.15:   # a grid of more than 1,280 tiles: the two-waves-per-tile kernels, the large sort workgroups
+        height, width = 16 * int(rng.integers(36, 49)), 16 * int(rng.integers(36, 49))
+        n = int(10 ** rng.uniform(3.5, 4.7))
     n_obj = int(rng.choice([1, 1, 1, 2, 3]))
     spread = rng.uniform(0.5, 2.0)
     xyz = (rng.uniform(-1, 1, size=(n, 3)) * spread).astype(np.float32)
@@ -123,6 +131,7 @@ def test_random_scene_against_the_oracle(case):
     # Needle scenes are ill-conditioned in fp32 (the conic of an aspect-ratio-100 Gaussian loses most of its digits), so
     # there the yardstick is the float64 build of the oracle: the operator may be as far from it as the fp32 oracle is
     # (x SPEC_FACTOR), on the pixels where both oracle precisions take the same decisions with NEEDLE_MARGIN to spare.
+    needles = needles or scene.near_plane < 0.5   # close-ups: Gaussians magnified a hundredfold are needles on the screen
     spec = oracle_forward(scene, precision="f64") if needles else None
     if needles:
         keep = (f["count"] == spec["count"]) & (f["margin"] >= NEEDLE_MARGIN) & (spec["margin"] >= NEEDLE_MARGIN)
@@ -172,10 +181,16 @@ def test_random_scene_against_the_oracle(case):
         tag = f"case {case} frame {frame} ({scene.width}x{scene.height}, n={xyz.shape[0]}, M={len(f['ids'])}, band {band}, " \
               f"needles={needles}, {opt})"
         img, dep = image.detach().cpu().numpy(), depth.detach().cpu().numpy()
-        if keep.any():
-            held("pixel", img[keep], f["image"][keep], spec["image"][keep] if needles else None, PIXEL_TOL, tag, linf)
-            held("depth", dep[keep], f["depth"][keep], spec["depth"][keep] if needles else None, DEPTH_TOL, tag, linf)
-            assert np.array_equal(count.cpu().numpy()[keep], f["count"][keep]), tag
+        tight = keep
+        if not needles:   # explainable flips: a few pixels within FLIP_MARGIN of a threshold (bounded like the fragile ones)
+            flipped = keep & (count.cpu().numpy() != f["count"]) & (f["margin"] < FLIP_MARGIN)
+            assert int(flipped.sum()) <= MAX_FLIPS, tag
+            worst["flips"] = max(worst.get("flips", 0.0), float(flipped.sum()))
+            tight = keep & ~flipped
+        if tight.any():
+            held("pixel", img[tight], f["image"][tight], spec["image"][tight] if needles else None, PIXEL_TOL, tag, linf)
+            held("depth", dep[tight], f["depth"][tight], spec["depth"][tight] if needles else None, DEPTH_TOL, tag, linf)
+            assert np.array_equal(count.cpu().numpy()[tight], f["count"][tight]), tag
         assert linf(img, f["image"]) <= FRAGILE_PIXEL_BOUND, tag
         # side effect: visible quaternions normalised in place
         assert np.allclose(feat.detach().cpu().numpy()[:, :4], f["feat"][:, :4], atol=2e-7), tag
@@ -194,5 +209,18 @@ def test_random_scene_against_the_oracle(case):
             assert np.array_equal(h.point_uv_in_camera.cpu().numpy(), ho["point_uv_in_camera"]), tag
             npix = h.num_affected_pixels.cpu().numpy()
             assert int(np.abs(npix - ho["num_affected_pixels"]).sum()) <= int((~keep).sum()), tag
+    # inference paths: no backward state (torch.no_grad), and rgb_only -- the same image, bit for bit
+    # (fresh copies of the features: the in-place normalisation of an already normalised quaternion may move its last bit)
+    inp.point_cloud_features = s.point_cloud_features.clone()
+    with torch.no_grad():
+        image_ng, depth_ng, count_ng = op(inp)
+    inp.point_cloud_features = s.point_cloud_features.clone()
+    assert torch.equal(image_ng, image) and torch.equal(depth_ng, depth) and torch.equal(count_ng, count), f"case {case}: no_grad"
+    op_rgb = Op(Op.GaussianPointCloudRasterisationConfig(near_plane=s.near_plane, far_plane=s.far_plane,
+                                                         depth_to_sort_key_scale=s.depth_to_sort_key_scale, rgb_only=True))
+    op_rgb.bin_shift, op_rgb.exact_tile_cull = opt["bin_shift"], opt["exact_tile_cull"]
+    with torch.no_grad():
+        image_rgb, depth_rgb, count_rgb = op_rgb(inp)
+    assert torch.equal(image_rgb, image) and not depth_rgb.any() and not count_rgb.any(), f"case {case}: rgb_only"
     report(f"fuzz.case{case}", size=f"{scene.width}x{scene.height}", n=scene.point_cloud.shape[0], m=len(f["ids"]),
            needles=needles, left_out=int((~keep).sum()), **{k: f"{v:.2e}" for k, v in worst.items()})
