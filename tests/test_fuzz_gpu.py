@@ -34,6 +34,7 @@ NEEDLE_MARGIN = 4e-5        # needle scenes: decisions this close to a threshold
 SPEC_FACTOR = 4.0           # ill-conditioned scenes: operator-to-f64 distance <= 4 x the fp32 oracle's own.  (Two fp32 evaluations
                             # in different association orders: on a 6,000-Gaussian scene the ratio is 0.9-1.2,
                             # test_needles_against_the_f64_spec holds 2; on a 200-Gaussian draw one row decides it: seen 3.1)
+SHARD_GRAD_TOL = 2e-4       # sharded vs un-sharded gradients: the same terms added per rank first (observed <= 3.5e-5 over 300 draws)
 FLIP_MARGIN = 1e-5          # ordinary scenes: a pixel this close to a threshold may still flip when the quadratic form of a
 MAX_FLIPS = 2               # Gaussian seen from very close cancels (seen: margin 1.3e-7, 1 pixel of 462,336): at most two
 
@@ -224,3 +225,84 @@ def test_random_scene_against_the_oracle(case):
     assert torch.equal(image_rgb, image) and not depth_rgb.any() and not count_rgb.any(), f"case {case}: rgb_only"
     report(f"fuzz.case{case}", size=f"{scene.width}x{scene.height}", n=scene.point_cloud.shape[0], m=len(f["ids"]),
            needles=needles, left_out=int((~keep).sum()), **{k: f"{v:.2e}" for k, v in worst.items()})
+
+
+@pytest.mark.parametrize("case", range(FIRST, FIRST + max(CASES // 2, 1)))
+def test_random_scene_sharded_over_tile_rows(case):
+    """The same random scenes split over 2-4 'ranks' (one operator per rank, run one after the other on the one GPU):
+    the ranks' rows assemble to the un-sharded image bit for bit; the sparse accumulator exchange -- every rank's produced
+    rows compacted, the lists merged in rank order (gs_compact_rows / gs_merge_rows, here without the wire) -- gives every
+    rank the un-sharded gradient up to the order of the additions; empty bands (more ranks than tile rows) included."""
+    from taichi_3d_gaussian_splatting_amd import CameraInfo, GaussianPointCloudRasterisation as Op, hip_ops
+    scene, band, _, opt = random_scene(case)
+    rng = np.random.default_rng(9_000 + case)
+    world = int(rng.integers(2, 5))
+    mode = "bands" if rng.random() < 0.7 else "interleaved"
+    s = scene.to("cuda")
+    g = torch.from_numpy((rng.random((scene.height, scene.width, 3)) * 2 - 1).astype(np.float32)).cuda()
+
+    def make_op(shard):
+        op = Op(Op.GaussianPointCloudRasterisationConfig(near_plane=s.near_plane, far_plane=s.far_plane,
+                                                         depth_to_sort_key_scale=s.depth_to_sort_key_scale))
+        op.bin_shift, op.exact_tile_cull, op.ordered_dispatch = opt["bin_shift"], opt["exact_tile_cull"], opt["ordered_dispatch"]
+        op.backward_on_walked_lists, op.speculative_sizes = opt["backward_on_walked_lists"], opt["speculative_sizes"]
+        op.shard = shard
+        return op
+
+    def run(op):
+        xyz = s.point_cloud.clone().requires_grad_(True)
+        feat = s.point_cloud_features.clone().requires_grad_(True)
+        inp = Op.GaussianPointCloudRasterisationInput(
+            point_cloud=xyz, point_cloud_features=feat, point_object_id=s.point_object_id,
+            point_invalid_mask=s.point_invalid_mask,
+            camera_info=CameraInfo(camera_intrinsics=s.camera_intrinsics, camera_height=s.height,
+                                   camera_width=s.width, camera_id=0),
+            q_pointcloud_camera=s.q_pointcloud_camera, t_pointcloud_camera=s.t_pointcloud_camera,
+            color_max_sh_band=band)
+        image, depth, count = op(inp)
+        (image * g).sum().backward()
+        return image.detach(), depth.detach(), count, xyz.grad, feat.grad
+
+    tag = f"case {case} ({scene.width}x{scene.height}, n={scene.point_cloud.shape[0]}, world {world} {mode}, {opt})"
+    full = run(make_op(None))
+    # phase 1: every rank alone, keeping the accumulator rows it produced
+    parts, lists = [], []
+    for r in range(world):
+        op = make_op((r, world, mode))
+        kept = {}
+        op.grad_accumulator_reduce = lambda acc, nk, kept=kept: (kept.update(acc=acc.clone(), nk=nk.clone()), acc)[1]
+        parts.append(run(op))
+        lists.append(kept)
+    image = sum(p[0] for p in parts)   # un-owned rows are zeros
+    assert torch.equal(image, full[0]), tag
+    assert torch.equal(sum(p[1] for p in parts), full[1]) and torch.equal(sum(p[2] for p in parts), full[2]), tag
+    if not lists[0]:   # nothing in the frustum: no backward state anywhere
+        assert not full[3].any() and not full[4].any(), tag
+        return
+    # phase 2: the exchange without the wire, then one rank's per-point pass on the merged accumulators
+    m = lists[0]["acc"].shape[0]
+    compact = [hip_ops.compact_rows(k["acc"], k["nk"]) for k in lists]
+    counts = [int(c[2].item()) for c in compact]
+    cap = max(4, -(-max(counts) // 4) * 4)
+    recv = torch.zeros((world, 13 * cap), dtype=torch.int32, device="cuda")
+    for r, (ids, rows, _) in enumerate(compact):
+        recv[r, :counts[r]] = ids[:counts[r]]
+        recv[r, cap:cap + 12 * counts[r]].view(torch.float32).copy_(rows[:counts[r]].reshape(-1))
+        assert (ids[:counts[r]][1:] > ids[:counts[r]][:-1]).all(), tag          # ascending row ids
+    merged = hip_ops.merge_rows(recv.view(-1), 13 * cap, cap, torch.tensor(counts, dtype=torch.int32, device="cuda"), world, m)
+    dense = torch.zeros_like(merged)
+    for k in lists:   # what a dense all-reduce would have summed (rank order, pixel count as an integer)
+        rows = k["nk"] > 0
+        dense[rows, :10] += k["acc"][rows, :10]
+        dense[rows, 10] = (dense[rows, 10].view(torch.int32) + k["acc"][rows, 10].view(torch.int32)).view(torch.float32)
+    assert torch.equal(merged[:, :11].view(torch.int32), dense[:, :11].view(torch.int32)), tag
+    op = make_op((0, world, mode))
+    op.grad_accumulator_reduce = lambda acc, nk: merged
+    shard0 = run(op)
+    worst = 0.0
+    for name, hip, ref in (("grad_xyz", shard0[3], full[3]), ("grad_feat", shard0[4], full[4])):
+        if ref.abs().max() > 0:
+            r = rel_l2(hip.cpu().numpy(), ref.cpu().numpy())
+            worst = max(worst, r)
+            assert r <= SHARD_GRAD_TOL, f"{tag}: {name} {r:.3e}"
+    report(f"fuzz.sharded.case{case}", world=world, mode=mode, rows_sent=counts, m=m, grad_vs_unsharded=f"{worst:.2e}")
