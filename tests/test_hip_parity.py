@@ -272,7 +272,9 @@ def test_list_layouts_are_output_identical(ops, scene, ofwd, obwd):
 
 @pytest.mark.parametrize("n,depth_bits,tile_bits,compressed", [
     (1, 17, 13, False), (2, 17, 13, True), (257, 8, 3, True), (5000, 17, 13, False), (5000, 17, 13, True),
-    (70_000, 9, 5, True), (300_001, 64, 13, False), (300_001, 19, 13, True)])
+    (70_000, 9, 5, True), (300_001, 64, 13, False), (300_001, 19, 13, True),
+    # above 512 x 4,096 keys the sort runs its large workgroups (16 rounds per wave), below the small ones (4)
+    (2_097_151, 13, 11, True), (2_300_003, 13, 11, True), (2_200_001, 17, 13, False)])
 def test_radix_sort_stable_vs_numpy(ops, n, depth_bits, tile_bits, compressed):
     rng = np.random.default_rng(n)
     if depth_bits == 64:  # negative depths: the full signed key is sorted
