@@ -35,6 +35,8 @@ def main() -> None:
     ap.add_argument("--far_plane", type=float, default=1000.0)
     ap.add_argument("--depth_to_sort_key_scale", type=float, default=100.0)
     args = ap.parse_args()
+    from taichi_3d_gaussian_splatting_amd import host_affinity
+    host_affinity.pin_host_threads(torch.cuda.current_device())   # launching threads on one L3 complex next to the GPU
     dev = torch.device("cuda:0")
 
     if args.synthetic:

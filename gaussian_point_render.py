@@ -93,6 +93,9 @@ def main() -> None:
     args = ap.parse_args()
     out = Path(args.output_prefix)
     os.makedirs(out, exist_ok=True)
+    if torch.cuda.is_available():   # the launching threads on one L3 complex next to the GPU (host_affinity.py)
+        from taichi_3d_gaussian_splatting_amd import host_affinity
+        host_affinity.pin_host_threads(torch.cuda.current_device())
     if args.poses.endswith(".pt"):
         config = GaussianPointRenderer.GaussianPointRendererConfig(args.parquet_path, torch.load(args.poses))
         if args.portrait_mode:

@@ -28,6 +28,9 @@ def main() -> None:
     if int(os.environ.get("WORLD_SIZE", "1")) > 1:
         torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
         torch.distributed.init_process_group("nccl")   # RCCL on ROCm
+    if torch.cuda.is_available():   # the launching threads on one L3 complex next to the GPU (host_affinity.py)
+        from taichi_3d_gaussian_splatting_amd import host_affinity
+        host_affinity.pin_host_threads(torch.cuda.current_device())
     GaussianPointCloudTrainer(config).train()
     if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()

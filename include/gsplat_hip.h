@@ -204,7 +204,7 @@ int gs_read_counters_async(const int32_t *counters, int32_t *host_counters_pinne
                                    pixels per lane (slower; profiles/r03_pmc_blend.md) */
 #define GS_BLEND_FOUR_WAVES 8   /* both blend passes: the four-waves-per-tile kernels (one pixel per lane) whenever the lists
                                    are per-tile lists taken as they are (bin_shift 0, filter 0).  Default (neither flag):
-                                   four waves when at most 1280 tiles are rendered -- a grid that cannot fill the chip with two.
+                                   four waves when at most 3840 tiles are rendered -- a grid that cannot fill the chip with two.
                                    Image, depth, counts, state and hit sets are bit-identical between the two forms. */
 int gs_blend_forward(const int32_t *bin_start, const int32_t *bin_end, const int32_t *payload,
                      const float *attrs, int width, int height, int tile_row_begin,

@@ -268,7 +268,9 @@ class GaussianPointCloudTrainer:
                 print(f"{console_key}_{step}={value};")
 
     def _loaders(self):
-        kw = dict(batch_size=None, pin_memory=True, num_workers=self.config.num_data_loader_workers)
+        from .host_affinity import reset_worker_affinity   # workers fork from a main thread that may be pinned to one complex
+        kw = dict(batch_size=None, pin_memory=True, num_workers=self.config.num_data_loader_workers,
+                  worker_init_fn=reset_worker_affinity if self.config.num_data_loader_workers > 0 else None)
         generator = torch.Generator().manual_seed(self.config.seed)   # same shuffling on every rank
         return (torch.utils.data.DataLoader(self.train_dataset, shuffle=True, generator=generator, **kw),
                 torch.utils.data.DataLoader(self.val_dataset, shuffle=False, **kw))

@@ -20,7 +20,7 @@
 //            reduce_partials_kernel, so gradients are bitwise reproducible.
 //  order   : tiles are handed to the hardware longest list / longest backward walk first (tile_order_kernel), which
 //            removes the tail of half-empty CUs of a launch in image order.
-//  small   : grids of at most 1,280 tiles run both passes with FOUR waves per tile and one pixel per lane
+//  small   : grids of at most 3,840 tiles run both passes with FOUR waves per tile and one pixel per lane
 //            (blend_*_small_kernel): same per-pixel arithmetic, half the issue slots per wave and entry.
 #include "gs_common.h"
 #include "gs_slots.h"
@@ -785,9 +785,10 @@ __global__ __launch_bounds__(BLEND_THREADS, GS_BWD_MIN_WAVES) void blend_backwar
 // sums add the same per-pixel terms in another order (four waves of 64 pixels instead of two of 128).
 constexpr int SMALL_THREADS = 256;
 #ifndef GS_SMALL_GRID_TILES
-#define GS_SMALL_GRID_TILES 1280   // at most this many owned tiles (5 x the 256 CUs): four waves per tile.  Measured at 256
-                                   // tiles (-21 %) and at the 1,080 tiles of one of eight bands of a 1920 x 1072 frame (-3 %);
-                                   // +19 % at 8,040 tiles
+#define GS_SMALL_GRID_TILES 3840   // at most this many owned tiles (15 x the 256 CUs): four waves per tile.  Measured, four
+                                   // against two waves per tile, backward / forward: 256 tiles -21 % / -20 %, 1,080 (one of eight
+                                   // bands of a 1920 x 1072 frame) -3 % of the rank's frame, 2,040 (one of four) -5 % of the frame,
+                                   // 2,500 -5 % / -10 %, 3,600 -4 % / -6 %, 4,080 +1 % of the frame, 5,120 +15 % / +1 %, 8,040 +19 % / +4 %
 #endif
 
 __device__ __forceinline__ float gs_pixel_alpha(const float4 p, const float4 q, float px, float py, float &dx, float &dy) {

@@ -102,6 +102,10 @@ def make_reference_stress_scene(seed: int = 0, n: int = 100_000, n_valid: int = 
 def make_config_scene(name: str, seed: int = 0) -> SyntheticScene:
     if name == "stress_t_ras":
         return make_reference_stress_scene(seed)
+    if name.startswith("custom:"):   # e.g. custom:n=200000,height=960,width=960,s_min=0.005,s_max=0.04 (tuning sweeps)
+        kw = dict(item.split("=") for item in name[len("custom:"):].split(","))
+        ints = ("n", "height", "width", "sh_degree")
+        return make_scene(seed=seed, **{k: (int(v) if k in ints else float(v)) for k, v in kw.items()})
     return make_scene(seed=seed, **CONFIGS[name])
 
 

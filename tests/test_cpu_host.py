@@ -151,3 +151,47 @@ def test_list_layout_object():
     assert band.sharded and list(band.owned_rows(1072)) == list(range(8, 20))
     assert list(ListLayout(row_begin=1, row_step=3).owned_rows(160)) == [1, 4, 7]
     assert list(ListLayout(row_begin=60, row_end=100).owned_rows(1072)) == list(range(60, 67))
+
+
+def test_host_affinity_picks_one_l3_complex_per_local_rank(monkeypatch):
+    """host_affinity on a made-up two-socket box (no real affinity call): rank r's threads go to the r-th L3 complex of the
+    GPU's NUMA node, PyTorch's intra-op pool is cut to its cores, unpin restores both."""
+    import os
+    import torch
+    from taichi_3d_gaussian_splatting_amd import host_affinity as h
+    assert h._parse_cpu_list("0-3,8,10-11\n") == {0, 1, 2, 3, 8, 10, 11}
+    # 2 sockets x 2 complexes x 4 cores, SMT siblings at +16; the GPU hangs off socket 1 (cpus 8-15, 24-31)
+    def fake_read(path):
+        if path.endswith("local_cpulist"):
+            return "8-15,24-31"
+        cpu = int(path.split("/cpu/cpu")[1].split("/")[0])
+        core = cpu % 16
+        if path.endswith("shared_cpu_list"):
+            base = core // 4 * 4
+            return f"{base}-{base + 3},{base + 16}-{base + 19}"
+        if path.endswith("thread_siblings_list"):
+            return f"{core},{core + 16}"
+        return None
+    calls = []
+    monkeypatch.setattr(h, "_read", fake_read)
+    monkeypatch.setattr(h, "gpu_local_cpus", lambda i: h._parse_cpu_list(fake_read("local_cpulist")))
+    monkeypatch.setattr(h, "_all_thread_ids", lambda: [101, 102])
+    monkeypatch.setattr(os, "sched_getaffinity", lambda pid: set(range(32)), raising=False)
+    monkeypatch.setattr(os, "sched_setaffinity", lambda tid, mask: calls.append((tid, set(mask))), raising=False)
+    monkeypatch.setattr(h, "_original_mask", None)
+    monkeypatch.setattr(h, "_original_torch_threads", None)
+    before = torch.get_num_threads()
+    try:
+        monkeypatch.setenv("LOCAL_RANK", "1")
+        chosen = h.pin_host_threads(0)
+        assert chosen == {12, 13, 14, 15, 28, 29, 30, 31}           # second complex of the GPU's socket
+        assert calls == [(101, chosen), (102, chosen)]
+        assert torch.get_num_threads() == min(before, 4)            # four cores behind the eight hardware threads
+        assert h.pin_host_threads(0, slot=0) == {8, 9, 10, 11, 24, 25, 26, 27}
+        del calls[:]
+        h.unpin_host_threads()
+        assert calls == [(101, set(range(32))), (102, set(range(32)))] and torch.get_num_threads() == before
+        monkeypatch.setenv("GS_PIN_HOST_THREADS", "0")
+        assert h.pin_host_threads(0) is None
+    finally:
+        torch.set_num_threads(before)

@@ -6,6 +6,9 @@ import os, sys, time, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from taichi_3d_gaussian_splatting_amd import CameraInfo, GaussianPointCloudRasterisation as Op, hip_ops
 from taichi_3d_gaussian_splatting_amd.synthetic import make_config_scene, make_grad_image
+from taichi_3d_gaussian_splatting_amd import host_affinity
+if os.environ.get("GS_NO_PIN") != "1":
+    host_affinity.pin_host_threads(0)   # launching threads on one L3 complex next to the GPU (as bench.py)
 s = make_config_scene(sys.argv[1] if len(sys.argv) > 1 else "headline_1m_1080p").to("cuda"); g = make_grad_image(s.height, s.width).to("cuda")
 MODE = os.environ.get("GS_SHARD_MODE", "bands")
 RANK = int(os.environ.get("GS_SHARD_RANK", "-1"))   # -1: the middle band (the heaviest one under perspective)

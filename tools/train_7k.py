@@ -34,6 +34,8 @@ ORACLE_ITERS = int(sys.argv[2]) if len(sys.argv) > 2 else 300
 SIZE = int(sys.argv[3]) if len(sys.argv) > 3 else 800
 N_TRUE, N_VIEWS = 30_000, 24
 dev = torch.device("cuda:0")
+from taichi_3d_gaussian_splatting_amd import host_affinity  # noqa: E402
+host_affinity.pin_host_threads(0)   # as gaussian_point_train.py: launching threads on one L3 complex next to the GPU
 import tempfile  # noqa: E402
 out_dir = os.path.join(ROOT, "gpurun_out", "train7k")
 os.makedirs(out_dir, exist_ok=True)
