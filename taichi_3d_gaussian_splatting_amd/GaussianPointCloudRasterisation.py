@@ -174,7 +174,9 @@ class GaussianPointCloudRasterisation(torch.nn.Module):
         # flight than the per-point kernel can hold), so off by default
         self.fused_slot_reduction = False
         # binned layouts: the backward pass walks the per-tile lists the forward pass wrote out while filtering its bin's
-        # list, instead of filtering the bin's list a second time (same entries in the same order: same bits)
+        # list, instead of filtering the bin's list a second time (same entries in the same order: the same bits on grids
+        # above 3,840 tiles; below, the per-tile lists let the backward take the four-waves-per-tile form, whose slot sums
+        # add the same per-pixel terms in another order)
         self.backward_on_walked_lists = True
         # the forward writes a normalised quaternion back only when the stored one differs (RAS:196-205: same memory
         # contents).  True = always write: what a training iteration pays -- the optimiser has just moved q -- for

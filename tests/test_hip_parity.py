@@ -786,8 +786,10 @@ def test_four_waves_per_tile_arm_at_a_larger_size(ops):
     worst = float(((a4[:, :10] - a2[:, :10]).abs() / scale).max())
     report("four_waves.cfg2", tiles=(s.width // 16) * (s.height // 16), max_scaled_difference_of_sums=worst)
     assert worst < 2e-6
-    # 2,500 tiles > 1,024: the library's own choice here is the two-wave form, bit for bit
-    assert torch.equal(part[None][0][raised].view(torch.int32), p2[raised].view(torch.int32))
+    # 2,500 tiles <= 3,840: the library's own choice here is the four-wave form, bit for bit
+    assert torch.equal(part[None][0][raised].view(torch.int32), p4[raised].view(torch.int32))
+    for i in range(6):
+        assert torch.equal(out[None][i], out["four_waves"][i]), i
 
 
 def test_ordered_dispatch_on_a_4k_grid(ops):
@@ -841,12 +843,13 @@ def test_operator_options_that_must_not_change_a_bit(scene):
 def test_backward_on_walked_lists_is_bit_identical(ops):
     """Binned layouts: the forward pass writes out every tile's own list as far as it walks it and the backward pass runs on
     those per-tile lists.  Same entries in the same order through the same arithmetic: gradients, hook fields and the
-    magnitude image equal the ones of the backward pass that filters the bin lists again, bit for bit (2,500 tiles: both
-    run the two-wave kernels), for 2x2- and 4x4-tile bins; and the emitted lists are the tiles' lists of the per-tile
-    layout, truncated where the forward pass stopped."""
+    magnitude image equal the ones of the backward pass that filters the bin lists again, bit for bit, for 2x2- and 4x4-tile
+    bins (8,040 tiles: both run the two-wave kernels; on grids of at most 3,840 tiles the walked lists let the backward pass
+    take the four-wave form, which adds the same per-pixel terms in another order); and the emitted lists are the tiles'
+    lists of the per-tile layout, truncated where the forward pass stopped."""
     from taichi_3d_gaussian_splatting_amd import GaussianPointCloudRasterisation as Op
     from taichi_3d_gaussian_splatting_amd.synthetic import make_config_scene, make_grad_image
-    s = make_config_scene("cfg2_100k_800")
+    s = make_config_scene("cfg3_400k_1080p")
     g = make_grad_image(s.height, s.width)
     cfg = Op.GaussianPointCloudRasterisationConfig(near_plane=s.near_plane, far_plane=s.far_plane,
                                                    depth_to_sort_key_scale=s.depth_to_sort_key_scale)
