@@ -84,8 +84,9 @@ def _all_thread_ids() -> List[int]:
 
 def pin_host_threads(device_index: int = 0, slot: Optional[int] = None) -> Optional[Set[int]]:
     """Restrict every thread of this process (those that exist now; later ones inherit) to the cores of ONE L3 complex on
-    the GPU's NUMA node.  ``slot`` picks the complex (default: LOCAL_RANK, so the ranks of a node spread over the
-    complexes).  Returns the CPU set, or None when nothing was changed."""
+    the GPU's NUMA node.  ``slot`` picks the complex (default: LOCAL_RANK when a launcher set it, else the device index:
+    the ranks of a node, or independent jobs on different GPUs, spread over the complexes).  Returns the CPU set, or None
+    when nothing was changed."""
     global _original_mask
     if os.environ.get("GS_PIN_HOST_THREADS", "1") == "0" or not hasattr(os, "sched_setaffinity"):
         return None
@@ -98,7 +99,8 @@ def pin_host_threads(device_index: int = 0, slot: Optional[int] = None) -> Optio
     if not groups:
         return None
     if slot is None:
-        slot = int(os.environ.get("LOCAL_RANK", "0"))
+        rank = os.environ.get("LOCAL_RANK", "")
+        slot = int(rank) if rank.isdigit() else int(device_index)
     chosen = groups[slot % len(groups)]
     if len(chosen) >= len(allowed):
         return None   # already that narrow

@@ -188,6 +188,8 @@ def test_host_affinity_picks_one_l3_complex_per_local_rank(monkeypatch):
         assert calls == [(101, chosen), (102, chosen)]
         assert torch.get_num_threads() == min(before, 4)            # four cores behind the eight hardware threads
         assert h.pin_host_threads(0, slot=0) == {8, 9, 10, 11, 24, 25, 26, 27}
+        monkeypatch.delenv("LOCAL_RANK")
+        assert h.pin_host_threads(1) == chosen and h.pin_host_threads(0) == {8, 9, 10, 11, 24, 25, 26, 27}   # no launcher: by device
         del calls[:]
         h.unpin_host_threads()
         assert calls == [(101, set(range(32))), (102, set(range(32)))] and torch.get_num_threads() == before
