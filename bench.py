@@ -117,6 +117,22 @@ def profiled_counters(kernel: str):
     return traffic, valu
 
 
+def self_launch(n_ranks: int) -> int:
+    """Re-run this command line as `n_ranks` processes (torch.distributed.run, one per GPU of this node, rendezvous on
+    127.0.0.1 at a free port); the children see WORLD_SIZE and take the normal path.  Returns the launcher's exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # the host driver only supports dmabuf IPC (RCCL needs it)
+    env.setdefault("OMP_NUM_THREADS", "8")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_ranks),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -126,8 +142,12 @@ def main() -> None:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-stage-profile", action="store_true")
     ap.add_argument("--no-hook", action="store_true", help="time the backward without a backward hook")
-    ap.add_argument("--hook-feature-copy", action="store_true",
-                    help="the hook also receives the [M,56] compact copy of the feature gradients (RAS:1132)")
+    ap.add_argument("--hook-feature-copy", action="store_true", help="(default since round 4; kept for old command lines)")
+    ap.add_argument("--no-hook-feature-copy", action="store_true",
+                    help="the hook does not receive the [M,56] compact copy of the feature gradients (RAS:1132) -- how "
+                         "GaussianPointTrainer configures the operator between densifications.  The default line times "
+                         "the DEFAULT operator (copy on, as the reference always gathers it, RAS:1131-1133) and reports "
+                         "this variant beside it (`variants`)")
     ap.add_argument("--forward-only", action="store_true", help="inference line: forward under no_grad")
     ap.add_argument("--rgb-only", action="store_true", help="with --forward-only: the reference's rgb_only config")
     ap.add_argument("--shard-mode", default="bands", choices=["bands", "interleaved"])
@@ -148,14 +168,22 @@ def main() -> None:
     from taichi_3d_gaussian_splatting_amd.distributed import shard_rasteriser_across_tile_rows
     from taichi_3d_gaussian_splatting_amd.synthetic import make_config_scene, make_grad_image
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: launch the ranks ourselves -- one process per GPU under torch.distributed.run
+        # on 127.0.0.1 (the container's hostname may not resolve), RCCL backend -- and relay rank 0's line
+        raise SystemExit(self_launch(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the launcher's --nproc-per-node must equal --gpus")
     assert torch.cuda.is_available(), "bench.py needs HIP devices"
     # one rank per GPU.  (Test hook: with fewer devices than ranks -- a 1-GPU box -- ranks share devices, which
     # RCCL refuses, so GS_BENCH_DIST_BACKEND=gloo lets the multi-rank plumbing be exercised there.)
+    backend = os.environ.get("GS_BENCH_DIST_BACKEND", "nccl")  # nccl == RCCL on ROCm
+    if world > 1 and backend == "nccl" and world > torch.cuda.device_count():
+        raise SystemExit(f"--gpus {world} but this node exposes {torch.cuda.device_count()} GPU(s): RCCL needs one device "
+                         f"per rank")
     device_index = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(device_index)
     device = torch.device("cuda", device_index)
@@ -166,7 +194,6 @@ def main() -> None:
     pinned = None if args.no_pin else host_affinity.pin_host_threads(device_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        backend = os.environ.get("GS_BENCH_DIST_BACKEND", "nccl")  # nccl == RCCL on ROCm
         if backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=device)
         else:
@@ -181,7 +208,9 @@ def main() -> None:
     hook_calls = []
     hook = None if (args.no_hook or args.forward_only) else (lambda h: hook_calls.append(1))
     op = Op(cfg, backward_valid_point_hook=hook)
-    op.hook_feature_gradients = bool(args.hook_feature_copy)   # GaussianPointTrainer: only on densification iterations
+    # the operator's default (True): the reference always gathers the [M,56] field (RAS:1131-1133).  The trainer switches
+    # it off between densifications: that variant is timed as well and reported in `variants`
+    op.hook_feature_gradients = not args.no_hook_feature_copy
     if world > 1:
         shard_rasteriser_across_tile_rows(op, mode=args.shard_mode)
     xyz = s.point_cloud.clone().requires_grad_(True)
@@ -213,27 +242,40 @@ def main() -> None:
     # pay the write every frame, as training does (same memory contents).  --static-scene: the skip stays.
     op.always_store_normalised_rotation = not args.static_scene
 
-    for i in range(args.warmup):
-        step()
-    fence()
-    # two events per step on torch's current stream (= the stream every kernel is launched on)
-    begins = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
-    ends = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        begins[i].record()
-        step()
-        ends[i].record()
-    fence()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    ms_per_step = 1e3 * elapsed / args.steps
-    per_step = sorted(begins[i].elapsed_time(ends[i]) for i in range(args.steps))
-    step_ms = {"median": round(per_step[len(per_step) // 2], 4),
-               "p90": round(per_step[int(0.9 * (len(per_step) - 1))], 4), "min": round(per_step[0], 4)}
+    def timed_run(warmup, steps):
+        """-> (wall-clock ms per step, max over ranks; {median, p90, min} of the per-step HIP-event times)"""
+        for _ in range(warmup):
+            step()
+        fence()
+        # two events per step on torch's current stream (= the stream every kernel is launched on)
+        begins = [torch.cuda.Event(enable_timing=True) for _ in range(steps)]
+        ends = [torch.cuda.Event(enable_timing=True) for _ in range(steps)]
+        t0 = time.perf_counter()
+        for i in range(steps):
+            begins[i].record()
+            step()
+            ends[i].record()
+        fence()
+        elapsed = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        per_step = sorted(begins[i].elapsed_time(ends[i]) for i in range(steps))
+        return 1e3 * elapsed / steps, {"median": round(per_step[len(per_step) // 2], 4),
+                                       "p90": round(per_step[int(0.9 * (len(per_step) - 1))], 4),
+                                       "min": round(per_step[0], 4)}
+
+    ms_per_step, step_ms = timed_run(args.warmup, args.steps)
+    # the other hook configuration, same K steps (not the driver's number): the trainer's steady state between
+    # densifications leaves out the [M,56] hook copy
+    variants = {}
+    if hook is not None and not args.no_hook_feature_copy:
+        op.hook_feature_gradients = False
+        v_ms, v_step = timed_run(min(args.warmup, 5), args.steps)
+        op.hook_feature_gradients = True
+        variants["hook_without_feature_copy"] = {"ms_per_step": round(v_ms, 4), "step_ms": v_step,
+                                                 "value": round(s.height * s.width / 1e6 / (v_ms / 1e3), 3)}
     pixels = s.height * s.width
     value = pixels / 1e6 / (ms_per_step / 1e3)
 
@@ -308,16 +350,28 @@ def main() -> None:
             k_tile = int(hip_ops.scan_block_sums(bs_t, counters_t, bsf_t)[0])
         sizes = {"N": n, "M": m, "K": int(k), "K_tile": k_tile, "P": pixels,
                  "tiles": (s.width // 16) * (s.height // 16), "bin_shift": layout.bin_shift}
-        stages_ms = {name: sum(a.elapsed_time(b) for a, b in pairs[1:]) / max(len(pairs) - 1, 1)
-                     for name, pairs in acc_ms.items()}
+        def median_ms(pairs):   # median over the repetitions after the first (one slow outlier must not name a stage)
+            t = sorted(a.elapsed_time(b) for a, b in (pairs[1:] or pairs))
+            return t[len(t) // 2]
+        stages_ms = {name: median_ms(pairs) for name, pairs in acc_ms.items()}
         p_owned = pixels if world == 1 else pixels * len(layout.owned_rows(s.height)) / (s.height // 16)
         bytes_per = algorithmic_bytes(n, m, int(k), p_owned, 4 if kdb > 0 else 8, k_tile)
         backward_stages = ("blend_backward", "reduce_partials", "point_backward")
         bytes_per = {k_: v for k_, v in bytes_per.items() if k_ in stages_ms}
         timed_stages = [k_ for k_ in stages_ms if not (args.forward_only and k_ in backward_stages)]
-        dominant = max(timed_stages, key=stages_ms.get)
+        # a stage whose (median) time exceeds the whole step was disturbed in this stage-by-stage profile (it is
+        # launched between events, with blocking size reads the operator does not have): it cannot be the dominant kernel
+        sane = [k_ for k_ in timed_stages if stages_ms[k_] <= ms_per_step] or timed_stages
+        dominant = max(sane, key=stages_ms.get)
         achieved = bytes_per[dominant] / (stages_ms[dominant] * 1e-3) / 1e9
         path_bytes = sum(bytes_per[k_] for k_ in timed_stages)   # the stages inside the timed step
+        # the same sum with SURVEY 8(d)'s literal accounting: K = the reference's binning (one key per (tile, Gaussian) of
+        # the tile boxes, no exact cull, no bins = the backward's slot count), 8-byte keys, B = 266 N + 744 M + 136 K + 56 P
+        k_ref = int(n_slots)
+        survey_bytes = (18 * n + 368 * m + 92 * k_ref + 28 * p_owned) if args.forward_only else \
+            (266 * n + 744 * m + 136 * k_ref + 56 * p_owned)
+        # forward blend: entries a tile actually stages before every pixel of it has stopped (what the backward will walk)
+        visited = int(tile_work.sum().item()) if op.ordered_dispatch else None
         # heavy-list scenes: the blend kernels leave a tile's list after a few entries (stress scene: 13 of 5,628), the
         # accounting charges them for whole lists -- the path figure is then not a bound on anything
         path_meaningful = k_tile <= 64 * max(m, 1)
@@ -349,8 +403,15 @@ def main() -> None:
             "valu": valu,
             "path": {"algorithmic_bytes": int(path_bytes),
                      "achieved": round(path_bytes / (ms_per_step * 1e-3) / 1e9, 2),
-                     "frac": round(path_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)} if path_meaningful
-            else None,
+                     "frac": round(path_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                     "survey_8d_literal": {"K_reference_binning": k_ref, "algorithmic_bytes": int(survey_bytes),
+                                           "achieved": round(survey_bytes / (ms_per_step * 1e-3) / 1e9, 2),
+                                           "frac": round(survey_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}}
+            if path_meaningful else None,
+            "blend_forward_bytes": None if visited is None else {
+                "whole_lists": int(48 * k_tile + 28 * p_owned), "visited_entries": visited,
+                "visited": int(48 * visited + 28 * p_owned),
+                "achieved_visited": round((48 * visited + 28 * p_owned) / (stages_ms["blend_forward"] * 1e-3) / 1e9, 2)},
             "hbm_stage_furthest_from_bound": None if worst is None else {
                 "stage": worst, "stage_ms": round(stages_ms[worst], 4), "algorithmic_bytes": int(bytes_per[worst]),
                 "achieved": round(bytes_per[worst] / (stages_ms[worst] * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS,
@@ -395,11 +456,13 @@ def main() -> None:
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": args.workload, "gaussians": n, "image": f"{s.width}x{s.height}",
                        "sh_degree": 3, "sharding": "none" if world == 1 else f"tile-row {args.shard_mode}/{world}",
-                       "backward_hook": hook is not None, "hook_feature_copy": bool(hook is not None and args.hook_feature_copy),
+                       "ranks_seen_by_backend": dist.get_world_size() if world > 1 else 1,
+                       "backend": (backend if world > 1 else None),
+                       "backward_hook": hook is not None, "hook_feature_copy": bool(hook is not None and not args.no_hook_feature_copy),
                        "forward_only": args.forward_only, "training_like": not args.static_scene,
                        "rgb_only": bool(cfg.rgb_only), "speculation": dict(op.speculation_stats),
                        "host_threads_on_cpus": None if pinned is None else len(pinned), **sizes},
-            "step_ms": step_ms,
+            "step_ms": step_ms, "variants": variants,
             "roofline": roofline, "cpu_baseline": cpu_baseline,
         }
         print(json.dumps(out), flush=True)

@@ -52,7 +52,15 @@ SCENES = {
     # oracle and of the HIP path.  Shows that the tie rule is the only difference on scenes with ties.
     "h_200pts_32x32_tied_keys_stable_sort": (dict(n=200, height=32, width=32, s_min=0.05, s_max=0.3, sh_degree=3, seed=5),
                                              3, dict(depth_to_sort_key_scale=20.0), None),
+    # NOT A TOY (round 4): 2,400 Gaussians over a 320 x 320 image = 400 tiles (about 250 of them non-empty, 5,000+ list
+    # entries, a few invalid rows); tie-free at a depth scale of 1e7.  About two hours of emulation.
+    "i_2400pts_320x320_400_tiles": (dict(n=2400, height=320, width=320, s_min=0.005, s_max=0.03, sh_degree=3, seed=41,
+                                         invalid_fraction=0.03), 3, dict(depth_to_sort_key_scale=1.0e7), None),
 }
+# forward outputs and integer fields of a regenerated archive must be bit-identical to the committed one (the gradients
+# are sums of fp32 atomic adds in OS-thread order: reproducible to ~1e-6 only, as on a GPU)
+BITWISE_FIELDS = ("image", "depth", "count", "features_after_forward", "hook_point_id", "hook_num_overlap_tiles",
+                  "hook_num_affected_pixels", "hook_depth", "hook_uv")
 STABLE_SORT_PATCH = ("point_in_camera_sort_key.sort()", "point_in_camera_sort_key.sort(stable=True)")
 
 
@@ -118,7 +126,16 @@ def main():
             hook_magnitude_image=h.magnitude_grad_viewspace_on_image.numpy(),
             hook_num_overlap_tiles=h.num_overlap_tiles.numpy(), hook_num_affected_pixels=h.num_affected_pixels.numpy(),
             hook_depth=h.point_depth.numpy(), hook_uv=h.point_uv_in_camera.numpy())
-        np.savez_compressed(os.path.join(HERE, f"reference_operator_{name}.npz"), **out)
+        path = os.path.join(HERE, f"reference_operator_{name}.npz")
+        if os.path.exists(path):
+            old = np.load(path)
+            for key in BITWISE_FIELDS:
+                assert np.array_equal(old[key], out[key]), f"{name}: {key} differs from the committed archive"
+            for key in ("grad_xyz", "grad_feat"):
+                d = np.abs(old[key] - out[key]).max()
+                assert d <= 1e-4 * max(1.0, np.abs(old[key]).max()), (name, key, d)
+            print(f"{name}: forward and integer fields bit-identical to the committed archive")
+        np.savez_compressed(path, **out)
         print(f"{name}: forward {t1 - t0:.1f} s, backward {t2 - t1:.1f} s, M={len(out['hook_point_id'])}, "
               f"mean image {out['image'].mean():.4f}, max count {out['count'].max()}")
 
