@@ -274,7 +274,11 @@ def test_list_layouts_are_output_identical(ops, scene, ofwd, obwd):
     (1, 17, 13, False), (2, 17, 13, True), (257, 8, 3, True), (5000, 17, 13, False), (5000, 17, 13, True),
     (70_000, 9, 5, True), (300_001, 64, 13, False), (300_001, 19, 13, True),
     # above 512 x 4,096 keys the sort runs its large workgroups (16 rounds per wave), below the small ones (4)
-    (2_097_151, 13, 11, True), (2_300_003, 13, 11, True), (2_200_001, 17, 13, False)])
+    (2_097_151, 13, 11, True), (2_300_003, 13, 11, True), (2_200_001, 17, 13, False),
+    # round 4 (single-sweep passes): more tiles than CUs -- the launch runs in several waves of workgroups -- in both
+    # key widths, and one key short / one key over a tile boundary of every tile size (1024 x {1, 2, 4, 8, 11})
+    (3_500_003, 11, 11, True), (2_400_001, 17, 13, False), (1024 * 11 * 7, 8, 8, True), (1024 * 8 * 31 + 1, 8, 8, True),
+    (1024 * 4 * 100 - 1, 10, 6, True), (1024 * 2 * 200 + 1, 16, 16, True), (1024 * 255, 3, 3, True)])
 def test_radix_sort_stable_vs_numpy(ops, n, depth_bits, tile_bits, compressed):
     rng = np.random.default_rng(n)
     if depth_bits == 64:  # negative depths: the full signed key is sorted
@@ -297,6 +301,21 @@ def test_radix_sort_stable_vs_numpy(ops, n, depth_bits, tile_bits, compressed):
     order = np.argsort(keys, kind="stable")
     assert np.array_equal(got, keys[order])
     assert np.array_equal(p.cpu().numpy(), payload[order])
+
+
+@pytest.mark.parametrize("n,capacity", [(100_000, 131_072), (700_001, 1_000_000), (2_900_000, 3_774_096), (0, 5000)])
+def test_radix_sort_with_the_count_on_the_device(ops, n, capacity):
+    """Speculative frames sort `*n_keys_device` pairs of a capacity-sized buffer (grids and tiles follow the capacity):
+    the first n pairs come out stably sorted, nothing past them is read as a key."""
+    rng = np.random.default_rng(capacity)
+    keys = rng.integers(0, 1 << 22, size=capacity).astype(np.uint32)
+    payload = np.arange(capacity, dtype=np.int32)
+    k, p = dev(keys.view(np.int32)), dev(payload)
+    n_dev = dev(np.array([n], dtype=np.int32))
+    k, p = ops.sort_pairs(k, p, 11, 11, 11, in_place=False, n_keys_device=n_dev)
+    order = np.argsort(keys[:n], kind="stable")
+    assert np.array_equal(k.cpu().numpy().view(np.uint32)[:n], keys[:n][order])
+    assert np.array_equal(p.cpu().numpy()[:n], payload[:n][order])
 
 
 def test_find_tile_start_and_end_known_answer(ops):
