@@ -267,6 +267,37 @@ int gs_compact_rows(const float *acc, const int32_t *num_keys, int n_visible, in
 int gs_merge_rows(const int32_t *lists, int64_t list_stride_words, int capacity, const int32_t *counts, int world,
                   int n_visible, float *acc, void *stream);
 
+
+/* ---- Multi-GPU with OWNER-SHARDED Gaussians (routed exchange on top of the tile-row bands; no reference counterpart).
+ * Rank g owns a contiguous block of point-cloud rows, projects only those (gs_filter_compact / gs_preprocess on its block
+ * with full-image ownership), and sends each projected 64-B record to the band(s) whose tile rows its tile box reaches:
+ *   gs_route_count   : counts[b] = records this rank sends to band b (bands = equal blocks of rows_per_band tile rows)
+ *   gs_route_scatter : send float[world][capacity + 1][16]: chunk b = header slot {count as int32 bits} + the records for
+ *                      band b in visible-list order; pos int32[world][n_visible_capacity] = slot (0-based, without the
+ *                      header) of record i in chunk b, -1 = not sent there.  The chunks are exchanged with one all-to-all
+ *                      (equal splits).  Only records with num_keys[i] > 0 travel (the others are incomplete).
+ *   gs_count_keys    : the receiving band's per-record counts (sort keys on its rows, reference box count, depth range)
+ *                      over the received buffer taken as an attrs array of world x (capacity + 1) records, headers and
+ *                      unused slots counting as Gaussians without keys -- then gs_scan_block_sums2 / gs_make_keys / ... run
+ *                      on that buffer unchanged; counters must be zeroed by the caller; counters[GS_COUNTER_NUM_VISIBLE]
+ *                      is set to n_slots.
+ *   gs_gather_returned_rows : backward.  The band's accumulators float[world x (capacity + 1)][12] go back through the
+ *                      same all-to-all; the owner sums, per record, the rows returned by its bands in band order.
+ * workspace: gs_route_workspace_bytes(n_visible_capacity, world), shared by gs_route_count and the gs_route_scatter that
+ * follows it (the scatter reads the offsets the count left there). */
+size_t gs_route_workspace_bytes(int n_visible_capacity, int world);
+int gs_route_count(const float *attrs, const int32_t *num_keys, int n_visible_capacity, const int32_t *counters,
+                   int width, int height, int rows_per_band, int world, int32_t *counts, void *workspace, void *stream);
+int gs_route_scatter(const float *attrs, const int32_t *num_keys, int n_visible_capacity, const int32_t *counters,
+                     int width, int height, int rows_per_band, int world, int capacity, const int32_t *counts,
+                     float *send, int32_t *pos, void *workspace, void *stream);
+int gs_count_keys(const float *records, int n_slots, int chunk_slots, int width, int height, int tile_row_begin,
+                  int tile_row_step, int tile_row_end, int bin_shift, int exact_tile_cull, float depth_scale,
+                  int32_t *counters, int32_t *num_overlap_tiles, int32_t *num_keys, int32_t *block_sums,
+                  int32_t *block_sums_full, void *stream);
+int gs_gather_returned_rows(const float *returned, const int32_t *pos, int n_visible, int n_visible_capacity, int world,
+                            int capacity, float *acc, void *stream);
+
 /* Backward per-point pass + gradient post-processing.  Replaces the per-point loop of
  * gaussian_point_rasterisation_backward (RAS:707-772), the dense zero-initialisation
  * (RAS:1051-1053), _clear_grad_by_color_max_sh_band (RAS:1167-1182) and the factor scaling

@@ -17,7 +17,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # GS_LIB_PATH: development knob (tuning sweeps load differently built variants of the library); default = in-tree build
 LIB_PATH = os.environ.get("GS_LIB_PATH") or os.path.join(_HERE, "libgsplat_hip.so")
-ABI_VERSION = 25
+ABI_VERSION = 26
 
 _c = ctypes
 _P = _c.c_void_p
@@ -48,6 +48,11 @@ _SIGNATURES = {
     "gs_compact_rows_workspace_bytes": (_c.c_size_t, [_I]),
     "gs_compact_rows": (_I, [_P, _P, _I, _I, _P, _P, _P, _P, _P]),
     "gs_merge_rows": (_I, [_P, _I64, _I, _P, _I, _I, _P, _P]),
+    "gs_route_workspace_bytes": (_c.c_size_t, [_I, _I]),
+    "gs_route_count": (_I, [_P, _P, _I, _P, _I, _I, _I, _I, _P, _P, _P]),
+    "gs_route_scatter": (_I, [_P, _P, _I, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P]),
+    "gs_count_keys": (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _P, _P, _P, _P, _P, _P]),
+    "gs_gather_returned_rows": (_I, [_P, _P, _I, _I, _I, _I, _P, _P]),
     "gs_loss_workspace_floats": (_c.c_longlong, [_I, _I]),
     "gs_loss_forward": (_I, [_P, _I, _I, _P, _I, _I, _F, _P, _P, _P, _P]),
     "gs_loss_backward": (_I, [_P, _I, _I, _P, _P, _I, _I, _F, _P, _P, _P, _P, _P]),

@@ -532,6 +532,84 @@ __global__ __launch_bounds__(GS_BLOCK) void preprocess_kernel(
     }
 }
 
+
+// ------------------------------------------------------------------ key count of RECEIVED records (owner-sharded Gaussians)
+// A band that receives projected records from the other ranks (gs_route_scatter; chunks of `chunk` 64-B slots per sending
+// rank, slot 0 of a chunk = header {number of valid records as int32 bits}) needs what gs_preprocess produces next to a
+// record: the number of sort keys it emits on THIS rank's tile rows (the walk of gs_make_keys on the same stored values),
+// the reference's box count (RAS:106-128: its scan gives the backward slots) and the largest quantised depth.  Header
+// slots and the unused tail of a chunk count as Gaussians without keys: the chunked buffer is used as the `attrs` array of
+// every later stage as it lies, in (sending rank, position) order = ascending global point id.
+__global__ __launch_bounds__(GS_BLOCK) void count_keys_kernel(
+    const float *__restrict__ records, int n_slots, int chunk, int width, int height, RowOwner ow, int bin_shift, int cull,
+    float depth_scale, int32_t *__restrict__ counters, int32_t *__restrict__ ntiles_full, int32_t *__restrict__ nkeys,
+    int32_t *__restrict__ block_sums, int32_t *__restrict__ block_sums_full) {
+    __shared__ int s_sum, s_sum_full, s_dq;
+    __shared__ BinWalkRec s_rec[GS_BLOCK];
+    __shared__ int s_cnt[GS_BLOCK];
+    if (threadIdx.x == 0) { s_sum = 0; s_sum_full = 0; s_dq = 0; }
+    s_cnt[threadIdx.x] = 0;
+    __syncthreads();
+    const int i = blockIdx.x * GS_BLOCK + threadIdx.x;
+    bool live = false;
+    if (i < n_slots) {
+        const int src = i / chunk, j = i - src * chunk;
+        const int valid = __builtin_bit_cast(int, records[(size_t)GS_ATTR_STRIDE * src * chunk]);
+        live = j >= 1 && j <= valid;
+    }
+    int owned = 0, full = 0, dq = 0;
+    float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0;
+    int t0u = 0, t1u = 0, t0v = 0, t1v = 0;
+    if (live) {
+        a0 = reinterpret_cast<const float4 *>(records + (size_t)GS_ATTR_STRIDE * i)[0];
+        a1 = reinterpret_cast<const float4 *>(records + (size_t)GS_ATTR_STRIDE * i)[1];
+        tile_box(a0.x, a0.y, a1.w, width / GS_TILE_WIDTH, height / GS_TILE_HEIGHT, t0u, t1u, t0v, t1v);
+        full = (t1u - t0u) * (t1v - t0v);
+        dq = (int32_t)(a0.z * depth_scale);
+        if (cull) gs_cull_box(a0.x, a0.y, a1.x, a1.y, a1.z, a0.w, t0u, t1u, t0v, t1v);   // as gs_preprocess / gs_make_keys
+    }
+    {
+        BinWalkRec *recs = s_rec + (threadIdx.x & ~(GS_WAVE - 1));
+        int *cnts = s_cnt + (threadIdx.x & ~(GS_WAVE - 1));
+        const int npairs = make_walk_rec(s_rec[threadIdx.x], live, a0.x, a0.y, a1.x, a1.y, a1.z, a0.w, t0u, t1u, t0v, t1v,
+                                         bin_shift, ow);
+        if (gs_mostly_heavy_wave(npairs)) {
+            if (live)
+                for_each_emitting_bin(t0u, t1u, t0v, t1v, bin_shift, ow, cull, a0.x, a0.y, a1.x, a1.y, a1.z, a0.w,
+                                      [&](int, int) { ++owned; });
+        } else {
+            walk_bins_balanced(recs, npairs, bin_shift, ow, cull, [&](int owner, int, int, bool survives) {
+                if (survives) atomicAdd(&cnts[owner], 1);
+            });
+            owned = cnts[gs_lane()];
+        }
+    }
+    if (i < n_slots) {
+        ntiles_full[i] = full;
+        nkeys[i] = owned;
+    }
+    int s = owned, sf = full;
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) {
+        s += __shfl_xor(s, d, GS_WAVE);
+        sf += __shfl_xor(sf, d, GS_WAVE);
+        dq = max(dq, __shfl_xor(dq, d, GS_WAVE));
+    }
+    if (gs_lane() == 0) {
+        if (s != 0) atomicAdd(&s_sum, s);
+        if (sf != 0) atomicAdd(&s_sum_full, sf);
+        if (dq > 0) atomicMax(&s_dq, dq);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        block_sums[blockIdx.x] = s_sum;
+        block_sums_full[blockIdx.x] = s_sum_full;
+        if (s_dq > __hip_atomic_load(&counters[GS_COUNTER_MAX_DEPTH_KEY], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+            atomicMax(&counters[GS_COUNTER_MAX_DEPTH_KEY], s_dq);
+        if (blockIdx.x == 0) counters[GS_COUNTER_NUM_VISIBLE] = n_slots;   // what the later stages index by
+    }
+}
+
 // ------------------------------------------------------------------ key generation
 // RAS:131-172 generate_point_sort_key_by_num_overlap_tiles
 // KeyT = uint64_t: reference layout (tile << 32) + int32 depth.  KeyT = uint32_t: compressed layout
@@ -721,6 +799,24 @@ int gs_preprocess(const float *xyz, float *features, const int32_t *object_id, c
                        n_visible_on_device, width, height, RowOwner{tile_row_begin, tile_row_step, tile_row_end},
                        bin_shift, exact_tile_cull, always_store_rotation, depth_scale, counters, attrs, num_overlap_tiles,
                        num_keys, block_sums, block_sums_full);
+    GS_CHECK_LAUNCH();
+    return 0;
+}
+
+
+int gs_count_keys(const float *records, int n_slots, int chunk_slots, int width, int height, int tile_row_begin,
+                  int tile_row_step, int tile_row_end, int bin_shift, int exact_tile_cull, float depth_scale,
+                  int32_t *counters, int32_t *num_overlap_tiles, int32_t *num_keys, int32_t *block_sums,
+                  int32_t *block_sums_full, void *stream) {
+    GS_REQUIRE(n_slots >= 0 && chunk_slots >= 1 && n_slots % chunk_slots == 0, "n_slots must be a whole number of chunks");
+    GS_REQUIRE(tile_row_step >= 1 && tile_row_begin >= 0 && tile_row_end >= 0, "tile row ownership");
+    GS_REQUIRE(bin_shift >= 0 && bin_shift <= 4, "bin_shift");
+    GS_REQUIRE(width % GS_TILE_WIDTH == 0 && height % GS_TILE_HEIGHT == 0, "image size must be a multiple of 16");
+    GS_REQUIRE(counters != nullptr, "counters");
+    if (n_slots == 0) return 0;
+    hipLaunchKernelGGL(count_keys_kernel, dim3(gs_div_up(n_slots, GS_BLOCK)), dim3(GS_BLOCK), 0, (hipStream_t)stream, records,
+                       n_slots, chunk_slots, width, height, RowOwner{tile_row_begin, tile_row_step, tile_row_end}, bin_shift,
+                       exact_tile_cull, depth_scale, counters, num_overlap_tiles, num_keys, block_sums, block_sums_full);
     GS_CHECK_LAUNCH();
     return 0;
 }

@@ -153,6 +153,134 @@ __global__ __launch_bounds__(GS_BLOCK) void rows_merge_kernel(const int32_t *__r
     }
 }
 
+
+// =================================================================== owner-sharded Gaussians: routed exchange (round 4)
+// Tile-row bands shard the pixels; with a replicated point cloud every rank still projects all N points and back-propagates
+// all M visible ones.  Here rank g OWNS rows [N g / G, N (g+1) / G) of the point cloud (contiguous: the concatenation of the
+// ranks' visible lists in rank order is the un-sharded visible list, so the stable tie order is unchanged), projects only
+// those, and ROUTES each 64-B record to the band(s) its tile box touches; a band blends what it receives, and returns one
+// 48-B accumulator row per received record to its owner, which runs the per-point backward on its own rows: per-Gaussian
+// work and parameters never replicate, gradients and optimiser state never cross a link.
+//   gs_route_count    per destination band: number of records this rank sends (ordered-compaction counts per workgroup +
+//                     their scan); the header of each send chunk
+//   gs_route_scatter  copies each record into the chunk of every band it touches, in visible-list order, and remembers
+//                     the position (pos[band][i]) for the way back
+//   gs_gather_returned_rows   owner side of the backward exchange: acc[i] = sum over bands, in band order, of the row
+//                     returned for record pos[band][i] -- a fixed order: bitwise reproducible
+// Send / receive buffers: float[world][capacity + 1][16] (forward; slot 0 of a chunk is the header {count as int32 bits})
+// and float[world][capacity + 1][12] (backward, same slots).  Fixed-size chunks: one all_to_all with equal splits.
+constexpr int ROUTE_MAX_WORLD = 64;
+
+// bands [b0, b1] whose tile rows the Gaussian's tile box (RAS:81-103, shrunk to the alpha >= 1/255 level set's bounding box
+// when the exact cull is on: attrs[3] < inf) reaches.  The receiving band walks the same box, so nothing it would emit a
+// key for is missing.
+__device__ __forceinline__ bool route_bands(const float4 a0, const float4 a1, int tw, int th, int rows_per_band, int &b0,
+                                            int &b1) {
+    int t0u, t1u, t0v, t1v;
+    gs_tile_box(a0.x, a0.y, a1.w, tw, th, t0u, t1u, t0v, t1v);
+    gs_cull_box(a0.x, a0.y, a1.x, a1.y, a1.z, a0.w, t0u, t1u, t0v, t1v);
+    if (t1u <= t0u || t1v <= t0v) return false;
+    b0 = t0v / rows_per_band;
+    b1 = (t1v - 1) / rows_per_band;
+    return true;
+}
+
+template <bool SCATTER>
+__global__ __launch_bounds__(GS_BLOCK) void route_kernel(
+    const float4 *__restrict__ attrs, const int32_t *__restrict__ num_keys, int m_capacity,
+    const int32_t *__restrict__ counters, int width, int height, int rows_per_band, int world, int nblk,
+    int32_t *__restrict__ block_counts /* [world][nblk]: counts (SCATTER = false) / exclusive offsets (true) */,
+    int capacity, float4 *__restrict__ send, int32_t *__restrict__ pos) {
+    __shared__ int s_cnt[GS_BLOCK / GS_WAVE][ROUTE_MAX_WORLD];
+    const int m = counters ? min(counters[GS_COUNTER_NUM_VISIBLE], m_capacity) : m_capacity;
+    const int i = blockIdx.x * GS_BLOCK + threadIdx.x, w = threadIdx.x >> 6;
+    int b0 = 0, b1 = -1;
+    float4 rec[4];
+    if (i < m && num_keys[i] > 0) {   // (num_keys == 0: the record is incomplete and can contribute nowhere)
+        rec[0] = attrs[4 * (size_t)i];
+        rec[1] = attrs[4 * (size_t)i + 1];
+        if (!route_bands(rec[0], rec[1], width / GS_TILE_WIDTH, height / GS_TILE_HEIGHT, rows_per_band, b0, b1)) { b0 = 0; b1 = -1; }
+        b1 = min(b1, world - 1);
+        if (SCATTER && b1 >= b0) { rec[2] = attrs[4 * (size_t)i + 2]; rec[3] = attrs[4 * (size_t)i + 3]; }
+    }
+    for (int b = 0; b < world; ++b) {
+        const unsigned long long bal = __builtin_amdgcn_ballot_w64(b0 <= b && b <= b1);
+        if (gs_lane() == 0) s_cnt[w][b] = __popcll(bal);
+    }
+    __syncthreads();
+    if (!SCATTER) {
+        if ((int)threadIdx.x < world) {
+            int c = 0;
+#pragma unroll
+            for (int k = 0; k < GS_BLOCK / GS_WAVE; ++k) c += s_cnt[k][threadIdx.x];
+            block_counts[(size_t)threadIdx.x * nblk + blockIdx.x] = c;
+        }
+        return;
+    }
+    for (int b = 0; b < world; ++b) {
+        const bool goes = b0 <= b && b <= b1;
+        const unsigned long long bal = __builtin_amdgcn_ballot_w64(goes);
+        int p = -1;
+        if (goes) {
+            p = block_counts[(size_t)b * nblk + blockIdx.x] + gs_mbcnt(bal);
+#pragma unroll
+            for (int k = 0; k < GS_BLOCK / GS_WAVE; ++k) p += k < w ? s_cnt[k][b] : 0;
+            if (p < capacity) {
+                float4 *dst = send + ((size_t)b * (capacity + 1) + 1 + p) * 4;
+                dst[0] = rec[0]; dst[1] = rec[1]; dst[2] = rec[2]; dst[3] = rec[3];
+            } else {
+                p = -1;   // (the host sees the overflow in the counts and repeats the exchange with a larger capacity)
+            }
+        }
+        if (i < m_capacity) pos[(size_t)b * m_capacity + i] = p;
+    }
+}
+
+// workgroup b: exclusive scan of band b's per-workgroup counts (in place), total -> counts[b] and the chunk's header
+__global__ __launch_bounds__(GS_BLOCK) void route_scan_kernel(int32_t *__restrict__ block_counts, int nblk,
+                                                             int32_t *__restrict__ counts) {
+    __shared__ int lds[4];
+    int32_t *row = block_counts + (size_t)blockIdx.x * nblk;
+    int carry = 0;
+    for (int base = 0; base < nblk; base += GS_BLOCK) {
+        const int i = base + threadIdx.x;
+        const int v = i < nblk ? row[i] : 0;
+        int total;
+        const int ex = gs_block_excl_scan(v, &total, lds);
+        if (i < nblk) row[i] = carry + ex;
+        carry += total;
+    }
+    if (threadIdx.x == 0) counts[blockIdx.x] = carry;
+}
+
+__global__ void route_headers_kernel(const int32_t *__restrict__ counts, int world, int capacity, float4 *__restrict__ send) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < world)
+        send[(size_t)b * (capacity + 1) * 4] = make_float4(__builtin_bit_cast(float, min(counts[b], capacity)), 0.f, 0.f, 0.f);
+}
+
+__global__ __launch_bounds__(GS_BLOCK) void gather_returned_kernel(const float4 *__restrict__ returned,
+                                                                 const int32_t *__restrict__ pos, int m, int m_capacity,
+                                                                 int world, int capacity, float4 *__restrict__ acc) {
+    const int i = blockIdx.x * GS_BLOCK + threadIdx.x;
+    if (i >= m) return;
+    float d[10] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    int npix = 0;
+    for (int b = 0; b < world; ++b) {   // band order = rank order: the same additions in the same order on every run
+        const int p = pos[(size_t)b * m_capacity + i];
+        if (p < 0) continue;
+        const float4 *row = returned + ((size_t)b * (capacity + 1) + 1 + p) * 3;
+        const float4 x = row[0], y = row[1], z = row[2];
+        d[0] += x.x; d[1] += x.y; d[2] += x.z; d[3] += x.w;
+        d[4] += y.x; d[5] += y.y; d[6] += y.z; d[7] += y.w;
+        d[8] += z.x; d[9] += z.y;
+        npix += __builtin_bit_cast(int, z.z);   // pixel count: int32 bits, summed as an integer
+    }
+    acc[3 * (size_t)i] = make_float4(d[0], d[1], d[2], d[3]);
+    acc[3 * (size_t)i + 1] = make_float4(d[4], d[5], d[6], d[7]);
+    acc[3 * (size_t)i + 2] = make_float4(d[8], d[9], __builtin_bit_cast(float, npix), 0.f);
+}
+
 }  // namespace
 
 extern "C" {
@@ -188,6 +316,59 @@ int gs_merge_rows(const int32_t *lists, int64_t list_stride_words, int capacity,
     if (n_visible == 0) return 0;
     hipLaunchKernelGGL(rows_merge_kernel, dim3(gs_div_up(n_visible, MERGE_IDS)), dim3(GS_BLOCK), 0, (hipStream_t)stream,
                        lists, (long long)list_stride_words, capacity, counts, world, n_visible,
+                       reinterpret_cast<float4 *>(acc));
+    GS_CHECK_LAUNCH();
+    return 0;
+}
+
+size_t gs_route_workspace_bytes(int n_visible_capacity, int world) {
+    return sizeof(int32_t) * ((size_t)gs_div_up(n_visible_capacity > 0 ? n_visible_capacity : 1, GS_BLOCK) * (size_t)world + 64);
+}
+
+int gs_route_count(const float *attrs, const int32_t *num_keys, int n_visible_capacity, const int32_t *counters, int width,
+                   int height, int rows_per_band, int world, int32_t *counts, void *workspace, void *stream) {
+    GS_REQUIRE(world >= 1 && world <= ROUTE_MAX_WORLD && rows_per_band >= 1 && n_visible_capacity >= 0, "sizes (world <= 64)");
+    hipStream_t s = (hipStream_t)stream;
+    if (n_visible_capacity == 0) {
+        GS_CHECK_HIP(hipMemsetAsync(counts, 0, sizeof(int32_t) * world, s));
+        return 0;
+    }
+    const int nblk = gs_div_up(n_visible_capacity, GS_BLOCK);
+    int32_t *block_counts = (int32_t *)workspace;
+    hipLaunchKernelGGL(route_kernel<false>, dim3(nblk), dim3(GS_BLOCK), 0, s, reinterpret_cast<const float4 *>(attrs),
+                       num_keys, n_visible_capacity, counters, width, height, rows_per_band, world, nblk, block_counts, 0,
+                       (float4 *)nullptr, (int32_t *)nullptr);
+    GS_CHECK_LAUNCH();
+    hipLaunchKernelGGL(route_scan_kernel, dim3(world), dim3(GS_BLOCK), 0, s, block_counts, nblk, counts);
+    GS_CHECK_LAUNCH();
+    return 0;
+}
+
+int gs_route_scatter(const float *attrs, const int32_t *num_keys, int n_visible_capacity, const int32_t *counters,
+                     int width, int height, int rows_per_band, int world, int capacity, const int32_t *counts, float *send,
+                     int32_t *pos, void *workspace, void *stream) {
+    GS_REQUIRE(world >= 1 && world <= ROUTE_MAX_WORLD && rows_per_band >= 1 && n_visible_capacity >= 0 && capacity >= 0,
+               "sizes (world <= 64)");
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(route_headers_kernel, dim3(1), dim3(ROUTE_MAX_WORLD), 0, s, counts, world, capacity,
+                       reinterpret_cast<float4 *>(send));
+    GS_CHECK_LAUNCH();
+    if (n_visible_capacity == 0) return 0;
+    const int nblk = gs_div_up(n_visible_capacity, GS_BLOCK);
+    hipLaunchKernelGGL(route_kernel<true>, dim3(nblk), dim3(GS_BLOCK), 0, s, reinterpret_cast<const float4 *>(attrs),
+                       num_keys, n_visible_capacity, counters, width, height, rows_per_band, world, nblk,
+                       (int32_t *)workspace, capacity, reinterpret_cast<float4 *>(send), pos);
+    GS_CHECK_LAUNCH();
+    return 0;
+}
+
+int gs_gather_returned_rows(const float *returned, const int32_t *pos, int n_visible, int n_visible_capacity, int world,
+                            int capacity, float *acc, void *stream) {
+    GS_REQUIRE(world >= 1 && world <= ROUTE_MAX_WORLD && n_visible >= 0 && n_visible <= n_visible_capacity && capacity >= 0,
+               "sizes (world <= 64)");
+    if (n_visible == 0) return 0;
+    hipLaunchKernelGGL(gather_returned_kernel, dim3(gs_div_up(n_visible, GS_BLOCK)), dim3(GS_BLOCK), 0, (hipStream_t)stream,
+                       reinterpret_cast<const float4 *>(returned), pos, n_visible, n_visible_capacity, world, capacity,
                        reinterpret_cast<float4 *>(acc));
     GS_CHECK_LAUNCH();
     return 0;
