@@ -163,7 +163,7 @@ size_t gs_sort_workspace_bytes(int64_t n_keys);
 int gs_sort_pairs(void *keys, int32_t *payload, void *keys_alt, int32_t *payload_alt,
                   int64_t n_keys, const int32_t *n_keys_device, int key_depth_bits, int depth_bits,
                   int tile_bits, int allow_result_in_alt, void *workspace, void *stream);
-/* The same sort; its first launch (which reads every key once for the digit totals of all passes) also zero-fills
+/* The same sort; its first launch also zero-fills
  * `also_zero` (16-byte aligned, also_zero_bytes % 16 == 0; may be NULL / 0) -- the frame's list ranges ride along instead
  * of a fill launch of their own (gs_tile_ranges with ranges_are_zeroed). */
 int gs_sort_pairs_and_zero(void *keys, int32_t *payload, void *keys_alt, int32_t *payload_alt,

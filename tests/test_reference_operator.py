@@ -26,22 +26,22 @@ import pytest
 import torch
 
 from oracle import gs_oracle as O
-from taichi_3d_gaussian_splatting_amd.synthetic import make_scene
+from taichi_3d_gaussian_splatting_amd.synthetic import SyntheticScene   # (a plain container for the archived inputs)
 
 FILES = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_operator_*.npz")))
 IMAGE_TOL_ORACLE, IMAGE_TOL_HIP = 2e-6, 1e-4
 
 
 def _load(path):
+    """Inputs come from the archive itself (every archive carries its `in_*` fields since round 4; the generator asserts
+    that regenerated forward outputs are bit-identical to the committed ones): nothing of the product builds them."""
     V = np.load(path)
-    s = make_scene(**ast.literal_eval(str(V["kwargs"])))
-    if not np.isnan(float(V["opacity_override"])):
-        s.point_cloud_features[:, 7] = float(V["opacity_override"])
-    if "in_xyz" in V.files:                      # archives that carry their inputs (poses / object ids not from make_scene)
-        s.point_cloud, s.point_cloud_features = torch.from_numpy(V["in_xyz"]), torch.from_numpy(V["in_feat"])
-        s.point_invalid_mask, s.point_object_id = torch.from_numpy(V["in_invalid"]), torch.from_numpy(V["in_object_id"])
-        s.camera_intrinsics = torch.from_numpy(V["in_K"])
-        s.q_pointcloud_camera, s.t_pointcloud_camera = torch.from_numpy(V["in_q"]), torch.from_numpy(V["in_t"])
+    kw = ast.literal_eval(str(V["kwargs"]))
+    s = SyntheticScene(
+        point_cloud=torch.from_numpy(V["in_xyz"]), point_cloud_features=torch.from_numpy(V["in_feat"]),
+        point_invalid_mask=torch.from_numpy(V["in_invalid"]), point_object_id=torch.from_numpy(V["in_object_id"]),
+        camera_intrinsics=torch.from_numpy(V["in_K"]), q_pointcloud_camera=torch.from_numpy(V["in_q"]),
+        t_pointcloud_camera=torch.from_numpy(V["in_t"]), height=int(kw["height"]), width=int(kw["width"]))
     return V, s, ast.literal_eval(str(V["config"])), int(V["band"])
 
 
