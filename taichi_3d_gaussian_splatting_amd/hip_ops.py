@@ -464,6 +464,62 @@ def point_backward(xyz, features, object_id, intrinsics, q_cp, t_cp, t_pc, ids, 
     return grad_xyz, grad_feat, gx_vis, gf_vis
 
 
+# ---------------------------------------------------------------- owner-sharded Gaussians: routed exchange (multi-GPU)
+def route_count(attrs, num_keys, counters, width, height, rows_per_band: int, world: int):
+    """-> (counts i32[world] on the device: records this rank sends to every band, workspace for route_scatter).
+    attrs / num_keys are capacity-sized, the visible count is read from ``counters`` on the device."""
+    dev = attrs.device
+    cap_m = attrs.shape[0]
+    counts = torch.empty(world, dtype=torch.int32, device=dev)
+    ws = torch.empty(_lib.load().gs_route_workspace_bytes(cap_m, world), dtype=torch.uint8, device=dev)
+    call("gs_route_count", ptr(attrs), ptr(num_keys), cap_m, ptr(counters), int(width), int(height), int(rows_per_band),
+         int(world), ptr(counts), ptr(ws), current_stream(dev))
+    return counts, ws
+
+
+def route_scatter(attrs, num_keys, counters, width, height, rows_per_band: int, world: int, capacity: int, counts,
+                  workspace):
+    """-> (send f32[world, capacity + 1, 16]: chunk b = header slot + this rank's records for band b in visible-list
+    order; pos i32[world, M_capacity]: slot of record i in chunk b or -1).  Must follow ``route_count`` on the same
+    inputs (it reads the offsets left in ``workspace``)."""
+    dev = attrs.device
+    cap_m = attrs.shape[0]
+    send = torch.empty((world, capacity + 1, ATTR_STRIDE), dtype=torch.float32, device=dev)
+    pos = torch.empty((world, max(cap_m, 1)), dtype=torch.int32, device=dev)
+    call("gs_route_scatter", ptr(attrs), ptr(num_keys), cap_m, ptr(counters), int(width), int(height), int(rows_per_band),
+         int(world), int(capacity), ptr(counts), ptr(send), ptr(pos), ptr(workspace), current_stream(dev))
+    return send, pos
+
+
+def count_keys(records: torch.Tensor, width, height, layout: ListLayout, depth_to_sort_key_scale,
+               ws: Optional[Workspaces] = None):
+    """Per-record counts of a RECEIVED buffer f32[world, chunk, 16] (see route_scatter), taken as an attrs array of
+    world * chunk records -> (counters i32[8], num_overlap_tiles, num_keys, block_sums, block_sums_full)."""
+    dev = records.device
+    world, chunk = records.shape[0], records.shape[1]
+    n = world * chunk
+    counters = torch.zeros(NUM_COUNTERS, dtype=torch.int32, device=dev)
+    ntiles = torch.empty(n, dtype=torch.int32, device=dev)
+    nkeys = torch.empty(n, dtype=torch.int32, device=dev)
+    nblk = (n + _PRE_BLOCK - 1) // _PRE_BLOCK
+    block_sums = _scratch(ws, "block_sums", nblk, torch.int32, dev)
+    block_sums_full = _scratch(ws, "block_sums_full", nblk, torch.int32, dev)
+    call("gs_count_keys", ptr(records), n, chunk, int(width), int(height), layout.row_begin, layout.row_step,
+         layout.row_end, layout.bin_shift, int(layout.exact_cull), float(depth_to_sort_key_scale), ptr(counters),
+         ptr(ntiles), ptr(nkeys), ptr(block_sums), ptr(block_sums_full), current_stream(dev))
+    return counters, ntiles, nkeys, block_sums, block_sums_full
+
+
+def gather_returned_rows(returned: torch.Tensor, pos: torch.Tensor, n_visible: int, capacity: int) -> torch.Tensor:
+    """Owner side of the backward exchange: returned f32[world, capacity + 1, 12] (chunk b = the accumulator rows band b
+    produced for the records this rank sent it) -> acc f32[n_visible, 12], summed per record in band order."""
+    world = returned.shape[0]
+    acc = torch.empty((n_visible, ACC_STRIDE), dtype=torch.float32, device=returned.device)
+    call("gs_gather_returned_rows", ptr(returned), ptr(pos), int(n_visible), pos.shape[1], world, int(capacity), ptr(acc),
+         current_stream(returned.device))
+    return acc
+
+
 # ---------------------------------------------------------------- adaptive-controller kernels (row F2)
 def ellipsoid_offsets(features: torch.Tensor) -> torch.Tensor:
     """Focal vector of each Gaussian's ellipsoid, f32[n,3] (ADC:10-25)."""

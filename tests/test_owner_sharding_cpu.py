@@ -1,0 +1,70 @@
+"""Host logic of the owner-sharded exchange on CPU (gloo, world size 2 and 3): the chunk all-to-all is a transposition
+(received[s] = rank s's send[me]), its inverse returns every row to the slot it was sent from, the chunk capacity is agreed
+from one size exchange, and the ranks' point blocks partition the cloud in rank order.  The device stages (routing, key
+count, blend) run in tests/test_owner_sharding_gpu.py."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        return sock.getsockname()[1]
+
+
+def _worker(rank, world, port):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from taichi_3d_gaussian_splatting_amd.owner_sharding import _all_to_all_chunks, _chunk_capacity
+        gen = torch.Generator().manual_seed(100 + rank)
+        counts = torch.randint(0, 200, (world,), generator=gen)                 # records for every band
+        mine = torch.cat([counts, torch.tensor([int(counts.sum()) + rank])])    # ... and the visible count
+        sizes = torch.empty((world, world + 1), dtype=torch.int64)
+        dist.all_gather_into_tensor(sizes.view(-1), mine.to(torch.int64))
+        capacity = _chunk_capacity(int(sizes[:, :world].max()))
+        assert capacity % 64 == 0 and capacity >= int(sizes[:, :world].max())
+        # forward: slot j of chunk b carries (sender, band, j); the header carries the count
+        send = torch.full((world, capacity + 1, 16), -1.0)
+        for b in range(world):
+            send[b, 0, 0] = float(counts[b])
+            for j in range(int(counts[b])):
+                send[b, 1 + j, :3] = torch.tensor([float(rank), float(b), float(j)])
+        recv = _all_to_all_chunks(send, None)
+        for s in range(world):
+            n = int(sizes[s, rank])
+            assert int(recv[s, 0, 0]) == n
+            assert torch.equal(recv[s, 1:1 + n, 0], torch.full((n,), float(s)))
+            assert torch.equal(recv[s, 1:1 + n, 1], torch.full((n,), float(rank)))
+            assert torch.equal(recv[s, 1:1 + n, 2], torch.arange(n, dtype=torch.float32))
+        # backward: the band answers slot by slot; the owner finds every answer where it sent the record
+        rows = torch.zeros((world, capacity + 1, 12))
+        rows[:, :, 0] = recv[:, :, 0] * 1000 + recv[:, :, 2]      # f(sender, slot)
+        rows[:, :, 1] = float(rank)                               # the answering band
+        back = _all_to_all_chunks(rows, None)
+        for b in range(world):
+            n = int(counts[b])
+            assert torch.equal(back[b, 1:1 + n, 0], rank * 1000 + torch.arange(n, dtype=torch.float32))
+            assert torch.equal(back[b, 1:1 + n, 1], torch.full((n,), float(b)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_chunk_exchange_is_a_transposition_and_its_inverse(world):
+    mp.spawn(_worker, args=(world, _free_port()), nprocs=world, join=True)
+
+
+def test_point_blocks_partition_the_cloud_in_rank_order():
+    from taichi_3d_gaussian_splatting_amd.owner_sharding import owned_point_rows
+    for n in (0, 1, 7, 1000, 1001, 999_999):
+        for world in (1, 2, 3, 8):
+            blocks = [owned_point_rows(n, r, world) for r in range(world)]
+            assert blocks[0].start == 0 and blocks[-1].stop == n
+            assert all(a.stop == b.start for a, b in zip(blocks, blocks[1:]))
+            assert max(len(b) for b in blocks) - min(len(b) for b in blocks) <= -(-n // world)
