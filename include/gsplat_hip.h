@@ -177,6 +177,12 @@ int gs_tile_ranges(const void *keys_sorted, int64_t n_keys, const int32_t *n_key
                    int key_depth_bits, int32_t *tile_start, int32_t *tile_end, int n_tiles,
                    void *stream);
 
+/* The same with ranges_are_zeroed != 0: the caller has zero-filled both arrays on this stream already (e.g.
+ * gs_sort_pairs_and_zero) -- no fill is issued. */
+int gs_tile_ranges_prezeroed(const void *keys_sorted, int64_t n_keys, const int32_t *n_keys_device,
+                             int key_depth_bits, int32_t *tile_start, int32_t *tile_end, int n_tiles,
+                             int ranges_are_zeroed, void *stream);
+
 /* Enqueues a copy of the device counters into PINNED host memory (no synchronisation): the host keeps launching
  * and waits for its own event when it needs the sizes. */
 int gs_read_counters_async(const int32_t *counters, int32_t *host_counters_pinned, int n, void *stream);
@@ -329,6 +335,72 @@ int gs_point_backward(const float *xyz, const float *features, const int32_t *ob
                       float *grad_xyz_visible, float *grad_features_visible, float *hook_compact,
                       const int32_t *slot_offsets, const int32_t *num_overlap_tiles, const uint8_t *slot_flags,
                       const float *partials, int width, int height, void *stream);
+
+
+/* ---- One entry point per pass (round 4).  A frame is ~25 launches forward and ~5 backward; issued one by one through a
+ * foreign-function interface the HOST becomes the bound on small frames (the reference's 4x / 2x down-sampled first
+ * iterations, TRN:139-148; a rank of a sharded frame).  GsFrame carries every buffer and option of a frame -- the
+ * caller still owns all of them -- and gs_frame_forward / gs_frame_backward run the stages named in `stages`, in the
+ * reference's order, by calling the stage entry points above: same kernels, same arguments, same results as the
+ * stage-by-stage calls.  Sizes that live on the device (M, K) are taken from `counters` exactly as the stage functions do
+ * (n_visible_on_device, n_keys_device): the caller sizes the key buffers (n_keys_capacity) and the key layout
+ * (key_depth_bits / depth_bits / tile_bits) from the previous frame, reads host_counters_pinned after `size_event`
+ * (recorded right behind the asynchronous copy of the counters) and redoes the list stages when the frame did not fit. */
+#define GS_FWD_POSE_INVERSE   (1u << 0)   /* gs_pose_inverse                    UTL:426-432                     */
+#define GS_FWD_FILTER_COMPACT (1u << 1)   /* gs_filter_compact                  RAS:31-78, 841-870              */
+#define GS_FWD_PREPROCESS     (1u << 2)   /* gs_preprocess                      RAS:239-315, 106-128            */
+#define GS_FWD_ROUTE_COUNT    (1u << 3)   /* gs_route_count   (owner-sharded)                                   */
+#define GS_FWD_ROUTE_SCATTER  (1u << 4)   /* gs_route_scatter (owner-sharded)                                   */
+#define GS_FWD_COUNT_KEYS     (1u << 5)   /* gs_count_keys    (owner-sharded: attrs = the received records)     */
+#define GS_FWD_SCAN           (1u << 6)   /* gs_scan_block_sums2                RAS:913-922                     */
+#define GS_FWD_READ_SIZES     (1u << 7)   /* gs_read_counters_async + event     (the size reads of RAS:870,916) */
+#define GS_FWD_MAKE_KEYS      (1u << 8)   /* gs_make_keys                       RAS:131-172                     */
+#define GS_FWD_SORT           (1u << 9)   /* gs_sort_pairs_and_zero             RAS:947-950                     */
+#define GS_FWD_RANGES         (1u << 10)  /* gs_tile_ranges                     RAS:175-193                     */
+#define GS_FWD_BLEND          (1u << 11)  /* gs_blend_forward                   RAS:318-485                     */
+#define GS_BWD_BLEND          (1u << 0)   /* gs_blend_backward                  RAS:531-705                     */
+#define GS_BWD_REDUCE         (1u << 1)   /* gs_reduce_partials                 (the sums of RAS:674-696)       */
+#define GS_BWD_GATHER_RETURNED (1u << 2)  /* gs_gather_returned_rows (owner-sharded)                            */
+#define GS_BWD_POINTS         (1u << 3)   /* gs_point_backward                  RAS:707-772, 1051-1053, 1102-1125 */
+typedef struct GsFrame {
+    /* sizes and options */
+    int32_t n_points, n_objects, width, height;
+    int32_t tile_row_begin, tile_row_step, tile_row_end;
+    int32_t bin_shift, exact_tile_cull, always_store_rotation;
+    int32_t key_depth_bits, depth_bits, tile_bits;
+    int32_t blend_flags;              /* GS_BLEND_* */
+    int32_t need_state;               /* slot_offsets / acc_alpha / last_effective are produced */
+    int32_t color_max_sh_band;
+    int32_t n_visible;                /* backward: M (known to the host by then); forward: ignored (capacity = n_points) */
+    int32_t backward_bin_shift, backward_filter;   /* the backward's list layout (0, 0 on walked lists) */
+    int32_t world, rows_per_band, chunk_capacity;  /* owner-sharded stages */
+    int32_t sorted_in_alt;            /* OUT (GS_FWD_SORT): 1 = the sorted pairs are in keys_alt / payload_alt */
+    float near_plane, far_plane, depth_scale;
+    float grad_q_factor, grad_s_factor, grad_alpha_factor, grad_color_factor, grad_high_order_color_factor;
+    int64_t n_keys_capacity, n_slots, n_records;   /* n_records: owner-sharded, world * (chunk_capacity + 1) */
+    /* inputs (RAS:788-804) */
+    const float *xyz; float *features; const int8_t *invalid_mask; const int32_t *object_id;
+    const float *intrinsics; const float *q_pointcloud_camera; const float *t_pointcloud_camera;
+    /* per-frame state */
+    float *q_camera_pointcloud, *t_camera_pointcloud;
+    int8_t *visible_mask; int32_t *ids; int32_t *counters; int32_t *host_counters_pinned; void *size_event;
+    float *attrs; int32_t *num_overlap_tiles, *num_keys, *block_sums, *block_sums_full;
+    void *keys, *keys_alt; int32_t *payload, *payload_alt, *slot_offsets;
+    int32_t *bin_ranges;              /* int32[2][number of bins]: start, end (16-byte aligned, bins padded to a multiple of 2) */
+    int32_t n_bins, pad0;
+    float *image, *depth, *acc_alpha; int32_t *last_effective, *valid_count;
+    int32_t *tile_order, *tile_work, *walked_list, *walked_start;
+    void *filter_workspace, *sort_workspace, *route_workspace;
+    int32_t *route_counts, *route_pos; float *route_send; const float *records;
+    /* backward */
+    const int32_t *list_start, *list_payload;   /* what the backward walks: bin_ranges + sorted payload, or the walked lists */
+    const float *grad_image; float *partials; uint8_t *slot_flags; float *magnitude_image; int32_t *tile_order_backward;
+    float *acc; const float *returned_rows;
+    float *grad_xyz, *grad_features, *grad_xyz_visible, *grad_features_visible, *hook_compact;
+} GsFrame;
+size_t gs_frame_struct_bytes(void);   /* sizeof(GsFrame): a binding checks its mirror of the struct against it */
+int gs_frame_forward(GsFrame *frame, uint32_t stages, void *stream);
+int gs_frame_backward(GsFrame *frame, uint32_t stages, void *stream);
 
 /* ---- adaptive-controller kernels (not on the per-frame hot path) ---------------- */
 

@@ -182,6 +182,10 @@ class GaussianPointCloudRasterisation(torch.nn.Module):
         # contents).  True = always write: what a training iteration pays -- the optimiser has just moved q -- for
         # benchmarks that time a static scene (bench.py)
         self.always_store_normalised_rotation = False
+        # speculative frames go through ONE C call per pass (gs_frame_forward / gs_frame_backward: the library issues the
+        # ~25 + ~5 launches back to back) instead of one foreign call per stage: same kernels, same arguments, same bits;
+        # what changes is the host time per frame -- which bounds small frames.  False = stage by stage (hip_ops)
+        self.frame_entry_points = True
         self._scratch = hip_ops.Workspaces()   # buffers that do not outlive a call, kept between frames
         self._size_guesses, self._readbacks = {}, {}   # (image size, list layout, planes) -> (key capacity, depth bound)
         self.speculation_stats = {"frames": 0, "redone": 0}
@@ -201,7 +205,21 @@ class GaussianPointCloudRasterisation(torch.nn.Module):
                 if not ctx.saved_tensors:   # forward ran without backward state (nothing differentiable was asked for)
                     return (None,) * 9
                 with _lib.stream_scope(ctx.saved_tensors[0].device):
-                    return _module_function._backward(ctx, *grads)
+                    state = getattr(ctx, "frame_state", None)
+                    if state is None:
+                        return _module_function._backward(ctx, *grads)
+                    if not (ctx.needs_input_grad[0] or ctx.needs_input_grad[1]):  # RAS:1028
+                        return (None,) * 9
+                    from . import frame_path
+                    grad_image = grads[0]
+                    if grad_image is None:  # only depth was used downstream: its gradient is ignored
+                        grad_image = torch.zeros((state.height, state.width, 3), dtype=torch.float32,
+                                                 device=ctx.saved_tensors[0].device)
+                    grad_xyz, grad_feat = frame_path.backward(
+                        outer, state, grad_image, backward_valid_point_hook,
+                        GaussianPointCloudRasterisation.BackwardValidPointHookInput,
+                        backward_valid_point_hook is not None and outer.hook_feature_gradients)
+                    return grad_xyz, grad_feat, None, None, None, None, None, None, None
 
             @staticmethod
             def _forward(ctx, pointcloud, pointcloud_features, point_invalid_mask, point_object_id,
@@ -220,6 +238,41 @@ class GaussianPointCloudRasterisation(torch.nn.Module):
                 q_pc = q_pointcloud_camera.to(torch.float32).contiguous()
                 t_pc = t_pointcloud_camera.to(torch.float32).contiguous()
 
+                rgb_only = bool(cfg.rgb_only)
+                # multi-GPU with the default (un-weighted) bands: outputs are allocated so that the all-gather of the
+                # other ranks' rows runs in place (distributed.all_gather_tile_rows)
+                gathered_rows = 0
+                if outer.image_gather is not None and outer.shard is not None and outer.shard[2] == "bands" and \
+                        outer.shard_row_weights is None:
+                    from .distributed import padded_image_rows
+                    gathered_rows = padded_image_rows(height, outer.shard[1])
+                guess_key = (width, height, layout, cfg.near_plane, cfg.far_plane, cfg.depth_to_sort_key_scale)
+                # one guess per (image size, layout, planes): data sets that mix resolutions keep speculating
+                guess = outer._size_guesses.get(guess_key) if outer.speculative_sizes else None
+                if guess is not None and outer.frame_entry_points and not outer.fused_slot_reduction and \
+                        q_pc.dim() == 2 and t_pc.dim() == 2 and q_pc.shape[0] == t_pc.shape[0] >= 1 and \
+                        q_pc.shape[1] == 4 and t_pc.shape[1] == 3:
+                    # the whole pass through ONE foreign call (frame_path.py); a frame that does not fit its speculative
+                    # capacities falls through to the stage-by-stage path below and is redone with exact sizes
+                    from . import frame_path
+                    image, depth, count, state, host = frame_path.forward(
+                        outer, xyz, pointcloud_features, invalid, obj, intrinsics, q_pc, t_pc, camera_info,
+                        color_max_sh_band, need_state, layout, guess, gathered_rows, outer._counter_readback(xyz.device))
+                    if outer._sizes_arrived(host, layout, width, height, guess, guess_key):
+                        if rgb_only:
+                            depth = torch.zeros((height, width), dtype=torch.float32, device=xyz.device)
+                            count = torch.zeros((height, width), dtype=torch.int32, device=xyz.device)
+                        if outer.image_gather is not None:
+                            outer.image_gather([image] if rgb_only else [image, depth, count])
+                        ctx.mark_non_differentiable(count)
+                        if need_state:
+                            ctx.save_for_backward(xyz, pointcloud_features, state.slab.buf, obj, intrinsics, t_pc)
+                            ctx.frame_state = state
+                            ctx.camera_info = camera_info
+                            ctx.set_materialize_grads(False)
+                        return image, depth, count
+                    outer.speculation_stats["frames"] -= 1   # (counted again by the redo below)
+                    guess = None
                 # RAS:845  (q,t)_camera<-pointcloud
                 q_cp, t_cp = hip_ops.pose_inverse(q_pc, t_pc)
                 # RAS:848-870  frustum filter + ordered compaction; M stays on the device
@@ -240,14 +293,6 @@ class GaussianPointCloudRasterisation(torch.nn.Module):
                 readback = outer._counter_readback(xyz.device)
                 readback.start(counters)
                 num_bins = layout.num_bins(width, height)
-                rgb_only = bool(cfg.rgb_only)
-                # multi-GPU with the default (un-weighted) bands: outputs are allocated so that the all-gather of the
-                # other ranks' rows runs in place (distributed.all_gather_tile_rows)
-                gathered_rows = 0
-                if outer.image_gather is not None and outer.shard is not None and outer.shard[2] == "bands" and \
-                        outer.shard_row_weights is None:
-                    from .distributed import padded_image_rows
-                    gathered_rows = padded_image_rows(height, outer.shard[1])
 
                 def lists_and_blend(attrs_, nkeys_, bsums_, bsums_full_, ntiles_, n_keys_, max_depth_key_, counters_):
                     # RAS:927-945 keys (one per (bin, Gaussian)), RAS:947-950 stable sort, RAS:952-964 list ranges,
@@ -282,9 +327,6 @@ class GaussianPointCloudRasterisation(torch.nn.Module):
                         start_, payload_, blended = blended[5], blended[6], blended[:5]
                     return payload_, slot_offsets_, start_, blended, work_, emit
 
-                guess_key = (width, height, layout, cfg.near_plane, cfg.far_plane, cfg.depth_to_sort_key_scale)
-                # one guess per (image size, layout, planes): data sets that mix resolutions keep speculating
-                guess = outer._size_guesses.get(guess_key) if outer.speculative_sizes else None
                 result = None
                 if guess is not None:
                     result = lists_and_blend(attrs, num_owned_tiles, block_sums, block_sums_full, num_overlap_tiles,
@@ -293,50 +335,8 @@ class GaussianPointCloudRasterisation(torch.nn.Module):
                 m, n_keys, n_slots = (host[hip_ops.COUNTER_NUM_VISIBLE], host[hip_ops.COUNTER_NUM_KEYS],
                                       host[hip_ops.COUNTER_NUM_SLOTS])
                 max_depth_key = host[hip_ops.COUNTER_MAX_DEPTH_KEY]
-                if n_keys >= 0x7fffffff or n_slots >= 0x7fffffff:
-                    raise RuntimeError("more than 2^31-1 (tile, Gaussian) pairs: key offsets are int32 as in the reference")
                 nb = (m + 255) // 256
-                # next frame's list layout, from this frame's key count K (after the exact cull, in the layout this frame
-                # used; scaled to the whole image when sharded) and M, with hysteresis:
-                #   per-tile keys -> 2x2-tile bins once K >= 2e6: key generation + three radix passes then cost more than
-                #     the blend kernels pay for filtering twice as many list entries (-4 % at the headline size); back
-                #     below 0.7e6 bin keys (small frames: the filter costs more than the sort saves);
-                #   -> 4x4-tile bins once a Gaussian emits >= 64 tile keys / >= 16 bin keys on average (lists dominated
-                #     by pairs that are never blended: the reference's stress distribution, 8.3 -> 0.64 ms); back below 3.
-                # Counting emitted keys rather than tile-box areas keeps needle-shaped Gaussians (huge boxes that the cull
-                # empties) from pushing an ordinary frame into the coarse bins.
-                # Sharded runs: every rank decides from its OWN key count (scaled to the whole image), so ranks may pick
-                # different layouts for the same frame.  That is correct by construction -- image, depth, count and
-                # gradients are bit-identical across layouts (tests: test_list_layouts_are_output_identical, the sharded
-                # x binned tests) -- and costs at most some load imbalance; set `bin_shift` to pin one layout everywhere.
-                owned = len(layout.owned_rows(height))
-                k_frame = n_keys * ((height // TILE_HEIGHT) / owned if owned else 1.0)
-                used = layout.bin_shift
-                if m == 0:
-                    choice = used       # nothing on screen: no information
-                elif used == 0:
-                    choice = 2 if k_frame >= 64 * m else (1 if k_frame >= 2_000_000 else 0)
-                elif used == 1:
-                    choice = 2 if k_frame >= 16 * m else (0 if k_frame < 700_000 else 1)
-                else:
-                    choice = 1 if k_frame < 3 * m else used
-                outer._auto_bin_shift = choice
-                if len(outer._auto_bin_shift_by_size) >= 64 and (width, height) not in outer._auto_bin_shift_by_size:
-                    outer._auto_bin_shift_by_size.pop(next(iter(outer._auto_bin_shift_by_size)))   # bounded
-                outer._auto_bin_shift_by_size[(width, height)] = outer._auto_bin_shift   # cameras of several sizes
-                fits = guess is not None and n_keys <= guess[0] and max_depth_key <= guess[1]
-                outer.speculation_stats["frames"] += 1
-                outer.speculation_stats["redone"] += 0 if (fits or guess is None) else 1
-                # capacities for the next frame: 30 % head-room over this frame, decaying slowly (1 % per frame) from the
-                # high-water mark -- training alternates between views whose key counts differ; the depth range as the
-                # largest value with the same number of bits, never less than the previous bound while it still fits
-                depth_bound = (1 << max(int(max_depth_key), 1).bit_length()) - 1
-                if guess is not None and depth_bound <= guess[1] <= 4 * depth_bound + 3:
-                    depth_bound = guess[1]
-                if len(outer._size_guesses) >= 16 and guess_key not in outer._size_guesses:
-                    outer._size_guesses.pop(next(iter(outer._size_guesses)))   # bounded: forget the oldest configuration
-                outer._size_guesses[guess_key] = (max(int(1.3 * n_keys) + 4096, int(0.99 * guess[0]) if guess else 0),
-                                                  depth_bound)
+                fits = outer._sizes_arrived(host, layout, width, height, guess, guess_key)
                 ids, attrs, num_overlap_tiles, num_owned_tiles = ids[:m], attrs[:m], num_overlap_tiles[:m], \
                     num_owned_tiles[:m]
                 if not fits:
@@ -440,10 +440,63 @@ class GaussianPointCloudRasterisation(torch.nn.Module):
         return hip_ops.ListLayout(bin_shift=auto if self.bin_shift is None else self.bin_shift,
                                   exact_cull=self.exact_tile_cull, row_begin=begin, row_step=step, row_end=end)
 
+    def _sizes_arrived(self, host, layout, width, height, guess, guess_key) -> bool:
+        """The frame's sizes have reached the host: picks the next frame's list layout and capacities; -> whether the
+        speculative launches of this frame (``guess`` = (key capacity, depth bound) or None) held."""
+        outer = self
+        m, n_keys, n_slots = (host[hip_ops.COUNTER_NUM_VISIBLE], host[hip_ops.COUNTER_NUM_KEYS],
+                              host[hip_ops.COUNTER_NUM_SLOTS])
+        max_depth_key = host[hip_ops.COUNTER_MAX_DEPTH_KEY]
+        if n_keys >= 0x7fffffff or n_slots >= 0x7fffffff:
+            raise RuntimeError("more than 2^31-1 (tile, Gaussian) pairs: key offsets are int32 as in the reference")
+        # next frame's list layout, from this frame's key count K (after the exact cull, in the layout this frame
+        # used; scaled to the whole image when sharded) and M, with hysteresis:
+        #   per-tile keys -> 2x2-tile bins once K >= 2e6: key generation + three radix passes then cost more than
+        #     the blend kernels pay for filtering twice as many list entries (-4 % at the headline size); back
+        #     below 0.7e6 bin keys (small frames: the filter costs more than the sort saves);
+        #   -> 4x4-tile bins once a Gaussian emits >= 64 tile keys / >= 16 bin keys on average (lists dominated
+        #     by pairs that are never blended: the reference's stress distribution, 8.3 -> 0.64 ms); back below 3.
+        # Counting emitted keys rather than tile-box areas keeps needle-shaped Gaussians (huge boxes that the cull
+        # empties) from pushing an ordinary frame into the coarse bins.
+        # Sharded runs: every rank decides from its OWN key count (scaled to the whole image), so ranks may pick
+        # different layouts for the same frame.  That is correct by construction -- image, depth, count and
+        # gradients are bit-identical across layouts (tests: test_list_layouts_are_output_identical, the sharded
+        # x binned tests) -- and costs at most some load imbalance; set `bin_shift` to pin one layout everywhere.
+        owned = len(layout.owned_rows(height))
+        k_frame = n_keys * ((height // TILE_HEIGHT) / owned if owned else 1.0)
+        used = layout.bin_shift
+        if m == 0:
+            choice = used       # nothing on screen: no information
+        elif used == 0:
+            choice = 2 if k_frame >= 64 * m else (1 if k_frame >= 2_000_000 else 0)
+        elif used == 1:
+            choice = 2 if k_frame >= 16 * m else (0 if k_frame < 700_000 else 1)
+        else:
+            choice = 1 if k_frame < 3 * m else used
+        outer._auto_bin_shift = choice
+        if len(outer._auto_bin_shift_by_size) >= 64 and (width, height) not in outer._auto_bin_shift_by_size:
+            outer._auto_bin_shift_by_size.pop(next(iter(outer._auto_bin_shift_by_size)))   # bounded
+        outer._auto_bin_shift_by_size[(width, height)] = outer._auto_bin_shift   # cameras of several sizes
+        fits = guess is not None and n_keys <= guess[0] and max_depth_key <= guess[1]
+        outer.speculation_stats["frames"] += 1
+        outer.speculation_stats["redone"] += 0 if (fits or guess is None) else 1
+        # capacities for the next frame: 30 % head-room over this frame, decaying slowly (1 % per frame) from the
+        # high-water mark -- training alternates between views whose key counts differ; the depth range as the
+        # largest value with the same number of bits, never less than the previous bound while it still fits
+        depth_bound = (1 << max(int(max_depth_key), 1).bit_length()) - 1
+        if guess is not None and depth_bound <= guess[1] <= 4 * depth_bound + 3:
+            depth_bound = guess[1]
+        if len(outer._size_guesses) >= 16 and guess_key not in outer._size_guesses:
+            outer._size_guesses.pop(next(iter(outer._size_guesses)))   # bounded: forget the oldest configuration
+        outer._size_guesses[guess_key] = (max(int(1.3 * n_keys) + 4096, int(0.99 * guess[0]) if guess else 0),
+                                          depth_bound)
+        return fits
+
     def _counter_readback(self, device):
         rb = self._readbacks.get(device)
         if rb is None:
             rb = self._readbacks[device] = hip_ops.CounterReadback(device)
+            rb.event.record(torch.cuda.current_stream(device))   # creates the HIP event: gs_frame_forward records it by handle
         return rb
 
     def forward(self, input_data: "GaussianPointCloudRasterisation.GaussianPointCloudRasterisationInput"):

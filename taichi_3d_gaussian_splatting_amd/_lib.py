@@ -17,7 +17,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # GS_LIB_PATH: development knob (tuning sweeps load differently built variants of the library); default = in-tree build
 LIB_PATH = os.environ.get("GS_LIB_PATH") or os.path.join(_HERE, "libgsplat_hip.so")
-ABI_VERSION = 26
+ABI_VERSION = 27
 
 _c = ctypes
 _P = _c.c_void_p
@@ -41,6 +41,10 @@ _SIGNATURES = {
     "gs_sort_pairs": (_I, [_P, _P, _P, _P, _I64, _P, _I, _I, _I, _I, _P, _P]),
     "gs_sort_pairs_and_zero": (_I, [_P, _P, _P, _P, _I64, _P, _I, _I, _I, _I, _P, _P, _c.c_size_t, _P]),
     "gs_tile_ranges": (_I, [_P, _I64, _P, _I, _P, _P, _I, _P]),
+    "gs_tile_ranges_prezeroed": (_I, [_P, _I64, _P, _I, _P, _P, _I, _I, _P]),
+    "gs_frame_struct_bytes": (_c.c_size_t, []),
+    "gs_frame_forward": (_I, [_P, _c.c_uint32, _P]),
+    "gs_frame_backward": (_I, [_P, _c.c_uint32, _P]),
     "gs_read_counters_async": (_I, [_P, _P, _I, _P]),
     "gs_blend_forward": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P]),
     "gs_blend_backward": (_I, [_P, _P, _P, _P, _P, _P, _P, _I64, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P, _P]),
@@ -73,6 +77,40 @@ _SIGNATURES = {
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 
 _lib: Optional[ctypes.CDLL] = None
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "gsplat_hip.h")
+
+
+def _frame_fields_from_header():
+    """ctypes fields of ``GsFrame`` and the GS_FWD_* / GS_BWD_* stage bits, read from include/gsplat_hip.h itself: the
+    struct has ~90 members and the header is the one definition (``load`` checks the mirror's size against the library)."""
+    import re
+    with open(HEADER_PATH) as fh:
+        text = fh.read()
+    body = re.search(r"typedef struct GsFrame \{(.*?)\} GsFrame;", text, re.S).group(1)
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    scalars = {"int32_t": _c.c_int32, "int64_t": _c.c_int64, "float": _c.c_float, "uint32_t": _c.c_uint32}
+    fields = []
+    for decl in body.split(";"):
+        decl = decl.replace("const ", " ").strip()
+        if not decl:
+            continue
+        base, rest = decl.split(None, 1)
+        for name in rest.split(","):
+            name = name.strip()
+            if name.startswith("*"):
+                fields.append((name.lstrip("* "), _c.c_void_p))
+            else:
+                fields.append((name, scalars[base]))
+    stages = {m.group(1): 1 << int(m.group(2)) for m in re.finditer(r"#define (GS_(?:FWD|BWD)_\w+)\s+\(1u << (\d+)\)", text)}
+    return fields, stages
+
+
+_FRAME_FIELDS, STAGES = _frame_fields_from_header()
+
+
+class GsFrame(ctypes.Structure):
+    """Mirror of ``GsFrame`` (include/gsplat_hip.h): pointers as integers (``tensor.data_ptr()``), 0 / None = NULL."""
+    _fields_ = _FRAME_FIELDS
 
 
 def build(verbose: bool = False) -> str:
@@ -96,6 +134,9 @@ def load() -> ctypes.CDLL:
             fn.argtypes = args
         if lib.gs_abi_version() != ABI_VERSION:
             raise RuntimeError(f"libgsplat_hip.so ABI {lib.gs_abi_version()} != expected {ABI_VERSION}")
+        if lib.gs_frame_struct_bytes() != ctypes.sizeof(GsFrame):
+            raise RuntimeError(f"GsFrame: the library's struct has {lib.gs_frame_struct_bytes()} bytes, the Python mirror "
+                               f"{ctypes.sizeof(GsFrame)} (include/gsplat_hip.h and the built library disagree)")
         _lib = lib
     return _lib
 

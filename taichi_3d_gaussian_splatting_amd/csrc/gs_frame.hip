@@ -1,0 +1,115 @@
+// gs_frame.hip -- one entry point per pass: the stages of a frame issued back to back from C (include/gsplat_hip.h,
+// "One entry point per pass").  Nothing is computed here: every stage is the stage entry point a host would otherwise call
+// through its FFI, with the same arguments, so results are identical to the stage-by-stage path by construction.
+#include "gs_common.h"
+
+#define GS_STAGE(call)            \
+    do {                          \
+        const int _rc = (call);   \
+        if (_rc < 0) return _rc;  \
+    } while (0)
+
+extern "C" {
+
+size_t gs_frame_struct_bytes(void) { return sizeof(GsFrame); }
+
+int gs_frame_forward(GsFrame *f, uint32_t stages, void *stream) {
+    GS_REQUIRE(f != nullptr, "frame");
+    const int filter = f->bin_shift == 0 ? 0 : (GS_FILTER_BOX | (f->exact_tile_cull ? GS_FILTER_CULL : 0));
+    if (stages & GS_FWD_POSE_INVERSE)
+        GS_STAGE(gs_pose_inverse(f->q_pointcloud_camera, f->t_pointcloud_camera, f->q_camera_pointcloud,
+                                 f->t_camera_pointcloud, f->n_objects, stream));
+    if (stages & GS_FWD_FILTER_COMPACT)
+        GS_STAGE(gs_filter_compact(f->xyz, f->invalid_mask, f->object_id, f->intrinsics, f->q_camera_pointcloud,
+                                   f->t_camera_pointcloud, f->n_points, f->near_plane, f->far_plane, f->width, f->height,
+                                   f->visible_mask, f->ids, f->counters, f->filter_workspace, stream));
+    if (stages & GS_FWD_PREPROCESS)   // launched for the capacity n_points; M is read from the counters on the device
+        GS_STAGE(gs_preprocess(f->xyz, f->features, f->object_id, f->intrinsics, f->q_camera_pointcloud,
+                               f->t_camera_pointcloud, f->ids, f->n_points, 1, f->width, f->height, f->tile_row_begin,
+                               f->tile_row_step, f->tile_row_end, f->bin_shift, f->exact_tile_cull, f->always_store_rotation,
+                               f->depth_scale, f->counters, f->attrs, f->num_overlap_tiles, f->num_keys, f->block_sums,
+                               f->block_sums_full, stream));
+    if (stages & GS_FWD_ROUTE_COUNT)
+        GS_STAGE(gs_route_count(f->attrs, f->num_keys, f->n_points, f->counters, f->width, f->height, f->rows_per_band,
+                                f->world, f->route_counts, f->route_workspace, stream));
+    if (stages & GS_FWD_ROUTE_SCATTER)
+        GS_STAGE(gs_route_scatter(f->attrs, f->num_keys, f->n_points, f->counters, f->width, f->height, f->rows_per_band,
+                                  f->world, f->chunk_capacity, f->route_counts, f->route_send, f->route_pos,
+                                  f->route_workspace, stream));
+    // owner-sharded band side: the received records are the attrs array of every later stage
+    const bool received = (stages & GS_FWD_COUNT_KEYS) != 0 || f->records != nullptr;
+    const float *attrs = received ? f->records : f->attrs;
+    const int n_list_points = received ? (int)f->n_records : f->n_points;
+    if (stages & GS_FWD_COUNT_KEYS) {
+        GS_CHECK_HIP(hipMemsetAsync(f->counters, 0, sizeof(int32_t) * GS_NUM_COUNTERS, (hipStream_t)stream));
+        GS_STAGE(gs_count_keys(f->records, (int)f->n_records, f->chunk_capacity + 1, f->width, f->height, f->tile_row_begin,
+                               f->tile_row_step, f->tile_row_end, f->bin_shift, f->exact_tile_cull, f->depth_scale,
+                               f->counters, f->num_overlap_tiles, f->num_keys, f->block_sums, f->block_sums_full, stream));
+    }
+    if (stages & GS_FWD_SCAN)
+        GS_STAGE(gs_scan_block_sums2(f->block_sums, f->block_sums_full, gs_div_up(n_list_points, GS_BLOCK), f->counters,
+                                     stream));
+    if (stages & GS_FWD_READ_SIZES) {
+        GS_STAGE(gs_read_counters_async(f->counters, f->host_counters_pinned, GS_NUM_COUNTERS, stream));
+        if (f->size_event != nullptr) GS_CHECK_HIP(hipEventRecord((hipEvent_t)f->size_event, (hipStream_t)stream));
+    }
+    const int32_t *n_keys_device = f->counters + GS_COUNTER_NUM_KEYS;
+    if (stages & GS_FWD_MAKE_KEYS)
+        GS_STAGE(gs_make_keys(attrs, f->num_keys, f->block_sums, n_list_points, f->counters, f->n_keys_capacity, f->width,
+                              f->height, f->tile_row_begin, f->tile_row_step, f->tile_row_end, f->bin_shift,
+                              f->exact_tile_cull, f->key_depth_bits, f->depth_scale, f->keys, f->payload,
+                              f->need_state ? f->num_overlap_tiles : nullptr, f->need_state ? f->block_sums_full : nullptr,
+                              f->need_state ? f->slot_offsets : nullptr, stream));
+    const size_t range_bytes = sizeof(int32_t) * 2 * (size_t)f->n_bins;
+    if (stages & GS_FWD_SORT) {
+        GS_REQUIRE(range_bytes % 16 == 0, "n_bins must be even (the ranges are zeroed with 16-byte stores)");
+        const int rc = gs_sort_pairs_and_zero(f->keys, f->payload, f->keys_alt, f->payload_alt, f->n_keys_capacity,
+                                              n_keys_device, f->key_depth_bits, f->depth_bits, f->tile_bits, 1,
+                                              f->sort_workspace, f->bin_ranges, range_bytes, stream);
+        if (rc < 0) return rc;
+        f->sorted_in_alt = rc;
+    }
+    const void *keys_sorted = f->sorted_in_alt ? f->keys_alt : f->keys;
+    const int32_t *payload_sorted = f->sorted_in_alt ? f->payload_alt : f->payload;
+    if (stages & GS_FWD_RANGES)
+        GS_STAGE(gs_tile_ranges_prezeroed(keys_sorted, f->n_keys_capacity, n_keys_device, f->key_depth_bits, f->bin_ranges,
+                                          f->bin_ranges + f->n_bins, f->n_bins, (stages & GS_FWD_SORT) ? 1 : 0, stream));
+    if (stages & GS_FWD_BLEND)
+        GS_STAGE(gs_blend_forward(f->bin_ranges, f->bin_ranges + f->n_bins, payload_sorted, attrs, f->width, f->height,
+                                  f->tile_row_begin, f->tile_row_step, f->tile_row_end, f->bin_shift, filter, f->image,
+                                  f->depth, f->acc_alpha, f->last_effective, f->valid_count, f->blend_flags, nullptr,
+                                  f->tile_order, f->tile_work, f->walked_list, f->walked_start, stream));
+    return 0;
+}
+
+int gs_frame_backward(GsFrame *f, uint32_t stages, void *stream) {
+    GS_REQUIRE(f != nullptr, "frame");
+    const bool received = f->records != nullptr;
+    const float *attrs = received ? f->records : f->attrs;
+    const int n_list_points = received ? (int)f->n_records : f->n_visible;
+    if (stages & GS_BWD_BLEND)
+        GS_STAGE(gs_blend_backward(f->list_start, f->list_payload, attrs, f->grad_image, f->acc_alpha, f->last_effective,
+                                   f->slot_offsets, f->n_slots, f->width, f->height, f->tile_row_begin, f->tile_row_step,
+                                   f->tile_row_end, f->backward_bin_shift, f->backward_filter, f->partials, f->slot_flags,
+                                   f->magnitude_image, nullptr, f->blend_flags & (GS_BLEND_TWO_WAVES | GS_BLEND_FOUR_WAVES),
+                                   f->tile_work, f->tile_order_backward, stream));
+    if (stages & GS_BWD_REDUCE)
+        GS_STAGE(gs_reduce_partials(f->slot_offsets, f->num_overlap_tiles, f->slot_flags, f->partials, n_list_points, f->acc,
+                                    (received || f->tile_row_begin != 0 || f->tile_row_step != 1 ||
+                                     f->tile_row_end < f->height / GS_TILE_HEIGHT) ? f->num_keys : nullptr,
+                                    f->n_slots, attrs, f->width, f->height, stream));
+    if (stages & GS_BWD_GATHER_RETURNED)
+        GS_STAGE(gs_gather_returned_rows(f->returned_rows, f->route_pos, f->n_visible, f->n_points, f->world,
+                                         f->chunk_capacity, f->acc, stream));
+    if (stages & GS_BWD_POINTS)
+        GS_STAGE(gs_point_backward(f->xyz, f->features, f->object_id, f->intrinsics, f->q_camera_pointcloud,
+                                   f->t_camera_pointcloud, f->t_pointcloud_camera, f->ids, f->visible_mask, f->n_visible,
+                                   f->n_points, f->acc, f->attrs, f->num_keys, f->color_max_sh_band, f->grad_q_factor,
+                                   f->grad_s_factor, f->grad_alpha_factor, f->grad_color_factor,
+                                   f->grad_high_order_color_factor, f->grad_xyz, f->grad_features, f->grad_xyz_visible,
+                                   f->grad_features_visible, f->hook_compact, nullptr, nullptr, nullptr, nullptr, f->width,
+                                   f->height, stream));
+    return 0;
+}
+
+}  // extern "C"

@@ -877,10 +877,19 @@ int gs_make_keys(const float *attrs, const int32_t *num_keys, const int32_t *blo
 
 int gs_tile_ranges(const void *keys_sorted, int64_t n_keys, const int32_t *n_keys_device, int key_depth_bits,
                    int32_t *tile_start, int32_t *tile_end, int n_tiles /* number of bins */, void *stream) {
+    return gs_tile_ranges_prezeroed(keys_sorted, n_keys, n_keys_device, key_depth_bits, tile_start, tile_end, n_tiles, 0,
+                                    stream);
+}
+
+int gs_tile_ranges_prezeroed(const void *keys_sorted, int64_t n_keys, const int32_t *n_keys_device, int key_depth_bits,
+                             int32_t *tile_start, int32_t *tile_end, int n_tiles /* number of bins */,
+                             int ranges_are_zeroed, void *stream) {
     GS_REQUIRE(n_keys >= 0 && n_tiles > 0, "sizes");
     GS_REQUIRE(key_depth_bits >= 0 && key_depth_bits < 32, "key_depth_bits");
     hipStream_t s = (hipStream_t)stream;
-    if (tile_end == tile_start + n_tiles) {  // adjacent halves of one buffer: a single fill
+    if (ranges_are_zeroed) {
+        // (gs_sort_pairs_and_zero filled them with its first launch)
+    } else if (tile_end == tile_start + n_tiles) {  // adjacent halves of one buffer: a single fill
         GS_CHECK_HIP(hipMemsetAsync(tile_start, 0, 2 * sizeof(int32_t) * n_tiles, s));
     } else {
         GS_CHECK_HIP(hipMemsetAsync(tile_start, 0, sizeof(int32_t) * n_tiles, s));

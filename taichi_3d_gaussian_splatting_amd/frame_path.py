@@ -1,0 +1,236 @@
+"""The operator's forward and backward pass through ONE C call each (``gs_frame_forward`` / ``gs_frame_backward``,
+include/gsplat_hip.h "One entry point per pass").
+
+A frame is ~25 launches forward and ~5 backward.  Issued stage by stage from Python (``hip_ops``: ~10 us of interpreter,
+``ctypes`` marshalling and ``torch.empty`` per stage) the HOST bounds every small frame: the reference's 4x / 2x
+down-sampled first iterations (TRN:139-148), BASELINE config 1, a rank of a sharded frame.  Here the host does, per pass:
+one slab allocation for everything that lives until the backward pass (carved up by offsets, no per-buffer tensors), the
+three output tensors, one ``GsFrame`` fill and one foreign call; the library issues the launches back to back.  The kernels,
+their arguments and therefore all results are those of the stage-by-stage path (``tests/test_hip_parity.py``:
+options that must not change a bit).
+
+Only the speculative case is handled here (capacities and key layout learnt from the previous frame, sizes read back behind
+an event while the GPU works): a frame that does not fit is redone by the stage-by-stage path with exact sizes.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Optional
+
+import torch
+
+from . import _lib, hip_ops
+
+_ALIGN = 256
+S = _lib.STAGES
+FORWARD_STAGES = (S["GS_FWD_POSE_INVERSE"] | S["GS_FWD_FILTER_COMPACT"] | S["GS_FWD_PREPROCESS"] | S["GS_FWD_SCAN"] |
+                  S["GS_FWD_READ_SIZES"] | S["GS_FWD_MAKE_KEYS"] | S["GS_FWD_SORT"] | S["GS_FWD_RANGES"] | S["GS_FWD_BLEND"])
+
+
+class Slab:
+    """One allocation, many buffers: ``add`` reserves 256-byte aligned ranges, ``allocate`` makes the tensor, ``ptr`` /
+    ``tensor`` hand out raw addresses / typed views (views are only built for what Python itself looks at)."""
+
+    def __init__(self):
+        self.offsets, self.total, self.buf, self.base = {}, 0, None, 0
+
+    def add(self, name: str, nbytes: int) -> None:
+        self.offsets[name] = (self.total, int(nbytes))
+        self.total = (self.total + int(nbytes) + _ALIGN - 1) // _ALIGN * _ALIGN
+
+    def allocate(self, device) -> "Slab":
+        self.buf = torch.empty(max(self.total, _ALIGN), dtype=torch.uint8, device=device)
+        self.base = self.buf.data_ptr()
+        return self
+
+    def ptr(self, name: str) -> int:
+        return self.base + self.offsets[name][0] if name in self.offsets else 0
+
+    def tensor(self, name: str, dtype: torch.dtype, shape) -> torch.Tensor:
+        off, nbytes = self.offsets[name]
+        return self.buf[off:off + nbytes].view(dtype).view(shape)
+
+
+class FrameState:
+    """What the backward pass needs of a forward pass that went through ``gs_frame_forward``."""
+    __slots__ = ("frame", "slab", "layout", "layout_bwd", "m", "n_slots", "walked", "width", "height", "n_keys")
+
+
+def _ws_bytes(ws: hip_ops.Workspaces, name: str, nbytes: int, device) -> int:
+    return ws.get(name, max(int(nbytes), 16), torch.uint8, device).data_ptr()
+
+
+def forward(outer, xyz, features, invalid, obj, intrinsics, q_pc, t_pc, camera_info, color_max_sh_band, need_state,
+            layout, guess, gathered_rows, readback):
+    """-> (image, depth, count, state, host counters).  All launches of the forward pass are enqueued by one call; the host
+    then waits for the frame's sizes (which arrive while the GPU is still working) and the CALLER checks that the
+    speculative capacities held."""
+    cfg = outer.config
+    dev = xyz.device
+    n = xyz.shape[0]
+    width, height = camera_info.camera_width, camera_info.camera_height
+    cap, depth_guess = int(guess[0]), int(guess[1])
+    num_bins = layout.num_bins(width, height)
+    n_bins = (num_bins + 1) & ~1
+    kdb, depth_bits, tile_bits = hip_ops.key_layout(cfg.near_plane, cfg.far_plane, cfg.depth_to_sort_key_scale, num_bins,
+                                                    depth_guess)
+    key_bytes = 4 if kdb > 0 else 8
+    pixels = width * height
+    tiles = (width // hip_ops.TILE_WIDTH) * (height // hip_ops.TILE_HEIGHT)
+    owned_tiles = hip_ops.num_owned_tiles(width, height, layout)
+    rgb_only = bool(cfg.rgb_only)
+    ordered = bool(outer.ordered_dispatch)
+    shift2 = 2 * layout.bin_shift
+    emit = bool(need_state and outer.backward_on_walked_lists and layout.filter != 0 and layout.bin_shift <= 2 and
+                (max(cap, 1) << shift2) < 2 ** 31)
+    n_obj = q_pc.shape[0]
+    slab = Slab()
+    slab.add("q_cp", 16 * n_obj)
+    slab.add("t_cp", 12 * n_obj)
+    slab.add("counters", 4 * hip_ops.NUM_COUNTERS)
+    slab.add("visible_mask", n)
+    slab.add("ids", 4 * n)
+    slab.add("attrs", 64 * n)
+    slab.add("ntiles", 4 * n)
+    slab.add("nkeys", 4 * n)
+    slab.add("ranges", 8 * n_bins)
+    if need_state:
+        slab.add("slot_offsets", 4 * n)
+        slab.add("acc_alpha", 4 * pixels)
+        slab.add("last_eff", 4 * pixels)
+        if ordered:
+            slab.add("tile_work", 4 * owned_tiles)
+    if emit:
+        slab.add("walked_list", 4 * (max(cap, 1) << shift2))
+        slab.add("walked_start", 4 * tiles)
+    else:   # the sorted payload itself is what the backward pass walks
+        slab.add("payload", 4 * max(cap, 1))
+        slab.add("payload_alt", 4 * max(cap, 1))
+    slab.allocate(dev)
+    ws = outer._scratch
+    lib = _lib.load()
+    # outputs (allocated as hip_ops.blend_forward does: un-owned rows zero, or padded for an in-place all-gather)
+    if gathered_rows >= height:
+        image = torch.empty((gathered_rows, width, 3), dtype=torch.float32, device=dev)[:height]
+        depth = None if rgb_only else torch.empty((gathered_rows, width), dtype=torch.float32, device=dev)[:height]
+        count = None if rgb_only else torch.empty((gathered_rows, width), dtype=torch.int32, device=dev)[:height]
+    else:
+        alloc = torch.zeros if layout.sharded else torch.empty
+        image = alloc((height, width, 3), dtype=torch.float32, device=dev)
+        depth = None if rgb_only else alloc((height, width), dtype=torch.float32, device=dev)
+        count = None if rgb_only else alloc((height, width), dtype=torch.int32, device=dev)
+
+    f = _lib.GsFrame()
+    f.n_points, f.n_objects, f.width, f.height = n, n_obj, width, height
+    f.tile_row_begin, f.tile_row_step, f.tile_row_end = layout.row_begin, layout.row_step, layout.row_end
+    f.bin_shift, f.exact_tile_cull = layout.bin_shift, int(layout.exact_cull)
+    f.always_store_rotation = int(bool(outer.always_store_normalised_rotation))
+    f.key_depth_bits, f.depth_bits, f.tile_bits = kdb, depth_bits, tile_bits
+    f.blend_flags = (hip_ops.BLEND_RGB_ONLY if rgb_only else 0) | (0 if need_state else hip_ops.BLEND_NO_STATE)
+    f.need_state = int(bool(need_state))
+    f.color_max_sh_band = int(color_max_sh_band)
+    f.near_plane, f.far_plane, f.depth_scale = cfg.near_plane, cfg.far_plane, cfg.depth_to_sort_key_scale
+    f.grad_q_factor, f.grad_s_factor, f.grad_alpha_factor = cfg.grad_q_factor, cfg.grad_s_factor, cfg.grad_alpha_factor
+    f.grad_color_factor, f.grad_high_order_color_factor = cfg.grad_color_factor, cfg.grad_high_order_color_factor
+    f.n_keys_capacity = cap
+    f.xyz, f.features, f.invalid_mask, f.object_id = xyz.data_ptr(), features.data_ptr(), invalid.data_ptr(), obj.data_ptr()
+    f.intrinsics, f.q_pointcloud_camera, f.t_pointcloud_camera = intrinsics.data_ptr(), q_pc.data_ptr(), t_pc.data_ptr()
+    f.q_camera_pointcloud, f.t_camera_pointcloud = slab.ptr("q_cp"), slab.ptr("t_cp")
+    f.visible_mask, f.ids, f.counters = slab.ptr("visible_mask"), slab.ptr("ids"), slab.ptr("counters")
+    f.host_counters_pinned, f.size_event = readback.host.data_ptr(), readback.event.cuda_event
+    f.attrs, f.num_overlap_tiles, f.num_keys = slab.ptr("attrs"), slab.ptr("ntiles"), slab.ptr("nkeys")
+    nblk = (n + 255) // 256
+    f.block_sums = _ws_bytes(ws, "f_block_sums", 4 * nblk, dev)
+    f.block_sums_full = _ws_bytes(ws, "f_block_sums_full", 4 * nblk, dev)
+    f.keys = _ws_bytes(ws, "f_keys", key_bytes * cap, dev)
+    f.keys_alt = _ws_bytes(ws, "f_keys_alt", key_bytes * cap, dev)
+    if emit:
+        f.payload = _ws_bytes(ws, "f_payload", 4 * cap, dev)
+        f.payload_alt = _ws_bytes(ws, "f_payload_alt", 4 * cap, dev)
+    else:
+        f.payload, f.payload_alt = slab.ptr("payload"), slab.ptr("payload_alt")
+    f.slot_offsets = slab.ptr("slot_offsets")
+    f.bin_ranges, f.n_bins = slab.ptr("ranges"), n_bins
+    f.image = image.data_ptr()
+    f.depth = 0 if depth is None else depth.data_ptr()
+    f.valid_count = 0 if count is None else count.data_ptr()
+    f.acc_alpha, f.last_effective = slab.ptr("acc_alpha"), slab.ptr("last_eff")
+    f.tile_order = _ws_bytes(ws, "f_order_fwd", 4 * owned_tiles, dev) if ordered else 0
+    f.tile_work = slab.ptr("tile_work")
+    f.walked_list, f.walked_start = slab.ptr("walked_list"), slab.ptr("walked_start")
+    f.filter_workspace = _ws_bytes(ws, "f_filter", lib.gs_filter_workspace_bytes(n), dev)
+    f.sort_workspace = _ws_bytes(ws, "f_sort", lib.gs_sort_workspace_bytes(cap), dev)
+    _lib.check(lib.gs_frame_forward(ctypes.addressof(f), FORWARD_STAGES, _lib.current_stream(dev)), "gs_frame_forward")
+    host = readback.wait()
+    state = FrameState()
+    state.frame, state.slab, state.layout, state.walked = f, slab, layout, emit
+    state.layout_bwd = hip_ops.walked_layout(layout) if emit else layout
+    state.width, state.height = width, height
+    state.m, state.n_keys = host[hip_ops.COUNTER_NUM_VISIBLE], host[hip_ops.COUNTER_NUM_KEYS]
+    state.n_slots = host[hip_ops.COUNTER_NUM_SLOTS]
+    return image, depth, count, state, host
+
+
+def backward(outer, state: FrameState, grad_image: torch.Tensor, hook, hook_input_type, want_feature_copy: bool):
+    """-> (grad_point_cloud, grad_point_cloud_features); calls the hook (RAS:1127-1142)."""
+    f, slab = state.frame, state.slab
+    dev = grad_image.device
+    n, m, width, height = f.n_points, int(state.m), state.width, state.height
+    n_slots = max(int(state.n_slots), 1)
+    ws = outer._scratch
+    lib = _lib.load()
+    layout_bwd = state.layout_bwd
+    grad_image = grad_image.contiguous()
+    if grad_image.dtype != torch.float32:
+        raise TypeError("grad_rasterized_image must be float32")
+    f.n_visible, f.n_slots = m, int(state.n_slots)
+    f.backward_bin_shift, f.backward_filter = layout_bwd.bin_shift, layout_bwd.filter
+    if state.walked:
+        f.list_start, f.list_payload = f.walked_start, f.walked_list
+    else:
+        f.list_start = f.bin_ranges
+        f.list_payload = f.payload_alt if f.sorted_in_alt else f.payload
+    f.grad_image = grad_image.data_ptr()
+    f.partials = _ws_bytes(ws, "f_partials", 48 * n_slots, dev)
+    f.slot_flags = _ws_bytes(ws, "f_slot_flags", (n_slots + 15) & ~15, dev)
+    alloc = torch.zeros if state.layout.sharded else torch.empty
+    magnitude = alloc((height, width, 2), dtype=torch.float32, device=dev)
+    f.magnitude_image = magnitude.data_ptr()
+    f.tile_order_backward = _ws_bytes(ws, "f_order_bwd", 4 * hip_ops.num_owned_tiles(width, height, state.layout), dev) \
+        if f.tile_work else 0
+    grad_xyz = torch.empty((n, 3), dtype=torch.float32, device=dev)
+    grad_feat = torch.empty((n, hip_ops.FEATURE_DIM), dtype=torch.float32, device=dev)
+    f.grad_xyz, f.grad_features = grad_xyz.data_ptr(), grad_feat.data_ptr()
+    gx_vis = gf_vis = fields = None
+    f.grad_xyz_visible = f.grad_features_visible = f.hook_compact = 0
+    if hook is not None:
+        gx_vis = torch.empty((m, 3), dtype=torch.float32, device=dev)
+        compact = torch.empty(7 * m, dtype=torch.float32, device=dev)
+        f.grad_xyz_visible, f.hook_compact = gx_vis.data_ptr(), compact.data_ptr()
+        if want_feature_copy:
+            gf_vis = torch.empty((m, hip_ops.FEATURE_DIM), dtype=torch.float32, device=dev)
+            f.grad_features_visible = gf_vis.data_ptr()
+        fields = dict(grad_viewspace=compact[0:2 * m].view(m, 2), magnitude_grad_viewspace=compact[2 * m:3 * m],
+                      num_affected_pixels=compact[3 * m:4 * m].view(torch.int32), point_depth=compact[4 * m:5 * m],
+                      point_uv_in_camera=compact[5 * m:7 * m].view(m, 2))
+    stream = _lib.current_stream(dev)
+    S_ = _lib.STAGES
+    reduce_hook = outer.grad_accumulator_reduce
+    if reduce_hook is None:
+        f.acc = _ws_bytes(ws, "f_acc", 48 * max(m, 1), dev)
+        _lib.check(lib.gs_frame_backward(ctypes.addressof(f), S_["GS_BWD_BLEND"] | S_["GS_BWD_REDUCE"] | S_["GS_BWD_POINTS"],
+                                         stream), "gs_frame_backward")
+    else:   # multi-GPU with a replicated point cloud: the accumulators are summed over the ranks between the two halves
+        acc = torch.empty((m, hip_ops.ACC_STRIDE), dtype=torch.float32, device=dev)
+        f.acc = acc.data_ptr()
+        _lib.check(lib.gs_frame_backward(ctypes.addressof(f), S_["GS_BWD_BLEND"] | S_["GS_BWD_REDUCE"], stream),
+                   "gs_frame_backward")
+        acc = reduce_hook(acc, slab.tensor("nkeys", torch.int32, (n,))[:m])
+        f.acc = acc.data_ptr()
+        _lib.check(lib.gs_frame_backward(ctypes.addressof(f), S_["GS_BWD_POINTS"], stream), "gs_frame_backward")
+    if hook is not None:
+        hook(hook_input_type(
+            point_id_in_camera_list=slab.tensor("ids", torch.int32, (n,))[:m], grad_point_in_camera=gx_vis,
+            grad_pointfeatures_in_camera=gf_vis, magnitude_grad_viewspace_on_image=magnitude,
+            num_overlap_tiles=slab.tensor("ntiles", torch.int32, (n,))[:m], **fields))
+    return grad_xyz, grad_feat

@@ -859,6 +859,75 @@ def test_operator_options_that_must_not_change_a_bit(scene):
         assert torch.equal(got[4].detach(), ref[4].detach()), attr     # the caller's features after the in-place normalisation
 
 
+@pytest.mark.parametrize("bin_shift,no_grad,rgb_only", [(None, False, False), (0, False, False), (1, False, False),
+                                                         (2, False, False), (1, True, False), (0, True, True)])
+def test_one_entry_point_per_pass_is_bit_identical(scene, bin_shift, no_grad, rgb_only):
+    """Speculative frames through gs_frame_forward / gs_frame_backward (one foreign call per pass, frame_path.py) against
+    the same frames issued stage by stage: the same kernels with the same arguments -- image, depth, count, dense gradients,
+    the in-place normalised quaternions and every hook field equal bit for bit, frame after frame (the first frame of an
+    operator always runs stage by stage: there is nothing to speculate from)."""
+    from taichi_3d_gaussian_splatting_amd import GaussianPointCloudRasterisation as Op
+    from taichi_3d_gaussian_splatting_amd.synthetic import make_grad_image
+    g = None if no_grad else make_grad_image(scene.height, scene.width)
+    cfg = Op.GaussianPointCloudRasterisationConfig(near_plane=scene.near_plane, far_plane=scene.far_plane,
+                                                   depth_to_sort_key_scale=scene.depth_to_sort_key_scale, rgb_only=rgb_only)
+    runs = {}
+    for frames in (True, False):
+        hooks = []
+        op = Op(cfg, backward_valid_point_hook=hooks.append)
+        op.frame_entry_points = frames
+        op.bin_shift = bin_shift
+        outs = []
+        for _ in range(3):
+            if no_grad:
+                with torch.no_grad():
+                    outs.append(_run_operator(scene, None, op=op))
+            else:
+                outs.append(_run_operator(scene, g, op=op))
+        runs[frames] = (outs, hooks, dict(op.speculation_stats))
+    assert runs[True][2] == runs[False][2] and runs[True][2]["frames"] == 3 and runs[True][2]["redone"] == 0
+    for a, b in zip(runs[True][0], runs[False][0]):
+        for i in range(3):
+            assert torch.equal(a[i], b[i]), i
+        assert torch.equal(a[4].detach(), b[4].detach())
+        if not no_grad:
+            assert torch.equal(a[3].grad.view(torch.int32), b[3].grad.view(torch.int32))
+            assert torch.equal(a[4].grad.view(torch.int32), b[4].grad.view(torch.int32))
+    for ha, hb in zip(runs[True][1], runs[False][1]):
+        for name in ("point_id_in_camera_list", "grad_point_in_camera", "grad_pointfeatures_in_camera", "grad_viewspace",
+                     "magnitude_grad_viewspace", "magnitude_grad_viewspace_on_image", "num_overlap_tiles",
+                     "num_affected_pixels", "point_depth", "point_uv_in_camera"):
+            x, y = getattr(ha, name), getattr(hb, name)
+            assert x.shape == y.shape and x.dtype == y.dtype, name
+            assert torch.equal(x.view(torch.int32) if x.dtype == torch.float32 else x,
+                               y.view(torch.int32) if y.dtype == torch.float32 else y), name
+    assert len(runs[True][1]) == (0 if no_grad else 3)
+
+
+def test_one_entry_point_per_pass_overflow_falls_back(scene):
+    """A frame that outgrows the capacities learnt from the previous one (four times the Gaussians on screen) is redone by
+    the stage-by-stage path with exact sizes: the same outputs as a fresh operator."""
+    from taichi_3d_gaussian_splatting_amd import GaussianPointCloudRasterisation as Op
+    from taichi_3d_gaussian_splatting_amd.synthetic import make_grad_image, make_scene
+    g = make_grad_image(256, 256)
+    small = make_scene(n=2000, height=256, width=256, s_min=0.01, s_max=0.05, seed=1)
+    big = make_scene(n=20000, height=256, width=256, s_min=0.01, s_max=0.08, seed=2)
+    op = Op(Op.GaussianPointCloudRasterisationConfig())
+    op.bin_shift = 0
+    _run_operator(small, g, op=op)
+    _run_operator(small, g, op=op)                     # through the frame entry points
+    got = _run_operator(big, g, op=op)                 # does not fit: redone
+    assert op.speculation_stats["redone"] == 1 and op.speculation_stats["frames"] == 3
+    fresh = Op(Op.GaussianPointCloudRasterisationConfig())
+    fresh.bin_shift = 0
+    ref = _run_operator(big, g, op=fresh)
+    for i in range(3):
+        assert torch.equal(got[i], ref[i])
+    assert torch.equal(got[4].grad.view(torch.int32), ref[4].grad.view(torch.int32))
+    again = _run_operator(big, g, op=op)               # and the next frame speculates again, through the entry points
+    assert torch.equal(again[0], ref[0]) and op.speculation_stats["redone"] == 1
+
+
 def test_backward_on_walked_lists_is_bit_identical(ops):
     """Binned layouts: the forward pass writes out every tile's own list as far as it walks it and the backward pass runs on
     those per-tile lists.  Same entries in the same order through the same arithmetic: gradients, hook fields and the

@@ -21,6 +21,11 @@ g = make_grad_image(s.height, s.width).to("cuda")
 op = Op(Op.GaussianPointCloudRasterisationConfig(near_plane=s.near_plane, far_plane=s.far_plane,
                                                  depth_to_sort_key_scale=s.depth_to_sort_key_scale),
         backward_valid_point_hook=lambda h: None)
+if os.environ.get("GS_FRAME_ENTRY_POINTS") == "0":   # stage-by-stage foreign calls (the path of rounds 1-3)
+    op.frame_entry_points = False
+if os.environ.get("GS_NO_PIN") != "1":
+    from taichi_3d_gaussian_splatting_amd import host_affinity  # noqa: E402
+    host_affinity.pin_host_threads(0)
 xyz = s.point_cloud.clone().requires_grad_(True)
 feat = s.point_cloud_features.clone().requires_grad_(True)
 inp = Op.GaussianPointCloudRasterisationInput(
@@ -43,7 +48,10 @@ t0 = time.perf_counter()
 for _ in range(steps):
     step()
 torch.cuda.synchronize()
-print(f"{workload}: {1e3 * (time.perf_counter() - t0) / steps:.4f} ms per step (wall, un-profiled)")
+print(f"[host_profile] {workload} frame_entry_points={op.frame_entry_points}: "
+      f"{1e3 * (time.perf_counter() - t0) / steps:.4f} ms per step (wall, un-profiled)", flush=True)
+if os.environ.get("GS_NO_CPROFILE") == "1":
+    sys.exit(0)
 pr = cProfile.Profile()
 pr.enable()
 for _ in range(steps):
