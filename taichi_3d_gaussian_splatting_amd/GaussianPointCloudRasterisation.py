@@ -271,27 +271,44 @@ class GaussianPointCloudRasterisation(torch.nn.Module):
                             ctx.camera_info = camera_info
                             ctx.set_materialize_grads(False)
                         return image, depth, count
-                    outer.speculation_stats["frames"] -= 1   # (counted again by the redo below)
-                    guess = None
-                # RAS:845  (q,t)_camera<-pointcloud
-                q_cp, t_cp = hip_ops.pose_inverse(q_pc, t_pc)
-                # RAS:848-870  frustum filter + ordered compaction; M stays on the device
-                visible_mask, ids, counters = hip_ops.filter_compact(
-                    xyz, invalid, obj, intrinsics, q_cp, t_cp, cfg.near_plane, cfg.far_plane, width, height,
-                    sync=False, ws=outer._scratch)
-                # RAS:887-911  per-point projection + tile counts (launched for the capacity N)
-                attrs, num_overlap_tiles, num_owned_tiles, block_sums, block_sums_full = hip_ops.preprocess(
-                    xyz, pointcloud_features, obj, intrinsics, q_cp, t_cp, ids, width, height, layout,
-                    cfg.depth_to_sort_key_scale, counters, n_visible_on_device=True,
-                    always_store_rotation=outer.always_store_normalised_rotation, ws=outer._scratch)
-                # RAS:913-922  scans.  The reference blocks twice on sizes (RAS:870,916); here the one read-back of
-                # M, K, the slot count and the depth range travels to pinned memory while the host keeps launching:
-                # key generation, sort, ranges and the blend run SPECULATIVELY from the device-side counts with the
-                # capacities learnt from the previous frame, and are redone with exact sizes in the rare frame that
-                # does not fit (first frame, jump in the number of keys or in the depth range).
-                hip_ops.scan_block_sums_async(block_sums, counters, block_sums_full)
-                readback = outer._counter_readback(xyz.device)
-                readback.start(counters)
+                    # The frame did not fit: its per-point products (compaction, projection, counts, scans -- everything
+                    # up to the size read) are good and are KEPT; only the list stages are redone below with exact sizes.
+                    # (Running the projection again would normalise the stored quaternions a second time: q / |q| of an
+                    # already normalised q can move by an ulp, and the frame would differ from a stage-by-stage one.)
+                    n_pts, slab, ws_ = xyz.shape[0], state.slab, outer._scratch
+                    visible_mask = slab.tensor("visible_mask", torch.int8, (n_pts,))
+                    ids = slab.tensor("ids", torch.int32, (n_pts,))
+                    attrs = slab.tensor("attrs", torch.float32, (n_pts, hip_ops.ATTR_STRIDE))
+                    num_overlap_tiles = slab.tensor("ntiles", torch.int32, (n_pts,))
+                    num_owned_tiles = slab.tensor("nkeys", torch.int32, (n_pts,))
+                    q_cp = slab.tensor("q_cp", torch.float32, (q_pc.shape[0], 4))
+                    t_cp = slab.tensor("t_cp", torch.float32, (q_pc.shape[0], 3))
+                    nblk_ = (n_pts + 255) // 256
+                    block_sums = ws_.get("f_block_sums", max(4 * nblk_, 16), torch.uint8, xyz.device).view(torch.int32)
+                    block_sums_full = ws_.get("f_block_sums_full", max(4 * nblk_, 16), torch.uint8, xyz.device).view(torch.int32)
+                    guess, frame_host = None, host
+                else:
+                    frame_host = None
+                if frame_host is None:
+                    # RAS:845  (q,t)_camera<-pointcloud
+                    q_cp, t_cp = hip_ops.pose_inverse(q_pc, t_pc)
+                    # RAS:848-870  frustum filter + ordered compaction; M stays on the device
+                    visible_mask, ids, counters = hip_ops.filter_compact(
+                        xyz, invalid, obj, intrinsics, q_cp, t_cp, cfg.near_plane, cfg.far_plane, width, height,
+                        sync=False, ws=outer._scratch)
+                    # RAS:887-911  per-point projection + tile counts (launched for the capacity N)
+                    attrs, num_overlap_tiles, num_owned_tiles, block_sums, block_sums_full = hip_ops.preprocess(
+                        xyz, pointcloud_features, obj, intrinsics, q_cp, t_cp, ids, width, height, layout,
+                        cfg.depth_to_sort_key_scale, counters, n_visible_on_device=True,
+                        always_store_rotation=outer.always_store_normalised_rotation, ws=outer._scratch)
+                    # RAS:913-922  scans.  The reference blocks twice on sizes (RAS:870,916); here the one read-back of
+                    # M, K, the slot count and the depth range travels to pinned memory while the host keeps launching:
+                    # key generation, sort, ranges and the blend run SPECULATIVELY from the device-side counts with the
+                    # capacities learnt from the previous frame, and are redone with exact sizes in the rare frame that
+                    # does not fit (first frame, jump in the number of keys or in the depth range).
+                    hip_ops.scan_block_sums_async(block_sums, counters, block_sums_full)
+                    readback = outer._counter_readback(xyz.device)
+                    readback.start(counters)
                 num_bins = layout.num_bins(width, height)
 
                 def lists_and_blend(attrs_, nkeys_, bsums_, bsums_full_, ntiles_, n_keys_, max_depth_key_, counters_):
@@ -331,12 +348,13 @@ class GaussianPointCloudRasterisation(torch.nn.Module):
                 if guess is not None:
                     result = lists_and_blend(attrs, num_owned_tiles, block_sums, block_sums_full, num_overlap_tiles,
                                              guess[0], guess[1], counters)
-                host = readback.wait()
+                host = frame_host if frame_host is not None else readback.wait()
                 m, n_keys, n_slots = (host[hip_ops.COUNTER_NUM_VISIBLE], host[hip_ops.COUNTER_NUM_KEYS],
                                       host[hip_ops.COUNTER_NUM_SLOTS])
                 max_depth_key = host[hip_ops.COUNTER_MAX_DEPTH_KEY]
                 nb = (m + 255) // 256
-                fits = outer._sizes_arrived(host, layout, width, height, guess, guess_key)
+                # (a frame that came back from gs_frame_forward too large has been accounted for already)
+                fits = False if frame_host is not None else outer._sizes_arrived(host, layout, width, height, guess, guess_key)
                 ids, attrs, num_overlap_tiles, num_owned_tiles = ids[:m], attrs[:m], num_overlap_tiles[:m], \
                     num_owned_tiles[:m]
                 if not fits:
