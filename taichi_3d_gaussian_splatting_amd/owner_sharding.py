@@ -28,66 +28,45 @@ the exchanges as device copies).
 """
 from __future__ import annotations
 
-from dataclasses import dataclass, field
-from typing import Callable, List, Optional, Sequence
+import ctypes
+from typing import Callable, Optional, Sequence
 
 import torch
 import torch.distributed as dist
 
 from . import _lib, hip_ops
 from .distributed import padded_image_rows, uniform_band_rows
+from .frame_path import Slab
 from .GaussianPointCloudRasterisation import GaussianPointCloudRasterisation as _Op
 
 TILE = 16
 
 
-@dataclass
 class _Frame:
-    """What one rank keeps between the phases of a frame."""
-    width: int = 0
-    height: int = 0
-    # owner side
-    xyz: torch.Tensor = None
-    features: torch.Tensor = None
-    obj: torch.Tensor = None
-    intrinsics: torch.Tensor = None
-    q_cp: torch.Tensor = None
-    t_cp: torch.Tensor = None
-    t_pc: torch.Tensor = None
-    visible_mask: torch.Tensor = None
-    ids: torch.Tensor = None
-    counters: torch.Tensor = None
-    attrs: torch.Tensor = None
-    num_overlap_tiles: torch.Tensor = None
-    num_keys: torch.Tensor = None
-    counts: torch.Tensor = None          # i32[world] on the device: records for every band
-    route_ws: torch.Tensor = None
-    pos: torch.Tensor = None
-    capacity: int = 0
-    n_visible: int = -1
-    color_max_sh_band: int = 0
-    # band side
-    records: torch.Tensor = None         # f32[world, capacity + 1, 16] as received
-    band_layout: hip_ops.ListLayout = None
-    layout_bwd: hip_ops.ListLayout = None
-    band_num_overlap_tiles: torch.Tensor = None
-    band_num_keys: torch.Tensor = None
-    slot_offsets: torch.Tensor = None
-    n_slots: int = 0
-    n_keys: int = 0
-    list_start: torch.Tensor = None
-    payload: torch.Tensor = None
-    acc_alpha: torch.Tensor = None
-    last_eff: torch.Tensor = None
-    tile_work: torch.Tensor = None
-    outputs: tuple = ()
-    stats: dict = field(default_factory=dict)
+    """What one rank keeps between the phases of a frame: the owner-side and the band-side ``GsFrame`` with the slabs
+    their pointers refer to, the tensors that travel, and the host's copies of the sizes."""
+
+    def __init__(self):
+        self.width = self.height = 0
+        self.owner = self.owner_slab = None          # projection of the rank's own rows, routing, per-point backward
+        self.band = self.band_slab = None            # lists and blend of the received records, per-pixel backward
+        self.keep = []                               # tensors the structs point into
+        self.counts = self.counters = None           # device: records per band i32[world], the owner-side counters
+        self.capacity, self.n_visible = 0, -1
+        self.records = None                          # f32[world, capacity + 1, 16] as received
+        self.band_layout = self.layout_bwd = None
+        self.walked = False
+        self.n_slots = self.n_keys = 0
+        self.outputs = ()
+        self.stats = {}
 
 
 class OwnerShardedRasteriser:
-    """One rank's device work of an owner-sharded frame, phase by phase (see the module docstring).  Options as the
-    single-GPU operator's: ``bin_shift`` (None = chosen per frame from the previous frame's sizes), ``exact_tile_cull``,
-    ``ordered_dispatch``, ``backward_on_walked_lists``, ``hook_feature_gradients``."""
+    """One rank's device work of an owner-sharded frame, phase by phase (see the module docstring); every phase is ONE
+    foreign call (``gs_frame_forward`` / ``gs_frame_backward`` with the phase's stages).  Options as the single-GPU
+    operator's: ``bin_shift`` (None = chosen per frame from the previous frame's sizes), ``exact_tile_cull``,
+    ``ordered_dispatch``, ``backward_on_walked_lists``, ``hook_feature_gradients``, ``speculative_sizes`` (the band's list
+    stages are launched with the key capacity and depth range of the previous frame and redone when they do not fit)."""
 
     def __init__(self, config: "_Op.GaussianPointCloudRasterisationConfig", rank: int, world: int,
                  backward_valid_point_hook: Optional[Callable] = None):
@@ -102,7 +81,11 @@ class OwnerShardedRasteriser:
         self.backward_on_walked_lists = True
         self.hook_feature_gradients = True
         self.always_store_normalised_rotation = False
+        self.speculative_sizes = True
+        self.speculation_stats = {"frames": 0, "redone": 0}
+        self._size_guesses = {}
         self._scratch = hip_ops.Workspaces()
+        self._readback = None
 
     # ------------------------------------------------------------------ geometry of the bands
     def band_rows(self, height: int) -> range:
@@ -118,6 +101,13 @@ class OwnerShardedRasteriser:
         return hip_ops.ListLayout(bin_shift=shift, exact_cull=self.exact_tile_cull, row_begin=rows.start, row_step=1,
                                   row_end=rows.stop)
 
+    def _ws(self, name: str, nbytes: int, device) -> int:
+        return self._scratch.get(name, max(int(nbytes), 16), torch.uint8, device).data_ptr()
+
+    def _call(self, which: str, frame_struct, stages: int, device) -> None:
+        fn = getattr(_lib.load(), which)
+        _lib.check(fn(ctypes.addressof(frame_struct), stages, _lib.current_stream(device)), which)
+
     # ------------------------------------------------------------------ phase A1: project the rank's own rows, count
     def project(self, input_data, need_state: bool = True) -> _Frame:
         cfg = self.config
@@ -129,83 +119,229 @@ class OwnerShardedRasteriser:
             raise RuntimeError("the rasteriser needs tensors on a HIP device (no CPU path)")
         if not feats.is_contiguous() or feats.dtype != torch.float32 or feats.shape[1] != 56:
             raise TypeError("point_cloud_features must be a contiguous float32 [N,56] tensor (normalised in place)")
-        f = _Frame(width=width, height=height, color_max_sh_band=input_data.color_max_sh_band)
-        f.xyz = input_data.point_cloud.detach().contiguous()
-        f.features = feats.detach()
-        f.obj = input_data.point_object_id.to(torch.int32).contiguous()
+        fr = _Frame()
+        fr.width, fr.height = width, height
+        xyz = input_data.point_cloud.detach().contiguous()
+        features = feats.detach()
+        dev = xyz.device
+        obj = input_data.point_object_id.to(torch.int32).contiguous()
         invalid = input_data.point_invalid_mask.to(torch.int8).contiguous()
-        f.intrinsics = cam.camera_intrinsics.to(device=f.xyz.device, dtype=torch.float32).contiguous()
-        f.t_pc = input_data.t_pointcloud_camera.to(torch.float32).contiguous()
-        f.q_cp, f.t_cp = hip_ops.pose_inverse(input_data.q_pointcloud_camera.to(torch.float32).contiguous(), f.t_pc)
-        f.visible_mask, f.ids, f.counters = hip_ops.filter_compact(
-            f.xyz, invalid, f.obj, f.intrinsics, f.q_cp, f.t_cp, cfg.near_plane, cfg.far_plane, width, height,
-            sync=False, ws=self._scratch)
+        intrinsics = cam.camera_intrinsics.to(device=dev, dtype=torch.float32).contiguous()
+        q_pc = input_data.q_pointcloud_camera.to(torch.float32).reshape(-1, 4).contiguous()
+        t_pc = input_data.t_pointcloud_camera.to(torch.float32).reshape(-1, 3).contiguous()
+        if q_pc.shape[0] != t_pc.shape[0] or q_pc.shape[0] == 0:
+            raise ValueError("q_pointcloud_camera / t_pointcloud_camera must be (K,4)/(K,3) with K >= 1")
+        fr.keep = [xyz, features, obj, invalid, intrinsics, q_pc, t_pc]
+        n, n_obj, world = xyz.shape[0], q_pc.shape[0], self.world
+        layout = self._layout(height, False)
+        slab = Slab()
+        slab.add("q_cp", 16 * n_obj)
+        slab.add("t_cp", 12 * n_obj)
+        slab.add("counters", 4 * hip_ops.NUM_COUNTERS)
+        slab.add("visible_mask", n)
+        slab.add("ids", 4 * n)
+        slab.add("attrs", 64 * n)
+        slab.add("ntiles", 4 * n)
+        slab.add("nkeys", 4 * n)
+        slab.add("route_counts", 4 * world)
+        slab.add("pos", 4 * world * max(n, 1))
+        slab.allocate(dev)
+        lib = _lib.load()
+        f = _lib.GsFrame()
+        f.n_points, f.n_objects, f.width, f.height = n, n_obj, width, height
         # full-image ownership: a record is completed (conic, colour) iff the Gaussian emits a key ANYWHERE on the image
-        f.attrs, f.num_overlap_tiles, f.num_keys, _, _ = hip_ops.preprocess(
-            f.xyz, f.features, f.obj, f.intrinsics, f.q_cp, f.t_cp, f.ids, width, height, self._layout(height, False),
-            cfg.depth_to_sort_key_scale, f.counters, n_visible_on_device=True,
-            always_store_rotation=self.always_store_normalised_rotation, ws=self._scratch)
-        rows_per_band = uniform_band_rows(height // TILE, self.world)
-        f.counts, f.route_ws = hip_ops.route_count(f.attrs, f.num_keys, f.counters, width, height, rows_per_band,
-                                                   self.world)
-        return f
+        f.tile_row_begin, f.tile_row_step, f.tile_row_end = 0, 1, hip_ops._NO_ROW_LIMIT
+        f.bin_shift, f.exact_tile_cull = layout.bin_shift, int(layout.exact_cull)
+        f.always_store_rotation = int(bool(self.always_store_normalised_rotation))
+        f.color_max_sh_band = int(input_data.color_max_sh_band)
+        f.near_plane, f.far_plane, f.depth_scale = cfg.near_plane, cfg.far_plane, cfg.depth_to_sort_key_scale
+        f.grad_q_factor, f.grad_s_factor, f.grad_alpha_factor = cfg.grad_q_factor, cfg.grad_s_factor, cfg.grad_alpha_factor
+        f.grad_color_factor, f.grad_high_order_color_factor = cfg.grad_color_factor, cfg.grad_high_order_color_factor
+        f.world, f.rows_per_band = world, uniform_band_rows(height // TILE, world)
+        f.xyz, f.features, f.invalid_mask, f.object_id = xyz.data_ptr(), features.data_ptr(), invalid.data_ptr(), obj.data_ptr()
+        f.intrinsics, f.q_pointcloud_camera, f.t_pointcloud_camera = intrinsics.data_ptr(), q_pc.data_ptr(), t_pc.data_ptr()
+        f.q_camera_pointcloud, f.t_camera_pointcloud = slab.ptr("q_cp"), slab.ptr("t_cp")
+        f.visible_mask, f.ids, f.counters = slab.ptr("visible_mask"), slab.ptr("ids"), slab.ptr("counters")
+        f.attrs, f.num_overlap_tiles, f.num_keys = slab.ptr("attrs"), slab.ptr("ntiles"), slab.ptr("nkeys")
+        nblk = (n + 255) // 256
+        f.block_sums = self._ws("o_block_sums", 4 * nblk, dev)
+        f.block_sums_full = self._ws("o_block_sums_full", 4 * nblk, dev)
+        f.filter_workspace = self._ws("o_filter", lib.gs_filter_workspace_bytes(n), dev)
+        f.route_workspace = self._ws("o_route", lib.gs_route_workspace_bytes(n, world), dev)
+        f.route_counts, f.route_pos = slab.ptr("route_counts"), slab.ptr("pos")
+        S = _lib.STAGES
+        self._call("gs_frame_forward", f, S["GS_FWD_POSE_INVERSE"] | S["GS_FWD_FILTER_COMPACT"] | S["GS_FWD_PREPROCESS"] |
+                   S["GS_FWD_ROUTE_COUNT"], dev)
+        fr.owner, fr.owner_slab = f, slab
+        fr.counts = slab.tensor("route_counts", torch.int32, (world,))
+        fr.counters = slab.tensor("counters", torch.int32, (hip_ops.NUM_COUNTERS,))
+        return fr
 
     # ------------------------------------------------------------------ phase A2: the send chunks
-    def pack(self, f: _Frame, capacity: int, n_visible: int) -> torch.Tensor:
+    def pack(self, fr: _Frame, capacity: int, n_visible: int) -> torch.Tensor:
         """-> send f32[world, capacity + 1, 16].  capacity: slots per chunk, the same on every rank (>= every count of
         every rank); n_visible: this rank's visible count (both known to the host after the one size read of the frame)."""
-        rows_per_band = uniform_band_rows(f.height // TILE, self.world)
-        f.capacity, f.n_visible = int(capacity), int(n_visible)
-        send, f.pos = hip_ops.route_scatter(f.attrs, f.num_keys, f.counters, f.width, f.height, rows_per_band, self.world,
-                                            capacity, f.counts, f.route_ws)
+        f = fr.owner
+        fr.capacity, fr.n_visible = int(capacity), int(n_visible)
+        dev = fr.keep[0].device
+        send = torch.empty((self.world, capacity + 1, hip_ops.ATTR_STRIDE), dtype=torch.float32, device=dev)
+        f.chunk_capacity, f.route_send = int(capacity), send.data_ptr()
+        self._call("gs_frame_forward", f, _lib.STAGES["GS_FWD_ROUTE_SCATTER"], dev)
         return send
 
     # ------------------------------------------------------------------ phase B: bin, sort, blend the received records
-    def blend(self, f: _Frame, received: torch.Tensor, need_state: bool = True, gather_in_place: bool = True):
+    def blend(self, fr: _Frame, received: torch.Tensor, need_state: bool = True, gather_in_place: bool = True):
         """received f32[world, capacity + 1, 16]: chunk s = what rank s sent to this band.  -> (image, depth, count):
         this rank's tile rows rendered (allocated so that the all-gather of the other bands runs in place)."""
         cfg = self.config
-        width, height = f.width, f.height
+        width, height = fr.width, fr.height
+        dev = received.device
         layout = self._layout(height, True)
-        f.records, f.band_layout = received, layout
-        records = received.view(-1, hip_ops.ATTR_STRIDE)
-        counters, ntiles, nkeys, bsums, bsums_full = hip_ops.count_keys(received, width, height, layout,
-                                                                        cfg.depth_to_sort_key_scale, ws=self._scratch)
-        n_keys, n_slots, max_depth_key, _ = hip_ops.scan_block_sums(bsums, counters, bsums_full)   # (one size read)
+        fr.records, fr.band_layout = received, layout
+        n_rec = received.shape[0] * received.shape[1]
         num_bins = layout.num_bins(width, height)
-        kdb, depth_bits, tile_bits = hip_ops.key_layout(cfg.near_plane, cfg.far_plane, cfg.depth_to_sort_key_scale,
-                                                        num_bins, max_depth_key)
-        keys, payload, slot_offsets = hip_ops.make_keys(
-            records, nkeys, bsums, n_keys, width, height, cfg.depth_to_sort_key_scale, layout, kdb,
-            ntiles if need_state else None, bsums_full if need_state else None, ws=self._scratch)
-        keys, payload = hip_ops.sort_pairs(keys, payload, depth_bits, tile_bits, kdb, in_place=False, ws=self._scratch)
-        start, end = hip_ops.tile_ranges(keys, num_bins, kdb)
-        del keys
-        work = None
-        if need_state and self.ordered_dispatch:
-            work = torch.empty(hip_ops.num_owned_tiles(width, height, layout), dtype=torch.int32, device=records.device)
-        emit = bool(need_state and self.backward_on_walked_lists and layout.filter != 0 and layout.bin_shift <= 2 and
-                    (max(payload.shape[0], 1) << (2 * layout.bin_shift)) < 2 ** 31)
+        n_bins = (num_bins + 1) & ~1
+        pixels = width * height
+        tiles = (width // TILE) * (height // TILE)
+        owned_tiles = hip_ops.num_owned_tiles(width, height, layout)
         rgb_only = bool(cfg.rgb_only)
-        blended = hip_ops.blend_forward(
-            start, end, payload, records, width, height, layout, rgb_only=rgb_only, need_state=need_state,
-            gathered_rows=padded_image_rows(height, self.world) if gather_in_place else 0, ordered=self.ordered_dispatch,
-            tile_work=work, ws=self._scratch, emit_walked_lists=emit)
+        ordered = bool(self.ordered_dispatch)
+        guess_key = (width, height, layout, cfg.near_plane, cfg.far_plane, cfg.depth_to_sort_key_scale)
+        guess = self._size_guesses.get(guess_key) if self.speculative_sizes else None
+        cap = int(guess[0]) if guess else 0
+        shift2 = 2 * layout.bin_shift
+        emit = bool(guess and need_state and self.backward_on_walked_lists and layout.filter != 0 and
+                    layout.bin_shift <= 2 and (max(cap, 1) << shift2) < 2 ** 31)
+        slab = Slab()
+        slab.add("counters", 4 * hip_ops.NUM_COUNTERS)
+        slab.add("ntiles", 4 * n_rec)
+        slab.add("nkeys", 4 * n_rec)
+        slab.add("ranges", 8 * n_bins)
+        if need_state:
+            slab.add("slot_offsets", 4 * n_rec)
+            slab.add("acc_alpha", 4 * pixels)
+            slab.add("last_eff", 4 * pixels)
+            if ordered:
+                slab.add("tile_work", 4 * owned_tiles)
         if emit:
-            start, payload, blended = blended[5], blended[6], blended[:5]
-        image, depth, acc_alpha, last_eff, count = blended
+            slab.add("walked_list", 4 * (max(cap, 1) << shift2))
+            slab.add("walked_start", 4 * tiles)
+        elif guess:
+            slab.add("payload", 4 * max(cap, 1))
+            slab.add("payload_alt", 4 * max(cap, 1))
+        slab.allocate(dev)
+        lib = _lib.load()
+        if gather_in_place:
+            rows = padded_image_rows(height, self.world)
+            image = torch.empty((rows, width, 3), dtype=torch.float32, device=dev)[:height]
+            depth = None if rgb_only else torch.empty((rows, width), dtype=torch.float32, device=dev)[:height]
+            count = None if rgb_only else torch.empty((rows, width), dtype=torch.int32, device=dev)[:height]
+        else:
+            image = torch.zeros((height, width, 3), dtype=torch.float32, device=dev)
+            depth = None if rgb_only else torch.zeros((height, width), dtype=torch.float32, device=dev)
+            count = None if rgb_only else torch.zeros((height, width), dtype=torch.int32, device=dev)
+        if self._readback is None:
+            self._readback = hip_ops.CounterReadback(dev)
+            self._readback.event.record(torch.cuda.current_stream(dev))   # creates the event the library records by handle
+        b = _lib.GsFrame()
+        b.n_points, b.width, b.height = n_rec, width, height
+        b.tile_row_begin, b.tile_row_step, b.tile_row_end = layout.row_begin, layout.row_step, layout.row_end
+        b.bin_shift, b.exact_tile_cull = layout.bin_shift, int(layout.exact_cull)
+        b.blend_flags = (hip_ops.BLEND_RGB_ONLY if rgb_only else 0) | (0 if need_state else hip_ops.BLEND_NO_STATE)
+        b.need_state = int(bool(need_state))
+        b.near_plane, b.far_plane, b.depth_scale = cfg.near_plane, cfg.far_plane, cfg.depth_to_sort_key_scale
+        b.world, b.chunk_capacity, b.n_records = self.world, fr.capacity, n_rec
+        b.records = received.data_ptr()
+        b.counters = slab.ptr("counters")
+        b.host_counters_pinned, b.size_event = self._readback.host.data_ptr(), self._readback.event.cuda_event
+        b.num_overlap_tiles, b.num_keys, b.slot_offsets = slab.ptr("ntiles"), slab.ptr("nkeys"), slab.ptr("slot_offsets")
+        nblk = (n_rec + 255) // 256
+        b.block_sums = self._ws("b_block_sums", 4 * nblk, dev)
+        b.block_sums_full = self._ws("b_block_sums_full", 4 * nblk, dev)
+        b.bin_ranges, b.n_bins = slab.ptr("ranges"), n_bins
+        b.image = image.data_ptr()
+        b.depth = 0 if depth is None else depth.data_ptr()
+        b.valid_count = 0 if count is None else count.data_ptr()
+        b.acc_alpha, b.last_effective = slab.ptr("acc_alpha"), slab.ptr("last_eff")
+        b.tile_order = self._ws("b_order_fwd", 4 * owned_tiles, dev) if ordered else 0
+        b.tile_work = slab.ptr("tile_work")
+        S = _lib.STAGES
+        stages = S["GS_FWD_COUNT_KEYS"] | S["GS_FWD_SCAN"] | S["GS_FWD_READ_SIZES"]
+        if guess:   # the list stages and the blend, speculatively, behind the size read
+            kdb, depth_bits, tile_bits = hip_ops.key_layout(cfg.near_plane, cfg.far_plane, cfg.depth_to_sort_key_scale,
+                                                            num_bins, int(guess[1]))
+            key_bytes = 4 if kdb > 0 else 8
+            b.key_depth_bits, b.depth_bits, b.tile_bits, b.n_keys_capacity = kdb, depth_bits, tile_bits, cap
+            b.keys = self._ws("b_keys", key_bytes * cap, dev)
+            b.keys_alt = self._ws("b_keys_alt", key_bytes * cap, dev)
+            if emit:
+                b.payload, b.payload_alt = self._ws("b_payload", 4 * cap, dev), self._ws("b_payload_alt", 4 * cap, dev)
+                b.walked_list, b.walked_start = slab.ptr("walked_list"), slab.ptr("walked_start")
+            else:
+                b.payload, b.payload_alt = slab.ptr("payload"), slab.ptr("payload_alt")
+            b.sort_workspace = self._ws("b_sort", lib.gs_sort_workspace_bytes(cap), dev)
+            stages |= S["GS_FWD_MAKE_KEYS"] | S["GS_FWD_SORT"] | S["GS_FWD_RANGES"] | S["GS_FWD_BLEND"]
+        self._call("gs_frame_forward", b, stages, dev)
+        host = self._readback.wait()
+        n_keys, n_slots = host[hip_ops.COUNTER_NUM_KEYS], host[hip_ops.COUNTER_NUM_SLOTS]
+        max_depth_key = host[hip_ops.COUNTER_MAX_DEPTH_KEY]
+        if n_keys >= 0x7fffffff or n_slots >= 0x7fffffff:
+            raise RuntimeError("more than 2^31-1 (tile, Gaussian) pairs: key offsets are int32 as in the reference")
+        fits = bool(guess) and n_keys <= guess[0] and max_depth_key <= guess[1]
+        self.speculation_stats["frames"] += 1
+        self.speculation_stats["redone"] += 1 if (guess and not fits) else 0
+        depth_bound = (1 << max(int(max_depth_key), 1).bit_length()) - 1
+        if guess and depth_bound <= guess[1] <= 4 * depth_bound + 3:
+            depth_bound = guess[1]
+        if len(self._size_guesses) >= 16 and guess_key not in self._size_guesses:
+            self._size_guesses.pop(next(iter(self._size_guesses)))
+        self._size_guesses[guess_key] = (max(int(1.3 * n_keys) + 4096, int(0.99 * guess[0]) if guess else 0), depth_bound)
+        fr.band, fr.band_slab, fr.walked = b, slab, emit
+        if not fits:   # first frame, or the frame outgrew the speculative sizes: the list stages with exact sizes
+            records = received.view(-1, hip_ops.ATTR_STRIDE)
+            nkeys = slab.tensor("nkeys", torch.int32, (n_rec,))
+            ntiles = slab.tensor("ntiles", torch.int32, (n_rec,))
+            bsums = self._scratch.get("b_block_sums", max(4 * nblk, 16), torch.uint8, dev).view(torch.int32)[:nblk]
+            bsums_full = self._scratch.get("b_block_sums_full", max(4 * nblk, 16), torch.uint8, dev).view(torch.int32)[:nblk]
+            kdb, depth_bits, tile_bits = hip_ops.key_layout(cfg.near_plane, cfg.far_plane, cfg.depth_to_sort_key_scale,
+                                                            num_bins, max_depth_key)
+            keys, payload, slot_offsets = hip_ops.make_keys(
+                records, nkeys, bsums, n_keys, width, height, cfg.depth_to_sort_key_scale, layout, kdb,
+                ntiles if need_state else None, bsums_full if need_state else None, ws=self._scratch)
+            keys, payload = hip_ops.sort_pairs(keys, payload, depth_bits, tile_bits, kdb, in_place=False, ws=self._scratch)
+            start, end = hip_ops.tile_ranges(keys, num_bins, kdb)
+            del keys
+            emit = bool(need_state and self.backward_on_walked_lists and layout.filter != 0 and layout.bin_shift <= 2 and
+                        (max(payload.shape[0], 1) << shift2) < 2 ** 31)
+            out = (image, depth,
+                   slab.tensor("acc_alpha", torch.float32, (height, width)) if need_state else None,
+                   slab.tensor("last_eff", torch.int32, (height, width)) if need_state else None, count)
+            work = slab.tensor("tile_work", torch.int32, (owned_tiles,)) if (need_state and ordered) else None
+            blended = hip_ops.blend_forward(start, end, payload, records, width, height, layout, out=out,
+                                            rgb_only=rgb_only, need_state=need_state, ordered=ordered, tile_work=work,
+                                            ws=self._scratch, emit_walked_lists=emit)
+            if emit:
+                start, payload = blended[5], blended[6]
+            fr.keep += [start, payload, slot_offsets]
+            b.list_start, b.list_payload = start.data_ptr(), payload.data_ptr()
+            if slot_offsets is not None:
+                b.slot_offsets = slot_offsets.data_ptr()
+            fr.walked = emit
+        elif emit:
+            b.list_start, b.list_payload = b.walked_start, b.walked_list
+        else:
+            b.list_start = b.bin_ranges
+            b.list_payload = b.payload_alt if b.sorted_in_alt else b.payload
         if rgb_only:
-            depth = torch.zeros((height, width), dtype=torch.float32, device=records.device)
-            count = torch.zeros((height, width), dtype=torch.int32, device=records.device)
-        f.band_num_overlap_tiles, f.band_num_keys, f.slot_offsets = ntiles, nkeys, slot_offsets
-        f.n_slots, f.n_keys = int(n_slots), int(n_keys)
-        f.list_start, f.payload, f.acc_alpha, f.last_eff, f.tile_work = start, payload, acc_alpha, last_eff, work
-        f.layout_bwd = hip_ops.walked_layout(layout) if emit else layout
-        f.outputs = (image, depth, count)
+            depth = torch.zeros((height, width), dtype=torch.float32, device=dev)
+            count = torch.zeros((height, width), dtype=torch.int32, device=dev)
+        fr.n_slots, fr.n_keys = int(n_slots), int(n_keys)
+        fr.layout_bwd = hip_ops.walked_layout(layout) if fr.walked else layout
+        fr.outputs = (image, depth, count)
         # next frame's list layout: the single-GPU operator's rule on this band's key count scaled to the whole image
         owned = max(len(layout.owned_rows(height)), 1)
         k_frame = n_keys * (height // TILE) / owned
-        m = max(int(records.shape[0]), 1)
+        m = max(n_rec, 1)
         used = layout.bin_shift
         if n_keys > 0:
             if used == 0:
@@ -214,42 +350,71 @@ class OwnerShardedRasteriser:
                 self._auto_bin_shift = 2 if k_frame >= 16 * m else (0 if k_frame < 700_000 else 1)
             else:
                 self._auto_bin_shift = 1 if k_frame < 3 * m else used
-        f.stats.update(records_received=int(records.shape[0]), keys=f.n_keys, slots=f.n_slots, bin_shift=used)
-        return f.outputs
+        fr.stats.update(records_received=n_rec, keys=fr.n_keys, slots=fr.n_slots, bin_shift=used,
+                        speculative=bool(guess), fits=fits)
+        return fr.outputs
 
     # ------------------------------------------------------------------ phase C: the band's pixels, backward
-    def backward_band(self, f: _Frame, grad_image: torch.Tensor) -> torch.Tensor:
+    def backward_band(self, fr: _Frame, grad_image: torch.Tensor) -> torch.Tensor:
         """-> f32[world, capacity + 1, 12]: chunk s = the accumulator rows of the records rank s sent, to be returned."""
-        records = f.records.view(-1, hip_ops.ATTR_STRIDE)
-        partials, flags, magnitude = hip_ops.blend_backward_partials(
-            f.list_start, f.payload, records, grad_image, f.acc_alpha, f.last_eff, f.slot_offsets, f.n_slots, f.width,
-            f.height, f.layout_bwd, tile_work=f.tile_work, ws=self._scratch)
-        acc = hip_ops.reduce_partials(f.slot_offsets, f.band_num_overlap_tiles, flags, partials, f.band_num_keys, records,
-                                      f.width, f.height)
-        f.stats["magnitude_image"] = magnitude
-        return acc.view(self.world, f.capacity + 1, hip_ops.ACC_STRIDE)
+        b = fr.band
+        dev = grad_image.device
+        width, height = fr.width, fr.height
+        grad_image = grad_image.contiguous()
+        if grad_image.dtype != torch.float32:
+            raise TypeError("grad_rasterized_image must be float32")
+        n_slots = max(fr.n_slots, 1)
+        b.n_slots = fr.n_slots
+        b.backward_bin_shift, b.backward_filter = fr.layout_bwd.bin_shift, fr.layout_bwd.filter
+        b.grad_image = grad_image.data_ptr()
+        b.partials = self._ws("b_partials", 48 * n_slots, dev)
+        b.slot_flags = self._ws("b_slot_flags", (n_slots + 15) & ~15, dev)
+        magnitude = torch.zeros((height, width, 2), dtype=torch.float32, device=dev)   # this rank's band, zeros elsewhere
+        b.magnitude_image = magnitude.data_ptr()
+        b.tile_order_backward = self._ws("b_order_bwd", 4 * hip_ops.num_owned_tiles(width, height, fr.band_layout), dev) \
+            if b.tile_work else 0
+        rows = torch.empty((self.world, fr.capacity + 1, hip_ops.ACC_STRIDE), dtype=torch.float32, device=dev)
+        b.acc = rows.data_ptr()
+        fr.keep.append(grad_image)
+        S = _lib.STAGES
+        self._call("gs_frame_backward", b, S["GS_BWD_BLEND"] | S["GS_BWD_REDUCE"], dev)
+        fr.stats["magnitude_image"] = magnitude
+        return rows
 
     # ------------------------------------------------------------------ phase D: the rank's own rows, backward
-    def backward_points(self, f: _Frame, returned: torch.Tensor):
+    def backward_points(self, fr: _Frame, returned: torch.Tensor):
         """returned f32[world, capacity + 1, 12]: chunk b = the rows band b produced for this rank's records.
         -> (grad_point_cloud [N_g,3], grad_point_cloud_features [N_g,56]); calls the hook with this rank's fields."""
-        cfg = self.config
-        m = f.n_visible
-        acc = hip_ops.gather_returned_rows(returned, f.pos, m, f.capacity)
-        ids, attrs = f.ids[:m], f.attrs[:m]
+        f, slab = fr.owner, fr.owner_slab
+        m, n = fr.n_visible, f.n_points
+        dev = returned.device
         hook = self.hook
-        out = hip_ops.point_backward(
-            f.xyz, f.features, f.obj, f.intrinsics, f.q_cp, f.t_cp, f.t_pc, ids, acc, attrs, f.color_max_sh_band,
-            cfg.grad_q_factor, cfg.grad_s_factor, cfg.grad_alpha_factor, cfg.grad_color_factor,
-            cfg.grad_high_order_color_factor, want_visible=hook is not None, visible_mask=f.visible_mask,
-            num_owned_tiles=f.num_keys[:m], want_visible_features=hook is not None and self.hook_feature_gradients,
-            want_hook_fields=hook is not None, width=f.width, height=f.height)
-        grad_xyz, grad_feat, gx_vis, gf_vis = out[:4]
+        f.n_visible = m
+        f.returned_rows = returned.data_ptr()
+        f.acc = self._ws("o_acc", 48 * max(m, 1), dev)
+        grad_xyz = torch.empty((n, 3), dtype=torch.float32, device=dev)
+        grad_feat = torch.empty((n, hip_ops.FEATURE_DIM), dtype=torch.float32, device=dev)
+        f.grad_xyz, f.grad_features = grad_xyz.data_ptr(), grad_feat.data_ptr()
+        gx_vis = gf_vis = fields = None
+        f.grad_xyz_visible = f.grad_features_visible = f.hook_compact = 0
+        if hook is not None:
+            gx_vis = torch.empty((m, 3), dtype=torch.float32, device=dev)
+            compact = torch.empty(7 * m, dtype=torch.float32, device=dev)
+            f.grad_xyz_visible, f.hook_compact = gx_vis.data_ptr(), compact.data_ptr()
+            if self.hook_feature_gradients:
+                gf_vis = torch.empty((m, hip_ops.FEATURE_DIM), dtype=torch.float32, device=dev)
+                f.grad_features_visible = gf_vis.data_ptr()
+            fields = dict(grad_viewspace=compact[0:2 * m].view(m, 2), magnitude_grad_viewspace=compact[2 * m:3 * m],
+                          num_affected_pixels=compact[3 * m:4 * m].view(torch.int32), point_depth=compact[4 * m:5 * m],
+                          point_uv_in_camera=compact[5 * m:7 * m].view(m, 2))
+        S = _lib.STAGES
+        self._call("gs_frame_backward", f, S["GS_BWD_GATHER_RETURNED"] | S["GS_BWD_POINTS"], dev)
         if hook is not None:   # RAS:1127-1142, with THIS RANK's rows: ids index the rank's block of the point cloud
             hook(_Op.BackwardValidPointHookInput(
-                point_id_in_camera_list=ids, grad_point_in_camera=gx_vis, grad_pointfeatures_in_camera=gf_vis,
-                magnitude_grad_viewspace_on_image=f.stats.get("magnitude_image"),   # this rank's band, zeros elsewhere
-                num_overlap_tiles=f.num_overlap_tiles[:m], **out[4]))
+                point_id_in_camera_list=slab.tensor("ids", torch.int32, (n,))[:m], grad_point_in_camera=gx_vis,
+                grad_pointfeatures_in_camera=gf_vis,
+                magnitude_grad_viewspace_on_image=fr.stats.get("magnitude_image"),   # this rank's band, zeros elsewhere
+                num_overlap_tiles=slab.tensor("ntiles", torch.int32, (n,))[:m], **fields))
         return grad_xyz, grad_feat
 
 
@@ -320,9 +485,9 @@ class OwnerShardedRasterisation(torch.nn.Module):
                 if f is None or not (ctx.needs_input_grad[0] or ctx.needs_input_grad[1]):
                     return None, None, None, None
                 core = outer.core
-                with _lib.stream_scope(f.xyz.device):
+                with _lib.stream_scope(f.keep[0].device):
                     if grad_image is None:
-                        grad_image = torch.zeros((f.height, f.width, 3), dtype=torch.float32, device=f.xyz.device)
+                        grad_image = torch.zeros((f.height, f.width, 3), dtype=torch.float32, device=f.keep[0].device)
                     rows = core.backward_band(f, grad_image.contiguous())
                     returned = _all_to_all_chunks(rows, outer.group)
                     grad_xyz, grad_feat = core.backward_points(f, returned)
@@ -391,4 +556,5 @@ def simulate_frame(cores: Sequence[OwnerShardedRasteriser], inputs: Sequence, gr
         timings["records_sent"] = host[:, :world].sum(dim=1).tolist()
         timings["visible"] = host[:, world].tolist()
         timings["frames"] = [dict(f.stats, magnitude_image=None) for f in frames]
+        timings["speculation"] = [dict(c.speculation_stats) for c in cores]
     return image, depth, count, grads
