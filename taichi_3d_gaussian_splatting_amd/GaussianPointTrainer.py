@@ -301,6 +301,10 @@ class GaussianPointCloudTrainer:
         last_problematic = -1000
 
         for iteration in range(cfg.num_iterations):
+            self.iteration_reached = iteration
+            # (addition: tools that train until a condition holds -- trained_workload.py -- set `stop_when`)
+            if getattr(self, "stop_when", None) is not None and self.stop_when(iteration):
+                break
             if iteration > 0 and iteration % cfg.half_downsample_factor_interval == 0 and downsample_factor > 1:
                 downsample_factor //= 2
             feature_optimizer.zero_grad(set_to_none=True)

@@ -102,6 +102,9 @@ def make_reference_stress_scene(seed: int = 0, n: int = 100_000, n_valid: int = 
 def make_config_scene(name: str, seed: int = 0) -> SyntheticScene:
     if name == "stress_t_ras":
         return make_reference_stress_scene(seed)
+    if name == "trained_1080p":   # a scene grown by the repository's own trainer (trained_workload.py; needs a HIP device)
+        from .trained_workload import load_or_make
+        return load_or_make("trained_1080p")["scene"]
     if name.startswith("custom:"):   # e.g. custom:n=200000,height=960,width=960,s_min=0.005,s_max=0.04 (tuning sweeps)
         kw = dict(item.split("=") for item in name[len("custom:"):].split(","))
         ints = ("n", "height", "width", "sh_degree")
