@@ -186,6 +186,10 @@ class GaussianPointCloudRasterisation(torch.nn.Module):
         # ~25 + ~5 launches back to back) instead of one foreign call per stage: same kernels, same arguments, same bits;
         # what changes is the host time per frame -- which bounds small frames.  False = stage by stage (hip_ops)
         self.frame_entry_points = True
+        # grids that cannot fill the chip (at most 3840 rendered tiles: down-sampled training frames, small views, a rank's
+        # band): the forward pass leaves per-pixel boundary states every 128 list entries and the backward pass gives a
+        # tile up to four workgroups (include/gsplat_hip.h "List splitting").  Same slot records up to rounding
+        self.split_small_grid_backward = True
         self._scratch = hip_ops.Workspaces()   # buffers that do not outlive a call, kept between frames
         self._size_guesses, self._readbacks = {}, {}   # (image size, list layout, planes) -> (key capacity, depth bound)
         self.speculation_stats = {"frames": 0, "redone": 0}
@@ -266,7 +270,9 @@ class GaussianPointCloudRasterisation(torch.nn.Module):
                             outer.image_gather([image] if rgb_only else [image, depth, count])
                         ctx.mark_non_differentiable(count)
                         if need_state:
-                            ctx.save_for_backward(xyz, pointcloud_features, state.slab.buf, obj, intrinsics, t_pc)
+                            # (a split backward pass reads the forward's image: saved as an output, in-place changes are caught)
+                            ctx.save_for_backward(xyz, pointcloud_features, state.slab.buf, obj, intrinsics, t_pc,
+                                                  image if state.split else None)
                             ctx.frame_state = state
                             ctx.camera_info = camera_info
                             ctx.set_materialize_grads(False)
@@ -336,13 +342,20 @@ class GaussianPointCloudRasterisation(torch.nn.Module):
                     # backward pass runs on those plain per-tile lists (no second filtering of the bin's entries)
                     emit = bool(need_state and outer.backward_on_walked_lists and layout.filter != 0 and
                                 layout.bin_shift <= 2 and (payload_.shape[0] << (2 * layout.bin_shift)) < 2 ** 31)
+                    boundary_ = None
+                    if need_state and outer.split_small_grid_backward:
+                        nbytes = hip_ops.boundary_states_bytes(payload_.shape[0] << (2 * layout.bin_shift if emit else 0),
+                                                               width, height, layout, emit)
+                        if nbytes:
+                            boundary_ = torch.empty(nbytes, dtype=torch.uint8, device=attrs_.device)
                     blended = hip_ops.blend_forward(start_, end_, payload_, attrs_, width, height, layout,
                                                     rgb_only=rgb_only, need_state=need_state,
                                                     gathered_rows=gathered_rows, ordered=outer.ordered_dispatch,
-                                                    tile_work=work_, ws=outer._scratch, emit_walked_lists=emit)
+                                                    tile_work=work_, ws=outer._scratch, emit_walked_lists=emit,
+                                                    boundary=boundary_)
                     if emit:   # what the backward pass walks: (list starts, list) of the emitted per-tile lists
                         start_, payload_, blended = blended[5], blended[6], blended[:5]
-                    return payload_, slot_offsets_, start_, blended, work_, emit
+                    return payload_, slot_offsets_, start_, blended, work_, emit, boundary_
 
                 result = None
                 if guess is not None:
@@ -360,7 +373,8 @@ class GaussianPointCloudRasterisation(torch.nn.Module):
                 if not fits:
                     result = lists_and_blend(attrs, num_owned_tiles, block_sums[:nb], block_sums_full[:nb],
                                              num_overlap_tiles, n_keys, max_depth_key, None)
-                payload, slot_offsets, tile_start, (image, depth, acc_alpha, last_eff, count), tile_work, walked = result
+                payload, slot_offsets, tile_start, (image, depth, acc_alpha, last_eff, count), tile_work, walked, \
+                    boundary = result
                 if slot_offsets is not None:
                     slot_offsets = slot_offsets[:m]
                 if rgb_only:
@@ -374,7 +388,8 @@ class GaussianPointCloudRasterisation(torch.nn.Module):
 
                 ctx.save_for_backward(xyz, pointcloud_features, payload, ids, tile_start, acc_alpha,
                                       last_eff, num_overlap_tiles, obj, q_cp, t_cp, t_pc, attrs, intrinsics,
-                                      slot_offsets, visible_mask, num_owned_tiles)
+                                      slot_offsets, visible_mask, num_owned_tiles, boundary,
+                                      image if boundary is not None else None)
                 ctx.tile_work = tile_work
                 ctx.layout_bwd = hip_ops.walked_layout(layout) if walked else layout
                 ctx.n_slots = n_slots
@@ -395,7 +410,7 @@ class GaussianPointCloudRasterisation(torch.nn.Module):
                 if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:  # RAS:1028
                     (xyz, features, payload, ids, tile_start, acc_alpha, last_eff, num_overlap_tiles,
                      obj, q_cp, t_cp, t_pc, attrs, intrinsics, slot_offsets, visible_mask,
-                     num_owned_tiles) = ctx.saved_tensors
+                     num_owned_tiles, boundary, image) = ctx.saved_tensors
                     cfg = outer.config
                     camera_info = ctx.camera_info
                     width, height = camera_info.camera_width, camera_info.camera_height
@@ -403,7 +418,8 @@ class GaussianPointCloudRasterisation(torch.nn.Module):
                     # RAS:531-705  per-pixel pass: one 48-B record per (Gaussian, tile) slot, no atomics
                     partials, slot_flags, magnitude_image = hip_ops.blend_backward_partials(
                         tile_start, payload, attrs, grad_rasterized_image, acc_alpha, last_eff, slot_offsets,
-                        ctx.n_slots, width, height, ctx.layout_bwd, tile_work=ctx.tile_work, ws=outer._scratch)
+                        ctx.n_slots, width, height, ctx.layout_bwd, tile_work=ctx.tile_work, ws=outer._scratch,
+                        image=image, boundary=boundary)
                     acc = slots = None
                     if outer.grad_accumulator_reduce is None and outer.fused_slot_reduction:
                         # the slot sums are formed inside the per-point kernel and stay in registers

@@ -23,6 +23,7 @@
 //  small   : grids of at most 3,840 tiles run both passes with FOUR waves per tile and one pixel per lane
 //            (blend_*_small_kernel): same per-pixel arithmetic, half the issue slots per wave and entry.
 #include "gs_common.h"
+#include <stdlib.h>
 #include "gs_slots.h"
 
 // Automatic FMA contraction is off in this file and every fused multiply-add is written explicitly:
@@ -87,10 +88,15 @@ struct TileCoord { int tile_u, tile_v, tile_id, index; };   // index: n-th owned
                          // Measured (tools/xcd_sweep.sh): C = 8, 120, 480 equal the default within 1 %; C = 30 (a fixed
                          // quarter of every tile row per XCD) is 25 % slower -- XCD load balance matters, L2 locality less.
 #endif
+__device__ __forceinline__ TileCoord owned_tile_at(int b, int nb, int tw, int row_begin, int row_step,
+                                                   const int32_t *__restrict__ tile_order);
 __device__ __forceinline__ TileCoord owned_tile(int tw, int row_begin, int row_step,
                                                 const int32_t *__restrict__ tile_order = nullptr) {
-    const int nb = gridDim.x;
-    int b = blockIdx.x;
+    return owned_tile_at(blockIdx.x, gridDim.x, tw, row_begin, row_step, tile_order);
+}
+// (b-th of nb workgroups: kernels that give a tile several workgroups pass blockIdx / split and gridDim / split)
+__device__ __forceinline__ TileCoord owned_tile_at(int b, int nb, int tw, int row_begin, int row_step,
+                                                   const int32_t *__restrict__ tile_order) {
     if (tile_order != nullptr) {
         b = tile_order[b];   // dispatch order (longest walks first, tile_order_kernel): a permutation of the owned tiles
     } else if (GS_XCD_CHUNK > 0) {
@@ -323,7 +329,7 @@ __global__ __launch_bounds__(BLEND_THREADS) void blend_forward_kernel(
     int row_step, int bin_shift, int filter, float *__restrict__ image, float *__restrict__ depth,
     float *__restrict__ acc_alpha, int32_t *__restrict__ last_effective, int32_t *__restrict__ valid_count,
     uint32_t *__restrict__ debug_hits, const int32_t *__restrict__ tile_order, int32_t *__restrict__ tile_work,
-    int32_t *__restrict__ walked_list, int32_t *__restrict__ walked_start) {
+    int32_t *__restrict__ walked_list, int32_t *__restrict__ walked_start, float4 *__restrict__ boundary) {
     __shared__ float4 s_p[BATCH], s_c[BATCH], s_q[BATCH];  // rows 0, 2, 3 of the kept records
     __shared__ int s_j[BATCH];                             // their list positions (last_effective is one of them + 1)
     __shared__ int s_o[DEBUG ? BATCH : 1];
@@ -451,6 +457,14 @@ __global__ __launch_bounds__(BLEND_THREADS) void blend_forward_kernel(
             }
         }
         kept_base += nbuf;
+        // Boundary states (split backward, see blend_backward_small_kernel): the pixel's transmittance and colour after
+        // every 128 entries of the tile's own list, at slot (list position >> 7) -- unique, because the tiles' lists are
+        // disjoint ranges and two boundaries of one list are 128 positions apart
+        if (STATE && boundary != nullptr && (emit || !STAGED) && nbuf == BATCH && pos < end) {
+            const size_t slot = (size_t)((emit ? wbase + kept_base : pos) >> 7) * 256 + (tid >> 3) * 16 + 2 * (tid & 7);
+            boundary[slot] = make_float4(T.x, Cr.x, Cg.x, Cb.x);
+            boundary[slot + 1] = make_float4(T.y, Cr.y, Cg.y, Cb.y);
+        }
     }
     const size_t p = (size_t)pv * width + pu;
     float *img = image + 3 * p;
@@ -805,7 +819,7 @@ __global__ __launch_bounds__(SMALL_THREADS) void blend_forward_small_kernel(
     const int32_t *__restrict__ payload, const float4 *__restrict__ attrs, int width, int height, int row_begin,
     int row_step, float *__restrict__ image, float *__restrict__ depth, float *__restrict__ acc_alpha,
     int32_t *__restrict__ last_effective, int32_t *__restrict__ valid_count, uint32_t *__restrict__ debug_hits,
-    const int32_t *__restrict__ tile_order, int32_t *__restrict__ tile_work) {
+    const int32_t *__restrict__ tile_order, int32_t *__restrict__ tile_work, float4 *__restrict__ boundary) {
     __shared__ float4 s_p[BATCH], s_c[BATCH], s_q[BATCH];
     __shared__ int s_o[DEBUG ? BATCH : 1];
     __shared__ int s_red[SMALL_THREADS / GS_WAVE];
@@ -881,6 +895,9 @@ __global__ __launch_bounds__(SMALL_THREADS) void blend_forward_small_kernel(
                 }
             }
         }
+        // boundary state after every 128 list entries (split backward; slot = list position >> 7, see the main kernel)
+        if (STATE && boundary != nullptr && pos < end)
+            boundary[(size_t)(pos >> 7) * 256 + tid] = make_float4(T, Cr, Cg, Cb);
     }
     const size_t p = (size_t)pv * width + pu;
     image[3 * p] = Cr; image[3 * p + 1] = Cg; image[3 * p + 2] = Cb;
@@ -903,13 +920,26 @@ __global__ __launch_bounds__(SMALL_THREADS) void blend_forward_small_kernel(
     if (DEBUG) { debug_hits[2 * p] = dc; debug_hits[2 * p + 1] = dh; }
 }
 
+// LIST SPLITTING (round 4).  On a grid that cannot fill the chip the launch lasts as long as the longest tile's dependent
+// chain (10k Gaussians at 256 x 256: 109 us for 256 workgroups).  The backward recursion of a pixel runs from the end of
+// its list to the start, but it can be CUT at any list position b if the state at b is known: the transmittance T_b in
+// front of entry b and the colour still to come, S_b = dL/dC . (C_final - C_b).  The forward pass leaves (T_b, C_b) of every
+// pixel at every 128th list position (`boundary`, 16 B per pixel and boundary); with them `split` workgroups share a
+// tile's list -- workgroup s walks the batches [s nb / split, (s + 1) nb / split) of 128 entries, the last one starts from
+// the final state as before.  Every list entry is still walked by exactly one workgroup, so the (Gaussian, tile) slot
+// records are written once, by plain stores, and stay bitwise reproducible; a slot sum differs from the un-split one in
+// rounding only (T_b as the forward computed it instead of recovered by divisions, S_b by subtraction).  The per-pixel
+// |grad uv| image is the sum of the segments' parts: each segment stores its part, the workgroup that arrives LAST at
+// the tile's counter adds the parts in segment order (deterministic) and resets the counter.
 template <bool DEBUG>
 __global__ __launch_bounds__(SMALL_THREADS) void blend_backward_small_kernel(
     const int32_t *__restrict__ tile_start, const int32_t *__restrict__ payload, const float4 *__restrict__ attrs,
     const float *__restrict__ grad_image, const float *__restrict__ acc_alpha, const int32_t *__restrict__ last_effective,
     int width, int height, int row_begin, int row_step, const int32_t *__restrict__ slot_offsets,
     float4 *__restrict__ partials, uint8_t *__restrict__ slot_flags, float *__restrict__ magnitude_image,
-    uint32_t *__restrict__ debug_hits, const int32_t *__restrict__ tile_order) {
+    uint32_t *__restrict__ debug_hits, const int32_t *__restrict__ tile_order, int split,
+    const float *__restrict__ image, const float4 *__restrict__ boundary, int32_t *__restrict__ tile_counters,
+    float2 *__restrict__ magnitude_parts) {
     __shared__ float4 s_p[BATCH], s_b[BATCH], s_c[BATCH], s_q[BATCH];
     __shared__ int s_o[BATCH];
     // one slice of partial sums PER WAVE, written with plain stores and added in a fixed order by the flush: four waves
@@ -918,14 +948,16 @@ __global__ __launch_bounds__(SMALL_THREADS) void blend_backward_small_kernel(
     __shared__ float s_acc[SMALL_THREADS / GS_WAVE][BATCH][GS_ACC_STRIDE];
     __shared__ int s_max[SMALL_THREADS / GS_WAVE];
     const int tw = width / GS_TILE_WIDTH, th = height / GS_TILE_HEIGHT;
-    const TileCoord tc = owned_tile(tw, row_begin, row_step, tile_order);
+    const int seg = split > 1 ? (int)blockIdx.x % split : 0;
+    const TileCoord tc = owned_tile_at(split > 1 ? (int)blockIdx.x / split : (int)blockIdx.x,
+                                       split > 1 ? (int)gridDim.x / split : (int)gridDim.x, tw, row_begin, row_step,
+                                       tile_order);
     const int tid = threadIdx.x, lane = tid & 63;
     const int pu = tc.tile_u * GS_TILE_WIDTH + (tid & 15), pv = tc.tile_v * GS_TILE_HEIGHT + (tid >> 4);
     const size_t p = (size_t)pv * width + pu;
     const int start = tile_start[tc.tile_id];
     const float px = (float)pu + 0.5f, py = (float)pv + 0.5f;
     const int last = last_effective[p];
-    float T = 1.0f - acc_alpha[p], S = 0.f;
     const float Gr = grad_image[3 * p], Gg = grad_image[3 * p + 1], Gb = grad_image[3 * p + 2];
     float mag_u = 0.f, mag_v = 0.f;
     unsigned dh = 0u, dc = 0u;
@@ -936,24 +968,35 @@ __global__ __launch_bounds__(SMALL_THREADS) void blend_backward_small_kernel(
     if (lane == 0) s_max[tid >> 6] = mx;
     __syncthreads();
     const int end = max(max(s_max[0], s_max[1]), max(s_max[2], s_max[3]));
+    // this workgroup's batches of the tile's list (batch k = positions start + 128 k ...), highest first
+    const int n_batches = end > start ? (end - start + BATCH - 1) / BATCH : 0;
+    const int k_lo = (int)((long long)seg * n_batches / split), k_hi = (int)((long long)(seg + 1) * n_batches / split);
+    float T, S;
+    if (k_hi == n_batches) {   // the end of the list: the pixel's final state
+        T = 1.0f - acc_alpha[p];
+        S = 0.f;
+    } else {                   // a cut: the state the forward pass left at list position start + 128 k_hi
+        const float4 st = boundary[(size_t)((start + BATCH * k_hi) >> 7) * 256 + tid];
+        T = st.x;
+        S = __builtin_fmaf(image[3 * p + 2] - st.w, Gb, __builtin_fmaf(image[3 * p + 1] - st.z, Gg, (image[3 * p] - st.y) * Gr));
+    }
     const int row = lane >> 4;
     const int slot = ((row & 1) << 1) | (row >> 1);
     const bool row_tail = (lane & 15) == 15;
-    int pos = end - 1;
-    while (pos >= start) {
+    for (int kb = k_hi - 1; kb >= k_lo; --kb) {
         __syncthreads();   // previous round fully flushed before its LDS is reused
-        const int batch_first = pos;
+        const int bottom = start + BATCH * kb;
+        const int batch_first = min(bottom + BATCH, end) - 1;   // highest list position of the batch
         {
-            const int j = pos - tid;
-            if (tid < BATCH && j >= start) {
+            const int j = batch_first - tid;
+            if (tid < BATCH && j >= bottom) {
                 const int o = payload[j];
                 const float4 *g = attrs + 4 * (size_t)o;
                 s_p[tid] = g[0]; s_b[tid] = g[1]; s_c[tid] = g[2]; s_q[tid] = g[3];
                 s_o[tid] = o;
             }
         }
-        const int nbuf = min(BATCH, pos - start + 1);
-        pos -= BATCH;
+        const int nbuf = batch_first - bottom + 1;
         {
             const int padded = (nbuf + GROUP - 1) & ~(GROUP - 1);
             if (tid < padded - nbuf) {
@@ -1043,9 +1086,41 @@ __global__ __launch_bounds__(SMALL_THREADS) void blend_backward_small_kernel(
             }
         }
     }
-    magnitude_image[2 * p] = mag_u;
-    magnitude_image[2 * p + 1] = mag_v;
-    if (DEBUG) { debug_hits[2 * p] = dc; debug_hits[2 * p + 1] = dh; }
+    if (split <= 1) {
+        magnitude_image[2 * p] = mag_u;
+        magnitude_image[2 * p + 1] = mag_v;
+        if (DEBUG) { debug_hits[2 * p] = dc; debug_hits[2 * p + 1] = dh; }
+        return;
+    }
+    // several workgroups per tile: this segment's part of the |grad uv| image; the last workgroup to arrive adds the parts
+    const size_t n_pixels = (size_t)width * height;
+    magnitude_parts[(size_t)seg * n_pixels + p] = make_float2(mag_u, mag_v);
+    if (DEBUG) {   // (unsigned sums: any order; the caller zeroes the buffer)
+        atomicAdd(&debug_hits[2 * p], dc);
+        atomicAdd(&debug_hits[2 * p + 1], dh);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const int arrived = __hip_atomic_fetch_add(&tile_counters[tc.index], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_max[0] = arrived == split - 1 ? 1 : 0;
+        if (arrived == split - 1) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            __hip_atomic_store(&tile_counters[tc.index], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // clean for the next launch
+        }
+    }
+    __syncthreads();
+    if (s_max[0]) {
+        float su = 0.f, sv = 0.f;
+        for (int q = 0; q < split; ++q) {   // segment order: the same sum on every run
+            const float2 m = magnitude_parts[(size_t)q * n_pixels + p];
+            su += m.x;
+            sv += m.y;
+        }
+        magnitude_image[2 * p] = su;
+        magnitude_image[2 * p + 1] = sv;
+    }
 }
 
 // ------------------------------------------------------------------------------- measurement arm: one wave per tile
@@ -1234,15 +1309,18 @@ static void launch_forward(bool debug, dim3 grid, hipStream_t s, const int32_t *
                            const int32_t *payload, const float4 *attrs, int width, int height, int rb, int rs,
                            int bin_shift, int filter, float *image, float *depth, float *acc_alpha,
                            int32_t *last_effective, int32_t *valid_count, uint32_t *debug_hits,
-                           const int32_t *tile_order, int32_t *tile_work, int32_t *walked_list, int32_t *walked_start) {
+                           const int32_t *tile_order, int32_t *tile_work, int32_t *walked_list, int32_t *walked_start,
+                           float4 *boundary) {
     if (debug)
         hipLaunchKernelGGL((blend_forward_kernel<STAGED, AUX, STATE, true>), grid, dim3(BLEND_THREADS), 0, s, bin_start,
                            bin_end, payload, attrs, width, height, rb, rs, bin_shift, filter, image, depth, acc_alpha,
-                           last_effective, valid_count, debug_hits, tile_order, tile_work, walked_list, walked_start);
+                           last_effective, valid_count, debug_hits, tile_order, tile_work, walked_list, walked_start,
+                           boundary);
     else
         hipLaunchKernelGGL((blend_forward_kernel<STAGED, AUX, STATE, false>), grid, dim3(BLEND_THREADS), 0, s, bin_start,
                            bin_end, payload, attrs, width, height, rb, rs, bin_shift, filter, image, depth, acc_alpha,
-                           last_effective, valid_count, debug_hits, tile_order, tile_work, walked_list, walked_start);
+                           last_effective, valid_count, debug_hits, tile_order, tile_work, walked_list, walked_start,
+                           boundary);
 }
 
 template <bool STAGED>
@@ -1270,11 +1348,40 @@ static int owned_row_count(int th, int begin, int step, int end) {
     return begin < hi ? (hi - 1 - begin) / step + 1 : 0;
 }
 
+// workgroups per tile of the split backward pass for a grid of `tiles` tiles (1 = no split)
+static int backward_split_for(int tiles) {
+    static const int forced = getenv("GS_BWD_SPLIT") ? atoi(getenv("GS_BWD_SPLIT")) : 0;   // tuning knob
+    if (forced > 0) return forced > GS_MAX_BACKWARD_SPLIT ? GS_MAX_BACKWARD_SPLIT : forced;
+    return tiles <= 1536 ? 4 : (tiles <= GS_SMALL_GRID_TILES ? 2 : 1);
+}
+
+size_t gs_blend_boundary_bytes(int64_t list_length) {
+    return ((size_t)((list_length > 0 ? list_length : 0) >> 7) + 2) * 256 * sizeof(float4);
+}
+
+size_t gs_blend_split_workspace_bytes(int width, int height) {
+    const size_t tiles = (size_t)(width / GS_TILE_WIDTH) * (height / GS_TILE_HEIGHT);
+    return ((tiles * sizeof(int32_t) + 255) & ~(size_t)255) + (size_t)GS_MAX_BACKWARD_SPLIT * width * height * sizeof(float2);
+}
+
 int gs_blend_forward(const int32_t *bin_start, const int32_t *bin_end, const int32_t *payload, const float *attrs,
                      int width, int height, int tile_row_begin, int tile_row_step, int tile_row_end, int bin_shift,
                      int filter, float *image, float *depth, float *acc_alpha, int32_t *last_effective,
                      int32_t *valid_count, int flags, uint32_t *debug_pixel_hits, int32_t *tile_order,
                      int32_t *tile_work, int32_t *walked_list, int32_t *walked_start, void *stream) {
+    return gs_blend_forward_with_boundaries(bin_start, bin_end, payload, attrs, width, height, tile_row_begin,
+                                            tile_row_step, tile_row_end, bin_shift, filter, image, depth, acc_alpha,
+                                            last_effective, valid_count, flags, debug_pixel_hits, tile_order, tile_work,
+                                            walked_list, walked_start, nullptr, stream);
+}
+
+int gs_blend_forward_with_boundaries(const int32_t *bin_start, const int32_t *bin_end, const int32_t *payload,
+                                     const float *attrs, int width, int height, int tile_row_begin, int tile_row_step,
+                                     int tile_row_end, int bin_shift, int filter, float *image, float *depth,
+                                     float *acc_alpha, int32_t *last_effective, int32_t *valid_count, int flags,
+                                     uint32_t *debug_pixel_hits, int32_t *tile_order, int32_t *tile_work,
+                                     int32_t *walked_list, int32_t *walked_start, float *boundary_states, void *stream) {
+    float4 *boundary = reinterpret_cast<float4 *>(boundary_states);
     GS_REQUIRE(width % GS_TILE_WIDTH == 0 && height % GS_TILE_HEIGHT == 0, "image size must be a multiple of 16");
     GS_REQUIRE(tile_row_step >= 1 && tile_row_begin >= 0 && tile_row_end >= 0, "tile row ownership");
     GS_REQUIRE(bin_shift >= 0 && bin_shift <= 4, "bin_shift");
@@ -1305,12 +1412,13 @@ int gs_blend_forward(const int32_t *bin_start, const int32_t *bin_end, const int
 #define GS_FWD_SMALL(AUX, STATE, DBG)                                                                                \
     hipLaunchKernelGGL((blend_forward_small_kernel<AUX, STATE, DBG>), grid, dim3(SMALL_THREADS), 0, s, bin_start,     \
                        bin_end, payload, a4, width, height, tile_row_begin, tile_row_step, image, depth, acc_alpha,   \
-                       last_effective, valid_count, debug_pixel_hits, tile_order, tile_work)
+                       last_effective, valid_count, debug_pixel_hits, tile_order, tile_work, boundary)
 #define GS_FWD_SMALL2(AUX, STATE) do { if (dbg) GS_FWD_SMALL(AUX, STATE, true); else GS_FWD_SMALL(AUX, STATE, false); } while (0)
 #define GS_FWD(STAGED, AUX, STATE)                                                                                  \
     launch_forward<STAGED, AUX, STATE>(dbg, grid, s, bin_start, bin_end, payload, a4, width, height, tile_row_begin, \
                                        tile_row_step, bin_shift, filter, image, depth, acc_alpha, last_effective,   \
-                                       valid_count, debug_pixel_hits, tile_order, tile_work, walked_list, walked_start)
+                                       valid_count, debug_pixel_hits, tile_order, tile_work, walked_list, walked_start,  \
+                                       boundary)
 #define GS_FWD2(STAGED)                                                                                             \
     do {                                                                                                            \
         if (aux && state) GS_FWD(STAGED, true, true);                                                               \
@@ -1338,6 +1446,19 @@ int gs_blend_backward(const int32_t *bin_start, const int32_t *payload, const fl
                       int tile_row_step, int tile_row_end, int bin_shift, int filter, float *partials,
                       uint8_t *slot_flags, float *magnitude_image, uint32_t *debug_pixel_hits, int flags,
                       const int32_t *tile_work, int32_t *tile_order, void *stream) {
+    return gs_blend_backward_split(bin_start, payload, attrs, grad_image, acc_alpha, last_effective, slot_offsets, n_slots,
+                                   width, height, tile_row_begin, tile_row_step, tile_row_end, bin_shift, filter, partials,
+                                   slot_flags, magnitude_image, debug_pixel_hits, flags, tile_work, tile_order, nullptr,
+                                   nullptr, nullptr, stream);
+}
+
+int gs_blend_backward_split(const int32_t *bin_start, const int32_t *payload, const float *attrs,
+                            const float *grad_image, const float *acc_alpha, const int32_t *last_effective,
+                            const int32_t *slot_offsets, int64_t n_slots, int width, int height, int tile_row_begin,
+                            int tile_row_step, int tile_row_end, int bin_shift, int filter, float *partials,
+                            uint8_t *slot_flags, float *magnitude_image, uint32_t *debug_pixel_hits, int flags,
+                            const int32_t *tile_work, int32_t *tile_order, const float *image,
+                            const float *boundary_states, void *split_workspace, void *stream) {
     GS_REQUIRE(width % GS_TILE_WIDTH == 0 && height % GS_TILE_HEIGHT == 0, "image size must be a multiple of 16");
     GS_REQUIRE(tile_row_step >= 1 && tile_row_begin >= 0 && tile_row_end >= 0, "tile row ownership");
     GS_REQUIRE(bin_shift >= 0 && bin_shift <= 4, "bin_shift");
@@ -1372,14 +1493,24 @@ int gs_blend_backward(const int32_t *bin_start, const int32_t *payload, const fl
                                grad_image, acc_alpha, last_effective, width, height, tile_row_begin, tile_row_step,
                                slot_offsets, p4, slot_flags, magnitude_image, debug_pixel_hits, tile_order);
     } else if (four_waves) {
+        // several workgroups per tile when the forward pass left its boundary states (see blend_backward_small_kernel)
+        const bool can_split = image != nullptr && boundary_states != nullptr && split_workspace != nullptr;
+        const int split = can_split ? backward_split_for(tw * rows) : 1;
+        int32_t *counters = (int32_t *)split_workspace;
+        float2 *parts = reinterpret_cast<float2 *>((char *)split_workspace +
+                                                   (((size_t)(tw * (height / GS_TILE_HEIGHT)) * sizeof(int32_t) + 255) & ~(size_t)255));
+        const dim3 sgrid(tw * rows * split);
+        const float4 *b4 = reinterpret_cast<const float4 *>(boundary_states);
         if (debug_pixel_hits != nullptr)
-            hipLaunchKernelGGL(blend_backward_small_kernel<true>, grid, dim3(SMALL_THREADS), 0, s, bin_start, payload, a4,
+            hipLaunchKernelGGL(blend_backward_small_kernel<true>, sgrid, dim3(SMALL_THREADS), 0, s, bin_start, payload, a4,
                                grad_image, acc_alpha, last_effective, width, height, tile_row_begin, tile_row_step,
-                               slot_offsets, p4, slot_flags, magnitude_image, debug_pixel_hits, tile_order);
+                               slot_offsets, p4, slot_flags, magnitude_image, debug_pixel_hits, tile_order, split, image, b4,
+                               counters, parts);
         else
-            hipLaunchKernelGGL(blend_backward_small_kernel<false>, grid, dim3(SMALL_THREADS), 0, s, bin_start, payload, a4,
+            hipLaunchKernelGGL(blend_backward_small_kernel<false>, sgrid, dim3(SMALL_THREADS), 0, s, bin_start, payload, a4,
                                grad_image, acc_alpha, last_effective, width, height, tile_row_begin, tile_row_step,
-                               slot_offsets, p4, slot_flags, magnitude_image, debug_pixel_hits, tile_order);
+                               slot_offsets, p4, slot_flags, magnitude_image, debug_pixel_hits, tile_order, split, image, b4,
+                               counters, parts);
     } else if (staged)
         launch_backward<true>(debug_pixel_hits != nullptr, grid, s, bin_start, payload, a4, grad_image, acc_alpha,
                               last_effective, width, height, tile_row_begin, tile_row_step, bin_shift, filter,

@@ -53,7 +53,7 @@ class Slab:
 
 class FrameState:
     """What the backward pass needs of a forward pass that went through ``gs_frame_forward``."""
-    __slots__ = ("frame", "slab", "layout", "layout_bwd", "m", "n_slots", "walked", "width", "height", "n_keys")
+    __slots__ = ("frame", "slab", "layout", "layout_bwd", "m", "n_slots", "walked", "width", "height", "n_keys", "split")
 
 
 def _ws_bytes(ws: hip_ops.Workspaces, name: str, nbytes: int, device) -> int:
@@ -106,6 +106,11 @@ def forward(outer, xyz, features, invalid, obj, intrinsics, q_pc, t_pc, camera_i
     else:   # the sorted payload itself is what the backward pass walks
         slab.add("payload", 4 * max(cap, 1))
         slab.add("payload_alt", 4 * max(cap, 1))
+    split = 0
+    if need_state and outer.split_small_grid_backward:   # boundary states for a split backward pass (small grids)
+        split = hip_ops.boundary_states_bytes(max(cap, 1) << (shift2 if emit else 0), width, height, layout, emit)
+        if split:
+            slab.add("boundary", split)
     slab.allocate(dev)
     ws = outer._scratch
     lib = _lib.load()
@@ -158,12 +163,15 @@ def forward(outer, xyz, features, invalid, obj, intrinsics, q_pc, t_pc, camera_i
     f.tile_order = _ws_bytes(ws, "f_order_fwd", 4 * owned_tiles, dev) if ordered else 0
     f.tile_work = slab.ptr("tile_work")
     f.walked_list, f.walked_start = slab.ptr("walked_list"), slab.ptr("walked_start")
+    f.boundary_states = slab.ptr("boundary")
+    f.split_workspace = hip_ops.split_workspace(ws, width, height, dev).data_ptr() if split else 0
     f.filter_workspace = _ws_bytes(ws, "f_filter", lib.gs_filter_workspace_bytes(n), dev)
     f.sort_workspace = _ws_bytes(ws, "f_sort", lib.gs_sort_workspace_bytes(cap), dev)
     _lib.check(lib.gs_frame_forward(ctypes.addressof(f), FORWARD_STAGES, _lib.current_stream(dev)), "gs_frame_forward")
     host = readback.wait()
     state = FrameState()
     state.frame, state.slab, state.layout, state.walked = f, slab, layout, emit
+    state.split = bool(split)   # (the split backward reads the forward's image: the caller saves it for the backward pass)
     state.layout_bwd = hip_ops.walked_layout(layout) if emit else layout
     state.width, state.height = width, height
     state.m, state.n_keys = host[hip_ops.COUNTER_NUM_VISIBLE], host[hip_ops.COUNTER_NUM_KEYS]

@@ -82,14 +82,15 @@ class Workspaces:
     def __init__(self):
         self._bufs = {}
 
-    def get(self, name: str, shape, dtype: torch.dtype, device) -> torch.Tensor:
+    def get(self, name: str, shape, dtype: torch.dtype, device, zeroed: bool = False) -> torch.Tensor:
+        """zeroed: the buffer is zero-filled when it is (re)allocated -- for workspaces whose users leave them zero."""
         numel = 1
         for d in (shape if isinstance(shape, (tuple, list)) else (shape,)):
             numel *= int(d)
         t = self._bufs.get(name)
         if t is None or t.numel() < numel or t.dtype != dtype or t.device != device:
             grow = numel if t is None else max(numel, (t.numel() * 5) // 4)
-            t = torch.empty(max(grow, 1), dtype=dtype, device=device)
+            t = (torch.zeros if zeroed else torch.empty)(max(grow, 1), dtype=dtype, device=device)
             self._bufs[name] = t
         return t[:numel].view(shape)
 
@@ -304,10 +305,33 @@ BLEND_NO_STATE = 2      # GS_BLEND_NO_STATE: no acc_alpha / last_effective (noth
 BLEND_ARMS = {None: 0, "two_waves": 4, "four_waves": 8, "one_wave": 16}   # GS_BLEND_TWO_WAVES / GS_BLEND_FOUR_WAVES (None: by tile count)
 
 
+SMALL_GRID_TILES = 3840          # csrc/gs_blend.hip GS_SMALL_GRID_TILES: the four-waves-per-tile kernels, split backward
+MAX_BOUNDARY_BYTES = 256 << 20   # above this the backward pass is not split (boundary states cost 4 KB per 128 list entries)
+
+
+def boundary_states_bytes(list_length: int, width: int, height: int, layout: ListLayout, walked: bool) -> int:
+    """Bytes of the buffer in which the forward pass leaves its boundary states for a SPLIT backward pass
+    (include/gsplat_hip.h "List splitting"), or 0 when the backward pass of this frame will not be split: the backward
+    walks per-tile lists (the layout's own, or the walked lists of a binned forward) on a grid of at most 3840 tiles."""
+    if not (walked or (layout.bin_shift == 0 and layout.filter == 0)):
+        return 0
+    if num_owned_tiles(width, height, layout) > SMALL_GRID_TILES:
+        return 0
+    nbytes = int(_lib.load().gs_blend_boundary_bytes(int(list_length)))
+    return nbytes if nbytes <= MAX_BOUNDARY_BYTES else 0
+
+
+def split_workspace(ws: Workspaces, width: int, height: int, device) -> torch.Tensor:
+    """The split backward's tile counters + per-segment images: zero when first used, left zero by the library."""
+    return ws.get("split_backward", int(_lib.load().gs_blend_split_workspace_bytes(int(width), int(height))), torch.uint8,
+                  device, zeroed=True)
+
+
 def blend_forward(bin_start, bin_end, payload, attrs, width, height, layout: ListLayout = ListLayout(),
                   out=None, rgb_only=False, need_state=True, debug_hits=False, gathered_rows: int = 0,
                   ordered: bool = False, tile_work: Optional[torch.Tensor] = None, arm: Optional[str] = None,
-                  ws: Optional[Workspaces] = None, emit_walked_lists: bool = False):
+                  ws: Optional[Workspaces] = None, emit_walked_lists: bool = False,
+                  boundary: Optional[torch.Tensor] = None):
     """-> (image, depth, acc_alpha, last_effective, count).  rgb_only: depth and count are not computed (returned
     as None); need_state=False: acc_alpha / last_effective are not computed (None) -- the inference path.
     debug_hits=True appends a uint32-as-int32 [H,W,2] tensor {blended count, hash of blended payloads} per pixel.
@@ -344,10 +368,11 @@ def blend_forward(bin_start, bin_end, payload, attrs, width, height, layout: Lis
             raise ValueError("walked lists: binned layout with state, and K << 2 bin_shift must fit int32")
         walked_list = torch.empty(max(payload.shape[0], 1) << (2 * layout.bin_shift), dtype=torch.int32, device=dev)
         walked_start = torch.empty((width // TILE_WIDTH) * (height // TILE_HEIGHT), dtype=torch.int32, device=dev)
-    call("gs_blend_forward", ptr(bin_start), ptr(bin_end), ptr(payload), ptr(attrs), int(width), int(height),
+    # boundary (uint8 buffer of boundary_states_bytes(...), optional): the forward leaves its boundary states there
+    call("gs_blend_forward_with_boundaries", ptr(bin_start), ptr(bin_end), ptr(payload), ptr(attrs), int(width), int(height),
          layout.row_begin, layout.row_step, layout.row_end, layout.bin_shift, layout.filter, ptr(image), ptr(depth),
          ptr(acc_alpha), ptr(last_eff), ptr(count), flags, ptr(dbg), ptr(order), ptr(tile_work), ptr(walked_list),
-         ptr(walked_start), current_stream(dev))
+         ptr(walked_start), ptr(boundary), current_stream(dev))
     if emit_walked_lists:
         out = out + (walked_start, walked_list)
     return out + (dbg,) if debug_hits else out
@@ -366,7 +391,8 @@ def num_owned_tiles(width: int, height: int, layout: ListLayout) -> int:
 
 def blend_backward_partials(bin_start, payload, attrs, grad_image, acc_alpha, last_eff, slot_offsets, n_slots,
                             width, height, layout: ListLayout = ListLayout(), debug_hits=False, tile_order=None,
-                            tile_work=None, arm: Optional[str] = None, ws: Optional[Workspaces] = None):
+                            tile_work=None, arm: Optional[str] = None, ws: Optional[Workspaces] = None,
+                            image: Optional[torch.Tensor] = None, boundary: Optional[torch.Tensor] = None):
     """Per-pixel backward pass -> (partials f32[S,12], slot_flags u8[S], magnitude image f32[H,W,2]): one partial
     record per (Gaussian, tile) slot, plain stores, no atomics.  debug_hits=True appends the per-pixel
     {count, hash} record of the pairs the backward treated as blended (see blend_forward)."""
@@ -380,10 +406,16 @@ def blend_backward_partials(bin_start, payload, attrs, grad_image, acc_alpha, la
     dbg = torch.zeros((height, width, 2), dtype=torch.int32, device=dev) if debug_hits else None
     if tile_work is not None:   # the forward's walk lengths: the library sorts the tiles by them (longest first)
         tile_order = _scratch(ws, "order_bwd", tile_work.shape[0], torch.int32, dev)
-    call("gs_blend_backward", ptr(bin_start), ptr(payload), ptr(attrs), ptr(grad_image), ptr(acc_alpha),
+    # image + boundary (the forward's output image and boundary states): the library may give a tile several workgroups
+    split_ws = None
+    if image is not None and boundary is not None:
+        split_ws = split_workspace(ws, width, height, dev) if ws is not None else torch.zeros(
+            int(_lib.load().gs_blend_split_workspace_bytes(int(width), int(height))), dtype=torch.uint8, device=dev)
+    call("gs_blend_backward_split", ptr(bin_start), ptr(payload), ptr(attrs), ptr(grad_image), ptr(acc_alpha),
          ptr(last_eff), ptr(slot_offsets), int(n_slots), int(width), int(height), layout.row_begin, layout.row_step,
          layout.row_end, layout.bin_shift, layout.filter, ptr(partials), ptr(flags), ptr(mag), ptr(dbg), BLEND_ARMS[arm],
-         ptr(tile_work), ptr(tile_order), current_stream(dev))
+         ptr(tile_work), ptr(tile_order), ptr(image if split_ws is not None else None),
+         ptr(boundary if split_ws is not None else None), ptr(split_ws), current_stream(dev))
     return (partials, flags, mag, dbg) if debug_hits else (partials, flags, mag)
 
 

@@ -82,6 +82,7 @@ class OwnerShardedRasteriser:
         self.hook_feature_gradients = True
         self.always_store_normalised_rotation = False
         self.speculative_sizes = True
+        self.split_small_grid_backward = True   # the band's backward pass gives a tile up to four workgroups (list splitting)
         self.speculation_stats = {"frames": 0, "redone": 0}
         self._size_guesses = {}
         self._scratch = hip_ops.Workspaces()
@@ -229,6 +230,11 @@ class OwnerShardedRasteriser:
         elif guess:
             slab.add("payload", 4 * max(cap, 1))
             slab.add("payload_alt", 4 * max(cap, 1))
+        split = 0
+        if guess and need_state and self.split_small_grid_backward:
+            split = hip_ops.boundary_states_bytes(max(cap, 1) << (shift2 if emit else 0), width, height, layout, emit)
+            if split:
+                slab.add("boundary", split)
         slab.allocate(dev)
         lib = _lib.load()
         if gather_in_place:
@@ -265,6 +271,9 @@ class OwnerShardedRasteriser:
         b.acc_alpha, b.last_effective = slab.ptr("acc_alpha"), slab.ptr("last_eff")
         b.tile_order = self._ws("b_order_fwd", 4 * owned_tiles, dev) if ordered else 0
         b.tile_work = slab.ptr("tile_work")
+        b.boundary_states = slab.ptr("boundary")
+        if need_state and self.split_small_grid_backward:
+            b.split_workspace = hip_ops.split_workspace(self._scratch, width, height, dev).data_ptr()
         S = _lib.STAGES
         stages = S["GS_FWD_COUNT_KEYS"] | S["GS_FWD_SCAN"] | S["GS_FWD_READ_SIZES"]
         if guess:   # the list stages and the blend, speculatively, behind the size read
@@ -317,9 +326,17 @@ class OwnerShardedRasteriser:
                    slab.tensor("acc_alpha", torch.float32, (height, width)) if need_state else None,
                    slab.tensor("last_eff", torch.int32, (height, width)) if need_state else None, count)
             work = slab.tensor("tile_work", torch.int32, (owned_tiles,)) if (need_state and ordered) else None
+            boundary = None
+            if need_state and self.split_small_grid_backward:
+                nbytes = hip_ops.boundary_states_bytes(max(payload.shape[0], 1) << (shift2 if emit else 0), width, height,
+                                                       layout, emit)
+                if nbytes:
+                    boundary = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+                    fr.keep.append(boundary)
+            b.boundary_states = 0 if boundary is None else boundary.data_ptr()
             blended = hip_ops.blend_forward(start, end, payload, records, width, height, layout, out=out,
                                             rgb_only=rgb_only, need_state=need_state, ordered=ordered, tile_work=work,
-                                            ws=self._scratch, emit_walked_lists=emit)
+                                            ws=self._scratch, emit_walked_lists=emit, boundary=boundary)
             if emit:
                 start, payload = blended[5], blended[6]
             fr.keep += [start, payload, slot_offsets]

@@ -28,7 +28,10 @@ import torch
 from .synthetic import SyntheticScene, make_scene
 
 WIDTH, HEIGHT = 1920, 1072      # the reference's /16 crop of 1080 (RAS:1193-1194, ImagePoseDataset.py:86-88)
-N_TRUE, N_VIEWS = 150_000, 30
+N_TRUE, N_VIEWS = 300_000, 30
+INIT_FRACTION = 0.1            # of the true positions (with noise) the training starts from: the cloud grows tenfold
+DENSIFY_THRESHOLD = 1e-6       # ADC default 6e-6, tuned for ~1-Mpixel images: at 2 Mpixels the per-pixel loss gradient
+                               # is half as large and the 30 k starting points would grow by a few hundred per refinement
 
 
 def _cache_path(tag: str) -> str:
@@ -39,7 +42,8 @@ def _cache_path(tag: str) -> str:
 
 def make_trained_scene(min_points: int = 300_000, width: int = WIDTH, height: int = HEIGHT, max_iterations: int = 6001,
                        n_true: int = N_TRUE, n_views: int = N_VIEWS, device: Optional[torch.device] = None,
-                       verbose: bool = False) -> dict:
+                       verbose: bool = False, init_fraction: float = INIT_FRACTION,
+                       densify_threshold: float = DENSIFY_THRESHOLD) -> dict:
     """-> {"scene": SyntheticScene (on the CPU), "stats": {...}}.  Needs a HIP device (it trains)."""
     import pandas as pd
     from PIL import Image
@@ -89,7 +93,7 @@ def make_trained_scene(min_points: int = 300_000, width: int = WIDTH, height: in
     for split, recs in records.items():
         with open(os.path.join(data, f"{split}.json"), "w") as fh:
             json.dump(recs, fh)
-    keep = torch.randperm(n_true, generator=g)[: n_true // 2]
+    keep = torch.randperm(n_true, generator=g)[: max(int(n_true * init_fraction), 1000)]
     init = gt.point_cloud[keep] + 0.01 * torch.randn(len(keep), 3, generator=g)
     pd.DataFrame(np.concatenate([init.numpy(), np.full((len(keep), 3), 128.0)], 1),
                  columns=["x", "y", "z", "r", "g", "b"]).to_parquet(os.path.join(data, "points.parquet"))
@@ -102,8 +106,9 @@ def make_trained_scene(min_points: int = 300_000, width: int = WIDTH, height: in
         val_interval=10 ** 9, log_loss_interval=10 ** 9, log_metrics_interval=10 ** 9, log_image_interval=10 ** 9,
         log_validation_image=False, summary_writer_log_dir=os.path.join(data, "logs"), num_data_loader_workers=0,
         output_model_dir=os.path.join(data, "checkpoints"))
-    cfg.gaussian_point_cloud_scene_config.max_num_points_ratio = 8.0
+    cfg.gaussian_point_cloud_scene_config.max_num_points_ratio = max(8.0, 2.5 * min_points / max(len(keep), 1))
     cfg.gaussian_point_cloud_scene_config.initial_alpha = 0.5
+    cfg.adaptive_controller_config.densification_view_space_position_gradients_threshold = densify_threshold
     trainer = TRN(cfg, device=dev)
     history = []
     original_refinement = trainer.adaptive_controller.refinement

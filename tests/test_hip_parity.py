@@ -811,6 +811,60 @@ def test_four_waves_per_tile_arm_at_a_larger_size(ops):
         assert torch.equal(out[None][i], out["four_waves"][i]), i
 
 
+@pytest.mark.parametrize("size,n,bin_shift", [(256, 10_000, 0), (640, 60_000, 0), (256, 10_000, 1), (512, 40_000, 2)])
+def test_split_backward_on_small_grids(ops, size, n, bin_shift):
+    """List splitting (include/gsplat_hip.h): on grids of at most 3,840 tiles the forward pass leaves every pixel's
+    transmittance and colour at every 128th position of its tile's list, and the backward pass gives a tile several
+    workgroups, each starting from such a state.  Against the un-split backward on the same lists: identical hit sets and
+    slot flags, pixel counts exact, slot sums and the per-Gaussian accumulators equal to rounding (the state at a cut comes
+    from the forward pass instead of from divisions / a running sum), the |grad uv| image likewise -- and two split runs
+    give the same bits.  Per-tile lists (both forward kernels' direct forms) and the walked lists of binned layouts."""
+    from taichi_3d_gaussian_splatting_amd.synthetic import make_grad_image, make_scene
+    s = make_scene(n=n, height=size, width=size, s_min=0.01, s_max=0.08, seed=size + bin_shift).to("cuda")
+    layout = ops.ListLayout(bin_shift=bin_shift)
+    st = _stages_to_ranges(ops, s, layout)
+    g = make_grad_image(size, size).cuda()
+    emit = bin_shift > 0
+    n_list = st["payload"].shape[0] << (2 * bin_shift if emit else 0)
+    nbytes = ops.boundary_states_bytes(n_list, size, size, layout, emit)
+    assert nbytes > 0
+    boundary = torch.full((nbytes,), 0x7f, dtype=torch.uint8, device="cuda")      # NaN-ish garbage: only written slots are read
+    work = torch.empty(ops.num_owned_tiles(size, size, layout), dtype=torch.int32, device="cuda")
+    fwd = ops.blend_forward(st["start"], st["end"], st["payload"], st["attrs"], size, size, layout, ordered=True,
+                            tile_work=work, emit_walked_lists=emit, boundary=boundary, debug_hits=True)
+    plain = ops.blend_forward(st["start"], st["end"], st["payload"], st["attrs"], size, size, layout, debug_hits=True)
+    for i in range(5):
+        assert torch.equal(fwd[i], plain[i])                                       # recording the states changes nothing
+    image, acc_alpha, last_eff = fwd[0], fwd[2], fwd[3]
+    if emit:
+        b_start, b_list, b_layout = fwd[5], fwd[6], ops.walked_layout(layout)
+    else:
+        b_start, b_list, b_layout = st["start"], st["payload"], layout
+    args = (b_start, b_list, st["attrs"], g, acc_alpha, last_eff, st["slot_offsets"], st["n_slots"], size, size, b_layout)
+    ws = ops.Workspaces()
+    p0, f0, m0, d0 = [t.clone() for t in ops.blend_backward_partials(*args, tile_work=work, debug_hits=True)]
+    runs = []
+    for _ in range(2):
+        out = ops.blend_backward_partials(*args, tile_work=work, debug_hits=True, ws=ws, image=image, boundary=boundary)
+        runs.append([t.clone() for t in out])
+    p1, f1, m1, d1 = runs[0]
+    assert torch.equal(d1, d0) and torch.equal(d1, fwd[-1])                       # the same (pixel, Gaussian) pairs
+    assert torch.equal(f1, f0)
+    raised = f0.bool()
+    assert torch.equal(p1[raised][:, 10].contiguous().view(torch.int32), p0[raised][:, 10].contiguous().view(torch.int32))
+    for a, b in zip(runs[0], runs[1]):                                            # bitwise reproducible
+        assert torch.equal(a[raised].view(torch.int32) if a is runs[0][0] else a, b[raised].view(torch.int32) if b is runs[1][0] else b)
+    a0 = ops.reduce_partials(st["slot_offsets"], st["ntiles"], f0, p0)
+    a1 = ops.reduce_partials(st["slot_offsets"], st["ntiles"], f1, p1)
+    scale = a0[:, :10].abs().amax(dim=0).clamp_min(1e-30)
+    worst = float(((a1[:, :10] - a0[:, :10]).abs() / scale).max())
+    rel = float((a1[:, :10] - a0[:, :10]).norm() / a0[:, :10].norm())
+    mag = float((m1 - m0).abs().max() / m0.abs().max().clamp_min(1e-30))
+    report("split_backward", size=size, bin_shift=bin_shift, tiles=(size // 16) ** 2, max_scaled_difference_of_sums=worst,
+           rel_l2_of_sums=rel, magnitude_image=mag)
+    assert worst < 5e-6 and rel < 2e-6 and mag < 1e-5
+
+
 def test_ordered_dispatch_on_a_4k_grid(ops):
     """Longest-first dispatch on a grid of 32,400 tiles (3840 x 2160: more tiles than the ordering kernel keeps in
     registers, and not a multiple of its eight lists' length): every tile is still rendered exactly once -- outputs
