@@ -23,6 +23,8 @@ op = Op(Op.GaussianPointCloudRasterisationConfig(near_plane=s.near_plane, far_pl
         backward_valid_point_hook=lambda h: None)
 if os.environ.get("GS_FRAME_ENTRY_POINTS") == "0":   # stage-by-stage foreign calls (the path of rounds 1-3)
     op.frame_entry_points = False
+if os.environ.get("GS_SPLIT") == "0":   # no list splitting on small grids
+    op.split_small_grid_backward = False
 if os.environ.get("GS_NO_PIN") != "1":
     from taichi_3d_gaussian_splatting_amd import host_affinity  # noqa: E402
     host_affinity.pin_host_threads(0)
@@ -48,7 +50,7 @@ t0 = time.perf_counter()
 for _ in range(steps):
     step()
 torch.cuda.synchronize()
-print(f"[host_profile] {workload} frame_entry_points={op.frame_entry_points}: "
+print(f"[host_profile] {workload} frame_entry_points={op.frame_entry_points} split={op.split_small_grid_backward}: "
       f"{1e3 * (time.perf_counter() - t0) / steps:.4f} ms per step (wall, un-profiled)", flush=True)
 if os.environ.get("GS_NO_CPROFILE") == "1":
     sys.exit(0)
