@@ -1092,31 +1092,35 @@ __global__ __launch_bounds__(SMALL_THREADS) void blend_backward_small_kernel(
         if (DEBUG) { debug_hits[2 * p] = dc; debug_hits[2 * p + 1] = dh; }
         return;
     }
-    // several workgroups per tile: this segment's part of the |grad uv| image; the last workgroup to arrive adds the parts
+    // several workgroups per tile: this segment's part of the |grad uv| image; the last workgroup to arrive adds the parts.
+    // The parts are stored WRITE-THROUGH (agent-scope atomic stores = sc1) and read back with agent-scope loads, every
+    // storing wave drains its stores before the workgroup's one arrival atomic: no release / acquire fence (a release
+    // fence writes back the XCD's whole L2: measured, one per workgroup made the split kernel slower than the un-split one)
     const size_t n_pixels = (size_t)width * height;
-    magnitude_parts[(size_t)seg * n_pixels + p] = make_float2(mag_u, mag_v);
+    typedef unsigned long long u64;
+    u64 *parts = reinterpret_cast<u64 *>(magnitude_parts);
+    __hip_atomic_store(&parts[(size_t)seg * n_pixels + p],
+                       (u64)__builtin_bit_cast(unsigned, mag_u) | ((u64)__builtin_bit_cast(unsigned, mag_v) << 32),
+                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (DEBUG) {   // (unsigned sums: any order; the caller zeroes the buffer)
         atomicAdd(&debug_hits[2 * p], dc);
         atomicAdd(&debug_hits[2 * p + 1], dh);
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave drains (Guideline 16, R1)
     __syncthreads();
     if (tid == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const int arrived = __hip_atomic_fetch_add(&tile_counters[tc.index], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         s_max[0] = arrived == split - 1 ? 1 : 0;
-        if (arrived == split - 1) {
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            __hip_atomic_store(&tile_counters[tc.index], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // clean for the next launch
-        }
+        if (arrived == split - 1)   // clean for the next launch
+            __hip_atomic_store(&tile_counters[tc.index], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __syncthreads();
     if (s_max[0]) {
         float su = 0.f, sv = 0.f;
         for (int q = 0; q < split; ++q) {   // segment order: the same sum on every run
-            const float2 m = magnitude_parts[(size_t)q * n_pixels + p];
-            su += m.x;
-            sv += m.y;
+            const u64 m = __hip_atomic_load(&parts[(size_t)q * n_pixels + p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            su += __builtin_bit_cast(float, (unsigned)m);
+            sv += __builtin_bit_cast(float, (unsigned)(m >> 32));
         }
         magnitude_image[2 * p] = su;
         magnitude_image[2 * p + 1] = sv;
@@ -1352,7 +1356,9 @@ static int owned_row_count(int th, int begin, int step, int end) {
 static int backward_split_for(int tiles) {
     static const int forced = getenv("GS_BWD_SPLIT") ? atoi(getenv("GS_BWD_SPLIT")) : 0;   // tuning knob
     if (forced > 0) return forced > GS_MAX_BACKWARD_SPLIT ? GS_MAX_BACKWARD_SPLIT : forced;
-    return tiles <= 1536 ? 4 : (tiles <= GS_SMALL_GRID_TILES ? 2 : 1);
+    // (a grid of ~1000 tiles x four waves fills the chip: beyond that the extra workgroups only cost -- measured: 2,500
+    //  tiles split in two 0.33 -> 0.45 ms per cfg-2 step, a 1,080-tile band 0.135 -> 0.29 ms)
+    return tiles <= 512 ? 4 : (tiles <= 1024 ? 2 : 1);
 }
 
 size_t gs_blend_boundary_bytes(int64_t list_length) {
