@@ -248,30 +248,33 @@ int gs_blend_backward(const int32_t *bin_start, const int32_t *payload, const fl
                       void *stream);
 
 
-/* List splitting for grids that cannot fill the chip (at most 3840 rendered tiles with per-tile lists, or the walked
- * lists of a binned forward pass): the forward pass leaves every pixel's transmittance and colour at every 128th position
- * of its tile's own list in `boundary_states` (float4 per pixel and boundary; gs_blend_boundary_bytes(list length) bytes,
- * list length = the payload's / walked list's capacity), and the backward pass gives a tile up to GS_MAX_BACKWARD_SPLIT
+/* List splitting for grids that cannot fill the chip (at most 1024 rendered tiles with per-tile lists taken as they are:
+ * bin_shift 0, filter 0 -- what small frames use): the forward pass leaves every pixel's transmittance and colour (and
+ * what the colour sums rounded away) at every 128th position of its tile's list in `boundary_states`
+ * (gs_blend_boundary_bytes(list_length, width, height) bytes; list_length = the payload's capacity, the SAME value in
+ * both calls), and the backward pass gives a tile up to GS_MAX_BACKWARD_SPLIT
  * workgroups, each starting from such a state (RAS:558-704 cut at list positions; `image` = the forward's output image).
  * split_workspace: gs_blend_split_workspace_bytes(width, height) bytes, ZERO when first used; the library leaves its
  * counters zero again.  Slot records stay bitwise reproducible; they differ from the un-split ones in rounding only.
  * With boundary_states / image / split_workspace NULL these are gs_blend_forward / gs_blend_backward. */
 #define GS_MAX_BACKWARD_SPLIT 4
-size_t gs_blend_boundary_bytes(int64_t list_length);
+size_t gs_blend_boundary_bytes(int64_t list_length, int width, int height);
 size_t gs_blend_split_workspace_bytes(int width, int height);
 int gs_blend_forward_with_boundaries(const int32_t *bin_start, const int32_t *bin_end, const int32_t *payload,
                                      const float *attrs, int width, int height, int tile_row_begin,
                                      int tile_row_step, int tile_row_end, int bin_shift, int filter, float *image,
                                      float *depth, float *acc_alpha, int32_t *last_effective, int32_t *valid_count,
                                      int flags, uint32_t *debug_pixel_hits, int32_t *tile_order, int32_t *tile_work,
-                                     int32_t *walked_list, int32_t *walked_start, float *boundary_states, void *stream);
+                                     int32_t *walked_list, int32_t *walked_start, float *boundary_states,
+                                     int64_t list_length, void *stream);
 int gs_blend_backward_split(const int32_t *bin_start, const int32_t *payload, const float *attrs,
                             const float *grad_image, const float *acc_alpha, const int32_t *last_effective,
                             const int32_t *slot_offsets, int64_t n_slots, int width, int height,
                             int tile_row_begin, int tile_row_step, int tile_row_end, int bin_shift, int filter,
                             float *partials, uint8_t *slot_flags, float *magnitude_image,
                             uint32_t *debug_pixel_hits, int flags, const int32_t *tile_work, int32_t *tile_order,
-                            const float *image, const float *boundary_states, void *split_workspace, void *stream);
+                            const float *image, const float *boundary_states, int64_t list_length,
+                            void *split_workspace, void *stream);
 
 /* Per-Gaussian sum of its flagged slots, in slot order (bitwise reproducible), into acc float[M][12].
  * Replaces the accumulation side of the reference's atomics (RAS:674-696).
@@ -416,7 +419,7 @@ typedef struct GsFrame {
     int32_t n_bins, pad0;
     float *image, *depth, *acc_alpha; int32_t *last_effective, *valid_count;
     int32_t *tile_order, *tile_work, *walked_list, *walked_start;
-    float *boundary_states; void *split_workspace;   /* list splitting (may be NULL) */
+    float *boundary_states; void *split_workspace;   /* list splitting (may be NULL); list length = n_keys_capacity */
     void *filter_workspace, *sort_workspace, *route_workspace;
     int32_t *route_counts, *route_pos; float *route_send; const float *records;
     /* backward */

@@ -17,7 +17,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # GS_LIB_PATH: development knob (tuning sweeps load differently built variants of the library); default = in-tree build
 LIB_PATH = os.environ.get("GS_LIB_PATH") or os.path.join(_HERE, "libgsplat_hip.so")
-ABI_VERSION = 28
+ABI_VERSION = 29
 
 _c = ctypes
 _P = _c.c_void_p
@@ -48,12 +48,12 @@ _SIGNATURES = {
     "gs_read_counters_async": (_I, [_P, _P, _I, _P]),
     "gs_blend_forward": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P]),
     "gs_blend_backward": (_I, [_P, _P, _P, _P, _P, _P, _P, _I64, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P, _P]),
-    "gs_blend_boundary_bytes": (_c.c_size_t, [_I64]),
+    "gs_blend_boundary_bytes": (_c.c_size_t, [_I64, _I, _I]),
     "gs_blend_split_workspace_bytes": (_c.c_size_t, [_I, _I]),
     "gs_blend_forward_with_boundaries": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P,
-                                              _P, _P, _P]),
+                                              _P, _P, _I64, _P]),
     "gs_blend_backward_split": (_I, [_P, _P, _P, _P, _P, _P, _P, _I64, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P,
-                                     _P, _P, _P, _P]),
+                                     _P, _P, _I64, _P, _P]),
     "gs_reduce_partials": (_I, [_P, _P, _P, _P, _I, _P, _P, _I64, _P, _I, _I, _P]),
     "gs_compact_rows_workspace_bytes": (_c.c_size_t, [_I]),
     "gs_compact_rows": (_I, [_P, _P, _I, _I, _P, _P, _P, _P, _P]),

@@ -329,7 +329,7 @@ __global__ __launch_bounds__(BLEND_THREADS) void blend_forward_kernel(
     int row_step, int bin_shift, int filter, float *__restrict__ image, float *__restrict__ depth,
     float *__restrict__ acc_alpha, int32_t *__restrict__ last_effective, int32_t *__restrict__ valid_count,
     uint32_t *__restrict__ debug_hits, const int32_t *__restrict__ tile_order, int32_t *__restrict__ tile_work,
-    int32_t *__restrict__ walked_list, int32_t *__restrict__ walked_start, float4 *__restrict__ boundary) {
+    int32_t *__restrict__ walked_list, int32_t *__restrict__ walked_start) {
     __shared__ float4 s_p[BATCH], s_c[BATCH], s_q[BATCH];  // rows 0, 2, 3 of the kept records
     __shared__ int s_j[BATCH];                             // their list positions (last_effective is one of them + 1)
     __shared__ int s_o[DEBUG ? BATCH : 1];
@@ -457,14 +457,6 @@ __global__ __launch_bounds__(BLEND_THREADS) void blend_forward_kernel(
             }
         }
         kept_base += nbuf;
-        // Boundary states (split backward, see blend_backward_small_kernel): the pixel's transmittance and colour after
-        // every 128 entries of the tile's own list, at slot (list position >> 7) -- unique, because the tiles' lists are
-        // disjoint ranges and two boundaries of one list are 128 positions apart
-        if (STATE && boundary != nullptr && (emit || !STAGED) && nbuf == BATCH && pos < end) {
-            const size_t slot = (size_t)((emit ? wbase + kept_base : pos) >> 7) * 256 + (tid >> 3) * 16 + 2 * (tid & 7);
-            boundary[slot] = make_float4(T.x, Cr.x, Cg.x, Cb.x);
-            boundary[slot + 1] = make_float4(T.y, Cr.y, Cg.y, Cb.y);
-        }
     }
     const size_t p = (size_t)pv * width + pu;
     float *img = image + 3 * p;
@@ -819,7 +811,8 @@ __global__ __launch_bounds__(SMALL_THREADS) void blend_forward_small_kernel(
     const int32_t *__restrict__ payload, const float4 *__restrict__ attrs, int width, int height, int row_begin,
     int row_step, float *__restrict__ image, float *__restrict__ depth, float *__restrict__ acc_alpha,
     int32_t *__restrict__ last_effective, int32_t *__restrict__ valid_count, uint32_t *__restrict__ debug_hits,
-    const int32_t *__restrict__ tile_order, int32_t *__restrict__ tile_work, float4 *__restrict__ boundary) {
+    const int32_t *__restrict__ tile_order, int32_t *__restrict__ tile_work, float4 *__restrict__ boundary,
+    float4 *__restrict__ final_error) {
     __shared__ float4 s_p[BATCH], s_c[BATCH], s_q[BATCH];
     __shared__ int s_o[DEBUG ? BATCH : 1];
     __shared__ int s_red[SMALL_THREADS / GS_WAVE];
@@ -830,6 +823,12 @@ __global__ __launch_bounds__(SMALL_THREADS) void blend_forward_small_kernel(
     const int start = tile_start[tc.tile_id], end = tile_end[tc.tile_id];
     const float px = (float)pu + 0.5f, py = (float)pv + 0.5f;
     float T = 1.0f, alive = 1.0f, Cr = 0.f, Cg = 0.f, Cb = 0.f, D = 0.f, Wd = 0.f;
+    // Rounding left behind by the colour sums (boundary states only): the image is the plain fp32 sum, as always; next to it
+    // E collects what each fma rounded away, so that C + E is the prefix colour to ~1e-14 and the split backward pass can
+    // form "colour still to come" = (C_final - C_b) + (E_final - E_b) without the cancellation error of the plain difference
+    // (measured without it: slot sums 2e-4 of the column maximum away from the un-split ones)
+    const bool track = STATE && boundary != nullptr;
+    float Er = 0.f, Eg = 0.f, Eb = 0.f;
     int last = start, cnt = 0;
     unsigned dh = 0u, dc = 0u;
     int pos = start;
@@ -879,6 +878,12 @@ __global__ __launch_bounds__(SMALL_THREADS) void blend_forward_small_kernel(
                 }
                 const float wgt = al * T;
                 const float4 c = s_c[k + i];
+                if (track) {   // (wave-uniform)  exact sum - rounded sum of this step, to first order
+                    const float nr = __builtin_fmaf(c.x, wgt, Cr), ng = __builtin_fmaf(c.y, wgt, Cg), nb_ = __builtin_fmaf(c.z, wgt, Cb);
+                    Er += __builtin_fmaf(c.x, wgt, Cr - nr);
+                    Eg += __builtin_fmaf(c.y, wgt, Cg - ng);
+                    Eb += __builtin_fmaf(c.z, wgt, Cb - nb_);
+                }
                 Cr = __builtin_fmaf(c.x, wgt, Cr);
                 Cg = __builtin_fmaf(c.y, wgt, Cg);
                 Cb = __builtin_fmaf(c.z, wgt, Cb);
@@ -895,12 +900,18 @@ __global__ __launch_bounds__(SMALL_THREADS) void blend_forward_small_kernel(
                 }
             }
         }
-        // boundary state after every 128 list entries (split backward; slot = list position >> 7, see the main kernel)
-        if (STATE && boundary != nullptr && pos < end)
-            boundary[(size_t)(pos >> 7) * 256 + tid] = make_float4(T, Cr, Cg, Cb);
+        // Boundary state after every 128 entries of the tile's list (split backward, blend_backward_small_kernel), at slot
+        // (list position >> 7): unique, because the tiles' lists are disjoint ranges and two boundaries of one list are 128
+        // positions apart
+        if (track && pos < end) {
+            float4 *st = boundary + ((size_t)(pos >> 7) * 256 + tid) * 2;
+            st[0] = make_float4(T, Cr, Cg, Cb);
+            st[1] = make_float4(Er, Eg, Eb, 0.f);
+        }
     }
     const size_t p = (size_t)pv * width + pu;
     image[3 * p] = Cr; image[3 * p + 1] = Cg; image[3 * p + 2] = Cb;
+    if (track) final_error[p] = make_float4(Er, Eg, Eb, 0.f);
     if (AUX) {
         depth[p] = D / fmaxf(Wd, 1e-6f);  // RAS:479-480
         valid_count[p] = cnt;
@@ -938,8 +949,8 @@ __global__ __launch_bounds__(SMALL_THREADS) void blend_backward_small_kernel(
     int width, int height, int row_begin, int row_step, const int32_t *__restrict__ slot_offsets,
     float4 *__restrict__ partials, uint8_t *__restrict__ slot_flags, float *__restrict__ magnitude_image,
     uint32_t *__restrict__ debug_hits, const int32_t *__restrict__ tile_order, int split,
-    const float *__restrict__ image, const float4 *__restrict__ boundary, int32_t *__restrict__ tile_counters,
-    float2 *__restrict__ magnitude_parts) {
+    const float *__restrict__ image, const float4 *__restrict__ boundary, const float4 *__restrict__ final_error,
+    int32_t *__restrict__ tile_counters, float2 *__restrict__ magnitude_parts) {
     __shared__ float4 s_p[BATCH], s_b[BATCH], s_c[BATCH], s_q[BATCH];
     __shared__ int s_o[BATCH];
     // one slice of partial sums PER WAVE, written with plain stores and added in a fixed order by the flush: four waves
@@ -976,9 +987,13 @@ __global__ __launch_bounds__(SMALL_THREADS) void blend_backward_small_kernel(
         T = 1.0f - acc_alpha[p];
         S = 0.f;
     } else {                   // a cut: the state the forward pass left at list position start + 128 k_hi
-        const float4 st = boundary[(size_t)((start + BATCH * k_hi) >> 7) * 256 + tid];
+        const float4 *rec = boundary + ((size_t)((start + BATCH * k_hi) >> 7) * 256 + tid) * 2;
+        const float4 st = rec[0], eb = rec[1], ef = final_error[p];
         T = st.x;
-        S = __builtin_fmaf(image[3 * p + 2] - st.w, Gb, __builtin_fmaf(image[3 * p + 1] - st.z, Gg, (image[3 * p] - st.y) * Gr));
+        // colour still to come behind the cut: (C_final - C_b) + (E_final - E_b), see blend_forward_small_kernel
+        const float dr = (image[3 * p] - st.y) + (ef.x - eb.x), dg = (image[3 * p + 1] - st.z) + (ef.y - eb.y),
+                    db = (image[3 * p + 2] - st.w) + (ef.z - eb.z);
+        S = __builtin_fmaf(db, Gb, __builtin_fmaf(dg, Gg, dr * Gr));
     }
     const int row = lane >> 4;
     const int slot = ((row & 1) << 1) | (row >> 1);
@@ -1313,18 +1328,15 @@ static void launch_forward(bool debug, dim3 grid, hipStream_t s, const int32_t *
                            const int32_t *payload, const float4 *attrs, int width, int height, int rb, int rs,
                            int bin_shift, int filter, float *image, float *depth, float *acc_alpha,
                            int32_t *last_effective, int32_t *valid_count, uint32_t *debug_hits,
-                           const int32_t *tile_order, int32_t *tile_work, int32_t *walked_list, int32_t *walked_start,
-                           float4 *boundary) {
+                           const int32_t *tile_order, int32_t *tile_work, int32_t *walked_list, int32_t *walked_start) {
     if (debug)
         hipLaunchKernelGGL((blend_forward_kernel<STAGED, AUX, STATE, true>), grid, dim3(BLEND_THREADS), 0, s, bin_start,
                            bin_end, payload, attrs, width, height, rb, rs, bin_shift, filter, image, depth, acc_alpha,
-                           last_effective, valid_count, debug_hits, tile_order, tile_work, walked_list, walked_start,
-                           boundary);
+                           last_effective, valid_count, debug_hits, tile_order, tile_work, walked_list, walked_start);
     else
         hipLaunchKernelGGL((blend_forward_kernel<STAGED, AUX, STATE, false>), grid, dim3(BLEND_THREADS), 0, s, bin_start,
                            bin_end, payload, attrs, width, height, rb, rs, bin_shift, filter, image, depth, acc_alpha,
-                           last_effective, valid_count, debug_hits, tile_order, tile_work, walked_list, walked_start,
-                           boundary);
+                           last_effective, valid_count, debug_hits, tile_order, tile_work, walked_list, walked_start);
 }
 
 template <bool STAGED>
@@ -1361,8 +1373,12 @@ static int backward_split_for(int tiles) {
     return tiles <= 512 ? 4 : (tiles <= 1024 ? 2 : 1);
 }
 
-size_t gs_blend_boundary_bytes(int64_t list_length) {
-    return ((size_t)((list_length > 0 ? list_length : 0) >> 7) + 2) * 256 * sizeof(float4);
+// [ (list_length >> 7) + 2 slots x 256 pixels x 2 float4 ][ width x height float4: what the image's sums rounded away ]
+static size_t boundary_slots_bytes(int64_t list_length) {
+    return ((size_t)((list_length > 0 ? list_length : 0) >> 7) + 2) * 256 * 2 * sizeof(float4);
+}
+size_t gs_blend_boundary_bytes(int64_t list_length, int width, int height) {
+    return boundary_slots_bytes(list_length) + (size_t)width * height * sizeof(float4);
 }
 
 size_t gs_blend_split_workspace_bytes(int width, int height) {
@@ -1378,7 +1394,7 @@ int gs_blend_forward(const int32_t *bin_start, const int32_t *bin_end, const int
     return gs_blend_forward_with_boundaries(bin_start, bin_end, payload, attrs, width, height, tile_row_begin,
                                             tile_row_step, tile_row_end, bin_shift, filter, image, depth, acc_alpha,
                                             last_effective, valid_count, flags, debug_pixel_hits, tile_order, tile_work,
-                                            walked_list, walked_start, nullptr, stream);
+                                            walked_list, walked_start, nullptr, 0, stream);
 }
 
 int gs_blend_forward_with_boundaries(const int32_t *bin_start, const int32_t *bin_end, const int32_t *payload,
@@ -1386,8 +1402,12 @@ int gs_blend_forward_with_boundaries(const int32_t *bin_start, const int32_t *bi
                                      int tile_row_end, int bin_shift, int filter, float *image, float *depth,
                                      float *acc_alpha, int32_t *last_effective, int32_t *valid_count, int flags,
                                      uint32_t *debug_pixel_hits, int32_t *tile_order, int32_t *tile_work,
-                                     int32_t *walked_list, int32_t *walked_start, float *boundary_states, void *stream) {
+                                     int32_t *walked_list, int32_t *walked_start, float *boundary_states,
+                                     int64_t list_length, void *stream) {
+    // (boundary states are only produced by the four-waves-per-tile kernel on per-tile lists: what small frames use)
     float4 *boundary = reinterpret_cast<float4 *>(boundary_states);
+    float4 *final_error = boundary_states == nullptr ? nullptr
+                                                     : reinterpret_cast<float4 *>((char *)boundary_states + boundary_slots_bytes(list_length));
     GS_REQUIRE(width % GS_TILE_WIDTH == 0 && height % GS_TILE_HEIGHT == 0, "image size must be a multiple of 16");
     GS_REQUIRE(tile_row_step >= 1 && tile_row_begin >= 0 && tile_row_end >= 0, "tile row ownership");
     GS_REQUIRE(bin_shift >= 0 && bin_shift <= 4, "bin_shift");
@@ -1418,13 +1438,12 @@ int gs_blend_forward_with_boundaries(const int32_t *bin_start, const int32_t *bi
 #define GS_FWD_SMALL(AUX, STATE, DBG)                                                                                \
     hipLaunchKernelGGL((blend_forward_small_kernel<AUX, STATE, DBG>), grid, dim3(SMALL_THREADS), 0, s, bin_start,     \
                        bin_end, payload, a4, width, height, tile_row_begin, tile_row_step, image, depth, acc_alpha,   \
-                       last_effective, valid_count, debug_pixel_hits, tile_order, tile_work, boundary)
+                       last_effective, valid_count, debug_pixel_hits, tile_order, tile_work, boundary, final_error)
 #define GS_FWD_SMALL2(AUX, STATE) do { if (dbg) GS_FWD_SMALL(AUX, STATE, true); else GS_FWD_SMALL(AUX, STATE, false); } while (0)
 #define GS_FWD(STAGED, AUX, STATE)                                                                                  \
     launch_forward<STAGED, AUX, STATE>(dbg, grid, s, bin_start, bin_end, payload, a4, width, height, tile_row_begin, \
                                        tile_row_step, bin_shift, filter, image, depth, acc_alpha, last_effective,   \
-                                       valid_count, debug_pixel_hits, tile_order, tile_work, walked_list, walked_start,  \
-                                       boundary)
+                                       valid_count, debug_pixel_hits, tile_order, tile_work, walked_list, walked_start)
 #define GS_FWD2(STAGED)                                                                                             \
     do {                                                                                                            \
         if (aux && state) GS_FWD(STAGED, true, true);                                                               \
@@ -1455,7 +1474,7 @@ int gs_blend_backward(const int32_t *bin_start, const int32_t *payload, const fl
     return gs_blend_backward_split(bin_start, payload, attrs, grad_image, acc_alpha, last_effective, slot_offsets, n_slots,
                                    width, height, tile_row_begin, tile_row_step, tile_row_end, bin_shift, filter, partials,
                                    slot_flags, magnitude_image, debug_pixel_hits, flags, tile_work, tile_order, nullptr,
-                                   nullptr, nullptr, stream);
+                                   nullptr, 0, nullptr, stream);
 }
 
 int gs_blend_backward_split(const int32_t *bin_start, const int32_t *payload, const float *attrs,
@@ -1464,7 +1483,7 @@ int gs_blend_backward_split(const int32_t *bin_start, const int32_t *payload, co
                             int tile_row_step, int tile_row_end, int bin_shift, int filter, float *partials,
                             uint8_t *slot_flags, float *magnitude_image, uint32_t *debug_pixel_hits, int flags,
                             const int32_t *tile_work, int32_t *tile_order, const float *image,
-                            const float *boundary_states, void *split_workspace, void *stream) {
+                            const float *boundary_states, int64_t list_length, void *split_workspace, void *stream) {
     GS_REQUIRE(width % GS_TILE_WIDTH == 0 && height % GS_TILE_HEIGHT == 0, "image size must be a multiple of 16");
     GS_REQUIRE(tile_row_step >= 1 && tile_row_begin >= 0 && tile_row_end >= 0, "tile row ownership");
     GS_REQUIRE(bin_shift >= 0 && bin_shift <= 4, "bin_shift");
@@ -1507,16 +1526,18 @@ int gs_blend_backward_split(const int32_t *bin_start, const int32_t *payload, co
                                                    (((size_t)(tw * (height / GS_TILE_HEIGHT)) * sizeof(int32_t) + 255) & ~(size_t)255));
         const dim3 sgrid(tw * rows * split);
         const float4 *b4 = reinterpret_cast<const float4 *>(boundary_states);
+        const float4 *e4 = boundary_states == nullptr ? nullptr
+                                                      : reinterpret_cast<const float4 *>((const char *)boundary_states + boundary_slots_bytes(list_length));
         if (debug_pixel_hits != nullptr)
             hipLaunchKernelGGL(blend_backward_small_kernel<true>, sgrid, dim3(SMALL_THREADS), 0, s, bin_start, payload, a4,
                                grad_image, acc_alpha, last_effective, width, height, tile_row_begin, tile_row_step,
                                slot_offsets, p4, slot_flags, magnitude_image, debug_pixel_hits, tile_order, split, image, b4,
-                               counters, parts);
+                               e4, counters, parts);
         else
             hipLaunchKernelGGL(blend_backward_small_kernel<false>, sgrid, dim3(SMALL_THREADS), 0, s, bin_start, payload, a4,
                                grad_image, acc_alpha, last_effective, width, height, tile_row_begin, tile_row_step,
                                slot_offsets, p4, slot_flags, magnitude_image, debug_pixel_hits, tile_order, split, image, b4,
-                               counters, parts);
+                               e4, counters, parts);
     } else if (staged)
         launch_backward<true>(debug_pixel_hits != nullptr, grid, s, bin_start, payload, a4, grad_image, acc_alpha,
                               last_effective, width, height, tile_row_begin, tile_row_step, bin_shift, filter,

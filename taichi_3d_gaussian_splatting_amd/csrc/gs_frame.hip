@@ -79,7 +79,7 @@ int gs_frame_forward(GsFrame *f, uint32_t stages, void *stream) {
             f->bin_ranges, f->bin_ranges + f->n_bins, payload_sorted, attrs, f->width, f->height, f->tile_row_begin,
             f->tile_row_step, f->tile_row_end, f->bin_shift, filter, f->image, f->depth, f->acc_alpha, f->last_effective,
             f->valid_count, f->blend_flags, nullptr, f->tile_order, f->tile_work, f->walked_list, f->walked_start,
-            f->boundary_states, stream));
+            f->boundary_states, f->n_keys_capacity, stream));
     return 0;
 }
 
@@ -94,7 +94,8 @@ int gs_frame_backward(GsFrame *f, uint32_t stages, void *stream) {
             f->width, f->height, f->tile_row_begin, f->tile_row_step, f->tile_row_end, f->backward_bin_shift,
             f->backward_filter, f->partials, f->slot_flags, f->magnitude_image, nullptr,
             f->blend_flags & (GS_BLEND_TWO_WAVES | GS_BLEND_FOUR_WAVES), f->tile_work, f->tile_order_backward,
-            f->boundary_states != nullptr ? f->image : nullptr, f->boundary_states, f->split_workspace, stream));
+            f->boundary_states != nullptr ? f->image : nullptr, f->boundary_states, f->n_keys_capacity, f->split_workspace,
+            stream));
     if (stages & GS_BWD_REDUCE)
         GS_STAGE(gs_reduce_partials(f->slot_offsets, f->num_overlap_tiles, f->slot_flags, f->partials, n_list_points, f->acc,
                                     (received || f->tile_row_begin != 0 || f->tile_row_step != 1 ||

@@ -305,19 +305,20 @@ BLEND_NO_STATE = 2      # GS_BLEND_NO_STATE: no acc_alpha / last_effective (noth
 BLEND_ARMS = {None: 0, "two_waves": 4, "four_waves": 8, "one_wave": 16}   # GS_BLEND_TWO_WAVES / GS_BLEND_FOUR_WAVES (None: by tile count)
 
 
-SMALL_GRID_TILES = 3840          # csrc/gs_blend.hip GS_SMALL_GRID_TILES: the four-waves-per-tile kernels, split backward
+SPLIT_GRID_TILES = 1024          # csrc/gs_blend.hip backward_split_for: grids up to this many tiles get a split backward
 MAX_BOUNDARY_BYTES = 256 << 20   # above this the backward pass is not split (boundary states cost 4 KB per 128 list entries)
 
 
 def boundary_states_bytes(list_length: int, width: int, height: int, layout: ListLayout, walked: bool) -> int:
     """Bytes of the buffer in which the forward pass leaves its boundary states for a SPLIT backward pass
-    (include/gsplat_hip.h "List splitting"), or 0 when the backward pass of this frame will not be split: the backward
-    walks per-tile lists (the layout's own, or the walked lists of a binned forward) on a grid of at most 3840 tiles."""
-    if not (walked or (layout.bin_shift == 0 and layout.filter == 0)):
+    (include/gsplat_hip.h "List splitting"), or 0 when the backward pass of this frame will not be split: both passes
+    walk the layout's own per-tile lists (bin_shift 0, no filter) on a grid of at most 1024 tiles.  list_length = the
+    payload's length (capacity), the same value the two blend calls are given."""
+    if walked or layout.bin_shift != 0 or layout.filter != 0:
         return 0
-    if num_owned_tiles(width, height, layout) > SMALL_GRID_TILES:
+    if num_owned_tiles(width, height, layout) > SPLIT_GRID_TILES:
         return 0
-    nbytes = int(_lib.load().gs_blend_boundary_bytes(int(list_length)))
+    nbytes = int(_lib.load().gs_blend_boundary_bytes(int(list_length), int(width), int(height)))
     return nbytes if nbytes <= MAX_BOUNDARY_BYTES else 0
 
 
@@ -372,7 +373,7 @@ def blend_forward(bin_start, bin_end, payload, attrs, width, height, layout: Lis
     call("gs_blend_forward_with_boundaries", ptr(bin_start), ptr(bin_end), ptr(payload), ptr(attrs), int(width), int(height),
          layout.row_begin, layout.row_step, layout.row_end, layout.bin_shift, layout.filter, ptr(image), ptr(depth),
          ptr(acc_alpha), ptr(last_eff), ptr(count), flags, ptr(dbg), ptr(order), ptr(tile_work), ptr(walked_list),
-         ptr(walked_start), ptr(boundary), current_stream(dev))
+         ptr(walked_start), ptr(boundary), int(payload.shape[0]), current_stream(dev))
     if emit_walked_lists:
         out = out + (walked_start, walked_list)
     return out + (dbg,) if debug_hits else out
@@ -415,7 +416,7 @@ def blend_backward_partials(bin_start, payload, attrs, grad_image, acc_alpha, la
          ptr(last_eff), ptr(slot_offsets), int(n_slots), int(width), int(height), layout.row_begin, layout.row_step,
          layout.row_end, layout.bin_shift, layout.filter, ptr(partials), ptr(flags), ptr(mag), ptr(dbg), BLEND_ARMS[arm],
          ptr(tile_work), ptr(tile_order), ptr(image if split_ws is not None else None),
-         ptr(boundary if split_ws is not None else None), ptr(split_ws), current_stream(dev))
+         ptr(boundary if split_ws is not None else None), int(payload.shape[0]), ptr(split_ws), current_stream(dev))
     return (partials, flags, mag, dbg) if debug_hits else (partials, flags, mag)
 
 

@@ -334,6 +334,7 @@ class OwnerShardedRasteriser:
                     boundary = torch.empty(nbytes, dtype=torch.uint8, device=dev)
                     fr.keep.append(boundary)
             b.boundary_states = 0 if boundary is None else boundary.data_ptr()
+            b.n_keys_capacity = int(payload.shape[0])   # (the list length the boundary buffer's layout is derived from)
             blended = hip_ops.blend_forward(start, end, payload, records, width, height, layout, out=out,
                                             rgb_only=rgb_only, need_state=need_state, ordered=ordered, tile_work=work,
                                             ws=self._scratch, emit_walked_lists=emit, boundary=boundary)

@@ -811,14 +811,15 @@ def test_four_waves_per_tile_arm_at_a_larger_size(ops):
         assert torch.equal(out[None][i], out["four_waves"][i]), i
 
 
-@pytest.mark.parametrize("size,n,bin_shift", [(256, 10_000, 0), (640, 60_000, 0), (256, 10_000, 1), (512, 40_000, 2)])
+@pytest.mark.parametrize("size,n,bin_shift", [(256, 10_000, 0), (512, 60_000, 0), (128, 6_000, 0), (400, 2_000, 0)])
 def test_split_backward_on_small_grids(ops, size, n, bin_shift):
-    """List splitting (include/gsplat_hip.h): on grids of at most 3,840 tiles the forward pass leaves every pixel's
-    transmittance and colour at every 128th position of its tile's list, and the backward pass gives a tile several
-    workgroups, each starting from such a state.  Against the un-split backward on the same lists: identical hit sets and
-    slot flags, pixel counts exact, slot sums and the per-Gaussian accumulators equal to rounding (the state at a cut comes
-    from the forward pass instead of from divisions / a running sum), the |grad uv| image likewise -- and two split runs
-    give the same bits.  Per-tile lists (both forward kernels' direct forms) and the walked lists of binned layouts."""
+    """List splitting (include/gsplat_hip.h): on grids of at most 1,024 tiles with per-tile lists the forward pass leaves
+    every pixel's transmittance and colour at every 128th position of its tile's list, and the backward pass gives a tile
+    four (<= 512 tiles) or two workgroups, each starting from such a state.  Against the un-split backward on the same
+    lists: identical hit sets and slot flags, pixel counts exact, slot sums and the per-Gaussian accumulators equal to
+    rounding (the state at a cut comes from the forward pass instead of from divisions / a running sum), the |grad uv|
+    image likewise -- and two split runs give the same bits.  Lists of 200-600 entries (several cuts per tile), of a
+    dozen (no cut at all: 400 x 400 with 2,000 Gaussians)."""
     from taichi_3d_gaussian_splatting_amd.synthetic import make_grad_image, make_scene
     s = make_scene(n=n, height=size, width=size, s_min=0.01, s_max=0.08, seed=size + bin_shift).to("cuda")
     layout = ops.ListLayout(bin_shift=bin_shift)
