@@ -911,7 +911,7 @@ __global__ __launch_bounds__(SMALL_THREADS) void blend_forward_small_kernel(
     }
     const size_t p = (size_t)pv * width + pu;
     image[3 * p] = Cr; image[3 * p + 1] = Cg; image[3 * p + 2] = Cb;
-    if (track) final_error[p] = make_float4(Er, Eg, Eb, 0.f);
+    if (track) final_error[p] = make_float4(Er, Eg, Eb, T);   // (.w: the final transmittance itself, see the split backward)
     if (AUX) {
         depth[p] = D / fmaxf(Wd, 1e-6f);  // RAS:479-480
         valid_count[p] = cnt;
@@ -989,11 +989,17 @@ __global__ __launch_bounds__(SMALL_THREADS) void blend_backward_small_kernel(
     } else {                   // a cut: the state the forward pass left at list position start + 128 k_hi
         const float4 *rec = boundary + ((size_t)((start + BATCH * k_hi) >> 7) * 256 + tid) * 2;
         const float4 st = rec[0], eb = rec[1], ef = final_error[p];
-        T = st.x;
+        // The reference starts its recursion from T = 1 - acc_alpha (RAS:560), i.e. from the final transmittance ROUNDED
+        // through acc_alpha -- for a nearly saturated pixel (T ~ 1e-3) that is a relative error of ~1e-4, carried by every
+        // T and S of the walk as a common factor.  The cut reproduces it: rho = (1 - acc_alpha) / T_final scales the exact
+        // state the forward pass left, so that a split walk computes what the un-split one does (to rounding) instead of
+        // something more accurate but 1e-4 away from it.
+        const float rho = (1.0f - acc_alpha[p]) / ef.w;
+        T = st.x * rho;
         // colour still to come behind the cut: (C_final - C_b) + (E_final - E_b), see blend_forward_small_kernel
         const float dr = (image[3 * p] - st.y) + (ef.x - eb.x), dg = (image[3 * p + 1] - st.z) + (ef.y - eb.y),
                     db = (image[3 * p + 2] - st.w) + (ef.z - eb.z);
-        S = __builtin_fmaf(db, Gb, __builtin_fmaf(dg, Gg, dr * Gr));
+        S = __builtin_fmaf(db, Gb, __builtin_fmaf(dg, Gg, dr * Gr)) * rho;
     }
     const int row = lane >> 4;
     const int slot = ((row & 1) << 1) | (row >> 1);
