@@ -150,7 +150,10 @@ def main() -> None:
                          "this variant beside it (`variants`)")
     ap.add_argument("--forward-only", action="store_true", help="inference line: forward under no_grad")
     ap.add_argument("--rgb-only", action="store_true", help="with --forward-only: the reference's rgb_only config")
-    ap.add_argument("--shard-mode", default="bands", choices=["bands", "interleaved"])
+    ap.add_argument("--shard-mode", default="owner", choices=["owner", "bands", "interleaved"],
+                    help="N > 1: 'owner' (default) = tile-row bands for the pixels + owner-sharded Gaussians with a routed "
+                         "exchange (owner_sharding.py: nothing per-Gaussian is replicated); 'bands' / 'interleaved' = the "
+                         "replicated point cloud of distributed.py")
     ap.add_argument("--no-pin", action="store_true",
                     help="leave the host threads where the scheduler puts them (default: all threads of the process on one "
                          "L3 complex of the GPU's NUMA node, taichi_3d_gaussian_splatting_amd/host_affinity.py)")
@@ -207,27 +210,36 @@ def main() -> None:
                                                    rgb_only=bool(args.rgb_only and args.forward_only))
     hook_calls = []
     hook = None if (args.no_hook or args.forward_only) else (lambda h: hook_calls.append(1))
-    op = Op(cfg, backward_valid_point_hook=hook)
+    owner_mode = world > 1 and args.shard_mode == "owner"
+    rows = slice(None)
+    if owner_mode:   # this rank OWNS a contiguous block of the point cloud; its inputs and gradients are that block
+        from taichi_3d_gaussian_splatting_amd.owner_sharding import OwnerShardedRasterisation, owned_point_rows
+        block = owned_point_rows(s.point_cloud.shape[0], rank, world)
+        rows = slice(block.start, block.stop)
+        module = OwnerShardedRasterisation(cfg, backward_valid_point_hook=hook)
+        op = module.core                     # (the options below live on the rank's core)
+    else:
+        op = module = Op(cfg, backward_valid_point_hook=hook)
     # the operator's default (True): the reference always gathers the [M,56] field (RAS:1131-1133).  The trainer switches
     # it off between densifications: that variant is timed as well and reported in `variants`
     op.hook_feature_gradients = not args.no_hook_feature_copy
-    if world > 1:
+    if world > 1 and not owner_mode:
         shard_rasteriser_across_tile_rows(op, mode=args.shard_mode)
-    xyz = s.point_cloud.clone().requires_grad_(True)
-    feat = s.point_cloud_features.clone().requires_grad_(True)
+    xyz = s.point_cloud[rows].clone().requires_grad_(True)
+    feat = s.point_cloud_features[rows].clone().requires_grad_(True)
     cam = CameraInfo(camera_intrinsics=s.camera_intrinsics, camera_height=s.height, camera_width=s.width, camera_id=0)
     inp = Op.GaussianPointCloudRasterisationInput(
-        point_cloud=xyz, point_cloud_features=feat, point_object_id=s.point_object_id,
-        point_invalid_mask=s.point_invalid_mask, camera_info=cam, q_pointcloud_camera=s.q_pointcloud_camera,
+        point_cloud=xyz, point_cloud_features=feat, point_object_id=s.point_object_id[rows],
+        point_invalid_mask=s.point_invalid_mask[rows], camera_info=cam, q_pointcloud_camera=s.q_pointcloud_camera,
         t_pointcloud_camera=s.t_pointcloud_camera, color_max_sh_band=3)
 
     def step():
         if args.forward_only:
             with torch.no_grad():
-                return op(inp)[0]
+                return module(inp)[0]
         xyz.grad = None
         feat.grad = None
-        image, depth, count = op(inp)
+        image, depth, count = module(inp)
         image.backward(grad_image)
         return image
 
@@ -282,7 +294,7 @@ def main() -> None:
     # ---------------------------------------------------------------- per-stage timing (rank-local)
     n = s.point_cloud.shape[0]
     roofline, stages_ms, sizes = None, {}, {}
-    if not args.no_stage_profile:
+    if not args.no_stage_profile and not owner_mode:   # (owner mode: tools/owner_shard_bench.py times a rank's phases)
         layout = op.list_layout(s.height)
         ev = lambda: torch.cuda.Event(enable_timing=True)  # noqa: E731
         reps = max(3, min(args.steps, 10))
@@ -455,7 +467,9 @@ def main() -> None:
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": args.workload, "gaussians": n, "image": f"{s.width}x{s.height}",
-                       "sh_degree": 3, "sharding": "none" if world == 1 else f"tile-row {args.shard_mode}/{world}",
+                       "sh_degree": 3, "sharding": "none" if world == 1 else (
+                           f"tile-row bands + owner-sharded Gaussians/{world}" if owner_mode else f"tile-row {args.shard_mode}/{world}"),
+                       "owner_sharding": dict(module.last_frame_stats, magnitude_image=None) if owner_mode else None,
                        "ranks_seen_by_backend": dist.get_world_size() if world > 1 else 1,
                        "backend": (backend if world > 1 else None),
                        "backward_hook": hook is not None, "hook_feature_copy": bool(hook is not None and not args.no_hook_feature_copy),

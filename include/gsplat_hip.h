@@ -83,6 +83,15 @@ int gs_filter_compact(const float *xyz, const int8_t *invalid_mask, const int32_
                       float far_plane, int width, int height, int8_t *mask, int32_t *ids,
                       int32_t *counters, void *workspace, void *stream);
 
+/* gs_pose_inverse + gs_filter_compact in one launch chain: the filter inverts the poses itself (same arithmetic, same bits)
+ * and leaves them in q_camera_pointcloud / t_camera_pointcloud for the later stages. */
+int gs_filter_compact_from_poses(const float *xyz, const int8_t *invalid_mask, const int32_t *object_id,
+                                 const float *intrinsics, const float *q_pointcloud_camera,
+                                 const float *t_pointcloud_camera, int n_objects, float *q_camera_pointcloud,
+                                 float *t_camera_pointcloud, int n_points, float near_plane, float far_plane,
+                                 int width, int height, int8_t *mask, int32_t *ids, int32_t *counters,
+                                 void *workspace, void *stream);
+
 /* Blocking read of the device counters into host memory (host sync, as RAS:870,916). */
 int gs_read_counters(const int32_t *counters, int32_t *host_counters, int n, void *stream);
 
@@ -125,6 +134,13 @@ int gs_scan_block_sums(int32_t *block_sums, int n_blocks, int32_t *counters, int
  * block_sums_full -> counters[GS_COUNTER_NUM_SLOTS]. */
 int gs_scan_block_sums2(int32_t *block_sums, int32_t *block_sums_full, int n_blocks, int32_t *counters,
                         void *stream);
+
+/* The same, and the frame's sizes {M, K, slots, depth range} are stored into host_counters_mapped[GS_COUNTER_*] by the
+ * kernel itself: host_counters_mapped must be pinned host memory the device can address (hipHostMalloc'd / a pinned torch
+ * tensor: the host pointer is valid on the device under ROCm's unified addressing); the values are visible to the host once
+ * the launch has completed (record an event behind it).  Saves the copy launch of gs_read_counters_async. */
+int gs_scan_block_sums2_to_host(int32_t *block_sums, int32_t *block_sums_full, int n_blocks, int32_t *counters,
+                                int32_t *host_counters_mapped, void *stream);
 
 /* Sort-key generation.  Replaces generate_point_sort_key_by_num_overlap_tiles (RAS:131-172).
  * payload[k] = offset into the visible list.  Key layout:

@@ -2,6 +2,7 @@
 // "One entry point per pass").  Nothing is computed here: every stage is the stage entry point a host would otherwise call
 // through its FFI, with the same arguments, so results are identical to the stage-by-stage path by construction.
 #include "gs_common.h"
+#include <stdlib.h>
 
 #define GS_STAGE(call)            \
     do {                          \
@@ -16,13 +17,20 @@ size_t gs_frame_struct_bytes(void) { return sizeof(GsFrame); }
 int gs_frame_forward(GsFrame *f, uint32_t stages, void *stream) {
     GS_REQUIRE(f != nullptr, "frame");
     const int filter = f->bin_shift == 0 ? 0 : (GS_FILTER_BOX | (f->exact_tile_cull ? GS_FILTER_CULL : 0));
-    if (stages & GS_FWD_POSE_INVERSE)
-        GS_STAGE(gs_pose_inverse(f->q_pointcloud_camera, f->t_pointcloud_camera, f->q_camera_pointcloud,
-                                 f->t_camera_pointcloud, f->n_objects, stream));
-    if (stages & GS_FWD_FILTER_COMPACT)
-        GS_STAGE(gs_filter_compact(f->xyz, f->invalid_mask, f->object_id, f->intrinsics, f->q_camera_pointcloud,
-                                   f->t_camera_pointcloud, f->n_points, f->near_plane, f->far_plane, f->width, f->height,
-                                   f->visible_mask, f->ids, f->counters, f->filter_workspace, stream));
+    if ((stages & GS_FWD_POSE_INVERSE) && (stages & GS_FWD_FILTER_COMPACT)) {   // the filter inverts the poses itself
+        GS_STAGE(gs_filter_compact_from_poses(f->xyz, f->invalid_mask, f->object_id, f->intrinsics, f->q_pointcloud_camera,
+                                              f->t_pointcloud_camera, f->n_objects, f->q_camera_pointcloud,
+                                              f->t_camera_pointcloud, f->n_points, f->near_plane, f->far_plane, f->width,
+                                              f->height, f->visible_mask, f->ids, f->counters, f->filter_workspace, stream));
+    } else {
+        if (stages & GS_FWD_POSE_INVERSE)
+            GS_STAGE(gs_pose_inverse(f->q_pointcloud_camera, f->t_pointcloud_camera, f->q_camera_pointcloud,
+                                     f->t_camera_pointcloud, f->n_objects, stream));
+        if (stages & GS_FWD_FILTER_COMPACT)
+            GS_STAGE(gs_filter_compact(f->xyz, f->invalid_mask, f->object_id, f->intrinsics, f->q_camera_pointcloud,
+                                       f->t_camera_pointcloud, f->n_points, f->near_plane, f->far_plane, f->width,
+                                       f->height, f->visible_mask, f->ids, f->counters, f->filter_workspace, stream));
+    }
     if (stages & GS_FWD_PREPROCESS)   // launched for the capacity n_points; M is read from the counters on the device
         GS_STAGE(gs_preprocess(f->xyz, f->features, f->object_id, f->intrinsics, f->q_camera_pointcloud,
                                f->t_camera_pointcloud, f->ids, f->n_points, 1, f->width, f->height, f->tile_row_begin,
@@ -46,11 +54,17 @@ int gs_frame_forward(GsFrame *f, uint32_t stages, void *stream) {
                                f->tile_row_step, f->tile_row_end, f->bin_shift, f->exact_tile_cull, f->depth_scale,
                                f->counters, f->num_overlap_tiles, f->num_keys, f->block_sums, f->block_sums_full, stream));
     }
+    // GS_HOST_MIRROR=0: the sizes travel through a copy launch (gs_read_counters_async) instead of being stored to the
+    // host's pinned memory by the scan kernel itself
+    static const bool host_mirror = !(getenv("GS_HOST_MIRROR") && atoi(getenv("GS_HOST_MIRROR")) == 0);
+    const bool scan_stores_sizes = host_mirror && (stages & GS_FWD_SCAN) && (stages & GS_FWD_READ_SIZES) &&
+                                   f->host_counters_pinned != nullptr;
     if (stages & GS_FWD_SCAN)
-        GS_STAGE(gs_scan_block_sums2(f->block_sums, f->block_sums_full, gs_div_up(n_list_points, GS_BLOCK), f->counters,
-                                     stream));
+        GS_STAGE(gs_scan_block_sums2_to_host(f->block_sums, f->block_sums_full, gs_div_up(n_list_points, GS_BLOCK),
+                                             f->counters, scan_stores_sizes ? f->host_counters_pinned : nullptr, stream));
     if (stages & GS_FWD_READ_SIZES) {
-        GS_STAGE(gs_read_counters_async(f->counters, f->host_counters_pinned, GS_NUM_COUNTERS, stream));
+        if (!scan_stores_sizes)
+            GS_STAGE(gs_read_counters_async(f->counters, f->host_counters_pinned, GS_NUM_COUNTERS, stream));
         if (f->size_event != nullptr) GS_CHECK_HIP(hipEventRecord((hipEvent_t)f->size_event, (hipStream_t)stream));
     }
     const int32_t *n_keys_device = f->counters + GS_COUNTER_NUM_KEYS;

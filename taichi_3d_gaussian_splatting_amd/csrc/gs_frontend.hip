@@ -187,11 +187,10 @@ __device__ __forceinline__ void quat_mul(const float a[4], const float b[4], flo
     o[3] = w0 * w1 - x0 * x1 - y0 * y1 - z0 * z1;
 }
 
-__global__ void pose_inverse_kernel(const float *__restrict__ q, const float *__restrict__ t,
-                                    float *__restrict__ q_inv, float *__restrict__ t_inv, int n) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    float qi[4] = {-q[4 * i], -q[4 * i + 1], -q[4 * i + 2], q[4 * i + 3]};
+// one pose: (q, t)_pointcloud<-camera -> (q, t)_camera<-pointcloud
+__device__ __forceinline__ void pose_inverse_one(const float *__restrict__ q, const float *__restrict__ t, int i,
+                                                 float qi[4], float ti[3]) {
+    qi[0] = -q[4 * i]; qi[1] = -q[4 * i + 1]; qi[2] = -q[4 * i + 2]; qi[3] = q[4 * i + 3];
     float nrm = sqrtf(((qi[0] * qi[0] + qi[1] * qi[1]) + qi[2] * qi[2]) + qi[3] * qi[3]);
     float qn[4] = {qi[0] / nrm, qi[1] / nrm, qi[2] / nrm, qi[3] / nrm};
     float v[4] = {t[3 * i], t[3 * i + 1], t[3 * i + 2], 0.f};
@@ -200,9 +199,19 @@ __global__ void pose_inverse_kernel(const float *__restrict__ q, const float *__
     quat_mul(qn, v, tmp);
     quat_mul(tmp, qc, out);
 #pragma unroll
+    for (int k = 0; k < 3; ++k) ti[k] = -out[k];
+}
+
+__global__ void pose_inverse_kernel(const float *__restrict__ q, const float *__restrict__ t,
+                                    float *__restrict__ q_inv, float *__restrict__ t_inv, int n) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float qi[4], ti[3];
+    pose_inverse_one(q, t, i, qi, ti);
+#pragma unroll
     for (int k = 0; k < 4; ++k) q_inv[4 * i + k] = qi[k];
 #pragma unroll
-    for (int k = 0; k < 3; ++k) t_inv[3 * i + k] = -out[k];
+    for (int k = 0; k < 3; ++k) t_inv[3 * i + k] = ti[k];
 }
 
 // ------------------------------------------------------------------ filter + ordered compaction
@@ -216,11 +225,27 @@ __global__ __launch_bounds__(GS_BLOCK) void filter_kernel(
     const float *__restrict__ xyz, const int8_t *__restrict__ invalid, const int32_t *__restrict__ obj,
     const float *__restrict__ Kmat, const float *__restrict__ q_cp, const float *__restrict__ t_cp, int n,
     float near_plane, float far_plane, int width, int height, int8_t *__restrict__ mask,
-    int32_t *__restrict__ block_counts, int32_t *__restrict__ counters) {
+    int32_t *__restrict__ block_counts, int32_t *__restrict__ counters, const float *__restrict__ q_pc,
+    const float *__restrict__ t_pc, int n_obj, float *__restrict__ q_cp_out, float *__restrict__ t_cp_out) {
     __shared__ int s_count;
     if (threadIdx.x == 0) s_count = 0;
     // the frame's counters start at zero (the first kernel of a frame does it: no separate fill launch)
     if (blockIdx.x == 0 && threadIdx.x < GS_NUM_COUNTERS) counters[threadIdx.x] = 0;
+    // Fused pose inverse (q_pc != null; UTL:426-432): every lane inverts the pose of its point's object itself -- the same
+    // device function as gs_pose_inverse, hence the same bits -- and workgroup 0 leaves the inverted poses in
+    // q_cp_out / t_cp_out for the later stages: one launch (and one dependent boundary) less per frame
+    const bool fused_pose = q_pc != nullptr;
+    if (fused_pose && blockIdx.x == 0)
+        for (int o = threadIdx.x; o < n_obj; o += GS_BLOCK) {
+            float qi[4], ti[3];
+            pose_inverse_one(q_pc, t_pc, o, qi, ti);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) q_cp_out[4 * o + k] = qi[k];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) t_cp_out[3 * o + k] = ti[k];
+        }
+    int cached_obj = -1;
+    float cq[4] = {0.f, 0.f, 0.f, 1.f}, ct[3] = {0.f, 0.f, 0.f};
     __syncthreads();
     float K[9];
 #pragma unroll
@@ -233,8 +258,19 @@ __global__ __launch_bounds__(GS_BLOCK) void filter_kernel(
         if (i < n) {
             if (invalid[i] != 1) {
                 int o = obj[i];
-                Mat3 R = rotmat_from_q(q_cp[4 * o], q_cp[4 * o + 1], q_cp[4 * o + 2], q_cp[4 * o + 3]);
-                float t[3] = {t_cp[3 * o], t_cp[3 * o + 1], t_cp[3 * o + 2]};
+                if (o != cached_obj) {   // (one object in most scenes: inverted or loaded once per lane)
+                    if (fused_pose) {
+                        pose_inverse_one(q_pc, t_pc, o, cq, ct);
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) cq[k] = q_cp[4 * o + k];
+#pragma unroll
+                        for (int k = 0; k < 3; ++k) ct[k] = t_cp[3 * o + k];
+                    }
+                    cached_obj = o;
+                }
+                Mat3 R = rotmat_from_q(cq[0], cq[1], cq[2], cq[3]);
+                float t[3] = {ct[0], ct[1], ct[2]};
                 float p[3] = {xyz[3 * (size_t)i], xyz[3 * (size_t)i + 1], xyz[3 * (size_t)i + 2]};
                 float uv[2], c[3];
                 project_point(R, t, K, p, uv, c);
@@ -259,9 +295,12 @@ __global__ __launch_bounds__(GS_BLOCK) void filter_kernel(
 __global__ __launch_bounds__(GS_BLOCK) void scan_single_block_kernel(int32_t *__restrict__ data, int n,
                                                                     int32_t *__restrict__ total_out,
                                                                     int32_t *__restrict__ data2,
-                                                                    int32_t *__restrict__ total_out2) {
+                                                                    int32_t *__restrict__ total_out2,
+                                                                    const int32_t *__restrict__ counters,
+                                                                    int32_t *__restrict__ host_mirror) {
     __shared__ long long lds[GS_BLOCK / GS_WAVE];
-    if (blockIdx.x == 1) { data = data2; total_out = total_out2; }
+    int mirror_slot = GS_COUNTER_NUM_KEYS;
+    if (blockIdx.x == 1) { data = data2; total_out = total_out2; mirror_slot = GS_COUNTER_NUM_SLOTS; }
     // every thread owns SCAN_ITEMS consecutive values: all loads of a 4096-value chunk are in flight together (the
     // one-value-per-thread form paid one L2 round trip per 256 values: 12 us for the 3.9 k block sums of 1e6 points)
     constexpr int SCAN_ITEMS = 16;
@@ -299,7 +338,20 @@ __global__ __launch_bounds__(GS_BLOCK) void scan_single_block_kernel(int32_t *__
         }
         carry += total;
     }
-    if (threadIdx.x == 0) *total_out = carry > 0x7fffffffLL ? 0x7fffffff : (int)carry;
+    if (threadIdx.x == 0) {
+        const int total = carry > 0x7fffffffLL ? 0x7fffffff : (int)carry;
+        *total_out = total;
+        // host_mirror (pinned, host-coherent memory mapped into the device's address space): the frame's sizes go to the
+        // host straight from this kernel -- visible when the kernel has completed (the event recorded behind it) -- instead
+        // of through a copy launch of their own (~6 us of a frame that is a chain of such launches)
+        if (host_mirror != nullptr) {
+            host_mirror[mirror_slot] = total;
+            if (blockIdx.x == 0) {
+                host_mirror[GS_COUNTER_NUM_VISIBLE] = counters[GS_COUNTER_NUM_VISIBLE];
+                host_mirror[GS_COUNTER_MAX_DEPTH_KEY] = counters[GS_COUNTER_MAX_DEPTH_KEY];
+            }
+        }
+    }
 }
 
 // RAS:861-870: point_id[mask] -- order-preserving compaction with wave ballots.  Every workgroup first sums the
@@ -749,17 +801,31 @@ int gs_filter_compact(const float *xyz, const int8_t *invalid_mask, const int32_
                       const float *intrinsics, const float *q_cp, const float *t_cp, int n_points,
                       float near_plane, float far_plane, int width, int height, int8_t *mask, int32_t *ids,
                       int32_t *counters, void *workspace, void *stream) {
+    return gs_filter_compact_from_poses(xyz, invalid_mask, object_id, intrinsics, nullptr, nullptr, 0, (float *)q_cp,
+                                        (float *)t_cp, n_points, near_plane, far_plane, width, height, mask, ids, counters,
+                                        workspace, stream);
+}
+
+int gs_filter_compact_from_poses(const float *xyz, const int8_t *invalid_mask, const int32_t *object_id,
+                                 const float *intrinsics, const float *q_pointcloud_camera,
+                                 const float *t_pointcloud_camera, int n_objects, float *q_cp, float *t_cp, int n_points,
+                                 float near_plane, float far_plane, int width, int height, int8_t *mask, int32_t *ids,
+                                 int32_t *counters, void *workspace, void *stream) {
     GS_REQUIRE(n_points >= 0, "n_points");
+    GS_REQUIRE(q_pointcloud_camera == nullptr || (t_pointcloud_camera != nullptr && n_objects > 0), "poses");
     GS_REQUIRE(width % GS_TILE_WIDTH == 0 && height % GS_TILE_HEIGHT == 0, "image size must be a multiple of 16");
     hipStream_t s = (hipStream_t)stream;
     int32_t *block_counts = (int32_t *)workspace;
     if (n_points == 0) {
         GS_CHECK_HIP(hipMemsetAsync(counters, 0, sizeof(int32_t) * GS_NUM_COUNTERS, s));
+        if (q_pointcloud_camera != nullptr)   // the later stages of the frame still expect the inverted poses
+            return gs_pose_inverse(q_pointcloud_camera, t_pointcloud_camera, q_cp, t_cp, n_objects, stream);
         return 0;
     }
     const int nblk = gs_div_up(n_points, FILTER_ITEMS);
     hipLaunchKernelGGL(filter_kernel, dim3(nblk), dim3(GS_BLOCK), 0, s, xyz, invalid_mask, object_id, intrinsics,
-                       q_cp, t_cp, n_points, near_plane, far_plane, width, height, mask, block_counts, counters);
+                       q_cp, t_cp, n_points, near_plane, far_plane, width, height, mask, block_counts, counters,
+                       q_pointcloud_camera, t_pointcloud_camera, n_objects, q_cp, t_cp);
     GS_CHECK_LAUNCH();
     hipLaunchKernelGGL(compact_kernel, dim3(nblk), dim3(GS_BLOCK), 0, s, mask, n_points, block_counts, ids,
                        counters + GS_COUNTER_NUM_VISIBLE);
@@ -829,20 +895,30 @@ int gs_scan_block_sums(int32_t *block_sums, int n_blocks, int32_t *counters, int
         return 0;
     }
     hipLaunchKernelGGL(scan_single_block_kernel, dim3(1), dim3(GS_BLOCK), 0, (hipStream_t)stream, block_sums,
-                       n_blocks, counters + counter_slot, (int32_t *)nullptr, (int32_t *)nullptr);
+                       n_blocks, counters + counter_slot, (int32_t *)nullptr, (int32_t *)nullptr, (const int32_t *)nullptr,
+                       (int32_t *)nullptr);
     GS_CHECK_LAUNCH();
     return 0;
 }
 
 int gs_scan_block_sums2(int32_t *block_sums, int32_t *block_sums_full, int n_blocks, int32_t *counters,
                         void *stream) {
+    return gs_scan_block_sums2_to_host(block_sums, block_sums_full, n_blocks, counters, nullptr, stream);
+}
+
+int gs_scan_block_sums2_to_host(int32_t *block_sums, int32_t *block_sums_full, int n_blocks, int32_t *counters,
+                                int32_t *host_counters_mapped, void *stream) {
     GS_REQUIRE(n_blocks >= 0, "n_blocks");
     if (n_blocks == 0) {
         GS_CHECK_HIP(hipMemsetAsync(counters + GS_COUNTER_NUM_KEYS, 0, 2 * sizeof(int32_t), (hipStream_t)stream));
+        if (host_counters_mapped != nullptr)
+            GS_CHECK_HIP(hipMemcpyAsync(host_counters_mapped, counters, sizeof(int32_t) * GS_NUM_COUNTERS, hipMemcpyDeviceToHost,
+                                        (hipStream_t)stream));
         return 0;
     }
     hipLaunchKernelGGL(scan_single_block_kernel, dim3(2), dim3(GS_BLOCK), 0, (hipStream_t)stream, block_sums,
-                       n_blocks, counters + GS_COUNTER_NUM_KEYS, block_sums_full, counters + GS_COUNTER_NUM_SLOTS);
+                       n_blocks, counters + GS_COUNTER_NUM_KEYS, block_sums_full, counters + GS_COUNTER_NUM_SLOTS, counters,
+                       host_counters_mapped);
     GS_CHECK_LAUNCH();
     return 0;
 }

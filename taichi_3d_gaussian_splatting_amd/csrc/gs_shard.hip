@@ -190,8 +190,11 @@ __global__ __launch_bounds__(GS_BLOCK) void route_kernel(
     const float4 *__restrict__ attrs, const int32_t *__restrict__ num_keys, int m_capacity,
     const int32_t *__restrict__ counters, int width, int height, int rows_per_band, int world, int nblk,
     int32_t *__restrict__ block_counts /* [world][nblk]: counts (SCATTER = false) / exclusive offsets (true) */,
-    int capacity, float4 *__restrict__ send, int32_t *__restrict__ pos) {
+    int capacity, float4 *__restrict__ send, int32_t *__restrict__ pos, const int32_t *__restrict__ counts) {
     __shared__ int s_cnt[GS_BLOCK / GS_WAVE][ROUTE_MAX_WORLD];
+    if (SCATTER && blockIdx.x == 0 && (int)threadIdx.x < world)   // the chunks' headers: number of valid records
+        send[(size_t)threadIdx.x * (capacity + 1) * 4] =
+            make_float4(__builtin_bit_cast(float, min(counts[threadIdx.x], capacity)), 0.f, 0.f, 0.f);
     const int m = counters ? min(counters[GS_COUNTER_NUM_VISIBLE], m_capacity) : m_capacity;
     const int i = blockIdx.x * GS_BLOCK + threadIdx.x, w = threadIdx.x >> 6;
     int b0 = 0, b1 = -1;
@@ -337,7 +340,7 @@ int gs_route_count(const float *attrs, const int32_t *num_keys, int n_visible_ca
     int32_t *block_counts = (int32_t *)workspace;
     hipLaunchKernelGGL(route_kernel<false>, dim3(nblk), dim3(GS_BLOCK), 0, s, reinterpret_cast<const float4 *>(attrs),
                        num_keys, n_visible_capacity, counters, width, height, rows_per_band, world, nblk, block_counts, 0,
-                       (float4 *)nullptr, (int32_t *)nullptr);
+                       (float4 *)nullptr, (int32_t *)nullptr, (const int32_t *)nullptr);
     GS_CHECK_LAUNCH();
     hipLaunchKernelGGL(route_scan_kernel, dim3(world), dim3(GS_BLOCK), 0, s, block_counts, nblk, counts);
     GS_CHECK_LAUNCH();
@@ -350,14 +353,16 @@ int gs_route_scatter(const float *attrs, const int32_t *num_keys, int n_visible_
     GS_REQUIRE(world >= 1 && world <= ROUTE_MAX_WORLD && rows_per_band >= 1 && n_visible_capacity >= 0 && capacity >= 0,
                "sizes (world <= 64)");
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(route_headers_kernel, dim3(1), dim3(ROUTE_MAX_WORLD), 0, s, counts, world, capacity,
-                       reinterpret_cast<float4 *>(send));
-    GS_CHECK_LAUNCH();
-    if (n_visible_capacity == 0) return 0;
+    if (n_visible_capacity == 0) {   // nothing to send: the headers alone
+        hipLaunchKernelGGL(route_headers_kernel, dim3(1), dim3(ROUTE_MAX_WORLD), 0, s, counts, world, capacity,
+                           reinterpret_cast<float4 *>(send));
+        GS_CHECK_LAUNCH();
+        return 0;
+    }
     const int nblk = gs_div_up(n_visible_capacity, GS_BLOCK);
     hipLaunchKernelGGL(route_kernel<true>, dim3(nblk), dim3(GS_BLOCK), 0, s, reinterpret_cast<const float4 *>(attrs),
                        num_keys, n_visible_capacity, counters, width, height, rows_per_band, world, nblk,
-                       (int32_t *)workspace, capacity, reinterpret_cast<float4 *>(send), pos);
+                       (int32_t *)workspace, capacity, reinterpret_cast<float4 *>(send), pos, counts);
     GS_CHECK_LAUNCH();
     return 0;
 }

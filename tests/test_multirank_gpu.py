@@ -137,6 +137,48 @@ def test_trainer_replicated_state_stays_identical_across_ranks(tmp_path):
     mp.spawn(_train_worker, args=(2, _free_port(), root), nprocs=2, join=True)
 
 
+def test_bench_launches_its_own_ranks_owner_sharded(tmp_path):
+    """`python bench.py --gpus 2` with NO launcher (how the driver may call it): bench.py re-runs itself under
+    torch.distributed.run, one process per rank (gloo here: the box has one GPU, RCCL refuses two ranks on one device), in
+    the default multi-GPU mode -- owner-sharded Gaussians -- and rank 0 prints the one JSON line, reporting the rank count the
+    back end saw."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, GS_BENCH_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for key in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(key, None)
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                          "--workload", "cfg2_100k_800", "--no-cpu-baseline"],
+                         cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["config"]["ranks_seen_by_backend"] == 2 and rec["config"]["backend"] == "gloo"
+    assert rec["config"]["sharding"] == "tile-row bands + owner-sharded Gaussians/2" and rec["value"] > 0
+    assert rec["config"]["owner_sharding"]["records_sent"] > 0 and rec["scaling"] == "strong"
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs (RCCL refuses two ranks on one device)")
+def test_bench_launches_its_own_ranks_over_rccl():
+    """The same on a multi-GPU node over RCCL: one rank per GPU (skipped on the one-GPU boxes of this pool)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for key in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "GS_BENCH_DIST_BACKEND"):
+        env.pop(key, None)
+    n = min(torch.cuda.device_count(), 8)
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(n), "--steps", "5", "--warmup", "2",
+                          "--no-cpu-baseline"], cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    rec = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][0])
+    assert rec["n_gpus"] == n and rec["config"]["ranks_seen_by_backend"] == n and rec["config"]["backend"] == "nccl"
+
+
 def test_bench_multi_rank_contract(tmp_path):
     """bench.py launched the way the driver launches it for N > 1 (torch.distributed.run, one process per rank), on this
     1-GPU box with the gloo transport: rank 0 prints exactly one JSON line with the contract's fields."""
@@ -148,7 +190,7 @@ def test_bench_multi_rank_contract(tmp_path):
     out = subprocess.run(
         [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
          "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
-         "--workload", "cfg2_100k_800", "--no-cpu-baseline"],
+         "--workload", "cfg2_100k_800", "--no-cpu-baseline", "--shard-mode", "bands"],
         cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
