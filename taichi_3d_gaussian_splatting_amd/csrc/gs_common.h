@@ -260,22 +260,46 @@ __device__ __forceinline__ void gs_sh_basis(const float d[3], float Y[16]) {  //
 }
 // W = R(q_camera_pointcloud), t = t_camera_pointcloud, p = the point; coeff(ch, k) = SH coefficient k of channel ch.
 // Ray origin = (-W^T) t (UTL:495-510), colour = sigmoid(SH . Y) (RAS:280-282,302-310, GP3:333-349).
-template <typename Coeff>
-__device__ __forceinline__ void gs_view_colour(const float W[9], const float t[3], const float p[3], Coeff coeff,
-                                               float rgb[3]) {
+// The 16-term dot product is summed as FOUR QUARTERS of four sequential terms, combined as (q0 + q1) + (q2 + q3): the
+// projection kernel evaluates a quarter per lane (twelve lanes read a Gaussian's 192 B of coefficients with one coalesced
+// 16-byte load each, gs_preprocess) and adds the quarters in exactly this tree, so the cooperative and the scalar
+// evaluation agree to the last bit.  (The reference sums the sixteen products in sequence: the CPU oracle does too, and
+// the two differ by an ulp of the pre-sigmoid sum -- well inside the colour bar of the parity tests.)
+__device__ __forceinline__ void gs_view_basis(const float W[9], const float t[3], const float p[3], float Y[16]) {
 #pragma clang fp contract(off)
     float ro[3];
 #pragma unroll
     for (int k = 0; k < 3; ++k) ro[k] = ((-W[k]) * t[0] + (-W[3 + k]) * t[1]) + (-W[6 + k]) * t[2];
     const float dir[3] = {p[0] - ro[0], p[1] - ro[1], p[2] - ro[2]};
-    float Y[16];
     gs_sh_basis(dir, Y);
+}
+__device__ __forceinline__ float gs_sh_quarter(float c0, float c1, float c2, float c3, float y0, float y1, float y2,
+                                               float y3) {
+#pragma clang fp contract(off)
+    float s = c0 * y0;
+    s = s + c1 * y1;
+    s = s + c2 * y2;
+    s = s + c3 * y3;
+    return s;
+}
+__device__ __forceinline__ float gs_colour_from_sum(float s) {
+#pragma clang fp contract(off)
+    return 1.f / (1.f + expf(-s));
+}
+template <typename Coeff>
+__device__ __forceinline__ void gs_view_colour(const float W[9], const float t[3], const float p[3], Coeff coeff,
+                                               float rgb[3]) {
+#pragma clang fp contract(off)
+    float Y[16];
+    gs_view_basis(W, t, p, Y);
 #pragma unroll
     for (int ch = 0; ch < 3; ++ch) {
-        float s = coeff(ch, 0) * Y[0];
+        float q[4];
 #pragma unroll
-        for (int k = 1; k < 16; ++k) s = s + coeff(ch, k) * Y[k];
-        rgb[ch] = 1.f / (1.f + expf(-s));
+        for (int j = 0; j < 4; ++j)
+            q[j] = gs_sh_quarter(coeff(ch, 4 * j), coeff(ch, 4 * j + 1), coeff(ch, 4 * j + 2), coeff(ch, 4 * j + 3), Y[4 * j],
+                                 Y[4 * j + 1], Y[4 * j + 2], Y[4 * j + 3]);
+        rgb[ch] = gs_colour_from_sum((q[0] + q[1]) + (q[2] + q[3]));
     }
 }
 

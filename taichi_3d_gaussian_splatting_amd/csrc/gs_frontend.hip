@@ -528,28 +528,68 @@ __global__ __launch_bounds__(GS_BLOCK) void preprocess_kernel(
             owned = cnts[gs_lane()];
         }
     }
+    // Colour (RAS:280-282,302-310; ray origin = (-R^T) t, UTL:495-510) -- only for Gaussians that emit at least one key on
+    // this GPU: nothing else is ever gathered by the blend kernels (tile-row sharding: most Gaussians touch the rows of one
+    // or two of the G GPUs).  The 192 B of SH coefficients are read COOPERATIVELY: every lane leaves the sixteen basis
+    // values of its Gaussian in LDS (the wave's slice of s_rec, free after the key count), then sixteen lanes serve one
+    // Gaussian -- twelve of them load one 16-byte quarter of a colour channel each (one coalesced 192-byte read per
+    // Gaussian, four Gaussians per load instruction) and form that quarter's part of SH . Y, two exchanges add the quarters
+    // in the tree of gs_view_colour, the sigmoid follows.  (One lane gathering its own row with twelve scattered 16-byte
+    // loads kept 64 partially used lines per instruction in flight: 1.64x the algorithmic HBM bytes, round 3.)
+    float rgb[3] = {0.f, 0.f, 0.f};
+    {
+        const bool wants = live && owned > 0;
+        const unsigned long long need = __builtin_amdgcn_ballot_w64(wants);
+        if (need != 0ull) {   // wave-uniform
+            float *Yw = reinterpret_cast<float *>(s_rec + (threadIdx.x & ~(GS_WAVE - 1)));   // 64 x 16 floats of this wave
+            const int lane = gs_lane();
+            __builtin_amdgcn_wave_barrier();
+            if (wants) {
+                const int o = obj[id];
+                const Mat3 W = rotmat_from_q(q_cp[4 * o], q_cp[4 * o + 1], q_cp[4 * o + 2], q_cp[4 * o + 3]);
+                const float t[3] = {t_cp[3 * o], t_cp[3 * o + 1], t_cp[3 * o + 2]};
+                const float p[3] = {xyz[3 * (size_t)id], xyz[3 * (size_t)id + 1], xyz[3 * (size_t)id + 2]};
+                float Y[16];
+                gs_view_basis(W.m, t, p, Y);
+                float4 *dst = reinterpret_cast<float4 *>(Yw + 16 * lane);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) dst[k] = make_float4(Y[4 * k], Y[4 * k + 1], Y[4 * k + 2], Y[4 * k + 3]);
+            }
+            __builtin_amdgcn_wave_barrier();
+            const int sub = lane & 15, quarter = sub & 3;
+            constexpr int IN_FLIGHT = 8;   // Gaussians-of-a-group whose coefficient loads are in flight together
+#pragma unroll
+            for (int it0 = 0; it0 < 16; it0 += IN_FLIGHT) {
+                float4 c4[IN_FLIGHT];
+#pragma unroll
+                for (int k = 0; k < IN_FLIGHT; ++k) {
+                    const int g = (it0 + k) * 4 + (lane >> 4);                 // the Gaussian (lane of this wave) served
+                    const int gid = __shfl(id, g, GS_WAVE);
+                    const bool on = ((need >> g) & 1ull) != 0ull && sub < 12;
+                    c4[k] = on ? reinterpret_cast<const float4 *>(feat + (size_t)GS_FEATURE_DIM * gid)[2 + sub]
+                               : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+#pragma unroll
+                for (int k = 0; k < IN_FLIGHT; ++k) {
+                    const int g = (it0 + k) * 4 + (lane >> 4);
+                    const float4 y = reinterpret_cast<const float4 *>(Yw + 16 * g)[quarter];
+                    const float part = gs_sh_quarter(c4[k].x, c4[k].y, c4[k].z, c4[k].w, y.x, y.y, y.z, y.w);
+                    const float pair = part + __shfl_xor(part, 1, GS_WAVE);    // q0 + q1 | q2 + q3
+                    const float sum = pair + __shfl_xor(pair, 2, GS_WAVE);     // (q0 + q1) + (q2 + q3)
+                    const float colour = gs_colour_from_sum(sum);
+                    // the channel's first lane leaves the colour in the (now consumed) basis slot of the Gaussian
+                    if (quarter == 0 && sub < 12 && ((need >> g) & 1ull) != 0ull) Yw[16 * g + (sub >> 2)] = colour;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            if (wants) { rgb[0] = Yw[16 * lane]; rgb[1] = Yw[16 * lane + 1]; rgb[2] = Yw[16 * lane + 2]; }
+        }
+    }
     if (live) {
         float4 *out = reinterpret_cast<float4 *>(attrs + (size_t)GS_ATTR_STRIDE * i);
         out[0] = make_float4(u_, v_, z_, qmax);  // always: the hook exposes uv and depth of every
                                                  // visible point (RAS:1138-1139)
         if (owned > 0) {
-            // Only Gaussians that emit at least one key on this GPU are ever gathered by the blend kernels:
-            // the SH colour (the most expensive part) and the rest of the record are skipped otherwise
-            // (tile-row sharding: most Gaussians touch the rows of only one or two of the G GPUs).
-            // colour: RAS:280-282,302-310; ray origin = (-R^T) t (UTL:495-510)
-            const float4 *row4 = reinterpret_cast<const float4 *>(feat + (size_t)GS_FEATURE_DIM * id);
-            const int o = obj[id];
-            const Mat3 W = rotmat_from_q(q_cp[4 * o], q_cp[4 * o + 1], q_cp[4 * o + 2], q_cp[4 * o + 3]);
-            const float t[3] = {t_cp[3 * o], t_cp[3 * o + 1], t_cp[3 * o + 2]};
-            const float p[3] = {xyz[3 * (size_t)id], xyz[3 * (size_t)id + 1], xyz[3 * (size_t)id + 2]};
-            float sh[48];
-#pragma unroll
-            for (int k = 0; k < 12; ++k) {
-                float4 v = row4[2 + k];
-                sh[4 * k] = v.x; sh[4 * k + 1] = v.y; sh[4 * k + 2] = v.z; sh[4 * k + 3] = v.w;
-            }
-            float rgb[3];   // shared source with the per-point backward (gs_common.h): bit-identical there
-            gs_view_colour(W.m, t, p, [&](int ch, int k) { return sh[16 * ch + k]; }, rgb);
             out[1] = make_float4(cA, cB, cC, radius);
             out[2] = make_float4(rgb[0], rgb[1], rgb[2], opacity);
             // the weight UTL:275-284 in the log2 domain: amp * 2^(dx*(A'dx + B'dy) + C'dy^2)

@@ -1230,6 +1230,19 @@ def test_operator_multi_object_poses():
     _check_acc("multi_object.grad_xyz", xyz.grad.cpu().numpy(), ob["grad_xyz"], FLIP_GRAD_TOL)
 
 
+def test_operator_cfg1_as_stated():
+    """BASELINE config 1 exactly as stated: 10k random Gaussians, 256 x 256, SH-degree-0 DATA (only the DC coefficients are
+    non-zero, `synthetic.CONFIGS["cfg1_10k_256"]`) rendered with colour band 0 -- forward and backward against the oracle.
+    (The module's fixture is the same size with degree-3 data; not a different code path, SURVEY 0.7, but the config as
+    written deserves its own line.)"""
+    from taichi_3d_gaussian_splatting_amd.synthetic import make_config_scene
+    s = make_config_scene("cfg1_10k_256")
+    assert float(s.point_cloud_features[:, 9:24].abs().max()) == 0.0      # degree-0 data
+    f = oracle_forward(s)
+    report("cfg1.sizes", M=len(f["ids"]), K=len(f["keys"]))
+    _operator_vs_oracle("cfg1", s, f, band=0)
+
+
 def test_operator_cfg2_size_forward_backward():
     """BASELINE config 2: 1e5 Gaussians, 800x800, SH degree 3, forward + backward vs the oracle."""
     from taichi_3d_gaussian_splatting_amd.synthetic import make_config_scene, make_grad_image
