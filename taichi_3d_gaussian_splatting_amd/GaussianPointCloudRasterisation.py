@@ -341,7 +341,7 @@ class GaussianPointCloudRasterisation(torch.nn.Module):
                     # binned layouts: the forward pass writes out every tile's own list as far as it walks it, and the
                     # backward pass runs on those plain per-tile lists (no second filtering of the bin's entries)
                     emit = bool(need_state and outer.backward_on_walked_lists and layout.filter != 0 and
-                                layout.bin_shift <= 2 and (payload_.shape[0] << (2 * layout.bin_shift)) < 2 ** 31)
+                                hip_ops.can_emit_walked_lists(payload_.shape[0], layout.bin_shift))
                     boundary_ = None
                     if need_state and outer.split_small_grid_backward:
                         nbytes = hip_ops.boundary_states_bytes(payload_.shape[0] << (2 * layout.bin_shift if emit else 0),
@@ -493,9 +493,12 @@ class GaussianPointCloudRasterisation(torch.nn.Module):
         # Counting emitted keys rather than tile-box areas keeps needle-shaped Gaussians (huge boxes that the cull
         # empties) from pushing an ordinary frame into the coarse bins.
         # Sharded runs: every rank decides from its OWN key count (scaled to the whole image), so ranks may pick
-        # different layouts for the same frame.  That is correct by construction -- image, depth, count and
-        # gradients are bit-identical across layouts (tests: test_list_layouts_are_output_identical, the sharded
-        # x binned tests) -- and costs at most some load imbalance; set `bin_shift` to pin one layout everywhere.
+        # different layouts for the same frame.  That is correct by construction -- image, depth and count are
+        # bit-identical across layouts (tests: test_list_layouts_are_output_identical, the sharded x binned tests), and
+        # the gradients every rank ends up with after the accumulator exchange are identical ACROSS RANKS.  They are not
+        # bit-identical to an un-sharded run or between layouts on small grids: a rank's band usually has <= 3,840
+        # tiles, where per-tile / walked lists select the four-waves-per-tile backward, whose slot sums add the same
+        # per-pixel terms in another order.  Costs at most some load imbalance; set `bin_shift` to pin one layout.
         owned = len(layout.owned_rows(height))
         k_frame = n_keys * ((height // TILE_HEIGHT) / owned if owned else 1.0)
         used = layout.bin_shift
@@ -525,6 +528,13 @@ class GaussianPointCloudRasterisation(torch.nn.Module):
         outer._size_guesses[guess_key] = (max(int(1.3 * n_keys) + 4096, int(0.99 * guess[0]) if guess else 0),
                                           depth_bound)
         return fits
+
+    def release_workspaces(self) -> None:
+        """Gives back the scratch buffers this operator keeps between frames (sort ping-pong, slot records, ...: they only
+        grow, to the high-water mark of training); they are re-allocated on demand.  Call it around evaluation or after a
+        densification shrank the frame -- not while a frame is in flight on another stream (the buffers assume the one
+        stream the operator is called on)."""
+        self._scratch.release()
 
     def _counter_readback(self, device):
         rb = self._readbacks.get(device)

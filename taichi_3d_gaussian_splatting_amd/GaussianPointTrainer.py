@@ -268,7 +268,9 @@ class GaussianPointCloudTrainer:
                 print(f"{console_key}_{step}={value};")
 
     def _loaders(self):
-        from .host_affinity import reset_worker_affinity   # workers fork from a main thread that may be pinned to one complex
+        import functools
+        from .host_affinity import original_mask, reset_worker_affinity   # the main thread may be pinned to one L3 complex
+        reset_worker_affinity = functools.partial(reset_worker_affinity, mask=original_mask())   # (also for spawned workers)
         kw = dict(batch_size=None, pin_memory=True, num_workers=self.config.num_data_loader_workers,
                   worker_init_fn=reset_worker_affinity if self.config.num_data_loader_workers > 0 else None)
         generator = torch.Generator().manual_seed(self.config.seed)   # same shuffling on every rank

@@ -179,6 +179,18 @@ def exchange_accumulators_sparse(acc: torch.Tensor, num_keys: torch.Tensor, grou
         raise RuntimeError(f"rank {rank}: {m} Gaussians in the frustum, other ranks {[row[1] for row in host]}: the "
                            f"replicated point clouds have diverged")
     counts = [row[0] for row in host]
+    if sum(counts) > 1.5 * m:
+        # most Gaussians were blended by several ranks (interleaved-like frames, the stress distribution, huge Gaussians):
+        # the gathered lists would weigh world x M x 52 B on every rank, several times the dense array -- one all-reduce of
+        # the 48 B x M array instead.  Every rank sees the same counts, so every rank takes this branch.
+        if stats is not None:
+            stats.update(rows_sent=counts[rank], rows_total=sum(counts), capacity=0, bytes_sent=48 * m, dense_bytes=48 * m,
+                         dense_fallback=True)
+        col = acc[:, 10]
+        col.copy_(col.view(torch.int32))
+        dist.all_reduce(acc, op=dist.ReduceOp.SUM, group=group)
+        col.view(torch.int32).copy_(col)
+        return acc
     cap = max(4, -(-max(counts) // 4) * 4)      # 16-B aligned rows behind the ids
     stride = 13 * cap
     send = torch.empty(stride, dtype=torch.int32, device=dev)

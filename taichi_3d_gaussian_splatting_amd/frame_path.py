@@ -81,8 +81,8 @@ def forward(outer, xyz, features, invalid, obj, intrinsics, q_pc, t_pc, camera_i
     rgb_only = bool(cfg.rgb_only)
     ordered = bool(outer.ordered_dispatch)
     shift2 = 2 * layout.bin_shift
-    emit = bool(need_state and outer.backward_on_walked_lists and layout.filter != 0 and layout.bin_shift <= 2 and
-                (max(cap, 1) << shift2) < 2 ** 31)
+    emit = bool(need_state and outer.backward_on_walked_lists and layout.filter != 0 and
+                hip_ops.can_emit_walked_lists(cap, layout.bin_shift))
     n_obj = q_pc.shape[0]
     slab = Slab()
     slab.add("q_cp", 16 * n_obj)

@@ -82,6 +82,13 @@ class Workspaces:
     def __init__(self):
         self._bufs = {}
 
+    def release(self) -> None:
+        """Drops every buffer (they come back on demand): for callers that want the high-water marks of training back
+        around evaluation or after a densification that shrank the frame.  Only call it when no launch that uses the
+        buffers is pending on another stream: the buffers assume ONE stream (calls on the operator's stream are ordered
+        by it; a buffer handed to a second stream while the first still reads it would race)."""
+        self._bufs.clear()
+
     def get(self, name: str, shape, dtype: torch.dtype, device, zeroed: bool = False) -> torch.Tensor:
         """zeroed: the buffer is zero-filled when it is (re)allocated -- for workspaces whose users leave them zero."""
         numel = 1
@@ -93,6 +100,18 @@ class Workspaces:
             t = (torch.zeros if zeroed else torch.empty)(max(grow, 1), dtype=dtype, device=device)
             self._bufs[name] = t
         return t[:numel].view(shape)
+
+
+WALKED_LIST_MAX_BYTES = 512 << 20   # above this a binned frame keeps the staged (re-filtering) backward
+
+
+def can_emit_walked_lists(n_keys: int, bin_shift: int) -> bool:
+    """Whether a binned forward pass may write out its per-tile lists for the backward pass: the buffer holds
+    (n_keys << 2 bin_shift) int32 -- the key capacity amplified by the tiles per bin -- and lives until the backward pass;
+    it must index with int32 and stay within WALKED_LIST_MAX_BYTES (a dense frame at 4 x 4-tile bins would otherwise pin
+    gigabytes per pending frame where the staged backward needs none)."""
+    entries = max(int(n_keys), 1) << (2 * int(bin_shift))
+    return 0 < bin_shift <= 2 and entries < 2 ** 31 and 4 * entries <= WALKED_LIST_MAX_BYTES
 
 
 def _scratch(ws: Optional["Workspaces"], name: str, shape, dtype, device) -> torch.Tensor:

@@ -100,8 +100,10 @@ def pin_host_threads(device_index: int = 0, slot: Optional[int] = None) -> Optio
         return None
     if slot is None:
         rank = os.environ.get("LOCAL_RANK", "")
-        slot = int(rank) if rank.isdigit() else int(device_index)
+        slot = int(rank) if rank.isdigit() else _stable_device_slot(device_index)
     chosen = groups[slot % len(groups)]
+    if os.environ.get("GS_PIN_HOST_THREADS_VERBOSE") == "1":
+        print(f"[host_affinity] device {device_index}: slot {slot}, cpus {sorted(chosen)}", flush=True)
     if len(chosen) >= len(allowed):
         return None   # already that narrow
     for tid in _all_thread_ids():
@@ -123,6 +125,28 @@ def pin_host_threads(device_index: int = 0, slot: Optional[int] = None) -> Optio
     return chosen
 
 
+def _stable_device_slot(device_index: int) -> int:
+    """A slot for a process that was given no LOCAL_RANK: the device index -- unless the devices were narrowed with
+    HIP_VISIBLE_DEVICES / CUDA_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES (then every process sees "device 0" and all of them would
+    take the same complex): in that case the PHYSICAL device's position, read from the visibility list or, failing that, from
+    its PCI bus id."""
+    for var in ("HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES"):
+        text = os.environ.get(var, "")
+        if text:
+            entries = [e.strip() for e in text.split(",") if e.strip()]
+            if 0 <= device_index < len(entries) and entries[device_index].isdigit():
+                return int(entries[device_index])
+            try:
+                import torch
+                bus = getattr(torch.cuda.get_device_properties(device_index), "pci_bus_id", None)
+                if bus is not None:
+                    return int(bus)
+            except Exception:
+                pass
+            break
+    return int(device_index)
+
+
 def unpin_host_threads() -> None:
     """Give every thread of the process the mask it had before the first ``pin_host_threads`` (for CPU-parallel work:
     the oracle leg of bench.py runs on all cores)."""
@@ -141,11 +165,26 @@ def unpin_host_threads() -> None:
             pass
 
 
-def reset_worker_affinity(_worker_id: int = 0) -> None:
-    """``worker_init_fn`` for ``torch.utils.data.DataLoader``: worker processes are forked from the pinned main thread and
-    would all sit on its complex."""
-    if _original_mask is not None and hasattr(os, "sched_setaffinity"):
+def original_mask() -> Optional[Set[int]]:
+    """The affinity mask the process had before it was pinned (None: never pinned)."""
+    return None if _original_mask is None else set(_original_mask)
+
+
+def reset_worker_affinity(_worker_id: int = 0, mask: Optional[Set[int]] = None) -> None:
+    """``worker_init_fn`` for ``torch.utils.data.DataLoader``: worker processes are started from the pinned main thread and
+    would all sit on its complex.  Forked workers inherit this module's record of the original mask; spawned / fork-server
+    workers do not -- pass it explicitly (``functools.partial(reset_worker_affinity, mask=original_mask())``); without either
+    the allowed set of the cgroup (``Cpus_allowed_list`` of /proc/self/status) is taken."""
+    if not hasattr(os, "sched_setaffinity"):
+        return
+    target = mask if mask is not None else _original_mask
+    if target is None:
+        text = _read("/proc/self/status") or ""
+        for line in text.splitlines():
+            if line.startswith("Cpus_allowed_list:"):
+                target = set(_parse_cpu_list(line.split(":", 1)[1].strip()))
+    if target:
         try:
-            os.sched_setaffinity(0, _original_mask)
+            os.sched_setaffinity(0, target)
         except OSError:
             pass

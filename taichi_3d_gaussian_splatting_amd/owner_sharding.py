@@ -212,7 +212,7 @@ class OwnerShardedRasteriser:
         cap = int(guess[0]) if guess else 0
         shift2 = 2 * layout.bin_shift
         emit = bool(guess and need_state and self.backward_on_walked_lists and layout.filter != 0 and
-                    layout.bin_shift <= 2 and (max(cap, 1) << shift2) < 2 ** 31)
+                    hip_ops.can_emit_walked_lists(cap, layout.bin_shift))
         slab = Slab()
         slab.add("counters", 4 * hip_ops.NUM_COUNTERS)
         slab.add("ntiles", 4 * n_rec)
@@ -320,8 +320,8 @@ class OwnerShardedRasteriser:
             keys, payload = hip_ops.sort_pairs(keys, payload, depth_bits, tile_bits, kdb, in_place=False, ws=self._scratch)
             start, end = hip_ops.tile_ranges(keys, num_bins, kdb)
             del keys
-            emit = bool(need_state and self.backward_on_walked_lists and layout.filter != 0 and layout.bin_shift <= 2 and
-                        (max(payload.shape[0], 1) << shift2) < 2 ** 31)
+            emit = bool(need_state and self.backward_on_walked_lists and layout.filter != 0 and
+                        hip_ops.can_emit_walked_lists(payload.shape[0], layout.bin_shift))
             out = (image, depth,
                    slab.tensor("acc_alpha", torch.float32, (height, width)) if need_state else None,
                    slab.tensor("last_eff", torch.int32, (height, width)) if need_state else None, count)

@@ -164,6 +164,35 @@ def test_sparse_accumulator_exchange_world2_and_3():
         mp.spawn(_sparse_worker, args=(world, _free_port(), 1000), nprocs=world, join=True)
 
 
+def _dense_fallback_worker(rank, world, port, m):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from taichi_3d_gaussian_splatting_amd.distributed import exchange_accumulators_sparse
+    gens = [torch.Generator().manual_seed(700 + r) for r in range(world)]
+    accs = []
+    for r in range(world):   # every rank produced (nearly) every row: huge Gaussians / the stress distribution
+        a = torch.rand(m, 12, generator=gens[r])
+        a[:, 10] = torch.randint(0, 5000, (m,), generator=gens[r], dtype=torch.int32).view(torch.float32)
+        a[:, 11] = 0.0
+        accs.append(a)
+    stats = {}
+    got = exchange_accumulators_sparse(accs[rank].clone(), torch.ones(m, dtype=torch.int32), compact=_compact_stand_in,
+                                       merge=_merge_stand_in, stats=stats)
+    assert stats.get("dense_fallback") is True and stats["bytes_sent"] == 48 * m
+    expect = sum(a[:, :10].double() for a in accs)
+    assert torch.allclose(got[:, :10].double(), expect, rtol=1e-6, atol=1e-6)
+    assert torch.equal(got[:, 10].contiguous().view(torch.int32), sum(a[:, 10].contiguous().view(torch.int32) for a in accs))
+    dist.destroy_process_group()
+
+
+def test_sparse_exchange_falls_back_to_the_dense_all_reduce():
+    """When the ranks' lists together exceed 1.5 M rows (every rank met most Gaussians) the gathered lists would weigh
+    several times the dense array: one all-reduce instead, decided from the gathered counts (the same on every rank)."""
+    for world in (2, 3):
+        mp.spawn(_dense_fallback_worker, args=(world, _free_port(), 600), nprocs=world, join=True)
+
+
 def test_owned_rows_partition():
     from taichi_3d_gaussian_splatting_amd.distributed import band_boundaries, owned_tile_rows
     for th in (1, 5, 67):
