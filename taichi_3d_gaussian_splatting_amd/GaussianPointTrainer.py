@@ -139,6 +139,29 @@ def _image_grid(images, nrow: int = 2, pad: int = 2) -> torch.Tensor:
     return grid
 
 
+class _OwnerRasterisationFacade:
+    """The few attributes the training loop touches on its rasteriser, for the owner-sharded module (whose options live on
+    the rank's ``core``)."""
+
+    def __init__(self, module):
+        self.module, self.core = module, module.core
+
+    def __call__(self, input_data):
+        return self.module(input_data)
+
+    @property
+    def hook_feature_gradients(self):
+        return self.core.hook_feature_gradients
+
+    @hook_feature_gradients.setter
+    def hook_feature_gradients(self, value):
+        self.core.hook_feature_gradients = bool(value)
+
+    @property
+    def speculation_stats(self):
+        return self.core.speculation_stats
+
+
 class GaussianPointCloudTrainer:
     @dataclass
     class TrainConfig(YAMLConfig):
@@ -174,6 +197,12 @@ class GaussianPointCloudTrainer:
         # additions (not in the reference)
         num_data_loader_workers: int = 4
         seed: int = 0
+        # multi-GPU (torch.distributed initialised): "replicated" = every rank holds the whole point cloud and the rasteriser
+        # is sharded over tile rows (distributed.py; loss, optimiser and controller run replicated and bit-identical);
+        # "owner" = every rank OWNS a contiguous block of the point cloud -- its parameters, its Adam state, its share of
+        # the controller's work -- and the rasteriser routes projected records / accumulator rows between the ranks
+        # (owner_sharding.py): nothing per-Gaussian is replicated
+        distributed_mode: str = "replicated"
         cache_dataset_on_device: bool = True      # keep the decoded training images in HBM (DeviceResidentSamples)
         device_cache_max_gb: float = 128.0        # ... unless they would need more than this; then stream them
 
@@ -201,6 +230,22 @@ class GaussianPointCloudTrainer:
                 for t in (self.scene.point_cloud, self.scene.point_cloud_features, self.scene.point_invalid_mask,
                           self.scene.point_object_id):
                     torch.distributed.broadcast(t.data if isinstance(t, torch.nn.Parameter) else t, src=0)
+        self.owner_sharded = bool(torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1 and
+                                  config.distributed_mode == "owner")
+        if config.distributed_mode not in ("replicated", "owner"):
+            raise ValueError(f"distributed_mode {config.distributed_mode!r}: 'replicated' or 'owner'")
+        if self.owner_sharded:
+            # this rank keeps ITS block of the (fixed-capacity) point cloud: parameters, mask, ids -- and with them the
+            # optimiser state and the controller's statistics, which are created from these tensors below
+            from .owner_sharding import owned_point_rows
+            world = torch.distributed.get_world_size()
+            block = owned_point_rows(self.scene.point_cloud.shape[0], self.rank, world)
+            rows = slice(block.start, block.stop)
+            with torch.no_grad():
+                self.scene.point_cloud = torch.nn.Parameter(self.scene.point_cloud.detach()[rows].clone())
+                self.scene.point_cloud_features = torch.nn.Parameter(self.scene.point_cloud_features.detach()[rows].clone())
+                self.scene.point_invalid_mask = self.scene.point_invalid_mask[rows].clone()
+                self.scene.point_object_id = self.scene.point_object_id[rows].clone()
         self.adaptive_controller = GaussianPointAdaptiveController(
             config=config.adaptive_controller_config,
             maintained_parameters=GaussianPointAdaptiveController.GaussianPointAdaptiveControllerMaintainedParameters(
@@ -208,11 +253,17 @@ class GaussianPointCloudTrainer:
                 pointcloud_features=self.scene.point_cloud_features,
                 point_invalid_mask=self.scene.point_invalid_mask,
                 point_object_id=self.scene.point_object_id))
-        self.rasterisation = GaussianPointCloudRasterisation(
-            config=config.rasterisation_config, backward_valid_point_hook=self.adaptive_controller.update)
-        if torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
-            from .distributed import shard_rasteriser_across_tile_rows
-            shard_rasteriser_across_tile_rows(self.rasterisation)
+        if self.owner_sharded:
+            from .owner_sharding import OwnerShardedRasterisation
+            module = OwnerShardedRasterisation(config.rasterisation_config,
+                                               backward_valid_point_hook=self.adaptive_controller.update)
+            self.rasterisation = _OwnerRasterisationFacade(module)
+        else:
+            self.rasterisation = GaussianPointCloudRasterisation(
+                config=config.rasterisation_config, backward_valid_point_hook=self.adaptive_controller.update)
+            if torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
+                from .distributed import shard_rasteriser_across_tile_rows
+                shard_rasteriser_across_tile_rows(self.rasterisation)
         self.loss_function = LossFunction(config=config.loss_function_config)
         self.best_psnr_score = 0.0
 
@@ -258,6 +309,38 @@ class GaussianPointCloudTrainer:
             point_cloud=scene.point_cloud, point_cloud_features=scene.point_cloud_features,
             point_object_id=scene.point_object_id, point_invalid_mask=scene.point_invalid_mask,
             camera_info=info, q_pointcloud_camera=q, t_pointcloud_camera=t, color_max_sh_band=band))
+
+    def _whole_scene(self):
+        """The scene to checkpoint: this rank's own when nothing is sharded; under owner sharding rank 0 receives every
+        rank's block (fixed capacity, so equal sizes up to the last block: padded with invalid rows) and assembles them."""
+        if not self.owner_sharded:
+            return self.scene
+        import torch.distributed as dist
+        world = dist.get_world_size()
+        n = torch.tensor([self.scene.point_cloud.shape[0]], dtype=torch.int64, device=self.device)
+        sizes = [torch.zeros_like(n) for _ in range(world)]
+        dist.all_gather(sizes, n)
+        cap = int(max(int(x) for x in sizes))
+
+        def padded(t, fill):
+            out = torch.full((cap,) + tuple(t.shape[1:]), fill, dtype=t.dtype, device=self.device)
+            out[:t.shape[0]] = t.detach()
+            return out
+
+        parts = [padded(self.scene.point_cloud, 0.0), padded(self.scene.point_cloud_features, 0.0),
+                 padded(self.scene.point_invalid_mask, 1), padded(self.scene.point_object_id, 0)]
+        gathered = []
+        for t in parts:
+            buf = [torch.empty_like(t) for _ in range(world)] if self.rank == 0 else None
+            dist.gather(t, buf, dst=0)
+            gathered.append(buf)
+        if self.rank != 0:
+            return None
+        import types
+        whole = types.SimpleNamespace(point_cloud=torch.cat(gathered[0]), point_cloud_features=torch.cat(gathered[1]),
+                                      point_invalid_mask=torch.cat(gathered[2]), point_object_id=torch.cat(gathered[3]))
+        whole.to_parquet = lambda path: GaussianPointCloudScene.to_parquet(whole, path)   # (reads exactly these tensors)
+        return whole
 
     def _scalar(self, tag: str, value: float, step: int, console_key: Optional[str] = None) -> None:
         if self.writer is not None:
@@ -437,9 +520,10 @@ class GaussianPointCloudTrainer:
         for tag, key, console in (("val/loss", "loss", "val_loss"), ("val/psnr", "psnr", "val_psnr"),
                                   ("val/ssim", "ssim", "val_ssim"), ("val/inference_time", "ms", "val_inference_time")):
             self._scalar(tag, mean[key], iteration, console)
+        scene = self._whole_scene()     # (owner-sharded: the ranks' blocks, gathered on rank 0; a collective)
         if self.rank == 0:
-            self.scene.to_parquet(os.path.join(self.config.output_model_dir, f"scene_{iteration}.parquet"))
+            scene.to_parquet(os.path.join(self.config.output_model_dir, f"scene_{iteration}.parquet"))
             if mean["psnr"] > self.best_psnr_score:
-                self.scene.to_parquet(os.path.join(self.config.output_model_dir, "best_scene.parquet"))
+                scene.to_parquet(os.path.join(self.config.output_model_dir, "best_scene.parquet"))
         self.best_psnr_score = max(self.best_psnr_score, mean["psnr"])
         return mean

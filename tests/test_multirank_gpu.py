@@ -137,6 +137,56 @@ def test_trainer_replicated_state_stays_identical_across_ranks(tmp_path):
     mp.spawn(_train_worker, args=(2, _free_port(), root), nprocs=2, join=True)
 
 
+def _owner_train_worker(rank, world, port, root):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import pandas as pd
+        from taichi_3d_gaussian_splatting_amd.GaussianPointTrainer import GaussianPointCloudTrainer as TRN
+        cfg = TRN.TrainConfig(
+            train_dataset_json_path=os.path.join(root, "train.json"), val_dataset_json_path=os.path.join(root, "val.json"),
+            pointcloud_parquet_path=os.path.join(root, "points.parquet"), num_iterations=61, val_interval=60,
+            feature_learning_rate=5e-3, position_learning_rate=5e-5, initial_downsample_factor=2,
+            half_downsample_factor_interval=30, log_loss_interval=10, log_metrics_interval=10 ** 6,
+            log_image_interval=10 ** 6, log_validation_image=False,
+            summary_writer_log_dir=os.path.join(root, f"owner_logs_rank{rank}"), num_data_loader_workers=0,
+            distributed_mode="owner")
+        cfg.adaptive_controller_config.num_iterations_warm_up = 20      # densify at 20 and 40
+        cfg.adaptive_controller_config.num_iterations_densify = 20
+        cfg.gaussian_point_cloud_scene_config.max_num_points_ratio = 2.0
+        cfg.gaussian_point_cloud_scene_config.initial_alpha = 0.5
+        trainer = TRN(cfg)
+        assert trainer.owner_sharded
+        capacity = trainer.scene.point_cloud.shape[0]
+        total = torch.tensor([capacity], device="cuda")
+        dist.all_reduce(total)
+        n_before = int((trainer.scene.point_invalid_mask == 0).sum())
+        first = trainer.scene.point_cloud_features.detach().clone()
+        trainer.train()
+        live = trainer.scene.point_invalid_mask == 0
+        assert trainer.scene.point_cloud.shape[0] == capacity            # the rank still holds its block, nothing more
+        assert int(live.sum()) != n_before                               # its share of the controller's work happened
+        assert not torch.equal(first, trainer.scene.point_cloud_features.detach())   # its parameters were stepped
+        assert torch.isfinite(trainer.scene.point_cloud.detach()[live]).all()
+        live_all = torch.tensor([int(live.sum())], device="cuda")
+        dist.all_reduce(live_all)
+        if rank == 0:   # the validation checkpoint holds the blocks of ALL ranks
+            df = pd.read_parquet(os.path.join(root, f"owner_logs_rank0", "scene_60.parquet"))
+            assert abs(len(df) - int(live_all)) <= int(0.2 * int(live_all)) and len(df) > int(live.sum())
+    finally:
+        dist.destroy_process_group()
+
+
+def test_trainer_with_owner_sharded_gaussians(tmp_path):
+    """The training loop on the owner-sharded rasteriser (TrainConfig.distributed_mode = "owner"): two ranks share the GPU,
+    each owns half of the fixed-capacity point cloud -- parameters, Adam state, controller statistics -- trains through two
+    densifications and a validation, and rank 0's checkpoint holds both halves."""
+    from tests.test_training_gpu import _write_dataset
+    root = str(tmp_path)
+    _write_dataset(root, torch.device("cuda:0"))
+    mp.spawn(_owner_train_worker, args=(2, _free_port(), root), nprocs=2, join=True)
+
+
 def test_bench_launches_its_own_ranks_owner_sharded(tmp_path):
     """`python bench.py --gpus 2` with NO launcher (how the driver may call it): bench.py re-runs itself under
     torch.distributed.run, one process per rank (gloo here: the box has one GPU, RCCL refuses two ranks on one device), in
