@@ -237,10 +237,15 @@ class GaussianPointCloudTrainer:
         if self.owner_sharded:
             # this rank keeps ITS block of the (fixed-capacity) point cloud: parameters, mask, ids -- and with them the
             # optimiser state and the controller's statistics, which are created from these tensors below
+            # (the live points sit at the front of the fixed-capacity tensors: the rank takes its contiguous share of the
+            #  LIVE rows and of the free rows, not a block of the capacity -- else the last ranks would own empty rows only)
             from .owner_sharding import owned_point_rows
             world = torch.distributed.get_world_size()
-            block = owned_point_rows(self.scene.point_cloud.shape[0], self.rank, world)
-            rows = slice(block.start, block.stop)
+            live_rows = torch.nonzero(self.scene.point_invalid_mask == 0).flatten()
+            free_rows = torch.nonzero(self.scene.point_invalid_mask != 0).flatten()
+            mine_live = owned_point_rows(live_rows.shape[0], self.rank, world)
+            mine_free = owned_point_rows(free_rows.shape[0], self.rank, world)
+            rows = torch.cat([live_rows[mine_live.start:mine_live.stop], free_rows[mine_free.start:mine_free.stop]])
             with torch.no_grad():
                 self.scene.point_cloud = torch.nn.Parameter(self.scene.point_cloud.detach()[rows].clone())
                 self.scene.point_cloud_features = torch.nn.Parameter(self.scene.point_cloud_features.detach()[rows].clone())
