@@ -27,7 +27,9 @@ def main() -> None:
     src = ap.add_mutually_exclusive_group(required=True)
     src.add_argument("--ply", help="3DGS-format PLY (official implementation / to_ply)")
     src.add_argument("--parquet", help="scene parquet written by the trainer")
-    src.add_argument("--synthetic", choices=sorted(CONFIGS), help="seeded synthetic workload, single pose")
+    src.add_argument("--synthetic", choices=sorted(CONFIGS) + ["stress_t_ras", "trained_1080p"],
+                     help="seeded synthetic workload, single pose; trained_1080p: the scene grown by the repository's own "
+                          "trainer (trained_workload.py), cycled through its thirty training / validation cameras")
     ap.add_argument("--dataset", help="dataset JSON whose poses / intrinsics are cycled (required with --ply/--parquet)")
     ap.add_argument("--iterations", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=1000)
@@ -42,9 +44,11 @@ def main() -> None:
     if args.synthetic:
         s = make_config_scene(args.synthetic).to(dev)
         xyz, feat, invalid, obj = s.point_cloud, s.point_cloud_features, s.point_invalid_mask, s.point_object_id
-        views = [(s.q_pointcloud_camera, s.t_pointcloud_camera,
-                  CameraInfo(camera_intrinsics=s.camera_intrinsics, camera_height=s.height, camera_width=s.width,
-                             camera_id=0))]
+        cam = CameraInfo(camera_intrinsics=s.camera_intrinsics, camera_height=s.height, camera_width=s.width, camera_id=0)
+        views = [(s.q_pointcloud_camera, s.t_pointcloud_camera, cam)]
+        if args.synthetic == "trained_1080p":   # the reference's protocol cycles the data set's poses (BENCH:109-160)
+            from taichi_3d_gaussian_splatting_amd.trained_workload import load_or_make
+            views = [(q.to(dev), t.to(dev), cam) for q, t in load_or_make("trained_1080p")["poses"]]
     else:
         if not args.dataset:
             ap.error("--dataset is required with --ply / --parquet")

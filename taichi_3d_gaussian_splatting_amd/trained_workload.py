@@ -147,7 +147,7 @@ def make_trained_scene(min_points: int = 300_000, width: int = WIDTH, height: in
         anisotropy_p99=float((scales.max(dim=1).values / scales.min(dim=1).values).quantile(0.99)),
         opacity_median=float(torch.sigmoid(feat[:, 7]).median()), true_gaussians=n_true, views=n_views,
         speculation=dict(trainer.rasterisation.speculation_stats))
-    return {"scene": out, "stats": stats}
+    return {"scene": out, "stats": stats, "poses": [(q.cpu(), t.cpu()) for q, t in poses]}
 
 
 def load_or_make(tag: str = "trained_1080p", **kwargs) -> dict:
