@@ -9,7 +9,7 @@ mkdir -p $OUT
 for spec in "$@"; do
     tag=${spec%%:*}; flags=${spec#*:}
     tmp=$(mktemp -d)
-    for f in gs_api gs_frontend gs_sort gs_blend gs_shard gs_point_backward gs_controller gs_loss gs_optim; do
+    for f in gs_api gs_frame gs_frontend gs_sort gs_blend gs_shard gs_point_backward gs_controller gs_loss gs_optim; do
         extra="$flags"   # (macros are file-specific: GS_GROUP_*, GS_RP_* in gs_blend, GS_SORT_* in gs_sort, ...)
         /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -fPIC -munsafe-fp-atomics -Wno-unused-function $extra -c $SRC/$f.hip -o $tmp/$f.o &
     done
