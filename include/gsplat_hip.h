@@ -125,6 +125,23 @@ int gs_preprocess(const float *xyz, float *features, const int32_t *object_id,
                   int32_t *num_overlap_tiles, int32_t *num_keys, int32_t *block_sums,
                   int32_t *block_sums_full, void *stream);
 
+/* The same projection with the colour LEFT OUT (row 2 of a record = 0, 0, 0, opacity), and the colours on their own:
+ * gs_view_colours writes floats 8..10 of the records of the Gaussians with num_keys > 0 (RAS:280-282,302-310) -- the same
+ * device code as inside gs_preprocess, bit-identical records from either way.  Nothing between projection and blend reads
+ * a colour, so gs_frame_forward runs gs_view_colours on a second stream beside key generation, sort and ranges
+ * (GS_FWD_COLOUR_ASYNC): a streaming pass over 192 B per Gaussian next to latency-bound launches. */
+int gs_preprocess_geometry(const float *xyz, float *features, const int32_t *object_id,
+                  const float *intrinsics, const float *q_camera_pointcloud,
+                  const float *t_camera_pointcloud, const int32_t *ids, int n_visible,
+                  int n_visible_on_device, int width, int height, int tile_row_begin,
+                  int tile_row_step, int tile_row_end, int bin_shift, int exact_tile_cull,
+                  int always_store_rotation, float depth_scale, int32_t *counters, float *attrs,
+                  int32_t *num_overlap_tiles, int32_t *num_keys, int32_t *block_sums,
+                  int32_t *block_sums_full, void *stream);
+int gs_view_colours(const float *xyz, const float *features, const int32_t *object_id, const float *q_camera_pointcloud,
+                    const float *t_camera_pointcloud, const int32_t *ids, int n_visible, int n_visible_on_device,
+                    const int32_t *counters, const int32_t *num_keys, float *attrs, void *stream);
+
 /* Exclusive scan of per-block sums (in place) and total -> counters[counter_slot]
  * (GS_COUNTER_NUM_KEYS for block_sums, GS_COUNTER_NUM_SLOTS for block_sums_full).
  * Replaces torch.cumsum/cat, RAS:913-922. */
@@ -403,6 +420,10 @@ int gs_point_backward(const float *xyz, const float *features, const int32_t *ob
 #define GS_FWD_SORT           (1u << 9)   /* gs_sort_pairs_and_zero             RAS:947-950                     */
 #define GS_FWD_RANGES         (1u << 10)  /* gs_tile_ranges                     RAS:175-193                     */
 #define GS_FWD_BLEND          (1u << 11)  /* gs_blend_forward                   RAS:318-485                     */
+#define GS_FWD_COLOUR_ASYNC   (1u << 12)  /* with GS_FWD_PREPROCESS: gs_preprocess_geometry on the stream, gs_view_colours on
+                                           * aux_stream (forked / joined through the two aux events) beside the list
+                                           * stages; the stream waits for the colours before the blend (or before
+                                           * returning).  Ignored when aux_stream is NULL.                        */
 #define GS_BWD_BLEND          (1u << 0)   /* gs_blend_backward                  RAS:531-705                     */
 #define GS_BWD_REDUCE         (1u << 1)   /* gs_reduce_partials                 (the sums of RAS:674-696)       */
 #define GS_BWD_GATHER_RETURNED (1u << 2)  /* gs_gather_returned_rows (owner-sharded)                            */
@@ -443,6 +464,8 @@ typedef struct GsFrame {
     const float *grad_image; float *partials; uint8_t *slot_flags; float *magnitude_image; int32_t *tile_order_backward;
     float *acc; const float *returned_rows;
     float *grad_xyz, *grad_features, *grad_xyz_visible, *grad_features_visible, *hook_compact;
+    /* GS_FWD_COLOUR_ASYNC: a second stream of the same device and two events, all created by the caller */
+    void *aux_stream, *aux_event_fork, *aux_event_join;
 } GsFrame;
 size_t gs_frame_struct_bytes(void);   /* sizeof(GsFrame): a binding checks its mirror of the struct against it */
 int gs_frame_forward(GsFrame *frame, uint32_t stages, void *stream);

@@ -190,6 +190,13 @@ class GaussianPointCloudRasterisation(torch.nn.Module):
         # band): the forward pass leaves per-pixel boundary states every 128 list entries and the backward pass gives a
         # tile up to four workgroups (include/gsplat_hip.h "List splitting").  Same slot records up to rounding
         self.split_small_grid_backward = True
+        # per-pass entry points only: the colours of the visible Gaussians (RAS:280-282,302-310 -- a streaming read of the
+        # 192 B of SH coefficients each) evaluated on a second stream BESIDE key generation, sort and ranges, which do not
+        # read them; the blend waits for them.  Same device code as inside gs_preprocess: the same bits (tested).  MEASURED
+        # SLOWER (headline 1.083 -> 1.098 ms, trained scene 0.808 -> 0.819, cfg 1 0.242 -> 0.252: the fork / join through
+        # two events costs ~10 us on this runtime and the list stages slow down by what the colours save), so off
+        self.colours_beside_list_stages = False
+        self._aux_streams = {}   # device -> (second stream, fork event, join event)
         self._scratch = hip_ops.Workspaces()   # buffers that do not outlive a call, kept between frames
         self._size_guesses, self._readbacks = {}, {}   # (image size, list layout, planes) -> (key capacity, depth bound)
         self.speculation_stats = {"frames": 0, "redone": 0}

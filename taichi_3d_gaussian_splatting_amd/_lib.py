@@ -17,7 +17,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # GS_LIB_PATH: development knob (tuning sweeps load differently built variants of the library); default = in-tree build
 LIB_PATH = os.environ.get("GS_LIB_PATH") or os.path.join(_HERE, "libgsplat_hip.so")
-ABI_VERSION = 30
+ABI_VERSION = 31
 
 _c = ctypes
 _P = _c.c_void_p
@@ -35,6 +35,9 @@ _SIGNATURES = {
     "gs_filter_compact_from_poses": (_I, [_P, _P, _P, _P, _P, _P, _I, _P, _P, _I, _F, _F, _I, _I, _P, _P, _P, _P, _P]),
     "gs_read_counters": (_I, [_P, _P, _I, _P]),
     "gs_preprocess": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _P, _P, _P, _P, _P, _P, _P]),
+    "gs_preprocess_geometry": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _P, _P, _P, _P, _P, _P,
+                                    _P]),
+    "gs_view_colours": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P]),
     "gs_scan_block_sums": (_I, [_P, _I, _P, _I, _P]),
     "gs_scan_block_sums2": (_I, [_P, _P, _I, _P, _P]),
     "gs_scan_block_sums2_to_host": (_I, [_P, _P, _I, _P, _P, _P]),

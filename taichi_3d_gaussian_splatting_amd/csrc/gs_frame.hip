@@ -10,12 +10,8 @@
         if (_rc < 0) return _rc;  \
     } while (0)
 
-extern "C" {
-
-size_t gs_frame_struct_bytes(void) { return sizeof(GsFrame); }
-
-int gs_frame_forward(GsFrame *f, uint32_t stages, void *stream) {
-    GS_REQUIRE(f != nullptr, "frame");
+// the forward stages; *colours_pending: work forked to f->aux_stream that `stream` has not waited for yet
+static int frame_forward_stages(GsFrame *f, uint32_t stages, void *stream, bool *colours_pending) {
     const int filter = f->bin_shift == 0 ? 0 : (GS_FILTER_BOX | (f->exact_tile_cull ? GS_FILTER_CULL : 0));
     if ((stages & GS_FWD_POSE_INVERSE) && (stages & GS_FWD_FILTER_COMPACT)) {   // the filter inverts the poses itself
         GS_STAGE(gs_filter_compact_from_poses(f->xyz, f->invalid_mask, f->object_id, f->intrinsics, f->q_pointcloud_camera,
@@ -31,12 +27,35 @@ int gs_frame_forward(GsFrame *f, uint32_t stages, void *stream) {
                                        f->t_camera_pointcloud, f->n_points, f->near_plane, f->far_plane, f->width,
                                        f->height, f->visible_mask, f->ids, f->counters, f->filter_workspace, stream));
     }
-    if (stages & GS_FWD_PREPROCESS)   // launched for the capacity n_points; M is read from the counters on the device
-        GS_STAGE(gs_preprocess(f->xyz, f->features, f->object_id, f->intrinsics, f->q_camera_pointcloud,
-                               f->t_camera_pointcloud, f->ids, f->n_points, 1, f->width, f->height, f->tile_row_begin,
-                               f->tile_row_step, f->tile_row_end, f->bin_shift, f->exact_tile_cull, f->always_store_rotation,
-                               f->depth_scale, f->counters, f->attrs, f->num_overlap_tiles, f->num_keys, f->block_sums,
-                               f->block_sums_full, stream));
+    // GS_FWD_COLOUR_ASYNC: the colours leave the projection and run on the caller's second stream beside the list stages
+    // (nothing before the blend reads them); GS_COLOUR_ASYNC=0 switches it off for A/B measurements
+    static const bool colour_async_allowed = !(getenv("GS_COLOUR_ASYNC") && atoi(getenv("GS_COLOUR_ASYNC")) == 0);
+    const bool colour_async = colour_async_allowed && (stages & GS_FWD_PREPROCESS) && (stages & GS_FWD_COLOUR_ASYNC) &&
+                              f->aux_stream != nullptr && f->aux_event_fork != nullptr && f->aux_event_join != nullptr;
+    if (stages & GS_FWD_PREPROCESS) {   // launched for the capacity n_points; M is read from the counters on the device
+        GS_STAGE((colour_async ? gs_preprocess_geometry : gs_preprocess)(
+            f->xyz, f->features, f->object_id, f->intrinsics, f->q_camera_pointcloud, f->t_camera_pointcloud, f->ids,
+            f->n_points, 1, f->width, f->height, f->tile_row_begin, f->tile_row_step, f->tile_row_end, f->bin_shift,
+            f->exact_tile_cull, f->always_store_rotation, f->depth_scale, f->counters, f->attrs, f->num_overlap_tiles,
+            f->num_keys, f->block_sums, f->block_sums_full, stream));
+        if (colour_async) {
+            GS_CHECK_HIP(hipEventRecord((hipEvent_t)f->aux_event_fork, (hipStream_t)stream));
+            GS_CHECK_HIP(hipStreamWaitEvent((hipStream_t)f->aux_stream, (hipEvent_t)f->aux_event_fork, 0));
+            const int rc = gs_view_colours(f->xyz, f->features, f->object_id, f->q_camera_pointcloud, f->t_camera_pointcloud,
+                                           f->ids, f->n_points, 1, f->counters, f->num_keys, f->attrs, f->aux_stream);
+            GS_CHECK_HIP(hipEventRecord((hipEvent_t)f->aux_event_join, (hipStream_t)f->aux_stream));
+            *colours_pending = true;   // (joined by the caller of this function whatever happens below)
+            if (rc < 0) return rc;
+        }
+    }
+#define GS_JOIN_COLOURS()                                                                                   \
+    do {                                                                                                    \
+        if (*colours_pending) {                                                                             \
+            *colours_pending = false;                                                                       \
+            GS_CHECK_HIP(hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)f->aux_event_join, 0));       \
+        }                                                                                                   \
+    } while (0)
+    if (stages & (GS_FWD_ROUTE_COUNT | GS_FWD_ROUTE_SCATTER)) GS_JOIN_COLOURS();   // the routed records carry colours
     if (stages & GS_FWD_ROUTE_COUNT)
         GS_STAGE(gs_route_count(f->attrs, f->num_keys, f->n_points, f->counters, f->width, f->height, f->rows_per_band,
                                 f->world, f->route_counts, f->route_workspace, stream));
@@ -88,6 +107,7 @@ int gs_frame_forward(GsFrame *f, uint32_t stages, void *stream) {
     if (stages & GS_FWD_RANGES)
         GS_STAGE(gs_tile_ranges_prezeroed(keys_sorted, f->n_keys_capacity, n_keys_device, f->key_depth_bits, f->bin_ranges,
                                           f->bin_ranges + f->n_bins, f->n_bins, (stages & GS_FWD_SORT) ? 1 : 0, stream));
+    GS_JOIN_COLOURS();
     if (stages & GS_FWD_BLEND)
         GS_STAGE(gs_blend_forward_with_boundaries(
             f->bin_ranges, f->bin_ranges + f->n_bins, payload_sorted, attrs, f->width, f->height, f->tile_row_begin,
@@ -95,6 +115,20 @@ int gs_frame_forward(GsFrame *f, uint32_t stages, void *stream) {
             f->valid_count, f->blend_flags, nullptr, f->tile_order, f->tile_work, f->walked_list, f->walked_start,
             f->boundary_states, f->n_keys_capacity, stream));
     return 0;
+}
+#undef GS_JOIN_COLOURS
+
+extern "C" {
+
+size_t gs_frame_struct_bytes(void) { return sizeof(GsFrame); }
+
+int gs_frame_forward(GsFrame *f, uint32_t stages, void *stream) {
+    GS_REQUIRE(f != nullptr, "frame");
+    bool colours_pending = false;
+    const int rc = frame_forward_stages(f, stages, stream, &colours_pending);
+    // the caller's stream never runs ahead of work this call forked, error or not
+    if (colours_pending) GS_CHECK_HIP(hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)f->aux_event_join, 0));
+    return rc;
 }
 
 int gs_frame_backward(GsFrame *f, uint32_t stages, void *stream) {

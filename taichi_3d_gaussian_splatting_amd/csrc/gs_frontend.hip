@@ -396,11 +396,68 @@ __global__ __launch_bounds__(GS_BLOCK) void compact_kernel(const int8_t *__restr
     if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) *total_out = running;
 }
 
+// The colours of a wave's Gaussians (RAS:280-282,302-310; ray origin = (-R^T) t, UTL:495-510), wave-convergent.  The 192 B
+// of SH coefficients are read COOPERATIVELY: every lane leaves the sixteen basis values of its Gaussian in LDS (Yw: 64 x
+// 16 floats of this wave), then sixteen lanes serve one Gaussian -- twelve of them load one 16-byte quarter of a colour
+// channel each (one coalesced 192-byte read per Gaussian, four Gaussians per load instruction) and form that quarter's
+// part of SH . Y, two exchanges add the quarters in the tree of gs_view_colour, the sigmoid follows.  (One lane gathering
+// its own row with twelve scattered 16-byte loads kept 64 partially used lines per instruction in flight: 1.64x the
+// algorithmic HBM bytes, round 3.)  Shared by gs_preprocess and gs_view_colours: the same bits from either.
+__device__ __forceinline__ void gs_wave_view_colours(bool wants, int id, const float *__restrict__ xyz,
+                                                     const float *__restrict__ feat, const int32_t *__restrict__ obj,
+                                                     const float *__restrict__ q_cp, const float *__restrict__ t_cp,
+                                                     float *Yw, float rgb[3]) {
+    const unsigned long long need = __builtin_amdgcn_ballot_w64(wants);
+    if (need == 0ull) return;   // wave-uniform
+    const int lane = gs_lane();
+    __builtin_amdgcn_wave_barrier();
+    if (wants) {
+        const int o = obj[id];
+        const Mat3 W = rotmat_from_q(q_cp[4 * o], q_cp[4 * o + 1], q_cp[4 * o + 2], q_cp[4 * o + 3]);
+        const float t[3] = {t_cp[3 * o], t_cp[3 * o + 1], t_cp[3 * o + 2]};
+        const float p[3] = {xyz[3 * (size_t)id], xyz[3 * (size_t)id + 1], xyz[3 * (size_t)id + 2]};
+        float Y[16];
+        gs_view_basis(W.m, t, p, Y);
+        float4 *dst = reinterpret_cast<float4 *>(Yw + 16 * lane);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) dst[k] = make_float4(Y[4 * k], Y[4 * k + 1], Y[4 * k + 2], Y[4 * k + 3]);
+    }
+    __builtin_amdgcn_wave_barrier();
+    const int sub = lane & 15, quarter = sub & 3;
+    constexpr int IN_FLIGHT = 8;   // Gaussians-of-a-group whose coefficient loads are in flight together
+#pragma unroll
+    for (int it0 = 0; it0 < 16; it0 += IN_FLIGHT) {
+        float4 c4[IN_FLIGHT];
+#pragma unroll
+        for (int k = 0; k < IN_FLIGHT; ++k) {
+            const int g = (it0 + k) * 4 + (lane >> 4);                 // the Gaussian (lane of this wave) served
+            const int gid = __shfl(id, g, GS_WAVE);
+            const bool on = ((need >> g) & 1ull) != 0ull && sub < 12;
+            c4[k] = on ? reinterpret_cast<const float4 *>(feat + (size_t)GS_FEATURE_DIM * gid)[2 + sub]
+                       : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int k = 0; k < IN_FLIGHT; ++k) {
+            const int g = (it0 + k) * 4 + (lane >> 4);
+            const float4 y = reinterpret_cast<const float4 *>(Yw + 16 * g)[quarter];
+            const float part = gs_sh_quarter(c4[k].x, c4[k].y, c4[k].z, c4[k].w, y.x, y.y, y.z, y.w);
+            const float pair = part + __shfl_xor(part, 1, GS_WAVE);    // q0 + q1 | q2 + q3
+            const float sum = pair + __shfl_xor(pair, 2, GS_WAVE);     // (q0 + q1) + (q2 + q3)
+            const float colour = gs_colour_from_sum(sum);
+            // the channel's first lane leaves the colour in the (now consumed) basis slot of the Gaussian
+            if (quarter == 0 && sub < 12 && ((need >> g) & 1ull) != 0ull) Yw[16 * g + (sub >> 2)] = colour;
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (wants) { rgb[0] = Yw[16 * lane]; rgb[1] = Yw[16 * lane + 1]; rgb[2] = Yw[16 * lane + 2]; }
+}
+
 // ------------------------------------------------------------------ per-visible-point projection
 // RAS:239-315 generate_point_attributes_in_camera_plane + RAS:106-128 generate_num_overlap_tiles.
 // One lane per visible point; the 224-B feature row is read as 14 x 16-B loads (the lines are reused by
 // the 14 loads out of L1; measured: the kernel is bound by its ~2.7 k VALU instructions per wave -- IEEE
 // divisions, expf, the cull loop -- and an LDS-staged coalesced gather was 6 % slower: lower occupancy).
+template <bool COLOUR>
 __global__ __launch_bounds__(GS_BLOCK) void preprocess_kernel(
     const float *__restrict__ xyz, float *__restrict__ feat, const int32_t *__restrict__ obj,
     const float *__restrict__ Kmat, const float *__restrict__ q_cp, const float *__restrict__ t_cp,
@@ -528,63 +585,13 @@ __global__ __launch_bounds__(GS_BLOCK) void preprocess_kernel(
             owned = cnts[gs_lane()];
         }
     }
-    // Colour (RAS:280-282,302-310; ray origin = (-R^T) t, UTL:495-510) -- only for Gaussians that emit at least one key on
-    // this GPU: nothing else is ever gathered by the blend kernels (tile-row sharding: most Gaussians touch the rows of one
-    // or two of the G GPUs).  The 192 B of SH coefficients are read COOPERATIVELY: every lane leaves the sixteen basis
-    // values of its Gaussian in LDS (the wave's slice of s_rec, free after the key count), then sixteen lanes serve one
-    // Gaussian -- twelve of them load one 16-byte quarter of a colour channel each (one coalesced 192-byte read per
-    // Gaussian, four Gaussians per load instruction) and form that quarter's part of SH . Y, two exchanges add the quarters
-    // in the tree of gs_view_colour, the sigmoid follows.  (One lane gathering its own row with twelve scattered 16-byte
-    // loads kept 64 partially used lines per instruction in flight: 1.64x the algorithmic HBM bytes, round 3.)
+    // Colour -- only for Gaussians that emit at least one key on this GPU: nothing else is ever gathered by the blend
+    // kernels (tile-row sharding: most Gaussians touch the rows of one or two of the G GPUs).  The basis values go through
+    // the wave's slice of s_rec, free after the key count.
     float rgb[3] = {0.f, 0.f, 0.f};
-    {
-        const bool wants = live && owned > 0;
-        const unsigned long long need = __builtin_amdgcn_ballot_w64(wants);
-        if (need != 0ull) {   // wave-uniform
-            float *Yw = reinterpret_cast<float *>(s_rec + (threadIdx.x & ~(GS_WAVE - 1)));   // 64 x 16 floats of this wave
-            const int lane = gs_lane();
-            __builtin_amdgcn_wave_barrier();
-            if (wants) {
-                const int o = obj[id];
-                const Mat3 W = rotmat_from_q(q_cp[4 * o], q_cp[4 * o + 1], q_cp[4 * o + 2], q_cp[4 * o + 3]);
-                const float t[3] = {t_cp[3 * o], t_cp[3 * o + 1], t_cp[3 * o + 2]};
-                const float p[3] = {xyz[3 * (size_t)id], xyz[3 * (size_t)id + 1], xyz[3 * (size_t)id + 2]};
-                float Y[16];
-                gs_view_basis(W.m, t, p, Y);
-                float4 *dst = reinterpret_cast<float4 *>(Yw + 16 * lane);
-#pragma unroll
-                for (int k = 0; k < 4; ++k) dst[k] = make_float4(Y[4 * k], Y[4 * k + 1], Y[4 * k + 2], Y[4 * k + 3]);
-            }
-            __builtin_amdgcn_wave_barrier();
-            const int sub = lane & 15, quarter = sub & 3;
-            constexpr int IN_FLIGHT = 8;   // Gaussians-of-a-group whose coefficient loads are in flight together
-#pragma unroll
-            for (int it0 = 0; it0 < 16; it0 += IN_FLIGHT) {
-                float4 c4[IN_FLIGHT];
-#pragma unroll
-                for (int k = 0; k < IN_FLIGHT; ++k) {
-                    const int g = (it0 + k) * 4 + (lane >> 4);                 // the Gaussian (lane of this wave) served
-                    const int gid = __shfl(id, g, GS_WAVE);
-                    const bool on = ((need >> g) & 1ull) != 0ull && sub < 12;
-                    c4[k] = on ? reinterpret_cast<const float4 *>(feat + (size_t)GS_FEATURE_DIM * gid)[2 + sub]
-                               : make_float4(0.f, 0.f, 0.f, 0.f);
-                }
-#pragma unroll
-                for (int k = 0; k < IN_FLIGHT; ++k) {
-                    const int g = (it0 + k) * 4 + (lane >> 4);
-                    const float4 y = reinterpret_cast<const float4 *>(Yw + 16 * g)[quarter];
-                    const float part = gs_sh_quarter(c4[k].x, c4[k].y, c4[k].z, c4[k].w, y.x, y.y, y.z, y.w);
-                    const float pair = part + __shfl_xor(part, 1, GS_WAVE);    // q0 + q1 | q2 + q3
-                    const float sum = pair + __shfl_xor(pair, 2, GS_WAVE);     // (q0 + q1) + (q2 + q3)
-                    const float colour = gs_colour_from_sum(sum);
-                    // the channel's first lane leaves the colour in the (now consumed) basis slot of the Gaussian
-                    if (quarter == 0 && sub < 12 && ((need >> g) & 1ull) != 0ull) Yw[16 * g + (sub >> 2)] = colour;
-                }
-            }
-            __builtin_amdgcn_wave_barrier();
-            if (wants) { rgb[0] = Yw[16 * lane]; rgb[1] = Yw[16 * lane + 1]; rgb[2] = Yw[16 * lane + 2]; }
-        }
-    }
+    if (COLOUR)   // (else: gs_view_colours fills rgb in behind this kernel, beside the list stages)
+        gs_wave_view_colours(live && owned > 0, id, xyz, feat, obj, q_cp, t_cp,
+                             reinterpret_cast<float *>(s_rec + (threadIdx.x & ~(GS_WAVE - 1))), rgb);
     if (live) {
         float4 *out = reinterpret_cast<float4 *>(attrs + (size_t)GS_ATTR_STRIDE * i);
         out[0] = make_float4(u_, v_, z_, qmax);  // always: the hook exposes uv and depth of every
@@ -621,6 +628,32 @@ __global__ __launch_bounds__(GS_BLOCK) void preprocess_kernel(
         if (counters != nullptr && s_dq > __hip_atomic_load(&counters[GS_COUNTER_MAX_DEPTH_KEY], __ATOMIC_RELAXED,
                                                             __HIP_MEMORY_SCOPE_AGENT))
             atomicMax(&counters[GS_COUNTER_MAX_DEPTH_KEY], s_dq);
+    }
+}
+
+
+// ------------------------------------------------------------------ colours of the visible points, on their own
+// The colour half of gs_preprocess (RAS:280-282,302-310) as a kernel of its own: gs_frame_forward runs it on a second
+// stream BESIDE key generation, sort and ranges (none of which read a colour) -- it is a plain streaming pass over the
+// 192 B of SH coefficients per Gaussian, the list stages are latency-bound launches that leave the HBM idle.
+// Writes floats 8..10 of the record (row 2 = r, g, b, opacity: the opacity is gs_preprocess_geometry's).
+__global__ __launch_bounds__(GS_BLOCK) void view_colours_kernel(
+    const float *__restrict__ xyz, const float *__restrict__ feat, const int32_t *__restrict__ obj,
+    const float *__restrict__ q_cp, const float *__restrict__ t_cp, const int32_t *__restrict__ ids, int m_capacity,
+    int use_device_count, const int32_t *__restrict__ counters, const int32_t *__restrict__ nkeys,
+    float *__restrict__ attrs) {
+    __shared__ float s_basis[GS_BLOCK * 16];
+    const int m = use_device_count ? min(counters[GS_COUNTER_NUM_VISIBLE], m_capacity) : m_capacity;
+    if (blockIdx.x * GS_BLOCK >= m) return;   // (workgroup-uniform)
+    const int i = blockIdx.x * GS_BLOCK + threadIdx.x;
+    const bool wants = i < m && nkeys[i] > 0;
+    const int id = wants ? ids[i] : 0;
+    float rgb[3] = {0.f, 0.f, 0.f};
+    gs_wave_view_colours(wants, id, xyz, feat, obj, q_cp, t_cp, s_basis + 16 * (threadIdx.x & ~(GS_WAVE - 1)), rgb);
+    if (wants) {
+        float *out = attrs + (size_t)GS_ATTR_STRIDE * i + 8;
+        *reinterpret_cast<float2 *>(out) = make_float2(rgb[0], rgb[1]);
+        out[2] = rgb[2];
     }
 }
 
@@ -888,23 +921,67 @@ int gs_read_counters_async(const int32_t *counters, int32_t *host_counters_pinne
     return 0;
 }
 
-int gs_preprocess(const float *xyz, float *features, const int32_t *object_id, const float *intrinsics,
-                  const float *q_cp, const float *t_cp, const int32_t *ids, int n_visible, int n_visible_on_device,
-                  int width, int height, int tile_row_begin, int tile_row_step, int tile_row_end, int bin_shift,
-                  int exact_tile_cull, int always_store_rotation, float depth_scale, int32_t *counters,
-                  float *attrs, int32_t *num_overlap_tiles, int32_t *num_keys, int32_t *block_sums,
-                  int32_t *block_sums_full, void *stream) {
+static int gs_preprocess_launch(bool colour, const float *xyz, float *features, const int32_t *object_id,
+                                const float *intrinsics, const float *q_cp, const float *t_cp, const int32_t *ids,
+                                int n_visible, int n_visible_on_device, int width, int height, int tile_row_begin,
+                                int tile_row_step, int tile_row_end, int bin_shift, int exact_tile_cull,
+                                int always_store_rotation, float depth_scale, int32_t *counters, float *attrs,
+                                int32_t *num_overlap_tiles, int32_t *num_keys, int32_t *block_sums,
+                                int32_t *block_sums_full, void *stream) {
     GS_REQUIRE(n_visible >= 0, "n_visible");
     GS_REQUIRE(tile_row_step >= 1 && tile_row_begin >= 0 && tile_row_end >= 0, "tile row ownership");
     GS_REQUIRE(bin_shift >= 0 && bin_shift <= 4, "bin_shift");
     GS_REQUIRE(width % GS_TILE_WIDTH == 0 && height % GS_TILE_HEIGHT == 0, "image size must be a multiple of 16");
     GS_REQUIRE(!n_visible_on_device || counters != nullptr, "device-side count needs counters");
     if (n_visible == 0) return 0;
-    hipLaunchKernelGGL(preprocess_kernel, dim3(gs_div_up(n_visible, GS_BLOCK)), dim3(GS_BLOCK), 0,
-                       (hipStream_t)stream, xyz, features, object_id, intrinsics, q_cp, t_cp, ids, n_visible,
-                       n_visible_on_device, width, height, RowOwner{tile_row_begin, tile_row_step, tile_row_end},
-                       bin_shift, exact_tile_cull, always_store_rotation, depth_scale, counters, attrs, num_overlap_tiles,
-                       num_keys, block_sums, block_sums_full);
+    const dim3 grid(gs_div_up(n_visible, GS_BLOCK)), block(GS_BLOCK);
+    const RowOwner ow{tile_row_begin, tile_row_step, tile_row_end};
+    if (colour)
+        hipLaunchKernelGGL(preprocess_kernel<true>, grid, block, 0, (hipStream_t)stream, xyz, features, object_id,
+                           intrinsics, q_cp, t_cp, ids, n_visible, n_visible_on_device, width, height, ow, bin_shift,
+                           exact_tile_cull, always_store_rotation, depth_scale, counters, attrs, num_overlap_tiles,
+                           num_keys, block_sums, block_sums_full);
+    else
+        hipLaunchKernelGGL(preprocess_kernel<false>, grid, block, 0, (hipStream_t)stream, xyz, features, object_id,
+                           intrinsics, q_cp, t_cp, ids, n_visible, n_visible_on_device, width, height, ow, bin_shift,
+                           exact_tile_cull, always_store_rotation, depth_scale, counters, attrs, num_overlap_tiles,
+                           num_keys, block_sums, block_sums_full);
+    GS_CHECK_LAUNCH();
+    return 0;
+}
+
+int gs_preprocess(const float *xyz, float *features, const int32_t *object_id, const float *intrinsics,
+                  const float *q_cp, const float *t_cp, const int32_t *ids, int n_visible, int n_visible_on_device,
+                  int width, int height, int tile_row_begin, int tile_row_step, int tile_row_end, int bin_shift,
+                  int exact_tile_cull, int always_store_rotation, float depth_scale, int32_t *counters,
+                  float *attrs, int32_t *num_overlap_tiles, int32_t *num_keys, int32_t *block_sums,
+                  int32_t *block_sums_full, void *stream) {
+    return gs_preprocess_launch(true, xyz, features, object_id, intrinsics, q_cp, t_cp, ids, n_visible,
+                                n_visible_on_device, width, height, tile_row_begin, tile_row_step, tile_row_end, bin_shift,
+                                exact_tile_cull, always_store_rotation, depth_scale, counters, attrs, num_overlap_tiles,
+                                num_keys, block_sums, block_sums_full, stream);
+}
+
+int gs_preprocess_geometry(const float *xyz, float *features, const int32_t *object_id, const float *intrinsics,
+                           const float *q_cp, const float *t_cp, const int32_t *ids, int n_visible,
+                           int n_visible_on_device, int width, int height, int tile_row_begin, int tile_row_step,
+                           int tile_row_end, int bin_shift, int exact_tile_cull, int always_store_rotation,
+                           float depth_scale, int32_t *counters, float *attrs, int32_t *num_overlap_tiles,
+                           int32_t *num_keys, int32_t *block_sums, int32_t *block_sums_full, void *stream) {
+    return gs_preprocess_launch(false, xyz, features, object_id, intrinsics, q_cp, t_cp, ids, n_visible,
+                                n_visible_on_device, width, height, tile_row_begin, tile_row_step, tile_row_end, bin_shift,
+                                exact_tile_cull, always_store_rotation, depth_scale, counters, attrs, num_overlap_tiles,
+                                num_keys, block_sums, block_sums_full, stream);
+}
+
+int gs_view_colours(const float *xyz, const float *features, const int32_t *object_id, const float *q_cp,
+                    const float *t_cp, const int32_t *ids, int n_visible, int n_visible_on_device,
+                    const int32_t *counters, const int32_t *num_keys, float *attrs, void *stream) {
+    GS_REQUIRE(n_visible >= 0, "n_visible");
+    GS_REQUIRE(!n_visible_on_device || counters != nullptr, "device-side count needs counters");
+    if (n_visible == 0) return 0;
+    hipLaunchKernelGGL(view_colours_kernel, dim3(gs_div_up(n_visible, GS_BLOCK)), dim3(GS_BLOCK), 0, (hipStream_t)stream,
+                       xyz, features, object_id, q_cp, t_cp, ids, n_visible, n_visible_on_device, counters, num_keys, attrs);
     GS_CHECK_LAUNCH();
     return 0;
 }

@@ -60,6 +60,20 @@ def _ws_bytes(ws: hip_ops.Workspaces, name: str, nbytes: int, device) -> int:
     return ws.get(name, max(int(nbytes), 16), torch.uint8, device).data_ptr()
 
 
+def aux_stream_of(outer, device):
+    """The operator's second stream on ``device`` and the two events gs_frame_forward forks / joins it with (created once
+    per operator and device; GS_FWD_COLOUR_ASYNC)."""
+    aux = outer._aux_streams.get(device)
+    if aux is None:
+        stream = torch.cuda.Stream(device)
+        fork, join = torch.cuda.Event(), torch.cuda.Event()
+        with torch.cuda.device(device):
+            fork.record(torch.cuda.current_stream(device))   # (creates the events the library records by handle)
+            join.record(torch.cuda.current_stream(device))
+        aux = outer._aux_streams[device] = (stream, fork, join)
+    return aux
+
+
 def forward(outer, xyz, features, invalid, obj, intrinsics, q_pc, t_pc, camera_info, color_max_sh_band, need_state,
             layout, guess, gathered_rows, readback):
     """-> (image, depth, count, state, host counters).  All launches of the forward pass are enqueued by one call; the host
@@ -167,7 +181,12 @@ def forward(outer, xyz, features, invalid, obj, intrinsics, q_pc, t_pc, camera_i
     f.split_workspace = hip_ops.split_workspace(ws, width, height, dev).data_ptr() if split else 0
     f.filter_workspace = _ws_bytes(ws, "f_filter", lib.gs_filter_workspace_bytes(n), dev)
     f.sort_workspace = _ws_bytes(ws, "f_sort", lib.gs_sort_workspace_bytes(cap), dev)
-    _lib.check(lib.gs_frame_forward(ctypes.addressof(f), FORWARD_STAGES, _lib.current_stream(dev)), "gs_frame_forward")
+    stages = FORWARD_STAGES
+    if getattr(outer, "colours_beside_list_stages", False):
+        aux, fork, join = aux_stream_of(outer, dev)
+        f.aux_stream, f.aux_event_fork, f.aux_event_join = aux.cuda_stream, fork.cuda_event, join.cuda_event
+        stages |= S["GS_FWD_COLOUR_ASYNC"]
+    _lib.check(lib.gs_frame_forward(ctypes.addressof(f), stages, _lib.current_stream(dev)), "gs_frame_forward")
     host = readback.wait()
     state = FrameState()
     state.frame, state.slab, state.layout, state.walked = f, slab, layout, emit

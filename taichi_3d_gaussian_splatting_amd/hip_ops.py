@@ -197,8 +197,9 @@ def filter_compact(xyz, invalid_mask, object_id, intrinsics, q_cp, t_cp, near_pl
 
 def preprocess(xyz, features, object_id, intrinsics, q_cp, t_cp, ids, width, height, layout: ListLayout = ListLayout(),
                depth_to_sort_key_scale=100.0, counters=None, n_visible_on_device=False,
-               always_store_rotation: bool = False, ws: Optional[Workspaces] = None):
+               always_store_rotation: bool = False, ws: Optional[Workspaces] = None, colours: bool = True):
     """-> (attrs f32[M,16], num_overlap_tiles i32[M], num_keys i32[M], block_sums, block_sums_full).
+    colours=False: gs_preprocess_geometry -- floats 8..10 of the records are left to ``view_colours``.
     Normalises features[ids, 0:4] IN PLACE (RAS:196-205).  num_overlap_tiles is the reference's box count
     (hook output; its scan gives the backward slots); num_keys is the number of sort keys emitted (bins reached in
     owned tile rows, after the exact cull); the two block_sums are int32[ceil(M/256)] partial sums of them."""
@@ -210,12 +211,22 @@ def preprocess(xyz, features, object_id, intrinsics, q_cp, t_cp, ids, width, hei
     nblk = (m + _PRE_BLOCK - 1) // _PRE_BLOCK
     block_sums = _scratch(ws, "block_sums", nblk, torch.int32, dev)
     block_sums_full = _scratch(ws, "block_sums_full", nblk, torch.int32, dev)
-    call("gs_preprocess", ptr(xyz), ptr(features), ptr(object_id), ptr(intrinsics), ptr(q_cp), ptr(t_cp), ptr(ids),
-         m, int(bool(n_visible_on_device)), int(width), int(height), layout.row_begin, layout.row_step, layout.row_end,
+    call("gs_preprocess" if colours else "gs_preprocess_geometry", ptr(xyz), ptr(features), ptr(object_id),
+         ptr(intrinsics), ptr(q_cp), ptr(t_cp), ptr(ids), m, int(bool(n_visible_on_device)), int(width), int(height), layout.row_begin, layout.row_step, layout.row_end,
          layout.bin_shift, int(layout.exact_cull), int(bool(always_store_rotation)), float(depth_to_sort_key_scale),
          ptr(counters), ptr(attrs),
          ptr(ntiles), ptr(nkeys), ptr(block_sums), ptr(block_sums_full), current_stream(dev))
     return attrs, ntiles, nkeys, block_sums, block_sums_full
+
+
+def view_colours(xyz, features, object_id, q_cp, t_cp, ids, num_keys, attrs, counters=None, n_visible_on_device=False,
+                 stream: Optional[int] = None) -> None:
+    """The colour half of ``preprocess`` (RAS:280-282,302-310): writes floats 8..10 of the records of the Gaussians with
+    num_keys > 0, in place.  stream: raw handle of the stream to launch on (default: torch's current stream)."""
+    dev = xyz.device
+    call("gs_view_colours", ptr(xyz), ptr(features), ptr(object_id), ptr(q_cp), ptr(t_cp), ptr(ids), ids.shape[0],
+         int(bool(n_visible_on_device)), ptr(counters), ptr(num_keys), ptr(attrs),
+         current_stream(dev) if stream is None else stream)
 
 
 def scan_block_sums(block_sums: torch.Tensor, counters: torch.Tensor,

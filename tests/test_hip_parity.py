@@ -959,6 +959,59 @@ def test_one_entry_point_per_pass_is_bit_identical(scene, bin_shift, no_grad, rg
     assert len(runs[True][1]) == (0 if no_grad else 3)
 
 
+def test_colours_on_their_own_are_bit_identical(ops, scene, ofwd):
+    """gs_preprocess_geometry + gs_view_colours (the colour half of the projection as a kernel of its own, which
+    gs_frame_forward runs on a second stream beside the list stages) leave the same records, bit for bit, as gs_preprocess
+    -- also launched on a stream of its own."""
+    s = scene
+    layout = ops.ListLayout(bin_shift=0, exact_cull=True)
+    args = (dev(s.point_cloud), None, dev(s.point_object_id), dev(s.camera_intrinsics), dev(ofwd["q_cp"]),
+            dev(ofwd["t_cp"]), dev(ofwd["ids"]), s.width, s.height, layout)
+
+    def run(colours):
+        feat = dev(s.point_cloud_features).clone()
+        a = list(args)
+        a[1] = feat
+        return feat, ops.preprocess(*a, colours=colours)
+
+    feat0, (attrs0, ntiles0, nkeys0, _, _) = run(True)
+    feat1, (attrs1, ntiles1, nkeys1, _, _) = run(False)
+    emits = nkeys0 > 0
+    assert torch.equal(nkeys0, nkeys1) and torch.equal(ntiles0, ntiles1) and torch.equal(feat0, feat1)
+    assert bool(emits.any()) and torch.equal(attrs1[emits][:, 8:11], torch.zeros_like(attrs1[emits][:, 8:11]))
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    ops.view_colours(args[0], feat1, args[2], args[4], args[5], args[6], nkeys1, attrs1, stream=side.cuda_stream)
+    torch.cuda.current_stream().wait_stream(side)
+    assert torch.equal(attrs0[:, 0:4].view(torch.int32), attrs1[:, 0:4].view(torch.int32))
+    assert torch.equal(attrs0[emits].view(torch.int32), attrs1[emits].view(torch.int32))
+    assert float(attrs0[emits][:, 8:11].min()) > 0.0   # sigmoid outputs: the colours really are there
+
+
+def test_colours_beside_the_list_stages_do_not_change_a_bit(scene):
+    """The operator with the colours evaluated on its second stream beside key generation, sort and ranges
+    (`colours_beside_list_stages`, the default of the per-pass entry points) against the colours inside gs_preprocess:
+    image, depth, count, gradients and the stored quaternions equal bit for bit over five frames."""
+    from taichi_3d_gaussian_splatting_amd import GaussianPointCloudRasterisation as Op
+    from taichi_3d_gaussian_splatting_amd.synthetic import make_grad_image
+    g = make_grad_image(scene.height, scene.width)
+    cfg = Op.GaussianPointCloudRasterisationConfig(near_plane=scene.near_plane, far_plane=scene.far_plane,
+                                                   depth_to_sort_key_scale=scene.depth_to_sort_key_scale)
+    runs = {}
+    for beside in (True, False):
+        op = Op(cfg)
+        op.colours_beside_list_stages = beside
+        runs[beside] = [_run_operator(scene, g, op=op) for _ in range(5)]
+        assert op.speculation_stats == {"frames": 5, "redone": 0}
+        assert bool(op._aux_streams) == beside
+    for a, b in zip(runs[True], runs[False]):
+        for i in range(3):
+            assert torch.equal(a[i], b[i]), i
+        assert torch.equal(a[3].grad.view(torch.int32), b[3].grad.view(torch.int32))
+        assert torch.equal(a[4].grad.view(torch.int32), b[4].grad.view(torch.int32))
+        assert torch.equal(a[4].detach(), b[4].detach())
+
+
 def test_one_entry_point_per_pass_overflow_falls_back(scene):
     """A frame that outgrows the capacities learnt from the previous one (four times the Gaussians on screen) is redone by
     the stage-by-stage path with exact sizes: the same outputs as a fresh operator."""
