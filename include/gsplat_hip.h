@@ -183,8 +183,10 @@ int gs_make_keys(const float *attrs, const int32_t *num_keys, const int32_t *blo
                  int32_t *payload, const int32_t *num_overlap_tiles,
                  const int32_t *block_offsets_full, int32_t *slot_offsets, void *stream);
 
-/* Stable LSD radix sort of (key, payload) pairs.  Replaces torch.sort + gather (RAS:947-950) with
- * the stable tie rule.  key_depth_bits selects the key layout (see gs_make_keys).  64-bit layout:
+/* Stable radix sort of (key, payload) pairs.  Replaces torch.sort + gather (RAS:947-950) with
+ * the stable tie rule.  (64-bit keys and large inputs: LSD passes of eight bits, three launches each; 32-bit keys up to
+ * ~4 M pairs: MSD-first -- one such pass on the top eight or nine bits, then every bucket sorted by its remaining bits
+ * inside one workgroup's LDS.  Same result.)  key_depth_bits selects the key layout (see gs_make_keys).  64-bit layout:
  * only the bit ranges [0,depth_bits) and [32,32+tile_bits) are sorted; depth_bits = 64 sorts the
  * whole key as a signed int64.  32-bit layout: bits [0, key_depth_bits+tile_bits).
  * keys_alt/payload_alt are ping-pong buffers of the same size.  Returns 0 when the sorted pairs are in
@@ -198,14 +200,21 @@ int gs_sort_pairs(void *keys, int32_t *payload, void *keys_alt, int32_t *payload
                   int tile_bits, int allow_result_in_alt, void *workspace, void *stream);
 /* The same sort; its first launch also zero-fills
  * `also_zero` (16-byte aligned, also_zero_bytes % 16 == 0; may be NULL / 0) -- the frame's list ranges ride along instead
- * of a fill launch of their own (gs_tile_ranges with ranges_are_zeroed). */
+ * of a fill launch of their own (gs_tile_ranges with ranges_are_zeroed).
+ * bins_in_any_order != 0 (32-bit keys): the caller needs what the frame needs -- the pairs of one bin (bits
+ * [key_depth_bits, key_depth_bits + tile_bits) of the key) CONTIGUOUS and in ascending, stable order within the bin --
+ * but not the bins themselves in ascending order: gs_tile_ranges and the blend kernels look a bin's list up by its range.
+ * The MSD-first sort then partitions by the LOWEST bits of the bin field, so that a bucket is every 256th (512th) bin of
+ * the frame instead of a run of adjacent ones: even buckets whatever the density of the scene (adjacent bins: 79 of the
+ * headline frame's 255 buckets exceeded a workgroup's LDS).  Order of the result: (bin mod 2^m, bin, depth, input). */
 int gs_sort_pairs_and_zero(void *keys, int32_t *payload, void *keys_alt, int32_t *payload_alt,
                            int64_t n_keys, const int32_t *n_keys_device, int key_depth_bits, int depth_bits,
-                           int tile_bits, int allow_result_in_alt, void *workspace, void *also_zero,
-                           size_t also_zero_bytes, void *stream);
+                           int tile_bits, int allow_result_in_alt, int bins_in_any_order, void *workspace,
+                           void *also_zero, size_t also_zero_bytes, void *stream);
 
 /* Per-bin [start,end) ranges (n_tiles = number of bins; per tile with bin_shift = 0).  Replaces
- * find_tile_start_and_end (RAS:175-193) including the zero-initialisation of RAS:954-957. */
+ * find_tile_start_and_end (RAS:175-193) including the zero-initialisation of RAS:954-957.  Needs every bin's keys
+ * contiguous, not the bins in ascending order (gs_sort_pairs_and_zero, bins_in_any_order). */
 int gs_tile_ranges(const void *keys_sorted, int64_t n_keys, const int32_t *n_keys_device,
                    int key_depth_bits, int32_t *tile_start, int32_t *tile_end, int n_tiles,
                    void *stream);

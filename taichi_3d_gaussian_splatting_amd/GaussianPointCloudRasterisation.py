@@ -338,7 +338,7 @@ class GaussianPointCloudRasterisation(torch.nn.Module):
                         ntiles_ if need_state else None, bsums_full_ if need_state else None, counters=counters_,
                         ws=outer._scratch)
                     keys, payload_ = hip_ops.sort_pairs(keys, payload_, depth_bits, tile_bits, kdb, in_place=False,
-                                                        n_keys_device=n_dev, ws=outer._scratch)
+                                                        n_keys_device=n_dev, ws=outer._scratch, bins_in_any_order=True)
                     start_, end_ = hip_ops.tile_ranges(keys, num_bins, kdb, n_keys_device=n_dev)
                     del keys
                     work_ = None

@@ -97,7 +97,7 @@ static int frame_forward_stages(GsFrame *f, uint32_t stages, void *stream, bool 
     if (stages & GS_FWD_SORT) {
         GS_REQUIRE(range_bytes % 16 == 0, "n_bins must be even (the ranges are zeroed with 16-byte stores)");
         const int rc = gs_sort_pairs_and_zero(f->keys, f->payload, f->keys_alt, f->payload_alt, f->n_keys_capacity,
-                                              n_keys_device, f->key_depth_bits, f->depth_bits, f->tile_bits, 1,
+                                              n_keys_device, f->key_depth_bits, f->depth_bits, f->tile_bits, 1, 1,
                                               f->sort_workspace, f->bin_ranges, range_bytes, stream);
         if (rc < 0) return rc;
         f->sorted_in_alt = rc;

@@ -294,10 +294,11 @@ def key_layout(near_plane: float, far_plane: float, depth_to_sort_key_scale: flo
 
 def sort_pairs(keys: torch.Tensor, payload: torch.Tensor, depth_bits: int, tile_bits: int,
                key_depth_bits: int = 0, in_place: bool = True, n_keys_device: Optional[torch.Tensor] = None,
-               ws: Optional[Workspaces] = None):
+               ws: Optional[Workspaces] = None, bins_in_any_order: bool = False):
     """Stable sort of (keys, payload).  in_place=True: the inputs hold the result.  in_place=False: returns the
     (keys, payload) tensors that hold the result (the inputs or the ping-pong buffers: no copy back after an
-    odd number of passes); the other pair is scratch."""
+    odd number of passes); the other pair is scratch.  bins_in_any_order: what a frame needs -- every bin's pairs
+    contiguous and stably sorted by depth, the bins themselves in the sort's own order (include/gsplat_hip.h)."""
     n = keys.shape[0]   # capacity when n_keys_device (an int32 device scalar holding the actual count) is given
     if n <= 1:
         return None if in_place else (keys, payload)
@@ -307,9 +308,10 @@ def sort_pairs(keys: torch.Tensor, payload: torch.Tensor, depth_bits: int, tile_
     keys_alt = _scratch(ws, "keys_alt", n, keys.dtype, dev)
     payload_alt = torch.empty_like(payload)   # (either payload buffer may end up holding the result: not scratch)
     scratch = _scratch(ws, "sort", _lib.load().gs_sort_workspace_bytes(n), torch.uint8, dev)
-    status = _lib.load().gs_sort_pairs(ptr(keys), ptr(payload), ptr(keys_alt), ptr(payload_alt), n,
-                                       ptr(n_keys_device), int(key_depth_bits), int(depth_bits), int(tile_bits), 0 if in_place else 1,
-                                       ptr(scratch), current_stream(dev))
+    status = _lib.load().gs_sort_pairs_and_zero(ptr(keys), ptr(payload), ptr(keys_alt), ptr(payload_alt), n,
+                                                ptr(n_keys_device), int(key_depth_bits), int(depth_bits), int(tile_bits),
+                                                0 if in_place else 1, int(bool(bins_in_any_order)), ptr(scratch), None, 0,
+                                                current_stream(dev))
     if status < 0:
         _lib.check(status, "gs_sort_pairs")
     if not in_place:

@@ -317,7 +317,8 @@ class OwnerShardedRasteriser:
             keys, payload, slot_offsets = hip_ops.make_keys(
                 records, nkeys, bsums, n_keys, width, height, cfg.depth_to_sort_key_scale, layout, kdb,
                 ntiles if need_state else None, bsums_full if need_state else None, ws=self._scratch)
-            keys, payload = hip_ops.sort_pairs(keys, payload, depth_bits, tile_bits, kdb, in_place=False, ws=self._scratch)
+            keys, payload = hip_ops.sort_pairs(keys, payload, depth_bits, tile_bits, kdb, in_place=False, ws=self._scratch,
+                                               bins_in_any_order=True)
             start, end = hip_ops.tile_ranges(keys, num_bins, kdb)
             del keys
             emit = bool(need_state and self.backward_on_walked_lists and layout.filter != 0 and

@@ -318,6 +318,82 @@ def test_radix_sort_with_the_count_on_the_device(ops, n, capacity):
     assert np.array_equal(p.cpu().numpy()[:n], payload[:n][order])
 
 
+@pytest.mark.parametrize("n,depth_bits,tile_bits,skew", [
+    (300_000, 9, 11, "one_bucket"),        # every key in ONE of the 256 buckets of the top digit: 18 chunks of the local sort
+    (200_000, 13, 13, "two_buckets"),      # 26 bits: three bucket-local passes of 6 bits, chunked (odd number of passes)
+    (50_000, 19, 13, "uniform"),           # 32 bits in use: three local passes of 8 bits
+    (1_000_000, 9, 13, "centre_heavy"),    # a trained scene's shape: most keys in a few buckets, some above the LDS capacity
+    (70_000, 5, 4, "uniform"),             # 9 bits: a one-bit local pass
+    (3_000, 9, 11, "uniform"),             # buckets of a dozen keys
+    (4_399_999, 11, 11, "uniform"),        # 1,024 buckets (ten-bit partitioning digit)
+    (3_000_000, 11, 9, "centre_heavy"),    # 512 buckets, uneven
+])
+def test_radix_sort_msd_first_on_skewed_keys(ops, n, depth_bits, tile_bits, skew):
+    """The MSD-first sort (one scatter pass on the top eight bits + bucket-local LSD passes in LDS) where its buckets are
+    anything but even: buckets far above the LDS capacity are sorted chunk by chunk through the other buffer -- still
+    bit-exact against the stable sort, payload included."""
+    rng = np.random.default_rng(n + depth_bits)
+    bits = depth_bits + tile_bits
+    low = bits - 8   # the bucket of a key = its top eight bits in use
+    if skew == "one_bucket":
+        keys = (5 << low) + rng.integers(0, 1 << low, size=n)
+    elif skew == "two_buckets":
+        keys = np.where(rng.random(n) < 0.7, 0, 200 << low) + rng.integers(0, 1 << low, size=n)
+    elif skew == "centre_heavy":
+        tile = np.clip(rng.normal(0.5, 0.04, size=n) * (1 << tile_bits), 0, (1 << tile_bits) - 1).astype(np.int64)
+        keys = (tile << depth_bits) + rng.integers(0, 1 << depth_bits, size=n)
+    else:
+        keys = rng.integers(0, 1 << bits, size=n)
+    keys = keys.astype(np.uint64).astype(np.uint32)
+    payload = rng.permutation(n).astype(np.int32)
+    k, p = dev(keys.view(np.int32)), dev(payload)
+    ops.sort_pairs(k, p, depth_bits, tile_bits, depth_bits)
+    order = np.argsort(keys, kind="stable")
+    assert np.array_equal(k.cpu().numpy().view(np.uint32), keys[order])
+    assert np.array_equal(p.cpu().numpy(), payload[order])
+
+
+@pytest.mark.parametrize("n,depth_bits,tile_bits,shape", [
+    (2_877_171, 9, 11, "centre_heavy"),    # the headline frame's size and key layout: 256 even buckets
+    (5_800_000, 9, 11, "centre_heavy"),    # BASELINE config 4: 512 buckets
+    (1_000_000, 9, 13, "centre_heavy"),    # a trained scene with per-tile keys
+    (48_000, 9, 8, "uniform"),             # 256 tiles: a bucket is one bin
+    (400_000, 11, 5, "uniform"),           # fewer bins than buckets: falls back to the top bits, ascending
+    (123_457, 12, 20, "uniform"),          # 32 bits in use
+    (9_500_000, 9, 13, "uniform"),         # too many pairs for the MSD-first path: LSD passes, ascending
+])
+def test_radix_sort_with_bins_in_any_order(ops, n, depth_bits, tile_bits, shape):
+    """What the frame asks of its sort (gs_sort_pairs_and_zero, bins_in_any_order): every bin's pairs CONTIGUOUS and in
+    stable ascending order within the bin; the bins themselves in whatever order the sort leaves them (the MSD-first sort
+    partitions by the lowest bits of the bin field: even buckets whatever the density of the scene).  Checked against the
+    stable sort: re-ordering the bins of the result stably must give exactly the fully sorted pairs."""
+    rng = np.random.default_rng(n)
+    if shape == "centre_heavy":
+        tile = np.clip(rng.normal(0.5, 0.15, size=n) * (1 << tile_bits), 0, (1 << tile_bits) - 1).astype(np.int64)
+    else:
+        tile = rng.integers(0, 1 << tile_bits, size=n)
+    keys = ((tile << depth_bits) + rng.integers(0, 1 << min(depth_bits, 7), size=n)).astype(np.uint64).astype(np.uint32)
+    payload = rng.permutation(n).astype(np.int32)
+    k, p = ops.sort_pairs(dev(keys.view(np.int32)), dev(payload), depth_bits, tile_bits, depth_bits, in_place=False,
+                          bins_in_any_order=True)
+    got_k, got_p = k.cpu().numpy().view(np.uint32), p.cpu().numpy()
+    bins = got_k >> depth_bits
+    runs = 1 + int((bins[1:] != bins[:-1]).sum())
+    assert runs == len(np.unique(tile)), "a bin's pairs are not contiguous"
+    by_bin = np.argsort(bins, kind="stable")
+    order = np.argsort(keys, kind="stable")
+    assert np.array_equal(got_k[by_bin], keys[order])
+    assert np.array_equal(got_p[by_bin], payload[order])
+    # and the ranges of such a result are the ranges of the sorted one, bin by bin
+    start, end = ops.tile_ranges(k, 1 << tile_bits, depth_bits)
+    counts = np.bincount(tile, minlength=1 << tile_bits)
+    assert np.array_equal((end - start).cpu().numpy(), counts)
+    s_, e_ = start.cpu().numpy(), end.cpu().numpy()
+    probe = rng.choice(np.nonzero(counts)[0], size=min(64, int((counts > 0).sum())), replace=False)
+    for b in probe:
+        assert (bins[s_[b]:e_[b]] == b).all()
+
+
 def test_find_tile_start_and_end_known_answer(ops):
     # the reference's own known-answer vector, T_RAS:18-51, through the drop-in symbol
     from taichi_3d_gaussian_splatting_amd.GaussianPointCloudRasterisation import find_tile_start_and_end

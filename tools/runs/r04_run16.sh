@@ -1,0 +1,15 @@
+#!/bin/bash
+# round 4, GPU call 16: MSD-first sort, bins in any order (partition by the lowest bits of the bin field: even buckets)
+cd $GRAFT_REPO_ROOT
+OUT=$GRAFT_REPO_ROOT/gpurun_out/r04_run16; mkdir -p $OUT
+timeout 600 python -m pytest tests/test_hip_parity.py -m gpu -q -x -k "radix_sort or keys_sort_ranges" > $OUT/pytest_sort.log 2>&1; tail -4 $OUT/pytest_sort.log
+GS_SORT_GROUPED=1 timeout 300 python tools/sort_bench.py 20 2>&1 | grep sort_bench | tee $OUT/sort_bench_grouped.txt
+GS_SORT_GROUPED=1 GS_SORT_SKEWED=1 timeout 300 python tools/sort_bench.py 20 2>&1 | grep sort_bench | tee $OUT/sort_bench_grouped_skewed.txt
+GS_SORT_SKEWED=1 timeout 300 python tools/sort_bench.py 20 2>&1 | grep sort_bench | tee $OUT/sort_bench_ascending_skewed.txt
+for arm in msd lsd; do
+for w in headline_1m_1080p cfg3_400k_1080p cfg4_2m_1080p trained_1080p cfg1_10k_256 cfg2_100k_800; do
+  GS_SORT_IMPL=$arm timeout 600 python bench.py --no-cpu-baseline --workload $w > $OUT/bench_${w}_$arm.json 2> $OUT/bench_${w}_$arm.err
+  python -c "
+import json; d=json.load(open('$OUT/bench_${w}_$arm.json')); r=d['roofline']; print('$w sort=$arm', d['ms_per_step'], d['value'], d['step_ms'], r and r['stages_ms'].get('sort_pairs'))"
+done; done
+timeout 2400 python -m pytest tests -m gpu -q -x > $OUT/pytest.log 2>&1; tail -5 $OUT/pytest.log

@@ -46,7 +46,8 @@ for _ in range(reps + 2):
     kdb, db, tb = hip_ops.key_layout(s.near_plane, s.far_plane, s.depth_to_sort_key_scale, num_tiles, max_dq)
     keys, payload, slot_off = timed("make_keys", lambda: hip_ops.make_keys(attrs, nowned, bsums, k, s.width, s.height,
                                                                  s.depth_to_sort_key_scale, LAYOUT, kdb, ntiles, bsums_full))
-    keys, payload = timed("sort_pairs", lambda: hip_ops.sort_pairs(keys, payload, db, tb, kdb, in_place=False))
+    keys, payload = timed("sort_pairs", lambda: hip_ops.sort_pairs(keys, payload, db, tb, kdb, in_place=False,
+                                                                        bins_in_any_order=True))
     start, end = timed("tile_ranges", lambda: hip_ops.tile_ranges(keys, num_tiles, kdb))
     image, depth, acc_alpha, last_eff, count = timed("blend_forward", lambda: hip_ops.blend_forward(
         start, end, payload, attrs, s.width, s.height, LAYOUT))
