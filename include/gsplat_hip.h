@@ -206,11 +206,16 @@ int gs_sort_pairs(void *keys, int32_t *payload, void *keys_alt, int32_t *payload
  * but not the bins themselves in ascending order: gs_tile_ranges and the blend kernels look a bin's list up by its range.
  * The MSD-first sort then partitions by the LOWEST bits of the bin field, so that a bucket is every 256th (512th) bin of
  * the frame instead of a run of adjacent ones: even buckets whatever the density of the scene (adjacent bins: 79 of the
- * headline frame's 255 buckets exceeded a workgroup's LDS).  Order of the result: (bin mod 2^m, bin, depth, input). */
+ * headline frame's 255 buckets exceeded a workgroup's LDS).  Order of the result: (bin mod 2^m, bin, depth, input).
+ * tile_start / tile_end (int32[n_tiles] each, may be NULL; zero-filled by the caller or through also_zero): when the
+ * MSD-first path runs and its buckets are made of whole bins, the bucket-local sort writes the bins' [start, end) ranges
+ * (gs_tile_ranges' output) on its way out, and the return value has bit 1 set: no ranges launch is needed.
+ * Returns (>= 0): bit 0 = the sorted pairs are in keys_alt / payload_alt, bit 1 = the ranges were written. */
 int gs_sort_pairs_and_zero(void *keys, int32_t *payload, void *keys_alt, int32_t *payload_alt,
                            int64_t n_keys, const int32_t *n_keys_device, int key_depth_bits, int depth_bits,
                            int tile_bits, int allow_result_in_alt, int bins_in_any_order, void *workspace,
-                           void *also_zero, size_t also_zero_bytes, void *stream);
+                           void *also_zero, size_t also_zero_bytes, int32_t *tile_start, int32_t *tile_end,
+                           int n_tiles, void *stream);
 
 /* Per-bin [start,end) ranges (n_tiles = number of bins; per tile with bin_shift = 0).  Replaces
  * find_tile_start_and_end (RAS:175-193) including the zero-initialisation of RAS:954-957.  Needs every bin's keys

@@ -44,7 +44,7 @@ _SIGNATURES = {
     "gs_make_keys": (_I, [_P, _P, _P, _I, _P, _I64, _I, _I, _I, _I, _I, _I, _I, _I, _F, _P, _P, _P, _P, _P, _P]),
     "gs_sort_workspace_bytes": (_c.c_size_t, [_I64]),
     "gs_sort_pairs": (_I, [_P, _P, _P, _P, _I64, _P, _I, _I, _I, _I, _P, _P]),
-    "gs_sort_pairs_and_zero": (_I, [_P, _P, _P, _P, _I64, _P, _I, _I, _I, _I, _I, _P, _P, _c.c_size_t, _P]),
+    "gs_sort_pairs_and_zero": (_I, [_P, _P, _P, _P, _I64, _P, _I, _I, _I, _I, _I, _P, _P, _c.c_size_t, _P, _P, _I, _P]),
     "gs_tile_ranges": (_I, [_P, _I64, _P, _I, _P, _P, _I, _P]),
     "gs_tile_ranges_prezeroed": (_I, [_P, _I64, _P, _I, _P, _P, _I, _I, _P]),
     "gs_frame_struct_bytes": (_c.c_size_t, []),

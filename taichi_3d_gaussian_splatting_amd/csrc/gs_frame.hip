@@ -94,17 +94,24 @@ static int frame_forward_stages(GsFrame *f, uint32_t stages, void *stream, bool 
                               f->need_state ? f->num_overlap_tiles : nullptr, f->need_state ? f->block_sums_full : nullptr,
                               f->need_state ? f->slot_offsets : nullptr, stream));
     const size_t range_bytes = sizeof(int32_t) * 2 * (size_t)f->n_bins;
+    bool ranges_written = false;
     if (stages & GS_FWD_SORT) {
         GS_REQUIRE(range_bytes % 16 == 0, "n_bins must be even (the ranges are zeroed with 16-byte stores)");
+        // GS_SORT_RANGES=0: the ranges always by their own launch (A/B measurements)
+        static const bool sort_writes_ranges = !(getenv("GS_SORT_RANGES") && atoi(getenv("GS_SORT_RANGES")) == 0);
+        const bool want = sort_writes_ranges && (stages & GS_FWD_RANGES);
         const int rc = gs_sort_pairs_and_zero(f->keys, f->payload, f->keys_alt, f->payload_alt, f->n_keys_capacity,
                                               n_keys_device, f->key_depth_bits, f->depth_bits, f->tile_bits, 1, 1,
-                                              f->sort_workspace, f->bin_ranges, range_bytes, stream);
+                                              f->sort_workspace, f->bin_ranges, range_bytes,
+                                              want ? f->bin_ranges : nullptr, want ? f->bin_ranges + f->n_bins : nullptr,
+                                              f->n_bins, stream);
         if (rc < 0) return rc;
-        f->sorted_in_alt = rc;
+        f->sorted_in_alt = rc & 1;
+        ranges_written = (rc & 2) != 0;
     }
     const void *keys_sorted = f->sorted_in_alt ? f->keys_alt : f->keys;
     const int32_t *payload_sorted = f->sorted_in_alt ? f->payload_alt : f->payload;
-    if (stages & GS_FWD_RANGES)
+    if ((stages & GS_FWD_RANGES) && !ranges_written)
         GS_STAGE(gs_tile_ranges_prezeroed(keys_sorted, f->n_keys_capacity, n_keys_device, f->key_depth_bits, f->bin_ranges,
                                           f->bin_ranges + f->n_bins, f->n_bins, (stages & GS_FWD_SORT) ? 1 : 0, stream));
     GS_JOIN_COLOURS();

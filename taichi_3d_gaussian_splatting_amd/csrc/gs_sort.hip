@@ -235,7 +235,9 @@ __global__ __launch_bounds__(LS_THREADS) void sort_local_kernel(uint32_t *__rest
                                                                 uint32_t *__restrict__ keys_tmp,
                                                                 int32_t *__restrict__ payload_tmp,
                                                                 const int32_t *__restrict__ totals, int low_bits,
-                                                                int part_shift, int part_bits) {
+                                                                int part_shift, int part_bits, int key_depth_bits,
+                                                                int n_tiles, int32_t *__restrict__ tile_start,
+                                                                int32_t *__restrict__ tile_end) {
     __shared__ uint32_t s_keys[LS_CAP];                 // (gfx950: 160 KB of LDS per workgroup)
     __shared__ int32_t s_pay[LS_CAP];
     __shared__ int s_cnt[LS_WAVES][LS_MAX_RADIX];       // running per-wave digit counts, then exclusive prefixes over waves
@@ -255,7 +257,21 @@ __global__ __launch_bounds__(LS_THREADS) void sort_local_kernel(uint32_t *__rest
     }
     __syncthreads();
     const int start = s_misc[0], nb = s_misc[1];
-    if (nb <= 1) return;   // (workgroup-uniform)
+    if (nb == 0) return;   // (workgroup-uniform)
+    // tile_start != NULL: the bucket is made of whole bins (the partitioning digit lies inside the bin field), so the
+    // [start, end) range of every bin (RAS:175-193; arrays zeroed by the sort's first launch) is known right here
+#define LS_EMIT_RANGE(k, prev_differs, next_differs, pos)                                              \
+    do {                                                                                               \
+        const unsigned _bin = (k) >> key_depth_bits;                                                   \
+        if (_bin < (unsigned)n_tiles) {   /* (keys the caller did not generate are never written) */   \
+            if (prev_differs) tile_start[_bin] = start + (pos);                                        \
+            if (next_differs) tile_end[_bin] = start + (pos) + 1;                                      \
+        }                                                                                              \
+    } while (0)
+    if (nb == 1) {
+        if (tile_start != nullptr && threadIdx.x == 0) LS_EMIT_RANGE(keys[start], true, true, 0);
+        return;
+    }
     // the bits a bucket is still to be sorted by, closed up: those above the partitioning digit moved down onto it
     const uint32_t below = (1u << part_shift) - 1u;
     const int above_shift = part_shift + part_bits;
@@ -361,7 +377,14 @@ __global__ __launch_bounds__(LS_THREADS) void sort_local_kernel(uint32_t *__rest
                         if (r < nrounds && p < cn) { key[r] = s_keys[p]; pay[r] = s_pay[p]; }
                     }
                 } else {                  // sorted: out, in place
-                    for (int p = threadIdx.x; p < cn; p += LS_THREADS) { src_k[p] = s_keys[p]; src_p[p] = s_pay[p]; }
+                    for (int p = threadIdx.x; p < cn; p += LS_THREADS) {
+                        const uint32_t k = s_keys[p];
+                        src_k[p] = k;
+                        src_p[p] = s_pay[p];
+                        if (tile_start != nullptr)
+                            LS_EMIT_RANGE(k, p == 0 || (s_keys[p - 1] >> key_depth_bits) != (k >> key_depth_bits),
+                                          p == cn - 1 || (s_keys[p + 1] >> key_depth_bits) != (k >> key_depth_bits), p);
+                    }
                 }
             } else {   // the chunk's digit runs behind the earlier chunks' in the other buffer
                 for (int p = threadIdx.x; p < cn; p += LS_THREADS) {
@@ -385,6 +408,16 @@ __global__ __launch_bounds__(LS_THREADS) void sort_local_kernel(uint32_t *__rest
         __syncthreads();
         for (int i = threadIdx.x; i < nb; i += LS_THREADS) { dst_k[i] = src_k[i]; dst_p[i] = src_p[i]; }
     }
+    if (!in_lds && tile_start != nullptr) {   // a chunked bucket lies sorted in global memory
+        __syncthreads();
+        const uint32_t *sorted = keys + start;
+        for (int i = threadIdx.x; i < nb; i += LS_THREADS) {
+            const uint32_t k = sorted[i];
+            LS_EMIT_RANGE(k, i == 0 || (sorted[i - 1] >> key_depth_bits) != (k >> key_depth_bits),
+                          i == nb - 1 || (sorted[i + 1] >> key_depth_bits) != (k >> key_depth_bits), i);
+        }
+    }
+#undef LS_EMIT_RANGE
 #undef LS_REST
 #undef LS_CNT
 #undef LS_BLOCK_EXCL_SCAN
@@ -462,19 +495,21 @@ static int msd_digit_bits(int64_t n_keys, int bits, int64_t bucket_keys) {
 template <int RB>
 static int sort_msd_first_rb(uint32_t *keys, int32_t *payload, uint32_t *keys_alt, int32_t *payload_alt, int64_t n_keys,
                              const int32_t *n_dev, int bits, int part_shift, int allow_result_in_alt, void *workspace,
-                             hipStream_t s, void *also_zero, size_t also_zero_bytes) {
+                             hipStream_t s, void *also_zero, size_t also_zero_bytes, int key_depth_bits, int n_tiles,
+                             int32_t *tile_start, int32_t *tile_end) {
     const int rc = sort_pairs_impl<uint32_t, RB>(keys, payload, keys_alt, payload_alt, n_keys, n_dev, &part_shift, 1, 0u, 1,
                                                  workspace, s, also_zero, also_zero_bytes);
     if (rc < 0) return rc;   // (rc == 1: the partitioned pairs are in the alt buffers)
     const int nblk = gs_div_up(n_keys, GS_BLOCK * sort_rounds_for(n_keys));
     const int32_t *totals = (const int32_t *)workspace + ((size_t)nblk << RB);
     hipLaunchKernelGGL(sort_local_kernel, dim3(1 << RB), dim3(LS_THREADS), 0, s, keys_alt, payload_alt, keys, payload,
-                       totals, bits - RB, part_shift, RB);
+                       totals, bits - RB, part_shift, RB, key_depth_bits, n_tiles, tile_start, tile_end);
     GS_CHECK_LAUNCH();
-    if (allow_result_in_alt) return 1;
+    const int ranges_written = tile_start != nullptr ? 2 : 0;
+    if (allow_result_in_alt) return 1 | ranges_written;
     GS_CHECK_HIP(hipMemcpyAsync(keys, keys_alt, sizeof(uint32_t) * n_keys, hipMemcpyDeviceToDevice, s));
     GS_CHECK_HIP(hipMemcpyAsync(payload, payload_alt, sizeof(int32_t) * n_keys, hipMemcpyDeviceToDevice, s));
-    return 0;
+    return ranges_written;
 }
 
 extern "C" {
@@ -488,13 +523,14 @@ int gs_sort_pairs(void *keys, int32_t *payload, void *keys_alt, int32_t *payload
                   const int32_t *n_keys_device, int key_depth_bits, int depth_bits, int tile_bits,
                   int allow_result_in_alt, void *workspace, void *stream) {
     return gs_sort_pairs_and_zero(keys, payload, keys_alt, payload_alt, n_keys, n_keys_device, key_depth_bits, depth_bits,
-                                  tile_bits, allow_result_in_alt, 0, workspace, nullptr, 0, stream);
+                                  tile_bits, allow_result_in_alt, 0, workspace, nullptr, 0, nullptr, nullptr, 0, stream);
 }
 
 int gs_sort_pairs_and_zero(void *keys, int32_t *payload, void *keys_alt, int32_t *payload_alt, int64_t n_keys,
                            const int32_t *n_keys_device, int key_depth_bits, int depth_bits, int tile_bits,
                            int allow_result_in_alt, int bins_in_any_order, void *workspace, void *also_zero,
-                           size_t also_zero_bytes, void *stream) {
+                           size_t also_zero_bytes, int32_t *tile_start, int32_t *tile_end, int n_tiles, void *stream) {
+    GS_REQUIRE((tile_start == nullptr) == (tile_end == nullptr) && n_tiles >= 0, "ranges");
     GS_REQUIRE(also_zero_bytes % 16 == 0 && ((uintptr_t)also_zero & 15) == 0, "also_zero must be 16-byte aligned");
     GS_REQUIRE(n_keys >= 0 && n_keys < 0x7fffffffLL, "n_keys must fit int32");
     GS_REQUIRE(depth_bits >= 0 && depth_bits <= 64 && tile_bits >= 0 && tile_bits <= 31, "bit ranges");
@@ -523,10 +559,14 @@ int gs_sort_pairs_and_zero(void *keys, int32_t *payload, void *keys_alt, int32_t
         if (m >= RADIX_BITS) {
             const int part_shift = grouped ? key_depth_bits : bits - m;
             uint32_t *k = (uint32_t *)keys, *ka = (uint32_t *)keys_alt;
+            // buckets of whole bins (the digit inside the bin field): the bucket-local sort knows every bin's range
+            int32_t *ts = part_shift >= key_depth_bits ? tile_start : nullptr, *te = ts ? tile_end : nullptr;
             return m == 8 ? sort_msd_first_rb<8>(k, payload, ka, payload_alt, n_keys, n_keys_device, bits, part_shift,
-                                                 allow_result_in_alt, workspace, s, also_zero, also_zero_bytes)
+                                                 allow_result_in_alt, workspace, s, also_zero, also_zero_bytes,
+                                                 key_depth_bits, n_tiles, ts, te)
                           : sort_msd_first_rb<9>(k, payload, ka, payload_alt, n_keys, n_keys_device, bits, part_shift,
-                                                 allow_result_in_alt, workspace, s, also_zero, also_zero_bytes);
+                                                 allow_result_in_alt, workspace, s, also_zero, also_zero_bytes,
+                                                 key_depth_bits, n_tiles, ts, te);
         }
         for (int sh = 0; sh < key_depth_bits + tile_bits; sh += RADIX_BITS) shifts[n_pass++] = sh;
         return sort_pairs_impl<uint32_t>((uint32_t *)keys, payload, (uint32_t *)keys_alt, payload_alt, n_keys,

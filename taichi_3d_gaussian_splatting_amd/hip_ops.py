@@ -294,28 +294,40 @@ def key_layout(near_plane: float, far_plane: float, depth_to_sort_key_scale: flo
 
 def sort_pairs(keys: torch.Tensor, payload: torch.Tensor, depth_bits: int, tile_bits: int,
                key_depth_bits: int = 0, in_place: bool = True, n_keys_device: Optional[torch.Tensor] = None,
-               ws: Optional[Workspaces] = None, bins_in_any_order: bool = False):
+               ws: Optional[Workspaces] = None, bins_in_any_order: bool = False, ranges: Optional[torch.Tensor] = None):
     """Stable sort of (keys, payload).  in_place=True: the inputs hold the result.  in_place=False: returns the
     (keys, payload) tensors that hold the result (the inputs or the ping-pong buffers: no copy back after an
     odd number of passes); the other pair is scratch.  bins_in_any_order: what a frame needs -- every bin's pairs
-    contiguous and stably sorted by depth, the bins themselves in the sort's own order (include/gsplat_hip.h)."""
+    contiguous and stably sorted by depth, the bins themselves in the sort's own order (include/gsplat_hip.h).
+    ranges: int32[2, number of bins] -- zero-filled here and, when the sort can (MSD-first path, buckets of whole bins),
+    filled with the bins' [start, end) ranges by the sort itself; with `ranges` the return value is
+    (keys, payload, ranges_were_written) and the caller runs ``tile_ranges`` only if they were not."""
     n = keys.shape[0]   # capacity when n_keys_device (an int32 device scalar holding the actual count) is given
+    if ranges is not None and (in_place or ranges.dtype != torch.int32 or ranges.dim() != 2 or ranges.shape[0] != 2):
+        raise ValueError("ranges: int32[2, bins], with in_place=False")
     if n <= 1:
+        if ranges is not None:
+            return keys, payload, False
         return None if in_place else (keys, payload)
     if keys.dtype != (torch.int64 if key_depth_bits == 0 else torch.int32):
         raise TypeError("key dtype does not match the key layout")
     dev = keys.device
+    if ranges is not None:
+        ranges.zero_()
     keys_alt = _scratch(ws, "keys_alt", n, keys.dtype, dev)
     payload_alt = torch.empty_like(payload)   # (either payload buffer may end up holding the result: not scratch)
     scratch = _scratch(ws, "sort", _lib.load().gs_sort_workspace_bytes(n), torch.uint8, dev)
     status = _lib.load().gs_sort_pairs_and_zero(ptr(keys), ptr(payload), ptr(keys_alt), ptr(payload_alt), n,
                                                 ptr(n_keys_device), int(key_depth_bits), int(depth_bits), int(tile_bits),
                                                 0 if in_place else 1, int(bool(bins_in_any_order)), ptr(scratch), None, 0,
-                                                current_stream(dev))
+                                                None if ranges is None else ranges[0].data_ptr(),
+                                                None if ranges is None else ranges[1].data_ptr(),
+                                                0 if ranges is None else ranges.shape[1], current_stream(dev))
     if status < 0:
         _lib.check(status, "gs_sort_pairs")
     if not in_place:
-        return (keys_alt, payload_alt) if status == 1 else (keys, payload)
+        out = (keys_alt, payload_alt) if status & 1 else (keys, payload)
+        return out + (bool(status & 2),) if ranges is not None else out
     return None
 
 

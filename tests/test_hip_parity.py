@@ -374,8 +374,9 @@ def test_radix_sort_with_bins_in_any_order(ops, n, depth_bits, tile_bits, shape)
         tile = rng.integers(0, 1 << tile_bits, size=n)
     keys = ((tile << depth_bits) + rng.integers(0, 1 << min(depth_bits, 7), size=n)).astype(np.uint64).astype(np.uint32)
     payload = rng.permutation(n).astype(np.int32)
-    k, p = ops.sort_pairs(dev(keys.view(np.int32)), dev(payload), depth_bits, tile_bits, depth_bits, in_place=False,
-                          bins_in_any_order=True)
+    ranges = torch.full((2, 1 << tile_bits), -7, dtype=torch.int32, device="cuda")
+    k, p, ranges_written = ops.sort_pairs(dev(keys.view(np.int32)), dev(payload), depth_bits, tile_bits, depth_bits,
+                                          in_place=False, bins_in_any_order=True, ranges=ranges)
     got_k, got_p = k.cpu().numpy().view(np.uint32), p.cpu().numpy()
     bins = got_k >> depth_bits
     runs = 1 + int((bins[1:] != bins[:-1]).sum())
@@ -384,7 +385,8 @@ def test_radix_sort_with_bins_in_any_order(ops, n, depth_bits, tile_bits, shape)
     order = np.argsort(keys, kind="stable")
     assert np.array_equal(got_k[by_bin], keys[order])
     assert np.array_equal(got_p[by_bin], payload[order])
-    # and the ranges of such a result are the ranges of the sorted one, bin by bin
+    # the ranges of such a result are the ranges of the sorted one, bin by bin -- from gs_tile_ranges and, where the
+    # MSD-first path ran on buckets of whole bins, from the sort itself (the same numbers)
     start, end = ops.tile_ranges(k, 1 << tile_bits, depth_bits)
     counts = np.bincount(tile, minlength=1 << tile_bits)
     assert np.array_equal((end - start).cpu().numpy(), counts)
@@ -392,6 +394,33 @@ def test_radix_sort_with_bins_in_any_order(ops, n, depth_bits, tile_bits, shape)
     probe = rng.choice(np.nonzero(counts)[0], size=min(64, int((counts > 0).sum())), replace=False)
     for b in probe:
         assert (bins[s_[b]:e_[b]] == b).all()
+    assert ranges_written == (tile_bits >= 8 and n < 9_000_000)
+    if ranges_written:
+        assert torch.equal(ranges[0], start) and torch.equal(ranges[1], end)
+    else:
+        assert not bool(ranges.any())   # zero-filled, left to gs_tile_ranges
+
+
+def test_radix_sort_writes_the_ranges_in_ascending_order_too(ops):
+    """Ascending output (bins_in_any_order off) with a partitioning digit inside the bin field: buckets are whole bins,
+    the sort writes the ranges; with the digit reaching into the depth field it leaves them to gs_tile_ranges."""
+    rng = np.random.default_rng(5)
+    for n, depth_bits, tile_bits, written in ((500_000, 9, 12, True), (500_000, 12, 6, False), (1, 9, 12, False),
+                                              (40_000, 9, 12, True)):
+        keys = rng.integers(0, 1 << (depth_bits + tile_bits), size=n).astype(np.uint32)
+        if n > 1000:
+            keys[: n // 50] = (3 << depth_bits) + 5     # a bucket with one heavy bin, one bucket of a single key
+            keys[n // 50] = ((1 << tile_bits) - 1) << depth_bits
+        payload = np.arange(n, dtype=np.int32)
+        ranges = torch.full((2, 1 << tile_bits), -7, dtype=torch.int32, device="cuda")
+        k, p, got = ops.sort_pairs(dev(keys.view(np.int32)), dev(payload), depth_bits, tile_bits, depth_bits, in_place=False,
+                                   ranges=ranges)
+        order = np.argsort(keys, kind="stable")
+        assert np.array_equal(k.cpu().numpy().view(np.uint32), keys[order]) and np.array_equal(p.cpu().numpy(), payload[order])
+        assert got == written
+        if got:
+            start, end = ops.tile_ranges(k, 1 << tile_bits, depth_bits)
+            assert torch.equal(ranges[0], start) and torch.equal(ranges[1], end)
 
 
 def test_find_tile_start_and_end_known_answer(ops):
