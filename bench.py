@@ -154,6 +154,9 @@ def main() -> None:
                     help="N > 1: 'owner' (default) = tile-row bands for the pixels + owner-sharded Gaussians with a routed "
                          "exchange (owner_sharding.py: nothing per-Gaussian is replicated); 'bands' / 'interleaved' = the "
                          "replicated point cloud of distributed.py")
+    ap.add_argument("--bin-shift", type=int, default=None,
+                    help="force the list layout (0 = per-tile keys, 1 = 2x2-tile bins, 2 = 4x4; default: the operator's own "
+                         "choice per frame) -- for A/B measurements of that choice")
     ap.add_argument("--no-pin", action="store_true",
                     help="leave the host threads where the scheduler puts them (default: all threads of the process on one "
                          "L3 complex of the GPU's NUMA node, taichi_3d_gaussian_splatting_amd/host_affinity.py)")
@@ -253,6 +256,8 @@ def main() -> None:
     # after the first frame (the stored quaternions are already normalised); `always_store_normalised_rotation` makes it
     # pay the write every frame, as training does (same memory contents).  --static-scene: the skip stays.
     op.always_store_normalised_rotation = not args.static_scene
+    if args.bin_shift is not None:
+        op.bin_shift = args.bin_shift
 
     def timed_run(warmup, steps):
         """-> (wall-clock ms per step, max over ranks; {median, p90, min} of the per-step HIP-event times)"""

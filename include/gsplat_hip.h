@@ -353,7 +353,10 @@ int gs_merge_rows(const int32_t *lists, int64_t list_stride_words, int capacity,
 /* ---- Multi-GPU with OWNER-SHARDED Gaussians (routed exchange on top of the tile-row bands; no reference counterpart).
  * Rank g owns a contiguous block of point-cloud rows, projects only those (gs_filter_compact / gs_preprocess on its block
  * with full-image ownership), and sends each projected 64-B record to the band(s) whose tile rows its tile box reaches:
- *   gs_route_count   : counts[b] = records this rank sends to band b (bands = equal blocks of rows_per_band tile rows)
+ *   gs_route_count   : counts[b] = records this rank sends to band b.  Bands = equal blocks of rows_per_band tile rows, or
+ *                      -- band_row_bounds != NULL, a HOST array of world + 1 non-decreasing tile rows from 0 to the number
+ *                      of tile rows -- band b = rows [bounds[b], bounds[b + 1]): boundaries that balance the bands' work
+ *                      on a scene whose Gaussians crowd into some rows (a band may be empty)
  *   gs_route_scatter : send float[world][capacity + 1][16]: chunk b = header slot {count as int32 bits} + the records for
  *                      band b in visible-list order; pos int32[world][n_visible_capacity] = slot (0-based, without the
  *                      header) of record i in chunk b, -1 = not sent there.  The chunks are exchanged with one all-to-all
@@ -369,9 +372,11 @@ int gs_merge_rows(const int32_t *lists, int64_t list_stride_words, int capacity,
  * follows it (the scatter reads the offsets the count left there). */
 size_t gs_route_workspace_bytes(int n_visible_capacity, int world);
 int gs_route_count(const float *attrs, const int32_t *num_keys, int n_visible_capacity, const int32_t *counters,
-                   int width, int height, int rows_per_band, int world, int32_t *counts, void *workspace, void *stream);
+                   int width, int height, int rows_per_band, int world, const int32_t *band_row_bounds, int32_t *counts,
+                   void *workspace, void *stream);
 int gs_route_scatter(const float *attrs, const int32_t *num_keys, int n_visible_capacity, const int32_t *counters,
-                     int width, int height, int rows_per_band, int world, int capacity, const int32_t *counts,
+                     int width, int height, int rows_per_band, int world, const int32_t *band_row_bounds, int capacity,
+                     const int32_t *counts,
                      float *send, int32_t *pos, void *workspace, void *stream);
 int gs_count_keys(const float *records, int n_slots, int chunk_slots, int width, int height, int tile_row_begin,
                   int tile_row_step, int tile_row_end, int bin_shift, int exact_tile_cull, float depth_scale,
@@ -480,6 +485,8 @@ typedef struct GsFrame {
     float *grad_xyz, *grad_features, *grad_xyz_visible, *grad_features_visible, *hook_compact;
     /* GS_FWD_COLOUR_ASYNC: a second stream of the same device and two events, all created by the caller */
     void *aux_stream, *aux_event_fork, *aux_event_join;
+    /* owner-sharded stages: HOST array of world + 1 tile rows (band b = rows [b, b + 1) of it), NULL = equal bands */
+    const int32_t *band_row_bounds;
 } GsFrame;
 size_t gs_frame_struct_bytes(void);   /* sizeof(GsFrame): a binding checks its mirror of the struct against it */
 int gs_frame_forward(GsFrame *frame, uint32_t stages, void *stream);

@@ -64,8 +64,8 @@ _SIGNATURES = {
     "gs_compact_rows": (_I, [_P, _P, _I, _I, _P, _P, _P, _P, _P]),
     "gs_merge_rows": (_I, [_P, _I64, _I, _P, _I, _I, _P, _P]),
     "gs_route_workspace_bytes": (_c.c_size_t, [_I, _I]),
-    "gs_route_count": (_I, [_P, _P, _I, _P, _I, _I, _I, _I, _P, _P, _P]),
-    "gs_route_scatter": (_I, [_P, _P, _I, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P]),
+    "gs_route_count": (_I, [_P, _P, _I, _P, _I, _I, _I, _I, _P, _P, _P, _P]),
+    "gs_route_scatter": (_I, [_P, _P, _I, _P, _I, _I, _I, _I, _P, _I, _P, _P, _P, _P, _P]),
     "gs_count_keys": (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _P, _P, _P, _P, _P, _P]),
     "gs_gather_returned_rows": (_I, [_P, _P, _I, _I, _I, _I, _P, _P]),
     "gs_loss_workspace_floats": (_c.c_longlong, [_I, _I]),

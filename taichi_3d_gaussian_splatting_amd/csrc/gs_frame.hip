@@ -58,11 +58,11 @@ static int frame_forward_stages(GsFrame *f, uint32_t stages, void *stream, bool 
     if (stages & (GS_FWD_ROUTE_COUNT | GS_FWD_ROUTE_SCATTER)) GS_JOIN_COLOURS();   // the routed records carry colours
     if (stages & GS_FWD_ROUTE_COUNT)
         GS_STAGE(gs_route_count(f->attrs, f->num_keys, f->n_points, f->counters, f->width, f->height, f->rows_per_band,
-                                f->world, f->route_counts, f->route_workspace, stream));
+                                f->world, f->band_row_bounds, f->route_counts, f->route_workspace, stream));
     if (stages & GS_FWD_ROUTE_SCATTER)
         GS_STAGE(gs_route_scatter(f->attrs, f->num_keys, f->n_points, f->counters, f->width, f->height, f->rows_per_band,
-                                  f->world, f->chunk_capacity, f->route_counts, f->route_send, f->route_pos,
-                                  f->route_workspace, stream));
+                                  f->world, f->band_row_bounds, f->chunk_capacity, f->route_counts, f->route_send,
+                                  f->route_pos, f->route_workspace, stream));
     // owner-sharded band side: the received records are the attrs array of every later stage
     const bool received = (stages & GS_FWD_COUNT_KEYS) != 0 || f->records != nullptr;
     const float *attrs = received ? f->records : f->attrs;

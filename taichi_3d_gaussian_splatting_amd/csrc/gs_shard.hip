@@ -174,21 +174,27 @@ constexpr int ROUTE_MAX_WORLD = 64;
 // bands [b0, b1] whose tile rows the Gaussian's tile box (RAS:81-103, shrunk to the alpha >= 1/255 level set's bounding box
 // when the exact cull is on: attrs[3] < inf) reaches.  The receiving band walks the same box, so nothing it would emit a
 // key for is missing.
-__device__ __forceinline__ bool route_bands(const float4 a0, const float4 a1, int tw, int th, int rows_per_band, int &b0,
-                                            int &b1) {
+// band g = tile rows [row[g], row[g + 1]); equal blocks, or boundaries that balance the bands' work (they may leave a band
+// empty).  Passed to the kernels by value.
+struct BandBounds { short row[ROUTE_MAX_WORLD + 1]; };
+
+__device__ __forceinline__ bool route_bands(const float4 a0, const float4 a1, int tw, int th, const BandBounds &bands,
+                                            int world, int &b0, int &b1) {
     int t0u, t1u, t0v, t1v;
     gs_tile_box(a0.x, a0.y, a1.w, tw, th, t0u, t1u, t0v, t1v);
     gs_cull_box(a0.x, a0.y, a1.x, a1.y, a1.z, a0.w, t0u, t1u, t0v, t1v);
     if (t1u <= t0u || t1v <= t0v) return false;
-    b0 = t0v / rows_per_band;
-    b1 = (t1v - 1) / rows_per_band;
+    b0 = 0;
+    while (b0 < world - 1 && bands.row[b0 + 1] <= t0v) ++b0;       // the band that holds tile row t0v
+    b1 = b0;
+    while (b1 < world - 1 && bands.row[b1 + 1] <= t1v - 1) ++b1;   // ... and the one that holds the last row
     return true;
 }
 
 template <bool SCATTER>
 __global__ __launch_bounds__(GS_BLOCK) void route_kernel(
     const float4 *__restrict__ attrs, const int32_t *__restrict__ num_keys, int m_capacity,
-    const int32_t *__restrict__ counters, int width, int height, int rows_per_band, int world, int nblk,
+    const int32_t *__restrict__ counters, int width, int height, BandBounds bands, int world, int nblk,
     int32_t *__restrict__ block_counts /* [world][nblk]: counts (SCATTER = false) / exclusive offsets (true) */,
     int capacity, float4 *__restrict__ send, int32_t *__restrict__ pos, const int32_t *__restrict__ counts) {
     __shared__ int s_cnt[GS_BLOCK / GS_WAVE][ROUTE_MAX_WORLD];
@@ -202,8 +208,7 @@ __global__ __launch_bounds__(GS_BLOCK) void route_kernel(
     if (i < m && num_keys[i] > 0) {   // (num_keys == 0: the record is incomplete and can contribute nowhere)
         rec[0] = attrs[4 * (size_t)i];
         rec[1] = attrs[4 * (size_t)i + 1];
-        if (!route_bands(rec[0], rec[1], width / GS_TILE_WIDTH, height / GS_TILE_HEIGHT, rows_per_band, b0, b1)) { b0 = 0; b1 = -1; }
-        b1 = min(b1, world - 1);
+        if (!route_bands(rec[0], rec[1], width / GS_TILE_WIDTH, height / GS_TILE_HEIGHT, bands, world, b0, b1)) { b0 = 0; b1 = -1; }
         if (SCATTER && b1 >= b0) { rec[2] = attrs[4 * (size_t)i + 2]; rec[3] = attrs[4 * (size_t)i + 3]; }
     }
     for (int b = 0; b < world; ++b) {
@@ -328,9 +333,26 @@ size_t gs_route_workspace_bytes(int n_visible_capacity, int world) {
     return sizeof(int32_t) * ((size_t)gs_div_up(n_visible_capacity > 0 ? n_visible_capacity : 1, GS_BLOCK) * (size_t)world + 64);
 }
 
+// the bands' boundaries as the kernels take them: equal blocks of rows_per_band tile rows, or the caller's world + 1 rows
+static int band_bounds(int height, int rows_per_band, int world, const int32_t *band_row_bounds, BandBounds &out) {
+    const int th = height / GS_TILE_HEIGHT;
+    GS_REQUIRE(th < 32768, "more than 32,767 tile rows");
+    for (int g = 0; g <= world; ++g) {
+        long long r = band_row_bounds ? band_row_bounds[g] : (long long)g * rows_per_band;
+        if (band_row_bounds)
+            GS_REQUIRE(r >= 0 && r <= th && (g == 0 ? r == 0 : r >= band_row_bounds[g - 1]) && (g < world || r == th),
+                       "band_row_bounds: world + 1 non-decreasing tile rows from 0 to the number of tile rows");
+        out.row[g] = (short)(r < th ? r : th);
+    }
+    return 0;
+}
+
 int gs_route_count(const float *attrs, const int32_t *num_keys, int n_visible_capacity, const int32_t *counters, int width,
-                   int height, int rows_per_band, int world, int32_t *counts, void *workspace, void *stream) {
+                   int height, int rows_per_band, int world, const int32_t *band_row_bounds, int32_t *counts,
+                   void *workspace, void *stream) {
     GS_REQUIRE(world >= 1 && world <= ROUTE_MAX_WORLD && rows_per_band >= 1 && n_visible_capacity >= 0, "sizes (world <= 64)");
+    BandBounds bands;
+    if (band_bounds(height, rows_per_band, world, band_row_bounds, bands) < 0) return -1;
     hipStream_t s = (hipStream_t)stream;
     if (n_visible_capacity == 0) {
         GS_CHECK_HIP(hipMemsetAsync(counts, 0, sizeof(int32_t) * world, s));
@@ -339,7 +361,7 @@ int gs_route_count(const float *attrs, const int32_t *num_keys, int n_visible_ca
     const int nblk = gs_div_up(n_visible_capacity, GS_BLOCK);
     int32_t *block_counts = (int32_t *)workspace;
     hipLaunchKernelGGL(route_kernel<false>, dim3(nblk), dim3(GS_BLOCK), 0, s, reinterpret_cast<const float4 *>(attrs),
-                       num_keys, n_visible_capacity, counters, width, height, rows_per_band, world, nblk, block_counts, 0,
+                       num_keys, n_visible_capacity, counters, width, height, bands, world, nblk, block_counts, 0,
                        (float4 *)nullptr, (int32_t *)nullptr, (const int32_t *)nullptr);
     GS_CHECK_LAUNCH();
     hipLaunchKernelGGL(route_scan_kernel, dim3(world), dim3(GS_BLOCK), 0, s, block_counts, nblk, counts);
@@ -348,10 +370,12 @@ int gs_route_count(const float *attrs, const int32_t *num_keys, int n_visible_ca
 }
 
 int gs_route_scatter(const float *attrs, const int32_t *num_keys, int n_visible_capacity, const int32_t *counters,
-                     int width, int height, int rows_per_band, int world, int capacity, const int32_t *counts, float *send,
-                     int32_t *pos, void *workspace, void *stream) {
+                     int width, int height, int rows_per_band, int world, const int32_t *band_row_bounds, int capacity,
+                     const int32_t *counts, float *send, int32_t *pos, void *workspace, void *stream) {
     GS_REQUIRE(world >= 1 && world <= ROUTE_MAX_WORLD && rows_per_band >= 1 && n_visible_capacity >= 0 && capacity >= 0,
                "sizes (world <= 64)");
+    BandBounds bands;
+    if (band_bounds(height, rows_per_band, world, band_row_bounds, bands) < 0) return -1;
     hipStream_t s = (hipStream_t)stream;
     if (n_visible_capacity == 0) {   // nothing to send: the headers alone
         hipLaunchKernelGGL(route_headers_kernel, dim3(1), dim3(ROUTE_MAX_WORLD), 0, s, counts, world, capacity,
@@ -361,7 +385,7 @@ int gs_route_scatter(const float *attrs, const int32_t *num_keys, int n_visible_
     }
     const int nblk = gs_div_up(n_visible_capacity, GS_BLOCK);
     hipLaunchKernelGGL(route_kernel<true>, dim3(nblk), dim3(GS_BLOCK), 0, s, reinterpret_cast<const float4 *>(attrs),
-                       num_keys, n_visible_capacity, counters, width, height, rows_per_band, world, nblk,
+                       num_keys, n_visible_capacity, counters, width, height, bands, world, nblk,
                        (int32_t *)workspace, capacity, reinterpret_cast<float4 *>(send), pos, counts);
     GS_CHECK_LAUNCH();
     return 0;

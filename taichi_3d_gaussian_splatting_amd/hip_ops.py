@@ -542,20 +542,31 @@ def point_backward(xyz, features, object_id, intrinsics, q_cp, t_cp, t_pc, ids, 
 
 
 # ---------------------------------------------------------------- owner-sharded Gaussians: routed exchange (multi-GPU)
-def route_count(attrs, num_keys, counters, width, height, rows_per_band: int, world: int):
+def _band_bounds_array(bounds, world: int):
+    """ctypes int32[world + 1] of the bands' tile-row boundaries (None: equal bands, NULL)."""
+    if bounds is None:
+        return None
+    if len(bounds) != world + 1:
+        raise ValueError("band boundaries: world + 1 tile rows")
+    return (ctypes.c_int32 * (world + 1))(*[int(b) for b in bounds])
+
+
+def route_count(attrs, num_keys, counters, width, height, rows_per_band: int, world: int, bounds=None):
     """-> (counts i32[world] on the device: records this rank sends to every band, workspace for route_scatter).
-    attrs / num_keys are capacity-sized, the visible count is read from ``counters`` on the device."""
+    attrs / num_keys are capacity-sized, the visible count is read from ``counters`` on the device.
+    bounds: world + 1 tile rows, band b = rows [bounds[b], bounds[b + 1]) (None: equal bands of rows_per_band rows)."""
     dev = attrs.device
     cap_m = attrs.shape[0]
     counts = torch.empty(world, dtype=torch.int32, device=dev)
     ws = torch.empty(_lib.load().gs_route_workspace_bytes(cap_m, world), dtype=torch.uint8, device=dev)
+    arr = _band_bounds_array(bounds, world)
     call("gs_route_count", ptr(attrs), ptr(num_keys), cap_m, ptr(counters), int(width), int(height), int(rows_per_band),
-         int(world), ptr(counts), ptr(ws), current_stream(dev))
+         int(world), None if arr is None else ctypes.addressof(arr), ptr(counts), ptr(ws), current_stream(dev))
     return counts, ws
 
 
 def route_scatter(attrs, num_keys, counters, width, height, rows_per_band: int, world: int, capacity: int, counts,
-                  workspace):
+                  workspace, bounds=None):
     """-> (send f32[world, capacity + 1, 16]: chunk b = header slot + this rank's records for band b in visible-list
     order; pos i32[world, M_capacity]: slot of record i in chunk b or -1).  Must follow ``route_count`` on the same
     inputs (it reads the offsets left in ``workspace``)."""
@@ -563,8 +574,10 @@ def route_scatter(attrs, num_keys, counters, width, height, rows_per_band: int, 
     cap_m = attrs.shape[0]
     send = torch.empty((world, capacity + 1, ATTR_STRIDE), dtype=torch.float32, device=dev)
     pos = torch.empty((world, max(cap_m, 1)), dtype=torch.int32, device=dev)
+    arr = _band_bounds_array(bounds, world)
     call("gs_route_scatter", ptr(attrs), ptr(num_keys), cap_m, ptr(counters), int(width), int(height), int(rows_per_band),
-         int(world), int(capacity), ptr(counts), ptr(send), ptr(pos), ptr(workspace), current_stream(dev))
+         int(world), None if arr is None else ctypes.addressof(arr), int(capacity), ptr(counts), ptr(send), ptr(pos),
+         ptr(workspace), current_stream(dev))
     return send, pos
 
 

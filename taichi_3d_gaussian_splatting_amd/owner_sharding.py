@@ -35,7 +35,7 @@ import torch
 import torch.distributed as dist
 
 from . import _lib, hip_ops
-from .distributed import padded_image_rows, uniform_band_rows
+from .distributed import band_boundaries, padded_image_rows, uniform_band_rows
 from .frame_path import Slab
 from .GaussianPointCloudRasterisation import GaussianPointCloudRasterisation as _Op
 
@@ -59,6 +59,7 @@ class _Frame:
         self.n_slots = self.n_keys = 0
         self.outputs = ()
         self.stats = {}
+        self.bounds_array = None                     # ctypes int32[world + 1]: weighted band boundaries (host)
 
 
 class OwnerShardedRasteriser:
@@ -83,16 +84,39 @@ class OwnerShardedRasteriser:
         self.always_store_normalised_rotation = False
         self.speculative_sizes = True
         self.split_small_grid_backward = True   # the band's backward pass gives a tile up to four workgroups (list splitting)
+        # per-tile-row weights that place the bands' boundaries (distributed.band_boundaries: band g ends where the running
+        # weight reaches (g + 1) / world of the total) -- THE SAME list on every rank.  None: equal bands.  A trained
+        # scene crowds its Gaussians into some rows: with equal bands the slowest of eight ranks took twice the fastest
+        # (``balanced_row_weights`` makes the list from the ranks' own walk lengths)
+        self.row_weights: Optional[Sequence[float]] = None
         self.speculation_stats = {"frames": 0, "redone": 0}
         self._size_guesses = {}
         self._scratch = hip_ops.Workspaces()
         self._readback = None
 
     # ------------------------------------------------------------------ geometry of the bands
+    def band_bounds(self, height: int) -> list:
+        """world + 1 tile rows: band g = rows [bounds[g], bounds[g + 1])."""
+        return band_boundaries(height // TILE, self.world, self.row_weights)
+
     def band_rows(self, height: int) -> range:
-        th = height // TILE
-        block = uniform_band_rows(th, self.world)
-        return range(min(self.rank * block, th), min((self.rank + 1) * block, th))
+        bounds = self.band_bounds(height)
+        return range(bounds[self.rank], bounds[self.rank + 1])
+
+    def row_work(self, fr: "_Frame") -> Optional[torch.Tensor]:
+        """f32[tile rows of the image] on the device: the list positions this rank's backward pass walks, summed per tile
+        row of its band (zeros elsewhere) -- after ``blend`` of a frame with state and ordered dispatch, else None.  Summed
+        over the ranks it is the weight list ``balanced_row_weights`` turns into boundaries."""
+        b = fr.band
+        if b is None or not b.tile_work or not b.need_state:
+            return None
+        rows = self.band_rows(fr.height)
+        cols = fr.width // TILE
+        out = torch.zeros(fr.height // TILE, dtype=torch.float32, device=fr.records.device)
+        if len(rows):
+            work = fr.band_slab.tensor("tile_work", torch.int32, (len(rows) * cols,))
+            out[rows.start:rows.stop] = work.view(len(rows), cols).sum(dim=1).to(torch.float32)
+        return out
 
     def _layout(self, height: int, sharded: bool) -> hip_ops.ListLayout:
         shift = self._auto_bin_shift if self.bin_shift is None else self.bin_shift
@@ -159,6 +183,9 @@ class OwnerShardedRasteriser:
         f.grad_q_factor, f.grad_s_factor, f.grad_alpha_factor = cfg.grad_q_factor, cfg.grad_s_factor, cfg.grad_alpha_factor
         f.grad_color_factor, f.grad_high_order_color_factor = cfg.grad_color_factor, cfg.grad_high_order_color_factor
         f.world, f.rows_per_band = world, uniform_band_rows(height // TILE, world)
+        if self.row_weights is not None:   # (a HOST array: read by the two routing calls only, kept alive by the frame)
+            fr.bounds_array = hip_ops._band_bounds_array(self.band_bounds(height), world)
+            f.band_row_bounds = ctypes.addressof(fr.bounds_array)
         f.xyz, f.features, f.invalid_mask, f.object_id = xyz.data_ptr(), features.data_ptr(), invalid.data_ptr(), obj.data_ptr()
         f.intrinsics, f.q_pointcloud_camera, f.t_pointcloud_camera = intrinsics.data_ptr(), q_pc.data_ptr(), t_pc.data_ptr()
         f.q_camera_pointcloud, f.t_camera_pointcloud = slab.ptr("q_cp"), slab.ptr("t_cp")
@@ -237,7 +264,7 @@ class OwnerShardedRasteriser:
                 slab.add("boundary", split)
         slab.allocate(dev)
         lib = _lib.load()
-        if gather_in_place:
+        if gather_in_place and self.row_weights is None:   # (weighted bands are unequal blocks: gathered through a packed buffer)
             rows = padded_image_rows(height, self.world)
             image = torch.empty((rows, width, 3), dtype=torch.float32, device=dev)[:height]
             depth = None if rgb_only else torch.empty((rows, width), dtype=torch.float32, device=dev)[:height]
@@ -437,6 +464,23 @@ class OwnerShardedRasteriser:
         return grad_xyz, grad_feat
 
 
+def balanced_row_weights(row_work: Sequence[float], world: int, current: Optional[Sequence[float]] = None,
+                         threshold: float = 1.15) -> Optional[list]:
+    """The per-tile-row weights for the NEXT frames' band boundaries: ``row_work`` (the ranks' ``row_work`` summed: list
+    positions walked per tile row) when the bands placed by ``current`` (None = equal bands) are out of balance by more
+    than ``threshold`` (heaviest band / mean band), else ``current`` itself -- moving the boundaries restarts the bands'
+    speculative sizes, so it is done only when it pays.  Every rank computes the same answer from the same numbers."""
+    work = [float(w) for w in row_work]
+    total = sum(work)
+    if total <= 0.0 or world <= 1:
+        return None if current is None else list(current)
+    bounds = band_boundaries(len(work), world, current)
+    heaviest = max(sum(work[bounds[g]:bounds[g + 1]]) for g in range(world))
+    if heaviest * world <= threshold * total:
+        return None if current is None else list(current)
+    return work
+
+
 def _chunk_capacity(max_count: int) -> int:
     """Slots per chunk for a largest count of ``max_count``: a multiple of 64 with one spare block (16-B aligned rows)."""
     return max(64, -(-int(max_count) // 64) * 64)
@@ -470,6 +514,12 @@ class OwnerShardedRasterisation(torch.nn.Module):
         self.core = OwnerShardedRasteriser(config, self.rank, self.world, backward_valid_point_hook)
         self.config = config
         self.last_frame_stats = {}
+        # every `rebalance_every`-th frame with state the ranks sum their per-tile-row walk lengths (one all-reduce of a
+        # few hundred floats + one host read) and move the band boundaries if the heaviest band carries more than
+        # `rebalance_threshold` times the mean (0 = equal bands for ever)
+        self.rebalance_every = 0
+        self.rebalance_threshold = 1.15
+        self._frames_with_state = 0
         outer = self
 
         class _fn(torch.autograd.Function):
@@ -490,7 +540,15 @@ class OwnerShardedRasterisation(torch.nn.Module):
                     image, depth, count = core.blend(f, received, need_state)
                     outs = [image] if core.config.rgb_only else [image, depth, count]
                     from .distributed import all_gather_tile_rows
-                    all_gather_tile_rows(outs, outer.rank, outer.world, outer.group)
+                    all_gather_tile_rows(outs, outer.rank, outer.world, outer.group, row_weights=core.row_weights)
+                    if need_state and outer.rebalance_every > 0:
+                        outer._frames_with_state += 1
+                        if outer._frames_with_state % outer.rebalance_every == 0:
+                            work = core.row_work(f)
+                            if work is not None:   # (the same on every rank: options and need_state agree)
+                                dist.all_reduce(work, op=dist.ReduceOp.SUM, group=outer.group)
+                                core.row_weights = balanced_row_weights(work.tolist(), outer.world, core.row_weights,
+                                                                        outer.rebalance_threshold)
                 outer.last_frame_stats = dict(f.stats, capacity=capacity, records_sent=int(host[outer.rank, :outer.world].sum()),
                                               bytes_sent_forward=int(send.numel() * 4))
                 ctx.frame = f if need_state else None
@@ -528,12 +586,13 @@ def owned_point_rows(n_points: int, rank: int, world: int) -> range:
 
 # ====================================================================== (b) all ranks in one process, in lockstep
 def simulate_frame(cores: Sequence[OwnerShardedRasteriser], inputs: Sequence, grad_image: Optional[torch.Tensor] = None,
-                   timings: Optional[dict] = None):
+                   timings: Optional[dict] = None, row_work: Optional[list] = None):
     """Plays one frame of ``len(cores)`` ranks on ONE device: every rank's four phases exactly as under
     torch.distributed, the exchanges as device copies between the ranks' buffers.  -> (image, depth, count, grads):
     the assembled frame and, when ``grad_image`` is given, per rank (grad_point_cloud, grad_point_cloud_features).
     timings (optional dict): filled with HIP-event times per rank and phase in ms -- what a rank's GPU does in a frame,
-    exchanges excluded."""
+    exchanges excluded.  row_work (optional list): receives the ranks' ``row_work`` summed (a float list per tile row, or
+    nothing when the frame kept no state) -- what ``balanced_row_weights`` turns into the next frames' boundaries."""
     world = len(cores)
     dev = inputs[0].point_cloud.device
 
@@ -555,6 +614,10 @@ def simulate_frame(cores: Sequence[OwnerShardedRasteriser], inputs: Sequence, gr
     outs = [timed("blend", g, lambda g=g: cores[g].blend(frames[g], received[g], grad_image is not None,
                                                           gather_in_place=False)) for g in range(world)]
     height = frames[0].height
+    if row_work is not None:
+        works = [cores[g].row_work(frames[g]) for g in range(world)]
+        if all(w is not None for w in works):
+            row_work[:] = torch.stack(works).sum(dim=0).tolist()
     image, depth, count = [torch.zeros_like(t) for t in outs[0]]
     for g in range(world):   # the all-gather of the bands
         rows = cores[g].band_rows(height)

@@ -68,3 +68,23 @@ def test_point_blocks_partition_the_cloud_in_rank_order():
             assert blocks[0].start == 0 and blocks[-1].stop == n
             assert all(a.stop == b.start for a, b in zip(blocks, blocks[1:]))
             assert max(len(b) for b in blocks) - min(len(b) for b in blocks) <= -(-n // world)
+
+
+def test_balanced_row_weights_move_the_boundaries_only_when_it_pays():
+    """The boundaries of the owner-sharded bands follow the ranks' summed walk lengths per tile row -- only when the
+    heaviest band carries more than the threshold times the mean (moving them restarts the bands' speculative sizes)."""
+    from taichi_3d_gaussian_splatting_amd.distributed import band_boundaries
+    from taichi_3d_gaussian_splatting_amd.owner_sharding import balanced_row_weights
+    rows, world = 67, 8
+    bell = [1000.0 * 2.718281828 ** (-((r - 33) / 12.0) ** 2) for r in range(rows)]     # a trained scene: crowded middle rows
+    assert balanced_row_weights([1.0] * rows, world) is None                            # even work: equal bands stay
+    assert balanced_row_weights([0.0] * rows, world) is None and balanced_row_weights(bell, 1) is None
+    new = balanced_row_weights(bell, world)
+    assert new == bell
+    equal, moved = band_boundaries(rows, world), band_boundaries(rows, world, new)
+    load = lambda b: max(sum(bell[b[g]:b[g + 1]]) for g in range(world)) * world / sum(bell)   # noqa: E731
+    assert load(equal) > 1.9 and load(moved) < 1.25
+    assert moved[0] == 0 and moved[-1] == rows and all(a <= b for a, b in zip(moved, moved[1:]))
+    assert balanced_row_weights(bell, world, current=new) == new                        # balanced now: nothing moves
+    drifted = [w * (1.0 + 0.02 * (r % 3)) for r, w in enumerate(bell)]
+    assert balanced_row_weights(drifted, world, current=new) == new                     # ... nor for a few per cent

@@ -50,13 +50,14 @@ def _unsharded(s, g, bin_shift=None):
     return image.detach(), depth.detach(), count, inp.point_cloud.grad, inp.point_cloud_features.grad, hooks[0], inp
 
 
-def _sharded(s, g, world, bin_shift=None, frames=1):
+def _sharded(s, g, world, bin_shift=None, frames=1, row_weights=None):
     from taichi_3d_gaussian_splatting_amd.owner_sharding import OwnerShardedRasteriser, owned_point_rows, simulate_frame
     n = s.point_cloud.shape[0]
     hooks = [[] for _ in range(world)]
     cores = [OwnerShardedRasteriser(_config(s), r, world, backward_valid_point_hook=hooks[r].append) for r in range(world)]
     for c in cores:
         c.bin_shift = bin_shift
+        c.row_weights = row_weights
     blocks = [owned_point_rows(n, r, world) for r in range(world)]
     for _ in range(frames):
         inputs = [_inputs(s, blocks[r], requires_grad=False) for r in range(world)]
@@ -66,9 +67,9 @@ def _sharded(s, g, world, bin_shift=None, frames=1):
     return image, depth, count, grads, [h[0] for h in hooks], blocks, inputs
 
 
-def _compare(s, g, world, bin_shift=None, frames=1, exact_grads=False):
+def _compare(s, g, world, bin_shift=None, frames=1, exact_grads=False, row_weights=None):
     base = _unsharded(s, g, bin_shift)
-    image, depth, count, grads, hooks, blocks, inputs = _sharded(s, g, world, bin_shift, frames)
+    image, depth, count, grads, hooks, blocks, inputs = _sharded(s, g, world, bin_shift, frames, row_weights)
     assert torch.equal(base[0], image) and torch.equal(base[1], depth) and torch.equal(base[2], count)
     gx = torch.cat([gr[0] for gr in grads])
     gf = torch.cat([gr[1] for gr in grads])
@@ -92,10 +93,10 @@ def _compare(s, g, world, bin_shift=None, frames=1, exact_grads=False):
     mag = torch.cat([h.magnitude_grad_viewspace for h in hooks])
     assert torch.allclose(mag, hb.magnitude_grad_viewspace, rtol=1e-4, atol=1e-12)
     # a rank's magnitude image is its band of the un-sharded one
-    th = s.height // 16
+    from taichi_3d_gaussian_splatting_amd.distributed import band_boundaries
+    bounds = band_boundaries(s.height // 16, world, row_weights)
     for r, h in enumerate(hooks):
-        block = -(-th // world)
-        sl = slice(min(r * block, th) * 16, min((r + 1) * block, th) * 16)
+        sl = slice(bounds[r] * 16, bounds[r + 1] * 16)
         assert torch.equal(h.magnitude_grad_viewspace_on_image[sl], hb.magnitude_grad_viewspace_on_image[sl])
     return base, (image, depth, count, gx, gf)
 
@@ -108,6 +109,62 @@ def test_owner_sharded_frame_equals_unsharded(world, height, bin_shift):
     s = make_scene(n=9000, height=height, width=160, s_min=0.01, s_max=0.08, seed=5, invalid_fraction=0.05).to(dev)
     g = make_grad_image(height, 160).to(dev)
     _compare(s, g, world, bin_shift, exact_grads=(world == 1))
+
+
+@pytest.mark.parametrize("world,weights", [
+    (4, [1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 30, 30, 1, 1, 1, 1]),      # the middle rows carry the work: short bands there
+    (3, [0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 5, 5, 5]),        # everything at the bottom: leading bands of no rows at all
+    (8, [3, 1, 4, 1, 5, 9, 2, 6, 5, 3, 5, 8, 9, 7, 9, 3]),
+])
+def test_owner_sharded_frame_with_balanced_bands_equals_unsharded(world, weights):
+    """Band boundaries placed by per-tile-row weights (`row_weights`: bands of unequal height, some of them empty) -- the
+    assembled frame is still the un-sharded one bit for bit, gradients and hook fields at the usual bars."""
+    from taichi_3d_gaussian_splatting_amd.distributed import band_boundaries
+    from taichi_3d_gaussian_splatting_amd.synthetic import make_grad_image, make_scene
+    dev = torch.device("cuda", 0)
+    s = make_scene(n=9000, height=256, width=160, s_min=0.01, s_max=0.08, seed=6, invalid_fraction=0.05).to(dev)
+    g = make_grad_image(256, 160).to(dev)
+    bounds = band_boundaries(16, world, weights)
+    assert bounds != band_boundaries(16, world)
+    _compare(s, g, world, None, frames=2, row_weights=[float(w) for w in weights])
+
+
+def test_owner_sharded_bands_follow_the_work():
+    """The rebalancing loop of OwnerShardedRasterisation, played in one process: the ranks' walk lengths per tile row
+    (`row_work`, summed) move the boundaries of a scene that crowds into the lower half of the image; the heaviest band's
+    share drops, the frame stays the un-sharded one bit for bit, and a second look leaves the boundaries where they are."""
+    from taichi_3d_gaussian_splatting_amd.distributed import band_boundaries
+    from taichi_3d_gaussian_splatting_amd.owner_sharding import (OwnerShardedRasteriser, balanced_row_weights, owned_point_rows,
+                                                                  simulate_frame)
+    from taichi_3d_gaussian_splatting_amd.synthetic import make_grad_image, make_scene
+    dev = torch.device("cuda", 0)
+    s = make_scene(n=12000, height=320, width=160, s_min=0.01, s_max=0.06, seed=9).to(dev)
+    s.point_cloud[:, 1] = s.point_cloud[:, 1].abs() * 0.9 + 0.05     # (y down: everything in the lower half of the frame)
+    g = make_grad_image(320, 160).to(dev)
+    base = _unsharded(s, g)
+    world, rows = 4, 320 // 16
+    cores = [OwnerShardedRasteriser(_config(s), r, world) for r in range(world)]
+    for c in cores:
+        c.bin_shift = 0   # (per-tile lists: a tile's walk length is then a property of the tile alone)
+    blocks = [owned_point_rows(s.point_cloud.shape[0], r, world) for r in range(world)]
+    work = []
+    for _ in range(2):
+        image, depth, count, _ = simulate_frame(cores, [_inputs(s, b, requires_grad=False) for b in blocks], g, row_work=work)
+    assert len(work) == rows and sum(work[: rows // 4]) == 0 and sum(work[rows // 2:]) > 0.8 * sum(work) > 0
+    share = lambda b: max(sum(work[b[k]:b[k + 1]]) for k in range(world)) / sum(work)   # noqa: E731
+    weights = balanced_row_weights(work, world)
+    assert weights is not None and share(band_boundaries(rows, world, weights)) < 0.75 * share(band_boundaries(rows, world))
+    for c in cores:
+        c.row_weights = weights
+    work2 = []
+    for _ in range(2):
+        image, depth, count, grads = simulate_frame(cores, [_inputs(s, b, requires_grad=False) for b in blocks], g,
+                                                    row_work=work2)
+    assert torch.equal(base[0], image) and torch.equal(base[1], depth) and torch.equal(base[2], count)
+    gf = torch.cat([gr[1] for gr in grads])
+    assert float((base[4] - gf).abs().max()) <= SHARD_GRAD_TOL * float(base[4].abs().max())
+    assert work2 == work                                             # the walk lengths are the tiles', not the bands'
+    assert balanced_row_weights(work2, world, current=weights) == weights
 
 
 def test_owner_sharded_second_frame_and_large_gaussians():

@@ -4,7 +4,9 @@
 / sort / blend of the records it receives, backward of its band, gather of the returned rows, per-point backward of its
 own rows -- the two all-to-alls and the all-gather as device copies), and each rank's phases are timed with HIP events.
 What is NOT in a rank's time: the wire (computed from the byte counts printed here) and the host's size reads.
-usage: python tools/owner_shard_bench.py [workload] ;  GS_SHARD_WORLDS=1,2,4,8  GS_BIN_SHIFT=n  GS_SHARD_REPS=10"""
+usage: python tools/owner_shard_bench.py [workload] ;  GS_SHARD_WORLDS=1,2,4,8  GS_BIN_SHIFT=n  GS_SHARD_REPS=10
+GS_SHARD_BALANCE=1: after the warm-up frames the band boundaries are moved to balance the ranks' walk lengths
+(owner_sharding.balanced_row_weights), as OwnerShardedRasterisation.rebalance_every does under torch.distributed"""
 import os
 import sys
 
@@ -13,7 +15,8 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from taichi_3d_gaussian_splatting_amd import CameraInfo, GaussianPointCloudRasterisation as Op  # noqa: E402
 from taichi_3d_gaussian_splatting_amd import host_affinity  # noqa: E402
-from taichi_3d_gaussian_splatting_amd.owner_sharding import OwnerShardedRasteriser, owned_point_rows, simulate_frame  # noqa: E402
+from taichi_3d_gaussian_splatting_amd.owner_sharding import (OwnerShardedRasteriser, balanced_row_weights,  # noqa: E402
+                                                               owned_point_rows, simulate_frame)
 from taichi_3d_gaussian_splatting_amd.synthetic import make_config_scene, make_grad_image  # noqa: E402
 
 if os.environ.get("GS_NO_PIN") != "1":
@@ -40,6 +43,15 @@ for G in tuple(int(x) for x in os.environ.get("GS_SHARD_WORLDS", "1,2,4,8").spli
         t_pointcloud_camera=s.t_pointcloud_camera, color_max_sh_band=3) for r, b in enumerate(blocks)]
     for _ in range(3):
         simulate_frame(cores, inputs, g)
+    if os.environ.get("GS_SHARD_BALANCE") == "1":
+        for _ in range(2):   # (a second look with the new boundaries in force: stays put when they are balanced)
+            work = []
+            simulate_frame(cores, inputs, g, row_work=work)
+            weights = balanced_row_weights(work, G, cores[0].row_weights) if work else None
+            for c in cores:
+                c.row_weights = weights
+            for _ in range(3):
+                simulate_frame(cores, inputs, g)
     per_rank = {}
     last = None
     for _ in range(reps):
@@ -60,4 +72,5 @@ for G in tuple(int(x) for x in os.environ.get("GS_SHARD_WORLDS", "1,2,4,8").spli
           f"{min(sent)}..{max(sent)} (visible {min(last['visible'])}..{max(last['visible'])}), "
           f"wire per rank forward {G * (cap + 1) * 64 / 1e6:.2f} MB padded / {max(sent) * 64 / 1e6:.2f} MB of records, "
           f"backward {G * (cap + 1) * 48 / 1e6:.2f} / {max(sent) * 48 / 1e6:.2f} MB; "
-          f"band keys {[f['keys'] for f in last['frames']]}, bin_shift {[f['bin_shift'] for f in last['frames']]}", flush=True)
+          f"band keys {[f['keys'] for f in last['frames']]}, bin_shift {[f['bin_shift'] for f in last['frames']]}, "
+          f"band rows {cores[0].band_bounds(s.height)}", flush=True)
