@@ -203,6 +203,11 @@ class GaussianPointCloudTrainer:
         # the controller's work -- and the rasteriser routes projected records / accumulator rows between the ranks
         # (owner_sharding.py): nothing per-Gaussian is replicated
         distributed_mode: str = "replicated"
+        # "owner" mode: every this-many iterations the ranks sum their walk lengths per tile row and move the band
+        # boundaries if the heaviest band carries more than 1.15x the mean (owner_sharding.balanced_row_weights); 0 = equal
+        # bands.  One view's weights place the boundaries for the following views too: scenes crowd the same rows from
+        # most cameras of a capture
+        owner_rebalance_every: int = 100
         cache_dataset_on_device: bool = True      # keep the decoded training images in HBM (DeviceResidentSamples)
         device_cache_max_gb: float = 128.0        # ... unless they would need more than this; then stream them
 
@@ -262,6 +267,7 @@ class GaussianPointCloudTrainer:
             from .owner_sharding import OwnerShardedRasterisation
             module = OwnerShardedRasterisation(config.rasterisation_config,
                                                backward_valid_point_hook=self.adaptive_controller.update)
+            module.rebalance_every = int(config.owner_rebalance_every)
             self.rasterisation = _OwnerRasterisationFacade(module)
         else:
             self.rasterisation = GaussianPointCloudRasterisation(

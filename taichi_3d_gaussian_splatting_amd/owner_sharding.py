@@ -95,9 +95,26 @@ class OwnerShardedRasteriser:
         self._readback = None
 
     # ------------------------------------------------------------------ geometry of the bands
+    def weights_for(self, height: int) -> Optional[list]:
+        """``row_weights`` for an image of ``height`` pixels: the list itself, or -- measured on a frame of another height
+        (the 4x / 2x down-sampled iterations of a training run, TRN:139-148) -- the same density over the image height
+        re-binned to this frame's tile rows (plain arithmetic on the list: the same on every rank)."""
+        w, th = self.row_weights, height // TILE
+        if w is None or len(w) == th:
+            return None if w is None else list(w)
+        n, out = len(w), []
+        for r in range(th):
+            a, b, acc = r * n / th, (r + 1) * n / th, 0.0
+            k = int(a)
+            while k < n and k < b:
+                acc += float(w[k]) * (min(b, k + 1) - max(a, k))
+                k += 1
+            out.append(acc)
+        return out
+
     def band_bounds(self, height: int) -> list:
         """world + 1 tile rows: band g = rows [bounds[g], bounds[g + 1])."""
-        return band_boundaries(height // TILE, self.world, self.row_weights)
+        return band_boundaries(height // TILE, self.world, self.weights_for(height))
 
     def band_rows(self, height: int) -> range:
         bounds = self.band_bounds(height)
@@ -540,14 +557,16 @@ class OwnerShardedRasterisation(torch.nn.Module):
                     image, depth, count = core.blend(f, received, need_state)
                     outs = [image] if core.config.rgb_only else [image, depth, count]
                     from .distributed import all_gather_tile_rows
-                    all_gather_tile_rows(outs, outer.rank, outer.world, outer.group, row_weights=core.row_weights)
+                    all_gather_tile_rows(outs, outer.rank, outer.world, outer.group,
+                                         row_weights=core.weights_for(image.shape[0]))
                     if need_state and outer.rebalance_every > 0:
                         outer._frames_with_state += 1
                         if outer._frames_with_state % outer.rebalance_every == 0:
                             work = core.row_work(f)
                             if work is not None:   # (the same on every rank: options and need_state agree)
                                 dist.all_reduce(work, op=dist.ReduceOp.SUM, group=outer.group)
-                                core.row_weights = balanced_row_weights(work.tolist(), outer.world, core.row_weights,
+                                core.row_weights = balanced_row_weights(work.tolist(), outer.world,
+                                                                        core.weights_for(image.shape[0]),
                                                                         outer.rebalance_threshold)
                 outer.last_frame_stats = dict(f.stats, capacity=capacity, records_sent=int(host[outer.rank, :outer.world].sum()),
                                               bytes_sent_forward=int(send.numel() * 4))

@@ -150,7 +150,7 @@ def _owner_train_worker(rank, world, port, root):
             half_downsample_factor_interval=30, log_loss_interval=10, log_metrics_interval=10 ** 6,
             log_image_interval=10 ** 6, log_validation_image=False,
             summary_writer_log_dir=os.path.join(root, f"owner_logs_rank{rank}"), num_data_loader_workers=0,
-            distributed_mode="owner")
+            distributed_mode="owner", owner_rebalance_every=7)   # (boundaries move while the resolution changes)
         cfg.adaptive_controller_config.num_iterations_warm_up = 20      # densify at 20 and 40
         cfg.adaptive_controller_config.num_iterations_densify = 20
         cfg.gaussian_point_cloud_scene_config.max_num_points_ratio = 2.0

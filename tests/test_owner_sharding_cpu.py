@@ -88,3 +88,22 @@ def test_balanced_row_weights_move_the_boundaries_only_when_it_pays():
     assert balanced_row_weights(bell, world, current=new) == new                        # balanced now: nothing moves
     drifted = [w * (1.0 + 0.02 * (r % 3)) for r, w in enumerate(bell)]
     assert balanced_row_weights(drifted, world, current=new) == new                     # ... nor for a few per cent
+
+
+def test_row_weights_follow_a_change_of_resolution():
+    """Weights measured on a frame of one height place the bands of a frame of another height (the down-sampled
+    iterations of a training run): the density over the image is re-binned, its total and its shape are kept."""
+    from taichi_3d_gaussian_splatting_amd import GaussianPointCloudRasterisation as Op
+    from taichi_3d_gaussian_splatting_amd.owner_sharding import OwnerShardedRasteriser
+    core = OwnerShardedRasteriser(Op.GaussianPointCloudRasterisationConfig(), 1, 4)
+    assert core.weights_for(320) is None and core.band_bounds(320) == [0, 5, 10, 15, 20]
+    core.row_weights = [0.0] * 10 + [4.0] * 10                       # measured at 20 tile rows: the lower half carries it all
+    assert core.weights_for(320) == core.row_weights
+    for height in (160, 640, 16 * 7, 16 * 33):
+        w = core.weights_for(height)
+        th = height // 16
+        assert len(w) == th and abs(sum(w) - 40.0) < 1e-9
+        assert sum(w[: th // 2]) <= 40.0 / th + 1e-9                 # (an odd row count shares one row between the halves)
+        bounds = core.band_bounds(height)
+        assert bounds[0] == 0 and bounds[-1] == th and bounds[1] >= th // 2
+    assert core.band_rows(320) == range(13, 15)

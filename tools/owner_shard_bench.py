@@ -47,7 +47,7 @@ for G in tuple(int(x) for x in os.environ.get("GS_SHARD_WORLDS", "1,2,4,8").spli
         for _ in range(2):   # (a second look with the new boundaries in force: stays put when they are balanced)
             work = []
             simulate_frame(cores, inputs, g, row_work=work)
-            weights = balanced_row_weights(work, G, cores[0].row_weights) if work else None
+            weights = balanced_row_weights(work, G, cores[0].weights_for(s.height)) if work else None
             for c in cores:
                 c.row_weights = weights
             for _ in range(3):
