@@ -215,7 +215,8 @@ constexpr int LS_THREADS = 1024;
 constexpr int LS_WAVES = LS_THREADS / GS_WAVE;
 constexpr int LS_ROUNDS = 16;                        // pairs per thread
 constexpr int LS_CAP = LS_THREADS * LS_ROUNDS;       // pairs of a chunk
-constexpr int LS_MAX_RADIX = 256;
+constexpr int LS_BITS = 6;                           // bits per bucket-local pass (64 digits = the lanes of a wave)
+constexpr int LS_MAX_RADIX = 1 << LS_BITS;
 
 // exclusive scan of `v` over the 1,024 threads of the workgroup into `ex` (two barriers).  A macro over the LDS array
 // itself: handed to a function as a pointer the array loses its address space, and this compiler then emits a flat-address
@@ -245,6 +246,7 @@ __global__ __launch_bounds__(LS_THREADS) void sort_local_kernel(uint32_t *__rest
     __shared__ int s_dbase[LS_MAX_RADIX];               // bucket-wide start of each digit (chunked buckets)
     __shared__ int s_drun[LS_MAX_RADIX];                // keys of the digit written by earlier chunks
     __shared__ int s_ccnt[LS_MAX_RADIX];                // the chunk's keys of each digit
+    __shared__ unsigned long long s_reg[LS_WAVES][LS_MAX_RADIX];   // per wave and digit: the lanes that hold it this round
     __shared__ int s_wave[2 * LS_WAVES];                // scratch of the block scans
     __shared__ int s_misc[2];
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -276,8 +278,8 @@ __global__ __launch_bounds__(LS_THREADS) void sort_local_kernel(uint32_t *__rest
     const uint32_t below = (1u << part_shift) - 1u;
     const int above_shift = part_shift + part_bits;
 #define LS_REST(k) ((above_shift >= 32 ? 0u : ((k) >> above_shift) << part_shift) | ((k) & below))
-    const int npass = (low_bits + 7) / 8;
-    const int lbits = (low_bits + npass - 1) / npass;   // <= 8 bits per pass, passes of equal width
+    const int npass = (low_bits + LS_BITS - 1) / LS_BITS;
+    const int lbits = (low_bits + npass - 1) / npass;   // <= 6 bits per pass, passes of equal width
     const int radix = 1 << lbits;
     const bool in_lds = nb <= LS_CAP;
     uint32_t *src_k = keys + start, *dst_k = keys_tmp + start;
@@ -289,6 +291,8 @@ __global__ __launch_bounds__(LS_THREADS) void sort_local_kernel(uint32_t *__rest
     // (an LDS-qualified pointer: through a generic volatile pointer this compiler emits a flat-address null check it cannot
     // encode -- "Illegal instruction detected: V_CMP_NE_U32 0, src_shared_base")
 #define LS_CNT(d) (*(volatile __attribute__((address_space(3))) int *)(&s_cnt[w][d]))
+#define LS_REG(d) (*(volatile __attribute__((address_space(3))) unsigned long long *)(&s_reg[w][d]))
+    LS_REG(lane) = 0ull;   // (64 digits = 64 lanes; every round's leader leaves its word zero again)
     for (int pass = 0; pass < npass; ++pass) {
         const int shift = pass * lbits;
         const unsigned dmask = (unsigned)radix - 1u;   // (LS_REST has low_bits bits)
@@ -328,18 +332,20 @@ __global__ __launch_bounds__(LS_THREADS) void sort_local_kernel(uint32_t *__rest
                     const int p = w * seg + r * GS_WAVE + lane;
                     const bool valid = p < cn;
                     const unsigned d = (LS_REST(key[r]) >> shift) & dmask;
-                    unsigned long long peers = __ballot(valid);   // 64-lane match-any on the digit
-#pragma unroll
-                    for (int b = 0; b < 8; ++b) {
-                        if (b < lbits) {
-                            const bool bit = (d >> b) & 1u;
-                            const unsigned long long m = __ballot(bit);
-                            peers &= bit ? m : ~m;
-                        }
-                    }
+                    // 64-lane match-any on the digit through LDS: every lane ORs its bit into its digit's word, then
+                    // reads the word back -- the lanes of the wave that hold the same digit.  OR commutes, so the word does
+                    // not depend on the order in which the LDS serves the lanes; a wave's LDS operations execute in
+                    // program order, so all bits are in before the first read.  (The scatter kernel's eight ballots with
+                    // their per-lane 64-bit selects cost ~45 VALU instructions per round here and made this kernel
+                    // VALU-bound: 2,575 -> see profiles/r04_sort.md.)
+                    if (valid) __hip_atomic_fetch_or(&s_reg[w][d], 1ull << lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    const unsigned long long peers = valid ? LS_REG(d) : 0ull;
                     const int rank = gs_mbcnt(peers);
                     const int before = valid ? LS_CNT(d) : 0;                       // every lane of a group reads ...
-                    if (valid && rank == 0) LS_CNT(d) = before + __popcll(peers);   // ... before its leader bumps the counter
+                    if (valid && rank == 0) {
+                        LS_CNT(d) = before + __popcll(peers);   // ... before its leader bumps the counter
+                        LS_REG(d) = 0ull;                       // ... and clears the word for the next round
+                    }
                     rnk[r] = valid ? before + rank : -1;
                 }
             }
@@ -420,6 +426,7 @@ __global__ __launch_bounds__(LS_THREADS) void sort_local_kernel(uint32_t *__rest
 #undef LS_EMIT_RANGE
 #undef LS_REST
 #undef LS_CNT
+#undef LS_REG
 #undef LS_BLOCK_EXCL_SCAN
 }
 
