@@ -200,9 +200,18 @@ def test_random_scene_against_the_oracle(case):
         assert np.isfinite(gx).all() and np.isfinite(gf).all(), tag
         invisible = np.setdiff1d(np.arange(gx.shape[0]), f["ids"])
         assert not gx[invisible].any() and not gf[invisible].any(), tag
+        # A pixel that flipped above the fragile margin (admitted above) carries its upstream gradient: the two
+        # implementations then differ by a DISCRETE term in the gradients.  Which of them took the better decision is for the
+        # float64 build to say (case 4277: one pixel of a Gaussian 103 pixels in radius -- the fp32 ORACLE is the one that
+        # flipped, 5.1e-4 from the spec, the operator 1.8e-5), so such a draw is held to the yardstick of the
+        # ill-conditioned scenes: as close to the spec as the fp32 oracle is.
+        ref64 = ob64
+        if not needles and worst.get("flips", 0.0) > 0:
+            spec_ = oracle_forward(scene, precision="f64")
+            ref64 = O.backward(spec_, g.astype(np.float64), band)
         for name, hip in (("grad_xyz", gx), ("grad_feat", gf)):
             if np.abs(ob[name]).max() > 0:
-                held(name, hip, ob[name], ob64[name] if needles else None, GRAD_TOL, tag, rel_l2)
+                held(name, hip, ob[name], ref64[name] if ref64 is not None else None, GRAD_TOL, tag, rel_l2)
         if hook is not None and len(f["ids"]) > 0:
             h, ho = got["h"], ob["hook"]
             assert np.array_equal(h.point_id_in_camera_list.cpu().numpy(), ho["point_id_in_camera_list"]), tag
