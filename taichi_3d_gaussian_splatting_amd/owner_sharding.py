@@ -537,6 +537,17 @@ class OwnerShardedRasterisation(torch.nn.Module):
         self.rebalance_every = 0
         self.rebalance_threshold = 1.15
         self._frames_with_state = 0
+        # the chunk capacity of the exchange is SPECULATED from the previous frame (15 % head-room, decaying 1 % per frame
+        # as the key capacities do): the gathered sizes travel to pinned memory behind an event while the host keeps
+        # launching pack, all-to-all and the band's stages, and are looked at where the host waits for the band's own sizes
+        # anyway -- no host stall before the exchange.  A frame whose records do not fit (gs_route_scatter drops what does
+        # not, the counts tell) repeats pack, exchange and blend with the exact capacity; every rank sees the same sizes
+        # and takes the same decision.  False: read the sizes first (one blocking read per frame)
+        self.speculative_capacity = True
+        self._capacity_guess = 0
+        self._sizes_host = None      # pinned int64[world, world + 1]
+        self._sizes_event = None
+        self.capacity_stats = {"frames": 0, "redone": 0}
         outer = self
 
         class _fn(torch.autograd.Function):
@@ -550,11 +561,32 @@ class OwnerShardedRasterisation(torch.nn.Module):
                     mine = torch.cat([f.counts.to(torch.int64), f.counters[:1].to(torch.int64)])
                     sizes = torch.empty((outer.world, outer.world + 1), dtype=torch.int64, device=mine.device)
                     dist.all_gather_into_tensor(sizes.view(-1), mine, group=outer.group)
-                    host = sizes.cpu()
-                    capacity = _chunk_capacity(int(host[:, :outer.world].max()))
-                    send = core.pack(f, capacity, int(host[outer.rank, outer.world]))
-                    received = _all_to_all_chunks(send, outer.group)
-                    image, depth, count = core.blend(f, received, need_state)
+                    speculate = outer.speculative_capacity and outer._capacity_guess > 0
+                    if speculate:
+                        if outer._sizes_host is None:
+                            outer._sizes_host = torch.empty((outer.world, outer.world + 1), dtype=torch.int64).pin_memory()
+                            outer._sizes_event = torch.cuda.Event()
+                        outer._sizes_host.copy_(sizes, non_blocking=True)
+                        outer._sizes_event.record(torch.cuda.current_stream(mine.device))
+                        capacity = outer._capacity_guess
+                        send = core.pack(f, capacity, -1)
+                        received = _all_to_all_chunks(send, outer.group)
+                        image, depth, count = core.blend(f, received, need_state)   # (ends waiting for the band's sizes)
+                        outer._sizes_event.synchronize()
+                        host = outer._sizes_host.clone()
+                    else:
+                        host = sizes.cpu()
+                    needed = int(host[:, :outer.world].max())
+                    outer.capacity_stats["frames"] += 1
+                    if not speculate or needed > capacity:   # first frame, or the records outgrew the speculated chunks
+                        outer.capacity_stats["redone"] += 1 if speculate else 0
+                        capacity = _chunk_capacity(needed)
+                        send = core.pack(f, capacity, int(host[outer.rank, outer.world]))
+                        received = _all_to_all_chunks(send, outer.group)
+                        image, depth, count = core.blend(f, received, need_state)
+                    f.n_visible = int(host[outer.rank, outer.world])
+                    outer._capacity_guess = max(_chunk_capacity(int(1.15 * needed) + 64),
+                                                _chunk_capacity(int(0.99 * outer._capacity_guess)))
                     outs = [image] if core.config.rgb_only else [image, depth, count]
                     from .distributed import all_gather_tile_rows
                     all_gather_tile_rows(outs, outer.rank, outer.world, outer.group,

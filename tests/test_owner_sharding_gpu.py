@@ -237,6 +237,18 @@ def _worker(rank, world, port, height):
         for a, b in ((base[3][sl], inp.point_cloud.grad), (base[4][sl], inp.point_cloud_features.grad)):
             assert float((a - b).abs().max()) <= SHARD_GRAD_TOL * float(base[4].abs().max())
         assert op.last_frame_stats["records_sent"] > 0
+        # the second frame ran on the chunk capacity speculated from the first (no blocking size read before the exchange)
+        assert op.capacity_stats == {"frames": 2, "redone": 0} and op._capacity_guess >= op.last_frame_stats["capacity"]
+        # a frame whose records outgrow the speculated chunks repeats pack, exchange and blend with the exact capacity --
+        # every rank takes the decision from the same gathered sizes -- and comes out the same
+        op._capacity_guess = 64
+        inp = _inputs(s, rows)
+        image, depth, count = op(inp)
+        image.backward(g)
+        assert op.capacity_stats == {"frames": 3, "redone": 1} and op.last_frame_stats["capacity"] > 64
+        assert torch.equal(base[0], image.detach()) and torch.equal(base[1], depth.detach()) and torch.equal(base[2], count)
+        for a, b in ((base[3][sl], inp.point_cloud.grad), (base[4][sl], inp.point_cloud_features.grad)):
+            assert float((a - b).abs().max()) <= SHARD_GRAD_TOL * float(base[4].abs().max())
         # under no_grad the forward alone (inference): the same image
         with torch.no_grad():
             image2 = op(_inputs(s, rows, requires_grad=False))[0]
