@@ -545,7 +545,7 @@ class OwnerShardedRasterisation(torch.nn.Module):
         # and takes the same decision.  False: read the sizes first (one blocking read per frame)
         self.speculative_capacity = True
         self._capacity_guess = 0
-        self._sizes_host = None      # pinned int64[world, world + 1]
+        self._sizes_host = None      # pinned int32[world, world + 1]
         self._sizes_event = None
         self.capacity_stats = {"frames": 0, "redone": 0}
         outer = self
@@ -558,13 +558,13 @@ class OwnerShardedRasterisation(torch.nn.Module):
                     f = core.project(input_data, need_state)
                     # ONE size exchange per frame: every rank's per-band counts and visible count (the chunk capacity
                     # must be the same everywhere)
-                    mine = torch.cat([f.counts.to(torch.int64), f.counters[:1].to(torch.int64)])
-                    sizes = torch.empty((outer.world, outer.world + 1), dtype=torch.int64, device=mine.device)
+                    mine = torch.cat([f.counts, f.counters[:1]])   # int32: records for every band, visible count
+                    sizes = torch.empty((outer.world, outer.world + 1), dtype=torch.int32, device=mine.device)
                     dist.all_gather_into_tensor(sizes.view(-1), mine, group=outer.group)
                     speculate = outer.speculative_capacity and outer._capacity_guess > 0
                     if speculate:
                         if outer._sizes_host is None:
-                            outer._sizes_host = torch.empty((outer.world, outer.world + 1), dtype=torch.int64).pin_memory()
+                            outer._sizes_host = torch.empty((outer.world, outer.world + 1), dtype=torch.int32).pin_memory()
                             outer._sizes_event = torch.cuda.Event()
                         outer._sizes_host.copy_(sizes, non_blocking=True)
                         outer._sizes_event.record(torch.cuda.current_stream(mine.device))
@@ -658,7 +658,7 @@ def simulate_frame(cores: Sequence[OwnerShardedRasteriser], inputs: Sequence, gr
         return out
 
     frames = [timed("project", g, lambda g=g: cores[g].project(inputs[g], grad_image is not None)) for g in range(world)]
-    host = torch.stack([torch.cat([f.counts.to(torch.int64), f.counters[:1].to(torch.int64)]) for f in frames]).cpu()
+    host = torch.stack([torch.cat([f.counts, f.counters[:1]]) for f in frames]).cpu()
     capacity = _chunk_capacity(int(host[:, :world].max()))
     sends = [timed("pack", g, lambda g=g: cores[g].pack(frames[g], capacity, int(host[g, world]))) for g in range(world)]
     received = [torch.stack([sends[s][g] for s in range(world)]) for g in range(world)]   # the all-to-all
