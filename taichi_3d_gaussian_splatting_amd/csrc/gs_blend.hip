@@ -13,8 +13,8 @@
 //            effective entry; 2 waves per tile, two pixels per lane; alpha is evaluated by the SAME expression as in
 //            the forward kernel (gs_pair_alpha below), so the hit test alpha >= 1/255 decides identically in both
 //            passes; the per-Gaussian partial sums (ten gradients + the pixel count) are reduced across the 64 lanes
-//            by a permlane-swap + DPP reduce-scatter (one hit entry at a time, or two sharing one reduce-scatter in
-//            the kernel that still filters bin lists), combined across the two waves in LDS (ds_add_f32), and stored
+//            by a permlane-swap + DPP reduce-scatter (two hit entries sharing one reduce-scatter, a
+//            round's odd one alone), combined across the two waves in LDS (ds_add_f32), and stored
 //            once per (tile, Gaussian) into that pair's private slot -- no global atomics at all (the reference issues
 //            eleven per (pixel, Gaussian), RAS:674-696); the slots of a Gaussian are summed in a fixed order by
 //            reduce_partials_kernel, so gradients are bitwise reproducible.
@@ -56,18 +56,21 @@ constexpr float STOP_T = 0.0001f;                  // RAS:458
 // (gs_wave_reduce12_pair, 50 per pair; one entry stays pending in registers: +15 VGPRs, four waves per SIMD instead of
 // five), 0 = none (measurement only: the partials are thrown away, gradients are wrong).  Same bits either way.  Measured
 // at the headline size (profiles/r03_exp1_backward_arms.txt): binned lists 0.489 -> 0.468 ms with pairs, per-tile lists
-// 0.460 -> 0.457 (the lost wave costs what the shorter reduction saves) -- hence pairs for the staged kernel only.
+// 0.460 -> 0.457 (the lost wave costs what the shorter reduction saves).  Both kernels pair.  (History: the one-switch
+// macro of the variant builds used to be called GS_BWD_REDUCE -- since the frame entry points, the name of a stage bit
+// in include/gsplat_hip.h with the value 2, so BOTH kernels have been built with pairs since then and every round-4
+// measurement is of that build; the switch is now GS_BWD_REDUCE_ARM and the direct kernel's default says 2.)
 #ifndef GS_BWD_REDUCE_STAGED
 #define GS_BWD_REDUCE_STAGED 2
 #endif
 #ifndef GS_BWD_REDUCE_DIRECT
-#define GS_BWD_REDUCE_DIRECT 1
+#define GS_BWD_REDUCE_DIRECT 2
 #endif
-#ifdef GS_BWD_REDUCE          // (one switch for both kernels: tools/build_variants.sh)
+#ifdef GS_BWD_REDUCE_ARM      // (one switch for both kernels: tools/build_variants.sh)
 #undef GS_BWD_REDUCE_STAGED
 #undef GS_BWD_REDUCE_DIRECT
-#define GS_BWD_REDUCE_STAGED GS_BWD_REDUCE
-#define GS_BWD_REDUCE_DIRECT GS_BWD_REDUCE
+#define GS_BWD_REDUCE_STAGED GS_BWD_REDUCE_ARM
+#define GS_BWD_REDUCE_DIRECT GS_BWD_REDUCE_ARM
 #endif
 #ifndef GS_BWD_TRIM
 #define GS_BWD_TRIM 1        // 1: hit masks combined on the scalar unit, |v| accumulated with the VOP3 abs modifier, the four

@@ -257,6 +257,17 @@ _tls = threading.local()
 _atomic_lock = threading.Lock()
 
 
+class _NoLock:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        return False
+
+
+_process_lock = _NoLock()     # a multiprocessing lock while a launch is spread over worker processes
+
+
 class _BlockCtx:
     def __init__(self, dim):
         self.dim = dim
@@ -303,7 +314,7 @@ def _block_sync():
 
 
 def ti_atomic_add(array, index, value):
-    with _atomic_lock:
+    with _atomic_lock, _process_lock:
         array[index] += value
 
 
@@ -315,6 +326,77 @@ def _to_numpy(x):
     except ImportError:  # pragma: no cover
         pass
     return x
+
+
+def _run_block(fn, call, b, dim):
+    """One 256-thread block of a tile kernel on real OS threads (barrier = ti.simt.block.sync())."""
+    ctx = _BlockCtx(dim)
+
+    def body(k):
+        _tls.mode, _tls.tid, _tls.block, _tls.shared_calls = "block", b * dim + k, ctx, 0
+        try:
+            fn(**call)
+        except threading.BrokenBarrierError:
+            pass
+        except BaseException as exc:  # noqa: BLE001
+            ctx.error = exc
+            ctx.barrier.abort()
+    threads = [threading.Thread(target=body, args=(k,)) for k in range(dim)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    if ctx.error is not None:
+        raise ctx.error
+
+
+def _run_blocks_in_processes(fn, call, n_blocks, dim, n_procs):
+    """The blocks of a tile kernel dealt to ``n_procs`` forked worker processes (GS_EMU_PROCS; a block is still 256 OS
+    threads of one process).  Blocks of a launch are independent except for their ``ti.atomic_add``s, whose order the
+    reference leaves undefined: every ndarray argument is moved to an anonymous shared mapping for the launch, the
+    atomics take a cross-process lock on top of the thread lock, and the arrays are copied back afterwards -- the same
+    statements on the same memory, only the interleaving of blocks differs (as on a GPU)."""
+    import mmap
+    import multiprocessing as mp
+    import traceback
+    global _process_lock
+    shared, keep = dict(call), []
+    for key, value in call.items():
+        if isinstance(value, np.ndarray):
+            buf = mmap.mmap(-1, max(value.nbytes, 1))
+            view = np.frombuffer(buf, dtype=value.dtype, count=value.size).reshape(value.shape)
+            view[...] = value
+            shared[key] = view
+            keep.append(buf)
+    ctx = mp.get_context("fork")
+    saved_lock, _process_lock = _process_lock, ctx.Lock()
+    sys.stdout.flush()
+    sys.stderr.flush()
+    pids = []
+    try:
+        for w in range(n_procs):
+            pid = os.fork()
+            if pid == 0:
+                code = 0
+                try:
+                    for b in range(w, n_blocks, n_procs):
+                        _run_block(fn, shared, b, dim)
+                except BaseException:  # noqa: BLE001
+                    traceback.print_exc()
+                    code = 1
+                finally:
+                    sys.stdout.flush()
+                    sys.stderr.flush()
+                    os._exit(code)
+            pids.append(pid)
+        failed = [pid for pid in pids if os.waitpid(pid, 0)[1] != 0]
+        if failed:
+            raise RuntimeError(f"{len(failed)} emulation worker(s) failed (traceback above)")
+    finally:
+        _process_lock = saved_lock
+    for key, value in call.items():
+        if isinstance(value, np.ndarray):
+            value[...] = shared[key]
 
 
 def _kernel(fn):
@@ -337,25 +419,12 @@ def _kernel(fn):
             pass
         total, dim = _tls.probe_n, _tls.block_dim
         assert total % dim == 0
-        for b in range(total // dim):
-            ctx = _BlockCtx(dim)
-
-            def body(k, ctx=ctx, b=b):
-                _tls.mode, _tls.tid, _tls.block, _tls.shared_calls = "block", b * dim + k, ctx, 0
-                try:
-                    fn(**call)
-                except threading.BrokenBarrierError:
-                    pass
-                except BaseException as exc:  # noqa: BLE001
-                    ctx.error = exc
-                    ctx.barrier.abort()
-            threads = [threading.Thread(target=body, args=(k,)) for k in range(dim)]
-            for t in threads:
-                t.start()
-            for t in threads:
-                t.join()
-            if ctx.error is not None:
-                raise ctx.error
+        n_procs = min(int(os.environ.get("GS_EMU_PROCS", "1")), total // dim)
+        if n_procs > 1:
+            _run_blocks_in_processes(fn, call, total // dim, dim, n_procs)
+        else:
+            for b in range(total // dim):
+                _run_block(fn, call, b, dim)
         _tls.mode = "seq"
     launch.__wrapped__ = fn
     return launch
