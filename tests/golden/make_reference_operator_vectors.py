@@ -6,7 +6,7 @@ seeded scenes, with Taichi replaced by the emulation in tests/golden/taichi_emul
 tile blend kernels run block by block on 256 OS threads with real barriers).
 
 Run in the build container only (the GPU box has no /root/reference; takes a few minutes):
-    python tests/golden/make_reference_operator_vectors.py
+    GS_EMU_PROCS=8 python tests/golden/make_reference_operator_vectors.py [scene names]
 
 Scenes are chosen so that no two sort keys tie (asserted): torch.sort's tie order is the one thing the reference
 leaves undefined (RAS:947), everything else is then a function of the inputs.
@@ -52,10 +52,16 @@ SCENES = {
     # oracle and of the HIP path.  Shows that the tie rule is the only difference on scenes with ties.
     "h_200pts_32x32_tied_keys_stable_sort": (dict(n=200, height=32, width=32, s_min=0.05, s_max=0.3, sh_degree=3, seed=5),
                                              3, dict(depth_to_sort_key_scale=20.0), None),
-    # NOT A TOY (round 4): 2,400 Gaussians over a 320 x 320 image = 400 tiles (about 250 of them non-empty, 5,000+ list
-    # entries, a few invalid rows); tie-free at a depth scale of 1e7.  About two hours of emulation.
+    # NOT A TOY (round 4): 2,400 Gaussians over a 320 x 320 image = 400 tiles (about 250 of them non-empty, 5,869 list
+    # entries, a few invalid rows); tie-free at a depth scale of 1e7.  90 s with GS_EMU_PROCS=8 (hours before the
+    # emulation ran the per-point loop of the backward kernel once instead of once per pixel thread).
     "i_2400pts_320x320_400_tiles": (dict(n=2400, height=320, width=320, s_min=0.005, s_max=0.03, sh_degree=3, seed=41,
                                          invalid_fraction=0.03), 3, dict(depth_to_sort_key_scale=1.0e7), None),
+    # DEPTH COMPLEXITY at scale (round 4): 6,000 Gaussians of opacity 0.73 over 384 x 384 = 576 tiles, 89,765 list entries,
+    # 142 tiles with more than 256 entries (the longest 614: three batches of the reference's staging), 42 % of the
+    # pixels stop at T' < 1e-4 (RAS:458-460), up to 100 blended Gaussians per pixel; tie-free at a depth scale of 1e7
+    "j_6000pts_384x384_deep_lists": (dict(n=6000, height=384, width=384, s_min=0.02, s_max=0.12, sh_degree=3, seed=43,
+                                          invalid_fraction=0.02), 3, dict(depth_to_sort_key_scale=1.0e7), 1.0),
 }
 # forward outputs and integer fields of a regenerated archive must be bit-identical to the committed one (the gradients
 # are sums of fp32 atomic adds in OS-thread order: reproducible to ~1e-6 only, as on a GPU)

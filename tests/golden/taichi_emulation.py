@@ -328,12 +328,18 @@ def _to_numpy(x):
     return x
 
 
-def _run_block(fn, call, b, dim):
+def _offload(k):
+    """Guards the k-th top-level loop of a kernel (see _OffloadRewriter): True when this execution is to run it."""
+    only = getattr(_tls, "offload_only", None)
+    return only is None or only == k
+
+
+def _run_block(fn, call, b, dim, offload=None):
     """One 256-thread block of a tile kernel on real OS threads (barrier = ti.simt.block.sync())."""
     ctx = _BlockCtx(dim)
 
     def body(k):
-        _tls.mode, _tls.tid, _tls.block, _tls.shared_calls = "block", b * dim + k, ctx, 0
+        _tls.mode, _tls.tid, _tls.block, _tls.shared_calls, _tls.offload_only = "block", b * dim + k, ctx, 0, offload
         try:
             fn(**call)
         except threading.BrokenBarrierError:
@@ -350,7 +356,7 @@ def _run_block(fn, call, b, dim):
         raise ctx.error
 
 
-def _run_blocks_in_processes(fn, call, n_blocks, dim, n_procs):
+def _run_blocks_in_processes(fn, call, n_blocks, dim, n_procs, offload=None):
     """The blocks of a tile kernel dealt to ``n_procs`` forked worker processes (GS_EMU_PROCS; a block is still 256 OS
     threads of one process).  Blocks of a launch are independent except for their ``ti.atomic_add``s, whose order the
     reference leaves undefined: every ndarray argument is moved to an anonymous shared mapping for the launch, the
@@ -380,7 +386,7 @@ def _run_blocks_in_processes(fn, call, n_blocks, dim, n_procs):
                 code = 0
                 try:
                     for b in range(w, n_blocks, n_procs):
-                        _run_block(fn, shared, b, dim)
+                        _run_block(fn, shared, b, dim, offload)
                 except BaseException:  # noqa: BLE001
                     traceback.print_exc()
                     code = 1
@@ -410,22 +416,35 @@ def _kernel(fn):
         if not parallel:
             _tls.mode = "seq"
             return fn(**call)
-        # how many threads, and the block size: run up to the parallel loop header once
-        _tls.mode, _tls.block_dim = "probe", 256
-        try:
-            fn(**call)
-            raise RuntimeError("block kernel without an ndrange loop")
-        except _Probe:
-            pass
-        total, dim = _tls.probe_n, _tls.block_dim
-        assert total % dim == 0
-        n_procs = min(int(os.environ.get("GS_EMU_PROCS", "1")), total // dim)
-        if n_procs > 1:
-            _run_blocks_in_processes(fn, call, total // dim, dim, n_procs)
-        else:
-            for b in range(total // dim):
-                _run_block(fn, call, b, dim)
-        _tls.mode = "seq"
+        # Every top-level loop of a Taichi kernel is an offloaded task of its own, and the tasks run one after the other.
+        # With the kernel's loops numbered by _OffloadRewriter the block loop runs on threads, every other top-level loop
+        # ONCE, sequentially, in its place (gaussian_point_rasterisation_backward: the per-point loop RAS:707-772 after
+        # the last tile).  Without the numbering (a module not loaded through load_reference) every thread runs the
+        # whole body -- the same results as long as the other loops only assign, and pixels x points times the work.
+        info = fn.__globals__.get("__ti_offloads__", {}).get(fn.__name__)
+        n_loops, block_loop = info if info is not None else (1, None)
+        for k in range(n_loops):
+            only = k if info is not None else None
+            if info is not None and k != block_loop:
+                _tls.mode, _tls.offload_only = "seq", k
+                fn(**call)
+                continue
+            # how many threads, and the block size: run up to the parallel loop header once
+            _tls.mode, _tls.block_dim, _tls.offload_only = "probe", 256, only
+            try:
+                fn(**call)
+                raise RuntimeError("block kernel without an ndrange loop")
+            except _Probe:
+                pass
+            total, dim = _tls.probe_n, _tls.block_dim
+            assert total % dim == 0
+            n_procs = min(int(os.environ.get("GS_EMU_PROCS", "1")), total // dim)
+            if n_procs > 1:
+                _run_blocks_in_processes(fn, call, total // dim, dim, n_procs, only)
+            else:
+                for b in range(total // dim):
+                    _run_block(fn, call, b, dim, only)
+        _tls.mode, _tls.offload_only = "seq", None
     launch.__wrapped__ = fn
     return launch
 
@@ -518,6 +537,35 @@ class _AtomicRewriter(ast.NodeTransformer):
         return node
 
 
+class _OffloadRewriter(ast.NodeTransformer):
+    """Top-level ``for`` loops of a ``@ti.kernel`` body -> ``if __ti_offload__(k): for ...`` (k = 0, 1, ... in source
+    order).  Taichi compiles every top-level loop of a kernel into an offloaded task of its own and runs the tasks in
+    order; the launcher (_kernel) uses the numbering to run the loop that uses ``ti.simt.block`` on threads and the other
+    loops once each.  ``offloads``: {kernel name: (number of top-level loops, index of the block loop or None)}."""
+
+    def __init__(self):
+        self.offloads = {}
+
+    def visit_FunctionDef(self, node):
+        is_kernel = any(isinstance(d, ast.Attribute) and d.attr == "kernel" and isinstance(d.value, ast.Name) and
+                        d.value.id == "ti" for d in node.decorator_list)
+        if not is_kernel:
+            return node
+        body, k, block_loop = [], 0, None
+        for stmt in node.body:
+            if isinstance(stmt, ast.For):
+                if "simt.block" in ast.unparse(stmt):
+                    block_loop = k
+                guard = ast.Call(func=ast.Name(id="__ti_offload__", ctx=ast.Load()), args=[ast.Constant(value=k)],
+                                 keywords=[])
+                stmt = ast.copy_location(ast.If(test=guard, body=[stmt], orelse=[]), stmt)
+                k += 1
+            body.append(stmt)
+        node.body = body
+        self.offloads[node.name] = (k, block_loop)
+        return node
+
+
 def load_reference(reference_root: str, modules=("Camera", "utils", "SphericalHarmonics", "GaussianPoint3D",
                                                   "GaussianPointCloudRasterisation"), source_patches=None):
     """Execute the reference's modules, from where they lie, against the emulated ``taichi``; returns
@@ -543,10 +591,12 @@ def load_reference(reference_root: str, modules=("Camera", "utils", "SphericalHa
         for old, new in (source_patches or {}).get(name, []):
             assert source.count(old) == 1, (name, old)
             source = source.replace(old, new)
-        tree = ast.fix_missing_locations(_AtomicRewriter().visit(ast.parse(source, filename=path)))
+        offloads = _OffloadRewriter()
+        tree = ast.fix_missing_locations(offloads.visit(_AtomicRewriter().visit(ast.parse(source, filename=path))))
         mod = types.ModuleType(f"{pkg_name}.{name}")
         mod.__file__, mod.__package__ = path, pkg_name
         mod.__dict__["__ti_atomic_add__"] = ti_atomic_add
+        mod.__dict__["__ti_offload__"], mod.__dict__["__ti_offloads__"] = _offload, offloads.offloads
         sys.modules[mod.__name__] = mod
         import linecache
         linecache.cache[path] = (len(source), None, source.splitlines(True), path)   # inspect.getsource for kernels
