@@ -62,6 +62,13 @@ SCENES = {
     # pixels stop at T' < 1e-4 (RAS:458-460), up to 100 blended Gaussians per pixel; tie-free at a depth scale of 1e7
     "j_6000pts_384x384_deep_lists": (dict(n=6000, height=384, width=384, s_min=0.02, s_max=0.12, sh_degree=3, seed=43,
                                           invalid_fraction=0.02), 3, dict(depth_to_sort_key_scale=1.0e7), 1.0),
+    # BASELINE.json configs[0] AS STATED (round 4): 10,000 Gaussians, 256 x 256, SH-degree-0 data, colour band 0, default
+    # planes and depth scale -- the kwargs are synthetic.CONFIGS["cfg1_10k_256"] with seed 0, i.e. the scene of
+    # bench.py --workload cfg1_10k_256 and of test_operator_cfg1_as_stated.  48,317 list entries, lists of up to 787
+    # (four batches); 64 % of the keys tie at the default scale, so -- as for vector h -- the reference's sort() call is
+    # patched to sort(stable=True), the one thing it leaves undefined.
+    "k_cfg1_10k_256x256_sh0_tied_keys_stable_sort": (dict(n=10_000, height=256, width=256, s_min=0.01, s_max=0.08,
+                                                          sh_degree=0, seed=0), 0, {}, None),
 }
 # forward outputs and integer fields of a regenerated archive must be bit-identical to the committed one (the gradients
 # are sums of fp32 atomic adds in OS-thread order: reproducible to ~1e-6 only, as on a GPU)

@@ -16,8 +16,14 @@ in the product imports it.  What is emulated, and how faithfully:
   ``ti.simt.block`` runs its loops sequentially; one that does (the two tile blend kernels) is run one 256-thread
   block at a time on real OS threads, ``ti.simt.block.sync()`` being a ``threading.Barrier`` and ``SharedArray`` a
   per-block array, so the barrier-separated staging through shared memory executes as written;
+* every TOP-LEVEL loop of a kernel is an offloaded task of its own, as in Taichi, and the tasks run in source order
+  (``_OffloadRewriter``): of ``gaussian_point_rasterisation_backward`` the pixel loop runs on the block threads and the
+  per-point loop behind it (RAS:707-772) ONCE, after the last tile.  (Until round 4 every pixel thread ran the whole
+  body: the same results, that loop only assigns, but pixels x points times its work -- the 2,400-Gaussian vector took
+  hours and now takes 90 s.)  ``GS_EMU_PROCS=n`` deals the blocks of a launch to n forked worker processes over
+  shared mappings of the array arguments;
 * ``ti.atomic_add(a[i], v)`` statements are rewritten (AST) to a locked ``a[i] += v``; the accumulation order is the
-  thread order, where the GPU's is undefined.
+  thread (and, with worker processes, block) order, where the GPU's is undefined.
 """
 from __future__ import annotations
 

@@ -16,6 +16,12 @@ Round 2 added: ``f_600pts_16x32_three_batches`` (598 entries in one tile: the re
 runs three batches forward and backward, incl. the clamp of RAS:579-585), ``g_160pts_128x128`` (64 tiles) and
 ``h_200pts_32x32_tied_keys_stable_sort`` (69 % tied keys; generated with the reference's ``sort()`` call patched to
 ``sort(stable=True)`` -- the tie rule is the only thing the reference leaves open).
+
+Round 4 added three vectors that are not toys (the emulation now runs a kernel's top-level loops as the separate offloads
+they are, and deals tiles to worker processes): ``i_2400pts_320x320_400_tiles``; ``j_6000pts_384x384_deep_lists`` (89,765
+list entries, lists of up to 614, 42 % of the pixels stop at T' < 1e-4); and ``k_cfg1_10k_256x256_sh0_tied_keys_stable_sort``
+-- BASELINE.json's configs[0] exactly as stated (the scene of ``bench.py --workload cfg1_10k_256``), 64 % tied keys, the
+stable-sort patch of vector h.  The fp32 oracle takes the reference's skip / stop decision on EVERY pixel of all of them.
 """
 import ast
 import glob
@@ -49,6 +55,16 @@ def _load(path):
 def _rel(a, b):
     return float(np.linalg.norm(np.asarray(a, np.float64) - np.asarray(b, np.float64)) /
                  max(np.linalg.norm(np.asarray(b, np.float64)), 1e-30))
+
+
+def _grad_tol(V):
+    """Relative-L2 bar of the gradients against a reference-run vector.  The reference adds its per-Gaussian sums with
+    fp32 atomics (emulated in thread order: an undefined order on a GPU too), the oracle in double, the HIP path in a
+    fixed fp32 tree -- so the distance is the REFERENCE's accumulation noise and grows with the terms per sum: observed
+    2e-7 .. 1e-6 on the vectors of up to 2,400 Gaussians (bar 2e-5), 8e-6 on vector j (6,000 Gaussians, up to 100 terms
+    per pixel and 614 entries per tile) and 1.4e-5 on vector k (BASELINE config 1: up to 787 entries per tile) -- bar 5e-5
+    from 5,000 visible Gaussians on."""
+    return 2e-5 if V["hook_point_id"].shape[0] < 5000 else 5e-5
 
 
 def _check(V, got, grad_tol, image_tol, fragile=None):
@@ -140,7 +156,7 @@ def test_oracle_matches_reference_operator(path, precision):
     # ones and takes the same decision on every pixel; the f64 build is 7.3e-6 away on vector i -- the reference's own
     # fp32 rounding of 2,321 small conics -- and decides four pixels of vector j differently.  Gradients, fp32 build:
     # 2e-7 .. 1e-6, and 8e-6 on vector j, where the reference's fp32 atomics add up to 100 terms per pixel and 614 per tile)
-    _check(V, got, grad_tol=2e-5 if precision == "f32" else 2e-4,
+    _check(V, got, grad_tol=_grad_tol(V) if precision == "f32" else 2e-4,
            image_tol=IMAGE_TOL_ORACLE if precision == "f32" else IMAGE_TOL_F64_SPEC,
            fragile=None if precision == "f32" else f["margin"] < 1e-5)
 
@@ -176,4 +192,4 @@ def test_hip_operator_matches_reference_operator(path):
     margin = O.forward(hs.point_cloud.numpy(), hs.point_cloud_features.numpy(), hs.point_invalid_mask.numpy(),
                        hs.point_object_id.numpy(), hs.camera_intrinsics.numpy(), hs.q_pointcloud_camera.numpy(),
                        hs.t_pointcloud_camera.numpy(), hs.height, hs.width, want_margin=True, **cfg)["margin"]
-    _check(V, got, grad_tol=2e-5, image_tol=IMAGE_TOL_HIP, fragile=margin < 1e-5)
+    _check(V, got, grad_tol=_grad_tol(V), image_tol=IMAGE_TOL_HIP, fragile=margin < 1e-5)
