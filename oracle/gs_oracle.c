@@ -57,12 +57,19 @@
 #ifdef GS_F64
 typedef double real;
 #define R_EXP exp
+#define R_EXP_SCALE exp
 #define R_SQRT sqrt
 #define R_FLOOR floor
 #define R_FABS fabs
 #else
 typedef float real;
 #define R_EXP expf
+/* The scale activation exp(s) (GP3:175-178) is the one transcendental on the way to the INTEGER outputs (covariance ->
+ * radius -> tile box -> counts, keys, slots): it is evaluated in double and rounded once, i.e. the correctly rounded
+ * fp32 exponential (up to double rounding, probability 2^-29), on this side and in the HIP projection alike -- two
+ * libms' expf differ in the last bit on a few per cent of the inputs (glibc's is correctly rounded on 99.93 %), and a
+ * radius one ulp apart moves a tile-box edge across a tile boundary once in a few thousand frames (fuzz case 6102). */
+#define R_EXP_SCALE(x) ((float)exp((double)(x)))
 #define R_SQRT sqrtf
 #define R_FLOOR floorf
 #define R_FABS fabsf
@@ -181,7 +188,7 @@ static void project_covariance(const real q[4], const real s[3], const real W[9]
     real J[6], R[9], S[9] = {0}, Rt[9], Wt[9], Jt[6];
     proj_jacobian(K, c, J);
     rotmat_from_q(q, R);
-    S[0] = R_EXP(s[0]); S[4] = R_EXP(s[1]); S[8] = R_EXP(s[2]);
+    S[0] = R_EXP_SCALE(s[0]); S[4] = R_EXP_SCALE(s[1]); S[8] = R_EXP_SCALE(s[2]);
     real RS[9], RSS[9], Sigma[9];
     matmul(R, S, RS, 3, 3, 3);
     matmul(RS, S, RSS, 3, 3, 3); /* S^T == S */

@@ -44,6 +44,9 @@ static inline int gs_div_up(long long a, long long b) { return (int)((a + b - 1)
 // ------------------------------------------------------------------ wave / block primitives
 #ifdef __HIPCC__
 
+// exp(x) correctly rounded to fp32 (double evaluation, one rounding): see the scale activation in gs_frontend.hip
+__device__ __forceinline__ float gs_exp_cr(float x) { return (float)exp((double)x); }
+
 // RAS:81-103 get_bounding_box_by_point_and_radii (shared by the front end and the backward flush, which
 // must agree bit-for-bit on the box: it defines the slot of a (Gaussian, tile) pair, RAS:163-166)
 __device__ __forceinline__ void gs_tile_box(float u, float v, float r, int tw, int th, int &t0u, int &t1u,

@@ -515,7 +515,12 @@ __global__ __launch_bounds__(GS_BLOCK) void preprocess_kernel(
         float J[6] = {K[0] / c[2], 0.f, -(K[0] * c[0]) / (c[2] * c[2]),
                       0.f, K[4] / c[2], -(K[4] * c[1]) / (c[2] * c[2])};
         const Mat3 R = rotmat_from_q(f[0], f[1], f[2], f[3]);
-        float S[9] = {expf(f[4]), 0.f, 0.f, 0.f, expf(f[5]), 0.f, 0.f, 0.f, expf(f[6])};
+        // The scale activation is the one transcendental on the way to the INTEGER outputs (covariance -> radius -> tile
+        // box -> counts, keys, slots).  Evaluated in double and rounded once it is the correctly rounded fp32 exponential
+        // (up to double rounding, 2^-29) -- the oracle does the same, so the two sides agree on the radius to the last bit
+        // whatever their libms; with expf on both sides 6 % of the radii were one ulp apart and a tile-box edge moved
+        // across a tile boundary once in a few thousand random frames (tests/test_fuzz_gpu.py, case 6102).
+        float S[9] = {gs_exp_cr(f[4]), 0.f, 0.f, 0.f, gs_exp_cr(f[5]), 0.f, 0.f, 0.f, gs_exp_cr(f[6])};
         float RS[9], RSS[9], Rt[9], Sigma[9];
         matmul<3, 3, 3>(R.m, S, RS);
         matmul<3, 3, 3>(RS, S, RSS);

@@ -85,6 +85,10 @@ def test_preprocess(ops, scene, ofwd):
         frac = close_fraction(a[rows, sl], ref[rows, sl], rtol=rtol, atol=1e-7)
         report(f"preprocess.{name}", close=frac, max_abs=float(np.abs(a[rows, sl] - ref[rows, sl]).max()))
         assert frac == 1.0, name
+    # Since the scale activation is the correctly rounded exponential on both sides (gs_exp_cr / R_EXP_SCALE), the chain
+    # scales -> covariance -> radius / conic is IEEE arithmetic in one order: how many rows agree to the last bit
+    report("preprocess.bits", radius_identical=float((a[emits, 7] == ref[emits, 7]).mean()),
+           conic_identical=float((a[emits, 4:7] == ref[emits, 4:7]).all(axis=1).mean()))
     # in-place quaternion normalisation of visible rows only (RAS:196-205)
     f_hip, f_ref = feat.cpu().numpy(), ofwd["feat"]
     assert np.allclose(f_hip[:, :4], f_ref[:, :4], rtol=0, atol=1e-7)
