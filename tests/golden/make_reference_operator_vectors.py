@@ -69,7 +69,38 @@ SCENES = {
     # patched to sort(stable=True), the one thing it leaves undefined.
     "k_cfg1_10k_256x256_sh0_tied_keys_stable_sort": (dict(n=10_000, height=256, width=256, s_min=0.01, s_max=0.08,
                                                           sh_degree=0, seed=0), 0, {}, None),
+    # DRAWS OF THE RANDOMISED PARITY SUITE (round 4; tests/test_fuzz_gpu.py:random_scene -- rotated off-centre cameras with
+    # unequal focal lengths, several objects under their own poses, un-normalised quaternions, invalid rows, needles:
+    # Gaussians with one axis 10-100 x the others, whose conics fp32 barely resolves).  Planes, depth scale and band are
+    # the draw's; their keys tie (scales 10 .. 1000), hence the stable-sort patch.
+    #   draw 17: 144 x 192, 2,182 rows (half of them invalid), 2 objects, needles, near 2 / far 10, 32,768 list entries
+    "l_fuzz17_144x192_needles_two_objects_tied_keys_stable_sort": ("fuzz:17", None, None, None),
+    #   draw 20: 144 x 192, 1,744 rows, needles seen from as close as 0.1 (a hundredfold magnification), lists of up to 721
+    "m_fuzz20_144x192_needles_close_ups_tied_keys_stable_sort": ("fuzz:20", None, None, None),
+    #   draw 9: 240 x 48, 4,454 rows, 3 objects, 42,968 list entries in 45 tiles: lists of up to 2,189 = nine batches
+    "n_fuzz9_240x48_three_objects_nine_batches_tied_keys_stable_sort": ("fuzz:9", None, None, None),
+    # THE REFERENCE'S OWN STRESS DISTRIBUTION (T_RAS:111-150: rows of U[0,1) data, camera 0.5 behind the cloud, every
+    # Gaussian over nearly every tile) at 256 x 144 with 300 valid rows of 600 (synthetic.make_reference_stress_scene)
+    "o_stress_distribution_256x144_tied_keys_stable_sort": ("stress:600:300:144:256", 3, {}, None),
 }
+
+
+def build_scene(spec):
+    """-> (scene, band, config kwargs, kwargs recorded in the archive) for a string-valued SCENES entry."""
+    kind, *args = spec.split(":")
+    if kind == "fuzz":
+        sys.path.insert(0, ROOT)
+        from tests.test_fuzz_gpu import random_scene
+        scene, band, _needles, _options = random_scene(int(args[0]))
+        cfg = dict(near_plane=float(scene.near_plane), far_plane=float(scene.far_plane),
+                   depth_to_sort_key_scale=float(scene.depth_to_sort_key_scale))
+        return scene, band, cfg, dict(height=scene.height, width=scene.width, builder=spec)
+    if kind == "stress":
+        from taichi_3d_gaussian_splatting_amd.synthetic import make_reference_stress_scene
+        n, n_valid, height, width = (int(a) for a in args)
+        scene = make_reference_stress_scene(0, n=n, n_valid=n_valid, height=height, width=width)
+        return scene, None, None, dict(height=height, width=width, builder=spec)
+    raise ValueError(spec)
 # forward outputs and integer fields of a regenerated archive must be bit-identical to the committed one (the gradients
 # are sums of fp32 atomic adds in OS-thread order: reproducible to ~1e-6 only, as on a GPU)
 BITWISE_FIELDS = ("image", "depth", "count", "features_after_forward", "hook_point_id", "hook_num_overlap_tiles",
@@ -88,7 +119,12 @@ def main():
             "GaussianPointCloudRasterisation": [STABLE_SORT_PATCH]} if tied else None)
         RAS, CAM = mods["GaussianPointCloudRasterisation"], mods["Camera"]
         Op = RAS.GaussianPointCloudRasterisation
-        s = make_scene(**kw)
+        if isinstance(kw, str):
+            s, draw_band, draw_cfg, kw = build_scene(kw)
+            band = draw_band if band is None else band
+            cfg_kw = draw_cfg if cfg_kw is None else cfg_kw
+        else:
+            s = make_scene(**kw)
         if opacity == "two_objects":
             gq = torch.Generator().manual_seed(99)
             q = torch.tensor([[0.0, 0.0, 0.0, 1.0]]).repeat(2, 1) + 0.15 * torch.randn(2, 4, generator=gq)
@@ -139,7 +175,11 @@ def main():
             hook_magnitude_image=h.magnitude_grad_viewspace_on_image.numpy(),
             hook_num_overlap_tiles=h.num_overlap_tiles.numpy(), hook_num_affected_pixels=h.num_affected_pixels.numpy(),
             hook_depth=h.point_depth.numpy(), hook_uv=h.point_uv_in_camera.numpy())
-        path = os.path.join(HERE, f"reference_operator_{name}.npz")
+        # GS_EMU_EXP=cr (taichi_emulation.py: exp / log correctly rounded instead of NumPy's fp32 routines) writes a second
+        # archive beside the default one: the pair brackets what the choice of the exponential does to the reference
+        exp_cr = os.environ.get("GS_EMU_EXP") == "cr"
+        out["emulated_exp"] = np.array("correctly rounded" if exp_cr else "numpy fp32")
+        path = os.path.join(HERE, f"reference_operator_{name}{'_exp_cr' if exp_cr else ''}.npz")
         if os.path.exists(path):
             old = np.load(path)
             for key in BITWISE_FIELDS:
