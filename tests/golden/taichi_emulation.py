@@ -376,10 +376,33 @@ def _run_block(fn, call, b, dim, offload=None):
 
 def _run_blocks_in_processes(fn, call, n_blocks, dim, n_procs, offload=None):
     """The blocks of a tile kernel dealt to ``n_procs`` forked worker processes (GS_EMU_PROCS; a block is still 256 OS
-    threads of one process).  Blocks of a launch are independent except for their ``ti.atomic_add``s, whose order the
-    reference leaves undefined: every ndarray argument is moved to an anonymous shared mapping for the launch, the
-    atomics take a cross-process lock on top of the thread lock, and the arrays are copied back afterwards -- the same
-    statements on the same memory, only the interleaving of blocks differs (as on a GPU)."""
+    threads of one process)."""
+    def work(w, shared):
+        for b in range(w, n_blocks, n_procs):
+            _run_block(fn, shared, b, dim, offload)
+    _run_in_processes(call, n_procs, work)
+
+
+def _run_loop_in_processes(fn, call, n_procs, offload):
+    """A top-level ``for i in range(n)`` loop of a kernel (a parallel loop in Taichi: its iterations are independent but
+    for atomics) dealt to worker processes: worker w runs the iterations w, w + n_procs, ... (``__ti_prange__``)."""
+    def work(w, shared):
+        _tls.mode, _tls.offload_only, _tls.prange = "seq", offload, (w, n_procs)
+        fn(**shared)
+    _run_in_processes(call, n_procs, work)
+
+
+def _prange(r):
+    part = getattr(_tls, "prange", None)
+    return r if part is None else r[part[0]::part[1]]
+
+
+def _run_in_processes(call, n_procs, work):
+    """``work(w, shared_arguments)`` in ``n_procs`` forked worker processes.  The units of a launch (blocks, loop
+    iterations) are independent except for their ``ti.atomic_add``s, whose order the reference leaves undefined: every
+    ndarray argument is moved to an anonymous shared mapping for the launch, the atomics take a cross-process lock on
+    top of the thread lock, and the arrays are copied back afterwards -- the same statements on the same memory, only
+    the interleaving differs (as on a GPU)."""
     import mmap
     import multiprocessing as mp
     import traceback
@@ -403,8 +426,7 @@ def _run_blocks_in_processes(fn, call, n_blocks, dim, n_procs, offload=None):
             if pid == 0:
                 code = 0
                 try:
-                    for b in range(w, n_blocks, n_procs):
-                        _run_block(fn, shared, b, dim, offload)
+                    work(w, shared)
                 except BaseException:  # noqa: BLE001
                     traceback.print_exc()
                     code = 1
@@ -431,21 +453,31 @@ def _kernel(fn):
     def launch(*args, **kwargs):
         bound = sig.bind(*args, **kwargs)
         call = {k: _to_numpy(v) for k, v in bound.arguments.items()}
+        info = fn.__globals__.get("__ti_offloads__", {}).get(fn.__name__)
+        n_procs = int(os.environ.get("GS_EMU_PROCS", "1"))
+        longest = max([v.shape[0] for v in call.values() if isinstance(v, np.ndarray) and v.ndim > 0] + [0])
         if not parallel:
-            _tls.mode = "seq"
-            return fn(**call)
+            _tls.mode, _tls.prange = "seq", None
+            if info is None or n_procs <= 1 or longest < 4096 or info[2] != info[0]:
+                return fn(**call)       # (short loops, or a loop that is not a plain `range`: in this process)
+            for k in range(info[0]):    # every top-level loop in its turn, its iterations dealt to the workers
+                _run_loop_in_processes(fn, call, n_procs, k)
+            _tls.offload_only = None
+            return None
         # Every top-level loop of a Taichi kernel is an offloaded task of its own, and the tasks run one after the other.
         # With the kernel's loops numbered by _OffloadRewriter the block loop runs on threads, every other top-level loop
         # ONCE, sequentially, in its place (gaussian_point_rasterisation_backward: the per-point loop RAS:707-772 after
         # the last tile).  Without the numbering (a module not loaded through load_reference) every thread runs the
         # whole body -- the same results as long as the other loops only assign, and pixels x points times the work.
-        info = fn.__globals__.get("__ti_offloads__", {}).get(fn.__name__)
-        n_loops, block_loop = info if info is not None else (1, None)
+        n_loops, block_loop = info[:2] if info is not None else (1, None)
         for k in range(n_loops):
             only = k if info is not None else None
             if info is not None and k != block_loop:
-                _tls.mode, _tls.offload_only = "seq", k
-                fn(**call)
+                if n_procs > 1 and longest >= 4096 and info[2] == n_loops - 1:
+                    _run_loop_in_processes(fn, call, n_procs, k)
+                else:
+                    _tls.mode, _tls.offload_only, _tls.prange = "seq", k, None
+                    fn(**call)
                 continue
             # how many threads, and the block size: run up to the parallel loop header once
             _tls.mode, _tls.block_dim, _tls.offload_only = "probe", 256, only
@@ -456,9 +488,8 @@ def _kernel(fn):
                 pass
             total, dim = _tls.probe_n, _tls.block_dim
             assert total % dim == 0
-            n_procs = min(int(os.environ.get("GS_EMU_PROCS", "1")), total // dim)
-            if n_procs > 1:
-                _run_blocks_in_processes(fn, call, total // dim, dim, n_procs, only)
+            if min(n_procs, total // dim) > 1:
+                _run_blocks_in_processes(fn, call, total // dim, dim, min(n_procs, total // dim), only)
             else:
                 for b in range(total // dim):
                     _run_block(fn, call, b, dim, only)
@@ -559,7 +590,7 @@ class _OffloadRewriter(ast.NodeTransformer):
     """Top-level ``for`` loops of a ``@ti.kernel`` body -> ``if __ti_offload__(k): for ...`` (k = 0, 1, ... in source
     order).  Taichi compiles every top-level loop of a kernel into an offloaded task of its own and runs the tasks in
     order; the launcher (_kernel) uses the numbering to run the loop that uses ``ti.simt.block`` on threads and the other
-    loops once each.  ``offloads``: {kernel name: (number of top-level loops, index of the block loop or None)}."""
+    loops once each.  ``offloads``: {kernel name: (number of top-level loops, index of the block loop or None, number of plain-range loops)}."""
 
     def __init__(self):
         self.offloads = {}
@@ -569,18 +600,23 @@ class _OffloadRewriter(ast.NodeTransformer):
                         d.value.id == "ti" for d in node.decorator_list)
         if not is_kernel:
             return node
-        body, k, block_loop = [], 0, None
+        body, k, block_loop, plain = [], 0, None, 0
         for stmt in node.body:
             if isinstance(stmt, ast.For):
                 if "simt.block" in ast.unparse(stmt):
                     block_loop = k
+                elif isinstance(stmt.iter, ast.Call) and isinstance(stmt.iter.func, ast.Name) and stmt.iter.func.id == "range":
+                    # a parallel loop over a plain range: its iterations can be dealt to worker processes
+                    stmt.iter = ast.copy_location(ast.Call(func=ast.Name(id="__ti_prange__", ctx=ast.Load()),
+                                                           args=[stmt.iter], keywords=[]), stmt.iter)
+                    plain += 1
                 guard = ast.Call(func=ast.Name(id="__ti_offload__", ctx=ast.Load()), args=[ast.Constant(value=k)],
                                  keywords=[])
                 stmt = ast.copy_location(ast.If(test=guard, body=[stmt], orelse=[]), stmt)
                 k += 1
             body.append(stmt)
         node.body = body
-        self.offloads[node.name] = (k, block_loop)
+        self.offloads[node.name] = (k, block_loop, plain)   # (top-level loops, index of the block loop, plain-range loops)
         return node
 
 
@@ -615,6 +651,7 @@ def load_reference(reference_root: str, modules=("Camera", "utils", "SphericalHa
         mod.__file__, mod.__package__ = path, pkg_name
         mod.__dict__["__ti_atomic_add__"] = ti_atomic_add
         mod.__dict__["__ti_offload__"], mod.__dict__["__ti_offloads__"] = _offload, offloads.offloads
+        mod.__dict__["__ti_prange__"] = _prange
         sys.modules[mod.__name__] = mod
         import linecache
         linecache.cache[path] = (len(source), None, source.splitlines(True), path)   # inspect.getsource for kernels
