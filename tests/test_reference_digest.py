@@ -18,6 +18,9 @@ from taichi_3d_gaussian_splatting_amd.synthetic import make_config_scene, make_g
 
 PATH = os.environ.get("GS_REFERENCE_DIGEST") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden",
                                                               "reference_digest_cfg2_100k_800_tied_keys_stable_sort.npz")
+# Observed (round 4): ids / tile counts identical; 1 of 640,000 pixels decided differently (margin 5.1e-11; 364 pixels lie
+# within 1e-8 of a threshold); image 4.2e-7 off that pixel, 4.5e-6 on it; gradients 9.0e-6 (sampled rows), 1.1e-6 (column
+# norms); uv, depth, normalised quaternions identical.
 pytestmark = pytest.mark.skipif(not os.path.exists(PATH), reason="digest not generated (tests/golden/make_reference_digest.py, 2.5 h)")
 IMAGE_TOL, GRAD_TOL = 2e-6, 5e-5      # the bars of tests/test_reference_operator.py for the large vectors
 
