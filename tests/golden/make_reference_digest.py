@@ -29,7 +29,10 @@ from make_reference_operator_vectors import STABLE_SORT_PATCH  # noqa: E402
 from taichi_3d_gaussian_splatting_amd.synthetic import make_config_scene, make_grad_image  # noqa: E402
 
 WORKLOAD, BAND, GRAD_SEED, ROW_SEED, N_ROWS = "cfg2_100k_800", 3, 31, 7, 4096
-OUT = os.path.join(HERE, "reference_digest_cfg2_100k_800_tied_keys_stable_sort.npz")
+# (GS_EMU_EXP=cr -- exp / log of the emulation correctly rounded -- writes a second file beside the committed one: the pair
+# shows what the exponential's last bit does to the frame, see tests/test_reference_digest.py)
+OUT = os.path.join(HERE, "reference_digest_cfg2_100k_800_tied_keys_stable_sort%s.npz" %
+                   ("_exp_cr" if os.environ.get("GS_EMU_EXP") == "cr" else ""))
 
 
 def input_hash(s, g) -> str:

@@ -17,12 +17,20 @@ from oracle import gs_oracle as O
 from taichi_3d_gaussian_splatting_amd.synthetic import make_config_scene, make_grad_image
 
 PATH = os.environ.get("GS_REFERENCE_DIGEST") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden",
-                                                              "reference_digest_cfg2_100k_800_tied_keys_stable_sort.npz")
-# Observed (round 4): ids / tile counts identical; 1 of 640,000 pixels decided differently (margin 5.1e-11; 364 pixels lie
-# within 1e-8 of a threshold); image 4.2e-7 off that pixel, 4.5e-6 on it; gradients 9.0e-6 (sampled rows), 1.1e-6 (column
-# norms); uv, depth, normalised quaternions identical.
-pytestmark = pytest.mark.skipif(not os.path.exists(PATH), reason="digest not generated (tests/golden/make_reference_digest.py, 2.5 h)")
-IMAGE_TOL, GRAD_TOL = 2e-6, 5e-5      # the bars of tests/test_reference_operator.py for the large vectors
+                                                              "reference_digest_cfg2_100k_800_tied_keys_stable_sort_exp_cr.npz")
+# Two runs were made (round 4, 68 minutes each on eight cores); the committed digest is the second.
+#  * Emulation with NumPy's fp32 exp (a few ulps: differs from the correctly rounded value on 39 % of the inputs): ids and
+#    tile counts identical; 1 of 640,000 pixels decided differently -- its alpha is 5.1e-11 from 1/255, a quarter of an ulp;
+#    364 pixels of the frame lie within 1e-8 of a threshold --; image 4.2e-7 off that pixel, 4.5e-6 on it; gradients 9.0e-6
+#    (sampled rows), 1.1e-6 (column norms).
+#  * Emulation with exp / log correctly rounded (GS_EMU_EXP=cr; glibc's expf, which the oracle calls, is correctly rounded
+#    on 99.93 % of the inputs): EVERY one of the 640,000 pixels decided as the reference decides it, image 2.4e-7, depth
+#    4.8e-7, gradients 6.6e-7 .. 1.3e-6 (rows), 4e-8 .. 1e-7 (column norms); uv, depth, normalised quaternions, ids, tile
+#    counts, affected-pixel counts identical.  So most of the 9e-6 of the first run was the exponential's last bit, not
+#    the order of the reference's atomics.
+# A digest made with NumPy's exp (GS_REFERENCE_DIGEST=...) is held to the looser bars and may have flipped pixels.
+pytestmark = pytest.mark.skipif(not os.path.exists(PATH), reason="digest not generated (tests/golden/make_reference_digest.py, 70 min)")
+IMAGE_TOL = 2e-6
 
 
 def _rel(a, b):
@@ -60,12 +68,13 @@ def test_forward_of_baseline_config_2_matches_the_reference_run(run):
           f"image_linf={float(image_err.max()):.3e}, depth_linf={float(depth_err.max()):.3e}, "
           f"pixels_within_5e-8_of_a_threshold={int((f['margin'] < 5e-8).sum())}, closest={float(f['margin'].min()):.2e}, "
           f"flipped={int((count_differs | (image_err > IMAGE_TOL)).sum())}")
-    # The reference's skip / stop decision on every pixel -- except that this run used NumPy's fp32 exp (a few ulps;
-    # one ulp of exp moves alpha by 2e-10), and 1,983 of the 640,000 pixels evaluate an alpha or a T' within 5e-8 of its
-    # threshold: a pixel closer than 1e-8 may be decided the other way, at most eight of them, each within one Gaussian.
+    # the reference's skip / stop decision on every pixel (bars by the exponential the run was made with, see above)
     flipped = count_differs | (image_err > IMAGE_TOL)
-    assert not (flipped & (f["margin"] >= 1e-8)).any() and int(flipped.sum()) <= 8 and float(image_err.max()) <= 5e-3
     n_flipped = int(flipped.sum())
+    if str(D["emulated_exp"]) == "correctly rounded":
+        assert n_flipped == 0
+    else:
+        assert not (flipped & (f["margin"] >= 1e-8)).any() and n_flipped <= 8 and float(image_err.max()) <= 5e-3
     assert float(depth_err.max()) <= 1e-4 * max(1.0, float(np.abs(D["depth_every_4th_row"]).max()))
     assert int(np.abs(h["num_affected_pixels"].astype(np.int64) - D["hook_num_affected_pixels"].astype(np.int64)).sum()) <= \
         8 * n_flipped      # (a pixel stopped one Gaussian later or earlier changes the counts of the Gaussians behind it)
@@ -81,7 +90,8 @@ def test_backward_of_baseline_config_2_matches_the_reference_run(run):
     worst = {}
     for name, a in fields.items():
         rows, sample, norms = D[f"{name}_rows"], D[f"{name}_sample"], D[f"{name}_column_norms"]
-        tol = GRAD_TOL if "grad" in name or "magnitude" in name else 1e-6
+        grad_tol = 1e-5 if str(D["emulated_exp"]) == "correctly rounded" else 5e-5
+        tol = grad_tol if "grad" in name or "magnitude" in name else 1e-6
         d_rows = _rel(a[rows], sample)
         mine = np.linalg.norm(a.astype(np.float64), axis=0)
         d_norms = float(np.abs(mine - norms).max() / max(float(norms.max()), 1e-30))
@@ -90,6 +100,6 @@ def test_backward_of_baseline_config_2_matches_the_reference_run(run):
     mag = h["magnitude_grad_viewspace_on_image"]
     d_mag = _rel(mag[::4], D["hook_magnitude_image_every_4th_row"])
     norm_reference = float(D["hook_magnitude_image_norm"])
-    assert d_mag <= GRAD_TOL and abs(float(np.linalg.norm(mag.astype(np.float64))) - norm_reference) <= GRAD_TOL * norm_reference
+    assert d_mag <= grad_tol and abs(float(np.linalg.norm(mag.astype(np.float64))) - norm_reference) <= grad_tol * norm_reference
     print("[parity] reference_digest.backward: " + ", ".join(f"{k}: rows {a:.2e} column_norms {c:.2e}" for k, (a, c) in worst.items()) +
           f", magnitude_image {d_mag:.2e}")
