@@ -103,3 +103,43 @@ def test_backward_of_baseline_config_2_matches_the_reference_run(run):
     assert d_mag <= grad_tol and abs(float(np.linalg.norm(mag.astype(np.float64))) - norm_reference) <= grad_tol * norm_reference
     print("[parity] reference_digest.backward: " + ", ".join(f"{k}: rows {a:.2e} column_norms {c:.2e}" for k, (a, c) in worst.items()) +
           f", magnitude_image {d_mag:.2e}")
+
+
+@pytest.mark.gpu
+@pytest.mark.xfail(reason="written after round 4's GPU budget was spent: not yet seen on a GPU (reports, cannot fail the suite); the "
+                          "two links it short-cuts -- reference run -> oracle above, oracle -> HIP operator in "
+                          "tests/test_hip_parity.py::test_operator_cfg2_size_forward_backward -- are both tested", strict=False)
+def test_hip_operator_matches_the_reference_run_of_baseline_config_2():
+    """The north star's sentence literally: the HIP operator's outputs against the reference's own run of BASELINE
+    configs[1], within 1e-4 L-inf per pixel (off the pixels a threshold decides: at most sixteen of the 1,983 that lie
+    within 5e-8 of one may go the other way, each within one blended Gaussian), integer fields exact, gradients 1e-4."""
+    import torch
+    from tests.test_reference_operator import _hip_outputs
+    D = np.load(PATH)
+    s = make_config_scene(str(D["workload"]))
+    g = make_grad_image(s.height, s.width, seed=int(D["grad_seed"]))
+    cfg = dict(near_plane=s.near_plane, far_plane=s.far_plane, depth_to_sort_key_scale=s.depth_to_sort_key_scale)
+    got = _hip_outputs({"grad_image": g.numpy()}, s, cfg, int(D["band"]))
+    torch.cuda.synchronize()
+    margin = O.forward(s.point_cloud.numpy(), s.point_cloud_features.numpy(), s.point_invalid_mask.numpy(),
+                       s.point_object_id.numpy(), s.camera_intrinsics.numpy(), s.q_pointcloud_camera.numpy(),
+                       s.t_pointcloud_camera.numpy(), s.height, s.width, want_margin=True, **cfg)["margin"]
+    assert np.array_equal(got["hook_point_id"], D["hook_point_id"])
+    assert np.array_equal(got["hook_num_overlap_tiles"], D["hook_num_overlap_tiles"])
+    image_err = np.abs(got["image"] - D["image"]).max(axis=2)
+    flipped = (got["count"] != D["count"].astype(got["count"].dtype)) | (image_err > 1e-4)
+    print(f"[parity] reference_digest.hip: flipped={int(flipped.sum())}, image_linf={float(image_err.max()):.3e}, "
+          f"image_linf_off_flips={float(image_err[~flipped].max()):.3e}")
+    assert not (flipped & (margin >= 1e-5)).any() and int(flipped.sum()) <= 16 and float(image_err.max()) <= 5e-3
+    assert float(np.abs(got["depth"][::4] - D["depth_every_4th_row"])[~flipped[::4]].max()) <= 2e-4
+    fields = dict(grad_xyz=got["grad_xyz"], grad_feat=got["grad_feat"], hook_grad_point=got["hook_grad_point"],
+                  hook_grad_features=got["hook_grad_features"], hook_grad_viewspace=got["hook_grad_viewspace"],
+                  hook_magnitude=got["hook_magnitude"].reshape(-1, 1), hook_depth=got["hook_depth"].reshape(-1, 1),
+                  hook_uv=got["hook_uv"], features_after_forward=got["features"])
+    for name, a in fields.items():
+        tol = 1e-4 if "grad" in name or "magnitude" in name else 1e-6
+        d_rows = _rel(a[D[f"{name}_rows"]], D[f"{name}_sample"])
+        norms = D[f"{name}_column_norms"]
+        d_norms = float(np.abs(np.linalg.norm(a.astype(np.float64), axis=0) - norms).max() / max(float(norms.max()), 1e-30))
+        print(f"[parity] reference_digest.hip.{name}: rows={d_rows:.3e}, column_norms={d_norms:.3e}")
+        assert d_rows <= tol and d_norms <= tol, (name, d_rows, d_norms)
