@@ -71,7 +71,8 @@ def _grad_tol(V):
     fp32 atomics (emulated in thread order: an undefined order on a GPU too), the oracle in double, the HIP path in a
     fixed fp32 tree; and these vectors were made with NumPy's fp32 exp, whose last bit differs from glibc's expf on 39 % of
     the inputs (BASELINE config 2 run both ways: 9e-6 with it, 7e-7 .. 1.3e-6 with exp correctly rounded,
-    tests/test_reference_digest.py) -- so the distance is the REFERENCE's own fp32 noise and grows with the terms per sum: observed
+    tests/test_reference_digest.py; vectors n and o regenerated that way: 1.9e-5 -> 1.8e-6 and 2.1e-5 -> 5.6e-6, only o's
+    36,864-term |grad uv| sums stay at 7.9e-6) -- so the distance is the REFERENCE's own fp32 noise and grows with the terms per sum: observed
     2e-7 .. 1e-6 on the vectors whose Gaussians touch up to 1,129 pixels (bar 2e-5); 8e-6 (j: up to 8,274 pixels per
     Gaussian), 1.4e-5 (k, BASELINE config 1: 1,550), 2.0e-5 (n: 6,223; o, the reference's stress distribution: every
     Gaussian over all 36,864 pixels) -- bar 5e-5 from 1,500 pixels per Gaussian on."""
