@@ -24,8 +24,11 @@
  *   [0] u  [1] v  [2] z (camera depth)  [3] qmax = 2 ln(255 opacity rescale) + 0.01 (exact-cull bound; +inf = off)
  *   [4] conic A  [5] conic B  [6] conic C  [7] 3-sigma radius   (UTL:257-272, RAS:311-315)
  *   [8] r  [9] g  [10] b  [11] opacity sigmoid(logit)            (RAS:299-310)
- *   [12] -0.5*A*log2(e)  [13] -B*log2(e)  [14] -0.5*C*log2(e)  [15] amp = opacity*rescale
- *        (the weight of UTL:275-284 as  amp * 2^(dx*(A'dx + B'dy) + C'dy^2), one v_exp_f32)
+ *   [12] -0.5*A*log2(e)  [13] -B*log2(e)  [14] -0.5*C*log2(e)  [15] rescale (UTL:266)
+ *        (the weight of UTL:275-284 as  opacity rescale 2^(dx*(A'dx + B'dy) + C'dy^2), one v_exp_f32; the two factors stay
+ *        apart because the reference multiplies exp(e) by rescale (UTL:284) and then by the opacity (RAS:447): where a
+ *        comparison with 1/255 or 1e-4 falls within the proven distance between the two roundings, the blend kernels
+ *        re-evaluate it exactly as the reference does, csrc/gs_common.h "threshold decisions")
  * Lists.  Sort keys are emitted per BIN of (1 << bin_shift)^2 tiles (bin_shift = 2: 64 x 64 pixels; 0: the
  * reference's per-tile keys).  A blend workgroup (one 16 x 16 tile) walks its bin's depth-sorted list and keeps,
  * in order, the entries that belong to its tile: `filter` = GS_FILTER_BOX (the tile lies in the Gaussian's tile
@@ -260,8 +263,6 @@ int gs_read_counters_async(const int32_t *counters, int32_t *host_counters_pinne
 #define GS_BLEND_RGB_ONLY 1
 #define GS_BLEND_NO_STATE 2
 #define GS_BLEND_TWO_WAVES 4    /* both blend passes: always the two-waves-per-tile kernels (two pixels per lane) */
-#define GS_BLEND_ONE_WAVE 16    /* gs_blend_backward only, per-tile lists: the measurement arm with one wave per tile and four
-                                   pixels per lane (slower; profiles/r03_pmc_blend.md) */
 #define GS_BLEND_FOUR_WAVES 8   /* both blend passes: the four-waves-per-tile kernels (one pixel per lane) whenever the lists
                                    are per-tile lists taken as they are (bin_shift 0, filter 0).  Default (neither flag):
                                    four waves when at most 3840 tiles are rendered -- a grid that cannot fill the chip with two.

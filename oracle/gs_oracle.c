@@ -63,12 +63,16 @@ typedef double real;
 #define R_FABS fabs
 #else
 typedef float real;
-#define R_EXP expf
-/* The scale activation exp(s) (GP3:175-178) is the one transcendental on the way to the INTEGER outputs (covariance ->
- * radius -> tile box -> counts, keys, slots): it is evaluated in double and rounded once, i.e. the correctly rounded
- * fp32 exponential (up to double rounding, probability 2^-29), on this side and in the HIP projection alike -- two
- * libms' expf differ in the last bit on a few per cent of the inputs (glibc's is correctly rounded on 99.93 %), and a
- * radius one ulp apart moves a tile-box edge across a tile boundary once in a few thousand frames (fuzz case 6102). */
+/* ONE DEFINITION OF exp ON EVERY SIDE (round 5): evaluated in double and rounded once, i.e. the correctly rounded fp32
+ * exponential (up to double rounding, probability 2^-29) -- here, in the emulated run of the reference's sources that
+ * produced tests/golden/reference_operator_*_exp_cr.npz (GS_EMU_EXP=cr) and in the HIP library wherever an exponential
+ * decides something discrete: the scale activation (GP3:175-178: covariance -> radius -> tile box -> counts, keys, slots),
+ * the opacity sigmoid (RAS:299-300: an input of every alpha >= 1/255 decision) and the exact re-evaluation of a Gaussian
+ * weight next to a threshold (csrc/gs_common.h, gs_alpha_reference_*).  Two libms' expf differ in the last bit on a few
+ * per cent of the inputs (glibc's is correctly rounded on 99.93 %); a radius one ulp apart moves a tile-box edge across a
+ * tile boundary once in a few thousand frames (fuzz case 6102), an alpha one ulp apart flips a skip decision once in a few
+ * frames of a million Gaussians. */
+#define R_EXP(x) ((float)exp((double)(x)))
 #define R_EXP_SCALE(x) ((float)exp((double)(x)))
 #define R_SQRT sqrtf
 #define R_FLOOR floorf

@@ -72,10 +72,6 @@ constexpr float STOP_T = 0.0001f;                  // RAS:458
 #define GS_BWD_REDUCE_STAGED GS_BWD_REDUCE_ARM
 #define GS_BWD_REDUCE_DIRECT GS_BWD_REDUCE_ARM
 #endif
-#ifndef GS_BWD_TRIM
-#define GS_BWD_TRIM 1        // 1: hit masks combined on the scalar unit, |v| accumulated with the VOP3 abs modifier, the four
-                             // list positions of a group read with one ds_read_b128
-#endif
 constexpr int GROUP = GS_GROUP_FWD > GS_GROUP_BWD ? (GS_GROUP_FWD > 4 ? GS_GROUP_FWD : 4) : (GS_GROUP_BWD > 4 ? GS_GROUP_BWD : 4);
                               // padding granularity of a staged batch (BATCH % GROUP == 0; covers both group sizes)
 constexpr int GROUP_FWD = GS_GROUP_FWD;  // list entries evaluated together in the forward blend loop
@@ -142,6 +138,71 @@ __device__ __forceinline__ v2f gs_pair_alpha(const float4 p, const float4 q, con
     return (v2f){__builtin_amdgcn_exp2f(e.x), __builtin_amdgcn_exp2f(e.y)} * splat(q.w);
 }
 __device__ __forceinline__ unsigned long long gs_ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+
+// ------------------------------------------------------------------------------- decisions as the reference takes them
+// (bounds and the exact expressions: gs_common.h)  What a staged entry leaves in LDS: row 0 with the RESCALE factor in .w
+// (the record keeps opacity and rescale apart -- the reference multiplies exp(e) by them one after the other, UTL:284 and
+// RAS:447), row 3 with amp = opacity * rescale in .w for the fast path, and the conic's kappa.
+__device__ __forceinline__ void gs_stage_rows(const float4 r0, const float4 r1, const float4 r2, const float4 r3, float4 &sp,
+                                              float4 &sq, float &kappa) {
+    sp = make_float4(r0.x, r0.y, r0.z, r3.w);
+    sq = make_float4(r3.x, r3.y, r3.z, r2.w * r3.w);
+    kappa = gs_conic_kappa(r1.x, r1.y, r1.z);
+}
+// [lo, hi) around `centre` with relative half-width `rel` (|ln fast - ln reference| <= rel): below lo and at or above hi the
+// fast value decides as the reference does.  rel >= 1/2 (a conic fp32 barely resolves) opens the bracket completely.
+__device__ __forceinline__ void gs_bracket(float centre, float rel, float &lo, float &hi) {
+    const bool open = !(rel < 0.5f);
+    lo = open ? 0.f : centre * (1.f - rel);
+    hi = open ? __builtin_inff() : centre / (1.f - rel);
+}
+__device__ __forceinline__ float gs_uniform(float x) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, x)));
+}
+// largest kappa of a staged batch (s_k[0 .. BATCH), zero behind the staged entries), wave-uniform
+__device__ __forceinline__ float gs_batch_kappa(const float *s_k) {
+    const int lane = gs_lane();
+    float m = fmaxf(s_k[lane], s_k[lane + GS_WAVE]);
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) m = fmaxf(m, __shfl_xor(m, d, GS_WAVE));
+    return gs_uniform(m);
+}
+// Does the REFERENCE's forward pass stop pixel (pxr, pyr) exactly at list position j_cur?  The whole wave replays the
+// pixel's history from the start of the list in the reference's arithmetic (RAS:440-470 with UTL:275-284 and the correctly
+// rounded exponential): 64 list entries per step, one per lane, then the transmittance recurrence over the hits in list
+// order.  FILTERED: the list covers a bin of several tiles -- the entries of other tiles are skipped as the staging
+// skips them (gs_entry_in_tile: the reference's tile box, RAS:81-103, and optionally the exact cull).  Called a few hundred
+// times per full-size frame: when a T' lands inside the bracket around 1e-4.
+template <bool FILTERED>
+__device__ __forceinline__ bool gs_reference_stops_at(const int32_t *__restrict__ payload, const float4 *__restrict__ attrs,
+                                                      int start, int j_cur, float pxr, float pyr, int tile_u, int tile_v,
+                                                      int tw, int th, int filter) {
+    const int lane = gs_lane();
+    float T = 1.0f;
+    for (int base = start; base <= j_cur; base += GS_WAVE) {
+        const int j = base + lane;
+        bool valid = j <= j_cur;
+        float a = 0.f;
+        if (valid) {
+            const float4 *g = attrs + 4 * (size_t)payload[j];
+            const float4 r0 = g[0], r1 = g[1];
+            if (FILTERED) valid = gs_entry_in_tile(r0, r1, tile_u, tile_v, tw, th, filter);
+            if (valid)
+                a = gs_alpha_reference_forward(pxr - r0.x, pyr - r0.y, r1.x, r1.y, r1.z,
+                                               reinterpret_cast<const float *>(g)[15], reinterpret_cast<const float *>(g)[11]);
+        }
+        unsigned long long m = gs_ballot(valid && a >= EPS_ALPHA);
+        while (m != 0ull) {
+            const int l = __builtin_ctzll(m);
+            m &= m - 1ull;
+            const float al = fminf(gs_readlane_f(a, l), CLAMP_ALPHA);
+            const float Tn = T * (1.0f - al);
+            if (Tn < STOP_T) return base + l == j_cur;   // RAS:458-460: the reference saturates the pixel here
+            T = Tn;
+        }
+    }
+    return false;
+}
 
 constexpr int BLEND_THREADS = 128;
 constexpr int BATCH = 128;               // staged (kept) entries per blend round
@@ -333,10 +394,12 @@ __global__ __launch_bounds__(BLEND_THREADS) void blend_forward_kernel(
     float *__restrict__ acc_alpha, int32_t *__restrict__ last_effective, int32_t *__restrict__ valid_count,
     uint32_t *__restrict__ debug_hits, const int32_t *__restrict__ tile_order, int32_t *__restrict__ tile_work,
     int32_t *__restrict__ walked_list, int32_t *__restrict__ walked_start) {
-    __shared__ float4 s_p[BATCH], s_c[BATCH], s_q[BATCH];  // rows 0, 2, 3 of the kept records
+    __shared__ float4 s_p[BATCH], s_b[BATCH], s_c[BATCH], s_q[BATCH];  // rows 0..3 of the kept records (gs_stage_rows)
+    __shared__ float s_k[BATCH];                           // their conics' kappa (width of the decision brackets)
     __shared__ int s_j[BATCH];                             // their list positions (last_effective is one of them + 1)
     __shared__ int s_o[DEBUG ? BATCH : 1];
     __shared__ int s_cnt[2 * FILL_PER_THREAD], s_next[1];
+    static_assert(BATCH == 2 * GS_WAVE && BLEND_THREADS == BATCH, "gs_batch_kappa, the s_k padding");
     const int tw = width / GS_TILE_WIDTH, th = height / GS_TILE_HEIGHT;
     const TileCoord tc = owned_tile(tw, row_begin, row_step, tile_order);
     const int tid = threadIdx.x;
@@ -369,12 +432,16 @@ __global__ __launch_bounds__(BLEND_THREADS) void blend_forward_kernel(
     auto keep = [&](const float4 r0, const float4 r1) {
         return gs_entry_in_tile(r0, r1, tc.tile_u, tc.tile_v, tw, th, filter);
     };
-    auto store = [&](int slot, int j, int o, const float4 r0, const float4, const float4 r2, const float4 r3) {
-        s_p[slot] = r0; s_c[slot] = r2; s_q[slot] = r3;
+    auto store = [&](int slot, int j, int o, const float4 r0, const float4 r1, const float4 r2, const float4 r3) {
+        float4 sp, sq;
+        float kappa;
+        gs_stage_rows(r0, r1, r2, r3, sp, sq, kappa);
+        s_p[slot] = sp; s_b[slot] = r1; s_c[slot] = r2; s_q[slot] = sq; s_k[slot] = kappa;
         if (STAGED) s_j[slot] = j;
         if (DEBUG) s_o[slot] = o;
         if (emit) walked_list[wbase + kept_base + slot] = o;
     };
+    float kappa_run = 0.f;   // largest kappa staged so far (wave-uniform)
 
     int pos = start;
     while (pos < end) {
@@ -393,8 +460,99 @@ __global__ __launch_bounds__(BLEND_THREADS) void blend_forward_kernel(
                 s_p[nbuf + tid] = make_float4(0.f, 0.f, 0.f, 0.f);
                 s_q[nbuf + tid] = make_float4(0.f, 0.f, 0.f, 0.f);
             }
+            if (tid >= nbuf) s_k[tid] = 0.f;
         }
         __syncthreads();
+        // The batch's decision brackets (gs_common.h), wave-uniform: [eps_lo, eps_hi) around the 1/255 skip threshold from the
+        // batch's largest kappa -- alpha below / above it decides as the reference's does, anything inside is settled by the
+        // entry's own bracket and, inside that, by the reference's expression -- and [stop_lo, stop_hi) around T' = 1e-4.
+        float eps_lo, eps_hi, stop_lo, stop_hi;
+        {
+            const float kb = gs_batch_kappa(s_k);
+            kappa_run = fmaxf(kappa_run, kb);
+            gs_bracket(EPS_ALPHA, gs_alpha_band(kb), eps_lo, eps_hi);
+            gs_bracket(STOP_T, gs_stop_band(kappa_run, kept_base + nbuf), stop_lo, stop_hi);
+            eps_lo = gs_uniform(eps_lo); eps_hi = gs_uniform(eps_hi);
+            stop_lo = gs_uniform(stop_lo); stop_hi = gs_uniform(stop_hi);
+        }
+        // The blend update of one entry, shared by the group loop and its careful twin below (al = 0 for a skipped pixel makes
+        // the update an exact no-op: T*(1-0) = T, C += c*0)
+        auto blend = [&](int e, float z, v2f al, v2f Tn, bool ok0, bool ok1) {
+            const v2f wgt = al * T;
+            const float4 c = s_c[e];
+            Cr = fma2(splat(c.x), wgt, Cr);
+            Cg = fma2(splat(c.y), wgt, Cg);
+            Cb = fma2(splat(c.z), wgt, Cb);
+            if (AUX) {
+                D = fma2(splat(z), wgt, D);
+                Wd = Wd + wgt;
+                cnt0 += ok0 ? 1 : 0;
+                cnt1 += ok1 ? 1 : 0;
+            }
+            T = Tn;
+            if (STATE) {
+                const int idx = (emit ? wbase + kept_base + e : STAGED ? s_j[e] : batch_first + e) + 1;
+                last0 = ok0 ? idx : last0;
+                last1 = ok1 ? idx : last1;
+            }
+            if (DEBUG) {
+                const unsigned hv = (unsigned)(s_o[e] + 1) * GS_HASH_MUL;
+                dc0 += ok0 ? 1u : 0u; dh0 += ok0 ? hv : 0u;
+                dc1 += ok1 ? 1u : 0u; dh1 += ok1 ? hv : 0u;
+            }
+        };
+        // One entry with every decision taken as the reference takes it: the group loop hands over (for the rest of its
+        // group) when a comparison falls inside a bracket -- a few hundred (wave, entry) visits per full-size frame.  alpha
+        // outside the ENTRY's own bracket is decided by the plain comparison, inside it by the reference's expression
+        // (UTL:275-284); a T' inside the stop bracket by a replay of the pixel's history in the reference's arithmetic.
+        // Kept out of the group loop's body so that its temporaries (double-precision exp, the replay's records) do not
+        // add to the registers of the hot path.
+        auto careful_entry = [&](int e) {
+            v2f dx;
+            float dy;
+            const float4 p = s_p[e];
+            const v2f a = gs_pair_alpha(p, s_q[e], px, py, dx, dy) * alive;
+            bool ok0 = a.x >= EPS_ALPHA, ok1 = a.y >= EPS_ALPHA;   // RAS:451
+            {
+                float lo, hi;
+                gs_bracket(EPS_ALPHA, gs_alpha_band(s_k[e]), lo, hi);
+                const bool in0 = a.x >= lo && a.x < hi, in1 = a.y >= lo && a.y < hi;
+                if (gs_ballot(in0 || in1) != 0ull) {
+                    const float4 b = s_b[e];
+                    const float opacity = s_c[e].w;
+#pragma clang loop unroll(disable)
+                    for (int c = 0; c < 2; ++c) {
+                        const float ex = gs_alpha_reference_forward(c ? dx.y : dx.x, dy, b.x, b.y, b.z, p.w, opacity);
+                        if (c ? in1 : in0) { if (c) ok1 = ex * alive.y >= EPS_ALPHA; else ok0 = ex * alive.x >= EPS_ALPHA; }
+                    }
+                }
+            }
+            if (gs_ballot(ok0 || ok1) == 0ull) return;
+            v2f al = {ok0 ? __builtin_amdgcn_fmed3f(a.x, 0.f, CLAMP_ALPHA) : 0.f,
+                      ok1 ? __builtin_amdgcn_fmed3f(a.y, 0.f, CLAMP_ALPHA) : 0.f};
+            v2f Tn = T * (splat(1.f) - al);
+            bool sat0 = ok0 && Tn.x < stop_lo, sat1 = ok1 && Tn.y < stop_lo;   // RAS:458-460, below the bracket
+            {
+                const bool fr0 = ok0 && !sat0 && Tn.x < stop_hi, fr1 = ok1 && !sat1 && Tn.y < stop_hi;
+                const unsigned long long mf0 = gs_ballot(fr0), mf1 = gs_ballot(fr1);
+                if ((mf0 | mf1) != 0ull) {
+                    const int j_cur = STAGED ? s_j[e] : batch_first + e;
+#pragma clang loop unroll(disable)
+                    for (int c = 0; c < 2; ++c)
+                        for (unsigned long long m = c ? mf1 : mf0; m != 0ull; m &= m - 1ull) {
+                            const int l = __builtin_ctzll(m);
+                            const bool stops = gs_reference_stops_at<STAGED>(
+                                payload, attrs, start, j_cur, gs_readlane_f(c ? px.y : px.x, l), gs_readlane_f(py, l),
+                                tc.tile_u, tc.tile_v, tw, th, filter);
+                            if ((tid & (GS_WAVE - 1)) == l) { if (c) sat1 = stops; else sat0 = stops; }
+                        }
+                }
+            }
+            if (sat0) { al.x = 0.f; alive.x = 0.f; ok0 = false; }
+            if (sat1) { al.y = 0.f; alive.y = 0.f; ok1 = false; }
+            Tn = T * (splat(1.f) - al);
+            blend(e, p.z, al, Tn, ok0, ok1);
+        };
         // Entries are evaluated in groups of GROUP: the LDS reads and the exp of a group are independent
         // and overlap (the per-pixel blend recurrence is the only serial part), which hides their latency.
         for (int k = 0; k < nbuf; k += GROUP_FWD) {
@@ -414,49 +572,36 @@ __global__ __launch_bounds__(BLEND_THREADS) void blend_forward_kernel(
             for (int i = 0; i < GROUP_FWD; ++i) { Cr = Cr + alpha[i]; last0 += (int)z[i]; }
             continue;
 #endif
+            int careful_from = GROUP_FWD;   // first entry of the group that needs the careful twin (none: GROUP_FWD)
 #pragma unroll
             for (int i = 0; i < GROUP_FWD; ++i) {
                 // a = alpha for a live pixel (x * 1.0f is exact), 0 for a saturated one
                 const v2f a = alpha[i] * alive;
-                bool ok0 = a.x >= EPS_ALPHA, ok1 = a.y >= EPS_ALPHA;  // RAS:451
+                bool ok0 = a.x >= eps_lo, ok1 = a.y >= eps_lo;        // RAS:451 (lower edge of the batch's bracket)
                 const unsigned long long mok0 = gs_ballot(ok0), mok1 = gs_ballot(ok1);
                 if ((mok0 | mok1) == 0ull) continue;                  // wave-uniform skip
-                // alpha = 0 for a skipped pixel makes the update below an exact no-op (T*(1-0) = T, C += c*0)
+                // an alpha inside the batch's bracket: the decision is not this loop's to take
+                if (((mok0 ^ gs_ballot(a.x >= eps_hi)) | (mok1 ^ gs_ballot(a.y >= eps_hi))) != 0ull) { careful_from = i; break; }
+                // alpha = 0 for a skipped pixel makes the update an exact no-op
                 v2f al = {ok0 ? __builtin_amdgcn_fmed3f(a.x, 0.f, CLAMP_ALPHA) : 0.f,
                           ok1 ? __builtin_amdgcn_fmed3f(a.y, 0.f, CLAMP_ALPHA) : 0.f};
                 v2f Tn = T * (splat(1.f) - al);
-                const bool low0 = Tn.x < STOP_T, low1 = Tn.y < STOP_T;
-                const bool sat0 = ok0 && low0, sat1 = ok1 && low1;
+                const bool low0 = Tn.x < stop_hi, low1 = Tn.y < stop_hi;
                 // (masks combined on the scalar unit: a ballot of the AND would be materialised as select + compare)
                 if (((mok0 & gs_ballot(low0)) | (mok1 & gs_ballot(low1))) != 0ull) {
                     // rare: RAS:458-460 -- the first Gaussian that would push T below 1e-4 saturates the
-                    // pixel and is NOT blended
+                    // pixel and is NOT blended (below the stop bracket on both sides; inside it: the careful twin)
+                    const bool sat0 = ok0 && Tn.x < stop_lo, sat1 = ok1 && Tn.y < stop_lo;
+                    if (gs_ballot((ok0 && low0 && !sat0) || (ok1 && low1 && !sat1)) != 0ull) { careful_from = i; break; }
                     if (sat0) { al.x = 0.f; alive.x = 0.f; ok0 = false; }
                     if (sat1) { al.y = 0.f; alive.y = 0.f; ok1 = false; }
                     Tn = T * (splat(1.f) - al);
                 }
-                const v2f wgt = al * T;
-                const float4 c = s_c[k + i];
-                Cr = fma2(splat(c.x), wgt, Cr);
-                Cg = fma2(splat(c.y), wgt, Cg);
-                Cb = fma2(splat(c.z), wgt, Cb);
-                if (AUX) {
-                    D = fma2(splat(z[i]), wgt, D);
-                    Wd = Wd + wgt;
-                    cnt0 += ok0 ? 1 : 0;
-                    cnt1 += ok1 ? 1 : 0;
-                }
-                T = Tn;
-                if (STATE) {
-                    const int idx = (emit ? wbase + kept_base + k + i : STAGED ? s_j[k + i] : batch_first + k + i) + 1;
-                    last0 = ok0 ? idx : last0;
-                    last1 = ok1 ? idx : last1;
-                }
-                if (DEBUG) {
-                    const unsigned hv = (unsigned)(s_o[k + i] + 1) * GS_HASH_MUL;
-                    dc0 += ok0 ? 1u : 0u; dh0 += ok0 ? hv : 0u;
-                    dc1 += ok1 ? 1u : 0u; dh1 += ok1 ? hv : 0u;
-                }
+                blend(k + i, z[i], al, Tn, ok0, ok1);
+            }
+            if (careful_from < GROUP_FWD) {
+#pragma clang loop unroll(disable)
+                for (int e = k + careful_from; e < k + GROUP_FWD; ++e) careful_entry(e);
             }
         }
         kept_base += nbuf;
@@ -508,7 +653,8 @@ __global__ __launch_bounds__(BLEND_THREADS, GS_BWD_MIN_WAVES) void blend_backwar
     int filter, const int32_t *__restrict__ slot_offsets, float4 *__restrict__ partials,
     uint8_t *__restrict__ slot_flags, float *__restrict__ magnitude_image, uint32_t *__restrict__ debug_hits,
     const int32_t *__restrict__ tile_order) {
-    __shared__ float4 s_p[BATCH], s_b[BATCH], s_c[BATCH], s_q[BATCH];  // rows 0..3 of the kept records
+    __shared__ float4 s_p[BATCH], s_b[BATCH], s_c[BATCH], s_q[BATCH];  // rows 0..3 of the kept records (gs_stage_rows)
+    __shared__ float s_k[BATCH];                   // their conics' kappa (width of the decision bracket)
     __shared__ __attribute__((aligned(16))) int s_j[BATCH];
     __shared__ int s_o[BATCH];
     __shared__ float s_acc[BATCH][GS_ACC_STRIDE];  // [entry][value]; value 10 = pixel count (as a float)
@@ -564,7 +710,10 @@ __global__ __launch_bounds__(BLEND_THREADS, GS_BWD_MIN_WAVES) void blend_backwar
         return gs_entry_in_tile(r0, r1, tc.tile_u, tc.tile_v, tw, th, filter);
     };
     auto store = [&](int slot_, int j, int o, const float4 r0, const float4 r1, const float4 r2, const float4 r3) {
-        s_p[slot_] = r0; s_b[slot_] = r1; s_c[slot_] = r2; s_q[slot_] = r3;
+        float4 sp, sq;
+        float kappa;
+        gs_stage_rows(r0, r1, r2, r3, sp, sq, kappa);
+        s_p[slot_] = sp; s_b[slot_] = r1; s_c[slot_] = r2; s_q[slot_] = sq; s_k[slot_] = kappa;
         if (STAGED) s_j[slot_] = j;
         s_o[slot_] = o;
     };
@@ -586,15 +735,19 @@ __global__ __launch_bounds__(BLEND_THREADS, GS_BWD_MIN_WAVES) void blend_backwar
                 s_q[nbuf + tid] = make_float4(0.f, 0.f, 0.f, 0.f);
                 s_j[nbuf + tid] = -1;
             }
+            if (tid >= nbuf) s_k[tid] = 0.f;
             float4 *z = reinterpret_cast<float4 *>(&s_acc[tid][0]);
             z[0] = make_float4(0.f, 0.f, 0.f, 0.f);
             z[1] = make_float4(0.f, 0.f, 0.f, 0.f);
             z[2] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
         __syncthreads();
+        // the batch's bracket around the 1/255 threshold (as in the forward kernel; wave-uniform)
+        float eps_lo, eps_hi;
+        gs_bracket(EPS_ALPHA, gs_alpha_band(gs_batch_kappa(s_k)), eps_lo, eps_hi);
+        eps_lo = gs_uniform(eps_lo); eps_hi = gs_uniform(eps_hi);
         for (int k = 0; k < nbuf; k += GROUP_BWD) {
             // descending positions: the whole group lies behind this wave's pixels
-#if GS_BWD_TRIM
             int jg[GROUP_BWD];
             if (STAGED) {
                 static_assert(GROUP_BWD % 4 == 0, "list positions are read four at a time");
@@ -608,30 +761,64 @@ __global__ __launch_bounds__(BLEND_THREADS, GS_BWD_MIN_WAVES) void blend_backwar
                 for (int i = 0; i < GROUP_BWD; ++i) jg[i] = batch_first - (k + i);
             }
             if (jg[GROUP_BWD - 1] >= wave_end) continue;
-#else
-            if ((STAGED ? s_j[k + GROUP_BWD - 1] : batch_first - (k + GROUP_BWD - 1)) >= wave_end) continue;
-#endif
             // group evaluation: LDS reads + exp of GROUP entries are independent and overlap
             v2f alpha[GROUP_BWD], dx[GROUP_BWD];
             float dy[GROUP_BWD];
 #pragma unroll
             for (int i = 0; i < GROUP_BWD; ++i) alpha[i] = gs_pair_alpha(s_p[k + i], s_q[k + i], px, py, dx[i], dy[i]);
+            // (A) the 1/255 decisions of the whole group (RAS:631): lower edge of the batch's bracket; an entry with an alpha
+            // inside the bracket is noted and settled before any entry is processed -- between the evaluation and the hit path,
+            // where few registers are live
+            bool a0[GROUP_BWD], a1[GROUP_BWD];
+            unsigned bracketed = 0u;   // wave-uniform: bit i = entry k + i has an alpha inside the batch's bracket
 #pragma unroll
             for (int i = 0; i < GROUP_BWD; ++i) {
-                const bool a0 = alpha[i].x >= EPS_ALPHA, a1 = alpha[i].y >= EPS_ALPHA;  // RAS:631, as RAS:451
-#if GS_BWD_TRIM
-                const unsigned long long ma0 = gs_ballot(a0), ma1 = gs_ballot(a1);
+                a0[i] = alpha[i].x >= eps_lo; a1[i] = alpha[i].y >= eps_lo;
+                const unsigned long long ma0 = gs_ballot(a0[i]), ma1 = gs_ballot(a1[i]);
+                if ((ma0 | ma1) != 0ull &&
+                    ((ma0 ^ gs_ballot(alpha[i].x >= eps_hi)) | (ma1 ^ gs_ballot(alpha[i].y >= eps_hi))) != 0ull)
+                    bracketed |= 1u << i;
+            }
+            if (bracketed != 0u) {
+                // rare (a few hundred (wave, entry) visits per full-size frame): outside the ENTRY's own bracket the plain
+                // comparison decides as the reference does, inside it the REFERENCE'S BACKWARD expression does (UTL:331-348:
+                // m = conic @ d first -- the reference's two passes round alpha differently and so may decide a pair
+                // differently; each pass of this library follows its counterpart)
+#pragma clang loop unroll(disable)
+                for (int ii = 0; ii < GROUP_BWD; ++ii) {
+                    if (((bracketed >> ii) & 1u) == 0u) continue;
+                    const int e = k + ii;
+                    v2f dxe;
+                    float dye;
+                    const float4 p = s_p[e];
+                    const v2f al = gs_pair_alpha(p, s_q[e], px, py, dxe, dye);
+                    float lo, hi;
+                    gs_bracket(EPS_ALPHA, gs_alpha_band(s_k[e]), lo, hi);
+                    bool r0 = al.x >= EPS_ALPHA, r1 = al.y >= EPS_ALPHA;
+                    const bool in0 = al.x >= lo && al.x < hi, in1 = al.y >= lo && al.y < hi;
+                    if (gs_ballot(in0 || in1) != 0ull) {
+                        const float4 b = s_b[e];
+                        const float opacity = s_c[e].w;
+#pragma clang loop unroll(disable)
+                        for (int c = 0; c < 2; ++c) {
+                            const float ex = gs_alpha_reference_backward(c ? dxe.y : dxe.x, dye, b.x, b.y, b.z, p.w, opacity);
+                            if (c ? in1 : in0) { if (c) r1 = ex >= EPS_ALPHA; else r0 = ex >= EPS_ALPHA; }
+                        }
+                    }
+#pragma unroll
+                    for (int i = 0; i < GROUP_BWD; ++i)
+                        if (i == ii) { a0[i] = r0; a1[i] = r1; }
+                }
+            }
+            // (B) the hit path, entry by entry
+#pragma unroll
+            for (int i = 0; i < GROUP_BWD; ++i) {
+                const unsigned long long ma0 = gs_ballot(a0[i]), ma1 = gs_ballot(a1[i]);
                 if ((ma0 | ma1) == 0ull) continue;  // wave-uniform skip: no pixel of this wave is touched
                 const int jj = jg[i];
                 const bool l0 = jj < last0, l1 = jj < last1;                            // RAS:618 (effective range)
-                const bool hit0 = a0 && l0, hit1 = a1 && l1;
+                const bool hit0 = a0[i] && l0, hit1 = a1[i] && l1;
                 if (((ma0 & gs_ballot(l0)) | (ma1 & gs_ballot(l1))) == 0ull) continue;
-#else
-                if (gs_ballot(a0 || a1) == 0ull) continue;  // wave-uniform skip: no pixel of this wave is touched
-                const int jj = STAGED ? s_j[k + i] : batch_first - (k + i);
-                const bool hit0 = a0 && (jj < last0), hit1 = a1 && (jj < last1);  // RAS:618 (effective range)
-                if ((gs_ballot(hit0) | gs_ballot(hit1)) == 0ull) continue;
-#endif
                 // The twelve per-lane partial sums of this entry (in-lane sums over the lane's two pixels), in the order of
                 // the accumulator record: v0, v1 (dL/dmu), c00, c01, c11 (2 dL/dcov), gr, gg, gb (dL/drgb), w, |v|, count, 0.
                 v2f pq[11];   // the eleven packed (two-pixel) partials of this entry
@@ -658,15 +845,10 @@ __global__ __launch_bounds__(BLEND_THREADS, GS_BWD_MIN_WAVES) void blend_backwar
                     const v2f m0 = fma2(dx[i], splat(b.x), splat(b.y * dy[i]));
                     const v2f m1 = fma2(dx[i], splat(b.y), splat(b.z * dy[i]));
                     const v2f v0 = w * m0, v1 = w * m1;  // dL/dmu = dL/dg * g * (conic @ d)   (UTL:343)
-#if GS_BWD_TRIM
                     asm("v_add_f32 %0, |%1|, %0" : "+v"(mag_u.x) : "v"(v0.x));
                     asm("v_add_f32 %0, |%1|, %0" : "+v"(mag_u.y) : "v"(v0.y));
                     asm("v_add_f32 %0, |%1|, %0" : "+v"(mag_v.x) : "v"(v1.x));
                     asm("v_add_f32 %0, |%1|, %0" : "+v"(mag_v.y) : "v"(v1.y));
-#else
-                    mag_u = mag_u + (v2f){fabsf(v0.x), fabsf(v0.y)};
-                    mag_v = mag_v + (v2f){fabsf(v1.x), fabsf(v1.y)};
-#endif
                     const v2f c00 = v0 * m0, c01 = v0 * m1, c11 = v1 * m1;  // 2 dL/dcov (UTL:345-346)
                     const v2f n2 = fma2(v1, v1, v0 * v0);
                     const v2f nv = {__builtin_amdgcn_sqrtf(n2.x), __builtin_amdgcn_sqrtf(n2.y)};  // v_sqrt_f32, 1 ulp
@@ -816,10 +998,11 @@ __global__ __launch_bounds__(SMALL_THREADS) void blend_forward_small_kernel(
     int32_t *__restrict__ last_effective, int32_t *__restrict__ valid_count, uint32_t *__restrict__ debug_hits,
     const int32_t *__restrict__ tile_order, int32_t *__restrict__ tile_work, float4 *__restrict__ boundary,
     float4 *__restrict__ final_error) {
-    __shared__ float4 s_p[BATCH], s_c[BATCH], s_q[BATCH];
+    __shared__ float4 s_p[BATCH], s_b[BATCH], s_c[BATCH], s_q[BATCH];   // (gs_stage_rows)
+    __shared__ float s_k[BATCH];
     __shared__ int s_o[DEBUG ? BATCH : 1];
     __shared__ int s_red[SMALL_THREADS / GS_WAVE];
-    const int tw = width / GS_TILE_WIDTH;
+    const int tw = width / GS_TILE_WIDTH, th = height / GS_TILE_HEIGHT;
     const TileCoord tc = owned_tile(tw, row_begin, row_step, tile_order);
     const int tid = threadIdx.x;
     const int pu = tc.tile_u * GS_TILE_WIDTH + (tid & 15), pv = tc.tile_v * GS_TILE_HEIGHT + (tid >> 4);
@@ -834,6 +1017,7 @@ __global__ __launch_bounds__(SMALL_THREADS) void blend_forward_small_kernel(
     float Er = 0.f, Eg = 0.f, Eb = 0.f;
     int last = start, cnt = 0;
     unsigned dh = 0u, dc = 0u;
+    float kappa_run = 0.f;
     int pos = start;
     while (pos < end) {
         if (__syncthreads_and(alive == 0.f ? 1 : 0)) break;   // barrier (protects the staged batch) + whole-tile early exit
@@ -843,7 +1027,11 @@ __global__ __launch_bounds__(SMALL_THREADS) void blend_forward_small_kernel(
             if (tid < BATCH && j < end) {
                 const int o = payload[j];
                 const float4 *g = attrs + 4 * (size_t)o;
-                s_p[tid] = g[0]; s_c[tid] = g[2]; s_q[tid] = g[3];
+                const float4 r1 = g[1], r2 = g[2];
+                float4 sp, sq;
+                float kappa;
+                gs_stage_rows(g[0], r1, r2, g[3], sp, sq, kappa);
+                s_p[tid] = sp; s_b[tid] = r1; s_c[tid] = r2; s_q[tid] = sq; s_k[tid] = kappa;
                 if (DEBUG) s_o[tid] = o;
             }
         }
@@ -855,8 +1043,72 @@ __global__ __launch_bounds__(SMALL_THREADS) void blend_forward_small_kernel(
                 s_p[nbuf + tid] = make_float4(0.f, 0.f, 0.f, 0.f);
                 s_q[nbuf + tid] = make_float4(0.f, 0.f, 0.f, 0.f);
             }
+            if (tid >= nbuf && tid < BATCH) s_k[tid] = 0.f;
         }
         __syncthreads();
+        float eps_lo, eps_hi, stop_lo, stop_hi;   // the batch's decision brackets, as in blend_forward_kernel
+        {
+            const float kb = gs_batch_kappa(s_k);
+            kappa_run = fmaxf(kappa_run, kb);
+            gs_bracket(EPS_ALPHA, gs_alpha_band(kb), eps_lo, eps_hi);
+            gs_bracket(STOP_T, gs_stop_band(kappa_run, pos - start), stop_lo, stop_hi);
+            eps_lo = gs_uniform(eps_lo); eps_hi = gs_uniform(eps_hi);
+            stop_lo = gs_uniform(stop_lo); stop_hi = gs_uniform(stop_hi);
+        }
+        // (the one-pixel forms of blend_forward_kernel's `blend` and `careful_entry`: see there)
+        auto blend = [&](int e, float z, float al, float Tn, bool ok) {
+            const float wgt = al * T;
+            const float4 c = s_c[e];
+            if (track) {   // (wave-uniform)  exact sum - rounded sum of this step, to first order
+                const float nr = __builtin_fmaf(c.x, wgt, Cr), ng = __builtin_fmaf(c.y, wgt, Cg), nb_ = __builtin_fmaf(c.z, wgt, Cb);
+                Er += __builtin_fmaf(c.x, wgt, Cr - nr);
+                Eg += __builtin_fmaf(c.y, wgt, Cg - ng);
+                Eb += __builtin_fmaf(c.z, wgt, Cb - nb_);
+            }
+            Cr = __builtin_fmaf(c.x, wgt, Cr);
+            Cg = __builtin_fmaf(c.y, wgt, Cg);
+            Cb = __builtin_fmaf(c.z, wgt, Cb);
+            if (AUX) {
+                D = __builtin_fmaf(z, wgt, D);
+                Wd = Wd + wgt;
+                cnt += ok ? 1 : 0;
+            }
+            T = Tn;
+            if (STATE) last = ok ? batch_first + e + 1 : last;
+            if (DEBUG) {
+                const unsigned hv = (unsigned)(s_o[e] + 1) * GS_HASH_MUL;
+                dc += ok ? 1u : 0u; dh += ok ? hv : 0u;
+            }
+        };
+        auto careful_entry = [&](int e) {
+            float dx, dy;
+            const float4 p = s_p[e];
+            const float a = gs_pixel_alpha(p, s_q[e], px, py, dx, dy) * alive;
+            bool ok = a >= EPS_ALPHA;   // RAS:451
+            {
+                float lo, hi;
+                gs_bracket(EPS_ALPHA, gs_alpha_band(s_k[e]), lo, hi);
+                const bool in = a >= lo && a < hi;
+                if (gs_ballot(in) != 0ull) {
+                    const float4 b = s_b[e];
+                    const float ex = gs_alpha_reference_forward(dx, dy, b.x, b.y, b.z, p.w, s_c[e].w);
+                    if (in) ok = ex * alive >= EPS_ALPHA;
+                }
+            }
+            if (gs_ballot(ok) == 0ull) return;
+            float al = ok ? __builtin_amdgcn_fmed3f(a, 0.f, CLAMP_ALPHA) : 0.f;
+            float Tn = T * (1.f - al);
+            bool sat = ok && Tn < stop_lo;   // RAS:458-460, below the bracket
+            for (unsigned long long m = gs_ballot(ok && !sat && Tn < stop_hi); m != 0ull; m &= m - 1ull) {
+                const int l = __builtin_ctzll(m);
+                const bool stops = gs_reference_stops_at<false>(payload, attrs, start, batch_first + e, gs_readlane_f(px, l),
+                                                                gs_readlane_f(py, l), tc.tile_u, tc.tile_v, tw, th, 0);
+                if ((tid & (GS_WAVE - 1)) == l) sat = stops;
+            }
+            if (sat) { al = 0.f; alive = 0.f; ok = false; }
+            Tn = T * (1.f - al);
+            blend(e, p.z, al, Tn, ok);
+        };
         for (int k = 0; k < nbuf; k += GROUP_FWD) {
             if (gs_ballot(alive != 0.f) == 0ull) break;   // every pixel of this wave is saturated
             float alpha[GROUP_FWD], z[GROUP_FWD];
@@ -867,40 +1119,28 @@ __global__ __launch_bounds__(SMALL_THREADS) void blend_forward_small_kernel(
                 alpha[i] = gs_pixel_alpha(p, s_q[k + i], px, py, dx, dy);
                 z[i] = p.z;
             }
+            int careful_from = GROUP_FWD;
 #pragma unroll
             for (int i = 0; i < GROUP_FWD; ++i) {
                 const float a = alpha[i] * alive;
-                bool ok = a >= EPS_ALPHA;                               // RAS:451
-                if (gs_ballot(ok) == 0ull) continue;
+                bool ok = a >= eps_lo;                                  // RAS:451 (lower edge of the batch's bracket)
+                const unsigned long long mok = gs_ballot(ok);
+                if (mok == 0ull) continue;
+                if ((mok ^ gs_ballot(a >= eps_hi)) != 0ull) { careful_from = i; break; }
                 float al = ok ? __builtin_amdgcn_fmed3f(a, 0.f, CLAMP_ALPHA) : 0.f;
                 float Tn = T * (1.f - al);
-                const bool sat = ok && Tn < STOP_T;
-                if (gs_ballot(sat) != 0ull) {                           // RAS:458-460: saturates the pixel, NOT blended
+                const bool low = Tn < stop_hi;
+                if ((mok & gs_ballot(low)) != 0ull) {                   // RAS:458-460: saturates the pixel, NOT blended
+                    const bool sat = ok && Tn < stop_lo;
+                    if (gs_ballot(ok && low && !sat) != 0ull) { careful_from = i; break; }
                     if (sat) { al = 0.f; alive = 0.f; ok = false; }
                     Tn = T * (1.f - al);
                 }
-                const float wgt = al * T;
-                const float4 c = s_c[k + i];
-                if (track) {   // (wave-uniform)  exact sum - rounded sum of this step, to first order
-                    const float nr = __builtin_fmaf(c.x, wgt, Cr), ng = __builtin_fmaf(c.y, wgt, Cg), nb_ = __builtin_fmaf(c.z, wgt, Cb);
-                    Er += __builtin_fmaf(c.x, wgt, Cr - nr);
-                    Eg += __builtin_fmaf(c.y, wgt, Cg - ng);
-                    Eb += __builtin_fmaf(c.z, wgt, Cb - nb_);
-                }
-                Cr = __builtin_fmaf(c.x, wgt, Cr);
-                Cg = __builtin_fmaf(c.y, wgt, Cg);
-                Cb = __builtin_fmaf(c.z, wgt, Cb);
-                if (AUX) {
-                    D = __builtin_fmaf(z[i], wgt, D);
-                    Wd = Wd + wgt;
-                    cnt += ok ? 1 : 0;
-                }
-                T = Tn;
-                if (STATE) last = ok ? batch_first + k + i + 1 : last;
-                if (DEBUG) {
-                    const unsigned hv = (unsigned)(s_o[k + i] + 1) * GS_HASH_MUL;
-                    dc += ok ? 1u : 0u; dh += ok ? hv : 0u;
-                }
+                blend(k + i, z[i], al, Tn, ok);
+            }
+            if (careful_from < GROUP_FWD) {
+#pragma clang loop unroll(disable)
+                for (int e = k + careful_from; e < k + GROUP_FWD; ++e) careful_entry(e);
             }
         }
         // Boundary state after every 128 entries of the tile's list (split backward, blend_backward_small_kernel), at slot
@@ -954,7 +1194,8 @@ __global__ __launch_bounds__(SMALL_THREADS) void blend_backward_small_kernel(
     uint32_t *__restrict__ debug_hits, const int32_t *__restrict__ tile_order, int split,
     const float *__restrict__ image, const float4 *__restrict__ boundary, const float4 *__restrict__ final_error,
     int32_t *__restrict__ tile_counters, float2 *__restrict__ magnitude_parts) {
-    __shared__ float4 s_p[BATCH], s_b[BATCH], s_c[BATCH], s_q[BATCH];
+    __shared__ float4 s_p[BATCH], s_b[BATCH], s_c[BATCH], s_q[BATCH];   // (gs_stage_rows)
+    __shared__ float s_k[BATCH];
     __shared__ int s_o[BATCH];
     // one slice of partial sums PER WAVE, written with plain stores and added in a fixed order by the flush: four waves
     // meeting in one row with ds_add_f32 would sum in arrival order (two waves are safe: a + b = b + a) and the gradients
@@ -1016,7 +1257,11 @@ __global__ __launch_bounds__(SMALL_THREADS) void blend_backward_small_kernel(
             if (tid < BATCH && j >= bottom) {
                 const int o = payload[j];
                 const float4 *g = attrs + 4 * (size_t)o;
-                s_p[tid] = g[0]; s_b[tid] = g[1]; s_c[tid] = g[2]; s_q[tid] = g[3];
+                const float4 r1 = g[1], r2 = g[2];
+                float4 sp, sq;
+                float kappa;
+                gs_stage_rows(g[0], r1, r2, g[3], sp, sq, kappa);
+                s_p[tid] = sp; s_b[tid] = r1; s_c[tid] = r2; s_q[tid] = sq; s_k[tid] = kappa;
                 s_o[tid] = o;
             }
         }
@@ -1027,6 +1272,7 @@ __global__ __launch_bounds__(SMALL_THREADS) void blend_backward_small_kernel(
                 s_p[nbuf + tid] = make_float4(0.f, 0.f, 0.f, 0.f);
                 s_q[nbuf + tid] = make_float4(0.f, 0.f, 0.f, 0.f);
             }
+            if (tid >= nbuf && tid < BATCH) s_k[tid] = 0.f;
             {   // thread t clears rows t & 127 of slices 2 (t >> 7) and 2 (t >> 7) + 1
                 const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
@@ -1037,19 +1283,53 @@ __global__ __launch_bounds__(SMALL_THREADS) void blend_backward_small_kernel(
             }
         }
         __syncthreads();
+        float eps_lo, eps_hi;   // the batch's bracket around the 1/255 threshold, as in blend_backward_kernel
+        gs_bracket(EPS_ALPHA, gs_alpha_band(gs_batch_kappa(s_k)), eps_lo, eps_hi);
+        eps_lo = gs_uniform(eps_lo); eps_hi = gs_uniform(eps_hi);
         for (int k = 0; k < nbuf; k += GROUP_BWD) {
             if (batch_first - (k + GROUP_BWD - 1) >= wave_end) continue;   // the whole group lies behind this wave's pixels
             float alpha[GROUP_BWD], dx[GROUP_BWD], dy[GROUP_BWD];
 #pragma unroll
             for (int i = 0; i < GROUP_BWD; ++i) alpha[i] = gs_pixel_alpha(s_p[k + i], s_q[k + i], px, py, dx[i], dy[i]);
+            // (A) the group's 1/255 decisions, (then) the bracketed ones settled by the reference's backward expression, (B) the
+            // hit path: the one-pixel form of blend_backward_kernel's loop, see there
+            bool a0[GROUP_BWD];
+            unsigned bracketed = 0u;
 #pragma unroll
             for (int i = 0; i < GROUP_BWD; ++i) {
-                const bool a0 = alpha[i] >= EPS_ALPHA;                   // RAS:631, as RAS:451
-                const unsigned long long ma = gs_ballot(a0);
+                a0[i] = alpha[i] >= eps_lo;                              // RAS:631 (lower edge of the batch's bracket)
+                const unsigned long long ma = gs_ballot(a0[i]);
+                if (ma != 0ull && (ma ^ gs_ballot(alpha[i] >= eps_hi)) != 0ull) bracketed |= 1u << i;
+            }
+            if (bracketed != 0u) {
+#pragma clang loop unroll(disable)
+                for (int ii = 0; ii < GROUP_BWD; ++ii) {
+                    if (((bracketed >> ii) & 1u) == 0u) continue;
+                    const int e = k + ii;
+                    float dxe, dye;
+                    const float4 p = s_p[e];
+                    const float al = gs_pixel_alpha(p, s_q[e], px, py, dxe, dye);
+                    float lo, hi;
+                    gs_bracket(EPS_ALPHA, gs_alpha_band(s_k[e]), lo, hi);
+                    bool r0 = al >= EPS_ALPHA;
+                    const bool in = al >= lo && al < hi;
+                    if (gs_ballot(in) != 0ull) {
+                        const float4 b = s_b[e];
+                        const float ex = gs_alpha_reference_backward(dxe, dye, b.x, b.y, b.z, p.w, s_c[e].w);
+                        if (in) r0 = ex >= EPS_ALPHA;
+                    }
+#pragma unroll
+                    for (int i = 0; i < GROUP_BWD; ++i)
+                        if (i == ii) a0[i] = r0;
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < GROUP_BWD; ++i) {
+                const unsigned long long ma = gs_ballot(a0[i]);
                 if (ma == 0ull) continue;
                 const int jj = batch_first - (k + i);
                 const bool l0 = jj < last;                               // RAS:618 (effective range)
-                const bool hit = a0 && l0;
+                const bool hit = a0[i] && l0;
                 if ((ma & gs_ballot(l0)) == 0ull) continue;
                 const float h = hit ? 1.f : 0.f;
                 const float al = hit ? __builtin_amdgcn_fmed3f(alpha[i], 0.f, CLAMP_ALPHA) : 0.f;
@@ -1148,148 +1428,6 @@ __global__ __launch_bounds__(SMALL_THREADS) void blend_backward_small_kernel(
         }
         magnitude_image[2 * p] = su;
         magnitude_image[2 * p + 1] = sv;
-    }
-}
-
-// ------------------------------------------------------------------------------- measurement arm: one wave per tile
-// FOUR pixels per lane, one wave per tile -- one 34-instruction reduce-scatter per (tile, entry)
-// instead of two plus the LDS combine, at the price of 33 in-lane additions instead of 11 and of the half-tile skip (a
-// wave now covers the whole tile, so "no pixel of this wave is hit" is rarer).  Per-tile lists taken as they are; selected
-// with GS_BLEND_ONE_WAVE.  Measured slower than the two-wave kernel (profiles/r03_pmc_blend.md), kept for the record.
-constexpr int WIDE_THREADS = 64;
-template <bool DEBUG>
-__global__ __launch_bounds__(WIDE_THREADS) void blend_backward_wide_kernel(
-    const int32_t *__restrict__ tile_start, const int32_t *__restrict__ payload, const float4 *__restrict__ attrs,
-    const float *__restrict__ grad_image, const float *__restrict__ acc_alpha, const int32_t *__restrict__ last_effective,
-    int width, int height, int row_begin, int row_step, const int32_t *__restrict__ slot_offsets,
-    float4 *__restrict__ partials, uint8_t *__restrict__ slot_flags, float *__restrict__ magnitude_image,
-    uint32_t *__restrict__ debug_hits, const int32_t *__restrict__ tile_order) {
-    __shared__ float4 s_p[BATCH], s_b[BATCH], s_c[BATCH], s_q[BATCH];
-    __shared__ int s_o[BATCH];
-    __shared__ float s_acc[BATCH][GS_ACC_STRIDE];
-    const int tw = width / GS_TILE_WIDTH, th = height / GS_TILE_HEIGHT;
-    const TileCoord tc = owned_tile(tw, row_begin, row_step, tile_order);
-    const int lane = threadIdx.x;
-    const int pu0 = tc.tile_u * GS_TILE_WIDTH + 4 * (lane & 3), pv = tc.tile_v * GS_TILE_HEIGHT + (lane >> 2);
-    const size_t p0 = (size_t)pv * width + pu0;
-    const int start = tile_start[tc.tile_id];
-    const float py = (float)pv + 0.5f;
-    float px[4], T[4], S[4], Gr[4], Gg[4], Gb[4], mag_u[4], mag_v[4];
-    int last[4];
-    unsigned dh[4], dc[4];
-    int mx = 0;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        px[q] = (float)(pu0 + q) + 0.5f;
-        last[q] = last_effective[p0 + q];
-        T[q] = 1.0f - acc_alpha[p0 + q];
-        S[q] = 0.f;
-        Gr[q] = grad_image[3 * (p0 + q)]; Gg[q] = grad_image[3 * (p0 + q) + 1]; Gb[q] = grad_image[3 * (p0 + q) + 2];
-        mag_u[q] = 0.f; mag_v[q] = 0.f; dh[q] = 0u; dc[q] = 0u;
-        mx = max(mx, last[q]);
-    }
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) mx = max(mx, __shfl_xor(mx, d, GS_WAVE));
-    const int end = mx;
-    const int row = lane >> 4;
-    const int slot = ((row & 1) << 1) | (row >> 1);
-    const bool row_tail = (lane & 15) == 15;
-    int pos = end - 1;
-    while (pos >= start) {
-        __builtin_amdgcn_wave_barrier();
-        const int batch_first = pos;
-#pragma unroll
-        for (int h = 0; h < BATCH / WIDE_THREADS; ++h) {
-            const int e = h * WIDE_THREADS + lane, j = pos - e;
-            if (j >= start) {
-                const int o = payload[j];
-                const float4 *g = attrs + 4 * (size_t)o;
-                s_p[e] = g[0]; s_b[e] = g[1]; s_c[e] = g[2]; s_q[e] = g[3];
-                s_o[e] = o;
-            } else {   // inert padding: amplitude 0 -> alpha 0, never a hit
-                s_p[e] = make_float4(0.f, 0.f, 0.f, 0.f);
-                s_q[e] = make_float4(0.f, 0.f, 0.f, 0.f);
-            }
-        }
-        const int nbuf = min(BATCH, pos - start + 1);
-        pos -= BATCH;
-        __builtin_amdgcn_wave_barrier();
-        for (int k = 0; k < nbuf; ++k) {
-            const float4 P = s_p[k], Q = s_q[k];
-            float alpha[4], dx[4], dy;
-            bool hit[4];
-            const int jj = batch_first - k;
-            bool any = false;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                alpha[q] = gs_pixel_alpha(P, Q, px[q], py, dx[q], dy);
-                hit[q] = alpha[q] >= EPS_ALPHA && jj < last[q];
-                any = any || hit[q];
-            }
-            if (gs_ballot(any) == 0ull) continue;
-            const float4 c = s_c[k], b = s_b[k];
-            float x[11];
-#pragma unroll
-            for (int n = 0; n < 11; ++n) x[n] = 0.f;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const float h = hit[q] ? 1.f : 0.f;
-                const float al = hit[q] ? __builtin_amdgcn_fmed3f(alpha[q], 0.f, CLAMP_ALPHA) : 0.f;
-                const float inv1m = __builtin_amdgcn_rcpf(1.f - al);
-                T[q] = T[q] * inv1m;
-                const float aT = al * T[q];
-                const float cg = __builtin_fmaf(c.z, Gb[q], __builtin_fmaf(c.y, Gg[q], c.x * Gr[q]));
-                const float dLda = __builtin_fmaf(T[q], cg, -(S[q] * inv1m)) * h;
-                S[q] = __builtin_fmaf(cg, aT, S[q]);
-                const float w = dLda * alpha[q];
-                const float m0 = __builtin_fmaf(dx[q], b.x, b.y * dy), m1 = __builtin_fmaf(dx[q], b.y, b.z * dy);
-                const float v0 = w * m0, v1 = w * m1;
-                mag_u[q] += fabsf(v0);
-                mag_v[q] += fabsf(v1);
-                x[0] += v0; x[1] += v1; x[2] += v0 * m0; x[3] += v0 * m1; x[4] += v1 * m1;
-                x[5] += aT * Gr[q]; x[6] += aT * Gg[q]; x[7] += aT * Gb[q]; x[8] += w;
-                x[9] += __builtin_amdgcn_sqrtf(__builtin_fmaf(v1, v1, v0 * v0)); x[10] += h;
-                if (DEBUG) {
-                    const unsigned hv = (unsigned)(s_o[k] + 1) * GS_HASH_MUL;
-                    dc[q] += hit[q] ? 1u : 0u; dh[q] += hit[q] ? hv : 0u;
-                }
-            }
-            float t0, t1, t2;
-            gs_wave_reduce12(x[0], x[1], x[2], x[3], x[4], x[5], x[6], x[7], x[8], x[9], x[10], 0.f, t0, t1, t2);
-            if (row_tail) {   // one wave per tile: plain stores, every entry of the round is written at most once
-                float *A = &s_acc[k][slot];
-                A[0] = t0; A[4] = t1; A[8] = t2;
-            }
-            if (lane == 0) s_o[k] |= 0x40000000;   // entry k was hit this round: its s_acc row is valid
-        }
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int h = 0; h < BATCH / WIDE_THREADS; ++h) {
-            const int e = h * WIDE_THREADS + lane;
-            if (e < nbuf && (s_o[e] & 0x40000000)) {
-                const int o = s_o[e] & 0x3fffffff;
-                const float4 *Sa = reinterpret_cast<const float4 *>(&s_acc[e][0]);
-                float4 r0 = Sa[0], r1 = Sa[1], r2 = Sa[2];
-                if (r2.z > 0.f) {
-                    const float4 a = s_p[e];
-                    int t0u, t1u, t0v, t1v;
-                    gs_tile_box(a.x, a.y, s_b[e].w, tw, th, t0u, t1u, t0v, t1v);
-                    const int dst_slot = slot_offsets[o] + (t1v - t0v) * (tc.tile_u - t0u) + (tc.tile_v - t0v);
-                    float4 *dst = partials + 3 * (size_t)dst_slot;
-                    r0.z *= 0.5f; r0.w *= 0.5f; r1.x *= 0.5f;
-                    r2.x *= (1.f - s_c[e].w);
-                    r2.z = __builtin_bit_cast(float, (int)r2.z);
-                    dst[0] = r0; dst[1] = r1; dst[2] = r2;
-                    slot_flags[dst_slot] = 1;
-                }
-            }
-        }
-    }
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        magnitude_image[2 * (p0 + q)] = mag_u[q];
-        magnitude_image[2 * (p0 + q) + 1] = mag_v[q];
-        if (DEBUG) { debug_hits[2 * (p0 + q)] = dc[q]; debug_hits[2 * (p0 + q) + 1] = dh[q]; }
     }
 }
 
@@ -1517,16 +1655,7 @@ int gs_blend_backward_split(const int32_t *bin_start, const int32_t *payload, co
     }
     const bool four_waves = !staged && !(flags & GS_BLEND_TWO_WAVES) &&
                             ((flags & GS_BLEND_FOUR_WAVES) || tw * rows <= GS_SMALL_GRID_TILES);
-    if (!staged && (flags & GS_BLEND_ONE_WAVE)) {   // measurement arm (four pixels per lane)
-        if (debug_pixel_hits != nullptr)
-            hipLaunchKernelGGL(blend_backward_wide_kernel<true>, grid, dim3(WIDE_THREADS), 0, s, bin_start, payload, a4,
-                               grad_image, acc_alpha, last_effective, width, height, tile_row_begin, tile_row_step,
-                               slot_offsets, p4, slot_flags, magnitude_image, debug_pixel_hits, tile_order);
-        else
-            hipLaunchKernelGGL(blend_backward_wide_kernel<false>, grid, dim3(WIDE_THREADS), 0, s, bin_start, payload, a4,
-                               grad_image, acc_alpha, last_effective, width, height, tile_row_begin, tile_row_step,
-                               slot_offsets, p4, slot_flags, magnitude_image, debug_pixel_hits, tile_order);
-    } else if (four_waves) {
+    if (four_waves) {
         // several workgroups per tile when the forward pass left its boundary states (see blend_backward_small_kernel)
         const bool can_split = image != nullptr && boundary_states != nullptr && split_workspace != nullptr;
         const int split = can_split ? backward_split_for(tw * rows) : 1;

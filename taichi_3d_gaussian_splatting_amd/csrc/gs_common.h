@@ -44,8 +44,103 @@ static inline int gs_div_up(long long a, long long b) { return (int)((a + b - 1)
 // ------------------------------------------------------------------ wave / block primitives
 #ifdef __HIPCC__
 
-// exp(x) correctly rounded to fp32 (double evaluation, one rounding): see the scale activation in gs_frontend.hip
-__device__ __forceinline__ float gs_exp_cr(float x) { return (float)exp((double)x); }
+// exp(x) correctly rounded to fp32: evaluated in double and rounded once (the oracle and the emulated reference run do the
+// same with their libm's double exp; two double evaluations that are each within an ulp of the true value round to the
+// same float unless it lies within ~2e-16 (relative) of a rounding boundary: once in ~1e8 calls).  See the scale activation
+// in gs_frontend.hip and the exact decisions of the blend kernels.  Written out (k = rint(x / ln 2), r = x - k ln 2 in two
+// pieces, Taylor polynomial of degree 13 on |r| <= 0.347: truncation 4e-18, then one ldexp) rather than calling the device
+// library's exp: a dozen live registers instead of forty, which matters where it is inlined next to a hot loop.
+// (A double literal the optimiser cannot hoist: left to itself it materialises the polynomial's coefficients at the top of
+// the kernel -- half of them in VGPR pairs, the scalar file being full -- where they stay live through the hot loops of the
+// blend kernels: +27 registers, one wave per SIMD less.  Two s_mov_b32 at the point of use instead.)
+template <unsigned long long BITS>
+__device__ __forceinline__ double gs_lit_f64() {
+    unsigned lo, hi;
+    asm volatile("s_mov_b32 %0, %2\n\ts_mov_b32 %1, %3" : "=s"(lo), "=s"(hi) : "i"((unsigned)(BITS & 0xffffffffull)), "i"((unsigned)(BITS >> 32)));
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | (unsigned long long)lo);
+}
+#define GS_LIT_F64(x) gs_lit_f64<__builtin_bit_cast(unsigned long long, (double)(x))>()
+__device__ __forceinline__ float gs_exp_cr(float xf) {
+    const double x = (double)fminf(fmaxf(xf, -800.0f), 100.0f);   // (NaN passes through fminf / fmaxf as the other operand: -800 -> 0)
+    const double kd = __builtin_rint(x * GS_LIT_F64(1.44269504088896340736));
+    double r = __builtin_fma(kd, GS_LIT_F64(-6.93147180369123816490e-01), x);
+    r = __builtin_fma(kd, GS_LIT_F64(-1.90821492927058770002e-10), r);
+    double p = GS_LIT_F64(1.0 / 6227020800.0);
+    p = __builtin_fma(p, r, GS_LIT_F64(1.0 / 479001600.0));
+    p = __builtin_fma(p, r, GS_LIT_F64(1.0 / 39916800.0));
+    p = __builtin_fma(p, r, GS_LIT_F64(1.0 / 3628800.0));
+    p = __builtin_fma(p, r, GS_LIT_F64(1.0 / 362880.0));
+    p = __builtin_fma(p, r, GS_LIT_F64(1.0 / 40320.0));
+    p = __builtin_fma(p, r, GS_LIT_F64(1.0 / 5040.0));
+    p = __builtin_fma(p, r, GS_LIT_F64(1.0 / 720.0));
+    p = __builtin_fma(p, r, GS_LIT_F64(1.0 / 120.0));
+    p = __builtin_fma(p, r, GS_LIT_F64(1.0 / 24.0));
+    p = __builtin_fma(p, r, GS_LIT_F64(1.0 / 6.0));
+    p = __builtin_fma(p, r, 0.5);
+    p = __builtin_fma(p, r, 1.0);
+    p = __builtin_fma(p, r, 1.0);
+    const float y = (float)__builtin_ldexp(p, (int)kd);
+    return xf != xf ? xf : y;
+}
+
+// ------------------------------------------------------------------ threshold decisions taken as the reference takes them
+// The blend kernels evaluate the Gaussian weight in the log2 domain from a pre-scaled conic (gs_pair_alpha, gs_blend.hip):
+// another fp32 rounding than the reference's expression (UTL:275-284 in the forward pass, UTL:331-348 in the backward
+// pass), so a pair whose alpha lies within a few 1e-6 (relative) of the 1/255 skip threshold (RAS:451 / RAS:631) could be
+// decided differently, and so could a pixel whose T' lies next to the 1e-4 stop threshold (RAS:458).  Those decisions are
+// discrete (a whole Gaussian blended or not), so the kernels bracket every comparison with a PROVEN bound on the distance
+// between their value and the reference's, and whatever falls inside the bracket is re-evaluated in the reference's own
+// expression order with the correctly rounded exponential (gs_exp_cr: the definition the oracle and the committed
+// reference-run vectors use) -- a wave-uniform rare path, a few hundred times per full-size frame.
+//
+// Bound on alpha (u = 2^-24, M = |A dx^2|/2 + |C dy^2|/2 + |B dx dy|, all from the same fp32 A, B, C, dx, dy on both sides):
+//   fast path : 3 roundings on the A term, 4 on the B and C terms, 1 on the sum            -> 5 u M on ln(alpha)
+//               v_exp_f32 1 ulp (taken as 4 u), amp = fl(opacity rescale), final product     -> 6 u
+//   reference : products and sums of UTL:281-283 (or UTL:336-339)                          -> 4 u M
+//               correctly rounded exp, x rescale, x opacity                                  -> 3 u
+//   total |ln alpha_fast - ln alpha_ref| <= 9 u (M + 1); GS_BAND_COEF = 12 adds a third (the largest ratio seen over 4e6
+//   random conics / pixels with anisotropy up to 100: 4.5, tools/alpha_band_check.py).
+// M against the exponent E = -(P + X), P = (A dx^2 + C dy^2)/2 >= 0, X = B dx dy, |X| <= rho P with rho = |B| / sqrt(A C):
+//   M = P + |X| <= |E| (1 + rho) / (1 - rho) = kappa |E|  -- kappa is a per-Gaussian constant (1 for an axis-aligned conic),
+//   and |E| = ln(amp / alpha) <= ln(255) < 5.6 wherever alpha is near 1/255 (amp <= 1).
+#define GS_BAND_COEF 12.0f
+#define GS_U24 5.9604644775390625e-8f
+// kappa of a conic, rounded up (approximate reciprocals and a 1 % allowance); degenerate, NaN and extreme (rho^2 > 0.9999) conics get 1e6, which
+// opens the bracket completely: every decision about such an entry is then taken by the exact expression
+__device__ __forceinline__ float gs_conic_kappa(float A, float B, float C) {
+    const float ac = A * C;
+    const float r2 = B * B * __builtin_amdgcn_rcpf(ac);
+    if (!(ac > 0.f) || !(r2 < 0.9999f)) return 1.0e6f;   // (1 - r2 keeps three digits up to here)
+    const float rho = __builtin_amdgcn_sqrtf(r2) * 1.0001f;
+    return (1.f + rho) * (1.f + rho) * __builtin_amdgcn_rcpf(1.f - r2) * 1.01f;
+}
+// relative half-width of the bracket around 1/255 for an entry (or a batch: its largest kappa)
+__device__ __forceinline__ float gs_alpha_band(float kappa) { return GS_BAND_COEF * GS_U24 * (5.6f * kappa + 1.0f); }
+// Relative half-width of the bracket around T' = 1e-4.  T is a product of (1 - a_i): the two sides' factors differ by
+// delta_i a_i / (1 - a_i) (+ 4 u of rounding per factor once the inputs differ), delta_i <= COEF u (kappa ln(1 / alpha_i) + 1).
+//   kappa part : a ln(1/a) / (1 - a) <= 5.55 ln(1 / (1 - a)) on [1/255, 0.99] (and <= 1 for a clamped factor), the logs sum to
+//                ln(1 / T') = 9.21 at the threshold                                           -> COEF u kappa_max 51.2
+//   flat part  : a / (1 - a) <= 21.5 ln(1 / (1 - a)) on the same interval (worst at the 0.99 clamp) -> COEF u 198
+//   rounding   : 4 u per blended entry, at most the list positions walked so far
+// kappa_max: the largest kappa among the entries the tile has staged so far (every pixel's history is a subset).
+__device__ __forceinline__ float gs_stop_band(float kappa_max, int walked) {
+    return GS_BAND_COEF * GS_U24 * (51.2f * kappa_max + 198.0f) + 4.0f * GS_U24 * (float)walked;
+}
+// alpha of UTL:275-284 (forward pass) and of UTL:331-348 (backward pass: m = conic @ d first) exactly as the reference
+// rounds them; dx, dy are the kernels' own px - u, py - v (the reference's xy_mean, same subtraction)
+__device__ __forceinline__ float gs_alpha_reference_forward(float dx, float dy, float A, float B, float C, float rescale,
+                                                            float opacity) {
+#pragma clang fp contract(off)
+    const float e = -0.5f * (dx * dx * A + dy * dy * C) - dx * dy * B;
+    return gs_exp_cr(e) * rescale * opacity;
+}
+__device__ __forceinline__ float gs_alpha_reference_backward(float dx, float dy, float A, float B, float C, float rescale,
+                                                             float opacity) {
+#pragma clang fp contract(off)
+    const float m0 = A * dx + B * dy, m1 = B * dx + C * dy;
+    const float e = -0.5f * (dx * m0 + dy * m1);
+    return gs_exp_cr(e) * rescale * opacity;
+}
 
 // RAS:81-103 get_bounding_box_by_point_and_radii (shared by the front end and the backward flush, which
 // must agree bit-for-bit on the box: it defines the slot of a (Gaussian, tile) pair, RAS:163-166)

@@ -477,7 +477,7 @@ __global__ __launch_bounds__(GS_BLOCK) void preprocess_kernel(
     int owned = 0, full = 0, dq = 0;
     const bool live = i < m;
     // quantities that outlive the geometry phase (the count phase below runs wave-convergent, outside any branch)
-    float u_ = 0.f, v_ = 0.f, z_ = 0.f, cA = 0.f, cB = 0.f, cC = 0.f, radius = 0.f, opacity = 0.f, amp = 0.f, qmax = 0.f;
+    float u_ = 0.f, v_ = 0.f, z_ = 0.f, cA = 0.f, cB = 0.f, cC = 0.f, radius = 0.f, opacity = 0.f, rescale = 0.f, qmax = 0.f;
     int t0u = 0, t1u = 0, t0v = 0, t1v = 0, id = 0;
     if (live) {
         id = ids[i];
@@ -547,14 +547,16 @@ __global__ __launch_bounds__(GS_BLOCK) void preprocess_kernel(
         float det0 = cov[0] * cov[3] - cov[1] * cov[2];
         float ca = cov[0] + 0.3f, cd = cov[3] + 0.3f;
         float det = ca * cd - cov[1] * cov[2];
-        float rescale = sqrtf(fmaxf(0.0f, det0 / det));
+        rescale = sqrtf(fmaxf(0.0f, det0 / det));
         float inv = 1.0f / det;
 
         // RAS:311-315 radius from the un-filtered covariance
         float dd = cov[0] - cov[3];
         float lam = (cov[0] + cov[3] + sqrtf(dd * dd + 4.0f * cov[1] * cov[2])) / 2.0f;
         radius = sqrtf(lam) * 3.0f;
-        opacity = 1.f / (1.f + expf(-f[7]));  // RAS:299-300
+        // (the correctly rounded exponential here too: the opacity is an INPUT of every 1/255 decision of the blend passes,
+        // which are taken exactly as the reference takes them only if both sides hold the same opacity bits)
+        opacity = 1.f / (1.f + gs_exp_cr(-f[7]));  // RAS:299-300
         cA = inv * cd; cB = inv * (-cov[1]); cC = inv * ca;
         u_ = uv[0]; v_ = uv[1]; z_ = c[2];
 
@@ -563,8 +565,7 @@ __global__ __launch_bounds__(GS_BLOCK) void preprocess_kernel(
         ntiles_full[i] = full;
         // the exact-cull bound of this Gaussian; +inf (never culled) when the cull is off.  Stored in the record: the
         // blend kernels apply the same test per tile.
-        amp = opacity * rescale;
-        qmax = cull ? gs_cull_qmax(amp) : __builtin_inff();
+        qmax = cull ? gs_cull_qmax(opacity * rescale) : __builtin_inff();
     }
     // number of sort keys = bins reached on this GPU: the walk of gs_make_keys on the same values (count and keys agree).
     // The (bin, Gaussian) pairs of a wave's 64 Gaussians are dealt to its lanes 64 at a time, so that ONE screen-filling
@@ -604,9 +605,11 @@ __global__ __launch_bounds__(GS_BLOCK) void preprocess_kernel(
         if (owned > 0) {
             out[1] = make_float4(cA, cB, cC, radius);
             out[2] = make_float4(rgb[0], rgb[1], rgb[2], opacity);
-            // the weight UTL:275-284 in the log2 domain: amp * 2^(dx*(A'dx + B'dy) + C'dy^2)
+            // the weight UTL:275-284 in the log2 domain: opacity * rescale * 2^(dx*(A'dx + B'dy) + C'dy^2).  The two factors
+            // stay apart in the record (opacity in row 2): the blend kernels multiply them when they stage an entry and need
+            // them one by one where they follow the reference's own rounding (gs_alpha_reference_*, gs_common.h)
             const float log2e = 1.4426950408889634f;
-            out[3] = make_float4((-0.5f * log2e) * cA, (-log2e) * cB, (-0.5f * log2e) * cC, amp);
+            out[3] = make_float4((-0.5f * log2e) * cA, (-log2e) * cB, (-0.5f * log2e) * cC, rescale);
         }
         nkeys[i] = owned;
     }

@@ -82,6 +82,12 @@ SCENES = {
     # THE REFERENCE'S OWN STRESS DISTRIBUTION (T_RAS:111-150: rows of U[0,1) data, camera 0.5 behind the cloud, every
     # Gaussian over nearly every tile) at 256 x 144 with 300 valid rows of 600 (synthetic.make_reference_stress_scene)
     "o_stress_distribution_256x144_tied_keys_stable_sort": ("stress:600:300:144:256", 3, {}, None),
+    # THE TRUCK CONFIGURATION'S RASTERISER PARAMETERS (round 5; config/tat_truck_every_8_test.yaml:44-47: near 0.4, far 2000,
+    # depth-to-sort-key scale 10 -- quantised depths of 20..40 over the whole cloud, so nearly every key of a tile ties):
+    # 6,000 Gaussians over 256 x 256 = 256 tiles, stable-sort patch
+    "p_truck_params_6000pts_256x256_tied_keys_stable_sort": (
+        dict(n=6000, height=256, width=256, s_min=0.01, s_max=0.06, sh_degree=3, seed=47, invalid_fraction=0.02), 3,
+        dict(near_plane=0.4, far_plane=2000.0, depth_to_sort_key_scale=10.0), None),
 }
 
 

@@ -39,7 +39,7 @@ def pack_attrs(f: dict, exact_cull: bool = False) -> np.ndarray:
     a[:, 12] = (np.float32(-0.5) * log2e) * a[:, 4]
     a[:, 13] = (-log2e) * a[:, 5]
     a[:, 14] = (np.float32(-0.5) * log2e) * a[:, 6]
-    a[:, 15] = amp
+    a[:, 15] = f["conic"][:, 3]                                           # rescale (the kernels form opacity * rescale)
     return a
 
 

@@ -80,7 +80,7 @@ def test_preprocess(ops, scene, ofwd):
     assert np.isinf(a[:, 3]).all() and (a[:, 3] > 0).all()     # cull off: the stored bound is +inf
     for name, sl, rtol in (("conic", slice(4, 7), 2e-5), ("radius", slice(7, 8), 1e-5), ("rgb", slice(8, 11), 2e-6),
                            ("opacity", slice(11, 12), 1e-6), ("prescaled_conic", slice(12, 15), 2e-5),
-                           ("amp", slice(15, 16), 2e-5)):
+                           ("rescale", slice(15, 16), 2e-5)):
         rows = emits
         frac = close_fraction(a[rows, sl], ref[rows, sl], rtol=rtol, atol=1e-7)
         report(f"preprocess.{name}", close=frac, max_abs=float(np.abs(a[rows, sl] - ref[rows, sl]).max()))

@@ -84,13 +84,12 @@ for _ in range(reps + 2):
         s.point_cloud, feat, s.point_object_id, s.camera_intrinsics, q_cp, t_cp, s.t_pointcloud_camera, ids, acc, attrs, 3,
         1.0, 0.5, 20.0, 5.0, 1.0, False, vmask, nowned))
     if ARMS and LAYOUT.bin_shift == 0:   # the forms of the blend kernels on the same per-tile lists
-        for arm_ in ("two_waves", "four_waves", "one_wave"):
+        for arm_ in ("two_waves", "four_waves"):
             arm_out[arm_] = timed(f"blend_backward[{arm_}]", lambda: hip_ops.blend_backward_partials(
                 start, payload, attrs, g, acc_alpha, last_eff, slot_off, n_slots, s.width, s.height, LAYOUT, arm=arm_,
                 tile_work=tile_work if ORDERED else None))
-            if arm_ != "one_wave":
-                timed(f"blend_forward[{arm_}]", lambda: hip_ops.blend_forward(
-                    start, end, payload, attrs, s.width, s.height, LAYOUT, arm=arm_, ordered=ORDERED))
+            timed(f"blend_forward[{arm_}]", lambda: hip_ops.blend_forward(
+                start, end, payload, attrs, s.width, s.height, LAYOUT, arm=arm_, ordered=ORDERED))
             arm_acc[arm_] = hip_ops.reduce_partials(slot_off, ntiles, arm_out[arm_][1], arm_out[arm_][0]).clone()
     if AB:   # A/B arm: slot reduction fused into the per-point kernel
         fused = timed("point_backward_fused", lambda: hip_ops.point_backward(
