@@ -20,15 +20,16 @@
  *
  * Packed per-visible-point record `attrs` (float[M][16], 64 B, 16-B aligned), produced by
  * gs_preprocess and gathered by the blend kernels with 16-B loads (rows 0 and 1 decide whether a list
- * entry belongs to a tile; forward blends from rows 0,2,3; backward from all four):
+ * entry belongs to a tile; both blend passes stage all four rows):
  *   [0] u  [1] v  [2] z (camera depth)  [3] qmax = 2 ln(255 opacity rescale) + 0.01 (exact-cull bound; +inf = off)
  *   [4] conic A  [5] conic B  [6] conic C  [7] 3-sigma radius   (UTL:257-272, RAS:311-315)
  *   [8] r  [9] g  [10] b  [11] opacity sigmoid(logit)            (RAS:299-310)
- *   [12] -0.5*A*log2(e)  [13] -B*log2(e)  [14] -0.5*C*log2(e)  [15] rescale (UTL:266)
- *        (the weight of UTL:275-284 as  opacity rescale 2^(dx*(A'dx + B'dy) + C'dy^2), one v_exp_f32; the two factors stay
- *        apart because the reference multiplies exp(e) by rescale (UTL:284) and then by the opacity (RAS:447): where a
- *        comparison with 1/255 or 1e-4 falls within the proven distance between the two roundings, the blend kernels
- *        re-evaluate it exactly as the reference does, csrc/gs_common.h "threshold decisions")
+ *   [12] amp = opacity * rescale  [13] stop-bracket weight (csrc/gs_common.h)  [14] 0  [15] rescale (UTL:266)
+ *        (alpha = amp * exp(e) with e the reference's exponent, evaluated in the reference's own operation order by each
+ *        pass -- UTL:281-283 forward, UTL:336-339 backward; opacity and rescale also stay apart because the reference
+ *        multiplies exp(e) by rescale (UTL:284) and then by the opacity (RAS:447): where a comparison with 1/255 or 1e-4
+ *        falls within the proven distance between the two roundings the blend kernels re-evaluate it exactly as the reference
+ *        does, csrc/gs_common.h "threshold decisions")
  * Lists.  Sort keys are emitted per BIN of (1 << bin_shift)^2 tiles (bin_shift = 2: 64 x 64 pixels; 0: the
  * reference's per-tile keys).  A blend workgroup (one 16 x 16 tile) walks its bin's depth-sorted list and keeps,
  * in order, the entries that belong to its tile: `filter` = GS_FILTER_BOX (the tile lies in the Gaussian's tile
@@ -307,6 +308,29 @@ int gs_blend_backward(const int32_t *bin_start, const int32_t *payload, const fl
  * With boundary_states / image / split_workspace NULL these are gs_blend_forward / gs_blend_backward. */
 #define GS_MAX_BACKWARD_SPLIT 4
 size_t gs_blend_boundary_bytes(int64_t list_length, int width, int height);
+/* Path statistics of the two-waves-per-tile blend kernels: counted only in a tuning build (-DGS_STATS=1, tools/blend_stats.py);
+ * the product build leaves them zero.  Synchronises `stream`, copies the GS_BLEND_STATS counters out and optionally clears
+ * them; returns 1 from a counting build, 0 from the product build, negative on error.
+ *   ENTRIES       (wave, list entry) visits whose alpha was evaluated          HIT_ENTRIES  visits that ran the hit path
+ *   HIT_PIXELS    pixels blended over those visits (of 128 per visit)          HIT_LANES    lanes with at least one of their two
+ *   CAREFUL_ENTRIES / BRACKETED  visits handed to the exact-decision path      EXACT_ALPHA  ... that evaluated the reference's expression
+ *   REPLAYS       pixel histories replayed for a T' next to 1e-4               REPLAY_ENTRIES  list positions those replays walked */
+#define GS_BLEND_STATS 16
+#define GS_STAT_FWD_ENTRIES 0
+#define GS_STAT_FWD_HIT_ENTRIES 1
+#define GS_STAT_FWD_HIT_PIXELS 2
+#define GS_STAT_FWD_HIT_LANES 3
+#define GS_STAT_FWD_CAREFUL_ENTRIES 4
+#define GS_STAT_FWD_EXACT_ALPHA 5
+#define GS_STAT_FWD_REPLAYS 6
+#define GS_STAT_FWD_REPLAY_ENTRIES 7
+#define GS_STAT_BWD_ENTRIES 8
+#define GS_STAT_BWD_HIT_ENTRIES 9
+#define GS_STAT_BWD_HIT_PIXELS 10
+#define GS_STAT_BWD_HIT_LANES 11
+#define GS_STAT_BWD_BRACKETED 12
+#define GS_STAT_BWD_EXACT_ALPHA 13
+int gs_blend_read_stats(uint64_t *counters, int clear, void *stream);
 size_t gs_blend_split_workspace_bytes(int width, int height);
 int gs_blend_forward_with_boundaries(const int32_t *bin_start, const int32_t *bin_end, const int32_t *payload,
                                      const float *attrs, int width, int height, int tile_row_begin,

@@ -54,6 +54,7 @@ _SIGNATURES = {
     "gs_blend_forward": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P]),
     "gs_blend_backward": (_I, [_P, _P, _P, _P, _P, _P, _P, _I64, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P, _P]),
     "gs_blend_boundary_bytes": (_c.c_size_t, [_I64, _I, _I]),
+    "gs_blend_read_stats": (_I, [_P, _I, _P]),
     "gs_blend_split_workspace_bytes": (_c.c_size_t, [_I, _I]),
     "gs_blend_forward_with_boundaries": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P,
                                               _P, _P, _I64, _P]),

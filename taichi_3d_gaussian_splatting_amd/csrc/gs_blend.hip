@@ -72,6 +72,23 @@ constexpr float STOP_T = 0.0001f;                  // RAS:458
 #define GS_BWD_REDUCE_STAGED GS_BWD_REDUCE_ARM
 #define GS_BWD_REDUCE_DIRECT GS_BWD_REDUCE_ARM
 #endif
+// Path statistics of the two-wave blend kernels (tuning builds only, -DGS_STATS=1: tools/blend_stats.py): how often the
+// hit path runs, how many of its lanes are live, how often the careful paths are entered.  One 64-bit atomic per wave and
+// event; gs_blend_read_stats reads (and clears) the counters -- all zero in the product build.
+#ifndef GS_STATS
+#define GS_STATS 0
+#endif
+__device__ unsigned long long gs_blend_stats_dev[GS_BLEND_STATS];
+#if GS_STATS
+#define GS_STAT(i, n) do { if ((threadIdx.x & 63) == 0) atomicAdd(&gs_blend_stats_dev[i], (unsigned long long)(n)); } while (0)
+#else
+#define GS_STAT(i, n) do { } while (0)
+#endif
+#ifndef GS_FWD_MIN_WAVES
+#define GS_FWD_MIN_WAVES 7   // second argument of __launch_bounds__ of the forward kernel: seven waves per SIMD = 72 registers, which
+                             // the allocator meets without scratch once asked (left alone it takes 79: six waves, forward
+                             // 0.278 -> 0.269 ms at the headline size)
+#endif
 constexpr int GROUP = GS_GROUP_FWD > GS_GROUP_BWD ? (GS_GROUP_FWD > 4 ? GS_GROUP_FWD : 4) : (GS_GROUP_BWD > 4 ? GS_GROUP_BWD : 4);
                               // padding granularity of a staged batch (BATCH % GROUP == 0; covers both group sizes)
 constexpr int GROUP_FWD = GS_GROUP_FWD;  // list entries evaluated together in the forward blend loop
@@ -116,67 +133,99 @@ __device__ __forceinline__ TileCoord owned_tile_at(int b, int nb, int tw, int ro
     return t;
 }
 
-// ------------------------------------------------------------------------------- forward
-// Workgroup = one tile = 2 wave64s; every lane owns TWO horizontally adjacent pixels and does its fp32
-// arithmetic on float2 values, which the compiler maps to the packed CDNA instructions
-// (v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32: two pixels per VALU issue).  The Gaussian weight uses the
-// pre-scaled row 3 of the record: alpha = amp * 2^(dx*(A'dx + B'dy) + C'dy^2)  -- 2 packed FMAs, 3 scalar
-// multiplies and one v_exp_f32 per pixel.
+// ------------------------------------------------------------------------------- the Gaussian weight
+// Workgroup = one tile = 2 wave64s; every lane owns TWO horizontally adjacent pixels and does its fp32 arithmetic on float2
+// values, which the compiler maps to the packed CDNA instructions (v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32: two pixels
+// per VALU issue).
 typedef float v2f __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ v2f fma2(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
 __device__ __forceinline__ v2f splat(float x) { return (v2f){x, x}; }
-
-// The Gaussian weight of one list entry at the two pixels of a lane (UTL:275-284 in the log2 domain, from rows 0 and 3
-// of the packed record).  BOTH blend kernels call this and nothing else to evaluate alpha: with contraction off the
-// two inlined copies are the same instruction sequence, so the forward and the backward pass take identical
-// `alpha >= 1/255` decisions for every (pixel, Gaussian) pair (RAS:451 vs RAS:631).
-__device__ __forceinline__ v2f gs_pair_alpha(const float4 p, const float4 q, const v2f px, const float py,
-                                             v2f &dx, float &dy) {
-    dx = px - splat(p.x);
-    dy = py - p.y;
-    const v2f e = fma2(dx, fma2(dx, splat(q.x), splat(q.y * dy)), splat(q.z * dy * dy));
-    return (v2f){__builtin_amdgcn_exp2f(e.x), __builtin_amdgcn_exp2f(e.y)} * splat(q.w);
-}
 __device__ __forceinline__ unsigned long long gs_ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+constexpr float GS_LOG2E = 1.4426950408889634f;
 
-// ------------------------------------------------------------------------------- decisions as the reference takes them
-// (bounds and the exact expressions: gs_common.h)  What a staged entry leaves in LDS: row 0 with the RESCALE factor in .w
-// (the record keeps opacity and rescale apart -- the reference multiplies exp(e) by them one after the other, UTL:284 and
-// RAS:447), row 3 with amp = opacity * rescale in .w for the fast path, and the conic's kappa.
-__device__ __forceinline__ void gs_stage_rows(const float4 r0, const float4 r1, const float4 r2, const float4 r3, float4 &sp,
-                                              float4 &sq, float &kappa) {
-    sp = make_float4(r0.x, r0.y, r0.z, r3.w);
-    sq = make_float4(r3.x, r3.y, r3.z, r2.w * r3.w);
-    kappa = gs_conic_kappa(r1.x, r1.y, r1.z);
+// What a staged list entry leaves in LDS for the group loops (two 16-B broadcast reads per entry and wave):
+//   P = (u, v, A, B)   Q = (C, amp, ., .)      amp = opacity * rescale, formed by gs_preprocess (float 12 of the record)
+//   forward:  Q.z = camera depth;  colour row (r, g, b, W), W = the Gaussian's stop-bracket weight (gs_stop_weight, float 13)
+//   backward: Q.z = radius, Q.w = rescale;  colour row (r, g, b, opacity)
+// THE EXPONENT IS THE REFERENCE'S TO THE LAST BIT (gs_common.h, "threshold decisions"): each pass evaluates the quadratic
+// form in the operation order of its counterpart, contraction off (this file) --
+//   forward  UTL:281-283   e = -0.5 * (dx*dx*A + dy*dy*C) - dx*dy*B        (the final fma rounds once, as the reference's
+//                                                                           subtraction does: -0.5 * t is exact)
+//   backward UTL:336-339   m = conic @ d,  e = -0.5 * (dx*m0 + dy*m1)      (m is also what the gradients need, UTL:343-346)
+// -- and alpha = 2^(e * log2 e) * amp: four packed instructions more per pixel pair than the pre-scaled log2-domain form of
+// rounds 1-4 (two in the backward pass, which gets m for free), for an alpha within u (2 |e| + 9) of the reference's
+// whatever the conic, instead of 9 u times the cancellation inside the quadratic form.
+__device__ __forceinline__ v2f gs_weight_from_exponent(v2f e, float amp) {
+    const v2f e2 = e * splat(GS_LOG2E);
+    return (v2f){__builtin_amdgcn_exp2f(e2.x), __builtin_amdgcn_exp2f(e2.y)} * splat(amp);
 }
-// [lo, hi) around `centre` with relative half-width `rel` (|ln fast - ln reference| <= rel): below lo and at or above hi the
-// fast value decides as the reference does.  rel >= 1/2 (a conic fp32 barely resolves) opens the bracket completely.
-__device__ __forceinline__ void gs_bracket(float centre, float rel, float &lo, float &hi) {
-    const bool open = !(rel < 0.5f);
-    lo = open ? 0.f : centre * (1.f - rel);
-    hi = open ? __builtin_inff() : centre / (1.f - rel);
+__device__ __forceinline__ v2f gs_pair_alpha_forward(const float4 P, const float4 Q, const v2f px, const float py, v2f &e) {
+    const v2f dx = px - splat(P.x);
+    const float dy = py - P.y;
+    const v2f t = (dx * dx) * splat(P.z) + splat((dy * dy) * Q.x);
+    e = fma2(splat(-0.5f), t, -((dx * splat(dy)) * splat(P.w)));
+    return gs_weight_from_exponent(e, Q.y);
 }
-__device__ __forceinline__ float gs_uniform(float x) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, x)));
+__device__ __forceinline__ v2f gs_pair_alpha_backward(const float4 P, const float4 Q, const v2f px, const float py, v2f &e,
+                                                      v2f &m0, v2f &m1) {
+    const v2f dx = px - splat(P.x);
+    const float dy = py - P.y;
+    m0 = splat(P.z) * dx + splat(P.w * dy);
+    m1 = splat(P.w) * dx + splat(Q.x * dy);
+    e = splat(-0.5f) * (dx * m0 + splat(dy) * m1);
+    return gs_weight_from_exponent(e, Q.y);
 }
-// largest kappa of a staged batch (s_k[0 .. BATCH), zero behind the staged entries), wave-uniform
-__device__ __forceinline__ float gs_batch_kappa(const float *s_k) {
-    const int lane = gs_lane();
-    float m = fmaxf(s_k[lane], s_k[lane + GS_WAVE]);
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) m = fmaxf(m, __shfl_xor(m, d, GS_WAVE));
-    return gs_uniform(m);
+// (one pixel per lane: the four-waves-per-tile kernels and the replay; the same operations, component by component)
+__device__ __forceinline__ float gs_exponent_forward(float dx, float dy, float A, float B, float C) {
+    const float t = (dx * dx) * A + (dy * dy) * C;
+    return __builtin_fmaf(-0.5f, t, -((dx * dy) * B));
 }
-// Does the REFERENCE's forward pass stop pixel (pxr, pyr) exactly at list position j_cur?  The whole wave replays the
-// pixel's history from the start of the list in the reference's arithmetic (RAS:440-470 with UTL:275-284 and the correctly
-// rounded exponential): 64 list entries per step, one per lane, then the transmittance recurrence over the hits in list
-// order.  FILTERED: the list covers a bin of several tiles -- the entries of other tiles are skipped as the staging
-// skips them (gs_entry_in_tile: the reference's tile box, RAS:81-103, and optionally the exact cull).  Called a few hundred
-// times per full-size frame: when a T' lands inside the bracket around 1e-4.
-template <bool FILTERED>
+__device__ __forceinline__ float gs_pixel_alpha_forward(const float4 P, const float4 Q, float px, float py, float &e) {
+    e = gs_exponent_forward(px - P.x, py - P.y, P.z, P.w, Q.x);
+    return __builtin_amdgcn_exp2f(e * GS_LOG2E) * Q.y;
+}
+__device__ __forceinline__ float gs_pixel_alpha_backward(const float4 P, const float4 Q, float px, float py, float &e, float &m0,
+                                                         float &m1) {
+    const float dx = px - P.x, dy = py - P.y;
+    m0 = P.z * dx + P.w * dy;
+    m1 = P.w * dx + Q.x * dy;
+    e = -0.5f * (dx * m0 + dy * m1);
+    return __builtin_amdgcn_exp2f(e * GS_LOG2E) * Q.y;
+}
+// the bracket around the 1/255 skip threshold (gs_common.h): below EPS_LO / from EPS_HI on, the kernels' alpha decides as the
+// reference's does
+constexpr float EPS_LO = EPS_ALPHA * (1.0f - GS_ALPHA_BAND), EPS_HI = EPS_ALPHA / (1.0f - GS_ALPHA_BAND);
+// rows of a record as the forward / backward group loops want them (see above)
+__device__ __forceinline__ void gs_stage_forward(const float4 r0, const float4 r1, const float4 r2, const float4 r3, float4 &P,
+                                                 float4 &Q, float4 &colour, float2 &rescale_opacity) {
+    P = make_float4(r0.x, r0.y, r1.x, r1.y);
+    Q = make_float4(r1.z, r3.x, r0.z, 0.f);
+    colour = make_float4(r2.x, r2.y, r2.z, r3.y);
+    rescale_opacity = make_float2(r3.w, r2.w);
+}
+__device__ __forceinline__ void gs_stage_backward(const float4 r0, const float4 r1, const float4 r2, const float4 r3, float4 &P,
+                                                  float4 &Q, float4 &colour) {
+    P = make_float4(r0.x, r0.y, r1.x, r1.y);
+    Q = make_float4(r1.z, r3.x, r1.w, r3.w);
+    colour = r2;
+}
+// The pixel's bracket around T' = 1e-4 from thr (its upper edge as the group loop keeps it: per-Gaussian weights + 4 u per
+// list position walked) and the pixel's own number of blended Gaussians (what the rounding term really is; -1: unknown)
+__device__ __forceinline__ void gs_stop_bracket(float thr, int walked, int blended, float &lo, float &hi) {
+    hi = blended >= 0 ? thr - STOP_T * 1.1f * GS_STOP_ROUNDING_BAND * (float)(walked - blended) : thr;
+    lo = fmaxf(STOP_T - (hi - STOP_T) * (1.0f / 1.1f), 0.f);
+}
+// Does the REFERENCE's forward pass stop pixel (pxr, pyr) at or before list position j_cur?  The whole wave replays the
+// pixel's history from the start of the list in the reference's arithmetic (RAS:440-470: the reference's exponent, the
+// correctly rounded exponential, * rescale * opacity, T *= 1 - min(alpha, 0.99)): 64 list entries per step, one per lane,
+// then the transmittance recurrence over the hits in list order.  BOXED: the list covers a bin of several tiles -- entries
+// whose tile box (RAS:81-103) does not hold this tile are skipped, as the staging skips them (entries the exact cull removed
+// there fail the 1/255 test here).  Called about a thousand times per full-size frame: when a T' lands inside the pixel's
+// bracket around 1e-4 (and the brackets hold: the stop, if any, is at j_cur).
+template <bool BOXED>
 __device__ __forceinline__ bool gs_reference_stops_at(const int32_t *__restrict__ payload, const float4 *__restrict__ attrs,
                                                       int start, int j_cur, float pxr, float pyr, int tile_u, int tile_v,
-                                                      int tw, int th, int filter) {
+                                                      int tw, int th) {
     const int lane = gs_lane();
     float T = 1.0f;
     for (int base = start; base <= j_cur; base += GS_WAVE) {
@@ -186,18 +235,17 @@ __device__ __forceinline__ bool gs_reference_stops_at(const int32_t *__restrict_
         if (valid) {
             const float4 *g = attrs + 4 * (size_t)payload[j];
             const float4 r0 = g[0], r1 = g[1];
-            if (FILTERED) valid = gs_entry_in_tile(r0, r1, tile_u, tile_v, tw, th, filter);
+            if (BOXED) valid = gs_entry_in_tile(r0, r1, tile_u, tile_v, tw, th, GS_FILTER_BOX);
             if (valid)
-                a = gs_alpha_reference_forward(pxr - r0.x, pyr - r0.y, r1.x, r1.y, r1.z,
-                                               reinterpret_cast<const float *>(g)[15], reinterpret_cast<const float *>(g)[11]);
+                a = gs_alpha_reference(gs_exponent_forward(pxr - r0.x, pyr - r0.y, r1.x, r1.y, r1.z),
+                                       reinterpret_cast<const float *>(g)[15], reinterpret_cast<const float *>(g)[11]);
         }
         unsigned long long m = gs_ballot(valid && a >= EPS_ALPHA);
         while (m != 0ull) {
             const int l = __builtin_ctzll(m);
             m &= m - 1ull;
-            const float al = fminf(gs_readlane_f(a, l), CLAMP_ALPHA);
-            const float Tn = T * (1.0f - al);
-            if (Tn < STOP_T) return base + l == j_cur;   // RAS:458-460: the reference saturates the pixel here
+            const float Tn = T * (1.0f - fminf(gs_readlane_f(a, l), CLAMP_ALPHA));
+            if (Tn < STOP_T) return true;   // RAS:458-460: the reference saturates the pixel here
             T = Tn;
         }
     }
@@ -387,19 +435,18 @@ __global__ __launch_bounds__(ORDER_THREADS) void tile_order_kernel(
 // STATE: acc_alpha / last_effective are produced (what the backward pass needs; off for inference)
 // DEBUG: per-pixel {number of blended Gaussians, wrap-around sum of (payload+1)*GS_HASH_MUL} -> debug_hits (tests)
 template <bool STAGED, bool AUX, bool STATE, bool DEBUG>
-__global__ __launch_bounds__(BLEND_THREADS) void blend_forward_kernel(
+__global__ __launch_bounds__(BLEND_THREADS, GS_FWD_MIN_WAVES) void blend_forward_kernel(
     const int32_t *__restrict__ bin_start, const int32_t *__restrict__ bin_end,
     const int32_t *__restrict__ payload, const float4 *__restrict__ attrs, int width, int height, int row_begin,
     int row_step, int bin_shift, int filter, float *__restrict__ image, float *__restrict__ depth,
     float *__restrict__ acc_alpha, int32_t *__restrict__ last_effective, int32_t *__restrict__ valid_count,
     uint32_t *__restrict__ debug_hits, const int32_t *__restrict__ tile_order, int32_t *__restrict__ tile_work,
     int32_t *__restrict__ walked_list, int32_t *__restrict__ walked_start) {
-    __shared__ float4 s_p[BATCH], s_b[BATCH], s_c[BATCH], s_q[BATCH];  // rows 0..3 of the kept records (gs_stage_rows)
-    __shared__ float s_k[BATCH];                           // their conics' kappa (width of the decision brackets)
+    __shared__ float4 s_p[BATCH], s_q[BATCH], s_c[BATCH];  // P, Q and the colour row of the kept records (gs_stage_forward)
+    __shared__ float2 s_ro[BATCH];                         // their (rescale, opacity): read by the careful path only
     __shared__ int s_j[BATCH];                             // their list positions (last_effective is one of them + 1)
     __shared__ int s_o[DEBUG ? BATCH : 1];
     __shared__ int s_cnt[2 * FILL_PER_THREAD], s_next[1];
-    static_assert(BATCH == 2 * GS_WAVE && BLEND_THREADS == BATCH, "gs_batch_kappa, the s_k padding");
     const int tw = width / GS_TILE_WIDTH, th = height / GS_TILE_HEIGHT;
     const TileCoord tc = owned_tile(tw, row_begin, row_step, tile_order);
     const int tid = threadIdx.x;
@@ -433,15 +480,17 @@ __global__ __launch_bounds__(BLEND_THREADS) void blend_forward_kernel(
         return gs_entry_in_tile(r0, r1, tc.tile_u, tc.tile_v, tw, th, filter);
     };
     auto store = [&](int slot, int j, int o, const float4 r0, const float4 r1, const float4 r2, const float4 r3) {
-        float4 sp, sq;
-        float kappa;
-        gs_stage_rows(r0, r1, r2, r3, sp, sq, kappa);
-        s_p[slot] = sp; s_b[slot] = r1; s_c[slot] = r2; s_q[slot] = sq; s_k[slot] = kappa;
+        float4 P, Q, colour;
+        float2 ro;
+        gs_stage_forward(r0, r1, r2, r3, P, Q, colour, ro);
+        s_p[slot] = P; s_q[slot] = Q; s_c[slot] = colour; s_ro[slot] = ro;
         if (STAGED) s_j[slot] = j;
         if (DEBUG) s_o[slot] = o;
         if (emit) walked_list[wbase + kept_base + slot] = o;
     };
-    float kappa_run = 0.f;   // largest kappa staged so far (wave-uniform)
+    // upper edge of each pixel's bracket around T' = 1e-4 (gs_common.h, 4.): + 4 u per list position walked (batch by batch),
+    // + every blended Gaussian's weight times its alpha
+    v2f thr = splat(STOP_T);
 
     int pos = start;
     while (pos < end) {
@@ -460,26 +509,14 @@ __global__ __launch_bounds__(BLEND_THREADS) void blend_forward_kernel(
                 s_p[nbuf + tid] = make_float4(0.f, 0.f, 0.f, 0.f);
                 s_q[nbuf + tid] = make_float4(0.f, 0.f, 0.f, 0.f);
             }
-            if (tid >= nbuf) s_k[tid] = 0.f;
         }
         __syncthreads();
-        // The batch's decision brackets (gs_common.h), wave-uniform: [eps_lo, eps_hi) around the 1/255 skip threshold from the
-        // batch's largest kappa -- alpha below / above it decides as the reference's does, anything inside is settled by the
-        // entry's own bracket and, inside that, by the reference's expression -- and [stop_lo, stop_hi) around T' = 1e-4.
-        float eps_lo, eps_hi, stop_lo, stop_hi;
-        {
-            const float kb = gs_batch_kappa(s_k);
-            kappa_run = fmaxf(kappa_run, kb);
-            gs_bracket(EPS_ALPHA, gs_alpha_band(kb), eps_lo, eps_hi);
-            gs_bracket(STOP_T, gs_stop_band(kappa_run, kept_base + nbuf), stop_lo, stop_hi);
-            eps_lo = gs_uniform(eps_lo); eps_hi = gs_uniform(eps_hi);
-            stop_lo = gs_uniform(stop_lo); stop_hi = gs_uniform(stop_hi);
-        }
+        thr = thr + splat(STOP_T * 1.1f * GS_STOP_ROUNDING_BAND * (float)nbuf);
+        const int walked = kept_base + nbuf;   // list positions of the tile walked so far (this batch included)
         // The blend update of one entry, shared by the group loop and its careful twin below (al = 0 for a skipped pixel makes
         // the update an exact no-op: T*(1-0) = T, C += c*0)
-        auto blend = [&](int e, float z, v2f al, v2f Tn, bool ok0, bool ok1) {
+        auto blend = [&](int e, const float4 c, float z, v2f al, v2f Tn, bool ok0, bool ok1) {
             const v2f wgt = al * T;
-            const float4 c = s_c[e];
             Cr = fma2(splat(c.x), wgt, Cr);
             Cg = fma2(splat(c.y), wgt, Cg);
             Cb = fma2(splat(c.z), wgt, Cb);
@@ -502,48 +539,52 @@ __global__ __launch_bounds__(BLEND_THREADS) void blend_forward_kernel(
             }
         };
         // One entry with every decision taken as the reference takes it: the group loop hands over (for the rest of its
-        // group) when a comparison falls inside a bracket -- a few hundred (wave, entry) visits per full-size frame.  alpha
-        // outside the ENTRY's own bracket is decided by the plain comparison, inside it by the reference's expression
-        // (UTL:275-284); a T' inside the stop bracket by a replay of the pixel's history in the reference's arithmetic.
-        // Kept out of the group loop's body so that its temporaries (double-precision exp, the replay's records) do not
-        // add to the registers of the hot path.
+        // group) when a comparison falls inside a bracket -- about a thousand (wave, entry) visits per full-size frame.  An
+        // alpha inside [EPS_LO, EPS_HI) is decided by the reference's expression (same exponent, correctly rounded exp,
+        // * rescale * opacity); a T' inside the pixel's stop bracket by a replay of the pixel's history in the reference's
+        // arithmetic.  Kept out of the group loop's body so that its temporaries (double-precision exp, the replay's records)
+        // do not add to the registers of the hot path.
         auto careful_entry = [&](int e) {
-            v2f dx;
-            float dy;
-            const float4 p = s_p[e];
-            const v2f a = gs_pair_alpha(p, s_q[e], px, py, dx, dy) * alive;
+            v2f ex;
+            const float4 P = s_p[e], Q = s_q[e];
+            const v2f a = gs_pair_alpha_forward(P, Q, px, py, ex) * alive;
             bool ok0 = a.x >= EPS_ALPHA, ok1 = a.y >= EPS_ALPHA;   // RAS:451
             {
-                float lo, hi;
-                gs_bracket(EPS_ALPHA, gs_alpha_band(s_k[e]), lo, hi);
-                const bool in0 = a.x >= lo && a.x < hi, in1 = a.y >= lo && a.y < hi;
+                const bool in0 = a.x >= EPS_LO && a.x < EPS_HI, in1 = a.y >= EPS_LO && a.y < EPS_HI;
                 if (gs_ballot(in0 || in1) != 0ull) {
-                    const float4 b = s_b[e];
-                    const float opacity = s_c[e].w;
+                    GS_STAT(GS_STAT_FWD_EXACT_ALPHA, 1);
+                    const float2 ro = s_ro[e];
 #pragma clang loop unroll(disable)
                     for (int c = 0; c < 2; ++c) {
-                        const float ex = gs_alpha_reference_forward(c ? dx.y : dx.x, dy, b.x, b.y, b.z, p.w, opacity);
-                        if (c ? in1 : in0) { if (c) ok1 = ex * alive.y >= EPS_ALPHA; else ok0 = ex * alive.x >= EPS_ALPHA; }
+                        const float exact = gs_alpha_reference(c ? ex.y : ex.x, ro.x, ro.y);
+                        if (c ? in1 : in0) { if (c) ok1 = exact * alive.y >= EPS_ALPHA; else ok0 = exact * alive.x >= EPS_ALPHA; }
                     }
                 }
             }
             if (gs_ballot(ok0 || ok1) == 0ull) return;
             v2f al = {ok0 ? __builtin_amdgcn_fmed3f(a.x, 0.f, CLAMP_ALPHA) : 0.f,
                       ok1 ? __builtin_amdgcn_fmed3f(a.y, 0.f, CLAMP_ALPHA) : 0.f};
+            const float4 c = s_c[e];
+            thr = fma2(splat(c.w), al, thr);   // this Gaussian's share of the pixel's stop bracket (its own factor included)
             v2f Tn = T * (splat(1.f) - al);
-            bool sat0 = ok0 && Tn.x < stop_lo, sat1 = ok1 && Tn.y < stop_lo;   // RAS:458-460, below the bracket
+            float lo0, hi0, lo1, hi1;
+            gs_stop_bracket(thr.x, walked, AUX ? cnt0 + 1 : -1, lo0, hi0);
+            gs_stop_bracket(thr.y, walked, AUX ? cnt1 + 1 : -1, lo1, hi1);
+            // RAS:458-460: below the pixel's bracket it stops on both sides, inside it the reference's arithmetic decides
+            bool sat0 = ok0 && Tn.x < lo0, sat1 = ok1 && Tn.y < lo1;
             {
-                const bool fr0 = ok0 && !sat0 && Tn.x < stop_hi, fr1 = ok1 && !sat1 && Tn.y < stop_hi;
-                const unsigned long long mf0 = gs_ballot(fr0), mf1 = gs_ballot(fr1);
+                const unsigned long long mf0 = gs_ballot(ok0 && !sat0 && Tn.x < hi0), mf1 = gs_ballot(ok1 && !sat1 && Tn.y < hi1);
                 if ((mf0 | mf1) != 0ull) {
                     const int j_cur = STAGED ? s_j[e] : batch_first + e;
 #pragma clang loop unroll(disable)
                     for (int c = 0; c < 2; ++c)
                         for (unsigned long long m = c ? mf1 : mf0; m != 0ull; m &= m - 1ull) {
                             const int l = __builtin_ctzll(m);
-                            const bool stops = gs_reference_stops_at<STAGED>(
-                                payload, attrs, start, j_cur, gs_readlane_f(c ? px.y : px.x, l), gs_readlane_f(py, l),
-                                tc.tile_u, tc.tile_v, tw, th, filter);
+                            GS_STAT(GS_STAT_FWD_REPLAYS, 1);
+                            GS_STAT(GS_STAT_FWD_REPLAY_ENTRIES, j_cur - start + 1);
+                            const bool stops = gs_reference_stops_at<STAGED>(payload, attrs, start, j_cur,
+                                                                             gs_readlane_f(c ? px.y : px.x, l), gs_readlane_f(py, l),
+                                                                             tc.tile_u, tc.tile_v, tw, th);
                             if ((tid & (GS_WAVE - 1)) == l) { if (c) sat1 = stops; else sat0 = stops; }
                         }
                 }
@@ -551,7 +592,7 @@ __global__ __launch_bounds__(BLEND_THREADS) void blend_forward_kernel(
             if (sat0) { al.x = 0.f; alive.x = 0.f; ok0 = false; }
             if (sat1) { al.y = 0.f; alive.y = 0.f; ok1 = false; }
             Tn = T * (splat(1.f) - al);
-            blend(e, p.z, al, Tn, ok0, ok1);
+            blend(e, c, Q.z, al, Tn, ok0, ok1);
         };
         // Entries are evaluated in groups of GROUP: the LDS reads and the exp of a group are independent
         // and overlap (the per-pixel blend recurrence is the only serial part), which hides their latency.
@@ -561,11 +602,10 @@ __global__ __launch_bounds__(BLEND_THREADS) void blend_forward_kernel(
             float z[GROUP_FWD];
 #pragma unroll
             for (int i = 0; i < GROUP_FWD; ++i) {
-                v2f dx;
-                float dy;
-                const float4 p = s_p[k + i];
-                alpha[i] = gs_pair_alpha(p, s_q[k + i], px, py, dx, dy);
-                z[i] = p.z;
+                v2f ex;
+                const float4 Q = s_q[k + i];
+                alpha[i] = gs_pair_alpha_forward(s_p[k + i], Q, px, py, ex);
+                z[i] = Q.z;
             }
 #if GS_ABLATE_FWD == 1   // tuning only: evaluation without the blend (what the alpha evaluation of every visited entry costs)
 #pragma unroll
@@ -573,33 +613,43 @@ __global__ __launch_bounds__(BLEND_THREADS) void blend_forward_kernel(
             continue;
 #endif
             int careful_from = GROUP_FWD;   // first entry of the group that needs the careful twin (none: GROUP_FWD)
+            GS_STAT(GS_STAT_FWD_ENTRIES, GROUP_FWD);
 #pragma unroll
             for (int i = 0; i < GROUP_FWD; ++i) {
                 // a = alpha for a live pixel (x * 1.0f is exact), 0 for a saturated one
                 const v2f a = alpha[i] * alive;
-                bool ok0 = a.x >= eps_lo, ok1 = a.y >= eps_lo;        // RAS:451 (lower edge of the batch's bracket)
+                bool ok0 = a.x >= EPS_LO, ok1 = a.y >= EPS_LO;        // RAS:451 (lower edge of the bracket)
                 const unsigned long long mok0 = gs_ballot(ok0), mok1 = gs_ballot(ok1);
                 if ((mok0 | mok1) == 0ull) continue;                  // wave-uniform skip
-                // an alpha inside the batch's bracket: the decision is not this loop's to take
-                if (((mok0 ^ gs_ballot(a.x >= eps_hi)) | (mok1 ^ gs_ballot(a.y >= eps_hi))) != 0ull) { careful_from = i; break; }
+                GS_STAT(GS_STAT_FWD_HIT_ENTRIES, 1);
+                GS_STAT(GS_STAT_FWD_HIT_PIXELS, __popcll(mok0) + __popcll(mok1));
+                GS_STAT(GS_STAT_FWD_HIT_LANES, __popcll(mok0 | mok1));
+                // an alpha inside the bracket: the decision is not this loop's to take
+                if (((mok0 ^ gs_ballot(a.x >= EPS_HI)) | (mok1 ^ gs_ballot(a.y >= EPS_HI))) != 0ull) { careful_from = i; break; }
                 // alpha = 0 for a skipped pixel makes the update an exact no-op
                 v2f al = {ok0 ? __builtin_amdgcn_fmed3f(a.x, 0.f, CLAMP_ALPHA) : 0.f,
                           ok1 ? __builtin_amdgcn_fmed3f(a.y, 0.f, CLAMP_ALPHA) : 0.f};
+                const float4 c = s_c[k + i];
+                thr = fma2(splat(c.w), al, thr);   // this Gaussian's share of the pixel's stop bracket (its own factor included)
                 v2f Tn = T * (splat(1.f) - al);
-                const bool low0 = Tn.x < stop_hi, low1 = Tn.y < stop_hi;
+                const bool low0 = Tn.x < thr.x, low1 = Tn.y < thr.y;
                 // (masks combined on the scalar unit: a ballot of the AND would be materialised as select + compare)
                 if (((mok0 & gs_ballot(low0)) | (mok1 & gs_ballot(low1))) != 0ull) {
                     // rare: RAS:458-460 -- the first Gaussian that would push T below 1e-4 saturates the
-                    // pixel and is NOT blended (below the stop bracket on both sides; inside it: the careful twin)
-                    const bool sat0 = ok0 && Tn.x < stop_lo, sat1 = ok1 && Tn.y < stop_lo;
-                    if (gs_ballot((ok0 && low0 && !sat0) || (ok1 && low1 && !sat1)) != 0ull) { careful_from = i; break; }
+                    // pixel and is NOT blended (below the pixel's bracket on both sides; inside it: the careful twin)
+                    float lo0, hi0, lo1, hi1;
+                    gs_stop_bracket(thr.x, walked, AUX ? cnt0 + 1 : -1, lo0, hi0);
+                    gs_stop_bracket(thr.y, walked, AUX ? cnt1 + 1 : -1, lo1, hi1);
+                    const bool sat0 = ok0 && Tn.x < lo0, sat1 = ok1 && Tn.y < lo1;
+                    if (gs_ballot((ok0 && !sat0 && Tn.x < hi0) || (ok1 && !sat1 && Tn.y < hi1)) != 0ull) { careful_from = i; break; }
                     if (sat0) { al.x = 0.f; alive.x = 0.f; ok0 = false; }
                     if (sat1) { al.y = 0.f; alive.y = 0.f; ok1 = false; }
                     Tn = T * (splat(1.f) - al);
                 }
-                blend(k + i, z[i], al, Tn, ok0, ok1);
+                blend(k + i, c, z[i], al, Tn, ok0, ok1);
             }
             if (careful_from < GROUP_FWD) {
+                GS_STAT(GS_STAT_FWD_CAREFUL_ENTRIES, GROUP_FWD - careful_from);
 #pragma clang loop unroll(disable)
                 for (int e = k + careful_from; e < k + GROUP_FWD; ++e) careful_entry(e);
             }
@@ -640,8 +690,8 @@ __global__ __launch_bounds__(BLEND_THREADS) void blend_forward_kernel(
 // ------------------------------------------------------------------------------- backward
 // Workgroup = one tile = 2 wave64s, every lane owns two horizontally adjacent pixels (as in the forward kernel).
 // Doubling the pixels per lane halves the number of cross-lane reductions, LDS record reads and per-entry uniform work
-// per pixel; the kernel is bound by VALU issue.  alpha comes from gs_pair_alpha (the forward's expression: identical hit
-// decisions), the conic products are formed only on the hit path, w = dL/dalpha * alpha_unclamped (= dL/dg * g,
+// per pixel; the kernel is bound by VALU issue.  alpha comes from gs_pair_alpha_backward (the reference's backward
+// expression, whose m = conic @ d also serves the gradients), w = dL/dalpha * alpha_unclamped (= dL/dg * g,
 // UTL:343), and the twelve-value reduce-scatter carries the pixel count as a float (exact below 2^24).  Per round of up
 // to 128 staged entries the two waves combine their partial sums in LDS (ds_add_f32), then thread k stores entry k's
 // 48-B record into its (Gaussian, tile) slot (plain stores).
@@ -653,8 +703,7 @@ __global__ __launch_bounds__(BLEND_THREADS, GS_BWD_MIN_WAVES) void blend_backwar
     int filter, const int32_t *__restrict__ slot_offsets, float4 *__restrict__ partials,
     uint8_t *__restrict__ slot_flags, float *__restrict__ magnitude_image, uint32_t *__restrict__ debug_hits,
     const int32_t *__restrict__ tile_order) {
-    __shared__ float4 s_p[BATCH], s_b[BATCH], s_c[BATCH], s_q[BATCH];  // rows 0..3 of the kept records (gs_stage_rows)
-    __shared__ float s_k[BATCH];                   // their conics' kappa (width of the decision bracket)
+    __shared__ float4 s_p[BATCH], s_q[BATCH], s_c[BATCH];  // P, Q and the colour row of the kept records (gs_stage_backward)
     __shared__ __attribute__((aligned(16))) int s_j[BATCH];
     __shared__ int s_o[BATCH];
     __shared__ float s_acc[BATCH][GS_ACC_STRIDE];  // [entry][value]; value 10 = pixel count (as a float)
@@ -710,10 +759,9 @@ __global__ __launch_bounds__(BLEND_THREADS, GS_BWD_MIN_WAVES) void blend_backwar
         return gs_entry_in_tile(r0, r1, tc.tile_u, tc.tile_v, tw, th, filter);
     };
     auto store = [&](int slot_, int j, int o, const float4 r0, const float4 r1, const float4 r2, const float4 r3) {
-        float4 sp, sq;
-        float kappa;
-        gs_stage_rows(r0, r1, r2, r3, sp, sq, kappa);
-        s_p[slot_] = sp; s_b[slot_] = r1; s_c[slot_] = r2; s_q[slot_] = sq; s_k[slot_] = kappa;
+        float4 P, Q, colour;
+        gs_stage_backward(r0, r1, r2, r3, P, Q, colour);
+        s_p[slot_] = P; s_q[slot_] = Q; s_c[slot_] = colour;
         if (STAGED) s_j[slot_] = j;
         s_o[slot_] = o;
     };
@@ -735,17 +783,12 @@ __global__ __launch_bounds__(BLEND_THREADS, GS_BWD_MIN_WAVES) void blend_backwar
                 s_q[nbuf + tid] = make_float4(0.f, 0.f, 0.f, 0.f);
                 s_j[nbuf + tid] = -1;
             }
-            if (tid >= nbuf) s_k[tid] = 0.f;
             float4 *z = reinterpret_cast<float4 *>(&s_acc[tid][0]);
             z[0] = make_float4(0.f, 0.f, 0.f, 0.f);
             z[1] = make_float4(0.f, 0.f, 0.f, 0.f);
             z[2] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
         __syncthreads();
-        // the batch's bracket around the 1/255 threshold (as in the forward kernel; wave-uniform)
-        float eps_lo, eps_hi;
-        gs_bracket(EPS_ALPHA, gs_alpha_band(gs_batch_kappa(s_k)), eps_lo, eps_hi);
-        eps_lo = gs_uniform(eps_lo); eps_hi = gs_uniform(eps_hi);
         for (int k = 0; k < nbuf; k += GROUP_BWD) {
             // descending positions: the whole group lies behind this wave's pixels
             int jg[GROUP_BWD];
@@ -762,47 +805,47 @@ __global__ __launch_bounds__(BLEND_THREADS, GS_BWD_MIN_WAVES) void blend_backwar
             }
             if (jg[GROUP_BWD - 1] >= wave_end) continue;
             // group evaluation: LDS reads + exp of GROUP entries are independent and overlap
-            v2f alpha[GROUP_BWD], dx[GROUP_BWD];
-            float dy[GROUP_BWD];
-#pragma unroll
-            for (int i = 0; i < GROUP_BWD; ++i) alpha[i] = gs_pair_alpha(s_p[k + i], s_q[k + i], px, py, dx[i], dy[i]);
-            // (A) the 1/255 decisions of the whole group (RAS:631): lower edge of the batch's bracket; an entry with an alpha
-            // inside the bracket is noted and settled before any entry is processed -- between the evaluation and the hit path,
-            // where few registers are live
-            bool a0[GROUP_BWD], a1[GROUP_BWD];
-            unsigned bracketed = 0u;   // wave-uniform: bit i = entry k + i has an alpha inside the batch's bracket
+            v2f alpha[GROUP_BWD], m0[GROUP_BWD], m1[GROUP_BWD];
 #pragma unroll
             for (int i = 0; i < GROUP_BWD; ++i) {
-                a0[i] = alpha[i].x >= eps_lo; a1[i] = alpha[i].y >= eps_lo;
+                v2f ex;
+                alpha[i] = gs_pair_alpha_backward(s_p[k + i], s_q[k + i], px, py, ex, m0[i], m1[i]);
+            }
+            // (A) the 1/255 decisions of the whole group (RAS:631): lower edge of the bracket; an entry with an alpha inside the
+            // bracket is noted and settled before any entry is processed -- between the evaluation and the hit path, where
+            // few registers are live
+            bool a0[GROUP_BWD], a1[GROUP_BWD];
+            unsigned bracketed = 0u;   // wave-uniform: bit i = entry k + i has an alpha inside the bracket
+            GS_STAT(GS_STAT_BWD_ENTRIES, GROUP_BWD);
+#pragma unroll
+            for (int i = 0; i < GROUP_BWD; ++i) {
+                a0[i] = alpha[i].x >= EPS_LO; a1[i] = alpha[i].y >= EPS_LO;
                 const unsigned long long ma0 = gs_ballot(a0[i]), ma1 = gs_ballot(a1[i]);
                 if ((ma0 | ma1) != 0ull &&
-                    ((ma0 ^ gs_ballot(alpha[i].x >= eps_hi)) | (ma1 ^ gs_ballot(alpha[i].y >= eps_hi))) != 0ull)
+                    ((ma0 ^ gs_ballot(alpha[i].x >= EPS_HI)) | (ma1 ^ gs_ballot(alpha[i].y >= EPS_HI))) != 0ull)
                     bracketed |= 1u << i;
             }
             if (bracketed != 0u) {
-                // rare (a few hundred (wave, entry) visits per full-size frame): outside the ENTRY's own bracket the plain
-                // comparison decides as the reference does, inside it the REFERENCE'S BACKWARD expression does (UTL:331-348:
-                // m = conic @ d first -- the reference's two passes round alpha differently and so may decide a pair
-                // differently; each pass of this library follows its counterpart)
+                // rare (about a thousand (wave, entry) visits per full-size frame): the reference's BACKWARD expression decides
+                // (same exponent -- UTL:336-339 -- correctly rounded exp, * rescale * opacity).  The reference's two passes round
+                // the exponent differently and so may decide a pair differently; each pass of this library follows its counterpart.
 #pragma clang loop unroll(disable)
                 for (int ii = 0; ii < GROUP_BWD; ++ii) {
                     if (((bracketed >> ii) & 1u) == 0u) continue;
+                    GS_STAT(GS_STAT_BWD_BRACKETED, 1);
                     const int e = k + ii;
-                    v2f dxe;
-                    float dye;
-                    const float4 p = s_p[e];
-                    const v2f al = gs_pair_alpha(p, s_q[e], px, py, dxe, dye);
-                    float lo, hi;
-                    gs_bracket(EPS_ALPHA, gs_alpha_band(s_k[e]), lo, hi);
+                    v2f ex, mm0, mm1;
+                    const float4 Q = s_q[e];
+                    const v2f al = gs_pair_alpha_backward(s_p[e], Q, px, py, ex, mm0, mm1);
                     bool r0 = al.x >= EPS_ALPHA, r1 = al.y >= EPS_ALPHA;
-                    const bool in0 = al.x >= lo && al.x < hi, in1 = al.y >= lo && al.y < hi;
+                    const bool in0 = al.x >= EPS_LO && al.x < EPS_HI, in1 = al.y >= EPS_LO && al.y < EPS_HI;
                     if (gs_ballot(in0 || in1) != 0ull) {
-                        const float4 b = s_b[e];
+                        GS_STAT(GS_STAT_BWD_EXACT_ALPHA, 1);
                         const float opacity = s_c[e].w;
 #pragma clang loop unroll(disable)
                         for (int c = 0; c < 2; ++c) {
-                            const float ex = gs_alpha_reference_backward(c ? dxe.y : dxe.x, dye, b.x, b.y, b.z, p.w, opacity);
-                            if (c ? in1 : in0) { if (c) r1 = ex >= EPS_ALPHA; else r0 = ex >= EPS_ALPHA; }
+                            const float exact = gs_alpha_reference(c ? ex.y : ex.x, Q.w, opacity);
+                            if (c ? in1 : in0) { if (c) r1 = exact >= EPS_ALPHA; else r0 = exact >= EPS_ALPHA; }
                         }
                     }
 #pragma unroll
@@ -819,6 +862,14 @@ __global__ __launch_bounds__(BLEND_THREADS, GS_BWD_MIN_WAVES) void blend_backwar
                 const bool l0 = jj < last0, l1 = jj < last1;                            // RAS:618 (effective range)
                 const bool hit0 = a0[i] && l0, hit1 = a1[i] && l1;
                 if (((ma0 & gs_ballot(l0)) | (ma1 & gs_ballot(l1))) == 0ull) continue;
+#if GS_STATS
+                {
+                    const unsigned long long mh0 = gs_ballot(hit0), mh1 = gs_ballot(hit1);
+                    GS_STAT(GS_STAT_BWD_HIT_ENTRIES, 1);
+                    GS_STAT(GS_STAT_BWD_HIT_PIXELS, __popcll(mh0) + __popcll(mh1));
+                    GS_STAT(GS_STAT_BWD_HIT_LANES, __popcll(mh0 | mh1));
+                }
+#endif
                 // The twelve per-lane partial sums of this entry (in-lane sums over the lane's two pixels), in the order of
                 // the accumulator record: v0, v1 (dL/dmu), c00, c01, c11 (2 dL/dcov), gr, gg, gb (dL/drgb), w, |v|, count, 0.
                 v2f pq[11];   // the eleven packed (two-pixel) partials of this entry
@@ -832,7 +883,7 @@ __global__ __launch_bounds__(BLEND_THREADS, GS_BWD_MIN_WAVES) void blend_backwar
                     const v2f inv1m = {__builtin_amdgcn_rcpf(one_m.x), __builtin_amdgcn_rcpf(one_m.y)};
                     T = T * inv1m;  // RAS:643, T_i = T_{i+1} / (1 - alpha_i)
                     const v2f aT = al * T;
-                    const float4 c = s_c[k + i], b = s_b[k + i];
+                    const float4 c = s_c[k + i];
                     const v2f gr = aT * Gr, gg = aT * Gg, gb = aT * Gb;
                     // dL/dalpha = sum_c (c_c T - w_c/(1-alpha)) G_c = T (c.G) - S/(1-alpha)       (RAS:652-657)
                     const v2f cg = fma2(splat(c.z), Gb, fma2(splat(c.y), Gg, splat(c.x) * Gr));
@@ -841,15 +892,13 @@ __global__ __launch_bounds__(BLEND_THREADS, GS_BWD_MIN_WAVES) void blend_backwar
                     // w = dL/dg * g = dL/dalpha * opacity * g = dL/dalpha * alpha (unclamped).  dL/dlogit = (1-o) w and the
                     // factor 1/2 of dg/dcov are per-Gaussian constants: applied once per (tile, Gaussian) in the flush.
                     const v2f w = dLda * alpha[i];
-                    // UTL:331-348: m = conic @ d
-                    const v2f m0 = fma2(dx[i], splat(b.x), splat(b.y * dy[i]));
-                    const v2f m1 = fma2(dx[i], splat(b.y), splat(b.z * dy[i]));
-                    const v2f v0 = w * m0, v1 = w * m1;  // dL/dmu = dL/dg * g * (conic @ d)   (UTL:343)
+                    // UTL:331-348: m = conic @ d (from the evaluation of alpha)
+                    const v2f v0 = w * m0[i], v1 = w * m1[i];  // dL/dmu = dL/dg * g * (conic @ d)   (UTL:343)
                     asm("v_add_f32 %0, |%1|, %0" : "+v"(mag_u.x) : "v"(v0.x));
                     asm("v_add_f32 %0, |%1|, %0" : "+v"(mag_u.y) : "v"(v0.y));
                     asm("v_add_f32 %0, |%1|, %0" : "+v"(mag_v.x) : "v"(v1.x));
                     asm("v_add_f32 %0, |%1|, %0" : "+v"(mag_v.y) : "v"(v1.y));
-                    const v2f c00 = v0 * m0, c01 = v0 * m1, c11 = v1 * m1;  // 2 dL/dcov (UTL:345-346)
+                    const v2f c00 = v0 * m0[i], c01 = v0 * m1[i], c11 = v1 * m1[i];  // 2 dL/dcov (UTL:345-346)
                     const v2f n2 = fma2(v1, v1, v0 * v0);
                     const v2f nv = {__builtin_amdgcn_sqrtf(n2.x), __builtin_amdgcn_sqrtf(n2.y)};  // v_sqrt_f32, 1 ulp
                     if (DEBUG) {
@@ -941,7 +990,7 @@ __global__ __launch_bounds__(BLEND_THREADS, GS_BWD_MIN_WAVES) void blend_backwar
             if (r2.z > 0.f) {
                 const float4 a = s_p[tid];
                 int t0u, t1u, t0v, t1v;
-                gs_tile_box(a.x, a.y, s_b[tid].w, tw, th, t0u, t1u, t0v, t1v);
+                gs_tile_box(a.x, a.y, s_q[tid].z, tw, th, t0u, t1u, t0v, t1v);
                 const int dst_slot = slot_offsets[s_o[tid]] + (t1v - t0v) * (tc.tile_u - t0u) + (tc.tile_v - t0v);
                 float4 *dst = partials + 3 * (size_t)dst_slot;
                 r0.z *= 0.5f; r0.w *= 0.5f; r1.x *= 0.5f;  // dg/dcov = 0.5 g (m m^T)
@@ -982,13 +1031,6 @@ constexpr int SMALL_THREADS = 256;
                                    // 2,500 -5 % / -10 %, 3,600 -4 % / -6 %, 4,080 +1 % of the frame, 5,120 +15 % / +1 %, 8,040 +19 % / +4 %
 #endif
 
-__device__ __forceinline__ float gs_pixel_alpha(const float4 p, const float4 q, float px, float py, float &dx, float &dy) {
-    // gs_pair_alpha for one pixel: the same operations (the packed form computes each component exactly like this)
-    dx = px - p.x;
-    dy = py - p.y;
-    const float e = __builtin_fmaf(dx, __builtin_fmaf(dx, q.x, q.y * dy), q.z * dy * dy);
-    return __builtin_amdgcn_exp2f(e) * q.w;
-}
 
 template <bool AUX, bool STATE, bool DEBUG>
 __global__ __launch_bounds__(SMALL_THREADS) void blend_forward_small_kernel(
@@ -998,8 +1040,8 @@ __global__ __launch_bounds__(SMALL_THREADS) void blend_forward_small_kernel(
     int32_t *__restrict__ last_effective, int32_t *__restrict__ valid_count, uint32_t *__restrict__ debug_hits,
     const int32_t *__restrict__ tile_order, int32_t *__restrict__ tile_work, float4 *__restrict__ boundary,
     float4 *__restrict__ final_error) {
-    __shared__ float4 s_p[BATCH], s_b[BATCH], s_c[BATCH], s_q[BATCH];   // (gs_stage_rows)
-    __shared__ float s_k[BATCH];
+    __shared__ float4 s_p[BATCH], s_q[BATCH], s_c[BATCH];   // (gs_stage_forward)
+    __shared__ float2 s_ro[BATCH];
     __shared__ int s_o[DEBUG ? BATCH : 1];
     __shared__ int s_red[SMALL_THREADS / GS_WAVE];
     const int tw = width / GS_TILE_WIDTH, th = height / GS_TILE_HEIGHT;
@@ -1017,7 +1059,7 @@ __global__ __launch_bounds__(SMALL_THREADS) void blend_forward_small_kernel(
     float Er = 0.f, Eg = 0.f, Eb = 0.f;
     int last = start, cnt = 0;
     unsigned dh = 0u, dc = 0u;
-    float kappa_run = 0.f;
+    float thr = STOP_T;   // upper edge of the pixel's stop bracket (blend_forward_kernel)
     int pos = start;
     while (pos < end) {
         if (__syncthreads_and(alive == 0.f ? 1 : 0)) break;   // barrier (protects the staged batch) + whole-tile early exit
@@ -1027,11 +1069,10 @@ __global__ __launch_bounds__(SMALL_THREADS) void blend_forward_small_kernel(
             if (tid < BATCH && j < end) {
                 const int o = payload[j];
                 const float4 *g = attrs + 4 * (size_t)o;
-                const float4 r1 = g[1], r2 = g[2];
-                float4 sp, sq;
-                float kappa;
-                gs_stage_rows(g[0], r1, r2, g[3], sp, sq, kappa);
-                s_p[tid] = sp; s_b[tid] = r1; s_c[tid] = r2; s_q[tid] = sq; s_k[tid] = kappa;
+                float4 P, Q, colour;
+                float2 ro;
+                gs_stage_forward(g[0], g[1], g[2], g[3], P, Q, colour, ro);
+                s_p[tid] = P; s_q[tid] = Q; s_c[tid] = colour; s_ro[tid] = ro;
                 if (DEBUG) s_o[tid] = o;
             }
         }
@@ -1043,22 +1084,13 @@ __global__ __launch_bounds__(SMALL_THREADS) void blend_forward_small_kernel(
                 s_p[nbuf + tid] = make_float4(0.f, 0.f, 0.f, 0.f);
                 s_q[nbuf + tid] = make_float4(0.f, 0.f, 0.f, 0.f);
             }
-            if (tid >= nbuf && tid < BATCH) s_k[tid] = 0.f;
         }
         __syncthreads();
-        float eps_lo, eps_hi, stop_lo, stop_hi;   // the batch's decision brackets, as in blend_forward_kernel
-        {
-            const float kb = gs_batch_kappa(s_k);
-            kappa_run = fmaxf(kappa_run, kb);
-            gs_bracket(EPS_ALPHA, gs_alpha_band(kb), eps_lo, eps_hi);
-            gs_bracket(STOP_T, gs_stop_band(kappa_run, pos - start), stop_lo, stop_hi);
-            eps_lo = gs_uniform(eps_lo); eps_hi = gs_uniform(eps_hi);
-            stop_lo = gs_uniform(stop_lo); stop_hi = gs_uniform(stop_hi);
-        }
-        // (the one-pixel forms of blend_forward_kernel's `blend` and `careful_entry`: see there)
-        auto blend = [&](int e, float z, float al, float Tn, bool ok) {
+        thr += STOP_T * 1.1f * GS_STOP_ROUNDING_BAND * (float)nbuf;
+        const int walked = pos - start;   // (>= the list positions walked so far)
+        // (the one-pixel forms of blend_forward_kernel's `blend`, `careful_entry` and group loop: see there)
+        auto blend = [&](int e, const float4 c, float z, float al, float Tn, bool ok) {
             const float wgt = al * T;
-            const float4 c = s_c[e];
             if (track) {   // (wave-uniform)  exact sum - rounded sum of this step, to first order
                 const float nr = __builtin_fmaf(c.x, wgt, Cr), ng = __builtin_fmaf(c.y, wgt, Cg), nb_ = __builtin_fmaf(c.z, wgt, Cb);
                 Er += __builtin_fmaf(c.x, wgt, Cr - nr);
@@ -1081,62 +1113,67 @@ __global__ __launch_bounds__(SMALL_THREADS) void blend_forward_small_kernel(
             }
         };
         auto careful_entry = [&](int e) {
-            float dx, dy;
-            const float4 p = s_p[e];
-            const float a = gs_pixel_alpha(p, s_q[e], px, py, dx, dy) * alive;
+            float ex;
+            const float4 Q = s_q[e];
+            const float a = gs_pixel_alpha_forward(s_p[e], Q, px, py, ex) * alive;
             bool ok = a >= EPS_ALPHA;   // RAS:451
             {
-                float lo, hi;
-                gs_bracket(EPS_ALPHA, gs_alpha_band(s_k[e]), lo, hi);
-                const bool in = a >= lo && a < hi;
+                const bool in = a >= EPS_LO && a < EPS_HI;
                 if (gs_ballot(in) != 0ull) {
-                    const float4 b = s_b[e];
-                    const float ex = gs_alpha_reference_forward(dx, dy, b.x, b.y, b.z, p.w, s_c[e].w);
-                    if (in) ok = ex * alive >= EPS_ALPHA;
+                    const float2 ro = s_ro[e];
+                    const float exact = gs_alpha_reference(ex, ro.x, ro.y);
+                    if (in) ok = exact * alive >= EPS_ALPHA;
                 }
             }
             if (gs_ballot(ok) == 0ull) return;
             float al = ok ? __builtin_amdgcn_fmed3f(a, 0.f, CLAMP_ALPHA) : 0.f;
+            const float4 c = s_c[e];
+            thr = __builtin_fmaf(c.w, al, thr);
             float Tn = T * (1.f - al);
-            bool sat = ok && Tn < stop_lo;   // RAS:458-460, below the bracket
-            for (unsigned long long m = gs_ballot(ok && !sat && Tn < stop_hi); m != 0ull; m &= m - 1ull) {
+            float lo, hi;
+            gs_stop_bracket(thr, walked, AUX ? cnt + 1 : -1, lo, hi);
+            bool sat = ok && Tn < lo;   // RAS:458-460, below the bracket
+            for (unsigned long long m = gs_ballot(ok && !sat && Tn < hi); m != 0ull; m &= m - 1ull) {
                 const int l = __builtin_ctzll(m);
                 const bool stops = gs_reference_stops_at<false>(payload, attrs, start, batch_first + e, gs_readlane_f(px, l),
-                                                                gs_readlane_f(py, l), tc.tile_u, tc.tile_v, tw, th, 0);
+                                                                gs_readlane_f(py, l), tc.tile_u, tc.tile_v, tw, th);
                 if ((tid & (GS_WAVE - 1)) == l) sat = stops;
             }
             if (sat) { al = 0.f; alive = 0.f; ok = false; }
             Tn = T * (1.f - al);
-            blend(e, p.z, al, Tn, ok);
+            blend(e, c, Q.z, al, Tn, ok);
         };
         for (int k = 0; k < nbuf; k += GROUP_FWD) {
             if (gs_ballot(alive != 0.f) == 0ull) break;   // every pixel of this wave is saturated
             float alpha[GROUP_FWD], z[GROUP_FWD];
 #pragma unroll
             for (int i = 0; i < GROUP_FWD; ++i) {
-                float dx, dy;
-                const float4 p = s_p[k + i];
-                alpha[i] = gs_pixel_alpha(p, s_q[k + i], px, py, dx, dy);
-                z[i] = p.z;
+                float ex;
+                const float4 Q = s_q[k + i];
+                alpha[i] = gs_pixel_alpha_forward(s_p[k + i], Q, px, py, ex);
+                z[i] = Q.z;
             }
             int careful_from = GROUP_FWD;
 #pragma unroll
             for (int i = 0; i < GROUP_FWD; ++i) {
                 const float a = alpha[i] * alive;
-                bool ok = a >= eps_lo;                                  // RAS:451 (lower edge of the batch's bracket)
+                bool ok = a >= EPS_LO;                                  // RAS:451 (lower edge of the bracket)
                 const unsigned long long mok = gs_ballot(ok);
                 if (mok == 0ull) continue;
-                if ((mok ^ gs_ballot(a >= eps_hi)) != 0ull) { careful_from = i; break; }
+                if ((mok ^ gs_ballot(a >= EPS_HI)) != 0ull) { careful_from = i; break; }
                 float al = ok ? __builtin_amdgcn_fmed3f(a, 0.f, CLAMP_ALPHA) : 0.f;
+                const float4 c = s_c[k + i];
+                thr = __builtin_fmaf(c.w, al, thr);
                 float Tn = T * (1.f - al);
-                const bool low = Tn < stop_hi;
-                if ((mok & gs_ballot(low)) != 0ull) {                   // RAS:458-460: saturates the pixel, NOT blended
-                    const bool sat = ok && Tn < stop_lo;
-                    if (gs_ballot(ok && low && !sat) != 0ull) { careful_from = i; break; }
+                if ((mok & gs_ballot(Tn < thr)) != 0ull) {              // RAS:458-460: saturates the pixel, NOT blended
+                    float lo, hi;
+                    gs_stop_bracket(thr, walked, AUX ? cnt + 1 : -1, lo, hi);
+                    const bool sat = ok && Tn < lo;
+                    if (gs_ballot(ok && !sat && Tn < hi) != 0ull) { careful_from = i; break; }
                     if (sat) { al = 0.f; alive = 0.f; ok = false; }
                     Tn = T * (1.f - al);
                 }
-                blend(k + i, z[i], al, Tn, ok);
+                blend(k + i, c, z[i], al, Tn, ok);
             }
             if (careful_from < GROUP_FWD) {
 #pragma clang loop unroll(disable)
@@ -1194,8 +1231,7 @@ __global__ __launch_bounds__(SMALL_THREADS) void blend_backward_small_kernel(
     uint32_t *__restrict__ debug_hits, const int32_t *__restrict__ tile_order, int split,
     const float *__restrict__ image, const float4 *__restrict__ boundary, const float4 *__restrict__ final_error,
     int32_t *__restrict__ tile_counters, float2 *__restrict__ magnitude_parts) {
-    __shared__ float4 s_p[BATCH], s_b[BATCH], s_c[BATCH], s_q[BATCH];   // (gs_stage_rows)
-    __shared__ float s_k[BATCH];
+    __shared__ float4 s_p[BATCH], s_q[BATCH], s_c[BATCH];   // (gs_stage_backward)
     __shared__ int s_o[BATCH];
     // one slice of partial sums PER WAVE, written with plain stores and added in a fixed order by the flush: four waves
     // meeting in one row with ds_add_f32 would sum in arrival order (two waves are safe: a + b = b + a) and the gradients
@@ -1257,11 +1293,9 @@ __global__ __launch_bounds__(SMALL_THREADS) void blend_backward_small_kernel(
             if (tid < BATCH && j >= bottom) {
                 const int o = payload[j];
                 const float4 *g = attrs + 4 * (size_t)o;
-                const float4 r1 = g[1], r2 = g[2];
-                float4 sp, sq;
-                float kappa;
-                gs_stage_rows(g[0], r1, r2, g[3], sp, sq, kappa);
-                s_p[tid] = sp; s_b[tid] = r1; s_c[tid] = r2; s_q[tid] = sq; s_k[tid] = kappa;
+                float4 P, Q, colour;
+                gs_stage_backward(g[0], g[1], g[2], g[3], P, Q, colour);
+                s_p[tid] = P; s_q[tid] = Q; s_c[tid] = colour;
                 s_o[tid] = o;
             }
         }
@@ -1272,7 +1306,6 @@ __global__ __launch_bounds__(SMALL_THREADS) void blend_backward_small_kernel(
                 s_p[nbuf + tid] = make_float4(0.f, 0.f, 0.f, 0.f);
                 s_q[nbuf + tid] = make_float4(0.f, 0.f, 0.f, 0.f);
             }
-            if (tid >= nbuf && tid < BATCH) s_k[tid] = 0.f;
             {   // thread t clears rows t & 127 of slices 2 (t >> 7) and 2 (t >> 7) + 1
                 const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
@@ -1283,40 +1316,37 @@ __global__ __launch_bounds__(SMALL_THREADS) void blend_backward_small_kernel(
             }
         }
         __syncthreads();
-        float eps_lo, eps_hi;   // the batch's bracket around the 1/255 threshold, as in blend_backward_kernel
-        gs_bracket(EPS_ALPHA, gs_alpha_band(gs_batch_kappa(s_k)), eps_lo, eps_hi);
-        eps_lo = gs_uniform(eps_lo); eps_hi = gs_uniform(eps_hi);
         for (int k = 0; k < nbuf; k += GROUP_BWD) {
             if (batch_first - (k + GROUP_BWD - 1) >= wave_end) continue;   // the whole group lies behind this wave's pixels
-            float alpha[GROUP_BWD], dx[GROUP_BWD], dy[GROUP_BWD];
+            float alpha[GROUP_BWD], m0[GROUP_BWD], m1[GROUP_BWD];
 #pragma unroll
-            for (int i = 0; i < GROUP_BWD; ++i) alpha[i] = gs_pixel_alpha(s_p[k + i], s_q[k + i], px, py, dx[i], dy[i]);
+            for (int i = 0; i < GROUP_BWD; ++i) {
+                float ex;
+                alpha[i] = gs_pixel_alpha_backward(s_p[k + i], s_q[k + i], px, py, ex, m0[i], m1[i]);
+            }
             // (A) the group's 1/255 decisions, (then) the bracketed ones settled by the reference's backward expression, (B) the
             // hit path: the one-pixel form of blend_backward_kernel's loop, see there
             bool a0[GROUP_BWD];
             unsigned bracketed = 0u;
 #pragma unroll
             for (int i = 0; i < GROUP_BWD; ++i) {
-                a0[i] = alpha[i] >= eps_lo;                              // RAS:631 (lower edge of the batch's bracket)
+                a0[i] = alpha[i] >= EPS_LO;                              // RAS:631 (lower edge of the bracket)
                 const unsigned long long ma = gs_ballot(a0[i]);
-                if (ma != 0ull && (ma ^ gs_ballot(alpha[i] >= eps_hi)) != 0ull) bracketed |= 1u << i;
+                if (ma != 0ull && (ma ^ gs_ballot(alpha[i] >= EPS_HI)) != 0ull) bracketed |= 1u << i;
             }
             if (bracketed != 0u) {
 #pragma clang loop unroll(disable)
                 for (int ii = 0; ii < GROUP_BWD; ++ii) {
                     if (((bracketed >> ii) & 1u) == 0u) continue;
                     const int e = k + ii;
-                    float dxe, dye;
-                    const float4 p = s_p[e];
-                    const float al = gs_pixel_alpha(p, s_q[e], px, py, dxe, dye);
-                    float lo, hi;
-                    gs_bracket(EPS_ALPHA, gs_alpha_band(s_k[e]), lo, hi);
+                    float ex, mm0, mm1;
+                    const float4 Q = s_q[e];
+                    const float al = gs_pixel_alpha_backward(s_p[e], Q, px, py, ex, mm0, mm1);
                     bool r0 = al >= EPS_ALPHA;
-                    const bool in = al >= lo && al < hi;
+                    const bool in = al >= EPS_LO && al < EPS_HI;
                     if (gs_ballot(in) != 0ull) {
-                        const float4 b = s_b[e];
-                        const float ex = gs_alpha_reference_backward(dxe, dye, b.x, b.y, b.z, p.w, s_c[e].w);
-                        if (in) r0 = ex >= EPS_ALPHA;
+                        const float exact = gs_alpha_reference(ex, Q.w, s_c[e].w);
+                        if (in) r0 = exact >= EPS_ALPHA;
                     }
 #pragma unroll
                     for (int i = 0; i < GROUP_BWD; ++i)
@@ -1336,18 +1366,16 @@ __global__ __launch_bounds__(SMALL_THREADS) void blend_backward_small_kernel(
                 const float inv1m = __builtin_amdgcn_rcpf(1.f - al);
                 T = T * inv1m;                                           // RAS:643
                 const float aT = al * T;
-                const float4 c = s_c[k + i], b = s_b[k + i];
+                const float4 c = s_c[k + i];
                 const float gr = aT * Gr, gg = aT * Gg, gb = aT * Gb;
                 const float cg = __builtin_fmaf(c.z, Gb, __builtin_fmaf(c.y, Gg, c.x * Gr));
                 const float dLda = __builtin_fmaf(T, cg, -(S * inv1m)) * h;   // RAS:652-657
                 S = __builtin_fmaf(cg, aT, S);
                 const float w = dLda * alpha[i];
-                const float m0 = __builtin_fmaf(dx[i], b.x, b.y * dy[i]);    // UTL:331-348: m = conic @ d
-                const float m1 = __builtin_fmaf(dx[i], b.y, b.z * dy[i]);
-                const float v0 = w * m0, v1 = w * m1;
+                const float v0 = w * m0[i], v1 = w * m1[i];              // UTL:331-348: m = conic @ d (from the evaluation of alpha)
                 mag_u += fabsf(v0);
                 mag_v += fabsf(v1);
-                const float c00 = v0 * m0, c01 = v0 * m1, c11 = v1 * m1;
+                const float c00 = v0 * m0[i], c01 = v0 * m1[i], c11 = v1 * m1[i];
                 const float nv = __builtin_amdgcn_sqrtf(__builtin_fmaf(v1, v1, v0 * v0));
                 if (DEBUG) {
                     const unsigned hv = (unsigned)(s_o[k + i] + 1) * GS_HASH_MUL;
@@ -1377,7 +1405,7 @@ __global__ __launch_bounds__(SMALL_THREADS) void blend_backward_small_kernel(
             if (r2.z > 0.f) {
                 const float4 a = s_p[tid];
                 int t0u, t1u, t0v, t1v;
-                gs_tile_box(a.x, a.y, s_b[tid].w, tw, th, t0u, t1u, t0v, t1v);
+                gs_tile_box(a.x, a.y, s_q[tid].z, tw, th, t0u, t1u, t0v, t1v);
                 const int dst_slot = slot_offsets[s_o[tid]] + (t1v - t0v) * (tc.tile_u - t0u) + (tc.tile_v - t0v);
                 float4 *dst = partials + 3 * (size_t)dst_slot;
                 r0.z *= 0.5f; r0.w *= 0.5f; r1.x *= 0.5f;
@@ -1526,6 +1554,18 @@ static size_t boundary_slots_bytes(int64_t list_length) {
 }
 size_t gs_blend_boundary_bytes(int64_t list_length, int width, int height) {
     return boundary_slots_bytes(list_length) + (size_t)width * height * sizeof(float4);
+}
+
+int gs_blend_read_stats(uint64_t *counters, int clear, void *stream) {
+    GS_REQUIRE(counters != nullptr, "counters");
+    hipStream_t s = (hipStream_t)stream;
+    GS_CHECK_HIP(hipStreamSynchronize(s));
+    GS_CHECK_HIP(hipMemcpyFromSymbol(counters, HIP_SYMBOL(gs_blend_stats_dev), sizeof(uint64_t) * GS_BLEND_STATS));
+    if (clear) {
+        const uint64_t zero[GS_BLEND_STATS] = {};
+        GS_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(gs_blend_stats_dev), zero, sizeof(zero)));
+    }
+    return GS_STATS;
 }
 
 size_t gs_blend_split_workspace_bytes(int width, int height) {

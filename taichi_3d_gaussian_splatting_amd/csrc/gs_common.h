@@ -84,61 +84,47 @@ __device__ __forceinline__ float gs_exp_cr(float xf) {
 }
 
 // ------------------------------------------------------------------ threshold decisions taken as the reference takes them
-// The blend kernels evaluate the Gaussian weight in the log2 domain from a pre-scaled conic (gs_pair_alpha, gs_blend.hip):
-// another fp32 rounding than the reference's expression (UTL:275-284 in the forward pass, UTL:331-348 in the backward
-// pass), so a pair whose alpha lies within a few 1e-6 (relative) of the 1/255 skip threshold (RAS:451 / RAS:631) could be
-// decided differently, and so could a pixel whose T' lies next to the 1e-4 stop threshold (RAS:458).  Those decisions are
-// discrete (a whole Gaussian blended or not), so the kernels bracket every comparison with a PROVEN bound on the distance
-// between their value and the reference's, and whatever falls inside the bracket is re-evaluated in the reference's own
-// expression order with the correctly rounded exponential (gs_exp_cr: the definition the oracle and the committed
-// reference-run vectors use) -- a wave-uniform rare path, a few hundred times per full-size frame.
-//
-// Bound on alpha (u = 2^-24, M = |A dx^2|/2 + |C dy^2|/2 + |B dx dy|, all from the same fp32 A, B, C, dx, dy on both sides):
-//   fast path : 3 roundings on the A term, 4 on the B and C terms, 1 on the sum            -> 5 u M on ln(alpha)
-//               v_exp_f32 1 ulp (taken as 4 u), amp = fl(opacity rescale), final product     -> 6 u
-//   reference : products and sums of UTL:281-283 (or UTL:336-339)                          -> 4 u M
-//               correctly rounded exp, x rescale, x opacity                                  -> 3 u
-//   total |ln alpha_fast - ln alpha_ref| <= 9 u (M + 1); GS_BAND_COEF = 12 adds a third (the largest ratio seen over 4e6
-//   random conics / pixels with anisotropy up to 100: 4.5, tools/alpha_band_check.py).
-// M against the exponent E = -(P + X), P = (A dx^2 + C dy^2)/2 >= 0, X = B dx dy, |X| <= rho P with rho = |B| / sqrt(A C):
-//   M = P + |X| <= |E| (1 + rho) / (1 - rho) = kappa |E|  -- kappa is a per-Gaussian constant (1 for an axis-aligned conic),
-//   and |E| = ln(amp / alpha) <= ln(255) < 5.6 wherever alpha is near 1/255 (amp <= 1).
-#define GS_BAND_COEF 12.0f
+// The reference skips a (pixel, Gaussian) pair whose alpha is below 1/255 (RAS:451 in the forward pass, RAS:631 in the
+// backward pass) and stops a pixel at the first Gaussian that would take its transmittance below 1e-4 (RAS:458).  Both are
+// DISCRETE decisions (a whole Gaussian blended or not): to produce the reference's results they must be taken exactly as
+// the reference takes them, on every pixel.  How the blend kernels (gs_blend.hip) get there:
+//  1. THE EXPONENT IS THE REFERENCE'S, TO THE LAST BIT.  Each pass evaluates the quadratic form in the operation order of
+//     its counterpart -- UTL:281-283 in the forward pass, UTL:336-339 (m = conic @ d first) in the backward pass -- from the
+//     same fp32 (dx, dy, A, B, C), contraction off.  (Rounds 1-4 evaluated a pre-scaled conic in the log2 domain, three
+//     instructions shorter per pixel pair: its rounding differs from the reference's by 9 u M, M = |A dx^2|/2 + |C dy^2|/2 +
+//     |B dx dy| -- the CANCELLATION between the three terms, up to thousands of times the exponent itself for a thin diagonal
+//     Gaussian -- which put 1e-4 between the two images on needle scenes and made every bracket below proportional to the
+//     conic's condition; the reference-order form leaves nothing that depends on the conic.)
+//  2. What remains between the two alphas (u = 2^-24, relative):
+//       kernels  : e * log2(e) -- constant and product rounded -> 2 u |e| on alpha;  v_exp_f32 1 ulp (taken as 4 u);
+//                  amp = fl(opacity * rescale) u;  exp * amp u                                  -> 2 u |e| + 6 u
+//       reference: exp correctly rounded u;  * rescale u (UTL:284);  * opacity u (RAS:447)       -> 3 u
+//     |ln alpha_kernel - ln alpha_reference| <= u (2 |e| + 9), |e| = ln(amp / alpha) <= ln(1 / alpha) (amp <= 1), and a third on
+//     top (GS_BAND_SAFETY).  At the 1/255 threshold |e| < 5.6: GS_ALPHA_BAND = 4/3 * 20.2 u = 1.6e-6.
+//  3. A comparison whose operand lies inside the bracket [threshold (1 - band), threshold / (1 - band)) is settled by the
+//     reference's own expression: exp(e) correctly rounded (gs_exp_cr: the definition the oracle and the committed
+//     reference-run vectors use), times rescale, times opacity -- wave-uniform rare paths, kept OUT of the hot loops.
+//  4. The stop test compares T' = T (1 - a) with 1e-4, T a product of (1 - a_i): the two sides' factors differ (relatively) by
+//     delta_i a_i / (1 - a_i) + 4 u (two roundings per side once the inputs differ), delta_i = u (2 ln(1 / a_i) + 9):
+//       a ln(1/a) / (1 - a) <= min(1, 6 a) on [1/255, 0.99] (and for a clamped factor)      -> 2 u * 6 a_i
+//       a / (1 - a) <= a H_k,  H_k = 1 / (1 - min(amp_k, 0.99)) -- per GAUSSIAN: alpha <= amp    -> 9 u * H_k a_i
+//     accumulated PER PIXEL with one packed FMA per hit-path execution: thr += W_k a_i, W_k = gs_stop_weight(amp_k) (stored
+//     in the record), thr = upper edge of the pixel's bracket around 1e-4; the rounding term (4 u per blended Gaussian) is
+//     added per batch from the list positions walked (gates the rare path) and replaced by the pixel's own count inside it.
+//     thr = STOP (1 + 1.1 beta) >= STOP e^beta holds for beta <= 0.19; here beta <= 4/3 u (12 + 9 * 101) sum(a_i) < 1.2e-3
+//     (sum a_i <= ln(1 / 1e-6)).  A T' inside [STOP - (thr - STOP) / 1.1, thr) is settled by replaying the pixel's history in
+//     the reference's arithmetic (gs_reference_stops_at, gs_blend.hip).
 #define GS_U24 5.9604644775390625e-8f
-// kappa of a conic, rounded up (approximate reciprocals and a 1 % allowance); degenerate, NaN and extreme (rho^2 > 0.9999) conics get 1e6, which
-// opens the bracket completely: every decision about such an entry is then taken by the exact expression
-__device__ __forceinline__ float gs_conic_kappa(float A, float B, float C) {
-    const float ac = A * C;
-    const float r2 = B * B * __builtin_amdgcn_rcpf(ac);
-    if (!(ac > 0.f) || !(r2 < 0.9999f)) return 1.0e6f;   // (1 - r2 keeps three digits up to here)
-    const float rho = __builtin_amdgcn_sqrtf(r2) * 1.0001f;
-    return (1.f + rho) * (1.f + rho) * __builtin_amdgcn_rcpf(1.f - r2) * 1.01f;
+#define GS_BAND_SAFETY (4.0f / 3.0f)
+#define GS_ALPHA_BAND (GS_BAND_SAFETY * GS_U24 * (2.0f * 5.6f + 9.0f))
+#define GS_STOP_ROUNDING_BAND (4.0f * GS_U24)   /* per blended Gaussian */
+__device__ __forceinline__ float gs_stop_weight(float amp, float stop_t) {
+    const float H = 1.0f / (1.0f - fminf(amp, 0.99f)) * 1.01f;
+    return stop_t * 1.1f * GS_BAND_SAFETY * GS_U24 * (12.0f + 9.0f * H);
 }
-// relative half-width of the bracket around 1/255 for an entry (or a batch: its largest kappa)
-__device__ __forceinline__ float gs_alpha_band(float kappa) { return GS_BAND_COEF * GS_U24 * (5.6f * kappa + 1.0f); }
-// Relative half-width of the bracket around T' = 1e-4.  T is a product of (1 - a_i): the two sides' factors differ by
-// delta_i a_i / (1 - a_i) (+ 4 u of rounding per factor once the inputs differ), delta_i <= COEF u (kappa ln(1 / alpha_i) + 1).
-//   kappa part : a ln(1/a) / (1 - a) <= 5.55 ln(1 / (1 - a)) on [1/255, 0.99] (and <= 1 for a clamped factor), the logs sum to
-//                ln(1 / T') = 9.21 at the threshold                                           -> COEF u kappa_max 51.2
-//   flat part  : a / (1 - a) <= 21.5 ln(1 / (1 - a)) on the same interval (worst at the 0.99 clamp) -> COEF u 198
-//   rounding   : 4 u per blended entry, at most the list positions walked so far
-// kappa_max: the largest kappa among the entries the tile has staged so far (every pixel's history is a subset).
-__device__ __forceinline__ float gs_stop_band(float kappa_max, int walked) {
-    return GS_BAND_COEF * GS_U24 * (51.2f * kappa_max + 198.0f) + 4.0f * GS_U24 * (float)walked;
-}
-// alpha of UTL:275-284 (forward pass) and of UTL:331-348 (backward pass: m = conic @ d first) exactly as the reference
-// rounds them; dx, dy are the kernels' own px - u, py - v (the reference's xy_mean, same subtraction)
-__device__ __forceinline__ float gs_alpha_reference_forward(float dx, float dy, float A, float B, float C, float rescale,
-                                                            float opacity) {
+// exp(e) * rescale * opacity as the reference rounds it (UTL:284 then RAS:447 / RAS:627), e = the reference's exponent
+__device__ __forceinline__ float gs_alpha_reference(float e, float rescale, float opacity) {
 #pragma clang fp contract(off)
-    const float e = -0.5f * (dx * dx * A + dy * dy * C) - dx * dy * B;
-    return gs_exp_cr(e) * rescale * opacity;
-}
-__device__ __forceinline__ float gs_alpha_reference_backward(float dx, float dy, float A, float B, float C, float rescale,
-                                                             float opacity) {
-#pragma clang fp contract(off)
-    const float m0 = A * dx + B * dy, m1 = B * dx + C * dy;
-    const float e = -0.5f * (dx * m0 + dy * m1);
     return gs_exp_cr(e) * rescale * opacity;
 }
 

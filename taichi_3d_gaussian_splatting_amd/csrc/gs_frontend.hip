@@ -458,7 +458,7 @@ __device__ __forceinline__ void gs_wave_view_colours(bool wants, int id, const f
 // the 14 loads out of L1; measured: the kernel is bound by its ~2.7 k VALU instructions per wave -- IEEE
 // divisions, expf, the cull loop -- and an LDS-staged coalesced gather was 6 % slower: lower occupancy).
 template <bool COLOUR>
-__global__ __launch_bounds__(GS_BLOCK) void preprocess_kernel(
+__global__ __launch_bounds__(GS_BLOCK, 6) void preprocess_kernel(
     const float *__restrict__ xyz, float *__restrict__ feat, const int32_t *__restrict__ obj,
     const float *__restrict__ Kmat, const float *__restrict__ q_cp, const float *__restrict__ t_cp,
     const int32_t *__restrict__ ids, int m_capacity, int use_device_count, int width, int height, RowOwner ow,
@@ -605,11 +605,12 @@ __global__ __launch_bounds__(GS_BLOCK) void preprocess_kernel(
         if (owned > 0) {
             out[1] = make_float4(cA, cB, cC, radius);
             out[2] = make_float4(rgb[0], rgb[1], rgb[2], opacity);
-            // the weight UTL:275-284 in the log2 domain: opacity * rescale * 2^(dx*(A'dx + B'dy) + C'dy^2).  The two factors
-            // stay apart in the record (opacity in row 2): the blend kernels multiply them when they stage an entry and need
-            // them one by one where they follow the reference's own rounding (gs_alpha_reference_*, gs_common.h)
-            const float log2e = 1.4426950408889634f;
-            out[3] = make_float4((-0.5f * log2e) * cA, (-log2e) * cB, (-0.5f * log2e) * cC, rescale);
+            // what the blend kernels want next to the conic (gs_blend.hip): amp = opacity * rescale (alpha = amp * exp(e)), the
+            // Gaussian's stop-bracket weight (gs_common.h, "threshold decisions") -- and the rescale factor on its own (the
+            // opacity is in row 2): the reference multiplies exp(e) by them one after the other (UTL:284, RAS:447), and so does
+            // the exact re-evaluation of an alpha next to 1/255
+            const float amp = opacity * rescale;
+            out[3] = make_float4(amp, gs_stop_weight(amp, 0.0001f), 0.f, rescale);
         }
         nkeys[i] = owned;
     }

@@ -35,11 +35,13 @@ def pack_attrs(f: dict, exact_cull: bool = False) -> np.ndarray:
         a[:, 3] = (np.float32(2.0) * np.log(np.float32(255.0) * amp) + np.float32(1e-2)) if exact_cull else np.inf
     a[:, 4:7] = f["conic"][:, 0:3]; a[:, 7] = f["radii"]
     a[:, 8:11] = f["rgb"]; a[:, 11] = f["alpha"]
-    log2e = np.float32(1.4426950408889634)
-    a[:, 12] = (np.float32(-0.5) * log2e) * a[:, 4]
-    a[:, 13] = (-log2e) * a[:, 5]
-    a[:, 14] = (np.float32(-0.5) * log2e) * a[:, 6]
-    a[:, 15] = f["conic"][:, 3]                                           # rescale (the kernels form opacity * rescale)
+    u24, stop_t = np.float32(2.0 ** -24), np.float32(0.0001)
+    a[:, 12] = amp
+    # gs_stop_weight (csrc/gs_common.h): the Gaussian's share of a pixel's bracket around T' = 1e-4, per unit of alpha
+    H = np.float32(1.0) / (np.float32(1.0) - np.minimum(amp, np.float32(0.99))) * np.float32(1.01)
+    a[:, 13] = stop_t * np.float32(1.1) * np.float32(4.0 / 3.0) * u24 * (np.float32(12.0) + np.float32(9.0) * H)
+    a[:, 14] = 0.0
+    a[:, 15] = f["conic"][:, 3]                                           # rescale
     return a
 
 

@@ -79,7 +79,7 @@ def test_preprocess(ops, scene, ofwd):
     report("preprocess.emitting", fraction=float(emits.mean()))
     assert np.isinf(a[:, 3]).all() and (a[:, 3] > 0).all()     # cull off: the stored bound is +inf
     for name, sl, rtol in (("conic", slice(4, 7), 2e-5), ("radius", slice(7, 8), 1e-5), ("rgb", slice(8, 11), 2e-6),
-                           ("opacity", slice(11, 12), 1e-6), ("prescaled_conic", slice(12, 15), 2e-5),
+                           ("opacity", slice(11, 12), 1e-6), ("amp_and_stop_weight", slice(12, 15), 2e-5),
                            ("rescale", slice(15, 16), 2e-5)):
         rows = emits
         frac = close_fraction(a[rows, sl], ref[rows, sl], rtol=rtol, atol=1e-7)
@@ -857,11 +857,17 @@ CHAIN_GRAD_TOL = 5e-5     # observed 5.3e-6 (features) / 8.2e-6 (positions) agai
 @pytest.mark.parametrize("workload,bin_shift", [("cfg2_100k_800", 0), ("headline_1m_1080p", 0), ("headline_1m_1080p", 1),
                                                 ("headline_1m_1080p", 2), ("cfg3_400k_1080p", 0)])
 def test_forward_and_backward_blend_the_same_pairs(ops, workload, bin_shift):
-    """a (pixel, Gaussian) pair must be treated as blended by the backward pass iff the forward
-    pass blended it.  Both kernels evaluate alpha through the same device function; here every pixel's blended set is
-    compared through {count, hash of the blended Gaussians' list offsets}: identical on EVERY pixel, at full size."""
+    """Which (pixel, Gaussian) pairs each pass blends, at full size, against the oracle's two passes -- EVERY pixel, every
+    Gaussian, no tolerance: the forward's per-pixel number of blended Gaussians and stop positions equal the oracle's
+    forward (RAS:451, RAS:458 decided as the reference decides them: csrc/gs_common.h, "threshold decisions"), the
+    backward's number of affected pixels per Gaussian equals the oracle's backward (RAS:631).  The reference evaluates alpha
+    by two differently rounded expressions in its two passes (UTL:275-284 / UTL:331-348), so ITS passes disagree on a pair
+    in a few millions; each HIP pass follows its counterpart, and the pixels on which the two HIP passes differ (compared
+    through {count, hash of the blended Gaussians' list offsets}) are reported and bounded."""
+    from oracle import gs_oracle as O
     from taichi_3d_gaussian_splatting_amd.synthetic import make_config_scene, make_grad_image
-    s = make_config_scene(workload).to("cuda")
+    s_cpu = make_config_scene(workload)
+    s = s_cpu.to("cuda")
     st = _stages_to_ranges(ops, s, ops.ListLayout(bin_shift=bin_shift))
     image, depth, acc_alpha, last_eff, count, dbg_f = ops.blend_forward(
         st["start"], st["end"], st["payload"], st["attrs"], s.width, s.height, st["layout"], debug_hits=True)
@@ -871,9 +877,19 @@ def test_forward_and_backward_blend_the_same_pairs(ops, workload, bin_shift):
         st["start"], st["payload"], st["attrs"], g, acc_alpha, last_eff, st["slot_offsets"], st["n_slots"],
         s.width, s.height, st["layout"], debug_hits=True)
     differing = int((dbg_f != dbg_b).any(dim=2).sum())
+    f = oracle_forward(s_cpu, want_margin=False)
+    ob = O.backward(f, make_grad_image(s.height, s.width).numpy(), 3)
+    count_mismatch = int((count.cpu().numpy() != f["count"]).sum())
+    acc = ops.reduce_partials(st["slot_offsets"], st["ntiles"], flags, partials)
+    npix = acc[:, 10].contiguous().view(torch.int32).cpu().numpy()
+    npix_mismatch = int((npix != ob["hook"]["num_affected_pixels"]).sum())
     report(f"hit_sets.{workload}.bin_shift{bin_shift}", pixels=s.height * s.width, keys=st["k"], blended_pairs=int(count.sum()),
-           pixels_with_different_sets=differing)
-    assert differing == 0
+           pixels_with_different_count_than_the_oracle=count_mismatch,
+           gaussians_with_different_pixel_count_than_the_oracle_backward=npix_mismatch,
+           pixels_on_which_the_two_passes_differ=differing, backward_pairs=int(npix.sum()))
+    assert count_mismatch == 0
+    assert npix_mismatch == 0
+    assert differing <= max(4, int(count.sum()) // 1_000_000)
     # and the debug build changes nothing: same partial sums as the production kernel, bit for bit
     partials2, flags2, mag2 = ops.blend_backward_partials(
         st["start"], st["payload"], st["attrs"], g, acc_alpha, last_eff, st["slot_offsets"], st["n_slots"],
@@ -881,9 +897,6 @@ def test_forward_and_backward_blend_the_same_pairs(ops, workload, bin_shift):
     raised = flags.bool()
     assert torch.equal(flags, flags2) and torch.equal(mag, mag2)
     assert torch.equal(partials[raised].view(torch.int32), partials2[raised].view(torch.int32))
-    # per-Gaussian pixel counts of the backward add up to the forward's per-pixel counts
-    acc = ops.reduce_partials(st["slot_offsets"], st["ntiles"], flags, partials)
-    assert int(acc[:, 10].contiguous().view(torch.int32).sum()) == int(count.sum())
 
 
 def test_four_waves_per_tile_arm_at_a_larger_size(ops):
@@ -905,7 +918,8 @@ def test_four_waves_per_tile_arm_at_a_larger_size(ops):
         assert torch.equal(out["four_waves"][i], out["two_waves"][i]), i
     p2, f2, m2, d2 = part["two_waves"]
     p4, f4, m4, d4 = part["four_waves"]
-    assert torch.equal(d4, d2) and torch.equal(d4, out["two_waves"][5]) and torch.equal(f4, f2) and torch.equal(m4, m2)
+    assert torch.equal(d4, d2) and torch.equal(f4, f2) and torch.equal(m4, m2)
+    assert int((d4 != out["two_waves"][5]).any(dim=2).sum()) <= 2   # (backward vs forward pairs: see test_forward_and_backward_...)
     raised = f2.bool()
     assert torch.equal(p4[raised][:, 10].contiguous().view(torch.int32), p2[raised][:, 10].contiguous().view(torch.int32))
     a2 = ops.reduce_partials(st["slot_offsets"], st["ntiles"], f2, p2)
@@ -958,7 +972,10 @@ def test_split_backward_on_small_grids(ops, size, n, bin_shift):
         out = ops.blend_backward_partials(*args, tile_work=work, debug_hits=True, ws=ws, image=image, boundary=boundary)
         runs.append([t.clone() for t in out])
     p1, f1, m1, d1 = runs[0]
-    assert torch.equal(d1, d0) and torch.equal(d1, fwd[-1])                       # the same (pixel, Gaussian) pairs
+    assert torch.equal(d1, d0)                                                    # the same (pixel, Gaussian) pairs
+    # (against the FORWARD pass's pairs: each pass follows its reference counterpart, whose two expressions for alpha round
+    #  differently -- a pair in a few millions sits between them)
+    assert int((d1 != fwd[-1]).any(dim=2).sum()) <= 2
     assert torch.equal(f1, f0)
     raised = f0.bool()
     assert torch.equal(p1[raised][:, 10].contiguous().view(torch.int32), p0[raised][:, 10].contiguous().view(torch.int32))

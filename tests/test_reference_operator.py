@@ -7,10 +7,17 @@ the only thing the reference leaves undefined, or were generated with its one so
 (their names say so); every output is then a function of the inputs and is compared here: image, depth, per-pixel
 counts, the in-place normalised features, dense gradients and all ten hook fields.
 
+ONE DEFINITION OF exp (round 5).  Every archive is `*_exp_cr.npz`: generated with GS_EMU_EXP=cr, i.e. the emulation's exp
+and log evaluated in double and rounded once -- the correctly rounded fp32 functions.  The oracle's fp32 build does the
+same (oracle/gs_oracle.c R_EXP), and so does the HIP library wherever an exponential decides something discrete (scale
+activation, opacity sigmoid, the exact re-evaluation of a weight next to a threshold: csrc/gs_common.h).  The archives
+made with NumPy's fp32 exp (whose last bit differs from the correctly rounded value on 39 % of the inputs) are gone.
+
 Tolerances.  Observed: fp32 oracle vs reference image L-inf 1.2e-7 .. 4.9e-7, every discrete output identical on every
 vector (per-pixel counts included), gradients 2e-7 .. 1e-6 relative L2 on the small vectors and up to 2e-5 on the large
-ones (_grad_tol).  The bars: image 2e-6 for the oracle and the north star's 1e-4 for the HIP path on top of its own
-oracle-parity tests; discrete outputs (visible ids, tile counts, per-pixel counts, affected-pixel counts) identical;
+ones (_grad_tol).  The bars: image 2e-6 for the oracle and the north star's 1e-4 for the HIP path ON EVERY PIXEL -- since
+round 5 no pixel is admitted as "fragile" for either: both take the reference's skip (RAS:451 / RAS:631) and stop (RAS:458)
+decision on every pixel; discrete outputs (visible ids, tile counts, per-pixel counts, affected-pixel counts) identical;
 gradients 2e-5 / 5e-5 relative L2 -- the reference accumulates with fp32 atomics (emulated in thread order), the oracle in
 double, the HIP path in a fixed fp32 order.
 
@@ -39,13 +46,13 @@ import torch
 from oracle import gs_oracle as O
 from taichi_3d_gaussian_splatting_amd.synthetic import SyntheticScene   # (a plain container for the archived inputs)
 
-ALL_FILES = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_operator_*.npz")))
+ALL_FILES = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_operator_*_exp_cr.npz")))
 # Needle scenes (Gaussians with one axis 10-100 x the others) are ill-conditioned in fp32 and have tests of their own below
 NEEDLE_FILES = [p for p in ALL_FILES if "needles" in os.path.basename(p)]
 FILES = [p for p in ALL_FILES if p not in NEEDLE_FILES]
 NEEDLE_MARGIN, SPEC_FACTOR = 4e-5, 4.0     # as tests/test_fuzz_gpu.py
 IMAGE_TOL_ORACLE, IMAGE_TOL_F64_SPEC, IMAGE_TOL_HIP = 2e-6, 2e-5, 1e-4
-MAX_FLIPPED_PIXELS, FLIP_GRAD_TOL = 8, 2e-4
+MAX_FLIPPED_PIXELS, FLIP_GRAD_TOL = 8, 2e-4    # (the f64 SPEC build only: it rounds differently by design; fp32 oracle and HIP: none)
 
 
 def _load(path):
@@ -81,7 +88,7 @@ def _grad_tol(V):
 
 def _check(V, got, grad_tol, image_tol, fragile=None):
     """got: dict with image, depth, count, features, grad_xyz, grad_feat and the ten hook fields.
-    fragile (HIP path and f64 spec build; None = none admitted: the fp32 oracle): bool[H, W], pixels on which the CPU
+    fragile (f64 spec build only; None = none admitted: the fp32 oracle and the HIP path): bool[H, W], pixels on which the CPU
     build evaluated an alpha or a T' within 1e-5 of its threshold (RAS:451, RAS:458) -- the admission rule of
     tests/test_fuzz_gpu.py: two correct implementations may decide such a pixel differently (seen once at a margin of
     1.3e-7 in 1,800 random frames).  A pixel that misses a bar must be one of them, there may be at
@@ -102,7 +109,9 @@ def _check(V, got, grad_tol, image_tol, fragile=None):
               f"image_linf={float(image_err.max()):.3e}")
         assert not (flipped & ~fragile).any() and n_flipped <= MAX_FLIPPED_PIXELS and float(image_err.max()) <= 5e-3
     affected = np.abs(got["hook_num_affected_pixels"].astype(np.int64) - V["hook_num_affected_pixels"].astype(np.int64))
-    assert int(affected.sum()) <= n_flipped      # identical unless a pixel flipped
+    # identical -- for the f64 spec build: unless a forward decision flipped, or (the backward evaluates alpha by another
+    # expression, UTL:331-348) a pair sits within the same margin of 1/255 there
+    assert int(affected.sum()) <= (0 if fragile is None else max(n_flipped, int(fragile.sum())))
     assert np.abs(got["features"] - V["features_after_forward"]).max() <= 2e-7      # in-place q normalisation
     assert np.abs(got["hook_uv"] - V["hook_uv"]).max() <= 1e-4 and np.abs(got["hook_depth"] - V["hook_depth"]).max() <= 1e-5
     if n_flipped:
@@ -208,10 +217,16 @@ def test_oracle_matches_reference_operator(path, precision):
 @pytest.mark.gpu
 @pytest.mark.parametrize("path", FILES, ids=[os.path.basename(p)[19:-4] for p in FILES])
 def test_hip_operator_matches_reference_operator(path):
+    """Every pixel within 1e-4 of the reference's run, every per-pixel count and every per-Gaussian affected-pixel count
+    identical: no pixel is admitted as fragile (round 5: a comparison inside the proven distance between the kernels'
+    rounding and the reference's is re-evaluated in the reference's expression order, csrc/gs_common.h)."""
     V, s, cfg, band = _load(path)
     got = _hip_outputs(V, s, cfg, band)
-    margin = _oracle_outputs(V, s, cfg, band, "f32")[1]
-    _check(V, got, grad_tol=_grad_tol(V), image_tol=IMAGE_TOL_HIP, fragile=margin < 1e-5)
+    assert np.array_equal(got["count"], V["count"])
+    assert np.array_equal(got["hook_num_affected_pixels"], V["hook_num_affected_pixels"])
+    print(f"[parity] reference_vector.hip.{os.path.basename(path)[19:-11]}: image_linf={float(np.abs(got['image'] - V['image']).max()):.3e}, "
+          f"flipped_pixels=0, grad_feat={_rel(got['grad_feat'], V['grad_feat']):.2e}")
+    _check(V, got, grad_tol=_grad_tol(V), image_tol=IMAGE_TOL_HIP, fragile=None)
 
 
 # ------------------------------------------------------------------------------------------------ needle scenes
@@ -248,27 +263,15 @@ def test_oracle_matches_reference_operator_on_needles(path):
             assert d_oracle <= d_reference + 1e-5, (key, name, d_oracle, d_reference)
 
 
-# The round's GPU budget ended one call short: vector l went through this test on an MI355X (passed), vector m stopped at a
-# sanity assertion of the test itself (kept-pixel fraction 0.7955 against an arbitrary 0.8, a CPU-side number) before its
-# first comparison.  Until it has been seen on a GPU its HIP leg reports without being able to fail the suite.
-NEEDLE_VECTORS_SEEN_ON_GPU = ("l_fuzz17_144x192_needles_two_objects_tied_keys_stable_sort_exp_cr",)
-
-
-def _needle_params():
-    for p in NEEDLE_FILES:
-        name = os.path.basename(p)[19:-4]
-        marks = [] if name in NEEDLE_VECTORS_SEEN_ON_GPU else [pytest.mark.xfail(
-            reason="HIP leg of this vector not yet run on a GPU (round 4 budget); the CPU test pins the oracle on it", strict=False)]
-        yield pytest.param(p, id=name, marks=marks)
-
-
 @pytest.mark.gpu
-@pytest.mark.parametrize("path", list(_needle_params()))
+@pytest.mark.parametrize("path", NEEDLE_FILES, ids=[os.path.basename(p)[19:-4] for p in NEEDLE_FILES])
 def test_hip_operator_on_needle_vectors(path):
     """The HIP operator evaluates alpha in the log2 domain from pre-scaled conics: another fp32 order, which on needles is
-    visible at 1e-4.  Integer outputs exact; everything else as close to the float64 build as the
-    reference run is (x SPEC_FACTOR), on the pixels where reference run and f64 build agree with NEEDLE_MARGIN to spare --
-    the yardstick of tests/test_fuzz_gpu.py, with the REFERENCE's run in the place of the fp32 oracle."""
+    visible at 1e-4 in the CONTINUOUS outputs.  Integer outputs exact -- since round 5 also every
+    pixel's count and every Gaussian's affected-pixel count: the skip / stop decisions are the reference's on needles too
+    (their wide brackets send more of them through the exact expression); everything else as close to the float64 build
+    as the reference run is (x SPEC_FACTOR), on the pixels where reference run and f64 build agree with NEEDLE_MARGIN to
+    spare -- the yardstick of tests/test_fuzz_gpu.py, with the REFERENCE's run in the place of the fp32 oracle."""
     V, s, cfg, band = _load(path)
     V = {k: V[k] for k in V.files}
     got = _hip_outputs(V, s, cfg, band)
@@ -280,7 +283,8 @@ def test_hip_operator_on_needle_vectors(path):
     assert np.abs(got["hook_uv"] - V["hook_uv"]).max() <= 1e-4 and np.abs(got["hook_depth"] - V["hook_depth"]).max() <= 1e-5
     keep = (V["count"] == spec["count"]) & (margin32 >= NEEDLE_MARGIN) & (margin64 >= NEEDLE_MARGIN)
     assert keep.mean() > 0.5      # (0.94 on vector l, 0.80 on vector m: close-ups put many pixels near a threshold)
-    assert np.array_equal(got["count"][keep], V["count"][keep])
+    assert np.array_equal(got["count"], V["count"])
+    assert np.array_equal(got["hook_num_affected_pixels"], V["hook_num_affected_pixels"])
     linf = lambda a, b: float(np.abs(np.asarray(a, np.float64) - np.asarray(b, np.float64)).max())   # noqa: E731
     report = {}
     for name, dist, floor, pick in (("image", linf, 1e-4, lambda d: d["image"][keep]), ("depth", linf, 2e-4, lambda d: d["depth"][keep]),
