@@ -221,19 +221,28 @@ __device__ __forceinline__ void gs_stop_bracket(float thr, int walked, int blend
 // then the transmittance recurrence over the hits in list order.  BOXED: the list covers a bin of several tiles -- entries
 // whose tile box (RAS:81-103) does not hold this tile are skipped, as the staging skips them (entries the exact cull removed
 // there fail the 1/255 test here).  Called about a thousand times per full-size frame: when a T' lands inside the pixel's
-// bracket around 1e-4 (and the brackets hold: the stop, if any, is at j_cur).
-template <bool BOXED>
-__device__ __forceinline__ bool gs_reference_stops_at(const int32_t *__restrict__ payload, const float4 *__restrict__ attrs,
-                                                      int start, int j_cur, float pxr, float pyr, int tile_u, int tile_v,
-                                                      int tw, int th) {
+// bracket around 1e-4 (and the brackets hold: the stop, if any, is at j_cur).  870 replays per headline frame cost the
+// forward kernel 35 us before the list entries were prefetched and the tile's own written-out list was used where it exists.
+template <bool BOXED, bool OWN_LIST>
+__device__ __forceinline__ bool gs_reference_stops_at(const int32_t *list, const float4 *__restrict__ attrs, int first,
+                                                      int j_cur, float pxr, float pyr, int tile_u, int tile_v, int tw, int th) {
+    // OWN_LIST: `list` is the tile's own kept entries as this workgroup has written them out so far (walked_list: read with
+    // workgroup-scope loads, behind the barrier that followed the stores)
+    auto entry_at = [&](int j) {
+        return OWN_LIST ? __hip_atomic_load(list + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : list[j];
+    };
     const int lane = gs_lane();
     float T = 1.0f;
-    for (int base = start; base <= j_cur; base += GS_WAVE) {
-        const int j = base + lane;
+    // (the next step's list entries are fetched while this step's records are on their way: the replay is a chain of
+    // dependent gathers on the critical path of its tile)
+    int o_next = first + lane <= j_cur ? entry_at(first + lane) : 0;
+    for (int base = first; base <= j_cur; base += GS_WAVE) {
+        const int j = base + lane, o = o_next;
         bool valid = j <= j_cur;
+        if (j + GS_WAVE <= j_cur) o_next = entry_at(j + GS_WAVE);
         float a = 0.f;
         if (valid) {
-            const float4 *g = attrs + 4 * (size_t)payload[j];
+            const float4 *g = attrs + 4 * (size_t)o;
             const float4 r0 = g[0], r1 = g[1];
             if (BOXED) valid = gs_entry_in_tile(r0, r1, tile_u, tile_v, tw, th, GS_FILTER_BOX);
             if (valid)
@@ -491,6 +500,7 @@ __global__ __launch_bounds__(BLEND_THREADS, GS_FWD_MIN_WAVES) void blend_forward
     // upper edge of each pixel's bracket around T' = 1e-4 (gs_common.h, 4.): + 4 u per list position walked (batch by batch),
     // + every blended Gaussian's weight times its alpha
     v2f thr = splat(STOP_T);
+    int park0 = GROUP_FWD, park1 = GROUP_FWD;   // entry of the current group at which the pixel is parked (GROUP_FWD: it is not)
 
     int pos = start;
     while (pos < end) {
@@ -538,16 +548,22 @@ __global__ __launch_bounds__(BLEND_THREADS, GS_FWD_MIN_WAVES) void blend_forward
                 dc1 += ok1 ? 1u : 0u; dh1 += ok1 ? hv : 0u;
             }
         };
-        // One entry with every decision taken as the reference takes it: the group loop hands over (for the rest of its
-        // group) when a comparison falls inside a bracket -- about a thousand (wave, entry) visits per full-size frame.  An
-        // alpha inside [EPS_LO, EPS_HI) is decided by the reference's expression (same exponent, correctly rounded exp,
-        // * rescale * opacity); a T' inside the pixel's stop bracket by a replay of the pixel's history in the reference's
-        // arithmetic.  Kept out of the group loop's body so that its temporaries (double-precision exp, the replay's records)
-        // do not add to the registers of the hot path.
-        auto careful_entry = [&](int e) {
+        // PARKED PIXELS.  When a comparison of the group loop falls inside a bracket -- an alpha inside [EPS_LO, EPS_HI), a T'
+        // inside the pixel's stop bracket: about a thousand (wave, entry) visits per full-size frame -- the decision is not the
+        // loop's to take: the pixel is PARKED at that entry (its state untouched, alive = 0 so that the rest of the group passes
+        // it by) and the loop goes on for the other pixels without leaving its straight-line body.  After the group the wave
+        // takes the parked pixels through the entries they missed with every decision taken as the reference takes it
+        // (careful_entry: the reference's expression with the same exponent, correctly rounded exp, * rescale * opacity; a
+        // replay of the pixel's history in the reference's arithmetic for a T' in the bracket).  Every update of a pixel that is
+        // not taking part (al = 0) is an exact no-op, so the catch-up runs the ordinary blend update on the whole wave.  Kept
+        // out of the group loop's body so that its temporaries (double-precision exp, the replay's records) do not add to the
+        // registers of the hot path, nor its exits to the loop's control flow (an early-exit form cost the forward kernel 20 us).
+        // m0 / m1: the pixels taking part; dead0 / dead1: those the reference stops during the catch-up.
+        auto careful_entry = [&](int e, bool m0, bool m1, bool &dead0, bool &dead1) {
             v2f ex;
             const float4 P = s_p[e], Q = s_q[e];
-            const v2f a = gs_pair_alpha_forward(P, Q, px, py, ex) * alive;
+            const v2f am = {m0 && !dead0 ? 1.f : 0.f, m1 && !dead1 ? 1.f : 0.f};
+            const v2f a = gs_pair_alpha_forward(P, Q, px, py, ex) * am;
             bool ok0 = a.x >= EPS_ALPHA, ok1 = a.y >= EPS_ALPHA;   // RAS:451
             {
                 const bool in0 = a.x >= EPS_LO && a.x < EPS_HI, in1 = a.y >= EPS_LO && a.y < EPS_HI;
@@ -557,7 +573,7 @@ __global__ __launch_bounds__(BLEND_THREADS, GS_FWD_MIN_WAVES) void blend_forward
 #pragma clang loop unroll(disable)
                     for (int c = 0; c < 2; ++c) {
                         const float exact = gs_alpha_reference(c ? ex.y : ex.x, ro.x, ro.y);
-                        if (c ? in1 : in0) { if (c) ok1 = exact * alive.y >= EPS_ALPHA; else ok0 = exact * alive.x >= EPS_ALPHA; }
+                        if (c ? in1 : in0) { if (c) ok1 = exact * am.y >= EPS_ALPHA; else ok0 = exact * am.x >= EPS_ALPHA; }
                     }
                 }
             }
@@ -582,15 +598,18 @@ __global__ __launch_bounds__(BLEND_THREADS, GS_FWD_MIN_WAVES) void blend_forward
                             const int l = __builtin_ctzll(m);
                             GS_STAT(GS_STAT_FWD_REPLAYS, 1);
                             GS_STAT(GS_STAT_FWD_REPLAY_ENTRIES, j_cur - start + 1);
-                            const bool stops = gs_reference_stops_at<STAGED>(payload, attrs, start, j_cur,
-                                                                             gs_readlane_f(c ? px.y : px.x, l), gs_readlane_f(py, l),
-                                                                             tc.tile_u, tc.tile_v, tw, th);
+                            const float pxr = gs_readlane_f(c ? px.y : px.x, l), pyr = gs_readlane_f(py, l);
+                            // (the tile's own written-out list where there is one: half the entries of the bin's, no box test)
+                            const bool stops = emit ? gs_reference_stops_at<false, true>(walked_list, attrs, wbase, wbase + kept_base + e,
+                                                                                        pxr, pyr, tc.tile_u, tc.tile_v, tw, th)
+                                                    : gs_reference_stops_at<STAGED, false>(payload, attrs, start, j_cur, pxr, pyr,
+                                                                                           tc.tile_u, tc.tile_v, tw, th);
                             if ((tid & (GS_WAVE - 1)) == l) { if (c) sat1 = stops; else sat0 = stops; }
                         }
                 }
             }
-            if (sat0) { al.x = 0.f; alive.x = 0.f; ok0 = false; }
-            if (sat1) { al.y = 0.f; alive.y = 0.f; ok1 = false; }
+            if (sat0) { al.x = 0.f; dead0 = true; ok0 = false; }
+            if (sat1) { al.y = 0.f; dead1 = true; ok1 = false; }
             Tn = T * (splat(1.f) - al);
             blend(e, c, Q.z, al, Tn, ok0, ok1);
         };
@@ -612,20 +631,28 @@ __global__ __launch_bounds__(BLEND_THREADS, GS_FWD_MIN_WAVES) void blend_forward
             for (int i = 0; i < GROUP_FWD; ++i) { Cr = Cr + alpha[i]; last0 += (int)z[i]; }
             continue;
 #endif
-            int careful_from = GROUP_FWD;   // first entry of the group that needs the careful twin (none: GROUP_FWD)
+            bool parked = false;   // wave-uniform: a pixel of this wave was parked in this group
             GS_STAT(GS_STAT_FWD_ENTRIES, GROUP_FWD);
 #pragma unroll
             for (int i = 0; i < GROUP_FWD; ++i) {
-                // a = alpha for a live pixel (x * 1.0f is exact), 0 for a saturated one
+                // a = alpha for a live pixel (x * 1.0f is exact), 0 for a saturated (or parked) one
                 const v2f a = alpha[i] * alive;
                 bool ok0 = a.x >= EPS_LO, ok1 = a.y >= EPS_LO;        // RAS:451 (lower edge of the bracket)
-                const unsigned long long mok0 = gs_ballot(ok0), mok1 = gs_ballot(ok1);
+                unsigned long long mok0 = gs_ballot(ok0), mok1 = gs_ballot(ok1);
                 if ((mok0 | mok1) == 0ull) continue;                  // wave-uniform skip
                 GS_STAT(GS_STAT_FWD_HIT_ENTRIES, 1);
                 GS_STAT(GS_STAT_FWD_HIT_PIXELS, __popcll(mok0) + __popcll(mok1));
                 GS_STAT(GS_STAT_FWD_HIT_LANES, __popcll(mok0 | mok1));
-                // an alpha inside the bracket: the decision is not this loop's to take
-                if (((mok0 ^ gs_ballot(a.x >= EPS_HI)) | (mok1 ^ gs_ballot(a.y >= EPS_HI))) != 0ull) { careful_from = i; break; }
+                {
+                    const unsigned long long mhi0 = gs_ballot(a.x >= EPS_HI), mhi1 = gs_ballot(a.y >= EPS_HI);
+                    if (((mok0 ^ mhi0) | (mok1 ^ mhi1)) != 0ull) {    // rare: an alpha inside the bracket -> park the pixel here
+                        if (ok0 && !(a.x >= EPS_HI)) { park0 = i; alive.x = 0.f; ok0 = false; }
+                        if (ok1 && !(a.y >= EPS_HI)) { park1 = i; alive.y = 0.f; ok1 = false; }
+                        parked = true;
+                        mok0 = mhi0; mok1 = mhi1;
+                        if ((mok0 | mok1) == 0ull) continue;
+                    }
+                }
                 // alpha = 0 for a skipped pixel makes the update an exact no-op
                 v2f al = {ok0 ? __builtin_amdgcn_fmed3f(a.x, 0.f, CLAMP_ALPHA) : 0.f,
                           ok1 ? __builtin_amdgcn_fmed3f(a.y, 0.f, CLAMP_ALPHA) : 0.f};
@@ -636,22 +663,34 @@ __global__ __launch_bounds__(BLEND_THREADS, GS_FWD_MIN_WAVES) void blend_forward
                 // (masks combined on the scalar unit: a ballot of the AND would be materialised as select + compare)
                 if (((mok0 & gs_ballot(low0)) | (mok1 & gs_ballot(low1))) != 0ull) {
                     // rare: RAS:458-460 -- the first Gaussian that would push T below 1e-4 saturates the
-                    // pixel and is NOT blended (below the pixel's bracket on both sides; inside it: the careful twin)
+                    // pixel and is NOT blended (below the pixel's bracket on both sides; inside it: parked)
                     float lo0, hi0, lo1, hi1;
                     gs_stop_bracket(thr.x, walked, AUX ? cnt0 + 1 : -1, lo0, hi0);
                     gs_stop_bracket(thr.y, walked, AUX ? cnt1 + 1 : -1, lo1, hi1);
                     const bool sat0 = ok0 && Tn.x < lo0, sat1 = ok1 && Tn.y < lo1;
-                    if (gs_ballot((ok0 && !sat0 && Tn.x < hi0) || (ok1 && !sat1 && Tn.y < hi1)) != 0ull) { careful_from = i; break; }
+                    const bool fr0 = ok0 && !sat0 && Tn.x < hi0, fr1 = ok1 && !sat1 && Tn.y < hi1;
+                    if (gs_ballot(fr0 || fr1) != 0ull) {
+                        if (fr0) { park0 = i; al.x = 0.f; alive.x = 0.f; ok0 = false; }
+                        if (fr1) { park1 = i; al.y = 0.f; alive.y = 0.f; ok1 = false; }
+                        parked = true;
+                    }
                     if (sat0) { al.x = 0.f; alive.x = 0.f; ok0 = false; }
                     if (sat1) { al.y = 0.f; alive.y = 0.f; ok1 = false; }
                     Tn = T * (splat(1.f) - al);
                 }
                 blend(k + i, c, z[i], al, Tn, ok0, ok1);
             }
-            if (careful_from < GROUP_FWD) {
-                GS_STAT(GS_STAT_FWD_CAREFUL_ENTRIES, GROUP_FWD - careful_from);
+            if (parked) {   // the parked pixels catch up on the entries of the group they missed
+                bool dead0 = false, dead1 = false;
 #pragma clang loop unroll(disable)
-                for (int e = k + careful_from; e < k + GROUP_FWD; ++e) careful_entry(e);
+                for (int i = 0; i < GROUP_FWD; ++i) {
+                    const bool m0 = park0 <= i, m1 = park1 <= i;
+                    if (gs_ballot(m0 || m1) == 0ull) continue;
+                    GS_STAT(GS_STAT_FWD_CAREFUL_ENTRIES, 1);
+                    careful_entry(k + i, m0, m1, dead0, dead1);
+                }
+                if (park0 < GROUP_FWD) { alive.x = dead0 ? 0.f : 1.f; park0 = GROUP_FWD; }
+                if (park1 < GROUP_FWD) { alive.y = dead1 ? 0.f : 1.f; park1 = GROUP_FWD; }
             }
         }
         kept_base += nbuf;
@@ -1135,8 +1174,8 @@ __global__ __launch_bounds__(SMALL_THREADS) void blend_forward_small_kernel(
             bool sat = ok && Tn < lo;   // RAS:458-460, below the bracket
             for (unsigned long long m = gs_ballot(ok && !sat && Tn < hi); m != 0ull; m &= m - 1ull) {
                 const int l = __builtin_ctzll(m);
-                const bool stops = gs_reference_stops_at<false>(payload, attrs, start, batch_first + e, gs_readlane_f(px, l),
-                                                                gs_readlane_f(py, l), tc.tile_u, tc.tile_v, tw, th);
+                const bool stops = gs_reference_stops_at<false, false>(payload, attrs, start, batch_first + e, gs_readlane_f(px, l),
+                                                                       gs_readlane_f(py, l), tc.tile_u, tc.tile_v, tw, th);
                 if ((tid & (GS_WAVE - 1)) == l) sat = stops;
             }
             if (sat) { al = 0.f; alive = 0.f; ok = false; }

@@ -443,9 +443,10 @@ REGRESSION_PIXEL_TOL = 5e-6  # 10x the largest non-fragile L-inf observed on any
 
 
 def _check_image(name, hip, ref, fragile):
-    """North star: L-inf <= 1e-4 on every pixel whose blend decisions are not within 5e-8 of a threshold (the oracle
-    reports them).  On those fragile pixels the error is bounded too (one skipped / added Gaussian) and the number
-    that actually flipped is reported.  The regression bar (5e-6) is 10x what is observed."""
+    """North star: L-inf <= 1e-4 ON EVERY PIXEL (round 5: the pixels whose blend decisions lie within 5e-8 of a threshold --
+    `fragile`, the oracle reports them -- are no longer admitted: the kernels take the reference's decision on them too,
+    csrc/gs_common.h "threshold decisions"; they are still counted in the report).  The regression bar (5e-6) is 10x what
+    is observed."""
     diff = np.abs(hip.astype(np.float64) - ref.astype(np.float64))
     if diff.ndim == 3:
         diff = diff.max(axis=2)
@@ -454,9 +455,8 @@ def _check_image(name, hip, ref, fragile):
     report(name, linf_nonfragile=float(diff[ok].max()), linf_all=float(diff.max()),
            fragile_fraction=float(fragile.mean()), fragile_pixels=int(fragile.sum()), flipped_pixels=flipped,
            over_tol_all=int((diff > PIXEL_TOL).sum()))
-    assert diff[ok].max() <= PIXEL_TOL
-    assert diff[ok].max() <= REGRESSION_PIXEL_TOL
-    assert diff.max() <= FRAGILE_PIXEL_BOUND
+    assert diff.max() <= PIXEL_TOL
+    assert diff.max() <= REGRESSION_PIXEL_TOL and flipped == 0
     assert fragile.mean() < 0.02
 
 
@@ -468,10 +468,9 @@ def test_blend_forward(ops, scene, ofwd):
     fragile = ofwd["margin"] < FRAGILE_MARGIN
     _check_image("blend_forward.image", image, ofwd["image"], fragile)
     _check_image("blend_forward.acc_alpha", acc_alpha, ofwd["acc_alpha"], fragile)
-    ok = ~fragile
-    assert np.allclose(depth[ok], ofwd["depth"][ok], rtol=1e-4, atol=1e-4)
-    assert np.array_equal(last_eff[ok], ofwd["last_eff"][ok])
-    assert np.array_equal(count[ok], ofwd["count"][ok])
+    assert np.allclose(depth, ofwd["depth"], rtol=1e-4, atol=1e-4)
+    assert np.array_equal(last_eff, ofwd["last_eff"])     # every pixel, the fragile ones included
+    assert np.array_equal(count, ofwd["count"])
 
 
 # Gradient bars (relative L2), each within 10x of what is observed (gpurun_out/pytest_r02b.log, round 2):
