@@ -22,9 +22,14 @@ Rank 0 prints ONE JSON line.  Besides the contract fields it carries
                  stays the wall-clock mean over the K steps between two barriers + synchronisations)
   roofline     : achieved algorithmic HBM GB/s of the dominant kernel vs the 8 TB/s peak, measured live with HIP
                  events on the launch stream (plus all stage times and the whole-path figure); `traffic` = PMC HBM
-                 bytes per launch from the committed profile -- only while the kernel sources are the profiled ones
-                 (hash recorded next to the profile), else null; `valu` = the VALU-issue view of the same kernel
-                 (the blend kernels are bound by VALU issue, not HBM: DESIGN.md section 5)
+                 bytes per launch from the committed profile, {raw, gfx950_corrected} (the guide's correction doubles
+                 the fetch counter: right for streaming reads, too much for gathers) -- only while the kernel sources are
+                 the profiled ones (hash recorded next to the profile), else null; `valu` = the VALU-issue view of the
+                 same kernel (the blend kernels are bound by VALU issue, not HBM: DESIGN.md section 5);
+                 `lane_utilisation` = how often the hit path runs and with how many live lanes, how often a decision is
+                 settled by the reference's own expression (counting build, tools/blend_stats.py; same hash rule)
+  variants     : the same K steps in other configurations -- without the [M,56] hook copy; over a seeded camera orbit
+                 (`camera_path`: lists, sizes and the size speculation change every step)
   cpu_baseline : the CPU oracle (a from-source port of the reference kernels; the reference itself
                  cannot run here -- taichi is absent and its kernels are CUDA-only) timed on this
                  box's host cores on one full frame of the same workload.
@@ -104,7 +109,11 @@ def profiled_counters(kernel: str):
         with open(os.path.join(ROOT, "profiles", f"{PROFILE_TAG}_hbm_traffic.csv")) as fh:
             for row in csv.DictReader(fh):
                 if row[""].startswith(kernel + "_kernel"):
-                    traffic = int((float(row["hbm_read_MB_gfx950_corrected"]) + float(row["hbm_write_MB"])) * 1e6)
+                    # both figures: the guide's gfx950 correction doubles FETCH_SIZE (128-B requests counted as 64 B) -- right
+                    # for streaming reads, too much for kernels whose reads are 16-B / 64-B gathers (profiles/README.md)
+                    traffic = {"raw": int((float(row["hbm_read_MB_raw"]) + float(row["hbm_write_MB"])) * 1e6),
+                               "gfx950_corrected": int((float(row["hbm_read_MB_gfx950_corrected"]) +
+                                                        float(row["hbm_write_MB"])) * 1e6)}
     except (OSError, KeyError, ValueError):
         pass
     try:
@@ -115,6 +124,56 @@ def profiled_counters(kernel: str):
     except (OSError, KeyError, ValueError):
         pass
     return traffic, valu
+
+
+def camera_orbit(q0, t0, n_poses: int, seed: int = 7):
+    """n poses T_pointcloud_camera = Rot * T0: the camera of the workload carried around the cloud's centre -- azimuth 2 pi k / n
+    (+ a seeded jitter), elevation within +- 0.2 rad -- at its own distance, looking at the centre as before.
+    Quaternions (x, y, z, w) as everywhere in the operator."""
+    import math
+    g = torch.Generator().manual_seed(seed)
+    out = []
+    q0c, t0c = q0.detach().cpu().double(), t0.detach().cpu().double()
+
+    def qmul(a, b):
+        ax, ay, az, aw = a
+        bx, by, bz, bw = b
+        return torch.tensor([aw * bx + ax * bw + ay * bz - az * by, aw * by - ax * bz + ay * bw + az * bx,
+                             aw * bz + ax * by - ay * bx + az * bw, aw * bw - ax * bx - ay * by - az * bz], dtype=torch.float64)
+
+    def rotate(q, v):
+        x, y, z, w = q
+        R = torch.tensor([[1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)],
+                          [2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)],
+                          [2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)]], dtype=torch.float64)
+        return R @ v
+    for k in range(n_poses):
+        az = 2 * math.pi * (k + 0.3 * float(torch.rand(1, generator=g))) / n_poses
+        el = 0.4 * float(torch.rand(1, generator=g)) - 0.2
+        qy = torch.tensor([0.0, math.sin(az / 2), 0.0, math.cos(az / 2)], dtype=torch.float64)
+        qx = torch.tensor([math.sin(el / 2), 0.0, 0.0, math.cos(el / 2)], dtype=torch.float64)
+        rot = qmul(qy, qx)
+        qs = torch.stack([qmul(rot, q0c[i]) for i in range(q0c.shape[0])])
+        ts = torch.stack([rotate(rot, t0c[i]) for i in range(t0c.shape[0])])
+        out.append((qs.to(q0.dtype).to(q0.device), ts.to(t0.dtype).to(t0.device)))
+    return out
+
+
+def profiled_lane_utilisation():
+    """Path statistics of the two blend kernels at the headline size (profiles/<tag>_blend_path_stats.json: counters of a
+    -DGS_STATS=1 build, tools/blend_stats.py) -- the share of (wave, entry) visits that run the hit path and the live pixels /
+    lanes on it, the visits settled by the exact-decision paths.  None when absent or taken with other kernel sources."""
+    try:
+        with open(os.path.join(ROOT, "profiles", f"{PROFILE_TAG}_source_hash.txt")) as fh:
+            if fh.read().split()[0] != kernel_source_hash():
+                return None
+        with open(os.path.join(ROOT, "profiles", f"{PROFILE_TAG}_blend_path_stats.json")) as fh:
+            d = json.load(fh)
+        return {"workload": d["workload"], "forward": d.get("forward"), "backward": d.get("backward"),
+                "exact_decisions": {k: d["counters"][k] for k in ("fwd_careful_entries", "fwd_exact_alpha", "fwd_replays",
+                                                                  "bwd_bracketed", "bwd_exact_alpha")}}
+    except (OSError, KeyError, ValueError, IndexError):
+        return None
 
 
 def self_launch(n_ranks: int) -> int:
@@ -160,6 +219,11 @@ def main() -> None:
     ap.add_argument("--no-pin", action="store_true",
                     help="leave the host threads where the scheduler puts them (default: all threads of the process on one "
                          "L3 complex of the GPU's NUMA node, taichi_3d_gaussian_splatting_amd/host_affinity.py)")
+    ap.add_argument("--camera-path", type=int, default=8,
+                    help="poses of the moving-camera variant reported beside the static line (`variants.camera_path`): a "
+                         "seeded orbit at the workload's camera distance, one pose per step in turn, so that list layout, sizes "
+                         "and the size speculation change every step (the reference's own protocol renders dataset poses, "
+                         "benchmark/inference_benchmark.py:109-160); 0 = off")
     ap.add_argument("--static-scene", action="store_true",
                     help="let the forward skip the write-back of quaternions that are already normalised (default: "
                          "training-like -- the in-place normalisation RAS:196-205 writes every visible row, every frame)")
@@ -295,6 +359,33 @@ def main() -> None:
                                                  "value": round(s.height * s.width / 1e6 / (v_ms / 1e3), 3)}
     pixels = s.height * s.width
     value = pixels / 1e6 / (ms_per_step / 1e3)
+    # the moving-camera variant: the same K steps over a seeded orbit (the driver's number stays the static line above)
+    if args.camera_path > 0 and world == 1:
+        poses = camera_orbit(s.q_pointcloud_camera, s.t_pointcloud_camera, args.camera_path)
+        inputs = [Op.GaussianPointCloudRasterisationInput(
+            point_cloud=xyz, point_cloud_features=feat, point_object_id=s.point_object_id[rows],
+            point_invalid_mask=s.point_invalid_mask[rows], camera_info=cam, q_pointcloud_camera=q, t_pointcloud_camera=t,
+            color_max_sh_band=3) for q, t in poses]
+        static_inp, turn = inp, [0]
+        before = dict(op.speculation_stats)
+
+        def moving_step():
+            nonlocal inp
+            inp = inputs[turn[0] % len(inputs)]
+            turn[0] += 1
+            return step_static()
+        step_static, step = step, moving_step
+        v_ms, v_step = timed_run(max(min(args.warmup, 5), len(inputs)), args.steps)
+        step, inp = step_static, static_inp
+        after = dict(op.speculation_stats)
+        variants["camera_path"] = {
+            "poses": len(inputs), "ms_per_step": round(v_ms, 4), "step_ms": v_step,
+            "value": round(pixels / 1e6 / (v_ms / 1e3), 3), "vs_static": round(v_ms / ms_per_step, 4),
+            "speculation": {k: after[k] - before[k] for k in after},
+            "note": "seeded orbit about the cloud's centre at the workload's camera distance (+- 0.2 rad of elevation), one pose "
+                    "per step in turn: every step rebuilds lists of another layout and size"}
+        for _ in range(2):   # (the stage profile below runs on the static camera again: let its size guesses settle)
+            step()
 
     # ---------------------------------------------------------------- per-stage timing (rank-local)
     n = s.point_cloud.shape[0]
@@ -418,7 +509,7 @@ def main() -> None:
             "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
             "kernel_ms": round(stages_ms[dominant], 4),
             "algorithmic_bytes": int(bytes_per[dominant]),
-            "valu": valu,
+            "valu": valu, "lane_utilisation": profiled_lane_utilisation(),
             "path": {"algorithmic_bytes": int(path_bytes),
                      "achieved": round(path_bytes / (ms_per_step * 1e-3) / 1e9, 2),
                      "frac": round(path_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),

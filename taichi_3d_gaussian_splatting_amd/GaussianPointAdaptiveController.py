@@ -96,6 +96,7 @@ class GaussianPointAdaptiveController:
         self.config = config
         self.maintained_parameters = maintained_parameters
         self.iteration_counter = -1
+        self.mask_version = 0   # bumped whenever the controller changes which rows are live (_add_densify_points)
         self.input_data: Optional[HookInput] = None
         self.densify_point_info = None
         self.has_plot = False
@@ -277,6 +278,7 @@ class GaussianPointAdaptiveController:
             invalid[free_rows] = 0
             _log.info("densified %d of %d candidates (%d splits, %d clones)", filled, wanted,
                       int(is_split.sum()), filled - int(is_split.sum()))
+        self.mask_version += 1   # the live set has changed (what depends on its size re-reads it)
         n_live_after = int((invalid == 0).sum())
         assert n_live_after == n_live_before - n_removed + filled
         _log.info("valid points %d -> %d (removed %d transparent, %d floaters)", n_live_before, n_live_after,

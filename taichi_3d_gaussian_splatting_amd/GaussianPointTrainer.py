@@ -371,6 +371,20 @@ class GaussianPointCloudTrainer:
         return (torch.utils.data.DataLoader(self.train_dataset, shuffle=True, generator=generator, **kw),
                 torch.utils.data.DataLoader(self.val_dataset, shuffle=False, **kw))
 
+    def _local_live_share(self) -> float:
+        """Owner-sharded Gaussians: n_live(this rank's block) / n_live(all blocks), as the scale regulariser needs it (a mean
+        over ALL live Gaussians, LOS:42-54).  The live set only changes when the controller densifies or prunes, so the two
+        counts are re-read (one all-reduce, one host read-back) only when its densification counter has moved."""
+        version = self.adaptive_controller.mask_version
+        cached = getattr(self, "_live_share_cache", None)
+        if cached is None or cached[0] != version:
+            counts = (self.scene.point_invalid_mask == 0).sum().to(torch.float64).reshape(1)
+            total = counts.clone()
+            torch.distributed.all_reduce(total)
+            cached = (version, float(counts.item()) / max(float(total.item()), 1.0))
+            self._live_share_cache = cached
+        return cached[1]
+
     # ------------------------------------------------------------------ training (TRN:120-272)
     def train(self):
         cfg = self.config
@@ -389,7 +403,8 @@ class GaussianPointCloudTrainer:
         if regularised:
             feature_optimizer.set_scale_regulariser(self.scene.point_cloud_features,
                                                     self.loss_function.config.regularization_weight,
-                                                    self.scene.point_invalid_mask)
+                                                    self.scene.point_invalid_mask,
+                                                    local_share=self._local_live_share if self.owner_sharded else None)
         scheduler = torch.optim.lr_scheduler.ExponentialLR(position_optimizer,
                                                            gamma=cfg.position_learning_rate_decay_rate)
         downsample_factor = cfg.initial_downsample_factor
@@ -421,8 +436,12 @@ class GaussianPointCloudTrainer:
             # gradient, from the same pre-step parameters); its VALUE is only needed where the loss is logged
             loss = loss.detach()
             if regularised and iteration % cfg.log_loss_interval == 0:
-                loss = loss + self.loss_function.regularization_value(self.scene.point_invalid_mask,
-                                                                      self.scene.point_cloud_features)
+                reg_value = self.loss_function.regularization_value(self.scene.point_invalid_mask,
+                                                                    self.scene.point_cloud_features)
+                if self.owner_sharded:   # mean over ALL live Gaussians: the blocks' means weighted by their share
+                    reg_value = reg_value * self._local_live_share()
+                    torch.distributed.all_reduce(reg_value)
+                loss = loss + reg_value
             raw_pred = image_pred.detach()
             image_pred = None   # the clamped CHW copy is only materialised on logging iterations (below)
             feature_optimizer.step()

@@ -34,15 +34,21 @@ class Adam(torch.optim.Optimizer):
             raise TypeError("point_invalid_mask must be int8")
         self._row_mask[id(param)] = point_invalid_mask
 
-    def set_scale_regulariser(self, features: torch.Tensor, weight: float, point_invalid_mask: torch.Tensor) -> None:
+    def set_scale_regulariser(self, features: torch.Tensor, weight: float, point_invalid_mask: torch.Tensor,
+                              local_share=None) -> None:
         """Fuse the gradient of ``weight * mean_live ||exp(features[:, 4:7])||`` (the trainer's scale regulariser,
         LOS:42-54) into the step of the [N,56] parameter ``features``: it is added to the incoming gradient inside the
         Adam kernel (from the pre-step parameters), so neither autograd nor a separate pass has to produce it.
-        ``weight = 0`` switches it off."""
+        ``weight = 0`` switches it off.
+
+        ``local_share`` (owner-sharded Gaussians: this tensor holds only the rank's block): a zero-argument callable
+        that returns n_live(this block) / n_live(all ranks).  The kernel divides by the live count it finds in the tensor
+        it is given; the reference's term is a mean over ALL live Gaussians (LOS:42-54), so the weight handed to the
+        kernel is ``weight * local_share()`` -- the same per-point gradient as an un-sharded run."""
         if features.dim() != 2 or features.shape[1] != 56:
             raise ValueError("the scale regulariser applies to the [N,56] feature matrix")
         if weight:
-            self._scale_regulariser[id(features)] = (float(weight), point_invalid_mask)
+            self._scale_regulariser[id(features)] = (float(weight), point_invalid_mask, local_share)
         else:
             self._scale_regulariser.pop(id(features), None)
 
@@ -76,7 +82,7 @@ class Adam(torch.optim.Optimizer):
                         # current as of the previous step: no lazy decay is owed for them
                         state["last_step"] = torch.full((p.shape[0],), int(state["step"]) - 1, dtype=torch.int32,
                                                         device=p.device)
-                    weight = reg[0] if reg is not None else 0.0
+                    weight = (reg[0] * (float(reg[2]()) if reg[2] is not None else 1.0)) if reg is not None else 0.0
                     ws = torch.empty(256, dtype=torch.int32, device=p.device) if weight else None
                     call("gs_adam_step_rows", ptr(p), ptr(grad), ptr(state["exp_avg"]), ptr(state["exp_avg_sq"]),
                          p.shape[0], p.shape[1], float(group["lr"]), float(beta1), float(beta2), float(group["eps"]),
@@ -84,7 +90,7 @@ class Adam(torch.optim.Optimizer):
                          current_stream(p.device))
                     continue
                 if reg is not None:
-                    weight, mask = reg
+                    weight, mask = reg[0] * (float(reg[2]()) if reg[2] is not None else 1.0), reg[1]
                     ws = torch.empty(256, dtype=torch.int32, device=p.device)
                     call("gs_adam_step_features", ptr(p), ptr(grad), ptr(state["exp_avg"]), ptr(state["exp_avg_sq"]),
                          p.shape[0], float(group["lr"]), float(beta1), float(beta2), float(group["eps"]), state["step"],

@@ -464,6 +464,51 @@ def test_adam_with_fused_scale_regulariser_matches_explicit_gradient():
                2.0 * LossFunction._regularization_loss(invalid.cpu(), a.detach().cpu()).item()) < 1e-5
 
 
+def test_scale_regulariser_of_an_owned_block_is_normalised_by_the_global_live_count():
+    """Owner-sharded Gaussians: a rank holds only its block of the [N,56] matrix, and the Adam kernel divides
+    the regulariser's gradient by the live count of the tensor it is given -- the reference's term is a mean over ALL live
+    Gaussians (LOS:42-54).  With `local_share` = n_live(block) / n_live(all) the blocks stepped on their own end up where
+    the un-sharded matrix does; without it they do not (every per-point term is then world-size times too large)."""
+    from taichi_3d_gaussian_splatting_amd.optim import Adam
+    dev = torch.device("cuda:0")
+    s = make_scene(n=30011, height=64, width=64, s_min=0.01, s_max=0.4, seed=5, invalid_fraction=0.3)
+    invalid = s.point_invalid_mask.to(dev)
+    feats = s.point_cloud_features.to(dev)
+    whole = torch.nn.Parameter(feats.clone())
+    cut = 11000                                   # unequal blocks with different live fractions
+    blocks = [(0, cut), (cut, feats.shape[0])]
+    n_live_all = int((invalid == 0).sum())
+    def run(with_share):
+        params, opts = [], []
+        for lo, hi in blocks:
+            p = torch.nn.Parameter(feats[lo:hi].clone())
+            mask = invalid[lo:hi].contiguous()
+            share = int((mask == 0).sum()) / n_live_all
+            o = Adam([p], lr=5e-3)
+            o.set_row_mask(p, mask)
+            o.set_scale_regulariser(p, 2.0, mask, local_share=(lambda sh=share: sh) if with_share else None)
+            params.append(p); opts.append(o)
+        return params, opts
+    opt_w = Adam([whole], lr=5e-3)
+    opt_w.set_row_mask(whole, invalid)
+    opt_w.set_scale_regulariser(whole, 2.0, invalid)
+    shared, opts_s = run(True)
+    naive, opts_n = run(False)
+    g = torch.Generator(device=dev).manual_seed(2)
+    for _ in range(4):
+        grad = torch.randn(feats.shape, device=dev, generator=g) * 1e-3
+        whole.grad = grad.clone()
+        opt_w.step()
+        for ps, os_ in ((shared, opts_s), (naive, opts_n)):
+            for (lo, hi), p, o in zip(blocks, ps, os_):
+                p.grad = grad[lo:hi].clone()
+                o.step()
+    live = invalid == 0
+    got, wrong = torch.cat([p.detach() for p in shared]), torch.cat([p.detach() for p in naive])
+    assert torch.allclose(got[live], whole.detach()[live], rtol=1e-6, atol=1e-7), (got - whole).abs()[live].max()
+    assert (wrong[live][:, 4:7] - whole.detach()[live][:, 4:7]).abs().max() > 1e-4      # what the fix is for
+
+
 def test_training_iteration_time_record():
     """Driver-side record of the training throughput the documents quote: one TRAINING iteration
     at the headline size -- operator forward, fused L1 + SSIM loss, backward with the controller's hook fields, both
