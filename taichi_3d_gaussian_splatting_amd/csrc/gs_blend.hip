@@ -172,8 +172,12 @@ __device__ __forceinline__ v2f gs_pair_alpha_backward(const float4 P, const floa
     const float dy = py - P.y;
     m0 = splat(P.z) * dx + splat(P.w * dy);
     m1 = splat(P.w) * dx + splat(Q.x * dy);
-    e = splat(-0.5f) * (dx * m0 + splat(dy) * m1);
-    return gs_weight_from_exponent(e, Q.y);
+    const v2f s = dx * m0 + splat(dy) * m1;
+    e = splat(-0.5f) * s;   // (exact: only the careful path looks at it)
+    // 2^(e log2 e) with e log2 e formed as s * (-0.5 log2 e): the same bits as (-0.5 s) * log2 e -- halving is exact -- in one
+    // multiplication
+    const v2f e2 = s * splat(-0.5f * GS_LOG2E);
+    return (v2f){__builtin_amdgcn_exp2f(e2.x), __builtin_amdgcn_exp2f(e2.y)} * splat(Q.y);
 }
 // (one pixel per lane: the four-waves-per-tile kernels and the replay; the same operations, component by component)
 __device__ __forceinline__ float gs_exponent_forward(float dx, float dy, float A, float B, float C) {
@@ -189,8 +193,9 @@ __device__ __forceinline__ float gs_pixel_alpha_backward(const float4 P, const f
     const float dx = px - P.x, dy = py - P.y;
     m0 = P.z * dx + P.w * dy;
     m1 = P.w * dx + Q.x * dy;
-    e = -0.5f * (dx * m0 + dy * m1);
-    return __builtin_amdgcn_exp2f(e * GS_LOG2E) * Q.y;
+    const float s = dx * m0 + dy * m1;
+    e = -0.5f * s;
+    return __builtin_amdgcn_exp2f(s * (-0.5f * GS_LOG2E)) * Q.y;   // (= (-0.5 s) * log2 e to the last bit, see the pair form)
 }
 // the bracket around the 1/255 skip threshold (gs_common.h): below EPS_LO / from EPS_HI on, the kernels' alpha decides as the
 // reference's does
@@ -853,15 +858,16 @@ __global__ __launch_bounds__(BLEND_THREADS, GS_BWD_MIN_WAVES) void blend_backwar
             // (A) the 1/255 decisions of the whole group (RAS:631): lower edge of the bracket; an entry with an alpha inside the
             // bracket is noted and settled before any entry is processed -- between the evaluation and the hit path, where
             // few registers are live
-            bool a0[GROUP_BWD], a1[GROUP_BWD];
+            // (the decisions are kept as lane MASKS in scalar registers -- gs_ballot / inverse_ballot: as bools they went through
+            // the vector unit and back, four instructions per entry)
+            unsigned long long ma0[GROUP_BWD], ma1[GROUP_BWD];
             unsigned bracketed = 0u;   // wave-uniform: bit i = entry k + i has an alpha inside the bracket
             GS_STAT(GS_STAT_BWD_ENTRIES, GROUP_BWD);
 #pragma unroll
             for (int i = 0; i < GROUP_BWD; ++i) {
-                a0[i] = alpha[i].x >= EPS_LO; a1[i] = alpha[i].y >= EPS_LO;
-                const unsigned long long ma0 = gs_ballot(a0[i]), ma1 = gs_ballot(a1[i]);
-                if ((ma0 | ma1) != 0ull &&
-                    ((ma0 ^ gs_ballot(alpha[i].x >= EPS_HI)) | (ma1 ^ gs_ballot(alpha[i].y >= EPS_HI))) != 0ull)
+                ma0[i] = gs_ballot(alpha[i].x >= EPS_LO); ma1[i] = gs_ballot(alpha[i].y >= EPS_LO);
+                if ((ma0[i] | ma1[i]) != 0ull &&
+                    ((ma0[i] ^ gs_ballot(alpha[i].x >= EPS_HI)) | (ma1[i] ^ gs_ballot(alpha[i].y >= EPS_HI))) != 0ull)
                     bracketed |= 1u << i;
             }
             if (bracketed != 0u) {
@@ -887,23 +893,23 @@ __global__ __launch_bounds__(BLEND_THREADS, GS_BWD_MIN_WAVES) void blend_backwar
                             if (c ? in1 : in0) { if (c) r1 = exact >= EPS_ALPHA; else r0 = exact >= EPS_ALPHA; }
                         }
                     }
+                    const unsigned long long mr0 = gs_ballot(r0), mr1 = gs_ballot(r1);
 #pragma unroll
                     for (int i = 0; i < GROUP_BWD; ++i)
-                        if (i == ii) { a0[i] = r0; a1[i] = r1; }
+                        if (i == ii) { ma0[i] = mr0; ma1[i] = mr1; }
                 }
             }
             // (B) the hit path, entry by entry
 #pragma unroll
             for (int i = 0; i < GROUP_BWD; ++i) {
-                const unsigned long long ma0 = gs_ballot(a0[i]), ma1 = gs_ballot(a1[i]);
-                if ((ma0 | ma1) == 0ull) continue;  // wave-uniform skip: no pixel of this wave is touched
+                if ((ma0[i] | ma1[i]) == 0ull) continue;  // wave-uniform skip: no pixel of this wave is touched
                 const int jj = jg[i];
-                const bool l0 = jj < last0, l1 = jj < last1;                            // RAS:618 (effective range)
-                const bool hit0 = a0[i] && l0, hit1 = a1[i] && l1;
-                if (((ma0 & gs_ballot(l0)) | (ma1 & gs_ballot(l1))) == 0ull) continue;
+                // RAS:618 (effective range)
+                const unsigned long long mh0 = ma0[i] & gs_ballot(jj < last0), mh1 = ma1[i] & gs_ballot(jj < last1);
+                if ((mh0 | mh1) == 0ull) continue;
+                const bool hit0 = __builtin_amdgcn_inverse_ballot_w64(mh0), hit1 = __builtin_amdgcn_inverse_ballot_w64(mh1);
 #if GS_STATS
                 {
-                    const unsigned long long mh0 = gs_ballot(hit0), mh1 = gs_ballot(hit1);
                     GS_STAT(GS_STAT_BWD_HIT_ENTRIES, 1);
                     GS_STAT(GS_STAT_BWD_HIT_PIXELS, __popcll(mh0) + __popcll(mh1));
                     GS_STAT(GS_STAT_BWD_HIT_LANES, __popcll(mh0 | mh1));
@@ -1365,13 +1371,12 @@ __global__ __launch_bounds__(SMALL_THREADS) void blend_backward_small_kernel(
             }
             // (A) the group's 1/255 decisions, (then) the bracketed ones settled by the reference's backward expression, (B) the
             // hit path: the one-pixel form of blend_backward_kernel's loop, see there
-            bool a0[GROUP_BWD];
+            unsigned long long ma[GROUP_BWD];   // (lane masks, as in blend_backward_kernel)
             unsigned bracketed = 0u;
 #pragma unroll
             for (int i = 0; i < GROUP_BWD; ++i) {
-                a0[i] = alpha[i] >= EPS_LO;                              // RAS:631 (lower edge of the bracket)
-                const unsigned long long ma = gs_ballot(a0[i]);
-                if (ma != 0ull && (ma ^ gs_ballot(alpha[i] >= EPS_HI)) != 0ull) bracketed |= 1u << i;
+                ma[i] = gs_ballot(alpha[i] >= EPS_LO);                   // RAS:631 (lower edge of the bracket)
+                if (ma[i] != 0ull && (ma[i] ^ gs_ballot(alpha[i] >= EPS_HI)) != 0ull) bracketed |= 1u << i;
             }
             if (bracketed != 0u) {
 #pragma clang loop unroll(disable)
@@ -1387,19 +1392,19 @@ __global__ __launch_bounds__(SMALL_THREADS) void blend_backward_small_kernel(
                         const float exact = gs_alpha_reference(ex, Q.w, s_c[e].w);
                         if (in) r0 = exact >= EPS_ALPHA;
                     }
+                    const unsigned long long mr = gs_ballot(r0);
 #pragma unroll
                     for (int i = 0; i < GROUP_BWD; ++i)
-                        if (i == ii) a0[i] = r0;
+                        if (i == ii) ma[i] = mr;
                 }
             }
 #pragma unroll
             for (int i = 0; i < GROUP_BWD; ++i) {
-                const unsigned long long ma = gs_ballot(a0[i]);
-                if (ma == 0ull) continue;
+                if (ma[i] == 0ull) continue;
                 const int jj = batch_first - (k + i);
-                const bool l0 = jj < last;                               // RAS:618 (effective range)
-                const bool hit = a0[i] && l0;
-                if ((ma & gs_ballot(l0)) == 0ull) continue;
+                const unsigned long long mh = ma[i] & gs_ballot(jj < last);   // RAS:618 (effective range)
+                if (mh == 0ull) continue;
+                const bool hit = __builtin_amdgcn_inverse_ballot_w64(mh);
                 const float h = hit ? 1.f : 0.f;
                 const float al = hit ? __builtin_amdgcn_fmed3f(alpha[i], 0.f, CLAMP_ALPHA) : 0.f;
                 const float inv1m = __builtin_amdgcn_rcpf(1.f - al);
