@@ -514,6 +514,13 @@ typedef struct GsFrame {
     const int32_t *band_row_bounds;
 } GsFrame;
 size_t gs_frame_struct_bytes(void);   /* sizeof(GsFrame): a binding checks its mirror of the struct against it */
+/* ... and the byte offsets of GS_FRAME_SENTINELS members spread over the struct, in this order:
+ *   n_points, blend_flags, near_plane, n_keys_capacity, xyz, q_camera_pointcloud, attrs, keys, bin_ranges, n_bins, image,
+ *   tile_order, boundary_states, route_counts, list_start, grad_image, acc, grad_xyz, aux_stream, band_row_bounds
+ * (a mirror built from another header -- two members swapped, a stale library of the same size -- passes the size check
+ * and would make the stages read wrong pointers).  Writes min(n, GS_FRAME_SENTINELS) offsets, returns GS_FRAME_SENTINELS. */
+#define GS_FRAME_SENTINELS 20
+int gs_frame_layout(int32_t *offsets, int n);
 int gs_frame_forward(GsFrame *frame, uint32_t stages, void *stream);
 int gs_frame_backward(GsFrame *frame, uint32_t stages, void *stream);
 

@@ -17,7 +17,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # GS_LIB_PATH: development knob (tuning sweeps load differently built variants of the library); default = in-tree build
 LIB_PATH = os.environ.get("GS_LIB_PATH") or os.path.join(_HERE, "libgsplat_hip.so")
-ABI_VERSION = 31
+ABI_VERSION = 32
 
 _c = ctypes
 _P = _c.c_void_p
@@ -48,6 +48,7 @@ _SIGNATURES = {
     "gs_tile_ranges": (_I, [_P, _I64, _P, _I, _P, _P, _I, _P]),
     "gs_tile_ranges_prezeroed": (_I, [_P, _I64, _P, _I, _P, _P, _I, _I, _P]),
     "gs_frame_struct_bytes": (_c.c_size_t, []),
+    "gs_frame_layout": (_I, [_P, _I]),
     "gs_frame_forward": (_I, [_P, _c.c_uint32, _P]),
     "gs_frame_backward": (_I, [_P, _c.c_uint32, _P]),
     "gs_read_counters_async": (_I, [_P, _P, _I, _P]),
@@ -120,6 +121,12 @@ def _frame_fields_from_header():
 _FRAME_FIELDS, STAGES = _frame_fields_from_header()
 
 
+# members whose offsets the library reports (gs_frame_layout, same order as in the header's comment)
+FRAME_SENTINELS = ("n_points", "blend_flags", "near_plane", "n_keys_capacity", "xyz", "q_camera_pointcloud", "attrs", "keys",
+                   "bin_ranges", "n_bins", "image", "tile_order", "boundary_states", "route_counts", "list_start", "grad_image",
+                   "acc", "grad_xyz", "aux_stream", "band_row_bounds")
+
+
 class GsFrame(ctypes.Structure):
     """Mirror of ``GsFrame`` (include/gsplat_hip.h): pointers as integers (``tensor.data_ptr()``), 0 / None = NULL."""
     _fields_ = _FRAME_FIELDS
@@ -149,6 +156,14 @@ def load() -> ctypes.CDLL:
         if lib.gs_frame_struct_bytes() != ctypes.sizeof(GsFrame):
             raise RuntimeError(f"GsFrame: the library's struct has {lib.gs_frame_struct_bytes()} bytes, the Python mirror "
                                f"{ctypes.sizeof(GsFrame)} (include/gsplat_hip.h and the built library disagree)")
+        # ... and where it keeps a score of members spread over the struct (the size alone passes two swapped pointers)
+        n = lib.gs_frame_layout(None, 0)
+        theirs = (ctypes.c_int32 * n)()
+        lib.gs_frame_layout(theirs, n)
+        ours = [getattr(GsFrame, name).offset for name in FRAME_SENTINELS]
+        if n != len(FRAME_SENTINELS) or list(theirs) != ours:
+            raise RuntimeError(f"GsFrame: member offsets differ between the library {list(theirs)} and the Python mirror {ours} "
+                               "(include/gsplat_hip.h and the built library disagree)")
         _lib = lib
     return _lib
 

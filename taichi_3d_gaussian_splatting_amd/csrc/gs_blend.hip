@@ -1492,6 +1492,10 @@ __global__ __launch_bounds__(SMALL_THREADS) void blend_backward_small_kernel(
     }
     __syncthreads();
     if (s_max[0]) {
+        // (the last workgroup to arrive: an acquire fence at agent scope -- only here, once per tile -- orders the loads below
+        // behind the arrival it has just observed; the other segments' stores were written through and drained before
+        // their own arrival)
+        __atomic_thread_fence(__ATOMIC_ACQUIRE);
         float su = 0.f, sv = 0.f;
         for (int q = 0; q < split; ++q) {   // segment order: the same sum on every run
             const u64 m = __hip_atomic_load(&parts[(size_t)q * n_pixels + p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

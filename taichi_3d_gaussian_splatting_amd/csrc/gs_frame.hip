@@ -4,6 +4,20 @@
 #include "gs_common.h"
 #include <stdlib.h>
 
+#include <stddef.h>
+
+extern "C" int gs_frame_layout(int32_t *offsets, int n) {
+    const size_t at[GS_FRAME_SENTINELS] = {
+        offsetof(GsFrame, n_points), offsetof(GsFrame, blend_flags), offsetof(GsFrame, near_plane),
+        offsetof(GsFrame, n_keys_capacity), offsetof(GsFrame, xyz), offsetof(GsFrame, q_camera_pointcloud),
+        offsetof(GsFrame, attrs), offsetof(GsFrame, keys), offsetof(GsFrame, bin_ranges), offsetof(GsFrame, n_bins),
+        offsetof(GsFrame, image), offsetof(GsFrame, tile_order), offsetof(GsFrame, boundary_states),
+        offsetof(GsFrame, route_counts), offsetof(GsFrame, list_start), offsetof(GsFrame, grad_image), offsetof(GsFrame, acc),
+        offsetof(GsFrame, grad_xyz), offsetof(GsFrame, aux_stream), offsetof(GsFrame, band_row_bounds)};
+    for (int i = 0; i < n && i < GS_FRAME_SENTINELS; ++i) offsets[i] = (int32_t)at[i];
+    return GS_FRAME_SENTINELS;
+}
+
 #define GS_STAGE(call)            \
     do {                          \
         const int _rc = (call);   \

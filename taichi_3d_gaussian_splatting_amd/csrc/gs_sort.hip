@@ -239,6 +239,9 @@ __global__ __launch_bounds__(LS_THREADS) void sort_local_kernel(uint32_t *__rest
                                                                 int part_shift, int part_bits, int key_depth_bits,
                                                                 int n_tiles, int32_t *__restrict__ tile_start,
                                                                 int32_t *__restrict__ tile_end) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "sort_local_kernel keeps a whole bucket in the 160 KB of LDS a gfx950 workgroup can have: this library is written for gfx950 (CDNA4) only"
+#endif
     __shared__ uint32_t s_keys[LS_CAP];                 // (gfx950: 160 KB of LDS per workgroup)
     __shared__ int32_t s_pay[LS_CAP];
     __shared__ int s_cnt[LS_WAVES][LS_MAX_RADIX];       // running per-wave digit counts, then exclusive prefixes over waves
@@ -339,9 +342,11 @@ __global__ __launch_bounds__(LS_THREADS) void sort_local_kernel(uint32_t *__rest
                     // their per-lane 64-bit selects cost ~45 VALU instructions per round here and made this kernel
                     // VALU-bound: 2,575 -> see profiles/r04_sort.md.)
                     if (valid) __hip_atomic_fetch_or(&s_reg[w][d], 1ull << lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    __builtin_amdgcn_wave_barrier();   // (no instruction: keeps the compiler from moving the read above the ORs)
                     const unsigned long long peers = valid ? LS_REG(d) : 0ull;
                     const int rank = gs_mbcnt(peers);
                     const int before = valid ? LS_CNT(d) : 0;                       // every lane of a group reads ...
+                    __builtin_amdgcn_wave_barrier();   // (... and the leader's clear below the reads)
                     if (valid && rank == 0) {
                         LS_CNT(d) = before + __popcll(peers);   // ... before its leader bumps the counter
                         LS_REG(d) = 0ull;                       // ... and clears the word for the next round
@@ -523,7 +528,7 @@ extern "C" {
 
 size_t gs_sort_workspace_bytes(int64_t n_keys) {
     const size_t nblk = (size_t)gs_div_up(n_keys > 0 ? n_keys : 1, GS_BLOCK * sort_rounds_for(n_keys));
-    return sizeof(int32_t) * (((size_t)nblk << MSD_MAX_BITS) + (1 << MSD_MAX_BITS) + 64);   // (1,024 digit rows at most)
+    return sizeof(int32_t) * (((size_t)nblk << MSD_MAX_BITS) + (1 << MSD_MAX_BITS) + 64);   // (2^MSD_MAX_BITS = 512 digit rows at most)
 }
 
 int gs_sort_pairs(void *keys, int32_t *payload, void *keys_alt, int32_t *payload_alt, int64_t n_keys,

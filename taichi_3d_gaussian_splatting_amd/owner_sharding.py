@@ -569,17 +569,25 @@ class OwnerShardedRasterisation(torch.nn.Module):
                         outer._sizes_host.copy_(sizes, non_blocking=True)
                         outer._sizes_event.record(torch.cuda.current_stream(mine.device))
                         capacity = outer._capacity_guess
+                        # (what blend() learns from a frame -- size guesses, the automatic bin shift, its counters -- is set
+                        # aside: a frame whose exchange turns out truncated is blended again below, and must not leave the
+                        # truncated frame's sizes behind nor be counted twice)
+                        learnt = (dict(core._size_guesses), core._auto_bin_shift, dict(core.speculation_stats))
                         send = core.pack(f, capacity, -1)
                         received = _all_to_all_chunks(send, outer.group)
                         image, depth, count = core.blend(f, received, need_state)   # (ends waiting for the band's sizes)
                         outer._sizes_event.synchronize()
                         host = outer._sizes_host.clone()
+                        f.n_visible = int(host[outer.rank, outer.world])   # (known from here on, whatever follows)
                     else:
                         host = sizes.cpu()
                     needed = int(host[:, :outer.world].max())
                     outer.capacity_stats["frames"] += 1
                     if not speculate or needed > capacity:   # first frame, or the records outgrew the speculated chunks
                         outer.capacity_stats["redone"] += 1 if speculate else 0
+                        if speculate:
+                            core._size_guesses, core._auto_bin_shift = learnt[0], learnt[1]
+                            core.speculation_stats.update(learnt[2])
                         capacity = _chunk_capacity(needed)
                         send = core.pack(f, capacity, int(host[outer.rank, outer.world]))
                         received = _all_to_all_chunks(send, outer.group)
