@@ -85,9 +85,8 @@ __device__ unsigned long long gs_blend_stats_dev[GS_BLEND_STATS];
 #define GS_STAT(i, n) do { } while (0)
 #endif
 #ifndef GS_FWD_MIN_WAVES
-#define GS_FWD_MIN_WAVES 7   // second argument of __launch_bounds__ of the forward kernel: seven waves per SIMD = 72 registers, which
-                             // the allocator meets without scratch once asked (left alone it takes 79: six waves, forward
-                             // 0.278 -> 0.269 ms at the headline size)
+#define GS_FWD_MIN_WAVES 6   // second argument of __launch_bounds__ of the forward kernel: six waves per SIMD (80 registers).  Seven
+                             // (72 registers) is met only with 24-32 B of scratch for no gain (0.272 vs 0.270 ms at the headline size)
 #endif
 constexpr int GROUP = GS_GROUP_FWD > GS_GROUP_BWD ? (GS_GROUP_FWD > 4 ? GS_GROUP_FWD : 4) : (GS_GROUP_BWD > 4 ? GS_GROUP_BWD : 4);
                               // padding granularity of a staged batch (BATCH % GROUP == 0; covers both group sizes)

@@ -100,7 +100,9 @@ __device__ __forceinline__ float gs_exp_cr(float xf) {
 //                  amp = fl(opacity * rescale) u;  exp * amp u                                  -> 2 u |e| + 6 u
 //       reference: exp correctly rounded u;  * rescale u (UTL:284);  * opacity u (RAS:447)       -> 3 u
 //     |ln alpha_kernel - ln alpha_reference| <= u (2 |e| + 9), |e| = ln(amp / alpha) <= ln(1 / alpha) (amp <= 1), and a third on
-//     top (GS_BAND_SAFETY).  At the 1/255 threshold |e| < 5.6: GS_ALPHA_BAND = 4/3 * 20.2 u = 1.6e-6.
+//     top (GS_BAND_SAFETY).  At the 1/255 threshold |e| < 5.6 for every positive-definite conic; the band is cut for
+//     |e| <= 20 (a conic that rounding has left indefinite can reach the threshold from a positive exponent):
+//     GS_ALPHA_BAND = 4/3 * 49 u = 3.9e-6.
 //  3. A comparison whose operand lies inside the bracket [threshold (1 - band), threshold / (1 - band)) is settled by the
 //     reference's own expression: exp(e) correctly rounded (gs_exp_cr: the definition the oracle and the committed
 //     reference-run vectors use), times rescale, times opacity -- wave-uniform rare paths, kept OUT of the hot loops.
@@ -116,7 +118,7 @@ __device__ __forceinline__ float gs_exp_cr(float xf) {
 //     the reference's arithmetic (gs_reference_stops_at, gs_blend.hip).
 #define GS_U24 5.9604644775390625e-8f
 #define GS_BAND_SAFETY (4.0f / 3.0f)
-#define GS_ALPHA_BAND (GS_BAND_SAFETY * GS_U24 * (2.0f * 5.6f + 9.0f))
+#define GS_ALPHA_BAND (GS_BAND_SAFETY * GS_U24 * (2.0f * 20.0f + 9.0f))
 #define GS_STOP_ROUNDING_BAND (4.0f * GS_U24)   /* per blended Gaussian */
 __device__ __forceinline__ float gs_stop_weight(float amp, float stop_t) {
     const float H = 1.0f / (1.0f - fminf(amp, 0.99f)) * 1.01f;

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Everything the round's documents quote, in one gpurun call (see profiles/README.md).  usage: tools/round_report.sh <tag>
 set -u
-TAG=${1:-r04}
+TAG=${1:-r05}
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out/report_$TAG
 mkdir -p $OUT
@@ -11,6 +11,13 @@ timeout 1500 python -m pytest tests -m gpu -q -s > $OUT/pytest.log 2>&1
 grep -E "passed|failed|\[record\]" $OUT/pytest.log | tail -5
 # 1. rocprofv3: kernel trace + HBM counters + SQ counters over the bench command
 bash tools/profile.sh $TAG > $OUT/profile.log 2>&1
+# 1b. path statistics of the blend kernels (a counting build of the library: how often the hit path runs, live lanes, how
+#     often a decision is settled by the reference's own expression) at the headline size and on the trained scene
+bash tools/build_variants.sh "stats:-DGS_STATS=1" > $OUT/build_stats.log 2>&1
+GS_LIB_PATH=variants/libgsplat_hip_stats.so python tools/blend_stats.py headline_1m_1080p > $OUT/blend_path_stats.json 2> $OUT/blend_stats.err
+for w in cfg3_400k_1080p cfg4_2m_1080p trained_1080p; do
+    GS_LIB_PATH=variants/libgsplat_hip_stats.so python tools/blend_stats.py $w 2>> $OUT/blend_stats.err >> $OUT/blend_path_stats_other_workloads.jsonl
+done
 # 2. bench lines of every workload (driver contract line first)
 : > $OUT/bench_all_configs.jsonl
 python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err
