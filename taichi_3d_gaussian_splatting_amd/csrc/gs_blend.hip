@@ -143,7 +143,9 @@ __device__ __forceinline__ unsigned long long gs_ballot(bool p) { return __built
 constexpr float GS_LOG2E = 1.4426950408889634f;
 
 // What a staged list entry leaves in LDS for the group loops (two 16-B broadcast reads per entry and wave):
-//   P = (u, v, A, B)   Q = (C, amp, ., .)      amp = opacity * rescale, formed by gs_preprocess (float 12 of the record)
+//   P = (u, v, A, C)   Q = (B, amp, ., .)      amp = opacity * rescale, formed by gs_preprocess (float 12 of the record)
+//   (C, which the packed arithmetic only ever uses as a per-lane scalar, sits in the one position -- the upper half of the
+//   second register pair -- from which the compiler will not broadcast without a v_mov)
 //   forward:  Q.z = camera depth;  colour row (r, g, b, W), W = the Gaussian's stop-bracket weight (gs_stop_weight, float 13)
 //   backward: Q.z = radius, Q.w = rescale;  colour row (r, g, b, opacity)
 // THE EXPONENT IS THE REFERENCE'S TO THE LAST BIT (gs_common.h, "threshold decisions"): each pass evaluates the quadratic
@@ -161,16 +163,17 @@ __device__ __forceinline__ v2f gs_weight_from_exponent(v2f e, float amp) {
 __device__ __forceinline__ v2f gs_pair_alpha_forward(const float4 P, const float4 Q, const v2f px, const float py, v2f &e) {
     const v2f dx = px - splat(P.x);
     const float dy = py - P.y;
-    const v2f t = (dx * dx) * splat(P.z) + splat((dy * dy) * Q.x);
-    e = fma2(splat(-0.5f), t, -((dx * splat(dy)) * splat(P.w)));
+    const v2f t = (dx * dx) * splat(P.z) + splat((dy * dy) * P.w);
+    const v2f x = (dx * splat(dy)) * splat(Q.x);
+    e = fma2(splat(-0.5f), t, -x);
     return gs_weight_from_exponent(e, Q.y);
 }
 __device__ __forceinline__ v2f gs_pair_alpha_backward(const float4 P, const float4 Q, const v2f px, const float py, v2f &e,
                                                       v2f &m0, v2f &m1) {
     const v2f dx = px - splat(P.x);
     const float dy = py - P.y;
-    m0 = splat(P.z) * dx + splat(P.w * dy);
-    m1 = splat(P.w) * dx + splat(Q.x * dy);
+    m0 = splat(P.z) * dx + splat(Q.x * dy);
+    m1 = splat(Q.x) * dx + splat(P.w * dy);
     const v2f s = dx * m0 + splat(dy) * m1;
     e = splat(-0.5f) * s;   // (exact: only the careful path looks at it)
     // 2^(e log2 e) with e log2 e formed as s * (-0.5 log2 e): the same bits as (-0.5 s) * log2 e -- halving is exact -- in one
@@ -184,14 +187,14 @@ __device__ __forceinline__ float gs_exponent_forward(float dx, float dy, float A
     return __builtin_fmaf(-0.5f, t, -((dx * dy) * B));
 }
 __device__ __forceinline__ float gs_pixel_alpha_forward(const float4 P, const float4 Q, float px, float py, float &e) {
-    e = gs_exponent_forward(px - P.x, py - P.y, P.z, P.w, Q.x);
+    e = gs_exponent_forward(px - P.x, py - P.y, P.z, Q.x, P.w);
     return __builtin_amdgcn_exp2f(e * GS_LOG2E) * Q.y;
 }
 __device__ __forceinline__ float gs_pixel_alpha_backward(const float4 P, const float4 Q, float px, float py, float &e, float &m0,
                                                          float &m1) {
     const float dx = px - P.x, dy = py - P.y;
-    m0 = P.z * dx + P.w * dy;
-    m1 = P.w * dx + Q.x * dy;
+    m0 = P.z * dx + Q.x * dy;
+    m1 = Q.x * dx + P.w * dy;
     const float s = dx * m0 + dy * m1;
     e = -0.5f * s;
     return __builtin_amdgcn_exp2f(s * (-0.5f * GS_LOG2E)) * Q.y;   // (= (-0.5 s) * log2 e to the last bit, see the pair form)
@@ -202,15 +205,15 @@ constexpr float EPS_LO = EPS_ALPHA * (1.0f - GS_ALPHA_BAND), EPS_HI = EPS_ALPHA 
 // rows of a record as the forward / backward group loops want them (see above)
 __device__ __forceinline__ void gs_stage_forward(const float4 r0, const float4 r1, const float4 r2, const float4 r3, float4 &P,
                                                  float4 &Q, float4 &colour, float2 &rescale_opacity) {
-    P = make_float4(r0.x, r0.y, r1.x, r1.y);
-    Q = make_float4(r1.z, r3.x, r0.z, 0.f);
+    P = make_float4(r0.x, r0.y, r1.x, r1.z);
+    Q = make_float4(r1.y, r3.x, r0.z, 0.f);
     colour = make_float4(r2.x, r2.y, r2.z, r3.y);
     rescale_opacity = make_float2(r3.w, r2.w);
 }
 __device__ __forceinline__ void gs_stage_backward(const float4 r0, const float4 r1, const float4 r2, const float4 r3, float4 &P,
                                                   float4 &Q, float4 &colour) {
-    P = make_float4(r0.x, r0.y, r1.x, r1.y);
-    Q = make_float4(r1.z, r3.x, r1.w, r3.w);
+    P = make_float4(r0.x, r0.y, r1.x, r1.z);
+    Q = make_float4(r1.y, r3.x, r1.w, r3.w);
     colour = r2;
 }
 // The pixel's bracket around T' = 1e-4 from thr (its upper edge as the group loop keeps it: per-Gaussian weights + 4 u per

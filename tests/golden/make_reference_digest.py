@@ -24,6 +24,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, HERE)
+os.environ.setdefault("GS_EMU_EXP", "cr")   # one definition of exp on every side: correctly rounded (tests/golden/README.md)
 import taichi_emulation as E  # noqa: E402
 from make_reference_operator_vectors import STABLE_SORT_PATCH  # noqa: E402
 from taichi_3d_gaussian_splatting_amd.synthetic import make_config_scene, make_grad_image  # noqa: E402

@@ -22,6 +22,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, HERE)
+os.environ.setdefault("GS_EMU_EXP", "cr")   # one definition of exp on every side: correctly rounded (tests/golden/README.md)
 import taichi_emulation as E  # noqa: E402
 from taichi_3d_gaussian_splatting_amd.synthetic import make_grad_image, make_scene  # noqa: E402
 
