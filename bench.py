@@ -56,7 +56,7 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 # VALU issue ceiling: 256 CUs x 4 SIMD-32, one wave64 fp32 instruction per 2 cycles per SIMD at 2.4 GHz
 VALU_PEAK_WAVE_INSTR_PER_S = 256 * 4 * 2.4e9 / 2.0
-PROFILE_TAG = "r04"
+PROFILE_TAG = "r05"
 
 
 def algorithmic_bytes(n, m, k, p, key_bytes=8, k_tile=None):
