@@ -15,29 +15,27 @@ import torch
 
 from oracle import gs_oracle as O
 from taichi_3d_gaussian_splatting_amd.synthetic import SyntheticScene
-from tests.helpers import FRAGILE_MARGIN, oracle_forward, rel_l2, report
+from tests.helpers import oracle_forward, rel_l2, report
 
 pytestmark = pytest.mark.gpu
 
 CASES = int(os.environ.get("GS_FUZZ_CASES", "24"))
 FIRST = int(os.environ.get("GS_FUZZ_FIRST", "0"))
 
-# Bars.  Observed (round 3, one MI355X; every case prints its distances as a [parity] line) over 600 draws with the large
-# cases at 1,296-2,304 tiles and 240 more with them at 3,844-5,184 tiles (36 such): ordinary scenes -- pixel 3.8e-6, depth
-# 1.4e-5, grad_xyz 6.5e-5, grad_feat 3.8e-5, one flipped pixel in one draw; ill-conditioned scenes (needles or close-ups),
-# against the fp32 oracle -- pixel 4.6e-4, depth 2.4e-3, gradients 2.3e-4 / 5.5e-4, every one within SPEC_FACTOR x the fp32
-# oracle's own distance to the f64 spec; sharded vs un-sharded gradients 4.2e-5.
-PIXEL_TOL = 1e-4            # north star, non-fragile pixels
-FRAGILE_PIXEL_BOUND = 1e-2  # one skipped / added Gaussian on a pixel whose decision sits on a threshold
-GRAD_TOL = 1e-4             # rel-L2 of the dense gradients, upstream gradient zeroed on the fragile pixels
+# Bars.  Observed (round 5, one MI355X; every case prints its distances as a [parity] line) over 540 fresh draws (seeds
+# 8000-8239 and 9000-9299; 242 of them needle scenes or close-ups, 44+ with grids above 3,844 tiles): the count image equal
+# to the fp32 oracle's on every pixel of every draw; image 4.2e-7 and depth 1.9e-6 over ALL pixels; gradients (rel-L2 vs the
+# fp32 oracle) 2.8e-5 / 2.1e-5 on ordinary scenes, 4.1e-5 / 5.8e-5 on ill-conditioned ones.  (Round 3, before the decisions
+# were exact: one flipped pixel per ~600 draws, ill-conditioned scenes 4.6e-4 / 2.4e-3 / 5.5e-4 from the fp32 oracle.)
+# Sharded vs un-sharded gradients 4.2e-5.
+PIXEL_TOL = 1e-4            # north star, every pixel (observed round 5: 4.2e-7 over 240 draws)
+GRAD_TOL = 1e-4             # rel-L2 of the dense gradients (ordinary scenes: upstream gradient on every pixel)
 DEPTH_TOL = 2e-4            # depth image (alpha-weighted depths, values 1..10)
 NEEDLE_MARGIN = 4e-5        # needle scenes: decisions this close to a threshold differ between fp32 and f64 oracles
 SPEC_FACTOR = 4.0           # ill-conditioned scenes: operator-to-f64 distance <= 4 x the fp32 oracle's own.  (Two fp32 evaluations
                             # in different association orders: on a 6,000-Gaussian scene the ratio is 0.9-1.2,
                             # test_needles_against_the_f64_spec holds 2; on a 200-Gaussian draw one row decides it: seen 3.1)
 SHARD_GRAD_TOL = 2e-4       # sharded vs un-sharded gradients: the same terms added per rank first (observed <= 4.2e-5 over 420 draws)
-FLIP_MARGIN = 1e-5          # ordinary scenes: a pixel this close to a threshold may still flip when the quadratic form of a
-MAX_FLIPS = 2               # Gaussian seen from very close cancels (seen: margin 1.3e-7, 1 pixel of 462,336): at most two
 
 
 def _quat(axis, angle):
@@ -128,17 +126,19 @@ def test_random_scene_against_the_oracle(case):
     scene, band, needles, opt = random_scene(case)
     f = oracle_forward(scene)
     rng = np.random.default_rng(5_000 + case)
-    # Pixels whose blend decisions sit on a threshold may legitimately differ between two correct implementations: they
-    # are compared with the loose per-pixel bound and get no upstream gradient (a flipped pair is a discrete change).
-    # Needle scenes are ill-conditioned in fp32 (the conic of an aspect-ratio-100 Gaussian loses most of its digits), so
-    # there the yardstick is the float64 build of the oracle: the operator may be as far from it as the fp32 oracle is
-    # (x SPEC_FACTOR), on the pixels where both oracle precisions take the same decisions with NEEDLE_MARGIN to spare.
+    # Blend decisions (skip below 1/255, stop below 1e-4) are taken as the fp32 reference takes them on EVERY pixel
+    # (csrc/gs_common.h "threshold decisions"): the count image is compared bit for bit and the image / depth bounds hold on
+    # all pixels, with the upstream gradient on all of them too.
+    # Needle scenes are ill-conditioned in fp32 (the conic of an aspect-ratio-100 Gaussian loses most of its digits): the
+    # decisions still match the fp32 oracle, but for the GRADIENTS the yardstick is the float64 build of the oracle -- the
+    # operator may be as far from it as the fp32 oracle is (x SPEC_FACTOR), with the upstream gradient on the pixels where
+    # both oracle precisions take the same decisions with NEEDLE_MARGIN to spare.
     needles = needles or scene.near_plane < 0.5   # close-ups: Gaussians magnified a hundredfold are needles on the screen
     spec = oracle_forward(scene, precision="f64") if needles else None
     if needles:
         keep = (f["count"] == spec["count"]) & (f["margin"] >= NEEDLE_MARGIN) & (spec["margin"] >= NEEDLE_MARGIN)
     else:
-        keep = f["margin"] >= FRAGILE_MARGIN
+        keep = np.ones_like(f["count"], dtype=bool)
     g = (rng.random((scene.height, scene.width, 3)) * 2 - 1).astype(np.float32) * keep[:, :, None]
     ob = O.backward(f, g, band)
     ob64 = O.backward(spec, g.astype(np.float64), band) if needles else None
@@ -183,32 +183,21 @@ def test_random_scene_against_the_oracle(case):
         tag = f"case {case} frame {frame} ({scene.width}x{scene.height}, n={xyz.shape[0]}, M={len(f['ids'])}, band {band}, " \
               f"needles={needles}, {opt})"
         img, dep = image.detach().cpu().numpy(), depth.detach().cpu().numpy()
-        tight = keep
-        if not needles:   # explainable flips: a few pixels within FLIP_MARGIN of a threshold (bounded like the fragile ones)
-            flipped = keep & (count.cpu().numpy() != f["count"]) & (f["margin"] < FLIP_MARGIN)
-            assert int(flipped.sum()) <= MAX_FLIPS, tag
-            worst["flips"] = max(worst.get("flips", 0.0), float(flipped.sum()))
-            tight = keep & ~flipped
-        if tight.any():
-            held("pixel", img[tight], f["image"][tight], spec["image"][tight] if needles else None, PIXEL_TOL, tag, linf)
-            held("depth", dep[tight], f["depth"][tight], spec["depth"][tight] if needles else None, DEPTH_TOL, tag, linf)
-            assert np.array_equal(count.cpu().numpy()[tight], f["count"][tight]), tag
-        assert linf(img, f["image"]) <= FRAGILE_PIXEL_BOUND, tag
+        cnt = count.cpu().numpy()
+        assert np.array_equal(cnt, f["count"]), f"{tag}: {int((cnt != f['count']).sum())} pixels blend another set than the oracle"
+        worst["pixel_all"] = max(worst.get("pixel_all", 0.0), linf(img, f["image"]))
+        worst["depth_all"] = max(worst.get("depth_all", 0.0), linf(dep, f["depth"]))
+        assert worst["pixel_all"] <= PIXEL_TOL and worst["depth_all"] <= DEPTH_TOL, tag
+        if needles and keep.any():   # and, where fp32 is a meaningful yardstick at all, no further from the spec than the fp32 oracle
+            held("pixel", img[keep], f["image"][keep], spec["image"][keep], PIXEL_TOL, tag, linf)
+            held("depth", dep[keep], f["depth"][keep], spec["depth"][keep], DEPTH_TOL, tag, linf)
         # side effect: visible quaternions normalised in place
         assert np.allclose(feat.detach().cpu().numpy()[:, :4], f["feat"][:, :4], atol=2e-7), tag
         gx, gf = xyz.grad.cpu().numpy(), feat.grad.cpu().numpy()
         assert np.isfinite(gx).all() and np.isfinite(gf).all(), tag
         invisible = np.setdiff1d(np.arange(gx.shape[0]), f["ids"])
         assert not gx[invisible].any() and not gf[invisible].any(), tag
-        # A pixel that flipped above the fragile margin (admitted above) carries its upstream gradient: the two
-        # implementations then differ by a DISCRETE term in the gradients.  Which of them took the better decision is for the
-        # float64 build to say (case 4277: one pixel of a Gaussian 103 pixels in radius -- the fp32 ORACLE is the one that
-        # flipped, 5.1e-4 from the spec, the operator 1.8e-5), so such a draw is held to the yardstick of the
-        # ill-conditioned scenes: as close to the spec as the fp32 oracle is.
         ref64 = ob64
-        if not needles and worst.get("flips", 0.0) > 0:
-            spec_ = oracle_forward(scene, precision="f64")
-            ref64 = O.backward(spec_, g.astype(np.float64), band)
         for name, hip in (("grad_xyz", gx), ("grad_feat", gf)):
             if np.abs(ob[name]).max() > 0:
                 held(name, hip, ob[name], ref64[name] if ref64 is not None else None, GRAD_TOL, tag, rel_l2)
@@ -219,7 +208,7 @@ def test_random_scene_against_the_oracle(case):
             assert np.array_equal(h.point_depth.cpu().numpy(), ho["point_depth"]), tag
             assert np.array_equal(h.point_uv_in_camera.cpu().numpy(), ho["point_uv_in_camera"]), tag
             npix = h.num_affected_pixels.cpu().numpy()
-            assert int(np.abs(npix - ho["num_affected_pixels"]).sum()) <= int((~keep).sum()), tag
+            assert np.array_equal(npix, ho["num_affected_pixels"]), tag
     # inference paths: no backward state (torch.no_grad), and rgb_only -- the same image, bit for bit
     # (fresh copies of the features: the in-place normalisation of an already normalised quaternion may move its last bit)
     inp.point_cloud_features = s.point_cloud_features.clone()
