@@ -163,6 +163,21 @@ int gs_scan_block_sums2(int32_t *block_sums, int32_t *block_sums_full, int n_blo
 int gs_scan_block_sums2_to_host(int32_t *block_sums, int32_t *block_sums_full, int n_blocks, int32_t *counters,
                                 int32_t *host_counters_mapped, void *stream);
 
+/* The same without the event: every size travels as ONE 64-bit word {stamp << 32 | value} stored with a system-scope
+ * store -- host_words[GS_COUNTER_NUM_VISIBLE .. GS_COUNTER_MAX_DEPTH_KEY], uint64[4] -- so the host needs no completion
+ * signal: it reads the four words until each carries the stamp it handed out for this frame (gs_wait_stamped_sizes).
+ * Recording an event behind the scan costs the stream ~6 us per frame (the next kernel waits for the signal packet);
+ * a word is valid or not on its own, so no ordering between the stores is needed.  host_words: host-coherent pinned
+ * memory (gs_host_alloc_coherent), 8-byte aligned; stamp != 0 and different from the previous frame's. */
+int gs_scan_block_sums2_stamped(int32_t *block_sums, int32_t *block_sums_full, int n_blocks, int32_t *counters,
+                                void *host_words, uint32_t stamp, void *stream);
+/* Host side of the above: spins (the calling thread only; no HIP call) until the four words carry `stamp`, then
+ * sizes4 = {M, K, slots, max depth key}.  Returns 0, or 1 when timeout_us passed first (nothing written). */
+int gs_wait_stamped_sizes(const void *host_words, uint32_t stamp, int64_t timeout_us, int32_t *sizes4);
+/* Pinned host memory that is coherent with the device while kernels run (hipHostMallocCoherent | Mapped). */
+int gs_host_alloc_coherent(int64_t bytes, void **out);
+int gs_host_free(void *p);
+
 /* Sort-key generation.  Replaces generate_point_sort_key_by_num_overlap_tiles (RAS:131-172).
  * payload[k] = offset into the visible list.  Key layout:
  *   key_depth_bits == 0 : uint64 keys[k] = (bin_id << 32) + int32(z * depth_scale)   (reference layout; with
@@ -451,7 +466,8 @@ int gs_point_backward(const float *xyz, const float *features, const int32_t *ob
  * stage-by-stage calls.  Sizes that live on the device (M, K) are taken from `counters` exactly as the stage functions do
  * (n_visible_on_device, n_keys_device): the caller sizes the key buffers (n_keys_capacity) and the key layout
  * (key_depth_bits / depth_bits / tile_bits) from the previous frame, reads host_counters_pinned after `size_event`
- * (recorded right behind the asynchronous copy of the counters) and redoes the list stages when the frame did not fit. */
+ * (recorded right behind the asynchronous copy of the counters; or, with size_stamp, once the stamped words have arrived:
+ * gs_wait_stamped_sizes) and redoes the list stages when the frame did not fit. */
 #define GS_FWD_POSE_INVERSE   (1u << 0)   /* gs_pose_inverse                    UTL:426-432                     */
 #define GS_FWD_FILTER_COMPACT (1u << 1)   /* gs_filter_compact                  RAS:31-78, 841-870              */
 #define GS_FWD_PREPROCESS     (1u << 2)   /* gs_preprocess                      RAS:239-315, 106-128            */
@@ -497,7 +513,9 @@ typedef struct GsFrame {
     float *attrs; int32_t *num_overlap_tiles, *num_keys, *block_sums, *block_sums_full;
     void *keys, *keys_alt; int32_t *payload, *payload_alt, *slot_offsets;
     int32_t *bin_ranges;              /* int32[2][number of bins]: start, end (16-byte aligned, bins padded to a multiple of 2) */
-    int32_t n_bins, pad0;
+    int32_t n_bins;
+    int32_t size_stamp;               /* != 0: the sizes travel as stamped words (gs_scan_block_sums2_stamped, host_counters_pinned =
+                                       * the uint64[4] words) and size_event is not recorded; 0: plain int32 counters + the event */
     float *image, *depth, *acc_alpha; int32_t *last_effective, *valid_count;
     int32_t *tile_order, *tile_work, *walked_list, *walked_start;
     float *boundary_states; void *split_workspace;   /* list splitting (may be NULL); list length = n_keys_capacity */

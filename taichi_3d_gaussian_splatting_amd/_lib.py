@@ -17,7 +17,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # GS_LIB_PATH: development knob (tuning sweeps load differently built variants of the library); default = in-tree build
 LIB_PATH = os.environ.get("GS_LIB_PATH") or os.path.join(_HERE, "libgsplat_hip.so")
-ABI_VERSION = 32
+ABI_VERSION = 33
 
 _c = ctypes
 _P = _c.c_void_p
@@ -41,6 +41,10 @@ _SIGNATURES = {
     "gs_scan_block_sums": (_I, [_P, _I, _P, _I, _P]),
     "gs_scan_block_sums2": (_I, [_P, _P, _I, _P, _P]),
     "gs_scan_block_sums2_to_host": (_I, [_P, _P, _I, _P, _P, _P]),
+    "gs_scan_block_sums2_stamped": (_I, [_P, _P, _I, _P, _P, _c.c_uint32, _P]),
+    "gs_wait_stamped_sizes": (_I, [_P, _c.c_uint32, _I64, _P]),
+    "gs_host_alloc_coherent": (_I, [_I64, _P]),
+    "gs_host_free": (_I, [_P]),
     "gs_make_keys": (_I, [_P, _P, _P, _I, _P, _I64, _I, _I, _I, _I, _I, _I, _I, _I, _F, _P, _P, _P, _P, _P, _P]),
     "gs_sort_workspace_bytes": (_c.c_size_t, [_I64]),
     "gs_sort_pairs": (_I, [_P, _P, _P, _P, _I64, _P, _I, _I, _I, _I, _P, _P]),

@@ -13,4 +13,4 @@ void gs_set_error(const char *fmt, ...) {
 }
 
 extern "C" const char *gs_last_error(void) { return g_error; }
-extern "C" int gs_abi_version(void) { return 32; }
+extern "C" int gs_abi_version(void) { return 33; }

@@ -361,9 +361,24 @@ __device__ __forceinline__ void gs_direct_step(const int32_t *__restrict__ paylo
 // all 8,040 tiles took 10-13 us per call, most of it fixed latency of a lone workgroup.)
 constexpr int ORDER_WGS = 8, ORDER_THREADS = 256, ORDER_CLASSES = 1024, ORDER_ITEMS = 4;
 constexpr int ORDER_WAVES = ORDER_THREADS / GS_WAVE, ORDER_CLASSES_PER_THREAD = ORDER_CLASSES / ORDER_THREADS;
+// Workgroups past the eight sorting ones (the backward pass' launch, gs_blend_backward_split) zero `zero_bytes` bytes at
+// `zero`, 16 KB each: the slot flags of the backward pass are cleared beside the sort instead of by a fill launch of their
+// own in front of it (5.4 us per frame at the headline size; the eight sorting workgroups leave 248 CUs idle).
+constexpr int ORDER_ZERO_PER_THREAD = 4;                                              // 16-byte stores per thread
+constexpr int ORDER_ZERO_BYTES_PER_WG = ORDER_THREADS * ORDER_ZERO_PER_THREAD * 16;   // 16 KB
 __global__ __launch_bounds__(ORDER_THREADS) void tile_order_kernel(
     const int32_t *__restrict__ work, const int32_t *__restrict__ bin_start, const int32_t *__restrict__ bin_end, int n,
-    int tw, int row_begin, int row_step, int bin_shift, int32_t *__restrict__ order) {
+    int tw, int row_begin, int row_step, int bin_shift, int32_t *__restrict__ order, uint4 *__restrict__ zero,
+    long long zero_bytes) {
+    if (blockIdx.x >= ORDER_WGS) {
+        const long long first = ((long long)(blockIdx.x - ORDER_WGS) * ORDER_ZERO_BYTES_PER_WG) / 16 + threadIdx.x;
+#pragma unroll
+        for (int k = 0; k < ORDER_ZERO_PER_THREAD; ++k) {
+            const long long q = first + (long long)k * ORDER_THREADS;
+            if (q * 16 < zero_bytes) zero[q] = make_uint4(0u, 0u, 0u, 0u);
+        }
+        return;
+    }
     // one histogram PER WAVE: the tiles of a frame crowd into few classes, and a shared histogram turns every LDS atomic
     // into a many-way same-address conflict
     __shared__ int s_hist[ORDER_WAVES][ORDER_CLASSES];
@@ -1519,6 +1534,9 @@ __global__ __launch_bounds__(SMALL_THREADS) void blend_backward_small_kernel(
 // LANES = 1: one lane per Gaussian (+ whole-wave help for the rare heavy one); LANES = 16: sixteen lanes (one DPP
 // row) per Gaussian, lane l taking the slot groups l, l + 16, ... -- chosen by the host when Gaussians own many slots
 // on average (a wave full of heavy Gaussians would otherwise serialise them).
+#ifndef GS_RP_CHUNK
+#define GS_RP_CHUNK 2        // 48-B records in flight per lane (gs_slots.h)
+#endif
 template <int LANES>
 __global__ __launch_bounds__(GS_BLOCK, GS_RP_MIN_BLOCKS) void reduce_partials_kernel(
     const int32_t *__restrict__ slot_offsets, const int32_t *__restrict__ ntiles_full,
@@ -1533,13 +1551,13 @@ __global__ __launch_bounds__(GS_BLOCK, GS_RP_MIN_BLOCKS) void reduce_partials_ke
 #pragma unroll
         for (int k = 0; k < 10; ++k) a.v[k] = 0.f;
         a.npix = 0;
-        for (int r0 = 4 * sub; r0 < n; r0 += 4 * LANES) rp_add_group<4>(slot_flags, partials, base + r0, min(4, n - r0), a);
+        for (int r0 = 4 * sub; r0 < n; r0 += 4 * LANES) rp_add_group<4, 4>(slot_flags, partials, base + r0, min(4, n - r0), a);
         // the LANES lanes of a Gaussian are one DPP row: totals land in lane 15 of the row
 #pragma unroll
         for (int k = 0; k < 10; ++k) a.v[k] = gs_row_sum_to_lane15(a.v[k]);
         a.npix = (int)gs_row_sum_to_lane15((float)a.npix);   // < 2^24: exact as a float
     } else {
-        gs_sum_slots_of_lane<2, 1>(live, i, slot_offsets, ntiles_full, slot_flags, partials, nkeys, attrs, tw, th, a);
+        gs_sum_slots_of_lane<GS_RP_CHUNK, 1>(live, i, slot_offsets, ntiles_full, slot_flags, partials, nkeys, attrs, tw, th, a);
     }
     if (live && sub == LANES - 1) {
         acc[3 * (size_t)i] = make_float4(a.v[0], a.v[1], a.v[2], a.v[3]);
@@ -1667,7 +1685,7 @@ int gs_blend_forward_with_boundaries(const int32_t *bin_start, const int32_t *bi
     GS_REQUIRE(walked_list == nullptr || (staged && state), "walked lists are emitted by the filtering (binned) forward with state");
     if (tile_order != nullptr) {   // longest lists first
         hipLaunchKernelGGL(tile_order_kernel, dim3(ORDER_WGS), dim3(ORDER_THREADS), 0, s, (const int32_t *)nullptr, bin_start,
-                           bin_end, tw * rows, tw, tile_row_begin, tile_row_step, bin_shift, tile_order);
+                           bin_end, tw * rows, tw, tile_row_begin, tile_row_step, bin_shift, tile_order, (uint4 *)nullptr, 0LL);
         GS_CHECK_LAUNCH();
     }
     const bool four_waves = !staged && !(flags & GS_BLEND_TWO_WAVES) &&
@@ -1728,10 +1746,14 @@ int gs_blend_backward_split(const int32_t *bin_start, const int32_t *payload, co
     GS_REQUIRE(n_slots >= 0, "n_slots");
     hipStream_t s = (hipStream_t)stream;
     // the flag buffer is padded to a multiple of 16 bytes (header): one aligned fill instead of an aligned fill plus a
-    // second launch for the odd tail
-    if (n_slots > 0) GS_CHECK_HIP(hipMemsetAsync(slot_flags, 0, ((size_t)n_slots + 15) & ~(size_t)15, s));
+    // second launch for the odd tail -- and no fill launch at all when the dispatch order is computed below: the order
+    // kernel's launch carries the workgroups that clear the flags (tile_order_kernel)
+    const size_t flag_bytes = ((size_t)n_slots + 15) & ~(size_t)15;
     const int tw = width / GS_TILE_WIDTH;
     const int rows = owned_row_count(height / GS_TILE_HEIGHT, tile_row_begin, tile_row_step, tile_row_end);
+    const bool order_clears_flags = tile_work != nullptr && rows > 0 && tw > 0 &&
+                                    (reinterpret_cast<uintptr_t>(slot_flags) & 15u) == 0;
+    if (n_slots > 0 && !order_clears_flags) GS_CHECK_HIP(hipMemsetAsync(slot_flags, 0, flag_bytes, s));
     if (rows == 0 || tw == 0) return 0;
     const dim3 grid(tw * rows);
     const float4 *a4 = reinterpret_cast<const float4 *>(attrs);
@@ -1739,8 +1761,10 @@ int gs_blend_backward_split(const int32_t *bin_start, const int32_t *payload, co
     const bool staged = bin_shift > 0 || filter != 0;
     GS_REQUIRE(tile_work == nullptr || tile_order != nullptr, "tile_work needs the tile_order buffer");
     if (tile_work != nullptr) {   // longest walks first, from the lengths the forward pass recorded
-        hipLaunchKernelGGL(tile_order_kernel, dim3(ORDER_WGS), dim3(ORDER_THREADS), 0, s, tile_work, (const int32_t *)nullptr,
-                           (const int32_t *)nullptr, tw * rows, tw, tile_row_begin, tile_row_step, bin_shift, tile_order);
+        const int zero_wgs = n_slots > 0 && order_clears_flags ? gs_div_up((long long)flag_bytes, ORDER_ZERO_BYTES_PER_WG) : 0;
+        hipLaunchKernelGGL(tile_order_kernel, dim3(ORDER_WGS + zero_wgs), dim3(ORDER_THREADS), 0, s, tile_work,
+                           (const int32_t *)nullptr, (const int32_t *)nullptr, tw * rows, tw, tile_row_begin, tile_row_step,
+                           bin_shift, tile_order, reinterpret_cast<uint4 *>(slot_flags), zero_wgs ? (long long)flag_bytes : 0LL);
         GS_CHECK_LAUNCH();
     }
     const bool four_waves = !staged && !(flags & GS_BLEND_TWO_WAVES) &&
@@ -1784,6 +1808,7 @@ int gs_reduce_partials(const int32_t *slot_offsets, const int32_t *num_overlap_t
     GS_REQUIRE(n_visible >= 0, "n_visible");
     GS_REQUIRE(attrs == nullptr || (width > 0 && height > 0 && width % GS_TILE_WIDTH == 0 && height % GS_TILE_HEIGHT == 0),
                "image size (needed with attrs)");
+    GS_REQUIRE((reinterpret_cast<uintptr_t>(slot_flags) & 3u) == 0, "slot_flags must be 4-byte aligned (it is read as dwords)");
     if (n_visible == 0) return 0;
     const float4 *p4 = reinterpret_cast<const float4 *>(partials);
     float4 *a4 = reinterpret_cast<float4 *>(acc);

@@ -92,10 +92,18 @@ static int frame_forward_stages(GsFrame *f, uint32_t stages, void *stream, bool 
     static const bool host_mirror = !(getenv("GS_HOST_MIRROR") && atoi(getenv("GS_HOST_MIRROR")) == 0);
     const bool scan_stores_sizes = host_mirror && (stages & GS_FWD_SCAN) && (stages & GS_FWD_READ_SIZES) &&
                                    f->host_counters_pinned != nullptr;
-    if (stages & GS_FWD_SCAN)
-        GS_STAGE(gs_scan_block_sums2_to_host(f->block_sums, f->block_sums_full, gs_div_up(n_list_points, GS_BLOCK),
-                                             f->counters, scan_stores_sizes ? f->host_counters_pinned : nullptr, stream));
-    if (stages & GS_FWD_READ_SIZES) {
+    // size_stamp: the sizes travel as stamped words the host polls -- no event behind the scan (gsplat_hip.h)
+    const bool stamped = scan_stores_sizes && f->size_stamp != 0;
+    GS_REQUIRE(f->size_stamp == 0 || stamped, "size_stamp needs GS_FWD_SCAN | GS_FWD_READ_SIZES and host_counters_pinned");
+    if (stages & GS_FWD_SCAN) {
+        if (stamped)
+            GS_STAGE(gs_scan_block_sums2_stamped(f->block_sums, f->block_sums_full, gs_div_up(n_list_points, GS_BLOCK),
+                                                 f->counters, f->host_counters_pinned, (uint32_t)f->size_stamp, stream));
+        else
+            GS_STAGE(gs_scan_block_sums2_to_host(f->block_sums, f->block_sums_full, gs_div_up(n_list_points, GS_BLOCK),
+                                                 f->counters, scan_stores_sizes ? f->host_counters_pinned : nullptr, stream));
+    }
+    if ((stages & GS_FWD_READ_SIZES) && !stamped) {
         if (!scan_stores_sizes)
             GS_STAGE(gs_read_counters_async(f->counters, f->host_counters_pinned, GS_NUM_COUNTERS, stream));
         if (f->size_event != nullptr) GS_CHECK_HIP(hipEventRecord((hipEvent_t)f->size_event, (hipStream_t)stream));

@@ -8,6 +8,9 @@
 // bit-for-bit with the oracle.
 #include "gs_common.h"
 #include <stdlib.h>
+#include <string.h>
+#include <chrono>
+#include <thread>
 
 #pragma clang fp contract(off)
 
@@ -297,7 +300,7 @@ __global__ __launch_bounds__(GS_BLOCK) void scan_single_block_kernel(int32_t *__
                                                                     int32_t *__restrict__ data2,
                                                                     int32_t *__restrict__ total_out2,
                                                                     const int32_t *__restrict__ counters,
-                                                                    int32_t *__restrict__ host_mirror) {
+                                                                    int32_t *__restrict__ host_mirror, uint32_t stamp) {
     __shared__ long long lds[GS_BLOCK / GS_WAVE];
     int mirror_slot = GS_COUNTER_NUM_KEYS;
     if (blockIdx.x == 1) { data = data2; total_out = total_out2; mirror_slot = GS_COUNTER_NUM_SLOTS; }
@@ -344,11 +347,24 @@ __global__ __launch_bounds__(GS_BLOCK) void scan_single_block_kernel(int32_t *__
         // host_mirror (pinned, host-coherent memory mapped into the device's address space): the frame's sizes go to the
         // host straight from this kernel -- visible when the kernel has completed (the event recorded behind it) -- instead
         // of through a copy launch of their own (~6 us of a frame that is a chain of such launches)
-        if (host_mirror != nullptr) {
+        if (host_mirror != nullptr && stamp == 0u) {
             host_mirror[mirror_slot] = total;
             if (blockIdx.x == 0) {
                 host_mirror[GS_COUNTER_NUM_VISIBLE] = counters[GS_COUNTER_NUM_VISIBLE];
                 host_mirror[GS_COUNTER_MAX_DEPTH_KEY] = counters[GS_COUNTER_MAX_DEPTH_KEY];
+            }
+        } else if (host_mirror != nullptr) {
+            // stamped words (gs_scan_block_sums2_stamped): {stamp, value} in one 8-byte system-scope store each -- written
+            // through to the host's memory, valid or not on its own, no event and no fence behind them
+            unsigned long long *words = reinterpret_cast<unsigned long long *>(host_mirror);
+            auto put = [&](int slot, int value) {
+                __hip_atomic_store(&words[slot], ((unsigned long long)stamp << 32) | (unsigned)value, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_SYSTEM);
+            };
+            put(mirror_slot, total);
+            if (blockIdx.x == 0) {
+                put(GS_COUNTER_NUM_VISIBLE, counters[GS_COUNTER_NUM_VISIBLE]);
+                put(GS_COUNTER_MAX_DEPTH_KEY, counters[GS_COUNTER_MAX_DEPTH_KEY]);
             }
         }
     }
@@ -1022,7 +1038,7 @@ int gs_scan_block_sums(int32_t *block_sums, int n_blocks, int32_t *counters, int
     }
     hipLaunchKernelGGL(scan_single_block_kernel, dim3(1), dim3(GS_BLOCK), 0, (hipStream_t)stream, block_sums,
                        n_blocks, counters + counter_slot, (int32_t *)nullptr, (int32_t *)nullptr, (const int32_t *)nullptr,
-                       (int32_t *)nullptr);
+                       (int32_t *)nullptr, 0u);
     GS_CHECK_LAUNCH();
     return 0;
 }
@@ -1044,8 +1060,57 @@ int gs_scan_block_sums2_to_host(int32_t *block_sums, int32_t *block_sums_full, i
     }
     hipLaunchKernelGGL(scan_single_block_kernel, dim3(2), dim3(GS_BLOCK), 0, (hipStream_t)stream, block_sums,
                        n_blocks, counters + GS_COUNTER_NUM_KEYS, block_sums_full, counters + GS_COUNTER_NUM_SLOTS, counters,
-                       host_counters_mapped);
+                       host_counters_mapped, 0u);
     GS_CHECK_LAUNCH();
+    return 0;
+}
+
+int gs_scan_block_sums2_stamped(int32_t *block_sums, int32_t *block_sums_full, int n_blocks, int32_t *counters,
+                                void *host_words, uint32_t stamp, void *stream) {
+    GS_REQUIRE(n_blocks >= 0, "n_blocks");
+    GS_REQUIRE(host_words != nullptr && (reinterpret_cast<uintptr_t>(host_words) & 7u) == 0, "host_words: 8-byte aligned host memory");
+    GS_REQUIRE(stamp != 0u, "stamp must not be 0");
+    // (also with no block at all: the kernel then stores the zero totals and the stamped words)
+    hipLaunchKernelGGL(scan_single_block_kernel, dim3(2), dim3(GS_BLOCK), 0, (hipStream_t)stream, block_sums,
+                       n_blocks, counters + GS_COUNTER_NUM_KEYS, block_sums_full, counters + GS_COUNTER_NUM_SLOTS, counters,
+                       reinterpret_cast<int32_t *>(host_words), stamp);
+    GS_CHECK_LAUNCH();
+    return 0;
+}
+
+int gs_wait_stamped_sizes(const void *host_words, uint32_t stamp, int64_t timeout_us, int32_t *sizes4) {
+    GS_REQUIRE(host_words != nullptr && sizes4 != nullptr && stamp != 0u, "gs_wait_stamped_sizes: arguments");
+    const volatile unsigned long long *w = reinterpret_cast<const volatile unsigned long long *>(host_words);
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned spins = 0;; ++spins) {
+        unsigned long long v[4];
+        bool all = true;
+        for (int k = 0; k < 4; ++k) {
+            v[k] = w[k];
+            all = all && (uint32_t)(v[k] >> 32) == stamp;
+        }
+        if (all) {
+            for (int k = 0; k < 4; ++k) sizes4[k] = (int32_t)(uint32_t)v[k];
+            return 0;
+        }
+        if ((spins & 63u) == 63u) {
+            const auto us = std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count();
+            if (us >= timeout_us) return 1;
+            if (us > 2000) std::this_thread::yield();   // a frame's sizes arrive within ~0.2 ms; be polite after 2 ms
+        }
+    }
+}
+
+int gs_host_alloc_coherent(int64_t bytes, void **out) {
+    GS_REQUIRE(bytes > 0 && out != nullptr, "gs_host_alloc_coherent: arguments");
+    *out = nullptr;
+    GS_CHECK_HIP(hipHostMalloc(out, (size_t)bytes, hipHostMallocCoherent | hipHostMallocMapped));
+    memset(*out, 0, (size_t)bytes);
+    return 0;
+}
+
+int gs_host_free(void *p) {
+    if (p != nullptr) GS_CHECK_HIP(hipHostFree(p));
     return 0;
 }
 

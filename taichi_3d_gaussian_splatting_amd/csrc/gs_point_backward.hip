@@ -266,6 +266,7 @@ extern "C" int gs_point_backward(const float *xyz, const float *features, const 
                     width > 0 && height > 0 && width % GS_TILE_WIDTH == 0 && height % GS_TILE_HEIGHT == 0),
                "gs_point_backward: either acc or the slot records of gs_blend_backward (+ image size)");
     GS_REQUIRE(n_visible == 0 || attrs != nullptr, "gs_point_backward: attrs (the packed records of the forward pass) is required");
+    GS_REQUIRE((reinterpret_cast<uintptr_t>(slot_flags) & 3u) == 0, "slot_flags must be 4-byte aligned (it is read as dwords)");
     hipStream_t s = (hipStream_t)stream;
     // rows of points outside the frustum: zeroed by the leading workgroups of the per-point kernel when the mask is known,
     // else both arrays are cleared first

@@ -12,14 +12,40 @@
 #ifdef __HIPCC__
 constexpr int RP_HEAVY = 128;
 struct SlotSum { float v[10]; int npix; };
+// The flags of up to MAXCNT consecutive slots as a bit mask (bit r: slot first + r is raised).  The bytes are fetched as the
+// ALIGNED dwords that hold them, all requested before the first one is looked at -- one memory latency for the whole group
+// (a loop of byte loads made the compiler wait for each one in turn: about ten dependent round trips per lane, most of
+// reduce_partials_kernel's 59 us at the headline size).  Flags are 0 / 1 bytes (gs_blend_backward); the buffer is
+// dword-aligned and allocated in multiples of 16 bytes (include/gsplat_hip.h), so the aligned dwords around a group are
+// inside it.  The first four dwords serve groups of up to 13 slots whatever their alignment; the rest is requested only
+// when a lane of the wave needs it.
+template <int MAXCNT>
+__device__ __forceinline__ unsigned rp_flag_mask(const uint8_t *__restrict__ flags, int first, int cnt) {
+    constexpr int ND = (MAXCNT + 3 + 3) / 4, ND0 = ND < 4 ? ND : 4;
+    const int sh = first & 3, nd = cnt > 0 ? (sh + cnt + 3) >> 2 : 1;   // dwords that hold the group (>= 1: the loads are unconditional)
+    const unsigned *w = reinterpret_cast<const unsigned *>(flags) + (cnt > 0 ? first >> 2 : 0);
+    unsigned d[ND];
+#pragma unroll
+    for (int i = 0; i < ND0; ++i) d[i] = w[min(i, nd - 1)];   // (a repeated dword lands beyond bit cnt: masked off below)
+#pragma unroll
+    for (int i = ND0; i < ND; ++i) d[i] = 0u;
+    if (ND > ND0 && __builtin_amdgcn_ballot_w64(nd > ND0) != 0ull) {
+#pragma unroll
+        for (int i = ND0; i < ND; ++i) d[i] = w[min(i, nd - 1)];
+    }
+    unsigned long long bits = 0ull;
+#pragma unroll
+    for (int i = 0; i < ND; ++i)   // bytes b0..b3 in {0,1} -> b0 | b1 << 1 | b2 << 2 | b3 << 3 (products land on distinct bits: no carries)
+        bits |= (unsigned long long)((((d[i] & 0x01010101u) * 0x01020408u) >> 24) & 0xFu) << (4 * i);
+    return (unsigned)(bits >> sh) & (cnt >= 32 ? ~0u : (1u << cnt) - 1u);
+}
+
 // raised slots fetched together: CHUNK 48-B records are requested before the first one is added (one record per round
 // left the kernel waiting on a full memory latency per slot); added in ascending order, so CHUNK does not change a bit
-template <int CHUNK>
+template <int CHUNK, int MAXCNT = 32>
 __device__ __forceinline__ void rp_add_group(const uint8_t *__restrict__ flags, const float4 *__restrict__ partials,
                                              int first, int cnt, SlotSum &a) {
-    unsigned mask = 0u;   // gather the flags of up to 32 consecutive slots (independent byte loads), then visit the
-                          // raised ones (independent 48-B loads): many loads in flight instead of one at a time
-    for (int r = 0; r < cnt; ++r) mask |= (flags[first + r] != 0 ? 1u : 0u) << r;
+    unsigned mask = rp_flag_mask<MAXCNT>(flags, first, cnt);
     while (mask) {
         int r[CHUNK];
         float4 p[CHUNK][3];
@@ -100,11 +126,11 @@ __device__ __forceinline__ void gs_sum_slots_of_lane(bool live, int i, const int
                 ra = max(ra, k0v); rb = min(rb, k1v);
                 const int first = bL + nv * (cu - b0u) - b0v;   // slot of (cu, row) = first + row
                 for (int row = ra; row < rb; row += 4)
-                    rp_add_group<HEAVY_CHUNK>(slot_flags, partials, first + row, min(4, rb - row), h);
+                    rp_add_group<HEAVY_CHUNK, 4>(slot_flags, partials, first + row, min(4, rb - row), h);
             }
         } else {
             for (int r0_ = 4 * lane; r0_ < nL; r0_ += 4 * GS_WAVE)
-                rp_add_group<HEAVY_CHUNK>(slot_flags, partials, bL + r0_, min(4, nL - r0_), h);
+                rp_add_group<HEAVY_CHUNK, 4>(slot_flags, partials, bL + r0_, min(4, nL - r0_), h);
         }
 #pragma unroll
         for (int k = 0; k < 10; ++k) {

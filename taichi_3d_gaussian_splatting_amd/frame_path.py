@@ -157,6 +157,7 @@ def forward(outer, xyz, features, invalid, obj, intrinsics, q_pc, t_pc, camera_i
     f.q_camera_pointcloud, f.t_camera_pointcloud = slab.ptr("q_cp"), slab.ptr("t_cp")
     f.visible_mask, f.ids, f.counters = slab.ptr("visible_mask"), slab.ptr("ids"), slab.ptr("counters")
     f.host_counters_pinned, f.size_event = readback.host.data_ptr(), readback.event.cuda_event
+    f.size_stamp = readback.next_stamp()   # != 0: the sizes arrive as stamped words, no event is recorded
     f.attrs, f.num_overlap_tiles, f.num_keys = slab.ptr("attrs"), slab.ptr("ntiles"), slab.ptr("nkeys")
     nblk = (n + 255) // 256
     f.block_sums = _ws_bytes(ws, "f_block_sums", 4 * nblk, dev)
@@ -187,7 +188,7 @@ def forward(outer, xyz, features, invalid, obj, intrinsics, q_pc, t_pc, camera_i
         f.aux_stream, f.aux_event_fork, f.aux_event_join = aux.cuda_stream, fork.cuda_event, join.cuda_event
         stages |= S["GS_FWD_COLOUR_ASYNC"]
     _lib.check(lib.gs_frame_forward(ctypes.addressof(f), stages, _lib.current_stream(dev)), "gs_frame_forward")
-    host = readback.wait()
+    host = readback.wait(f.size_stamp)
     state = FrameState()
     state.frame, state.slab, state.layout, state.walked = f, slab, layout, emit
     state.split = bool(split)   # (the split backward reads the forward's image: the caller saves it for the backward pass)

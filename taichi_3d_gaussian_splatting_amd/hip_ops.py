@@ -8,6 +8,7 @@ PyTorch is plumbing here (device memory + streams); all arithmetic runs in the H
 from __future__ import annotations
 
 import ctypes
+import os
 from dataclasses import dataclass
 from typing import Optional, Tuple
 
@@ -139,22 +140,64 @@ def read_counters(counters: torch.Tensor) -> Tuple[int, ...]:
 
 
 class CounterReadback:
-    """The frame's sizes (M, K, slot count, depth range) on their way to the host WITHOUT stalling the launch queue:
-    ``start`` enqueues the scans' counters into pinned memory and records an event; the host keeps launching the
-    kernels that can work from the device-side counts and calls ``wait`` when it needs the numbers."""
+    """The frame's sizes (M, K, slot count, depth range) on their way to the host WITHOUT stalling the launch queue.
+
+    Two transports into the same 64 bytes of pinned host memory:
+    * ``start`` / ``wait()``: the counters are copied (or stored by the scan kernel) as int32[NUM_COUNTERS] and an event
+      recorded behind them tells the host when;
+    * ``next_stamp`` / ``wait(stamp)`` (gs_frame_forward with GsFrame.size_stamp): each size arrives as one 64-bit word
+      {stamp, value} written through to host memory by the scan kernel, and the host reads the words until they carry the
+      frame's stamp -- no event, whose signal packet holds the next kernel back by ~6 us per frame.  Needs memory that is
+      coherent while kernels run (gs_host_alloc_coherent); GS_SIZE_STAMPS=0 or a failed allocation leave the event form."""
 
     def __init__(self, device):
-        self.host = torch.empty(NUM_COUNTERS, dtype=torch.int32).pin_memory()
-        self.event = torch.cuda.Event()
         self.device = device
+        self.event = torch.cuda.Event()
+        self._raw, self._stamp = None, 0
+        if os.environ.get("GS_SIZE_STAMPS", "1") != "0":
+            p = ctypes.c_void_p()
+            if _lib.load().gs_host_alloc_coherent(4 * NUM_COUNTERS, ctypes.byref(p)) == 0 and p.value:
+                self._raw = p.value
+                self._buf = (ctypes.c_int32 * NUM_COUNTERS).from_address(p.value)
+                self.host = torch.frombuffer(self._buf, dtype=torch.int32)
+        if self._raw is None:
+            self.host = torch.empty(NUM_COUNTERS, dtype=torch.int32).pin_memory()
+
+    def __del__(self):
+        raw, self._raw = getattr(self, "_raw", None), None
+        if raw is not None:
+            try:
+                _lib.load().gs_host_free(ctypes.c_void_p(raw))
+            except Exception:   # interpreter shutdown
+                pass
 
     def start(self, counters: torch.Tensor) -> None:
         call("gs_read_counters_async", ptr(counters), self.host.data_ptr(), NUM_COUNTERS, current_stream(self.device))
         self.event.record(torch.cuda.current_stream(self.device))
 
-    def wait(self) -> Tuple[int, ...]:
-        self.event.synchronize()
-        return tuple(self.host.tolist())
+    def next_stamp(self) -> int:
+        """A stamp for the next frame's sizes (0: stamps are not available, use the event)."""
+        if self._raw is None:
+            return 0
+        self._stamp = self._stamp % 0x7FFFFFFF + 1
+        return self._stamp
+
+    def wait(self, stamp: int = 0) -> Tuple[int, ...]:
+        if not stamp:
+            self.event.synchronize()
+            return tuple(self.host.tolist())
+        sizes = (ctypes.c_int32 * 4)()
+        lib = _lib.load()
+        rc = lib.gs_wait_stamped_sizes(ctypes.c_void_p(self._raw), stamp, 2_000_000, sizes)
+        if rc == 1:   # not there after 2 s: let the stream finish (a fault surfaces here), then they must be
+            torch.cuda.current_stream(self.device).synchronize()
+            rc = lib.gs_wait_stamped_sizes(ctypes.c_void_p(self._raw), stamp, 100_000, sizes)
+        if rc != 0:
+            raise RuntimeError("the frame's sizes never reached the host (stamped words; GS_SIZE_STAMPS=0 selects the event form)")
+        out = [0] * NUM_COUNTERS
+        out[COUNTER_NUM_VISIBLE], out[COUNTER_NUM_KEYS] = sizes[0], sizes[1]
+        out[COUNTER_NUM_SLOTS], out[COUNTER_MAX_DEPTH_KEY] = sizes[2], sizes[3]
+        return tuple(out)
 
 
 def scan_block_sums_async(block_sums: torch.Tensor, counters: torch.Tensor, block_sums_full: torch.Tensor) -> None:
