@@ -48,10 +48,11 @@ struct Factors { float q, s, alpha, color, color_hi; int keep; /* SH coefficient
 constexpr int ZERO_ROUNDS = 8;   // rows per thread of the workgroups that zero the rows of invisible points
 // Where a Gaussian's accumulator record comes from when it is not read from `acc`: the slot records of gs_blend_backward,
 // summed here (gs_slots.h) -- the fused form of gs_reduce_partials + gs_point_backward: one launch less and the 48 B x M
-// accumulator array is neither written nor read back.  MEASURED SLOWER at the headline size (0.186 ms against 0.069 +
-// 0.101 ms for the two kernels): the slot gather is latency-bound and lives on waves in flight, and this kernel runs two
-// waves per SIMD (61 KB of row staging per workgroup) where gs_reduce_partials runs six.  Kept as an option of the entry
-// point (small frames, where a launch costs more than the gather), not the operator's default.
+// accumulator array is neither written nor read back.  MEASURED SLOWER at the headline size (round 5, flags fetched as
+// aligned dwords: 0.158 ms against 0.053 + 0.093 ms for the two kernels; round 3: 0.186 against 0.069 + 0.101): the slot
+// gather lives on waves in flight, and this kernel runs two waves per SIMD (61 KB of row staging per workgroup) where
+// gs_reduce_partials runs six.  Kept as an option of the entry point (small frames, where a launch costs more than the
+// gather), not the operator's default.
 struct SlotSource {
     const int32_t *slot_offsets, *ntiles_full;
     const uint8_t *slot_flags;
