@@ -51,6 +51,25 @@ def test_argument_validation_without_gpu(lib):
     assert l.gs_sort_workspace_bytes(10_000_000) > 256 * 4 * (10_000_000 // 4096)
 
 
+def test_stamped_size_words_host_side(lib):
+    """gs_wait_stamped_sizes (the host half of GsFrame.size_stamp): the four 64-bit words {stamp << 32 | value} are valid
+    only when ALL of them carry the frame's stamp; a stale word (the previous frame's stamp) keeps the host waiting."""
+    lib = lib.load()
+    words = (ctypes.c_uint64 * 4)()
+    sizes = (ctypes.c_int32 * 4)()
+    assert lib.gs_wait_stamped_sizes(words, 7, 2000, sizes) == 1             # nothing has arrived: timeout, nothing written
+    assert list(sizes) == [0, 0, 0, 0]
+    for k, v in enumerate((977848, 2877171, 9524086, 400)):
+        words[k] = (7 << 32) | v
+    assert lib.gs_wait_stamped_sizes(words, 7, 2000, sizes) == 0
+    assert list(sizes) == [977848, 2877171, 9524086, 400]
+    words[2] = (6 << 32) | 123                                               # one word still from the frame before
+    assert lib.gs_wait_stamped_sizes(words, 7, 2000, sizes) == 1
+    words[2] = (7 << 32) | 0x7FFFFFFF                                        # a saturated count travels as it is
+    assert lib.gs_wait_stamped_sizes(words, 7, 2000, sizes) == 0 and sizes[2] == 0x7FFFFFFF
+    assert lib.gs_wait_stamped_sizes(words, 0, 2000, sizes) < 0              # stamp 0 is "no stamp": an argument error
+
+
 def test_product_path_has_no_cpu_fallback():
     from taichi_3d_gaussian_splatting_amd import CameraInfo, GaussianPointCloudRasterisation as Op
     from taichi_3d_gaussian_splatting_amd.synthetic import make_scene

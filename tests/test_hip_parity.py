@@ -1285,6 +1285,74 @@ def test_speculative_sizes_overflow_is_redone(scene):
     assert len(op2._size_guesses) == 2 and op2.speculation_stats == {"frames": 6, "redone": 0}
 
 
+@pytest.mark.parametrize("mix", ["ordinary", "sixteen_lanes"])
+def test_slot_sums_against_a_host_reference(ops, mix):
+    """gs_reduce_partials on synthetic slot layouts: every Gaussian's flagged slots summed, the others never looked at (they
+    hold NaNs), for slot runs of every length around the group sizes of the flag gather (gs_slots.h: the flags of a run are
+    fetched as the aligned dwords that hold them -- 1..13 slots from the first four dwords whatever the alignment, up to 32
+    per group, above 128 the whole wave) starting at every byte alignment.  Integer-valued records: the sums are exact in
+    any order, so the comparison is bit for bit."""
+    rng = np.random.default_rng(11)
+    if mix == "ordinary":
+        n = np.concatenate([np.zeros(50, int), rng.integers(1, 14, 3000), rng.integers(14, 33, 600), rng.integers(33, 129, 200),
+                            rng.integers(129, 700, 12), np.arange(0, 70)])
+    else:   # hundreds of slots per Gaussian on average: sixteen lanes per Gaussian (reduce_partials_kernel<16>)
+        n = np.concatenate([rng.integers(600, 1500, 40), np.arange(0, 9), rng.integers(1, 14, 10)])
+    rng.shuffle(n)
+    m, total = len(n), int(n.sum())
+    if mix == "sixteen_lanes":
+        assert total > 512 * m
+    offsets = np.concatenate([[0], np.cumsum(n)[:-1]]).astype(np.int32)
+    flags = (rng.random(total) < 0.6).astype(np.uint8)
+    rows = rng.integers(-8, 9, (total, 12)).astype(np.float32)
+    npix = rng.integers(0, 257, total).astype(np.int32)
+    rows[:, 10] = npix.view(np.float32)
+    rows[:, 11] = 0.0
+    stored = rows.copy()
+    stored[flags == 0] = np.nan                                   # a slot that was never written
+    owner = np.repeat(np.arange(m), n)
+    expect = np.zeros((m, 12), np.float64)
+    np.add.at(expect, owner[flags == 1], rows[flags == 1].astype(np.float64))
+    expect_npix = np.zeros(m, np.int64)
+    np.add.at(expect_npix, owner[flags == 1], npix[flags == 1])
+    padded = np.zeros((total + 15) & ~15, np.uint8)              # (the header's allocation rule for the flags)
+    padded[:total] = flags
+    acc = ops.reduce_partials(torch.from_numpy(offsets).cuda(), torch.from_numpy(n.astype(np.int32)).cuda(),
+                              torch.from_numpy(padded).cuda()[:total], torch.from_numpy(stored).cuda()).cpu().numpy()
+    assert np.array_equal(acc[:, :10], expect[:, :10].astype(np.float32))
+    assert np.array_equal(acc[:, 10].view(np.int32), expect_npix.astype(np.int32))
+
+
+def test_sizes_as_stamped_words_and_behind_an_event_are_the_same_frames(scene, monkeypatch):
+    """The frame's sizes reach the host as stamped 64-bit words the host polls (default: no event behind the scan) or as
+    int32 counters behind an event (GS_SIZE_STAMPS=0): same frames, same speculation history, over a sequence whose sizes
+    change every frame (more keys, fewer keys, a deeper depth range, nothing on screen)."""
+    import copy
+    from taichi_3d_gaussian_splatting_amd import GaussianPointCloudRasterisation as Op
+    from taichi_3d_gaussian_splatting_amd.synthetic import make_grad_image
+    g = make_grad_image(scene.height, scene.width)
+    few = small_scene(n=500, size=scene.height, seed=3)
+    far = small_scene(n=3000, size=scene.height, seed=4)
+    far.point_cloud[:, 2] += 40.0
+    nothing = copy.deepcopy(scene)
+    nothing.point_invalid_mask = torch.ones_like(scene.point_invalid_mask)
+    seq = [few, scene, scene, nothing, far, few, scene, nothing, nothing, scene]
+    cfg = Op.GaussianPointCloudRasterisationConfig()
+    stamped = Op(cfg)
+    monkeypatch.setenv("GS_SIZE_STAMPS", "0")
+    evented = Op(cfg)
+    evented._counter_readback(torch.device("cuda", torch.cuda.current_device()))   # (the transport is chosen when the read-back is made)
+    monkeypatch.delenv("GS_SIZE_STAMPS")
+    for sc in seq:
+        a, b = _run_operator(sc, g, op=stamped), _run_operator(sc, g, op=evented)
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
+        assert torch.equal(a[3].grad, b[3].grad) and torch.equal(a[4].grad, b[4].grad)
+    assert stamped.speculation_stats == evented.speculation_stats and stamped.speculation_stats["frames"] == len(seq)
+    rb_s, rb_e = list(stamped._readbacks.values())[0], list(evented._readbacks.values())[0]
+    assert rb_s._raw is not None and rb_s._stamp == len(seq) - 1   # (frame 0 has nothing to speculate from: stage by stage)
+    assert rb_e._raw is None and rb_e.next_stamp() == 0
+
+
 def test_speculative_depth_overflow_cannot_write_outside_the_ranges(ops):
     """a speculative frame builds 32-bit keys with the PREVIOUS frame's depth width.  When this frame's
     quantised depths need more bits, the excess used to spill into the bin field, and with a bin count that is not a power
