@@ -18,8 +18,9 @@ RCCL all-gather of the rendered rows + all-reduce of the per-Gaussian gradient a
 scaling is STRONG: total work is fixed, value = frame pixels / max-over-ranks step time.
 
 Rank 0 prints ONE JSON line.  Besides the contract fields it carries
-  step_ms      : per-step GPU time from HIP events on the launch stream around each step: median, p90, min (ms_per_step
-                 stays the wall-clock mean over the K steps between two barriers + synchronisations)
+  step_ms      : per-step GPU time from HIP events on the launch stream around each step: median, p90, min -- taken over K
+                 more steps AFTER the timed region (an event between two steps costs the stream ~6 us; ms_per_step is the
+                 wall-clock mean over exactly K steps between two barriers + synchronisations, nothing else enqueued)
   roofline     : achieved algorithmic HBM GB/s of the dominant kernel vs the 8 TB/s peak, measured live with HIP
                  events on the launch stream (plus all stage times and the whole-path figure); `traffic` = PMC HBM
                  bytes per launch from the committed profile, {raw, gfx950_corrected} (the guide's correction doubles
@@ -328,20 +329,26 @@ def main() -> None:
         for _ in range(warmup):
             step()
         fence()
-        # two events per step on torch's current stream (= the stream every kernel is launched on)
-        begins = [torch.cuda.Event(enable_timing=True) for _ in range(steps)]
-        ends = [torch.cuda.Event(enable_timing=True) for _ in range(steps)]
+        # THE timed region: exactly `steps` steps between two fences, nothing else on the stream (an event record between
+        # two steps holds the next kernel back by ~6 us: the per-step statistics below come from a pass of their own)
         t0 = time.perf_counter()
         for i in range(steps):
-            begins[i].record()
             step()
-            ends[i].record()
         fence()
         elapsed = time.perf_counter() - t0
         if world > 1:
             t = torch.tensor([elapsed], dtype=torch.float64, device=device)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
+        # per-step distribution (not the headline number): the same steps once more, two events per step on torch's current
+        # stream (= the stream every kernel is launched on)
+        begins = [torch.cuda.Event(enable_timing=True) for _ in range(steps)]
+        ends = [torch.cuda.Event(enable_timing=True) for _ in range(steps)]
+        for i in range(steps):
+            begins[i].record()
+            step()
+            ends[i].record()
+        fence()
         per_step = sorted(begins[i].elapsed_time(ends[i]) for i in range(steps))
         return 1e3 * elapsed / steps, {"median": round(per_step[len(per_step) // 2], 4),
                                        "p90": round(per_step[int(0.9 * (len(per_step) - 1))], 4),
