@@ -17,6 +17,11 @@ N > 1: the same frame is sharded over contiguous bands of 16-pixel tile rows (on
 RCCL all-gather of the rendered rows + all-reduce of the per-Gaussian gradient accumulators), so the
 scaling is STRONG: total work is fixed, value = frame pixels / max-over-ranks step time.
 
+Warm-up: the W warm-up steps are followed by untimed steps until the GPU has been under the operator's load for
+WARMUP_FLOOR_MS = 40 ms (config.warmup_floor_ms, config.warmup_steps_run): a GPU that has idled needs ~20 ms of this load to
+reach the shader clock it then holds, and the VALU-bound blend kernels run 10 % slower at the start of that ramp
+(profiles/r05_clock_ramp.txt) -- `--warmup 5` alone timed the ramp, not the path.  GS_BENCH_WARMUP_FLOOR_MS=0: exactly W.
+
 Rank 0 prints ONE JSON line.  Besides the contract fields it carries
   step_ms      : per-step GPU time from HIP events on the launch stream around each step: median, p90, min -- taken over K
                  more steps AFTER the timed region (an event between two steps costs the stream ~6 us; ms_per_step is the
@@ -44,6 +49,7 @@ from __future__ import annotations
 import argparse
 import hashlib
 import json
+import math
 import os
 import sys
 import time
@@ -58,6 +64,9 @@ HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s 
 # VALU issue ceiling: 256 CUs x 4 SIMD-32, one wave64 fp32 instruction per 2 cycles per SIMD at 2.4 GHz
 VALU_PEAK_WAVE_INSTR_PER_S = 256 * 4 * 2.4e9 / 2.0
 PROFILE_TAG = "r05"
+# Warm-up floor (ms of continuous load before the timed region; profiles/r05_clock_ramp.txt): the W warm-up steps are
+# followed by untimed steps until the GPU has been under this load that long.  0 = exactly W steps.
+WARMUP_FLOOR_MS = float(os.environ.get("GS_BENCH_WARMUP_FLOOR_MS", "40"))
 
 
 def algorithmic_bytes(n, m, k, p, key_bytes=8, k_tile=None):
@@ -324,10 +333,43 @@ def main() -> None:
     if args.bin_shift is not None:
         op.bin_shift = args.bin_shift
 
+    warmup_steps_run = []   # per timed_run call: W + the steps of the warm-up floor
+
     def timed_run(warmup, steps):
         """-> (wall-clock ms per step, max over ranks; {median, p90, min} of the per-step HIP-event times)"""
+        t_load, after_first = None, 0
         for _ in range(warmup):
             step()
+            if t_load is None:   # (the first step of a fresh operator is mostly host work: library, allocations)
+                torch.cuda.synchronize()
+                t_load = time.perf_counter()
+            else:
+                after_first += 1
+        # warm-up floor: a GPU that has idled needs ~20 ms of THIS load to reach the shader clock it then holds -- the
+        # VALU-bound blend kernels are 10 % slower at the start of the ramp (profiles/r05_clock_ramp.txt); five warm-up steps
+        # are 6 ms.  Keep stepping, untimed, until the load has lasted WARMUP_FLOOR_MS (reported in config.warmup_steps_run).
+        # The number of extra steps is computed once, the same on every rank (steps of a sharded frame hold collectives).
+        extra = 0
+        if WARMUP_FLOOR_MS > 0:
+            while t_load is None or after_first < 2:   # (two steps behind the first one: a step-time estimate)
+                step()
+                extra += 1
+                if t_load is None:
+                    torch.cuda.synchronize()
+                    t_load = time.perf_counter()
+                else:
+                    after_first += 1
+            torch.cuda.synchronize()
+            loaded_ms = 1e3 * (time.perf_counter() - t_load)
+            if world > 1:
+                t = torch.tensor([loaded_ms], dtype=torch.float64, device=device)
+                dist.all_reduce(t, op=dist.ReduceOp.MIN)
+                loaded_ms = float(t.item())
+            more = int(math.ceil(max(WARMUP_FLOOR_MS - loaded_ms, 0.0) / max(loaded_ms / after_first, 1e-3)))
+            for _ in range(min(more, 400)):
+                step()
+            extra += min(more, 400)
+        warmup_steps_run.append(warmup + extra)
         fence()
         # THE timed region: exactly `steps` steps between two fences, nothing else on the stream (an event record between
         # two steps holds the next kernel back by ~6 us: the per-step statistics below come from a pass of their own)
@@ -579,7 +621,8 @@ def main() -> None:
                        "backward_hook": hook is not None, "hook_feature_copy": bool(hook is not None and not args.no_hook_feature_copy),
                        "forward_only": args.forward_only, "training_like": not args.static_scene,
                        "rgb_only": bool(cfg.rgb_only), "speculation": dict(op.speculation_stats),
-                       "host_threads_on_cpus": None if pinned is None else len(pinned), **sizes},
+                       "host_threads_on_cpus": None if pinned is None else len(pinned),
+                       "warmup_floor_ms": WARMUP_FLOOR_MS, "warmup_steps_run": warmup_steps_run[0], **sizes},
             "step_ms": step_ms, "variants": variants,
             "roofline": roofline, "cpu_baseline": cpu_baseline,
         }
