@@ -47,6 +47,7 @@ cfg4_2m_1080p, stress_t_ras}.
 from __future__ import annotations
 
 import argparse
+import gc
 import hashlib
 import json
 import math
@@ -337,6 +338,11 @@ def main() -> None:
 
     def timed_run(warmup, steps):
         """-> (wall-clock ms per step, max over ranks; {median, p90, min} of the per-step HIP-event times)"""
+        # (as `timeit` does: no garbage collection inside a timed region -- a full collection of this process takes ~45 ms of
+        # the host thread, which runs only ~1 ms ahead of the GPU.  Collected HERE, in front of the warm-up: 45 ms of idling
+        # between warm-up and timed region would send the GPU down its clock ramp again)
+        gc.collect()
+        gc.disable()
         t_load, after_first = None, 0
         for _ in range(warmup):
             step()
@@ -378,6 +384,7 @@ def main() -> None:
             step()
         fence()
         elapsed = time.perf_counter() - t0
+        gc.enable()
         if world > 1:
             t = torch.tensor([elapsed], dtype=torch.float64, device=device)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
