@@ -384,7 +384,6 @@ def main() -> None:
             step()
         fence()
         elapsed = time.perf_counter() - t0
-        gc.enable()
         if world > 1:
             t = torch.tensor([elapsed], dtype=torch.float64, device=device)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -398,6 +397,7 @@ def main() -> None:
             step()
             ends[i].record()
         fence()
+        gc.enable()
         per_step = sorted(begins[i].elapsed_time(ends[i]) for i in range(steps))
         return 1e3 * elapsed / steps, {"median": round(per_step[len(per_step) // 2], 4),
                                        "p90": round(per_step[int(0.9 * (len(per_step) - 1))], 4),
