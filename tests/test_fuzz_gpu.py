@@ -22,8 +22,8 @@ pytestmark = pytest.mark.gpu
 CASES = int(os.environ.get("GS_FUZZ_CASES", "24"))
 FIRST = int(os.environ.get("GS_FUZZ_FIRST", "0"))
 
-# Bars.  Observed (round 5, one MI355X; every case prints its distances as a [parity] line) over 840 fresh draws (seeds
-# 8000-8239, 9000-9299, 10000-10299; 242 of the first 540 needle scenes or close-ups, 44+ with grids above 3,844 tiles): the count image equal
+# Bars.  Observed (round 5, one MI355X; every case prints its distances as a [parity] line) over 1,440 fresh draws (seeds
+# 8000-8239, 9000-9299, 10000-10299, 11000-11599; 242 of the first 540 needle scenes or close-ups, 44+ with grids above 3,844 tiles): the count image equal
 # to the fp32 oracle's on every pixel of every draw; image 4.2e-7 and depth 1.9e-6 over ALL pixels; gradients (rel-L2 vs the
 # fp32 oracle) 2.8e-5 / 2.1e-5 on ordinary scenes, 4.1e-5 / 5.8e-5 on ill-conditioned ones.  (Round 3, before the decisions
 # were exact: one flipped pixel per ~600 draws, ill-conditioned scenes 4.6e-4 / 2.4e-3 / 5.5e-4 from the fp32 oracle.)
