@@ -21,6 +21,8 @@ Warm-up: the W warm-up steps are followed by untimed steps until the GPU has bee
 WARMUP_FLOOR_MS = 40 ms (config.warmup_floor_ms, config.warmup_steps_run): a GPU that has idled needs ~20 ms of this load to
 reach the shader clock it then holds, and the VALU-bound blend kernels run 10 % slower at the start of that ramp
 (profiles/r05_clock_ramp.txt) -- `--warmup 5` alone timed the ramp, not the path.  GS_BENCH_WARMUP_FLOOR_MS=0: exactly W.
+The literal protocol is measured too and reported beside it: `ms_per_step_strict_warmup` = the same K steps timed straight
+behind exactly W warm-up steps (they then count as warm-up load towards the floor).
 
 Rank 0 prints ONE JSON line.  Besides the contract fields it carries
   step_ms      : per-step GPU time from HIP events on the launch stream around each step: median, p90, min -- taken over K
@@ -336,13 +338,35 @@ def main() -> None:
 
     warmup_steps_run = []   # per timed_run call: W + the steps of the warm-up floor
 
-    def timed_run(warmup, steps):
+    strict_warmup_ms = []   # wall-clock ms per step of K steps timed straight after exactly W warm-up steps (first timed_run)
+
+    def wall_clock_steps(steps):
+        """exactly `steps` steps between two fences, nothing else on the stream -> ms per step (max over ranks)"""
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        fence()
+        elapsed = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        return 1e3 * elapsed / steps
+
+    def timed_run(warmup, steps, strict_too=False):
         """-> (wall-clock ms per step, max over ranks; {median, p90, min} of the per-step HIP-event times)"""
         # (as `timeit` does: no garbage collection inside a timed region -- a full collection of this process takes ~45 ms of
         # the host thread, which runs only ~1 ms ahead of the GPU.  Collected HERE, in front of the warm-up: 45 ms of idling
         # between warm-up and timed region would send the GPU down its clock ramp again)
         gc.collect()
         gc.disable()
+        try:
+            return _timed_run(warmup, steps, strict_too)
+        finally:
+            gc.enable()
+
+    def _timed_run(warmup, steps, strict_too):
         t_load, after_first = None, 0
         for _ in range(warmup):
             step()
@@ -351,11 +375,17 @@ def main() -> None:
                 t_load = time.perf_counter()
             else:
                 after_first += 1
+        # THE LITERAL PROTOCOL first: K steps timed behind exactly W warm-up steps, reported beside the
+        # floored number as ms_per_step_strict_warmup.  These K steps are load like any other: they count towards the floor.
+        extra = 0
+        if strict_too and WARMUP_FLOOR_MS > 0 and warmup > 0:
+            strict_warmup_ms.append(wall_clock_steps(steps))
+            after_first += steps
+            extra += steps
         # warm-up floor: a GPU that has idled needs ~20 ms of THIS load to reach the shader clock it then holds -- the
         # VALU-bound blend kernels are 10 % slower at the start of the ramp (profiles/r05_clock_ramp.txt); five warm-up steps
         # are 6 ms.  Keep stepping, untimed, until the load has lasted WARMUP_FLOOR_MS (reported in config.warmup_steps_run).
         # The number of extra steps is computed once, the same on every rank (steps of a sharded frame hold collectives).
-        extra = 0
         if WARMUP_FLOOR_MS > 0:
             while t_load is None or after_first < 2:   # (two steps behind the first one: a step-time estimate)
                 step()
@@ -376,18 +406,9 @@ def main() -> None:
                 step()
             extra += min(more, 400)
         warmup_steps_run.append(warmup + extra)
-        fence()
         # THE timed region: exactly `steps` steps between two fences, nothing else on the stream (an event record between
         # two steps holds the next kernel back by ~6 us: the per-step statistics below come from a pass of their own)
-        t0 = time.perf_counter()
-        for i in range(steps):
-            step()
-        fence()
-        elapsed = time.perf_counter() - t0
-        if world > 1:
-            t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            elapsed = float(t.item())
+        ms = wall_clock_steps(steps)
         # per-step distribution (not the headline number): the same steps once more, two events per step on torch's current
         # stream (= the stream every kernel is launched on)
         begins = [torch.cuda.Event(enable_timing=True) for _ in range(steps)]
@@ -397,13 +418,12 @@ def main() -> None:
             step()
             ends[i].record()
         fence()
-        gc.enable()
         per_step = sorted(begins[i].elapsed_time(ends[i]) for i in range(steps))
-        return 1e3 * elapsed / steps, {"median": round(per_step[len(per_step) // 2], 4),
-                                       "p90": round(per_step[int(0.9 * (len(per_step) - 1))], 4),
-                                       "min": round(per_step[0], 4)}
+        return ms, {"median": round(per_step[len(per_step) // 2], 4),
+                    "p90": round(per_step[int(0.9 * (len(per_step) - 1))], 4),
+                    "min": round(per_step[0], 4)}
 
-    ms_per_step, step_ms = timed_run(args.warmup, args.steps)
+    ms_per_step, step_ms = timed_run(args.warmup, args.steps, strict_too=True)
     # the other hook configuration, same K steps (not the driver's number): the trainer's steady state between
     # densifications leaves out the [M,56] hook copy
     variants = {}
@@ -630,6 +650,10 @@ def main() -> None:
                        "rgb_only": bool(cfg.rgb_only), "speculation": dict(op.speculation_stats),
                        "host_threads_on_cpus": None if pinned is None else len(pinned),
                        "warmup_floor_ms": WARMUP_FLOOR_MS, "warmup_steps_run": warmup_steps_run[0], **sizes},
+            # the literal protocol: the same K steps timed straight behind exactly W warm-up steps (no warm-up floor), i.e. partly on
+            # the GPU's clock ramp -- reported beside the floored number (null: GS_BENCH_WARMUP_FLOOR_MS=0, ms_per_step is it)
+            "ms_per_step_strict_warmup": round(strict_warmup_ms[0], 4) if strict_warmup_ms else None,
+            "value_strict_warmup": round(pixels / 1e6 / (strict_warmup_ms[0] / 1e3), 3) if strict_warmup_ms else None,
             "step_ms": step_ms, "variants": variants,
             "roofline": roofline, "cpu_baseline": cpu_baseline,
         }

@@ -67,6 +67,11 @@ extern "C" {
 #define GS_COUNTER_MAX_DEPTH_KEY 3 /* max over visible points of int32(z * depth_scale) (gs_preprocess) */
 #define GS_NUM_COUNTERS 8
 
+/* ABI version of this header.  A TUNING build of the library (measurement arms compiled in: -DGS_TUNING_BUILD=1,
+ * tools/build_variants.sh) reports GS_ABI_VERSION + GS_ABI_TUNING_OFFSET, which the product loader refuses. */
+#define GS_ABI_VERSION 34
+#define GS_ABI_TUNING_OFFSET 1000
+
 const char *gs_last_error(void);
 int gs_abi_version(void);
 

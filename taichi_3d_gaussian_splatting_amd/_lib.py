@@ -17,7 +17,8 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # GS_LIB_PATH: development knob (tuning sweeps load differently built variants of the library); default = in-tree build
 LIB_PATH = os.environ.get("GS_LIB_PATH") or os.path.join(_HERE, "libgsplat_hip.so")
-ABI_VERSION = 33
+ABI_VERSION = 34
+ABI_TUNING_OFFSET = 1000   # a tuning build of the library (measurement arms compiled in) reports ABI_VERSION + this
 
 _c = ctypes
 _P = _c.c_void_p
@@ -155,8 +156,14 @@ def load() -> ctypes.CDLL:
             fn = getattr(lib, name)  # AttributeError if the library does not export the symbol
             fn.restype = res
             fn.argtypes = args
-        if lib.gs_abi_version() != ABI_VERSION:
-            raise RuntimeError(f"libgsplat_hip.so ABI {lib.gs_abi_version()} != expected {ABI_VERSION}")
+        abi = lib.gs_abi_version()
+        if abi == ABI_VERSION + ABI_TUNING_OFFSET and os.environ.get("GS_ALLOW_TUNING_LIB") == "1":
+            pass   # a measuring tool asked for a tuning build (tools/blend_stats.py, tools/x_arms.sh): never the product path
+        elif abi == ABI_VERSION + ABI_TUNING_OFFSET:
+            raise RuntimeError(f"{LIB_PATH} is a TUNING build (measurement arms compiled in: its results may be wrong on "
+                               "purpose); only the measuring tools load it, with GS_ALLOW_TUNING_LIB=1")
+        elif abi != ABI_VERSION:
+            raise RuntimeError(f"libgsplat_hip.so ABI {abi} != expected {ABI_VERSION}")
         if lib.gs_frame_struct_bytes() != ctypes.sizeof(GsFrame):
             raise RuntimeError(f"GsFrame: the library's struct has {lib.gs_frame_struct_bytes()} bytes, the Python mirror "
                                f"{ctypes.sizeof(GsFrame)} (include/gsplat_hip.h and the built library disagree)")

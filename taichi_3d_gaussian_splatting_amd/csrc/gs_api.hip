@@ -13,4 +13,10 @@ void gs_set_error(const char *fmt, ...) {
 }
 
 extern "C" const char *gs_last_error(void) { return g_error; }
-extern "C" int gs_abi_version(void) { return 33; }
+// A tuning build (measurement arms compiled in: tools/build_variants.sh ... -DGS_TUNING_BUILD=1) reports another version, so
+// the product loader (_lib.load) refuses it.
+#ifdef GS_TUNING_BUILD
+extern "C" int gs_abi_version(void) { return GS_ABI_VERSION + GS_ABI_TUNING_OFFSET; }
+#else
+extern "C" int gs_abi_version(void) { return GS_ABI_VERSION; }
+#endif

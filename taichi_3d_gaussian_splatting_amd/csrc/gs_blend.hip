@@ -37,6 +37,17 @@ namespace {
 constexpr float EPS_ALPHA = (float)(1.0 / 255.0);  // RAS:451
 constexpr float CLAMP_ALPHA = 0.99f;               // RAS:453
 constexpr float STOP_T = 0.0001f;                  // RAS:458
+// MEASUREMENT ARMS (GS_ABLATE_FWD, GS_BWD_REDUCE_ARM = 0, GS_MFMA_REDUCE, GS_STATS) exist in tuning builds only: they are
+// honoured when GS_TUNING_BUILD is defined -- which also changes gs_abi_version() (gs_api.hip), so that _lib.load refuses
+// such a library unless the measuring tool asks for it (GS_ALLOW_TUNING_LIB=1) -- and are a compile error otherwise: one
+// stray -D cannot ship a library that blends nothing or throws its gradients away.
+#ifndef GS_TUNING_BUILD
+#if defined(GS_ABLATE_FWD) || defined(GS_MFMA_REDUCE) || defined(GS_STATS) || \
+    (defined(GS_BWD_REDUCE_ARM) && GS_BWD_REDUCE_ARM == 0) || (defined(GS_BWD_REDUCE_STAGED) && GS_BWD_REDUCE_STAGED == 0) || \
+    (defined(GS_BWD_REDUCE_DIRECT) && GS_BWD_REDUCE_DIRECT == 0)
+#error "GS_ABLATE_FWD / GS_MFMA_REDUCE / GS_STATS / GS_BWD_REDUCE_* = 0 are measurement arms: build them with -DGS_TUNING_BUILD=1 (tools/build_variants.sh)"
+#endif
+#endif
 #ifndef GS_ABLATE_FWD
 #define GS_ABLATE_FWD 0   // 1: forward evaluates alpha but blends nothing (tools/build_variants.sh, measurements only)
 #endif
@@ -78,8 +89,8 @@ constexpr float STOP_T = 0.0001f;                  // RAS:458
 #ifndef GS_STATS
 #define GS_STATS 0
 #endif
-__device__ unsigned long long gs_blend_stats_dev[GS_BLEND_STATS];
 #if GS_STATS
+__device__ unsigned long long gs_blend_stats_dev[GS_BLEND_STATS];
 #define GS_STAT(i, n) do { if ((threadIdx.x & 63) == 0) atomicAdd(&gs_blend_stats_dev[i], (unsigned long long)(n)); } while (0)
 #else
 #define GS_STAT(i, n) do { } while (0)
@@ -543,7 +554,7 @@ __global__ __launch_bounds__(BLEND_THREADS, GS_FWD_MIN_WAVES) void blend_forward
             }
         }
         __syncthreads();
-        thr = thr + splat(STOP_T * 1.1f * GS_STOP_ROUNDING_BAND * (float)nbuf);
+        thr = thr + splat(STOP_T * 1.1f * GS_STOP_ROUNDING_BAND * (float)nbuf + GS_STOP_THR_SLACK);
         const int walked = kept_base + nbuf;   // list positions of the tile walked so far (this batch included)
         // The blend update of one entry, shared by the group loop and its careful twin below (al = 0 for a skipped pixel makes
         // the update an exact no-op: T*(1-0) = T, C += c*0)
@@ -1148,8 +1159,9 @@ __global__ __launch_bounds__(SMALL_THREADS) void blend_forward_small_kernel(
             }
         }
         __syncthreads();
-        thr += STOP_T * 1.1f * GS_STOP_ROUNDING_BAND * (float)nbuf;
-        const int walked = pos - start;   // (>= the list positions walked so far)
+        thr += STOP_T * 1.1f * GS_STOP_ROUNDING_BAND * (float)nbuf + GS_STOP_THR_SLACK;
+        const int walked = min(pos, end) - start;   // list positions walked so far, this batch included (pos has already moved
+                                                    // BATCH on: past `end` in the last, partial batch)
         // (the one-pixel forms of blend_forward_kernel's `blend`, `careful_entry` and group loop: see there)
         auto blend = [&](int e, const float4 c, float z, float al, float Tn, bool ok) {
             const float wgt = al * T;
@@ -1628,11 +1640,16 @@ int gs_blend_read_stats(uint64_t *counters, int clear, void *stream) {
     GS_REQUIRE(counters != nullptr, "counters");
     hipStream_t s = (hipStream_t)stream;
     GS_CHECK_HIP(hipStreamSynchronize(s));
+#if GS_STATS
     GS_CHECK_HIP(hipMemcpyFromSymbol(counters, HIP_SYMBOL(gs_blend_stats_dev), sizeof(uint64_t) * GS_BLEND_STATS));
     if (clear) {
         const uint64_t zero[GS_BLEND_STATS] = {};
         GS_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(gs_blend_stats_dev), zero, sizeof(zero)));
     }
+#else   // the product build has no counters
+    (void)clear;
+    for (int i = 0; i < GS_BLEND_STATS; ++i) counters[i] = 0;
+#endif
     return GS_STATS;
 }
 

@@ -119,7 +119,13 @@ __device__ __forceinline__ float gs_exp_cr(float xf) {
 #define GS_U24 5.9604644775390625e-8f
 #define GS_BAND_SAFETY (4.0f / 3.0f)
 #define GS_ALPHA_BAND (GS_BAND_SAFETY * GS_U24 * (2.0f * 20.0f + 9.0f))
-#define GS_STOP_ROUNDING_BAND (4.0f * GS_U24)   /* per blended Gaussian */
+// thr itself is an fp32 number near 1e-4 (ulp 2^-37 = 7.3e-12): every `thr += W_k a` rounds by up to half an ulp -- an
+// increment below that is lost altogether -- i.e. by 0.56 u in the units of the rounding term (1.1 STOP u = 6.6e-12), so the
+// term charged per blended Gaussian is 5 u, not the 4 u of the transmittance product alone; the per-batch addition and the
+// subtraction inside gs_stop_bracket round once each: GS_STOP_THR_SLACK (more than two half-ulps) per batch, never taken
+// back.
+#define GS_STOP_ROUNDING_BAND (5.0f * GS_U24)   /* per blended Gaussian: 4 u (two roundings per side) + 1 u (thr's own) */
+#define GS_STOP_THR_SLACK 8.0e-12f              /* per batch */
 __device__ __forceinline__ float gs_stop_weight(float amp, float stop_t) {
     const float H = 1.0f / (1.0f - fminf(amp, 0.99f)) * 1.01f;
     return stop_t * 1.1f * GS_BAND_SAFETY * GS_U24 * (12.0f + 9.0f * H);

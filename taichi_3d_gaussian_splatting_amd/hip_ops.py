@@ -142,7 +142,7 @@ def read_counters(counters: torch.Tensor) -> Tuple[int, ...]:
 class CounterReadback:
     """The frame's sizes (M, K, slot count, depth range) on their way to the host WITHOUT stalling the launch queue.
 
-    Two transports into the same 64 bytes of pinned host memory:
+    Two transports into the same 4 * NUM_COUNTERS = 32 bytes of pinned host memory (read as int32[8] or as uint64[4]):
     * ``start`` / ``wait()``: the counters are copied (or stored by the scan kernel) as int32[NUM_COUNTERS] and an event
       recorded behind them tells the host when;
     * ``next_stamp`` / ``wait(stamp)`` (gs_frame_forward with GsFrame.size_stamp): each size arrives as one 64-bit word
@@ -154,7 +154,9 @@ class CounterReadback:
         self.device = device
         self.event = torch.cuda.Event()
         self._raw, self._stamp = None, 0
-        if os.environ.get("GS_SIZE_STAMPS", "1") != "0":
+        # (GS_HOST_MIRROR=0 -- the development knob of gs_frame_forward that sends the sizes through a copy launch -- excludes
+        # the stamped words, which the scan kernel itself stores: the event form is used then)
+        if os.environ.get("GS_SIZE_STAMPS", "1") != "0" and os.environ.get("GS_HOST_MIRROR", "1") != "0":
             p = ctypes.c_void_p()
             if _lib.load().gs_host_alloc_coherent(4 * NUM_COUNTERS, ctypes.byref(p)) == 0 and p.value:
                 self._raw = p.value

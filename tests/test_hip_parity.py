@@ -853,6 +853,33 @@ def test_long_saturating_chains_against_the_f64_spec():
 CHAIN_GRAD_TOL = 5e-5     # observed 5.3e-6 (features) / 8.2e-6 (positions) against the fp32 oracle, round 3
 
 
+@pytest.mark.parametrize("n,seed", [(131, 31), (137, 32), (150, 33), (259, 34)])
+def test_pixels_that_stop_in_the_last_partial_batch(ops, n, seed):
+    """the four-waves-per-tile forward counted the list positions of the LAST, partial batch as a full
+    batch of 128 when it formed a pixel's stop bracket (the bracket came out narrower than the proven one).  Lists of
+    128 + k (and 256 + k) entries on which pixels stop inside the tail batch: every pixel's count and stop position must be
+    the oracle's, in the four-wave form the library picks for such a grid and in the two-wave form."""
+    from taichi_3d_gaussian_splatting_amd.synthetic import make_scene
+    s_cpu = make_scene(n=n, height=64, width=64, s_min=1.5, s_max=4.0, sh_degree=3, seed=seed)
+    g = torch.Generator().manual_seed(seed + 1)
+    lo = -2.9 if n < 200 else -3.6    # opacity ~0.05-0.11 (~0.027-0.06): the transmittance reaches 1e-4 near the end of the list
+    s_cpu.point_cloud_features[:, 7] = lo + 0.8 * torch.rand(n, generator=g)
+    f = oracle_forward(s_cpu, want_margin=False)
+    tail_first = (n - 1) // 128 * 128
+    stopped = f["acc_alpha"] > 0.9998
+    in_tail = stopped & (f["count"] >= tail_first)
+    report(f"tail_batch.n{n}", pixels=int(stopped.size), stopped=int(stopped.sum()), stopped_in_tail_batch=int(in_tail.sum()),
+           min_count=int(f["count"].min()), max_count=int(f["count"].max()))
+    assert in_tail.sum() >= 200, "the scene no longer stops pixels in the tail batch"
+    s = s_cpu.to("cuda")
+    st = _stages_to_ranges(ops, s, ops.ListLayout(bin_shift=0))
+    for arm in ("four_waves", "two_waves", None):
+        out = ops.blend_forward(st["start"], st["end"], st["payload"], st["attrs"], s.width, s.height, st["layout"], arm=arm)
+        count = out[4].cpu().numpy()
+        assert np.array_equal(count, f["count"]), (arm, int((count != f["count"]).sum()))
+        assert np.abs(out[0].cpu().numpy() - f["image"]).max() <= 5e-6
+
+
 @pytest.mark.parametrize("workload,bin_shift", [("cfg2_100k_800", 0), ("headline_1m_1080p", 0), ("headline_1m_1080p", 1),
                                                 ("headline_1m_1080p", 2), ("cfg3_400k_1080p", 0)])
 def test_forward_and_backward_blend_the_same_pairs(ops, workload, bin_shift):

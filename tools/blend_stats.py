@@ -4,7 +4,7 @@ how many of them run the hit path and with how many live lanes, how often a deci
 by the reference's expression, how many pixel histories are replayed (development tool; run through gpurun).
 
 Needs a counting build of the library:
-    tools/build_variants.sh "stats:-DGS_STATS=1"
+    tools/build_variants.sh "stats:-DGS_TUNING_BUILD=1 -DGS_STATS=1"
     GS_LIB_PATH=variants/libgsplat_hip_stats.so python tools/blend_stats.py [workload]
 """
 import ctypes
@@ -13,6 +13,8 @@ import os
 import sys
 
 import torch
+
+os.environ.setdefault("GS_ALLOW_TUNING_LIB", "1")   # this tool measures a counting build (never the product path)
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -28,7 +30,7 @@ NAMES = ["fwd_entries", "fwd_hit_entries", "fwd_hit_pixels", "fwd_hit_lanes", "f
 def read(clear=True):
     buf = (ctypes.c_uint64 * 16)()
     counting = _lib.load().gs_blend_read_stats(buf, int(clear), None)
-    assert counting == 1, "not a counting build: tools/build_variants.sh 'stats:-DGS_STATS=1' and set GS_LIB_PATH"
+    assert counting == 1, "not a counting build: tools/build_variants.sh 'stats:-DGS_TUNING_BUILD=1 -DGS_STATS=1' and set GS_LIB_PATH"
     return dict(zip(NAMES, list(buf)))
 
 

@@ -1,6 +1,9 @@
 #!/bin/bash
 # Builds differently tuned variants of libgsplat_hip.so into variants/ (development tool for tuning sweeps:
 # GS_LIB_PATH=variants/libgsplat_hip_<tag>.so python tools/stage_bench.py ...).  usage: tools/build_variants.sh "tag:-DFLAG=.. -DFLAG2=.." ...
+# A variant that switches a MEASUREMENT ARM on (GS_STATS, GS_ABLATE_FWD, GS_MFMA_REDUCE, GS_BWD_REDUCE_ARM=0) must also pass
+# -DGS_TUNING_BUILD=1 (the sources refuse to compile otherwise); the library then reports another ABI version and only loads
+# with GS_ALLOW_TUNING_LIB=1 in the environment.
 set -e
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 SRC=$ROOT/taichi_3d_gaussian_splatting_amd/csrc

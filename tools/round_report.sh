@@ -13,7 +13,7 @@ grep -E "passed|failed|\[record\]" $OUT/pytest.log | tail -5
 bash tools/profile.sh $TAG > $OUT/profile.log 2>&1
 # 1b. path statistics of the blend kernels (a counting build of the library: how often the hit path runs, live lanes, how
 #     often a decision is settled by the reference's own expression) at the headline size and on the trained scene
-bash tools/build_variants.sh "stats:-DGS_STATS=1" > $OUT/build_stats.log 2>&1
+bash tools/build_variants.sh "stats:-DGS_TUNING_BUILD=1 -DGS_STATS=1" > $OUT/build_stats.log 2>&1
 GS_LIB_PATH=variants/libgsplat_hip_stats.so python tools/blend_stats.py headline_1m_1080p > $OUT/blend_path_stats.json 2> $OUT/blend_stats.err
 for w in cfg3_400k_1080p cfg4_2m_1080p trained_1080p; do
     GS_LIB_PATH=variants/libgsplat_hip_stats.so python tools/blend_stats.py $w 2>> $OUT/blend_stats.err >> $OUT/blend_path_stats_other_workloads.jsonl
