@@ -288,6 +288,10 @@ int gs_read_counters_async(const int32_t *counters, int32_t *host_counters_pinne
                                    are per-tile lists taken as they are (bin_shift 0, filter 0).  Default (neither flag):
                                    four waves when at most 3840 tiles are rendered -- a grid that cannot fill the chip with two.
                                    Image, depth, counts, state and hit sets are bit-identical between the two forms. */
+#define GS_BLEND_ONE_WAVE 16    /* backward pass: the one-wave-per-tile kernel (four pixels per lane, cross-lane sums through
+                                   LDS) whenever the lists are per-tile lists taken as they are.  Default (no flag): larger grids
+                                   than the four-wave form's.  Decisions, the |grad uv| image and debug hashes are bit-identical
+                                   to the two-wave kernel's; slot sums add the same per-pixel terms in another order. */
 int gs_blend_forward(const int32_t *bin_start, const int32_t *bin_end, const int32_t *payload,
                      const float *attrs, int width, int height, int tile_row_begin,
                      int tile_row_step, int tile_row_end, int bin_shift, int filter, float *image,

@@ -71,11 +71,13 @@ constexpr float STOP_T = 0.0001f;                  // RAS:458
 // macro of the variant builds used to be called GS_BWD_REDUCE -- since the frame entry points, the name of a stage bit
 // in include/gsplat_hip.h with the value 2, so BOTH kernels have been built with pairs since then and every round-4
 // measurement is of that build; the switch is now GS_BWD_REDUCE_ARM and the direct kernel's default says 2.)
+// Round 6: 3 = through LDS (the default now: see the REDUCE == 3 arm), 4 = the same with the read-back deferred to the next
+// hit entry (measured slower: the kernel is not waiting for the LDS, it is short of LDS cycles).
 #ifndef GS_BWD_REDUCE_STAGED
-#define GS_BWD_REDUCE_STAGED 2
+#define GS_BWD_REDUCE_STAGED 3
 #endif
 #ifndef GS_BWD_REDUCE_DIRECT
-#define GS_BWD_REDUCE_DIRECT 2
+#define GS_BWD_REDUCE_DIRECT 3
 #endif
 #ifdef GS_BWD_REDUCE_ARM      // (one switch for both kernels: tools/build_variants.sh)
 #undef GS_BWD_REDUCE_STAGED
@@ -99,6 +101,7 @@ __device__ unsigned long long gs_blend_stats_dev[GS_BLEND_STATS];
 #define GS_FWD_MIN_WAVES 6   // second argument of __launch_bounds__ of the forward kernel: six waves per SIMD (80 registers).  Seven
                              // (72 registers) is met only with 24-32 B of scratch for no gain (0.272 vs 0.270 ms at the headline size)
 #endif
+constexpr int GS_TR_ROWS = 11, GS_TR_STRIDE = 68;   // backward, REDUCE 3: rows of the LDS transpose and their distance in floats
 constexpr int GROUP = GS_GROUP_FWD > GS_GROUP_BWD ? (GS_GROUP_FWD > 4 ? GS_GROUP_FWD : 4) : (GS_GROUP_BWD > 4 ? GS_GROUP_BWD : 4);
                               // padding granularity of a staged batch (BATCH % GROUP == 0; covers both group sizes)
 constexpr int GROUP_FWD = GS_GROUP_FWD;  // list entries evaluated together in the forward blend loop
@@ -779,6 +782,9 @@ __global__ __launch_bounds__(BLEND_THREADS, GS_BWD_MIN_WAVES) void blend_backwar
     __shared__ __attribute__((aligned(16))) int s_j[BATCH];
     __shared__ int s_o[BATCH];
     __shared__ float s_acc[BATCH][GS_ACC_STRIDE];  // [entry][value]; value 10 = pixel count (as a float)
+    constexpr int REDUCE_ = STAGED ? GS_BWD_REDUCE_STAGED : GS_BWD_REDUCE_DIRECT;
+    // REDUCE 3: the cross-lane sums go THROUGH LDS (gs_lds_reduce11 below): per wave eleven rows of 64 partials, 68 floats apart
+    __shared__ __attribute__((aligned(16))) float s_tr[REDUCE_ >= 3 ? BLEND_THREADS / GS_WAVE : 1][REDUCE_ >= 3 ? GS_TR_ROWS * GS_TR_STRIDE : 4];
     __shared__ int s_max[BLEND_THREADS / GS_WAVE];
     __shared__ int s_cnt[2 * FILL_PER_THREAD], s_next[1];
     const int tw = width / GS_TILE_WIDTH, th = height / GS_TILE_HEIGHT;
@@ -819,6 +825,17 @@ __global__ __launch_bounds__(BLEND_THREADS, GS_BWD_MIN_WAVES) void blend_backwar
     // destination of this lane's pair-reduce results (gs_wave_reduce12_pair): lanes 7 and 15 of each row
     const bool pair_tail = (lane & 7) == 7, pair_b_sel = (row >> 1) != 0;
     const int pair_vi = 2 * ((lane >> 3) & 1) + (row & 1);
+    // (REDUCE 3) lane 4 n + p reads floats [16 p, 16 p + 16) of row n; lanes 44.. read row 10 again and add nothing
+    const int tr_read = min(lane >> 2, GS_TR_ROWS - 1) * GS_TR_STRIDE + 16 * (lane & 3);
+    const bool tr_owner = (lane & 3) == 0 && lane < 4 * GS_TR_ROWS;
+    // (REDUCE 4) sixteen fetched values -> this lane's quarter of row n -> the wave's total of value n -> the entry's row
+    auto tr_sum = [&](const float4 a, const float4 b, const float4 c4, const float4 d, int entry, bool live) {
+        float t = (((a.x + a.y) + (a.z + a.w)) + ((b.x + b.y) + (b.z + b.w))) +
+                  (((c4.x + c4.y) + (c4.z + c4.w)) + ((d.x + d.y) + (d.z + d.w)));
+        t += gs_dpp<0xb1, 0xf, 0xf>(t);   // quad_perm [1,0,3,2]
+        t += gs_dpp<0x4e, 0xf, 0xf>(t);   // quad_perm [2,3,0,1]
+        if (tr_owner && live) atomicAdd(&s_acc[entry][lane >> 2], t);
+    };
     float pend_x[12];
     int pend_k = 0;
     int pend = 0;   // wave-uniform: 1 while a hit entry's partials are waiting in pend_x (REDUCE == 2)
@@ -945,6 +962,20 @@ __global__ __launch_bounds__(BLEND_THREADS, GS_BWD_MIN_WAVES) void blend_backwar
 #endif
                 // The twelve per-lane partial sums of this entry (in-lane sums over the lane's two pixels), in the order of
                 // the accumulator record: v0, v1 (dL/dmu), c00, c01, c11 (2 dL/dcov), gr, gg, gb (dL/drgb), w, |v|, count, 0.
+                // (REDUCE 4) the PREVIOUS hit entry's rows are fetched now and summed behind this entry's arithmetic: nothing waits
+                // for the LDS.  (The first hit entry of a round fetches rows that nobody adds.)
+                // (the colour row FIRST: LDS reads return in order, and the arithmetic below waits for this one only.  Read as all
+                // 16 bytes -- volatile, or the compiler trims the unused opacity off and issues ds_read_b96, which takes the LDS
+                // eight cycles where ds_read_b128 takes four; the kernel is short of LDS cycles since its reduction moved there)
+                const gs_v4f cv = *reinterpret_cast<const volatile gs_v4f *>(&s_c[k + i]);
+                const float4 c = make_float4(cv.x, cv.y, cv.z, cv.w);
+                float4 qa, qb, qc, qd;
+                if constexpr (REDUCE == 4) {
+                    __builtin_amdgcn_wave_barrier();
+                    const float4 *src = reinterpret_cast<const float4 *>(&s_tr[tid >> 6][0] + tr_read);
+                    qa = src[0]; qb = src[1]; qc = src[2]; qd = src[3];
+                    __builtin_amdgcn_wave_barrier();   // (this entry's stores stay below these reads)
+                }
                 v2f pq[11];   // the eleven packed (two-pixel) partials of this entry
                 {
                     // alpha = 0 for a pixel that is not hit makes its whole update an exact no-op
@@ -956,7 +987,6 @@ __global__ __launch_bounds__(BLEND_THREADS, GS_BWD_MIN_WAVES) void blend_backwar
                     const v2f inv1m = {__builtin_amdgcn_rcpf(one_m.x), __builtin_amdgcn_rcpf(one_m.y)};
                     T = T * inv1m;  // RAS:643, T_i = T_{i+1} / (1 - alpha_i)
                     const v2f aT = al * T;
-                    const float4 c = s_c[k + i];
                     const v2f gr = aT * Gr, gg = aT * Gg, gb = aT * Gb;
                     // dL/dalpha = sum_c (c_c T - w_c/(1-alpha)) G_c = T (c.G) - S/(1-alpha)       (RAS:652-657)
                     const v2f cg = fma2(splat(c.z), Gb, fma2(splat(c.y), Gg, splat(c.x) * Gr));
@@ -984,9 +1014,14 @@ __global__ __launch_bounds__(BLEND_THREADS, GS_BWD_MIN_WAVES) void blend_backwar
                 }
                 // in-lane sums over the lane's two pixels (inline asm: the vectoriser would otherwise shuffle the operands
                 // into v_pk_add_f32 pairs with more moves than it saves adds)
+                // (value 9 -- the two square roots -- is added by the compiler: a transcendental result needs a wait state before
+                // another VALU instruction reads it, and the hazard recogniser does not look inside an asm statement: scheduled
+                // straight behind v_sqrt_f32 the asm form read a stale register once in ~30 hit entries, REDUCE 4's schedule)
                 auto partials_of_entry = [&](float (&x)[12]) {
 #pragma unroll
-                    for (int n = 0; n < 11; ++n) asm("v_add_f32 %0, %1, %2" : "=v"(x[n]) : "v"(pq[n].x), "v"(pq[n].y));
+                    for (int n = 0; n < 11; ++n)
+                        if (n != 9) asm("v_add_f32 %0, %1, %2" : "=v"(x[n]) : "v"(pq[n].x), "v"(pq[n].y));
+                    x[9] = pq[9].x + pq[9].y;
                     x[11] = 0.f;
                 };
                 if constexpr (REDUCE == 0) {   // measurement only: what the kernel costs without the cross-lane sums
@@ -1020,6 +1055,44 @@ __global__ __launch_bounds__(BLEND_THREADS, GS_BWD_MIN_WAVES) void blend_backwar
                         pend_k = k + i;
                         pend = 1;
                     }
+                } else if constexpr (REDUCE == 3) {
+                    // The LDS pipe instead of the vector unit (tools/ubench/valu_exec_mask.hip: a permlane swap costs the SIMD 3.5 ns,
+                    // a DPP add 1.9, a plain add 1.1 -- the pair reduce-scatter is 53 ns of VALU time per hit entry, a quarter of the
+                    // kernel -- while the LDS pipe idles 80 % of the time): every lane stores its eleven partials as eleven rows of
+                    // 64, lane 4 n + p reads the p-th quarter of row n back (four 16-byte reads, conflict-free with rows 68 floats
+                    // apart), adds its sixteen values in a fixed tree, two quad-permute adds combine the quarters, and lane 4 n adds
+                    // the wave's total of value n to the entry's row (the two waves of the tile meet there: a + b = b + a).  A wave's
+                    // LDS operations execute in program order, so the reads see the stores without a barrier.
+                    float x[12];
+                    partials_of_entry(x);
+                    float *rows = &s_tr[tid >> 6][0];
+#pragma unroll
+                    for (int n = 0; n < GS_TR_ROWS; ++n) rows[n * GS_TR_STRIDE + lane] = x[n];
+                    __builtin_amdgcn_wave_barrier();   // (no instruction: the compiler keeps the reads below the stores)
+                    const float4 *src = reinterpret_cast<const float4 *>(rows + tr_read);
+                    const float4 a = src[0], b = src[1], c4 = src[2], d = src[3];
+                    float t = (((a.x + a.y) + (a.z + a.w)) + ((b.x + b.y) + (b.z + b.w))) +
+                              (((c4.x + c4.y) + (c4.z + c4.w)) + ((d.x + d.y) + (d.z + d.w)));
+                    t += gs_dpp<0xb1, 0xf, 0xf>(t);   // quad_perm [1,0,3,2]
+                    t += gs_dpp<0x4e, 0xf, 0xf>(t);   // quad_perm [2,3,0,1]
+                    __builtin_amdgcn_wave_barrier();   // (the next entry's stores stay below these reads)
+                    if (tr_owner) atomicAdd(&s_acc[k + i][lane >> 2], t);
+                } else if constexpr (REDUCE == 4) {
+                    // REDUCE 3 with the LDS round trip taken off the wave's critical path: an entry's rows are stored here and read
+                    // back at the top of the NEXT hit entry's path (above) -- one buffer is enough, the wave's LDS operations execute
+                    // in program order: the fetch of the old rows is ahead of these stores -- or by the drain behind the round's loop.
+                    float x[12];
+                    partials_of_entry(x);
+                    // (an empty asm that "rewrites" one fetched value once this entry's partials exist: the compiler cannot start
+                    // the sum -- and wait for the fetch -- before the arithmetic above)
+                    asm volatile("" : "+v"(qa.x), "+v"(qb.x), "+v"(qc.x), "+v"(qd.x) : "v"(x[0]), "v"(x[10]));
+                    tr_sum(qa, qb, qc, qd, pend_k, __builtin_amdgcn_readfirstlane(pend) != 0);
+                    float *rows = &s_tr[tid >> 6][0];
+#pragma unroll
+                    for (int n = 0; n < GS_TR_ROWS; ++n) rows[n * GS_TR_STRIDE + lane] = x[n];
+                    __builtin_amdgcn_wave_barrier();
+                    pend_k = k + i;
+                    pend = 1;
                 } else {
                     float x[12];
                     partials_of_entry(x);
@@ -1042,6 +1115,12 @@ __global__ __launch_bounds__(BLEND_THREADS, GS_BWD_MIN_WAVES) void blend_backwar
 #endif
                 }
             }
+        }
+        if (REDUCE == 4 && __builtin_amdgcn_readfirstlane(pend)) {   // the round's last hit entry is still in its rows
+            const float4 *src = reinterpret_cast<const float4 *>(&s_tr[tid >> 6][0] + tr_read);
+            const float4 qa = src[0], qb = src[1], qc = src[2], qd = src[3];
+            tr_sum(qa, qb, qc, qd, pend_k, true);
+            pend = 0;
         }
         if (REDUCE == 2 && __builtin_amdgcn_readfirstlane(pend)) {   // the round's odd hit entry
             float t0, t1, t2;
@@ -1084,6 +1163,286 @@ __global__ __launch_bounds__(BLEND_THREADS, GS_BWD_MIN_WAVES) void blend_backwar
     if (DEBUG) {
         debug_hits[2 * p] = dc0; debug_hits[2 * p + 1] = dh0;
         debug_hits[2 * p + 2] = dc1; debug_hits[2 * p + 3] = dh1;
+    }
+}
+
+// ------------------------------------------------------------------------------- backward, ONE wave per tile
+// Per-tile lists taken as they are (bin_shift 0, no filter: the walked lists the forward pass writes out, or the
+// reference's own keys) on grids large enough to fill the chip.  One wave64 owns the whole 16 x 16 tile -- FOUR pixels per
+// lane: lane (c, r) holds columns 2c, 2c + 1 of rows r and r + 8 ("set A" and "set B", each a packed pair exactly as a lane
+// of the two-wave kernel holds it) -- because what the two-wave kernel pays PER WAVE AND ENTRY is then paid once per tile and
+// entry:
+//   * the cross-lane sums of a hit entry (a quarter of the two-wave kernel's time): one reduction per (tile, entry) instead
+//     of one per half-tile, and no combining of two waves' totals (plain LDS stores instead of ds_add_f32, no zero-fill);
+//   * the two 16-byte broadcast reads of the staged record, the colour row, the x-parts of m = conic @ d (the two sets share
+//     their columns), every scalar decision and branch of the group loop;
+//   * and a lone wave needs no workgroup barrier at all: its LDS operations execute in program order.
+// The cross-lane sums go through LDS (the REDUCE 3 arm of the two-wave kernel: stores of eleven rows, four 16-byte reads per
+// lane, a fixed tree of fifteen adds, two quad-permute adds), which costs the vector unit 23 ns per hit entry where the
+// permlane / DPP reduce-scatter costs 58 (tools/ubench/valu_exec_mask.hip) -- and with one wave per tile the LDS pipe has
+// the room (two waves per tile doing the same keep it 80 % busy: profiles/r06_backward_arms.md).
+// Per pixel the arithmetic is the two-wave kernel's, operation by operation: decisions, the |grad uv| image and the debug
+// hashes are bit-identical; a slot's sums add the same per-pixel terms in another order.
+constexpr int WIDE_BATCH = 64;   // staged entries per round (one per lane)
+constexpr int WIDE_GROUP = 2;    // entries evaluated together
+#ifndef GS_BWD_WIDE_MIN_WAVES
+#define GS_BWD_WIDE_MIN_WAVES 4
+#endif
+#ifndef GS_BWD_WIDE_PRIO
+#define GS_BWD_WIDE_PRIO 1   // 0: every tile at the default priority (A/B)
+#endif
+struct WideSet {   // one packed pixel pair of a lane
+    v2f T, S, Gr, Gg, Gb, mag_u, mag_v;
+    int last0, last1;
+    float py;
+    unsigned dh0, dh1, dc0, dc1;
+};
+template <bool DEBUG>
+__global__ __launch_bounds__(GS_WAVE, GS_BWD_WIDE_MIN_WAVES) void blend_backward_wide_kernel(
+    const int32_t *__restrict__ tile_start, const int32_t *__restrict__ payload, const float4 *__restrict__ attrs,
+    const float *__restrict__ grad_image, const float *__restrict__ acc_alpha, const int32_t *__restrict__ last_effective,
+    int width, int height, int row_begin, int row_step, const int32_t *__restrict__ slot_offsets,
+    float4 *__restrict__ partials, uint8_t *__restrict__ slot_flags, float *__restrict__ magnitude_image,
+    uint32_t *__restrict__ debug_hits, const int32_t *__restrict__ tile_order) {
+    __shared__ float4 s_p[WIDE_BATCH], s_q[WIDE_BATCH], s_c[WIDE_BATCH];   // (gs_stage_backward)
+    __shared__ int s_o[WIDE_BATCH];
+    __shared__ __attribute__((aligned(16))) float s_acc[WIDE_BATCH][GS_ACC_STRIDE];   // [entry][value], written once per hit entry
+    __shared__ __attribute__((aligned(16))) float s_tr[GS_TR_ROWS * GS_TR_STRIDE];   // the rows of the LDS transpose
+    const int tw = width / GS_TILE_WIDTH, th = height / GS_TILE_HEIGHT;
+    const TileCoord tc = owned_tile(tw, row_begin, row_step, tile_order);
+    // A tile is ONE wave's serial chain here, and the longest chains (2.4 x the mean at the headline scene) are what the launch
+    // lasts if they have to share their SIMD's issue slots evenly with three lighter waves.  Tiles are dispatched longest walk
+    // first (tile_order), so the position in the grid is the work estimate: the first eighth of the grid runs at priority 3,
+    // the next eighth at 2, the next quarter at 1 -- the long chains finish early and the short ones fill in behind them.
+#if GS_BWD_WIDE_PRIO
+    if (tile_order != nullptr) {
+        const unsigned b = blockIdx.x, n = gridDim.x;
+        if (8 * b < n) __builtin_amdgcn_s_setprio(3);
+        else if (4 * b < n) __builtin_amdgcn_s_setprio(2);
+        else if (2 * b < n) __builtin_amdgcn_s_setprio(1);
+    }
+#endif
+    const int lane = threadIdx.x;
+    const int pu = tc.tile_u * GS_TILE_WIDTH + 2 * (lane & 7);   // left pixel of both pairs
+    const int pv = tc.tile_v * GS_TILE_HEIGHT + (lane >> 3);     // row of set A; set B: eight rows below
+    // (pixel index of set h, recomputed where it is used -- at both ends of the kernel -- rather than kept in registers)
+    auto pixel_of = [&](int h) { return (size_t)(pv + 8 * h) * width + pu; };
+    const int start = tile_start[tc.tile_id];
+    const v2f px = {(float)pu + 0.5f, (float)pu + 1.5f};
+    WideSet st[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const size_t p = pixel_of(h);
+        st[h].py = (float)(pv + 8 * h) + 0.5f;
+        st[h].last0 = last_effective[p]; st[h].last1 = last_effective[p + 1];
+        st[h].T = (v2f){1.0f - acc_alpha[p], 1.0f - acc_alpha[p + 1]};
+        st[h].S = splat(0.f);
+        const float *gi = grad_image + 3 * p;
+        st[h].Gr = (v2f){gi[0], gi[3]}; st[h].Gg = (v2f){gi[1], gi[4]}; st[h].Gb = (v2f){gi[2], gi[5]};
+        st[h].mag_u = splat(0.f); st[h].mag_v = splat(0.f);
+        st[h].dh0 = st[h].dh1 = st[h].dc0 = st[h].dc1 = 0u;
+    }
+    // no pixel of the tile touches a list position at or beyond the tile-wide max of `last`
+    int mx = max(max(st[0].last0, st[0].last1), max(st[1].last0, st[1].last1));
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) mx = max(mx, __shfl_xor(mx, d, GS_WAVE));
+    const int end = __builtin_amdgcn_readfirstlane(mx);
+    // the LDS transpose (see the REDUCE 3 arm of blend_backward_kernel): lane 4 n + p reads floats [16 p, 16 p + 16) of row n
+    const int tr_read = min(lane >> 2, GS_TR_ROWS - 1) * GS_TR_STRIDE + 16 * (lane & 3);
+    const bool tr_owner = (lane & 3) == 0 && lane < 4 * GS_TR_ROWS;
+
+    int pos = end - 1;   // next list position to stage, walking down to `start`
+    int o_next = pos - lane >= start ? payload[pos - lane] : 0;   // (the next round's list entries are fetched a round ahead)
+    while (pos >= start) {
+        const int nbuf = min(WIDE_BATCH, pos - start + 1);
+        const int batch_first = pos;   // staged entry k sits at list position batch_first - k
+        {
+            const int o = o_next;
+            const bool valid = lane < nbuf;
+            float4 r0, r1, r2, r3;
+            if (valid) {
+                const float4 *g = attrs + 4 * (size_t)o;
+                r0 = g[0]; r1 = g[1]; r2 = g[2]; r3 = g[3];
+            }
+            pos -= WIDE_BATCH;
+            o_next = pos - lane >= start ? payload[pos - lane] : 0;
+            float4 P = make_float4(0.f, 0.f, 0.f, 0.f), Q = P, colour = P;   // (inert padding: amplitude 0 -> alpha 0, never a hit)
+            if (valid) gs_stage_backward(r0, r1, r2, r3, P, Q, colour);
+            __builtin_amdgcn_wave_barrier();   // (the previous round's flush has read its rows: program order)
+            s_p[lane] = P; s_q[lane] = Q; s_c[lane] = colour;
+            s_o[lane] = o;
+            __builtin_amdgcn_wave_barrier();
+        }
+        unsigned long long hit_entries = 0ull;   // wave-uniform: staged entries whose row of s_acc holds this round's sums
+        for (int k = 0; k < nbuf; k += WIDE_GROUP) {
+            // group evaluation: the LDS reads and exponentials of the group's entries are independent and overlap
+            v2f alpha[WIDE_GROUP][2], m0[WIDE_GROUP][2], m1[WIDE_GROUP][2];
+            unsigned long long ma0[WIDE_GROUP][2], ma1[WIDE_GROUP][2];
+            unsigned bracketed = 0u;   // bit 2 i + h: entry k + i has an alpha of set h inside the bracket around 1/255
+#pragma unroll
+            for (int i = 0; i < WIDE_GROUP; ++i) {
+                const float4 P = s_p[k + i], Q = s_q[k + i];
+                // UTL:336-339, operation by operation as gs_pair_alpha_backward; the products with dx serve both sets
+                const v2f dx = px - splat(P.x);
+                const v2f ax = splat(P.z) * dx, bx = splat(Q.x) * dx;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const float dy = st[h].py - P.y;
+                    m0[i][h] = ax + splat(Q.x * dy);
+                    m1[i][h] = bx + splat(P.w * dy);
+                    const v2f sq = dx * m0[i][h] + splat(dy) * m1[i][h];
+                    const v2f e2 = sq * splat(-0.5f * GS_LOG2E);
+                    alpha[i][h] = (v2f){__builtin_amdgcn_exp2f(e2.x), __builtin_amdgcn_exp2f(e2.y)} * splat(Q.y);
+                    ma0[i][h] = gs_ballot(alpha[i][h].x >= EPS_LO); ma1[i][h] = gs_ballot(alpha[i][h].y >= EPS_LO);
+                    if ((ma0[i][h] | ma1[i][h]) != 0ull &&
+                        ((ma0[i][h] ^ gs_ballot(alpha[i][h].x >= EPS_HI)) | (ma1[i][h] ^ gs_ballot(alpha[i][h].y >= EPS_HI))) != 0ull)
+                        bracketed |= 1u << (2 * i + h);
+                }
+            }
+            if (bracketed != 0u) {   // rare: the reference's BACKWARD expression decides (as in blend_backward_kernel)
+#pragma clang loop unroll(disable)
+                for (int b = 0; b < 2 * WIDE_GROUP; ++b) {
+                    if (((bracketed >> b) & 1u) == 0u) continue;
+                    const int e = k + (b >> 1), hsel = b & 1;
+                    v2f ex, mm0, mm1;
+                    const float4 Q = s_q[e];
+                    const float pyh = hsel ? st[1].py : st[0].py;
+                    const v2f al = gs_pair_alpha_backward(s_p[e], Q, px, pyh, ex, mm0, mm1);
+                    bool r0 = al.x >= EPS_ALPHA, r1 = al.y >= EPS_ALPHA;
+                    const bool in0 = al.x >= EPS_LO && al.x < EPS_HI, in1 = al.y >= EPS_LO && al.y < EPS_HI;
+                    if (gs_ballot(in0 || in1) != 0ull) {
+                        const float opacity = s_c[e].w;
+#pragma clang loop unroll(disable)
+                        for (int c = 0; c < 2; ++c) {
+                            const float exact = gs_alpha_reference(c ? ex.y : ex.x, Q.w, opacity);
+                            if (c ? in1 : in0) { if (c) r1 = exact >= EPS_ALPHA; else r0 = exact >= EPS_ALPHA; }
+                        }
+                    }
+                    const unsigned long long mr0 = gs_ballot(r0), mr1 = gs_ballot(r1);
+#pragma unroll
+                    for (int i = 0; i < WIDE_GROUP; ++i)
+#pragma unroll
+                        for (int h = 0; h < 2; ++h)
+                            if (2 * i + h == b) { ma0[i][h] = mr0; ma1[i][h] = mr1; }
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < WIDE_GROUP; ++i) {
+                if ((ma0[i][0] | ma1[i][0] | ma0[i][1] | ma1[i][1]) == 0ull) continue;   // wave-uniform: no pixel of the tile is touched
+                const int jj = batch_first - (k + i);
+                unsigned long long mh0[2], mh1[2];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {   // RAS:618 (effective range)
+                    mh0[h] = ma0[i][h] & gs_ballot(jj < st[h].last0);
+                    mh1[h] = ma1[i][h] & gs_ballot(jj < st[h].last1);
+                }
+                if ((mh0[0] | mh1[0] | mh0[1] | mh1[1]) == 0ull) continue;
+                const float4 c = s_c[k + i];
+                // the eleven per-lane partial sums of this entry over the lane's four pixels, in the order of the accumulator
+                // record: v0, v1 (dL/dmu), c00, c01, c11 (2 dL/dcov), gr, gg, gb (dL/drgb), w, |v|, count
+                float xs[2][GS_TR_ROWS];   // per set: in-lane sums over its pixel pair
+                const bool any_a = (mh0[0] | mh1[0]) != 0ull, any_b = (mh0[1] | mh1[1]) != 0ull;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    if (!(h ? any_b : any_a)) continue;   // wave-uniform: this half of the tile is not touched
+                    WideSet &w_ = st[h];
+                    const bool hit0 = __builtin_amdgcn_inverse_ballot_w64(mh0[h]), hit1 = __builtin_amdgcn_inverse_ballot_w64(mh1[h]);
+                    // (the two-wave kernel's hit path, operation by operation)
+                    const v2f hm = {hit0 ? 1.f : 0.f, hit1 ? 1.f : 0.f};
+                    const v2f al = {hit0 ? __builtin_amdgcn_fmed3f(alpha[i][h].x, 0.f, CLAMP_ALPHA) : 0.f,
+                                    hit1 ? __builtin_amdgcn_fmed3f(alpha[i][h].y, 0.f, CLAMP_ALPHA) : 0.f};
+                    const v2f one_m = splat(1.f) - al;
+                    const v2f inv1m = {__builtin_amdgcn_rcpf(one_m.x), __builtin_amdgcn_rcpf(one_m.y)};
+                    w_.T = w_.T * inv1m;  // RAS:643
+                    const v2f aT = al * w_.T;
+                    const v2f gr = aT * w_.Gr, gg = aT * w_.Gg, gb = aT * w_.Gb;
+                    const v2f cg = fma2(splat(c.z), w_.Gb, fma2(splat(c.y), w_.Gg, splat(c.x) * w_.Gr));
+                    const v2f dLda = fma2(w_.T, cg, -(w_.S * inv1m)) * hm;   // RAS:652-657
+                    w_.S = fma2(cg, aT, w_.S);
+                    const v2f wv = dLda * alpha[i][h];
+                    const v2f v0 = wv * m0[i][h], v1 = wv * m1[i][h];   // UTL:343
+                    w_.mag_u = w_.mag_u + (v2f){__builtin_fabsf(v0.x), __builtin_fabsf(v0.y)};
+                    w_.mag_v = w_.mag_v + (v2f){__builtin_fabsf(v1.x), __builtin_fabsf(v1.y)};
+                    const v2f c00 = v0 * m0[i][h], c01 = v0 * m1[i][h], c11 = v1 * m1[i][h];   // UTL:345-346
+                    const v2f n2 = fma2(v1, v1, v0 * v0);
+                    const v2f nv = {__builtin_amdgcn_sqrtf(n2.x), __builtin_amdgcn_sqrtf(n2.y)};
+                    if (DEBUG) {
+                        const unsigned hv = (unsigned)(s_o[k + i] + 1) * GS_HASH_MUL;
+                        w_.dc0 += hit0 ? 1u : 0u; w_.dh0 += hit0 ? hv : 0u;
+                        w_.dc1 += hit1 ? 1u : 0u; w_.dh1 += hit1 ? hv : 0u;
+                    }
+                    const v2f pq[GS_TR_ROWS] = {v0, v1, c00, c01, c11, gr, gg, gb, wv, nv, hm};
+                    // (inline asm: left to itself the vectoriser shuffles the operands into v_pk_add_f32 pairs -- fifteen moves for
+                    // five packed adds; the leading s_nop covers the transcendental results of value 9, which the hazard
+                    // recogniser cannot see an asm statement read)
+#pragma unroll
+                    for (int n = 0; n < GS_TR_ROWS; ++n) {
+                        if (n == 9) asm("s_nop 0\n\tv_add_f32 %0, %1, %2" : "=v"(xs[h][n]) : "v"(pq[n].x), "v"(pq[n].y));
+                        else asm("v_add_f32 %0, %1, %2" : "=v"(xs[h][n]) : "v"(pq[n].x), "v"(pq[n].y));
+                    }
+                }
+                // cross-lane sums through LDS: eleven rows of 64 partials (a lane's four pixels in the fixed order (A.x + A.y) +
+                // (B.x + B.y)), lane 4 n + p adds the p-th quarter of row n, two quad-permute adds combine the quarters, lane
+                // 4 n stores the tile's total of value n in the entry's row
+                if (any_a && any_b) {
+#pragma unroll
+                    for (int n = 0; n < GS_TR_ROWS; ++n) {
+                        float both;
+                        asm("v_add_f32 %0, %1, %2" : "=v"(both) : "v"(xs[0][n]), "v"(xs[1][n]));
+                        s_tr[n * GS_TR_STRIDE + lane] = both;
+                    }
+                } else if (any_a) {
+#pragma unroll
+                    for (int n = 0; n < GS_TR_ROWS; ++n) s_tr[n * GS_TR_STRIDE + lane] = xs[0][n];
+                } else {
+#pragma unroll
+                    for (int n = 0; n < GS_TR_ROWS; ++n) s_tr[n * GS_TR_STRIDE + lane] = xs[1][n];
+                }
+                __builtin_amdgcn_wave_barrier();
+                const float4 *src = reinterpret_cast<const float4 *>(s_tr + tr_read);
+                const float4 a = src[0], b4 = src[1], c4 = src[2], d4 = src[3];
+                float t = (((a.x + a.y) + (a.z + a.w)) + ((b4.x + b4.y) + (b4.z + b4.w))) +
+                          (((c4.x + c4.y) + (c4.z + c4.w)) + ((d4.x + d4.y) + (d4.z + d4.w)));
+                t += gs_dpp<0xb1, 0xf, 0xf>(t);   // quad_perm [1,0,3,2]
+                t += gs_dpp<0x4e, 0xf, 0xf>(t);   // quad_perm [2,3,0,1]
+                __builtin_amdgcn_wave_barrier();
+                if (tr_owner) s_acc[k + i][lane >> 2] = t;
+                hit_entries |= 1ull << (k + i);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        // flush: lane k owns staged entry k -> one 48-B store into the (Gaussian, tile) slot
+        if ((hit_entries >> lane) & 1ull) {
+            const float4 *Sa = reinterpret_cast<const float4 *>(&s_acc[lane][0]);
+            float4 r0 = Sa[0], r1 = Sa[1], r2 = Sa[2];
+            if (r2.z > 0.f) {
+                const float4 a = s_p[lane];
+                int t0u, t1u, t0v, t1v;
+                gs_tile_box(a.x, a.y, s_q[lane].z, tw, th, t0u, t1u, t0v, t1v);
+                const int dst_slot = slot_offsets[s_o[lane]] + (t1v - t0v) * (tc.tile_u - t0u) + (tc.tile_v - t0v);
+                float4 *dst = partials + 3 * (size_t)dst_slot;
+                r0.z *= 0.5f; r0.w *= 0.5f; r1.x *= 0.5f;  // dg/dcov = 0.5 g (m m^T)
+                r2.x *= (1.f - s_c[lane].w);               // dL/dlogit = (1 - opacity) * sum(w)
+                r2.z = __builtin_bit_cast(float, (int)r2.z);  // pixel count: float sum -> int32 bits (layout of `acc`)
+                r2.w = 0.f;
+                dst[0] = r0;
+                dst[1] = r1;
+                dst[2] = r2;
+                slot_flags[dst_slot] = 1;
+            }
+        }
+    }
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const size_t p = pixel_of(h);
+        magnitude_image[2 * p] = st[h].mag_u.x;
+        magnitude_image[2 * p + 1] = st[h].mag_v.x;
+        magnitude_image[2 * p + 2] = st[h].mag_u.y;
+        magnitude_image[2 * p + 3] = st[h].mag_v.y;
+        if (DEBUG) {
+            debug_hits[2 * p] = st[h].dc0; debug_hits[2 * p + 1] = st[h].dh0;
+            debug_hits[2 * p + 2] = st[h].dc1; debug_hits[2 * p + 3] = st[h].dh1;
+        }
     }
 }
 
@@ -1784,8 +2143,14 @@ int gs_blend_backward_split(const int32_t *bin_start, const int32_t *payload, co
                            bin_shift, tile_order, reinterpret_cast<uint4 *>(slot_flags), zero_wgs ? (long long)flag_bytes : 0LL);
         GS_CHECK_LAUNCH();
     }
-    const bool four_waves = !staged && !(flags & GS_BLEND_TWO_WAVES) &&
+    const bool four_waves = !staged && !(flags & (GS_BLEND_TWO_WAVES | GS_BLEND_ONE_WAVE)) &&
                             ((flags & GS_BLEND_FOUR_WAVES) || tw * rows <= GS_SMALL_GRID_TILES);
+    // per-tile lists on a grid that fills the chip: one wave per tile, four pixels per lane (blend_backward_wide_kernel)
+    // (GS_BWD_ONE_WAVE=1: the library's own choice on large grids, A/B knob.  Measured at the headline size, same box: two
+    // waves per tile with the LDS reduction 0.400 ms, one wave per tile 0.408, two waves with the register reduce-scatter
+    // 0.423: profiles/r06_backward_arms.md)
+    static const bool wide_default = getenv("GS_BWD_ONE_WAVE") && atoi(getenv("GS_BWD_ONE_WAVE")) == 1;
+    const bool one_wave = !staged && !four_waves && ((flags & GS_BLEND_ONE_WAVE) || (!(flags & GS_BLEND_TWO_WAVES) && wide_default));
     if (four_waves) {
         // several workgroups per tile when the forward pass left its boundary states (see blend_backward_small_kernel)
         const bool can_split = image != nullptr && boundary_states != nullptr && split_workspace != nullptr;
@@ -1807,6 +2172,15 @@ int gs_blend_backward_split(const int32_t *bin_start, const int32_t *payload, co
                                grad_image, acc_alpha, last_effective, width, height, tile_row_begin, tile_row_step,
                                slot_offsets, p4, slot_flags, magnitude_image, debug_pixel_hits, tile_order, split, image, b4,
                                e4, counters, parts);
+    } else if (one_wave) {
+        if (debug_pixel_hits != nullptr)
+            hipLaunchKernelGGL(blend_backward_wide_kernel<true>, grid, dim3(GS_WAVE), 0, s, bin_start, payload, a4, grad_image,
+                               acc_alpha, last_effective, width, height, tile_row_begin, tile_row_step, slot_offsets, p4,
+                               slot_flags, magnitude_image, debug_pixel_hits, tile_order);
+        else
+            hipLaunchKernelGGL(blend_backward_wide_kernel<false>, grid, dim3(GS_WAVE), 0, s, bin_start, payload, a4, grad_image,
+                               acc_alpha, last_effective, width, height, tile_row_begin, tile_row_step, slot_offsets, p4,
+                               slot_flags, magnitude_image, debug_pixel_hits, tile_order);
     } else if (staged)
         launch_backward<true>(debug_pixel_hits != nullptr, grid, s, bin_start, payload, a4, grad_image, acc_alpha,
                               last_effective, width, height, tile_row_begin, tile_row_step, bin_shift, filter,

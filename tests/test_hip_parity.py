@@ -960,6 +960,38 @@ def test_four_waves_per_tile_arm_at_a_larger_size(ops):
         assert torch.equal(out[None][i], out["four_waves"][i]), i
 
 
+@pytest.mark.parametrize("workload", ["cfg2_100k_800", "headline_1m_1080p"])
+def test_one_wave_per_tile_backward(ops, workload):
+    """The backward blend with ONE wave per tile (four pixels per lane, cross-lane sums through LDS: round 6) against the
+    two-wave kernel on the same lists: which pairs are blended (per-pixel count + hash), the slot flags and the per-pixel
+    |grad uv| image bit for bit, every slot's pixel count equal, slot sums equal up to the order of the per-pixel terms;
+    bitwise reproducible from run to run.  (An explicit arm: the library's own choice on large grids stays the two-wave kernel
+    with the same LDS reduction, which measured faster -- profiles/r06_backward_arms.md.)"""
+    from taichi_3d_gaussian_splatting_amd.synthetic import make_config_scene, make_grad_image
+    s = make_config_scene(workload).to("cuda")
+    st = _stages_to_ranges(ops, s, ops.ListLayout(bin_shift=0))
+    g = make_grad_image(s.height, s.width).cuda()
+    fwd = ops.blend_forward(st["start"], st["end"], st["payload"], st["attrs"], s.width, s.height, st["layout"], arm="two_waves")
+    part = {}
+    for arm in ("two_waves", "one_wave", "one_wave_again", None):
+        part[arm] = ops.blend_backward_partials(st["start"], st["payload"], st["attrs"], g, fwd[2], fwd[3], st["slot_offsets"],
+                                                st["n_slots"], s.width, s.height, st["layout"], debug_hits=True,
+                                                arm=None if arm is None else arm.replace("_again", ""))
+    p2, f2, m2, d2 = part["two_waves"]
+    p1, f1, m1, d1 = part["one_wave"]
+    assert torch.equal(d1, d2) and torch.equal(f1, f2) and torch.equal(m1, m2)
+    raised = f2.bool()
+    assert torch.equal(p1[raised][:, 10].contiguous().view(torch.int32), p2[raised][:, 10].contiguous().view(torch.int32))
+    assert torch.equal(p1[raised].view(torch.int32), part["one_wave_again"][0][raised].view(torch.int32))   # reproducible
+    a2 = ops.reduce_partials(st["slot_offsets"], st["ntiles"], f2, p2)
+    a1 = ops.reduce_partials(st["slot_offsets"], st["ntiles"], f1, p1)
+    scale = a2[:, :10].abs().amax(dim=0).clamp_min(1e-30)
+    worst = float(((a1[:, :10] - a2[:, :10]).abs() / scale).max())
+    report(f"one_wave.{workload}", tiles=(s.width // 16) * (s.height // 16), max_scaled_difference_of_sums=worst)
+    assert worst < 2e-6
+    assert torch.equal(part[None][2], m1) and torch.equal(part[None][1], f1)
+
+
 @pytest.mark.parametrize("size,n,bin_shift", [(256, 10_000, 0), (512, 60_000, 0), (128, 6_000, 0), (400, 2_000, 0)])
 def test_split_backward_on_small_grids(ops, size, n, bin_shift):
     """List splitting (include/gsplat_hip.h): on grids of at most 1,024 tiles with per-tile lists the forward pass leaves
