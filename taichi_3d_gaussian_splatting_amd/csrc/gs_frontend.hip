@@ -459,13 +459,18 @@ __device__ __forceinline__ void gs_wave_view_colours(bool wants, int id, const f
             const float part = gs_sh_quarter(c4[k].x, c4[k].y, c4[k].z, c4[k].w, y.x, y.y, y.z, y.w);
             const float pair = part + __shfl_xor(part, 1, GS_WAVE);    // q0 + q1 | q2 + q3
             const float sum = pair + __shfl_xor(pair, 2, GS_WAVE);     // (q0 + q1) + (q2 + q3)
-            const float colour = gs_colour_from_sum(sum);
-            // the channel's first lane leaves the colour in the (now consumed) basis slot of the Gaussian
-            if (quarter == 0 && sub < 12 && ((need >> g) & 1ull) != 0ull) Yw[16 * g + (sub >> 2)] = colour;
+            // the channel's first lane leaves the SUM in the (now consumed) basis slot of the Gaussian; the sigmoid is applied
+            // once per Gaussian and channel below (round 6: applied here it was evaluated by all 64 lanes in each of the sixteen
+            // iterations -- 1,024 exponentials and divisions per wave for the 192 that are kept)
+            if (quarter == 0 && sub < 12 && ((need >> g) & 1ull) != 0ull) Yw[16 * g + (sub >> 2)] = sum;
         }
     }
     __builtin_amdgcn_wave_barrier();
-    if (wants) { rgb[0] = Yw[16 * lane]; rgb[1] = Yw[16 * lane + 1]; rgb[2] = Yw[16 * lane + 2]; }
+    if (wants) {
+        rgb[0] = gs_colour_from_sum(Yw[16 * lane]);
+        rgb[1] = gs_colour_from_sum(Yw[16 * lane + 1]);
+        rgb[2] = gs_colour_from_sum(Yw[16 * lane + 2]);
+    }
 }
 
 // ------------------------------------------------------------------ per-visible-point projection

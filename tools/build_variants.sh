@@ -14,6 +14,7 @@ for spec in "$@"; do
     tmp=$(mktemp -d)
     for f in gs_api gs_frame gs_frontend gs_sort gs_blend gs_shard gs_point_backward gs_controller gs_loss gs_optim; do
         extra="$flags"   # (macros are file-specific: GS_GROUP_*, GS_RP_* in gs_blend, GS_SORT_* in gs_sort, ...)
+        case $f in gs_frontend|gs_point_backward) extra="$extra -fno-slp-vectorize";; esac   # (as csrc/Makefile)
         /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -fPIC -munsafe-fp-atomics -Wno-unused-function $extra -c $SRC/$f.hip -o $tmp/$f.o &
     done
     wait
