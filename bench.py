@@ -291,27 +291,44 @@ def main() -> None:
     hook_calls = []
     hook = None if (args.no_hook or args.forward_only) else (lambda h: hook_calls.append(1))
     owner_mode = world > 1 and args.shard_mode == "owner"
-    rows = slice(None)
-    if owner_mode:   # this rank OWNS a contiguous block of the point cloud; its inputs and gradients are that block
-        from taichi_3d_gaussian_splatting_amd.owner_sharding import OwnerShardedRasterisation, owned_point_rows
-        block = owned_point_rows(s.point_cloud.shape[0], rank, world)
-        rows = slice(block.start, block.stop)
-        module = OwnerShardedRasterisation(cfg, backward_valid_point_hook=hook)
-        op = module.core                     # (the options below live on the rank's core)
-    else:
-        op = module = Op(cfg, backward_valid_point_hook=hook)
-    # the operator's default (True): the reference always gathers the [M,56] field (RAS:1131-1133).  The trainer switches
-    # it off between densifications: that variant is timed as well and reported in `variants`
-    op.hook_feature_gradients = not args.no_hook_feature_copy
-    if world > 1 and not owner_mode:
-        shard_rasteriser_across_tile_rows(op, mode=args.shard_mode)
-    xyz = s.point_cloud[rows].clone().requires_grad_(True)
-    feat = s.point_cloud_features[rows].clone().requires_grad_(True)
     cam = CameraInfo(camera_intrinsics=s.camera_intrinsics, camera_height=s.height, camera_width=s.width, camera_id=0)
-    inp = Op.GaussianPointCloudRasterisationInput(
-        point_cloud=xyz, point_cloud_features=feat, point_object_id=s.point_object_id[rows],
-        point_invalid_mask=s.point_invalid_mask[rows], camera_info=cam, q_pointcloud_camera=s.q_pointcloud_camera,
-        t_pointcloud_camera=s.t_pointcloud_camera, color_max_sh_band=3)
+
+    def build_mode(shard_mode):
+        """The operator of one sharding mode with this rank's inputs -> dict(module, op, xyz, feat, inp, rows, owner).
+        "owner": this rank OWNS a contiguous block of the point cloud (its inputs and gradients are that block);
+        "bands" / "interleaved": the north-star partitioning -- replicated cloud, tile rows per rank, all-gather of the rows."""
+        owner = world > 1 and shard_mode == "owner"
+        rws = slice(None)
+        if owner:
+            from taichi_3d_gaussian_splatting_amd.owner_sharding import OwnerShardedRasterisation, owned_point_rows
+            block = owned_point_rows(s.point_cloud.shape[0], rank, world)
+            rws = slice(block.start, block.stop)
+            mod = OwnerShardedRasterisation(cfg, backward_valid_point_hook=hook)
+            core = mod.core                     # (the options below live on the rank's core)
+        else:
+            core = mod = Op(cfg, backward_valid_point_hook=hook)
+        # the operator's default (True): the reference always gathers the [M,56] field (RAS:1131-1133).  The trainer switches
+        # it off between densifications: that variant is timed as well and reported in `variants`
+        core.hook_feature_gradients = not args.no_hook_feature_copy
+        if world > 1 and not owner:
+            shard_rasteriser_across_tile_rows(core, mode=shard_mode)
+        x = s.point_cloud[rws].clone().requires_grad_(True)
+        f = s.point_cloud_features[rws].clone().requires_grad_(True)
+        i = Op.GaussianPointCloudRasterisationInput(
+            point_cloud=x, point_cloud_features=f, point_object_id=s.point_object_id[rws],
+            point_invalid_mask=s.point_invalid_mask[rws], camera_info=cam, q_pointcloud_camera=s.q_pointcloud_camera,
+            t_pointcloud_camera=s.t_pointcloud_camera, color_max_sh_band=3)
+        # Training-like steady state: an optimiser step leaves every quaternion off unit length, so every forward's in-place
+        # normalisation (RAS:196-205) writes the visible rows back.  On this static scene the operator would skip that write
+        # after the first frame (the stored quaternions are already normalised); `always_store_normalised_rotation` makes it
+        # pay the write every frame, as training does (same memory contents).  --static-scene: the skip stays.
+        core.always_store_normalised_rotation = not args.static_scene
+        if args.bin_shift is not None:
+            core.bin_shift = args.bin_shift
+        return {"module": mod, "op": core, "xyz": x, "feat": f, "inp": i, "rows": rws, "owner": owner}
+
+    cur = build_mode(args.shard_mode)
+    module, op, xyz, feat, inp, rows = cur["module"], cur["op"], cur["xyz"], cur["feat"], cur["inp"], cur["rows"]
 
     def step():
         if args.forward_only:
@@ -327,14 +344,6 @@ def main() -> None:
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
-
-    # Training-like steady state: an optimiser step leaves every quaternion off unit length, so every forward's in-place
-    # normalisation (RAS:196-205) writes the visible rows back.  On this static scene the operator would skip that write
-    # after the first frame (the stored quaternions are already normalised); `always_store_normalised_rotation` makes it
-    # pay the write every frame, as training does (same memory contents).  --static-scene: the skip stays.
-    op.always_store_normalised_rotation = not args.static_scene
-    if args.bin_shift is not None:
-        op.bin_shift = args.bin_shift
 
     warmup_steps_run = []   # per timed_run call: W + the steps of the warm-up floor
 
@@ -435,6 +444,71 @@ def main() -> None:
                                                  "value": round(s.height * s.width / 1e6 / (v_ms / 1e3), 3)}
     pixels = s.height * s.width
     value = pixels / 1e6 / (ms_per_step / 1e3)
+
+    # ---------------------------------------------------------------- N > 1: what each rank did, and the OTHER sharding mode
+    # A scaling record is only interpretable if it says which partitioning it timed.  The line's number is the mode asked
+    # for (default: owner-sharded Gaussians -- two all-to-alls + the all-gather of the rows); `variants.shard_mode_*` holds the
+    # same K steps in the other one (the north star's: replicated cloud, tile-row bands, ONE all-gather of the rendered rows +
+    # the sparse accumulator exchange of the backward pass) -- each with the ranks the backend saw, every rank's own pass times
+    # (HIP events on its launch stream) and the bytes each collective moved per step.
+    def per_rank_report(mode_state, steps):
+        """every rank times `steps` more steps with events around its forward and backward passes -> gathered lists"""
+        mod, x, f, i = mode_state["module"], mode_state["xyz"], mode_state["feat"], mode_state["inp"]
+        ev = lambda: torch.cuda.Event(enable_timing=True)   # noqa: E731
+        marks = []
+        for _ in range(steps):
+            a, b, c = ev(), ev(), ev()
+            x.grad = None
+            f.grad = None
+            a.record()
+            image, depth, count = mod(i)
+            b.record()
+            image.backward(grad_image)
+            c.record()
+            marks.append((a, b, c))
+        fence()
+        med = lambda v: sorted(v)[len(v) // 2]   # noqa: E731
+        mine = {"forward": round(med([a.elapsed_time(b) for a, b, c in marks]), 4),
+                "backward": round(med([b.elapsed_time(c) for a, b, c in marks]), 4),
+                "step": round(med([a.elapsed_time(c) for a, b, c in marks]), 4)}
+        core = mode_state["op"]
+        h, w = s.height, s.width
+        from taichi_3d_gaussian_splatting_amd.distributed import padded_image_rows
+        gathered_rows = padded_image_rows(h, world)
+        if mode_state["owner"]:
+            st = dict(mod.last_frame_stats)
+            mine["collectives_bytes_per_step"] = {
+                "forward_all_to_all_sent": int(st.get("bytes_sent_forward", 0)),
+                "backward_all_to_all_sent": int(st.get("records_received", 0)) * 48,   # one 48-B row back per received record
+                "image_all_gather_contributed": gathered_rows // world * w * 20}          # rgb + depth + count of this rank's band
+            mine["records_received"] = int(st.get("records_received", 0))
+        else:
+            st = dict(getattr(core, "exchange_stats", {}) or {})
+            mine["collectives_bytes_per_step"] = {
+                "image_all_gather_contributed": gathered_rows // world * w * 20,
+                "accumulator_exchange_sent": int(st.get("bytes_sent", 0)),
+                "accumulator_rows_sent": int(st.get("rows_sent", 0))}
+        everyone = [None] * world
+        dist.all_gather_object(everyone, mine)
+        return everyone
+
+    if world > 1 and not args.forward_only:
+        per_rank = per_rank_report(cur, min(args.steps, 10))
+        other_mode = "bands" if owner_mode else "owner"
+        main_state = (module, op, xyz, feat, inp, rows)
+        other = build_mode(other_mode)
+        module, op, xyz, feat, inp, rows = (other[k] for k in ("module", "op", "xyz", "feat", "inp", "rows"))
+        o_ms, o_step = timed_run(min(args.warmup, 5), args.steps)
+        variants["shard_mode_" + other_mode] = {
+            "sharding": (f"tile-row bands + owner-sharded Gaussians/{world}" if other["owner"] else f"tile-row {other_mode}/{world}"),
+            "ms_per_step": round(o_ms, 4), "step_ms": o_step, "value": round(pixels / 1e6 / (o_ms / 1e3), 3),
+            "ranks_seen_by_backend": dist.get_world_size(), "backend": backend,
+            "per_rank": per_rank_report(other, min(args.steps, 10))}
+        module, op, xyz, feat, inp, rows = main_state
+        for _ in range(2):
+            step()
+    else:
+        per_rank = None
     # the moving-camera variant: the same K steps over a seeded orbit (the driver's number stays the static line above)
     if args.camera_path > 0 and world == 1:
         poses = camera_orbit(s.q_pointcloud_camera, s.t_pointcloud_camera, args.camera_path)
@@ -644,6 +718,7 @@ def main() -> None:
                            f"tile-row bands + owner-sharded Gaussians/{world}" if owner_mode else f"tile-row {args.shard_mode}/{world}"),
                        "owner_sharding": dict(module.last_frame_stats, magnitude_image=None) if owner_mode else None,
                        "ranks_seen_by_backend": dist.get_world_size() if world > 1 else 1,
+                       "per_rank": per_rank,
                        "backend": (backend if world > 1 else None),
                        "backward_hook": hook is not None, "hook_feature_copy": bool(hook is not None and not args.no_hook_feature_copy),
                        "forward_only": args.forward_only, "training_like": not args.static_scene,

@@ -209,6 +209,20 @@ def test_bench_launches_its_own_ranks_owner_sharded(tmp_path):
     assert rec["n_gpus"] == 2 and rec["config"]["ranks_seen_by_backend"] == 2 and rec["config"]["backend"] == "gloo"
     assert rec["config"]["sharding"] == "tile-row bands + owner-sharded Gaussians/2" and rec["value"] > 0
     assert rec["config"]["owner_sharding"]["records_sent"] > 0 and rec["scaling"] == "strong"
+    # the record carries BOTH partitionings -- the line's own (owner) and the north star's (replicated
+    # cloud, bands, one all-gather of the rows) -- each with the ranks the back end saw, every rank's pass times and the bytes
+    # its collectives moved
+    assert len(rec["config"]["per_rank"]) == 2
+    for r in rec["config"]["per_rank"]:
+        assert r["step"] > 0 and r["forward"] > 0 and r["backward"] > 0
+        assert r["collectives_bytes_per_step"]["forward_all_to_all_sent"] > 0
+        assert r["collectives_bytes_per_step"]["image_all_gather_contributed"] > 0
+    bands = rec["variants"]["shard_mode_bands"]
+    assert bands["sharding"] == "tile-row bands/2" and bands["ranks_seen_by_backend"] == 2 and bands["value"] > 0
+    assert len(bands["per_rank"]) == 2
+    for r in bands["per_rank"]:
+        assert r["step"] > 0 and r["collectives_bytes_per_step"]["image_all_gather_contributed"] > 0
+        assert r["collectives_bytes_per_step"]["accumulator_exchange_sent"] > 0
 
 
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs (RCCL refuses two ranks on one device)")
@@ -249,3 +263,6 @@ def test_bench_multi_rank_contract(tmp_path):
     assert rec["n_gpus"] == 2 and rec["steps"] == 3 and rec["warmup"] == 1 and rec["scaling"] == "strong"
     assert rec["config"]["sharding"] == "tile-row bands/2" and rec["value"] > 0 and rec["unit"] == "Mpixels/s"
     assert rec["roofline"]["bound"] == "hbm" and 0 < rec["roofline"]["frac"] < 1
+    owner = rec["variants"]["shard_mode_owner"]   # (the line asked for bands: the other mode rides along)
+    assert owner["sharding"] == "tile-row bands + owner-sharded Gaussians/2" and owner["value"] > 0
+    assert len(owner["per_rank"]) == 2 and len(rec["config"]["per_rank"]) == 2
