@@ -354,6 +354,8 @@ size_t gs_blend_boundary_bytes(int64_t list_length, int width, int height);
 #define GS_STAT_BWD_HIT_LANES 11
 #define GS_STAT_BWD_BRACKETED 12
 #define GS_STAT_BWD_EXACT_ALPHA 13
+#define GS_STAT_FWD_HIT_BLOCKS 14   /* sum over hit visits of the 8 x 8-pixel blocks (of the wave's two) that hold a hit pixel */
+#define GS_STAT_BWD_HIT_BLOCKS 15
 int gs_blend_read_stats(uint64_t *counters, int clear, void *stream);
 size_t gs_blend_split_workspace_bytes(int width, int height);
 int gs_blend_forward_with_boundaries(const int32_t *bin_start, const int32_t *bin_end, const int32_t *payload,

@@ -679,6 +679,7 @@ __global__ __launch_bounds__(BLEND_THREADS, GS_FWD_MIN_WAVES) void blend_forward
                 GS_STAT(GS_STAT_FWD_HIT_ENTRIES, 1);
                 GS_STAT(GS_STAT_FWD_HIT_PIXELS, __popcll(mok0) + __popcll(mok1));
                 GS_STAT(GS_STAT_FWD_HIT_LANES, __popcll(mok0 | mok1));
+                GS_STAT(GS_STAT_FWD_HIT_BLOCKS, (((mok0 | mok1) & 0x0f0f0f0f0f0f0f0full) != 0ull) + (((mok0 | mok1) & 0xf0f0f0f0f0f0f0f0ull) != 0ull));
                 {
                     const unsigned long long mhi0 = gs_ballot(a.x >= EPS_HI), mhi1 = gs_ballot(a.y >= EPS_HI);
                     if (((mok0 ^ mhi0) | (mok1 ^ mhi1)) != 0ull) {    // rare: an alpha inside the bracket -> park the pixel here
@@ -958,6 +959,7 @@ __global__ __launch_bounds__(BLEND_THREADS, GS_BWD_MIN_WAVES) void blend_backwar
                     GS_STAT(GS_STAT_BWD_HIT_ENTRIES, 1);
                     GS_STAT(GS_STAT_BWD_HIT_PIXELS, __popcll(mh0) + __popcll(mh1));
                     GS_STAT(GS_STAT_BWD_HIT_LANES, __popcll(mh0 | mh1));
+                    GS_STAT(GS_STAT_BWD_HIT_BLOCKS, (((mh0 | mh1) & 0x0f0f0f0f0f0f0f0full) != 0ull) + (((mh0 | mh1) & 0xf0f0f0f0f0f0f0f0ull) != 0ull));
                 }
 #endif
                 // The twelve per-lane partial sums of this entry (in-lane sums over the lane's two pixels), in the order of

@@ -111,6 +111,7 @@ __global__ __launch_bounds__(GS_BLOCK) void sort_scatter_kernel(
     constexpr int DIG = 1 << RB, PER = DIG / GS_BLOCK;   // thread t looks after the digits [t PER, (t + 1) PER)
     if (n_device) n = min((long long)*n_device, n);
     __shared__ int s_cnt[WAVES][DIG];   // running per-wave digit counts, later exclusive prefix over waves
+    __shared__ unsigned long long s_reg[WAVES][DIG];   // per wave and digit: the lanes that hold it this round (match-any)
     __shared__ int s_local[DIG];        // block-local start of each digit's run
     __shared__ int s_gbase[DIG];        // global position of the block's first key of each digit
     __shared__ KeyT s_keys[SORT_ITEMS];
@@ -132,11 +133,14 @@ __global__ __launch_bounds__(GS_BLOCK) void sort_scatter_kernel(
 #pragma unroll
     for (int k = 0; k < WAVES; ++k)
 #pragma unroll
-        for (int d = threadIdx.x; d < DIG; d += GS_BLOCK) s_cnt[k][d] = 0;
+        for (int d = threadIdx.x; d < DIG; d += GS_BLOCK) { s_cnt[k][d] = 0; s_reg[k][d] = 0ull; }
     __syncthreads();
     const long long block_base = (long long)blockIdx.x * SORT_ITEMS;
     const long long wave_base = block_base + (long long)w * (SORT_ITEMS / WAVES);
-    volatile int *cnt = &s_cnt[w][0];   // volatile: LDS accesses of a wave stay in program order
+    // (LDS-qualified volatile accesses: the LDS operations of a wave to its counters stay in program order; a generic volatile
+    // pointer makes this compiler emit a flat-address null check it cannot encode, see sort_local_kernel)
+#define SC_CNT(d) (*(volatile __attribute__((address_space(3))) int *)(&s_cnt[w][d]))
+#define SC_REG(d) (*(volatile __attribute__((address_space(3))) unsigned long long *)(&s_reg[w][d]))
     KeyT key[SORT_ROUNDS];
     int32_t pay[SORT_ROUNDS];
     int rnk[SORT_ROUNDS];   // rank among the same-digit keys of this wave; -1 = past the end of the array
@@ -146,19 +150,30 @@ __global__ __launch_bounds__(GS_BLOCK) void sort_scatter_kernel(
         const bool valid = i < n;
         key[r] = valid ? keys_in[i] : (KeyT)0;
         pay[r] = valid ? payload_in[i] : 0;
-        const unsigned d = digit_of<KeyT, RB>(key[r], shift, flip);
-        unsigned long long peers = __ballot(valid);   // 64-lane match-any on the digit
+    }
 #pragma unroll
-        for (int b = 0; b < RB; ++b) {
-            const bool bit = (d >> b) & 1u;
-            const unsigned long long m = __ballot(bit);
-            peers &= bit ? m : ~m;
-        }
+    for (int r = 0; r < SORT_ROUNDS; ++r) {
+        const long long i = wave_base + r * GS_WAVE + lane;
+        const bool valid = i < n;
+        const unsigned d = digit_of<KeyT, RB>(key[r], shift, flip);
+        // 64-lane match-any on the digit THROUGH LDS (round 6: as sort_local_kernel has done since round 4): every lane ORs
+        // its bit into its digit's word and reads the word back -- the lanes of the wave that hold the same digit.  OR
+        // commutes, a wave's LDS operations execute in program order.  (RB ballots with their per-lane 64-bit selects were
+        // ~45 VALU instructions per round: sixteen dependent rounds of them per wave.)
+        if (valid) __hip_atomic_fetch_or(&s_reg[w][d], 1ull << lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __builtin_amdgcn_wave_barrier();
+        const unsigned long long peers = valid ? SC_REG(d) : 0ull;
         const int rank = gs_mbcnt(peers);
-        const int before = valid ? cnt[d] : 0;                       // every lane of a group reads ...
-        if (valid && rank == 0) cnt[d] = before + __popcll(peers);   // ... before its leader bumps the counter
+        const int before = valid ? SC_CNT(d) : 0;                       // every lane of a group reads ...
+        __builtin_amdgcn_wave_barrier();
+        if (valid && rank == 0) {
+            SC_CNT(d) = before + __popcll(peers);   // ... before its leader bumps the counter
+            SC_REG(d) = 0ull;                       // ... and clears the word for the next round
+        }
         rnk[r] = valid ? before + rank : -1;
     }
+#undef SC_CNT
+#undef SC_REG
     __syncthreads();
     {
         int run[PER], sum = 0;

@@ -187,6 +187,14 @@ def main():
         exp_cr = os.environ.get("GS_EMU_EXP") == "cr"
         out["emulated_exp"] = np.array("correctly rounded" if exp_cr else "numpy fp32")
         path = os.path.join(HERE, f"reference_operator_{name}{'_exp_cr' if exp_cr else ''}.npz")
+        # GS_EMU_OUT_DIR (make_arithmetic_residue.py): another arithmetic of the emulation (GS_EMU_FMA / GS_EMU_RCP_DIV /
+        # NumPy's exp) writes elsewhere and is not compared with the committed archive here
+        if os.environ.get("GS_EMU_OUT_DIR"):
+            out["emulated_arithmetic"] = np.array(f"fma={int(E.EMU_FMA)} rcp_div={int(E.EMU_RCP_DIV)} exp={'cr' if exp_cr else 'numpy'}")
+            path = os.path.join(os.environ["GS_EMU_OUT_DIR"], os.path.basename(path))
+        elif E.EMU_FMA or E.EMU_RCP_DIV:
+            raise SystemExit("GS_EMU_FMA / GS_EMU_RCP_DIV change the reference's arithmetic: set GS_EMU_OUT_DIR (the committed "
+                             "archives are the IEEE run)")
         if os.path.exists(path):
             old = np.load(path)
             for key in BITWISE_FIELDS:

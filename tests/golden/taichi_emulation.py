@@ -38,6 +38,48 @@ import numpy as np
 
 F32 = np.float32
 
+# ARITHMETIC SWITCHES (round 6, tests/golden/make_arithmetic_residue.py): real Taichi compiles the reference's kernels with
+# ``fast_math=True`` -- LLVM may contract a multiplication and an addition into one fused multiply-add and turn a division
+# into a multiplication by the reciprocal -- which cannot be observed here.  The default emulation is IEEE fp32 with neither.
+# These two switches re-run the reference's sources with one of the liberties taken EVERYWHERE it syntactically can be, to
+# measure how much of the reference's output depends on that choice (see load_reference: the rewrite is on the AST).
+#   GS_EMU_FMA=1      a*b + c, c + a*b, a*b - c, c - a*b, x += a*b and the sums of products of ``@`` round once
+#   GS_EMU_RCP_DIV=1  a / b  is  a * (1 / b), both roundings in fp32
+EMU_FMA = os.environ.get("GS_EMU_FMA") == "1"
+EMU_RCP_DIV = os.environ.get("GS_EMU_RCP_DIV") == "1"
+
+
+def _plain_number(v):
+    return isinstance(v, (int, float, np.integer, np.floating)) and not isinstance(v, bool)
+
+
+def ti_fma(a, b, c):
+    """a * b + c with ONE rounding to fp32 for fp32 scalars / vectors (the product of two fp32 numbers is exact in double);
+    integers stay integers, anything else (torch tensors of the glue code) takes the plain expression."""
+    ops = (a, b, c)
+    if all(isinstance(v, (int, np.integer)) and not isinstance(v, bool) for v in ops):
+        return a * b + c
+    if not all(isinstance(v, Mat) or _plain_number(v) for v in ops):
+        return a * b + c
+    raw = [v.a if isinstance(v, Mat) else v for v in ops]
+    r = np.asarray(np.asarray(raw[0], np.float64) * np.asarray(raw[1], np.float64) + np.asarray(raw[2], np.float64)).astype(F32)
+    return Mat(r) if any(isinstance(v, Mat) for v in ops) else r[()]
+
+
+def ti_neg(x):
+    return -x
+
+
+def ti_div(a, b):
+    """a / b as a * (1 / b), each step rounded to fp32 (fp32 scalars / vectors only; Taichi's ``/`` on two integers is a
+    floating-point division too)."""
+    if not all(isinstance(v, Mat) or _plain_number(v) for v in (a, b)):
+        return a / b
+    ra = a.a if isinstance(a, Mat) else F32(a)
+    rb = b.a if isinstance(b, Mat) else F32(b)
+    r = ra * (F32(1.0) / rb)
+    return Mat(r) if isinstance(r, np.ndarray) else r
+
 
 # --------------------------------------------------------------------------------------------------- vectors / matrices
 def _f(x):
@@ -93,8 +135,8 @@ class Mat:
     def __rsub__(self, o): return Mat(self._other(o) - self.a)
     def __mul__(self, o): return Mat(self.a * self._other(o))
     def __rmul__(self, o): return Mat(self._other(o) * self.a)
-    def __truediv__(self, o): return Mat(self.a / self._other(o))
-    def __rtruediv__(self, o): return Mat(self._other(o) / self.a)
+    def __truediv__(self, o): return ti_div(self, o) if EMU_RCP_DIV else Mat(self.a / self._other(o))
+    def __rtruediv__(self, o): return ti_div(o, self) if EMU_RCP_DIV else Mat(self._other(o) / self.a)
     def __neg__(self): return Mat(-self.a)
     def __pos__(self): return self
 
@@ -112,6 +154,8 @@ class Mat:
 
     # ---- products: unrolled, left to right, every step rounded to fp32
     def __matmul__(self, o):
+        if EMU_FMA:
+            return self._matmul_fma(o)
         A, B = self.a, o.a
         if A.ndim == 1 and B.ndim == 1:
             s = A[0] * B[0]
@@ -143,6 +187,26 @@ class Mat:
                 out[i, j] = s
         return Mat(out)
 
+    def _matmul_fma(self, o):
+        """the same sums of products with every ``s + a*b`` fused (one rounding per step)"""
+        A, B = self.a, o.a
+        A2 = A.reshape(1, -1) if A.ndim == 1 else A
+        B2 = B.reshape(-1, 1) if B.ndim == 1 else B
+        out = np.empty((A2.shape[0], B2.shape[1]), F32)
+        for i in range(A2.shape[0]):
+            for j in range(B2.shape[1]):
+                s = A2[i, 0] * B2[0, j]
+                for k in range(1, A2.shape[1]):
+                    s = ti_fma(A2[i, k], B2[k, j], s)
+                out[i, j] = s
+        if A.ndim == 1 and B.ndim == 1:
+            return out[0, 0]
+        if A.ndim == 1:
+            return Mat(out[0])
+        if B.ndim == 1:
+            return Mat(out[:, 0])
+        return Mat(out)
+
     def dot(self, o):
         return self @ o
 
@@ -152,6 +216,8 @@ class Mat:
     def determinant(self):
         a = self.a
         if a.shape == (2, 2):
+            if EMU_FMA:
+                return ti_fma(a[0, 0], a[1, 1], -(a[0, 1] * a[1, 0]))
             return a[0, 0] * a[1, 1] - a[0, 1] * a[1, 0]
         if a.shape == (3, 3):
             return (a[0, 0] * (a[1, 1] * a[2, 2] - a[2, 1] * a[1, 2]) - a[1, 0] * (a[0, 1] * a[2, 2] - a[2, 1] * a[0, 2]) +
@@ -176,7 +242,7 @@ class Mat:
         flat = self.a.reshape(-1)
         s = flat[0] * flat[0]
         for k in range(1, flat.shape[0]):
-            s = s + flat[k] * flat[k]
+            s = ti_fma(flat[k], flat[k], s) if EMU_FMA else s + flat[k] * flat[k]
         return np.sqrt(s)
 
 
@@ -267,7 +333,7 @@ def _cast(x, t):
 
 
 def _normalize(v):
-    return Mat(v.a / v.norm())
+    return v / v.norm() if EMU_RCP_DIV else Mat(v.a / v.norm())
 
 
 # --------------------------------------------------------------------------------------------------- execution model
@@ -586,6 +652,57 @@ class _AtomicRewriter(ast.NodeTransformer):
         return node
 
 
+class _ArithmeticRewriter(ast.NodeTransformer):
+    """GS_EMU_FMA / GS_EMU_RCP_DIV: inside ``@ti.func`` / ``@ti.kernel`` bodies, ``a*b + c`` (either order), ``a*b - c``,
+    ``c - a*b`` and ``x += a*b`` become ``__ti_fma__`` calls, ``a / b`` becomes ``__ti_div__(a, b)``.  The torch glue of the
+    operator (plain Python between the kernels) is left alone."""
+
+    def __init__(self, fma, rcp_div):
+        self.fma, self.rcp_div, self.inside = fma, rcp_div, 0
+
+    @staticmethod
+    def _call(name, *args):
+        return ast.Call(func=ast.Name(id=name, ctx=ast.Load()), args=list(args), keywords=[])
+
+    def visit_FunctionDef(self, node):
+        taichi = any(isinstance(d, ast.Attribute) and d.attr in ("kernel", "func") and isinstance(d.value, ast.Name) and
+                     d.value.id == "ti" for d in node.decorator_list)
+        self.inside += int(taichi)
+        self.generic_visit(node)
+        self.inside -= int(taichi)
+        return node
+
+    def visit_BinOp(self, node):
+        self.generic_visit(node)
+        if not self.inside:
+            return node
+        is_mul = lambda n: isinstance(n, ast.BinOp) and isinstance(n.op, ast.Mult)   # noqa: E731
+        new = None
+        if self.fma and isinstance(node.op, ast.Add):
+            if is_mul(node.left):
+                new = self._call("__ti_fma__", node.left.left, node.left.right, node.right)
+            elif is_mul(node.right):
+                new = self._call("__ti_fma__", node.right.left, node.right.right, node.left)
+        elif self.fma and isinstance(node.op, ast.Sub):
+            if is_mul(node.left):
+                new = self._call("__ti_fma__", node.left.left, node.left.right, self._call("__ti_neg__", node.right))
+            elif is_mul(node.right):
+                new = self._call("__ti_fma__", self._call("__ti_neg__", node.right.left), node.right.right, node.left)
+        elif self.rcp_div and isinstance(node.op, ast.Div):
+            new = self._call("__ti_div__", node.left, node.right)
+        return ast.copy_location(new, node) if new is not None else node
+
+    def visit_AugAssign(self, node):
+        self.generic_visit(node)
+        if (self.inside and self.fma and isinstance(node.op, (ast.Add, ast.Sub)) and isinstance(node.value, ast.BinOp) and
+                isinstance(node.value.op, ast.Mult) and isinstance(node.target, ast.Name)):
+            load = ast.Name(id=node.target.id, ctx=ast.Load())
+            a = node.value.left if isinstance(node.op, ast.Add) else self._call("__ti_neg__", node.value.left)
+            return ast.copy_location(ast.Assign(targets=[node.target], value=self._call("__ti_fma__", a, node.value.right, load)),
+                                     node)
+        return node
+
+
 class _OffloadRewriter(ast.NodeTransformer):
     """Top-level ``for`` loops of a ``@ti.kernel`` body -> ``if __ti_offload__(k): for ...`` (k = 0, 1, ... in source
     order).  Taichi compiles every top-level loop of a kernel into an offloaded task of its own and runs the tasks in
@@ -646,10 +763,14 @@ def load_reference(reference_root: str, modules=("Camera", "utils", "SphericalHa
             assert source.count(old) == 1, (name, old)
             source = source.replace(old, new)
         offloads = _OffloadRewriter()
-        tree = ast.fix_missing_locations(offloads.visit(_AtomicRewriter().visit(ast.parse(source, filename=path))))
+        tree = _AtomicRewriter().visit(ast.parse(source, filename=path))
+        if EMU_FMA or EMU_RCP_DIV:
+            tree = _ArithmeticRewriter(EMU_FMA, EMU_RCP_DIV).visit(tree)
+        tree = ast.fix_missing_locations(offloads.visit(tree))
         mod = types.ModuleType(f"{pkg_name}.{name}")
         mod.__file__, mod.__package__ = path, pkg_name
         mod.__dict__["__ti_atomic_add__"] = ti_atomic_add
+        mod.__dict__["__ti_fma__"], mod.__dict__["__ti_neg__"], mod.__dict__["__ti_div__"] = ti_fma, ti_neg, ti_div
         mod.__dict__["__ti_offload__"], mod.__dict__["__ti_offloads__"] = _offload, offloads.offloads
         mod.__dict__["__ti_prange__"] = _prange
         sys.modules[mod.__name__] = mod

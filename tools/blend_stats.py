@@ -24,7 +24,7 @@ from taichi_3d_gaussian_splatting_amd.synthetic import make_config_scene, make_g
 
 NAMES = ["fwd_entries", "fwd_hit_entries", "fwd_hit_pixels", "fwd_hit_lanes", "fwd_careful_entries", "fwd_exact_alpha",
          "fwd_replays", "fwd_replay_entries", "bwd_entries", "bwd_hit_entries", "bwd_hit_pixels", "bwd_hit_lanes",
-         "bwd_bracketed", "bwd_exact_alpha"]
+         "bwd_bracketed", "bwd_exact_alpha", "fwd_hit_blocks", "bwd_hit_blocks"]
 
 
 def read(clear=True):
@@ -58,6 +58,7 @@ def main():
             hit_path_share_of_visits=c["fwd_hit_entries"] / c["fwd_entries"],
             live_pixels_per_hit_visit_of_128=c["fwd_hit_pixels"] / max(c["fwd_hit_entries"], 1),
             live_lanes_per_hit_visit_of_64=c["fwd_hit_lanes"] / max(c["fwd_hit_entries"], 1),
+            blocks_of_8x8_with_a_hit_per_hit_visit_of_2=c["fwd_hit_blocks"] / max(c["fwd_hit_entries"], 1),
             careful_share_of_visits=c["fwd_careful_entries"] / c["fwd_entries"],
             replayed_entries_per_replay=c["fwd_replay_entries"] / max(c["fwd_replays"], 1))
     if c["bwd_entries"]:
@@ -65,6 +66,7 @@ def main():
             hit_path_share_of_visits=c["bwd_hit_entries"] / c["bwd_entries"],
             live_pixels_per_hit_visit_of_128=c["bwd_hit_pixels"] / max(c["bwd_hit_entries"], 1),
             live_lanes_per_hit_visit_of_64=c["bwd_hit_lanes"] / max(c["bwd_hit_entries"], 1),
+            blocks_of_8x8_with_a_hit_per_hit_visit_of_2=c["bwd_hit_blocks"] / max(c["bwd_hit_entries"], 1),
             bracketed_share_of_visits=c["bwd_bracketed"] / c["bwd_entries"])
     print(json.dumps(out))
 
