@@ -630,6 +630,8 @@ def build_taichi_module():
     simt.block = block
     ti.simt = simt
     ti.init = lambda *a, **k: None
+    rng = np.random.default_rng(0)      # ti.random(): uniform [0, 1) in f32 (the controller's densify-by-sampling, GP3:391-395)
+    ti.random = lambda dtype=None: np.float32(rng.random(dtype=np.float32))
     ti.cpu, ti.cuda, ti.gpu = "cpu", "cuda", "gpu"
     ti.profiler = _Inert()
     return ti, tm

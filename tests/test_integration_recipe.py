@@ -23,6 +23,20 @@ def test_integration_recipe_runs_against_the_reference_host_code():
         assert needle in out.stdout
 
 
+@pytest.mark.skipif(not os.path.isdir("/root/reference"), reason="the reference sources are only in the build container")
+def test_the_reference_trainer_loop_runs_on_the_drop_in_surface():
+    """tests/reference_trainer_check.py: the reference's own GaussianPointCloudTrainer.train() (TRN:117-263), unmodified,
+    20 iterations on the injected operator's types with the CPU oracle computing behind them (no GPU in this container and
+    no reference on the GPU box: see the script's header for what that does and does not show)."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "reference_trainer_check.py")], cwd=ROOT,
+                         capture_output=True, text=True, timeout=900)
+    print(out.stdout[-3000:])
+    assert out.returncode == 0, out.stderr[-3000:]
+    assert out.stdout.rstrip().endswith("OK")
+    for needle in ("reference train(): 20 iterations", "hook payloads consumed 20", "checkpoints written by the reference's to_parquet"):
+        assert needle in out.stdout
+
+
 def test_drop_in_module_exports_the_reference_names():
     import importlib
     # (the package re-exports the class under the module's name, so the module is fetched by name)
