@@ -24,7 +24,7 @@
  *   [0] u  [1] v  [2] z (camera depth)  [3] qmax = 2 ln(255 opacity rescale) + 0.01 (exact-cull bound; +inf = off)
  *   [4] conic A  [5] conic B  [6] conic C  [7] 3-sigma radius   (UTL:257-272, RAS:311-315)
  *   [8] r  [9] g  [10] b  [11] opacity sigmoid(logit)            (RAS:299-310)
- *   [12] amp = opacity * rescale  [13] stop-bracket weight (csrc/gs_common.h)  [14] 0  [15] rescale (UTL:266)
+ *   [12] amp = opacity * rescale  [13] stop-bracket weight  [14] e_lo: exponents below it are skips for certain (csrc/gs_common.h)  [15] rescale (UTL:266)
  *        (alpha = amp * exp(e) with e the reference's exponent, evaluated in the reference's own operation order by each
  *        pass -- UTL:281-283 forward, UTL:336-339 backward; opacity and rescale also stay apart because the reference
  *        multiplies exp(e) by rescale (UTL:284) and then by the opacity (RAS:447): where a comparison with 1/255 or 1e-4
@@ -69,7 +69,7 @@ extern "C" {
 
 /* ABI version of this header.  A TUNING build of the library (measurement arms compiled in: -DGS_TUNING_BUILD=1,
  * tools/build_variants.sh) reports GS_ABI_VERSION + GS_ABI_TUNING_OFFSET, which the product loader refuses. */
-#define GS_ABI_VERSION 34
+#define GS_ABI_VERSION 35
 #define GS_ABI_TUNING_OFFSET 1000
 
 const char *gs_last_error(void);

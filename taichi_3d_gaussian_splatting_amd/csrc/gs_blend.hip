@@ -54,6 +54,11 @@ constexpr float STOP_T = 0.0001f;                  // RAS:458
 #ifndef GS_GROUP_FWD
 #define GS_GROUP_FWD 4
 #endif
+#ifndef GS_FWD_UPFRONT
+#define GS_FWD_UPFRONT 0   // 1: the four exponents of a group are pinned in front of the first hit test.  Measured slower (forward
+                           // stage 0.260 -> 0.269 ms, same box, alternating runs; GS_GROUP_FWD = 2: 0.269 either way): left alone the
+                           // compiler sinks each evaluation to its own test, which keeps fewer values live
+#endif
 #ifndef GS_GROUP_BWD
 #define GS_GROUP_BWD 4
 #endif
@@ -156,12 +161,17 @@ __device__ __forceinline__ v2f splat(float x) { return (v2f){x, x}; }
 __device__ __forceinline__ unsigned long long gs_ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 constexpr float GS_LOG2E = 1.4426950408889634f;
 
-// What a staged list entry leaves in LDS for the group loops (two 16-B broadcast reads per entry and wave):
-//   P = (u, v, A, C)   Q = (B, amp, ., .)      amp = opacity * rescale, formed by gs_preprocess (float 12 of the record)
+// What a staged list entry leaves in LDS for the group loops:
+//   P = (u, v, A, C)                     one 16-B broadcast read per entry and wave, with (B, lim) -- 8 B -- in front of the hit test
+//   forward:  Q = (B, e_lo, amp, depth)  colour row (r, g, b, W)     W = the Gaussian's stop-bracket weight (gs_stop_weight, float 13)
+//   backward: Q = (B, amp, radius, s_hi) colour row (r, g, b, opacity)   (one 16-B read; the rescale factor, which only the
+//             exact re-evaluation of an alpha next to 1/255 wants, is fetched from the record itself there)
+//   amp = opacity * rescale, formed by gs_preprocess (float 12 of the record); e_lo = the exponent below which the reference
+//   skips the pair for certain (float 14: gs_common.h, "the 1/255 decision in the exponent's domain"); s_hi = -2 e_lo, the same
+//   bound on the backward pass' quadratic form s = -2 e.  Forward: the second half of Q and the colour row are read on the
+//   hit path only.
 //   (C, which the packed arithmetic only ever uses as a per-lane scalar, sits in the one position -- the upper half of the
 //   second register pair -- from which the compiler will not broadcast without a v_mov)
-//   forward:  Q.z = camera depth;  colour row (r, g, b, W), W = the Gaussian's stop-bracket weight (gs_stop_weight, float 13)
-//   backward: Q.z = radius, Q.w = rescale;  colour row (r, g, b, opacity)
 // THE EXPONENT IS THE REFERENCE'S TO THE LAST BIT (gs_common.h, "threshold decisions"): each pass evaluates the quadratic
 // form in the operation order of its counterpart, contraction off (this file) --
 //   forward  UTL:281-283   e = -0.5 * (dx*dx*A + dy*dy*C) - dx*dy*B        (the final fma rounds once, as the reference's
@@ -170,30 +180,43 @@ constexpr float GS_LOG2E = 1.4426950408889634f;
 // -- and alpha = 2^(e * log2 e) * amp: four packed instructions more per pixel pair than the pre-scaled log2-domain form of
 // rounds 1-4 (two in the backward pass, which gets m for free), for an alpha within u (2 |e| + 9) of the reference's
 // whatever the conic, instead of 9 u times the cancellation inside the quadratic form.
+// Round 6: the exponent is compared with e_lo FIRST, and the exponential (two v_exp_f32 and two packed products per pixel
+// pair: 14 of the 35 ns a visit without a hit cost the SIMD) is evaluated on the hit path only -- a quarter of the (wave,
+// entry) visits never get there.
 __device__ __forceinline__ v2f gs_weight_from_exponent(v2f e, float amp) {
     const v2f e2 = e * splat(GS_LOG2E);
     return (v2f){__builtin_amdgcn_exp2f(e2.x), __builtin_amdgcn_exp2f(e2.y)} * splat(amp);
 }
-__device__ __forceinline__ v2f gs_pair_alpha_forward(const float4 P, const float4 Q, const v2f px, const float py, v2f &e) {
+__device__ __forceinline__ v2f gs_pair_exponent_forward(const float4 P, const float B, const v2f px, const float py) {
     const v2f dx = px - splat(P.x);
     const float dy = py - P.y;
     const v2f t = (dx * dx) * splat(P.z) + splat((dy * dy) * P.w);
-    const v2f x = (dx * splat(dy)) * splat(Q.x);
-    e = fma2(splat(-0.5f), t, -x);
-    return gs_weight_from_exponent(e, Q.y);
+    const v2f x = (dx * splat(dy)) * splat(B);
+    return fma2(splat(-0.5f), t, -x);
+}
+__device__ __forceinline__ v2f gs_pair_alpha_forward(const float4 P, const float4 Q, const v2f px, const float py, v2f &e) {
+    e = gs_pair_exponent_forward(P, Q.x, px, py);
+    return gs_weight_from_exponent(e, Q.z);
+}
+// the backward pass' quadratic form s = d . (conic @ d) = -2 e (UTL:336-339) and m = conic @ d
+__device__ __forceinline__ v2f gs_pair_form_backward(const float4 P, const float B, const v2f px, const float py, v2f &m0, v2f &m1) {
+    const v2f dx = px - splat(P.x);
+    const float dy = py - P.y;
+    m0 = splat(P.z) * dx + splat(B * dy);
+    m1 = splat(B) * dx + splat(P.w * dy);
+    return dx * m0 + splat(dy) * m1;
+}
+// 2^(e log2 e) amp with e log2 e formed as s * (-0.5 log2 e): the same bits as (-0.5 s) * log2 e -- halving is exact -- in one
+// multiplication
+__device__ __forceinline__ v2f gs_pair_alpha_from_form(const v2f s, const float amp) {
+    const v2f e2 = s * splat(-0.5f * GS_LOG2E);
+    return (v2f){__builtin_amdgcn_exp2f(e2.x), __builtin_amdgcn_exp2f(e2.y)} * splat(amp);
 }
 __device__ __forceinline__ v2f gs_pair_alpha_backward(const float4 P, const float4 Q, const v2f px, const float py, v2f &e,
                                                       v2f &m0, v2f &m1) {
-    const v2f dx = px - splat(P.x);
-    const float dy = py - P.y;
-    m0 = splat(P.z) * dx + splat(Q.x * dy);
-    m1 = splat(Q.x) * dx + splat(P.w * dy);
-    const v2f s = dx * m0 + splat(dy) * m1;
+    const v2f s = gs_pair_form_backward(P, Q.x, px, py, m0, m1);
     e = splat(-0.5f) * s;   // (exact: only the careful path looks at it)
-    // 2^(e log2 e) with e log2 e formed as s * (-0.5 log2 e): the same bits as (-0.5 s) * log2 e -- halving is exact -- in one
-    // multiplication
-    const v2f e2 = s * splat(-0.5f * GS_LOG2E);
-    return (v2f){__builtin_amdgcn_exp2f(e2.x), __builtin_amdgcn_exp2f(e2.y)} * splat(Q.y);
+    return gs_pair_alpha_from_form(s, Q.y);
 }
 // (one pixel per lane: the four-waves-per-tile kernels and the replay; the same operations, component by component)
 __device__ __forceinline__ float gs_exponent_forward(float dx, float dy, float A, float B, float C) {
@@ -202,7 +225,7 @@ __device__ __forceinline__ float gs_exponent_forward(float dx, float dy, float A
 }
 __device__ __forceinline__ float gs_pixel_alpha_forward(const float4 P, const float4 Q, float px, float py, float &e) {
     e = gs_exponent_forward(px - P.x, py - P.y, P.z, Q.x, P.w);
-    return __builtin_amdgcn_exp2f(e * GS_LOG2E) * Q.y;
+    return __builtin_amdgcn_exp2f(e * GS_LOG2E) * Q.z;
 }
 __device__ __forceinline__ float gs_pixel_alpha_backward(const float4 P, const float4 Q, float px, float py, float &e, float &m0,
                                                          float &m1) {
@@ -220,14 +243,14 @@ constexpr float EPS_LO = EPS_ALPHA * (1.0f - GS_ALPHA_BAND), EPS_HI = EPS_ALPHA 
 __device__ __forceinline__ void gs_stage_forward(const float4 r0, const float4 r1, const float4 r2, const float4 r3, float4 &P,
                                                  float4 &Q, float4 &colour, float2 &rescale_opacity) {
     P = make_float4(r0.x, r0.y, r1.x, r1.z);
-    Q = make_float4(r1.y, r3.x, r0.z, 0.f);
+    Q = make_float4(r1.y, r3.z, r3.x, r0.z);
     colour = make_float4(r2.x, r2.y, r2.z, r3.y);
     rescale_opacity = make_float2(r3.w, r2.w);
 }
 __device__ __forceinline__ void gs_stage_backward(const float4 r0, const float4 r1, const float4 r2, const float4 r3, float4 &P,
                                                   float4 &Q, float4 &colour) {
     P = make_float4(r0.x, r0.y, r1.x, r1.z);
-    Q = make_float4(r1.y, r3.x, r1.w, r3.w);
+    Q = make_float4(r1.y, r3.x, r1.w, -2.0f * r3.z);   // (B, amp, radius, s_hi = -2 e_lo: exact)
     colour = r2;
 }
 // The pixel's bracket around T' = 1e-4 from thr (its upper edge as the group loop keeps it: per-Gaussian weights + 4 u per
@@ -514,9 +537,10 @@ __global__ __launch_bounds__(BLEND_THREADS, GS_FWD_MIN_WAVES) void blend_forward
                            : start;
     int kept_base = 0;   // entries this tile kept in earlier rounds
 
-    // alive = 1 until the pixel saturates, then 0: it multiplies alpha, so a dead pixel never passes the
-    // 1/255 test again and needs no separate predicate in the hot loop.
-    v2f T = splat(1.0f), alive = splat(1.0f);
+    // alive0 / alive1: the lanes whose left / right pixel has not saturated (wave-uniform masks in scalar registers: ANDed with
+    // the ballot of the hit test on the scalar unit -- no per-pixel "alive" factor in the vector arithmetic)
+    v2f T = splat(1.0f);
+    unsigned long long alive0 = ~0ull, alive1 = ~0ull;
     v2f Cr = splat(0.f), Cg = splat(0.f), Cb = splat(0.f), D = splat(0.f), Wd = splat(0.f);
     int last0 = wbase, last1 = wbase, cnt0 = 0, cnt1 = 0;
     unsigned dh0 = 0u, dh1 = 0u, dc0 = 0u, dc1 = 0u;
@@ -541,7 +565,7 @@ __global__ __launch_bounds__(BLEND_THREADS, GS_FWD_MIN_WAVES) void blend_forward
     int pos = start;
     while (pos < end) {
         // barrier (protects the staged batch) + whole-tile early exit vote
-        if (__syncthreads_and((alive.x + alive.y == 0.f) ? 1 : 0)) break;
+        if (__syncthreads_and((alive0 | alive1) == 0ull ? 1 : 0)) break;
         int nbuf = 0;
         const int batch_first = pos;   // direct path: staged entry k sits at list position batch_first + k
         if (STAGED)
@@ -549,11 +573,11 @@ __global__ __launch_bounds__(BLEND_THREADS, GS_FWD_MIN_WAVES) void blend_forward
                 gs_fill_step<+1>(payload, attrs, pos, end, nbuf, s_cnt, s_next, keep, store);
         else
             gs_direct_step<+1>(payload, attrs, pos, end, nbuf, store);
-        {   // pad to a multiple of GROUP with inert records (amplitude 0 -> alpha 0, never blended)
+        {   // pad to a multiple of GROUP with inert records (e_lo = +inf: no exponent passes the hit test)
             const int padded = (nbuf + GROUP - 1) & ~(GROUP - 1);
             if (tid < padded - nbuf) {
                 s_p[nbuf + tid] = make_float4(0.f, 0.f, 0.f, 0.f);
-                s_q[nbuf + tid] = make_float4(0.f, 0.f, 0.f, 0.f);
+                s_q[nbuf + tid] = make_float4(0.f, __builtin_inff(), 0.f, 0.f);
             }
         }
         __syncthreads();
@@ -584,16 +608,17 @@ __global__ __launch_bounds__(BLEND_THREADS, GS_FWD_MIN_WAVES) void blend_forward
                 dc1 += ok1 ? 1u : 0u; dh1 += ok1 ? hv : 0u;
             }
         };
-        // PARKED PIXELS.  When a comparison of the group loop falls inside a bracket -- an alpha inside [EPS_LO, EPS_HI), a T'
-        // inside the pixel's stop bracket: about a thousand (wave, entry) visits per full-size frame -- the decision is not the
-        // loop's to take: the pixel is PARKED at that entry (its state untouched, alive = 0 so that the rest of the group passes
-        // it by) and the loop goes on for the other pixels without leaving its straight-line body.  After the group the wave
-        // takes the parked pixels through the entries they missed with every decision taken as the reference takes it
-        // (careful_entry: the reference's expression with the same exponent, correctly rounded exp, * rescale * opacity; a
-        // replay of the pixel's history in the reference's arithmetic for a T' in the bracket).  Every update of a pixel that is
-        // not taking part (al = 0) is an exact no-op, so the catch-up runs the ordinary blend update on the whole wave.  Kept
-        // out of the group loop's body so that its temporaries (double-precision exp, the replay's records) do not add to the
-        // registers of the hot path, nor its exits to the loop's control flow (an early-exit form cost the forward kernel 20 us).
+        // PARKED PIXELS.  When a comparison of the group loop falls inside a bracket -- an exponent at or above e_lo whose alpha
+        // does not reach EPS_HI, a T' inside the pixel's stop bracket: about a thousand (wave, entry) visits per full-size frame
+        // -- the decision is not the loop's to take: the pixel is PARKED at that entry (its state untouched, its alive bit cleared
+        // so that the rest of the group passes it by) and the loop goes on for the other pixels without leaving its straight-line
+        // body.  After the group the wave takes the parked pixels through the entries they missed with every decision taken as
+        // the reference takes it (careful_entry: the reference's expression with the same exponent, correctly rounded exp, *
+        // rescale * opacity; a replay of the pixel's history in the reference's arithmetic for a T' in the bracket).  Every
+        // update of a pixel that is not taking part (al = 0) is an exact no-op, so the catch-up runs the ordinary blend update
+        // on the whole wave.  Kept out of the group loop's body so that its temporaries (double-precision exp, the replay's
+        // records) do not add to the registers of the hot path, nor its exits to the loop's control flow (an early-exit form
+        // cost the forward kernel 20 us).
         // m0 / m1: the pixels taking part; dead0 / dead1: those the reference stops during the catch-up.
         auto careful_entry = [&](int e, bool m0, bool m1, bool &dead0, bool &dead1) {
             v2f ex;
@@ -647,53 +672,59 @@ __global__ __launch_bounds__(BLEND_THREADS, GS_FWD_MIN_WAVES) void blend_forward
             if (sat0) { al.x = 0.f; dead0 = true; ok0 = false; }
             if (sat1) { al.y = 0.f; dead1 = true; ok1 = false; }
             Tn = T * (splat(1.f) - al);
-            blend(e, c, Q.z, al, Tn, ok0, ok1);
+            blend(e, c, Q.w, al, Tn, ok0, ok1);
         };
-        // Entries are evaluated in groups of GROUP: the LDS reads and the exp of a group are independent
+        // Entries are evaluated in groups of GROUP: the LDS reads and the quadratic forms of a group are independent
         // and overlap (the per-pixel blend recurrence is the only serial part), which hides their latency.
         for (int k = 0; k < nbuf; k += GROUP_FWD) {
-            if (gs_ballot(alive.x + alive.y != 0.f) == 0ull) break;  // every pixel of this wave is saturated
-            v2f alpha[GROUP_FWD];
-            float z[GROUP_FWD];
+            if ((alive0 | alive1) == 0ull) break;  // every pixel of this wave is saturated
+            v2f ex[GROUP_FWD];
+            float elo[GROUP_FWD];
 #pragma unroll
             for (int i = 0; i < GROUP_FWD; ++i) {
-                v2f ex;
-                const float4 Q = s_q[k + i];
-                alpha[i] = gs_pair_alpha_forward(s_p[k + i], Q, px, py, ex);
-                z[i] = Q.z;
+                const float2 q = *reinterpret_cast<const float2 *>(&s_q[k + i]);   // (B, e_lo)
+                ex[i] = gs_pair_exponent_forward(s_p[k + i], q.x, px, py);
+                elo[i] = q.y;
             }
-#if GS_ABLATE_FWD == 1   // tuning only: evaluation without the blend (what the alpha evaluation of every visited entry costs)
+#if GS_FWD_UPFRONT   // the group's exponents exist before the first hit test (left alone the compiler sinks each evaluation to its test)
 #pragma unroll
-            for (int i = 0; i < GROUP_FWD; ++i) { Cr = Cr + alpha[i]; last0 += (int)z[i]; }
+            for (int i = 0; i < GROUP_FWD; ++i) asm volatile("" : "+v"(ex[i].x), "+v"(ex[i].y));
+#endif
+#if GS_ABLATE_FWD == 1   // tuning only: evaluation without the blend (what the evaluation of every visited entry costs)
+#pragma unroll
+            for (int i = 0; i < GROUP_FWD; ++i) { Cr = Cr + ex[i]; last0 += (int)elo[i]; }
             continue;
 #endif
             bool parked = false;   // wave-uniform: a pixel of this wave was parked in this group
             GS_STAT(GS_STAT_FWD_ENTRIES, GROUP_FWD);
 #pragma unroll
             for (int i = 0; i < GROUP_FWD; ++i) {
-                // a = alpha for a live pixel (x * 1.0f is exact), 0 for a saturated (or parked) one
-                const v2f a = alpha[i] * alive;
-                bool ok0 = a.x >= EPS_LO, ok1 = a.y >= EPS_LO;        // RAS:451 (lower edge of the bracket)
-                unsigned long long mok0 = gs_ballot(ok0), mok1 = gs_ballot(ok1);
-                if ((mok0 | mok1) == 0ull) continue;                  // wave-uniform skip
+                // RAS:451 in the exponent's domain: below e_lo the reference skips the pair (live pixels only)
+                unsigned long long mok0 = gs_ballot(ex[i].x >= elo[i]) & alive0, mok1 = gs_ballot(ex[i].y >= elo[i]) & alive1;
+                if ((mok0 | mok1) == 0ull) continue;                  // wave-uniform skip: no exponential is evaluated
                 GS_STAT(GS_STAT_FWD_HIT_ENTRIES, 1);
                 GS_STAT(GS_STAT_FWD_HIT_PIXELS, __popcll(mok0) + __popcll(mok1));
                 GS_STAT(GS_STAT_FWD_HIT_LANES, __popcll(mok0 | mok1));
                 GS_STAT(GS_STAT_FWD_HIT_BLOCKS, (((mok0 | mok1) & 0x0f0f0f0f0f0f0f0full) != 0ull) + (((mok0 | mok1) & 0xf0f0f0f0f0f0f0f0ull) != 0ull));
+                const float4 c = s_c[k + i];
+                const float2 az = reinterpret_cast<const float2 *>(&s_q[k + i])[1];   // (amp, depth)
+                const v2f a = gs_weight_from_exponent(ex[i], az.x);
                 {
-                    const unsigned long long mhi0 = gs_ballot(a.x >= EPS_HI), mhi1 = gs_ballot(a.y >= EPS_HI);
-                    if (((mok0 ^ mhi0) | (mok1 ^ mhi1)) != 0ull) {    // rare: an alpha inside the bracket -> park the pixel here
-                        if (ok0 && !(a.x >= EPS_HI)) { park0 = i; alive.x = 0.f; ok0 = false; }
-                        if (ok1 && !(a.y >= EPS_HI)) { park1 = i; alive.y = 0.f; ok1 = false; }
+                    const unsigned long long mhi0 = gs_ballot(a.x >= EPS_HI) & mok0, mhi1 = gs_ballot(a.y >= EPS_HI) & mok1;
+                    if (((mok0 ^ mhi0) | (mok1 ^ mhi1)) != 0ull) {    // rare: not a hit for certain -> park the pixel here
+                        const unsigned long long p0 = mok0 & ~mhi0, p1 = mok1 & ~mhi1;
+                        if (__builtin_amdgcn_inverse_ballot_w64(p0)) park0 = i;
+                        if (__builtin_amdgcn_inverse_ballot_w64(p1)) park1 = i;
+                        alive0 &= ~p0; alive1 &= ~p1;
                         parked = true;
                         mok0 = mhi0; mok1 = mhi1;
                         if ((mok0 | mok1) == 0ull) continue;
                     }
                 }
+                bool ok0 = __builtin_amdgcn_inverse_ballot_w64(mok0), ok1 = __builtin_amdgcn_inverse_ballot_w64(mok1);
                 // alpha = 0 for a skipped pixel makes the update an exact no-op
                 v2f al = {ok0 ? __builtin_amdgcn_fmed3f(a.x, 0.f, CLAMP_ALPHA) : 0.f,
                           ok1 ? __builtin_amdgcn_fmed3f(a.y, 0.f, CLAMP_ALPHA) : 0.f};
-                const float4 c = s_c[k + i];
                 thr = fma2(splat(c.w), al, thr);   // this Gaussian's share of the pixel's stop bracket (its own factor included)
                 v2f Tn = T * (splat(1.f) - al);
                 const bool low0 = Tn.x < thr.x, low1 = Tn.y < thr.y;
@@ -706,16 +737,19 @@ __global__ __launch_bounds__(BLEND_THREADS, GS_FWD_MIN_WAVES) void blend_forward
                     gs_stop_bracket(thr.y, walked, AUX ? cnt1 + 1 : -1, lo1, hi1);
                     const bool sat0 = ok0 && Tn.x < lo0, sat1 = ok1 && Tn.y < lo1;
                     const bool fr0 = ok0 && !sat0 && Tn.x < hi0, fr1 = ok1 && !sat1 && Tn.y < hi1;
-                    if (gs_ballot(fr0 || fr1) != 0ull) {
-                        if (fr0) { park0 = i; al.x = 0.f; alive.x = 0.f; ok0 = false; }
-                        if (fr1) { park1 = i; al.y = 0.f; alive.y = 0.f; ok1 = false; }
+                    const unsigned long long mfr0 = gs_ballot(fr0), mfr1 = gs_ballot(fr1);
+                    if ((mfr0 | mfr1) != 0ull) {
+                        if (fr0) { park0 = i; al.x = 0.f; ok0 = false; }
+                        if (fr1) { park1 = i; al.y = 0.f; ok1 = false; }
+                        alive0 &= ~mfr0; alive1 &= ~mfr1;
                         parked = true;
                     }
-                    if (sat0) { al.x = 0.f; alive.x = 0.f; ok0 = false; }
-                    if (sat1) { al.y = 0.f; alive.y = 0.f; ok1 = false; }
+                    if (sat0) { al.x = 0.f; ok0 = false; }
+                    if (sat1) { al.y = 0.f; ok1 = false; }
+                    alive0 &= ~gs_ballot(sat0); alive1 &= ~gs_ballot(sat1);
                     Tn = T * (splat(1.f) - al);
                 }
-                blend(k + i, c, z[i], al, Tn, ok0, ok1);
+                blend(k + i, c, az.y, al, Tn, ok0, ok1);
             }
             if (parked) {   // the parked pixels catch up on the entries of the group they missed
                 bool dead0 = false, dead1 = false;
@@ -726,8 +760,9 @@ __global__ __launch_bounds__(BLEND_THREADS, GS_FWD_MIN_WAVES) void blend_forward
                     GS_STAT(GS_STAT_FWD_CAREFUL_ENTRIES, 1);
                     careful_entry(k + i, m0, m1, dead0, dead1);
                 }
-                if (park0 < GROUP_FWD) { alive.x = dead0 ? 0.f : 1.f; park0 = GROUP_FWD; }
-                if (park1 < GROUP_FWD) { alive.y = dead1 ? 0.f : 1.f; park1 = GROUP_FWD; }
+                alive0 |= gs_ballot(park0 < GROUP_FWD && !dead0);
+                alive1 |= gs_ballot(park1 < GROUP_FWD && !dead1);
+                park0 = GROUP_FWD; park1 = GROUP_FWD;
             }
         }
         kept_base += nbuf;
@@ -868,9 +903,9 @@ __global__ __launch_bounds__(BLEND_THREADS, GS_BWD_MIN_WAVES) void blend_backwar
             gs_direct_step<-1>(payload, attrs, pos, start, nbuf, store);
         {
             const int padded = (nbuf + GROUP - 1) & ~(GROUP - 1);
-            if (tid < padded - nbuf) {   // inert padding: amplitude 0 -> alpha 0, never a hit
+            if (tid < padded - nbuf) {   // inert padding: s_hi = -inf, no quadratic form passes the hit test
                 s_p[nbuf + tid] = make_float4(0.f, 0.f, 0.f, 0.f);
-                s_q[nbuf + tid] = make_float4(0.f, 0.f, 0.f, 0.f);
+                s_q[nbuf + tid] = make_float4(0.f, 0.f, 0.f, -__builtin_inff());
                 s_j[nbuf + tid] = -1;
             }
             float4 *z = reinterpret_cast<float4 *>(&s_acc[tid][0]);
@@ -894,16 +929,20 @@ __global__ __launch_bounds__(BLEND_THREADS, GS_BWD_MIN_WAVES) void blend_backwar
                 for (int i = 0; i < GROUP_BWD; ++i) jg[i] = batch_first - (k + i);
             }
             if (jg[GROUP_BWD - 1] >= wave_end) continue;
-            // group evaluation: LDS reads + exp of GROUP entries are independent and overlap
-            v2f alpha[GROUP_BWD], m0[GROUP_BWD], m1[GROUP_BWD];
+            // group evaluation: LDS reads + quadratic forms of GROUP entries are independent and overlap
+            v2f alpha[GROUP_BWD], m0[GROUP_BWD], m1[GROUP_BWD];   // alpha[i]: the form s = -2 e until the entry's hit test, then alpha
+            float amp[GROUP_BWD], shi[GROUP_BWD];
 #pragma unroll
             for (int i = 0; i < GROUP_BWD; ++i) {
-                v2f ex;
-                alpha[i] = gs_pair_alpha_backward(s_p[k + i], s_q[k + i], px, py, ex, m0[i], m1[i]);
+                const float4 Q = s_q[k + i];
+                alpha[i] = gs_pair_form_backward(s_p[k + i], Q.x, px, py, m0[i], m1[i]);
+                amp[i] = Q.y; shi[i] = Q.w;
             }
-            // (A) the 1/255 decisions of the whole group (RAS:631): lower edge of the bracket; an entry with an alpha inside the
-            // bracket is noted and settled before any entry is processed -- between the evaluation and the hit path, where
-            // few registers are live
+            // (A) the decisions of the whole group: RAS:631 in the exponent's domain -- s <= s_hi is e >= e_lo, below which the
+            // reference skips the pair for certain (gs_common.h) -- and RAS:618 (effective range).  Only an entry that may hit a
+            // pixel of this wave has its exponentials evaluated; one whose alpha then does not reach EPS_HI on every such pixel
+            // is noted and settled before any entry is processed -- between the evaluation and the hit path, where few
+            // registers are live
             // (the decisions are kept as lane MASKS in scalar registers -- gs_ballot / inverse_ballot: as bools they went through
             // the vector unit and back, four instructions per entry)
             unsigned long long ma0[GROUP_BWD], ma1[GROUP_BWD];
@@ -911,10 +950,13 @@ __global__ __launch_bounds__(BLEND_THREADS, GS_BWD_MIN_WAVES) void blend_backwar
             GS_STAT(GS_STAT_BWD_ENTRIES, GROUP_BWD);
 #pragma unroll
             for (int i = 0; i < GROUP_BWD; ++i) {
-                ma0[i] = gs_ballot(alpha[i].x >= EPS_LO); ma1[i] = gs_ballot(alpha[i].y >= EPS_LO);
-                if ((ma0[i] | ma1[i]) != 0ull &&
-                    ((ma0[i] ^ gs_ballot(alpha[i].x >= EPS_HI)) | (ma1[i] ^ gs_ballot(alpha[i].y >= EPS_HI))) != 0ull)
-                    bracketed |= 1u << i;
+                ma0[i] = gs_ballot(alpha[i].x <= shi[i]) & gs_ballot(jg[i] < last0);
+                ma1[i] = gs_ballot(alpha[i].y <= shi[i]) & gs_ballot(jg[i] < last1);
+                if ((ma0[i] | ma1[i]) != 0ull) {   // (wave-uniform)
+                    alpha[i] = gs_pair_alpha_from_form(alpha[i], amp[i]);
+                    if (((ma0[i] & ~gs_ballot(alpha[i].x >= EPS_HI)) | (ma1[i] & ~gs_ballot(alpha[i].y >= EPS_HI))) != 0ull)
+                        bracketed |= 1u << i;
+                }
             }
             if (bracketed != 0u) {
                 // rare (about a thousand (wave, entry) visits per full-size frame): the reference's BACKWARD expression decides
@@ -933,13 +975,15 @@ __global__ __launch_bounds__(BLEND_THREADS, GS_BWD_MIN_WAVES) void blend_backwar
                     if (gs_ballot(in0 || in1) != 0ull) {
                         GS_STAT(GS_STAT_BWD_EXACT_ALPHA, 1);
                         const float opacity = s_c[e].w;
+                        const float rescale = reinterpret_cast<const float *>(attrs + 4 * (size_t)s_o[e])[15];
 #pragma clang loop unroll(disable)
                         for (int c = 0; c < 2; ++c) {
-                            const float exact = gs_alpha_reference(c ? ex.y : ex.x, Q.w, opacity);
+                            const float exact = gs_alpha_reference(c ? ex.y : ex.x, rescale, opacity);
                             if (c ? in1 : in0) { if (c) r1 = exact >= EPS_ALPHA; else r0 = exact >= EPS_ALPHA; }
                         }
                     }
-                    const unsigned long long mr0 = gs_ballot(r0), mr1 = gs_ballot(r1);
+                    const int jj = STAGED ? s_j[e] : batch_first - e;
+                    const unsigned long long mr0 = gs_ballot(r0 && jj < last0), mr1 = gs_ballot(r1 && jj < last1);
 #pragma unroll
                     for (int i = 0; i < GROUP_BWD; ++i)
                         if (i == ii) { ma0[i] = mr0; ma1[i] = mr1; }
@@ -948,11 +992,8 @@ __global__ __launch_bounds__(BLEND_THREADS, GS_BWD_MIN_WAVES) void blend_backwar
             // (B) the hit path, entry by entry
 #pragma unroll
             for (int i = 0; i < GROUP_BWD; ++i) {
-                if ((ma0[i] | ma1[i]) == 0ull) continue;  // wave-uniform skip: no pixel of this wave is touched
-                const int jj = jg[i];
-                // RAS:618 (effective range)
-                const unsigned long long mh0 = ma0[i] & gs_ballot(jj < last0), mh1 = ma1[i] & gs_ballot(jj < last1);
-                if ((mh0 | mh1) == 0ull) continue;
+                const unsigned long long mh0 = ma0[i], mh1 = ma1[i];
+                if ((mh0 | mh1) == 0ull) continue;  // wave-uniform skip: no pixel of this wave is touched
                 const bool hit0 = __builtin_amdgcn_inverse_ballot_w64(mh0), hit1 = __builtin_amdgcn_inverse_ballot_w64(mh1);
 #if GS_STATS
                 {
@@ -1316,7 +1357,7 @@ __global__ __launch_bounds__(GS_WAVE, GS_BWD_WIDE_MIN_WAVES) void blend_backward
                         const float opacity = s_c[e].w;
 #pragma clang loop unroll(disable)
                         for (int c = 0; c < 2; ++c) {
-                            const float exact = gs_alpha_reference(c ? ex.y : ex.x, Q.w, opacity);
+                            const float exact = gs_alpha_reference(c ? ex.y : ex.x, reinterpret_cast<const float *>(attrs + 4 * (size_t)s_o[e])[15], opacity);
                             if (c ? in1 : in0) { if (c) r1 = exact >= EPS_ALPHA; else r0 = exact >= EPS_ALPHA; }
                         }
                     }
@@ -1484,19 +1525,20 @@ __global__ __launch_bounds__(SMALL_THREADS) void blend_forward_small_kernel(
     const int pu = tc.tile_u * GS_TILE_WIDTH + (tid & 15), pv = tc.tile_v * GS_TILE_HEIGHT + (tid >> 4);
     const int start = tile_start[tc.tile_id], end = tile_end[tc.tile_id];
     const float px = (float)pu + 0.5f, py = (float)pv + 0.5f;
-    float T = 1.0f, alive = 1.0f, Cr = 0.f, Cg = 0.f, Cb = 0.f, D = 0.f, Wd = 0.f;
+    float T = 1.0f, Cr = 0.f, Cg = 0.f, Cb = 0.f, D = 0.f, Wd = 0.f;
     // Rounding left behind by the colour sums (boundary states only): the image is the plain fp32 sum, as always; next to it
     // E collects what each fma rounded away, so that C + E is the prefix colour to ~1e-14 and the split backward pass can
     // form "colour still to come" = (C_final - C_b) + (E_final - E_b) without the cancellation error of the plain difference
     // (measured without it: slot sums 2e-4 of the column maximum away from the un-split ones)
     const bool track = STATE && boundary != nullptr;
     float Er = 0.f, Eg = 0.f, Eb = 0.f;
+    unsigned long long alive_m = ~0ull;   // the lanes whose pixel has not saturated (wave-uniform, as in blend_forward_kernel)
     int last = start, cnt = 0;
     unsigned dh = 0u, dc = 0u;
     float thr = STOP_T;   // upper edge of the pixel's stop bracket (blend_forward_kernel)
     int pos = start;
     while (pos < end) {
-        if (__syncthreads_and(alive == 0.f ? 1 : 0)) break;   // barrier (protects the staged batch) + whole-tile early exit
+        if (__syncthreads_and(alive_m == 0ull ? 1 : 0)) break;   // barrier (protects the staged batch) + whole-tile early exit
         const int batch_first = pos;
         {
             const int j = pos + tid;
@@ -1516,7 +1558,7 @@ __global__ __launch_bounds__(SMALL_THREADS) void blend_forward_small_kernel(
             const int padded = (nbuf + GROUP - 1) & ~(GROUP - 1);
             if (tid < padded - nbuf) {
                 s_p[nbuf + tid] = make_float4(0.f, 0.f, 0.f, 0.f);
-                s_q[nbuf + tid] = make_float4(0.f, 0.f, 0.f, 0.f);
+                s_q[nbuf + tid] = make_float4(0.f, __builtin_inff(), 0.f, 0.f);   // (e_lo = +inf: never passes the hit test)
             }
         }
         __syncthreads();
@@ -1550,14 +1592,15 @@ __global__ __launch_bounds__(SMALL_THREADS) void blend_forward_small_kernel(
         auto careful_entry = [&](int e) {
             float ex;
             const float4 Q = s_q[e];
-            const float a = gs_pixel_alpha_forward(s_p[e], Q, px, py, ex) * alive;
+            const bool live = __builtin_amdgcn_inverse_ballot_w64(alive_m);
+            const float a = live ? gs_pixel_alpha_forward(s_p[e], Q, px, py, ex) : 0.f;
             bool ok = a >= EPS_ALPHA;   // RAS:451
             {
                 const bool in = a >= EPS_LO && a < EPS_HI;
                 if (gs_ballot(in) != 0ull) {
                     const float2 ro = s_ro[e];
                     const float exact = gs_alpha_reference(ex, ro.x, ro.y);
-                    if (in) ok = exact * alive >= EPS_ALPHA;
+                    if (in) ok = exact >= EPS_ALPHA;
                 }
             }
             if (gs_ballot(ok) == 0ull) return;
@@ -1574,41 +1617,45 @@ __global__ __launch_bounds__(SMALL_THREADS) void blend_forward_small_kernel(
                                                                        gs_readlane_f(py, l), tc.tile_u, tc.tile_v, tw, th);
                 if ((tid & (GS_WAVE - 1)) == l) sat = stops;
             }
-            if (sat) { al = 0.f; alive = 0.f; ok = false; }
+            if (sat) { al = 0.f; ok = false; }
+            alive_m &= ~gs_ballot(sat);
             Tn = T * (1.f - al);
-            blend(e, c, Q.z, al, Tn, ok);
+            blend(e, c, Q.w, al, Tn, ok);
         };
         for (int k = 0; k < nbuf; k += GROUP_FWD) {
-            if (gs_ballot(alive != 0.f) == 0ull) break;   // every pixel of this wave is saturated
-            float alpha[GROUP_FWD], z[GROUP_FWD];
+            if (alive_m == 0ull) break;   // every pixel of this wave is saturated
+            float ex[GROUP_FWD], elo[GROUP_FWD];
 #pragma unroll
             for (int i = 0; i < GROUP_FWD; ++i) {
-                float ex;
-                const float4 Q = s_q[k + i];
-                alpha[i] = gs_pixel_alpha_forward(s_p[k + i], Q, px, py, ex);
-                z[i] = Q.z;
+                const float4 P = s_p[k + i];
+                const float2 q = *reinterpret_cast<const float2 *>(&s_q[k + i]);   // (B, e_lo)
+                ex[i] = gs_exponent_forward(px - P.x, py - P.y, P.z, q.x, P.w);
+                elo[i] = q.y;
             }
             int careful_from = GROUP_FWD;
 #pragma unroll
             for (int i = 0; i < GROUP_FWD; ++i) {
-                const float a = alpha[i] * alive;
-                bool ok = a >= EPS_LO;                                  // RAS:451 (lower edge of the bracket)
-                const unsigned long long mok = gs_ballot(ok);
+                const unsigned long long mok = gs_ballot(ex[i] >= elo[i]) & alive_m;   // RAS:451 in the exponent's domain
                 if (mok == 0ull) continue;
-                if ((mok ^ gs_ballot(a >= EPS_HI)) != 0ull) { careful_from = i; break; }
-                float al = ok ? __builtin_amdgcn_fmed3f(a, 0.f, CLAMP_ALPHA) : 0.f;
                 const float4 c = s_c[k + i];
+                const float2 az = reinterpret_cast<const float2 *>(&s_q[k + i])[1];   // (amp, depth)
+                const float a = __builtin_amdgcn_exp2f(ex[i] * GS_LOG2E) * az.x;
+                if ((mok ^ (gs_ballot(a >= EPS_HI) & mok)) != 0ull) { careful_from = i; break; }
+                bool ok = __builtin_amdgcn_inverse_ballot_w64(mok);
+                float al = ok ? __builtin_amdgcn_fmed3f(a, 0.f, CLAMP_ALPHA) : 0.f;
                 thr = __builtin_fmaf(c.w, al, thr);
                 float Tn = T * (1.f - al);
                 if ((mok & gs_ballot(Tn < thr)) != 0ull) {              // RAS:458-460: saturates the pixel, NOT blended
                     float lo, hi;
                     gs_stop_bracket(thr, walked, AUX ? cnt + 1 : -1, lo, hi);
                     const bool sat = ok && Tn < lo;
-                    if (gs_ballot(ok && !sat && Tn < hi) != 0ull) { careful_from = i; break; }
-                    if (sat) { al = 0.f; alive = 0.f; ok = false; }
+                    if (gs_ballot(ok && !sat && Tn < hi) != 0ull) { careful_from = i; break; }   // (thr keeps this entry's share: the
+                                                                                                 //  careful twin adds it again -- wider, safe)
+                    if (sat) { al = 0.f; ok = false; }
+                    alive_m &= ~gs_ballot(sat);
                     Tn = T * (1.f - al);
                 }
-                blend(k + i, c, z[i], al, Tn, ok);
+                blend(k + i, c, az.y, al, Tn, ok);
             }
             if (careful_from < GROUP_FWD) {
 #pragma clang loop unroll(disable)
@@ -1779,7 +1826,7 @@ __global__ __launch_bounds__(SMALL_THREADS) void blend_backward_small_kernel(
                     bool r0 = al >= EPS_ALPHA;
                     const bool in = al >= EPS_LO && al < EPS_HI;
                     if (gs_ballot(in) != 0ull) {
-                        const float exact = gs_alpha_reference(ex, Q.w, s_c[e].w);
+                        const float exact = gs_alpha_reference(ex, reinterpret_cast<const float *>(attrs + 4 * (size_t)s_o[e])[15], s_c[e].w);
                         if (in) r0 = exact >= EPS_ALPHA;
                     }
                     const unsigned long long mr = gs_ballot(r0);

@@ -130,6 +130,22 @@ __device__ __forceinline__ float gs_stop_weight(float amp, float stop_t) {
     const float H = 1.0f / (1.0f - fminf(amp, 0.99f)) * 1.01f;
     return stop_t * 1.1f * GS_BAND_SAFETY * GS_U24 * (12.0f + 9.0f * H);
 }
+// THE 1/255 DECISION IN THE EXPONENT'S DOMAIN (round 6).  The reference's alpha is a non-decreasing function of its exponent e
+// -- exp correctly rounded, then two roundings of products with positive constants -- so "alpha >= 1/255" is "e >= e*" for
+// one float e* per Gaussian, and e* lies within 3 u of L = ln(fl(1/255) / (rescale opacity)) (three relative roundings of at most
+// u each, additive in the log domain).  gs_preprocess leaves e_lo = L~ - h in the record (float 14), L~ = -logf(255 amp):
+//   |L~ - L| <= 3 u (amp = fl(opacity rescale), the product with 255, fl(1/255) against 1/255) + 2 ulp(L~) (logf: 1 ulp claimed,
+//   two charged) = u (3 + 4 |L~|);  with the reference's own 3 u:  h = 4/3 u (6 + 4 |L~|)   (GS_BAND_SAFETY on top, as everywhere).
+// e < e_lo => the reference skips the pair, whatever the blend kernels' own alpha would say: they compare the exponent (which
+// is the reference's to the last bit) BEFORE evaluating any exponential, and pay for v_exp_f32 only where a pixel may be hit.
+// A pixel with e >= e_lo is a hit for certain once the kernels' alpha reaches EPS_HI (the bracket of 2. above); in between
+// (e within ~1e-5 of the threshold: a few hundred pixels per full-size frame) the reference's expression decides (3. above).
+// amp = 0 or NaN gives NaN: no exponent compares >= NaN, and the reference's alpha (0, or NaN) is never >= 1/255 either.
+__device__ __forceinline__ float gs_hit_exponent_lo(float amp) {
+#pragma clang fp contract(off)
+    const float L = -logf(255.0f * amp);
+    return L - GS_BAND_SAFETY * GS_U24 * (6.0f + 4.0f * fabsf(L));
+}
 // exp(e) * rescale * opacity as the reference rounds it (UTL:284 then RAS:447 / RAS:627), e = the reference's exponent
 __device__ __forceinline__ float gs_alpha_reference(float e, float rescale, float opacity) {
 #pragma clang fp contract(off)

@@ -629,9 +629,10 @@ __global__ __launch_bounds__(GS_BLOCK, 6) void preprocess_kernel(
             // what the blend kernels want next to the conic (gs_blend.hip): amp = opacity * rescale (alpha = amp * exp(e)), the
             // Gaussian's stop-bracket weight (gs_common.h, "threshold decisions") -- and the rescale factor on its own (the
             // opacity is in row 2): the reference multiplies exp(e) by them one after the other (UTL:284, RAS:447), and so does
-            // the exact re-evaluation of an alpha next to 1/255
+            // the exact re-evaluation of an alpha next to 1/255; float 14: the exponent below which the reference skips the pair
+            // for certain (gs_common.h, "the 1/255 decision in the exponent's domain")
             const float amp = opacity * rescale;
-            out[3] = make_float4(amp, gs_stop_weight(amp, 0.0001f), 0.f, rescale);
+            out[3] = make_float4(amp, gs_stop_weight(amp, 0.0001f), gs_hit_exponent_lo(amp), rescale);
         }
         nkeys[i] = owned;
     }

@@ -40,7 +40,10 @@ def pack_attrs(f: dict, exact_cull: bool = False) -> np.ndarray:
     # gs_stop_weight (csrc/gs_common.h): the Gaussian's share of a pixel's bracket around T' = 1e-4, per unit of alpha
     H = np.float32(1.0) / (np.float32(1.0) - np.minimum(amp, np.float32(0.99))) * np.float32(1.01)
     a[:, 13] = stop_t * np.float32(1.1) * np.float32(4.0 / 3.0) * u24 * (np.float32(12.0) + np.float32(9.0) * H)
-    a[:, 14] = 0.0
+    # gs_hit_exponent_lo (csrc/gs_common.h): the exponent below which the reference skips the pair for certain
+    with np.errstate(divide="ignore", invalid="ignore"):
+        L = -np.log(np.float32(255.0) * amp).astype(np.float32)
+        a[:, 14] = L - np.float32(4.0 / 3.0) * u24 * (np.float32(6.0) + np.float32(4.0) * np.abs(L))
     a[:, 15] = f["conic"][:, 3]                                           # rescale
     return a
 
