@@ -331,6 +331,15 @@ int gs_blend_backward(const int32_t *bin_start, const int32_t *payload, const fl
  * counters zero again.  Slot records stay bitwise reproducible; they differ from the un-split ones in rounding only.
  * With boundary_states / image / split_workspace NULL these are gs_blend_forward / gs_blend_backward. */
 #define GS_MAX_BACKWARD_SPLIT 4
+/* The forward pass of such a grid is split too (round 6: gs_blend_forward_split; at most 1024 rendered tiles, per-tile lists):
+ * a probe launch leaves, per pixel and list segment, the product of (1 - alpha) over the segment's hits; every segment then
+ * blends its share of the list starting from the product of the segments in front of it, with the stop rule (RAS:458-460)
+ * applied against that transmittance -- every 1/255 and 1e-4 decision is still taken as the reference takes it, colours,
+ * depth and state equal the un-split ones to rounding -- and a third launch adds the segments' results in order.
+ * forward_split_workspace: gs_blend_forward_split_workspace_bytes(width, height) bytes of scratch, dead when the call's
+ * work has completed; NULL = un-split.  debug_pixel_hits must be ZERO on entry when the forward is split. */
+#define GS_MAX_FORWARD_SPLIT 4
+size_t gs_blend_forward_split_workspace_bytes(int width, int height);
 size_t gs_blend_boundary_bytes(int64_t list_length, int width, int height);
 /* Path statistics of the two-waves-per-tile blend kernels: counted only in a tuning build (-DGS_STATS=1, tools/blend_stats.py);
  * the product build leaves them zero.  Synchronises `stream`, copies the GS_BLEND_STATS counters out and optionally clears
@@ -365,6 +374,13 @@ int gs_blend_forward_with_boundaries(const int32_t *bin_start, const int32_t *bi
                                      int flags, uint32_t *debug_pixel_hits, int32_t *tile_order, int32_t *tile_work,
                                      int32_t *walked_list, int32_t *walked_start, float *boundary_states,
                                      int64_t list_length, void *stream);
+int gs_blend_forward_split(const int32_t *bin_start, const int32_t *bin_end, const int32_t *payload,
+                           const float *attrs, int width, int height, int tile_row_begin,
+                           int tile_row_step, int tile_row_end, int bin_shift, int filter, float *image,
+                           float *depth, float *acc_alpha, int32_t *last_effective, int32_t *valid_count,
+                           int flags, uint32_t *debug_pixel_hits, int32_t *tile_order, int32_t *tile_work,
+                           int32_t *walked_list, int32_t *walked_start, float *boundary_states,
+                           int64_t list_length, void *forward_split_workspace, void *stream);
 int gs_blend_backward_split(const int32_t *bin_start, const int32_t *payload, const float *attrs,
                             const float *grad_image, const float *acc_alpha, const int32_t *last_effective,
                             const int32_t *slot_offsets, int64_t n_slots, int width, int height,
@@ -530,6 +546,7 @@ typedef struct GsFrame {
     float *image, *depth, *acc_alpha; int32_t *last_effective, *valid_count;
     int32_t *tile_order, *tile_work, *walked_list, *walked_start;
     float *boundary_states; void *split_workspace;   /* list splitting (may be NULL); list length = n_keys_capacity */
+    void *forward_split_workspace;                   /* gs_blend_forward_split (may be NULL: the forward is not split) */
     void *filter_workspace, *sort_workspace, *route_workspace;
     int32_t *route_counts, *route_pos; float *route_send; const float *records;
     /* backward */

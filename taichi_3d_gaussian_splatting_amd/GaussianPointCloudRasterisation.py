@@ -190,6 +190,8 @@ class GaussianPointCloudRasterisation(torch.nn.Module):
         # band): the forward pass leaves per-pixel boundary states every 128 list entries and the backward pass gives a
         # tile up to four workgroups (include/gsplat_hip.h "List splitting").  Same slot records up to rounding
         self.split_small_grid_backward = True
+        # ... and so does the forward pass (probe / blend / combine: gs_blend_forward_split)
+        self.split_small_grid_forward = True
         # per-pass entry points only: the colours of the visible Gaussians (RAS:280-282,302-310 -- a streaming read of the
         # 192 B of SH coefficients each) evaluated on a second stream BESIDE key generation, sort and ranges, which do not
         # read them; the blend waits for them.  Same device code as inside gs_preprocess: the same bits (tested).  MEASURED
@@ -359,7 +361,7 @@ class GaussianPointCloudRasterisation(torch.nn.Module):
                                                     rgb_only=rgb_only, need_state=need_state,
                                                     gathered_rows=gathered_rows, ordered=outer.ordered_dispatch,
                                                     tile_work=work_, ws=outer._scratch, emit_walked_lists=emit,
-                                                    boundary=boundary_)
+                                                    boundary=boundary_, split=outer.split_small_grid_forward)
                     if emit:   # what the backward pass walks: (list starts, list) of the emitted per-tile lists
                         start_, payload_, blended = blended[5], blended[6], blended[:5]
                     return payload_, slot_offsets_, start_, blended, work_, emit, boundary_

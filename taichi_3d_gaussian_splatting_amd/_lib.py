@@ -64,6 +64,9 @@ _SIGNATURES = {
     "gs_blend_split_workspace_bytes": (_c.c_size_t, [_I, _I]),
     "gs_blend_forward_with_boundaries": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P,
                                               _P, _P, _I64, _P]),
+    "gs_blend_forward_split_workspace_bytes": (_c.c_size_t, [_I, _I]),
+    "gs_blend_forward_split": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P,
+                                    _P, _P, _I64, _P, _P]),
     "gs_blend_backward_split": (_I, [_P, _P, _P, _P, _P, _P, _P, _I64, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P,
                                      _P, _P, _I64, _P, _P]),
     "gs_reduce_partials": (_I, [_P, _P, _P, _P, _I, _P, _P, _I64, _P, _I, _I, _P]),

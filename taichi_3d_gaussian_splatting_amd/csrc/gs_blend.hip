@@ -1507,6 +1507,29 @@ constexpr int SMALL_THREADS = 256;
 #endif
 
 
+// FORWARD LIST SPLITTING (round 6).  The launch of a grid that cannot fill the chip lasts as long as the longest tile's
+// dependent chain; the forward recursion of a pixel can be CUT at any list position if the transmittance in front of it is
+// known -- and that is a product of factors (1 - alpha) none of which depends on the others.  Three launches:
+//   probe   (blend_forward_probe_kernel): segment s < split - 1 of every tile walks its share of the list and leaves, per
+//           pixel, P_s = the product of (1 - alpha) over its hits (the 1/255 decisions taken exactly as everywhere else),
+//           the share of the stop bracket those hits carry and their number -- no colours, no stop rule;
+//   blend   (this kernel, split > 1): segment s starts from T_in = P_0 ... P_{s-1} and blends its share with the stop rule
+//           applied against the true transmittance.  A pixel the reference stopped in an earlier segment is recognised by
+//           T_in itself: the products (1 - alpha) only fall, so "some T' of an earlier segment was below 1e-4" is "T_in is"
+//           -- decided by the pixel's bracket as every stop decision is, and by a replay of the pixel's history in the
+//           reference's arithmetic inside it (gs_reference_stops_at).  T_in is the reference's transmittance re-associated
+//           (s extra roundings: charged to the bracket), so decisions stay the reference's; colours, depth and state are
+//           the un-split ones to rounding, not to the bit;
+//   combine (blend_forward_combine_kernel): adds the segments' partial results in segment order, writes the outputs, and
+//           turns the boundary states of segments > 0 (local colours) into prefix colours for the split backward pass.
+// split == 1 is the un-split kernel, bit for bit.
+constexpr int FSPLIT_PART_F4 = 3;   // float4 per (segment, pixel): (Cr, Cg, Cb, T_end) (D, Wd, count, last) (Er, Eg, Eb, alive at the start)
+__device__ __forceinline__ void gs_segment_batches(int start, int end, int seg, int split, int &k_lo, int &k_hi) {
+    const int nb = end > start ? (end - start + BATCH - 1) / BATCH : 0;   // batch k = list positions [start + 128 k, start + 128 (k + 1))
+    k_lo = (int)((long long)seg * nb / split);
+    k_hi = (int)((long long)(seg + 1) * nb / split);
+}
+
 template <bool AUX, bool STATE, bool DEBUG>
 __global__ __launch_bounds__(SMALL_THREADS) void blend_forward_small_kernel(
     const int32_t *__restrict__ tile_start, const int32_t *__restrict__ tile_end,
@@ -1514,17 +1537,25 @@ __global__ __launch_bounds__(SMALL_THREADS) void blend_forward_small_kernel(
     int row_step, float *__restrict__ image, float *__restrict__ depth, float *__restrict__ acc_alpha,
     int32_t *__restrict__ last_effective, int32_t *__restrict__ valid_count, uint32_t *__restrict__ debug_hits,
     const int32_t *__restrict__ tile_order, int32_t *__restrict__ tile_work, float4 *__restrict__ boundary,
-    float4 *__restrict__ final_error) {
+    float4 *__restrict__ final_error, int split, const float4 *__restrict__ probe, float4 *__restrict__ parts) {
     __shared__ float4 s_p[BATCH], s_q[BATCH], s_c[BATCH];   // (gs_stage_forward)
     __shared__ float2 s_ro[BATCH];
     __shared__ int s_o[DEBUG ? BATCH : 1];
     __shared__ int s_red[SMALL_THREADS / GS_WAVE];
     const int tw = width / GS_TILE_WIDTH, th = height / GS_TILE_HEIGHT;
-    const TileCoord tc = owned_tile(tw, row_begin, row_step, tile_order);
+    const int seg = split > 1 ? (int)blockIdx.x % split : 0;
+    const TileCoord tc = owned_tile_at(split > 1 ? (int)blockIdx.x / split : (int)blockIdx.x,
+                                       split > 1 ? (int)gridDim.x / split : (int)gridDim.x, tw, row_begin, row_step, tile_order);
     const int tid = threadIdx.x;
     const int pu = tc.tile_u * GS_TILE_WIDTH + (tid & 15), pv = tc.tile_v * GS_TILE_HEIGHT + (tid >> 4);
-    const int start = tile_start[tc.tile_id], end = tile_end[tc.tile_id];
+    const int start = tile_start[tc.tile_id], list_end = tile_end[tc.tile_id];
     const float px = (float)pu + 0.5f, py = (float)pv + 0.5f;
+    const size_t p = (size_t)pv * width + pu, n_pixels = (size_t)width * height;
+    int k_lo = 0, k_hi = 0;
+    if (split > 1) gs_segment_batches(start, list_end, seg, split, k_lo, k_hi);
+    // this workgroup's share of the list: [first, end)
+    const int first = split > 1 ? start + BATCH * k_lo : start;
+    const int end = split > 1 ? min(start + BATCH * k_hi, list_end) : list_end;
     float T = 1.0f, Cr = 0.f, Cg = 0.f, Cb = 0.f, D = 0.f, Wd = 0.f;
     // Rounding left behind by the colour sums (boundary states only): the image is the plain fp32 sum, as always; next to it
     // E collects what each fma rounded away, so that C + E is the prefix colour to ~1e-14 and the split backward pass can
@@ -1536,7 +1567,39 @@ __global__ __launch_bounds__(SMALL_THREADS) void blend_forward_small_kernel(
     int last = start, cnt = 0;
     unsigned dh = 0u, dc = 0u;
     float thr = STOP_T;   // upper edge of the pixel's stop bracket (blend_forward_kernel)
-    int pos = start;
+    int cnt_in = 0;       // Gaussians blended in front of this segment (the bracket's rounding term counts them)
+    bool alive_in = true;
+    if (seg > 0) {
+        // the state in front of the segment, from the probes of the segments before it (in list order)
+        float bracket = 0.f;
+#pragma clang loop unroll(disable)
+        for (int q = 0; q < seg; ++q) {
+            const float4 pr = probe[(size_t)q * n_pixels + p];
+            T = T * pr.x;
+            bracket += pr.y;
+            cnt_in += __builtin_bit_cast(int, pr.z);
+        }
+        // the bracket as the un-split walk would hold it here (its batches in front of the cut are all full), plus one
+        // rounding per segment product (T_in = (P_0 P_1) ... : seg multiplications the reference's chain does not have; the
+        // chains' own roundings are the 4 u per blended Gaussian every stop bracket charges) and per partial sum of `bracket`
+        const int walked_in = first - start;
+        thr = STOP_T + bracket + (STOP_T * 1.1f * GS_STOP_ROUNDING_BAND * (float)walked_in +
+                                  (float)(k_lo + 2 * seg) * GS_STOP_THR_SLACK + (float)seg * STOP_T * 1.1f * GS_BAND_SAFETY * GS_U24);
+        {   // RAS:458-460 over the segments in front: has the reference stopped this pixel already?  (wave-convergent)
+            float lo, hi;
+            gs_stop_bracket(thr, walked_in, cnt_in, lo, hi);
+            bool dead = cnt_in > 0 && T < lo;
+            for (unsigned long long m = gs_ballot(cnt_in > 0 && !dead && T < hi); m != 0ull; m &= m - 1ull) {
+                const int l = __builtin_ctzll(m);
+                const bool stops = gs_reference_stops_at<false, false>(payload, attrs, start, first - 1, gs_readlane_f(px, l),
+                                                                       gs_readlane_f(py, l), tc.tile_u, tc.tile_v, tw, th);
+                if ((tid & (GS_WAVE - 1)) == l) dead = stops;
+            }
+            alive_in = !dead;
+            alive_m = gs_ballot(alive_in);
+        }
+    }
+    int pos = first;
     while (pos < end) {
         if (__syncthreads_and(alive_m == 0ull ? 1 : 0)) break;   // barrier (protects the staged batch) + whole-tile early exit
         const int batch_first = pos;
@@ -1565,6 +1628,7 @@ __global__ __launch_bounds__(SMALL_THREADS) void blend_forward_small_kernel(
         thr += STOP_T * 1.1f * GS_STOP_ROUNDING_BAND * (float)nbuf + GS_STOP_THR_SLACK;
         const int walked = min(pos, end) - start;   // list positions walked so far, this batch included (pos has already moved
                                                     // BATCH on: past `end` in the last, partial batch)
+        const int cnt_base = AUX ? cnt_in + 1 : -1; // (+ cnt: the pixel's own number of blended Gaussians, this one included)
         // (the one-pixel forms of blend_forward_kernel's `blend`, `careful_entry` and group loop: see there)
         auto blend = [&](int e, const float4 c, float z, float al, float Tn, bool ok) {
             const float wgt = al * T;
@@ -1609,7 +1673,7 @@ __global__ __launch_bounds__(SMALL_THREADS) void blend_forward_small_kernel(
             thr = __builtin_fmaf(c.w, al, thr);
             float Tn = T * (1.f - al);
             float lo, hi;
-            gs_stop_bracket(thr, walked, AUX ? cnt + 1 : -1, lo, hi);
+            gs_stop_bracket(thr, walked, AUX ? cnt_base + cnt : -1, lo, hi);
             bool sat = ok && Tn < lo;   // RAS:458-460, below the bracket
             for (unsigned long long m = gs_ballot(ok && !sat && Tn < hi); m != 0ull; m &= m - 1ull) {
                 const int l = __builtin_ctzll(m);
@@ -1647,7 +1711,7 @@ __global__ __launch_bounds__(SMALL_THREADS) void blend_forward_small_kernel(
                 float Tn = T * (1.f - al);
                 if ((mok & gs_ballot(Tn < thr)) != 0ull) {              // RAS:458-460: saturates the pixel, NOT blended
                     float lo, hi;
-                    gs_stop_bracket(thr, walked, AUX ? cnt + 1 : -1, lo, hi);
+                    gs_stop_bracket(thr, walked, AUX ? cnt_base + cnt : -1, lo, hi);
                     const bool sat = ok && Tn < lo;
                     if (gs_ballot(ok && !sat && Tn < hi) != 0ull) { careful_from = i; break; }   // (thr keeps this entry's share: the
                                                                                                  //  careful twin adds it again -- wider, safe)
@@ -1665,13 +1729,23 @@ __global__ __launch_bounds__(SMALL_THREADS) void blend_forward_small_kernel(
         // Boundary state after every 128 entries of the tile's list (split backward, blend_backward_small_kernel), at slot
         // (list position >> 7): unique, because the tiles' lists are disjoint ranges and two boundaries of one list are 128
         // positions apart
-        if (track && pos < end) {
+        if (track && pos < list_end) {
             float4 *st = boundary + ((size_t)(pos >> 7) * 256 + tid) * 2;
             st[0] = make_float4(T, Cr, Cg, Cb);
             st[1] = make_float4(Er, Eg, Eb, 0.f);
         }
     }
-    const size_t p = (size_t)pv * width + pu;
+    if (split > 1) {   // this segment's partial results; blend_forward_combine_kernel adds them up
+        float4 *out = parts + ((size_t)seg * n_pixels + p) * FSPLIT_PART_F4;
+        out[0] = make_float4(Cr, Cg, Cb, T);
+        out[1] = make_float4(D, Wd, __builtin_bit_cast(float, cnt), __builtin_bit_cast(float, last));
+        out[2] = make_float4(Er, Eg, Eb, alive_in ? 1.f : 0.f);
+        if (DEBUG) {   // (unsigned sums: any order; the caller zeroes the buffer)
+            atomicAdd(&debug_hits[2 * p], dc);
+            atomicAdd(&debug_hits[2 * p + 1], dh);
+        }
+        return;
+    }
     image[3 * p] = Cr; image[3 * p + 1] = Cg; image[3 * p + 2] = Cb;
     if (track) final_error[p] = make_float4(Er, Eg, Eb, T);   // (.w: the final transmittance itself, see the split backward)
     if (AUX) {
@@ -1691,6 +1765,147 @@ __global__ __launch_bounds__(SMALL_THREADS) void blend_forward_small_kernel(
         }
     }
     if (DEBUG) { debug_hits[2 * p] = dc; debug_hits[2 * p + 1] = dh; }
+}
+
+// The probe of the forward list split (see blend_forward_small_kernel): workgroup (tile, s), s < split - 1, walks the batches
+// of segment s and leaves per pixel (P_s, the hits' share of the stop bracket, their number).  Per pixel and entry the
+// exponent, the hit test and alpha are the blend kernel's, operation by operation; an alpha short of EPS_HI is settled by the
+// reference's expression on the spot (this kernel has registers to spare).  A pixel whose own product has fallen below
+// 0.9e-4 is below every stop bracket whatever comes in front of it: it stops looking, and so does its tile when all have.
+__global__ __launch_bounds__(SMALL_THREADS) void blend_forward_probe_kernel(
+    const int32_t *__restrict__ tile_start, const int32_t *__restrict__ tile_end, const int32_t *__restrict__ payload,
+    const float4 *__restrict__ attrs, int width, int height, int row_begin, int row_step,
+    const int32_t *__restrict__ tile_order, int split, float4 *__restrict__ probe) {
+    __shared__ float4 s_p[BATCH], s_q[BATCH];   // P and Q of gs_stage_forward
+    __shared__ float4 s_w[BATCH];               // (stop weight, rescale, opacity, .)
+    const int tw = width / GS_TILE_WIDTH;
+    const int seg = (int)blockIdx.x % (split - 1);
+    const TileCoord tc = owned_tile_at((int)blockIdx.x / (split - 1), (int)gridDim.x / (split - 1), tw, row_begin, row_step,
+                                       tile_order);
+    const int tid = threadIdx.x;
+    const int pu = tc.tile_u * GS_TILE_WIDTH + (tid & 15), pv = tc.tile_v * GS_TILE_HEIGHT + (tid >> 4);
+    const int start = tile_start[tc.tile_id], list_end = tile_end[tc.tile_id];
+    const float px = (float)pu + 0.5f, py = (float)pv + 0.5f;
+    const size_t p = (size_t)pv * width + pu, n_pixels = (size_t)width * height;
+    int k_lo, k_hi;
+    gs_segment_batches(start, list_end, seg, split, k_lo, k_hi);
+    const int end = min(start + BATCH * k_hi, list_end);
+    float P = 1.0f, bracket = 0.f;
+    int cnt = 0;
+    unsigned long long looking = ~0ull;   // the lanes whose pixel is still looking (wave-uniform)
+    for (int pos = start + BATCH * k_lo; pos < end; pos += BATCH) {
+        if (__syncthreads_and(looking == 0ull ? 1 : 0)) break;   // barrier (protects the staged batch) + whole-tile early exit
+        {
+            const int j = pos + tid;
+            if (tid < BATCH && j < end) {
+                const float4 *g = attrs + 4 * (size_t)payload[j];
+                float4 Pq, Q, colour;
+                float2 ro;
+                gs_stage_forward(g[0], g[1], g[2], g[3], Pq, Q, colour, ro);
+                s_p[tid] = Pq; s_q[tid] = Q; s_w[tid] = make_float4(colour.w, ro.x, ro.y, 0.f);
+            }
+        }
+        const int nbuf = min(BATCH, end - pos);
+        __syncthreads();
+        for (int e = 0; e < nbuf; ++e) {
+            if (looking == 0ull) break;
+            const float4 Pq = s_p[e], Q = s_q[e];
+            const float ex = gs_exponent_forward(px - Pq.x, py - Pq.y, Pq.z, Q.x, Pq.w);
+            const unsigned long long mok = gs_ballot(ex >= Q.y) & looking;   // RAS:451 in the exponent's domain
+            if (mok == 0ull) continue;
+            const float4 w = s_w[e];
+            const float a = __builtin_amdgcn_exp2f(ex * GS_LOG2E) * Q.z;
+            bool ok = __builtin_amdgcn_inverse_ballot_w64(mok);
+            const bool unsure = ok && !(a >= EPS_HI);
+            if (gs_ballot(unsure) != 0ull) {   // rare: the reference's own expression decides
+                const float exact = gs_alpha_reference(ex, w.y, w.z);
+                if (unsure) ok = exact >= EPS_ALPHA;
+            }
+            const float al = ok ? __builtin_amdgcn_fmed3f(a, 0.f, CLAMP_ALPHA) : 0.f;
+            P = P * (1.f - al);
+            bracket = __builtin_fmaf(w.x, al, bracket);
+            cnt += ok ? 1 : 0;
+            looking &= ~gs_ballot(P < 0.9f * STOP_T);
+        }
+    }
+    probe[(size_t)seg * n_pixels + p] = make_float4(P, bracket, __builtin_bit_cast(float, cnt), 0.f);
+}
+
+// error-free sum: s = fl(a + b), returns a + b - s (contraction is off in this file)
+__device__ __forceinline__ float gs_two_sum(float a, float b, float &s) {
+    s = a + b;
+    const float bb = s - a;
+    return (a - (s - bb)) + (b - bb);
+}
+
+// The last launch of the forward list split: the segments' partial results added in segment order -> the outputs of
+// blend_forward_small_kernel; boundary states of segments > 0 (local colours) -> prefix colours (see there).
+template <bool AUX, bool STATE>
+__global__ __launch_bounds__(SMALL_THREADS) void blend_forward_combine_kernel(
+    const int32_t *__restrict__ tile_start, const int32_t *__restrict__ tile_end, int width, int height, int row_begin,
+    int row_step, float *__restrict__ image, float *__restrict__ depth, float *__restrict__ acc_alpha,
+    int32_t *__restrict__ last_effective, int32_t *__restrict__ valid_count, const int32_t *__restrict__ tile_order,
+    int32_t *__restrict__ tile_work, float4 *__restrict__ boundary, float4 *__restrict__ final_error, int split,
+    const float4 *__restrict__ parts) {
+    __shared__ int s_red[SMALL_THREADS / GS_WAVE];
+    const int tw = width / GS_TILE_WIDTH;
+    const TileCoord tc = owned_tile(tw, row_begin, row_step, tile_order);
+    const int tid = threadIdx.x;
+    const int pu = tc.tile_u * GS_TILE_WIDTH + (tid & 15), pv = tc.tile_v * GS_TILE_HEIGHT + (tid >> 4);
+    const size_t p = (size_t)pv * width + pu, n_pixels = (size_t)width * height;
+    const int start = tile_start[tc.tile_id], end = tile_end[tc.tile_id];
+    const bool track = STATE && boundary != nullptr;
+    float C[3] = {0.f, 0.f, 0.f}, E[3] = {0.f, 0.f, 0.f}, D = 0.f, Wd = 0.f, T = 1.0f;
+    int cnt = 0, last = start;
+#pragma clang loop unroll(disable)
+    for (int q = 0; q < split; ++q) {
+        const float4 *in = parts + ((size_t)q * n_pixels + p) * FSPLIT_PART_F4;
+        const float4 r0 = in[0], r1 = in[1], r2 = in[2];
+        if (track && q > 0) {   // segment q's boundary states: local colour + the colour in front of the segment
+            int k_lo, k_hi;
+            gs_segment_batches(start, end, q, split, k_lo, k_hi);
+            for (int kb = k_lo; kb < k_hi; ++kb) {
+                const int pos = start + BATCH * (kb + 1);
+                if (pos >= end) break;
+                float4 *st = boundary + ((size_t)(pos >> 7) * 256 + tid) * 2;
+                float4 a = st[0], b = st[1];
+                float sum;
+                b.x += E[0] + gs_two_sum(C[0], a.y, sum); a.y = sum;
+                b.y += E[1] + gs_two_sum(C[1], a.z, sum); a.z = sum;
+                b.z += E[2] + gs_two_sum(C[2], a.w, sum); a.w = sum;
+                st[0] = a; st[1] = b;
+            }
+        }
+        const float part[3] = {r0.x, r0.y, r0.z}, err[3] = {r2.x, r2.y, r2.z};
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float sum;
+            E[c] += err[c] + gs_two_sum(C[c], part[c], sum);
+            C[c] = sum;
+        }
+        D += r1.x; Wd += r1.y;
+        cnt += __builtin_bit_cast(int, r1.z);
+        last = max(last, __builtin_bit_cast(int, r1.w));
+        if (r2.w != 0.f) T = r0.w;   // the transmittance the pixel ends with: that of the last segment it was alive in
+    }
+    image[3 * p] = C[0]; image[3 * p + 1] = C[1]; image[3 * p + 2] = C[2];
+    if (track) final_error[p] = make_float4(E[0], E[1], E[2], T);
+    if (AUX) {
+        depth[p] = D / fmaxf(Wd, 1e-6f);  // RAS:479-480
+        valid_count[p] = cnt;
+    }
+    if (STATE) {
+        acc_alpha[p] = 1.f - T;
+        last_effective[p] = last;
+        if (tile_work != nullptr) {
+            int mx = last;
+#pragma unroll
+            for (int d = 32; d > 0; d >>= 1) mx = max(mx, __shfl_xor(mx, d, GS_WAVE));
+            if ((tid & 63) == 0) s_red[tid >> 6] = mx;
+            __syncthreads();
+            if (tid == 0) tile_work[tc.index] = max(max(s_red[0], s_red[1]), max(s_red[2], s_red[3])) - start;
+        }
+    }
 }
 
 // LIST SPLITTING (round 4).  On a grid that cannot fill the chip the launch lasts as long as the longest tile's dependent
@@ -2071,10 +2286,10 @@ int gs_blend_forward(const int32_t *bin_start, const int32_t *bin_end, const int
                      int filter, float *image, float *depth, float *acc_alpha, int32_t *last_effective,
                      int32_t *valid_count, int flags, uint32_t *debug_pixel_hits, int32_t *tile_order,
                      int32_t *tile_work, int32_t *walked_list, int32_t *walked_start, void *stream) {
-    return gs_blend_forward_with_boundaries(bin_start, bin_end, payload, attrs, width, height, tile_row_begin,
-                                            tile_row_step, tile_row_end, bin_shift, filter, image, depth, acc_alpha,
-                                            last_effective, valid_count, flags, debug_pixel_hits, tile_order, tile_work,
-                                            walked_list, walked_start, nullptr, 0, stream);
+    return gs_blend_forward_split(bin_start, bin_end, payload, attrs, width, height, tile_row_begin, tile_row_step,
+                                  tile_row_end, bin_shift, filter, image, depth, acc_alpha, last_effective, valid_count, flags,
+                                  debug_pixel_hits, tile_order, tile_work, walked_list, walked_start, nullptr, 0, nullptr,
+                                  stream);
 }
 
 int gs_blend_forward_with_boundaries(const int32_t *bin_start, const int32_t *bin_end, const int32_t *payload,
@@ -2084,6 +2299,31 @@ int gs_blend_forward_with_boundaries(const int32_t *bin_start, const int32_t *bi
                                      uint32_t *debug_pixel_hits, int32_t *tile_order, int32_t *tile_work,
                                      int32_t *walked_list, int32_t *walked_start, float *boundary_states,
                                      int64_t list_length, void *stream) {
+    return gs_blend_forward_split(bin_start, bin_end, payload, attrs, width, height, tile_row_begin, tile_row_step,
+                                  tile_row_end, bin_shift, filter, image, depth, acc_alpha, last_effective, valid_count, flags,
+                                  debug_pixel_hits, tile_order, tile_work, walked_list, walked_start, boundary_states,
+                                  list_length, nullptr, stream);
+}
+
+size_t gs_blend_forward_split_workspace_bytes(int width, int height) {
+    const size_t pixels = (size_t)width * height;
+    return pixels * sizeof(float4) * ((GS_MAX_FORWARD_SPLIT - 1) + (size_t)GS_MAX_FORWARD_SPLIT * FSPLIT_PART_F4);
+}
+
+// workgroups per tile of the split forward pass for a grid of `tiles` tiles (1 = no split)
+static int forward_split_for(int tiles) {
+    static const int forced = getenv("GS_FWD_SPLIT") ? atoi(getenv("GS_FWD_SPLIT")) : 0;   // tuning knob
+    if (forced > 0) return forced > GS_MAX_FORWARD_SPLIT ? GS_MAX_FORWARD_SPLIT : forced;
+    return tiles <= 512 ? 4 : (tiles <= 1024 ? 2 : 1);
+}
+
+int gs_blend_forward_split(const int32_t *bin_start, const int32_t *bin_end, const int32_t *payload,
+                           const float *attrs, int width, int height, int tile_row_begin, int tile_row_step,
+                           int tile_row_end, int bin_shift, int filter, float *image, float *depth,
+                           float *acc_alpha, int32_t *last_effective, int32_t *valid_count, int flags,
+                           uint32_t *debug_pixel_hits, int32_t *tile_order, int32_t *tile_work,
+                           int32_t *walked_list, int32_t *walked_start, float *boundary_states,
+                           int64_t list_length, void *forward_split_workspace, void *stream) {
     // (boundary states are only produced by the four-waves-per-tile kernel on per-tile lists: what small frames use)
     float4 *boundary = reinterpret_cast<float4 *>(boundary_states);
     float4 *final_error = boundary_states == nullptr ? nullptr
@@ -2115,10 +2355,26 @@ int gs_blend_forward_with_boundaries(const int32_t *bin_start, const int32_t *bi
     }
     const bool four_waves = !staged && !(flags & GS_BLEND_TWO_WAVES) &&
                             ((flags & GS_BLEND_FOUR_WAVES) || tw * rows <= GS_SMALL_GRID_TILES);
+    // several workgroups per tile on a grid that cannot fill the chip (see blend_forward_small_kernel): probe, blend, combine
+    const int split = four_waves && forward_split_workspace != nullptr ? forward_split_for(tw * rows) : 1;
+    const size_t n_pixels = (size_t)width * height;
+    float4 *probe = reinterpret_cast<float4 *>(forward_split_workspace);
+    float4 *parts = probe == nullptr ? nullptr : probe + (GS_MAX_FORWARD_SPLIT - 1) * n_pixels;
+    if (split > 1) {
+        hipLaunchKernelGGL(blend_forward_probe_kernel, dim3(tw * rows * (split - 1)), dim3(SMALL_THREADS), 0, s, bin_start,
+                           bin_end, payload, a4, width, height, tile_row_begin, tile_row_step, tile_order, split, probe);
+        GS_CHECK_LAUNCH();
+    }
+    const dim3 sgrid(tw * rows * split);
 #define GS_FWD_SMALL(AUX, STATE, DBG)                                                                                \
-    hipLaunchKernelGGL((blend_forward_small_kernel<AUX, STATE, DBG>), grid, dim3(SMALL_THREADS), 0, s, bin_start,     \
+    hipLaunchKernelGGL((blend_forward_small_kernel<AUX, STATE, DBG>), sgrid, dim3(SMALL_THREADS), 0, s, bin_start,    \
                        bin_end, payload, a4, width, height, tile_row_begin, tile_row_step, image, depth, acc_alpha,   \
-                       last_effective, valid_count, debug_pixel_hits, tile_order, tile_work, boundary, final_error)
+                       last_effective, valid_count, debug_pixel_hits, tile_order, tile_work, boundary, final_error,   \
+                       split, probe, parts)
+#define GS_FWD_COMBINE(AUX, STATE)                                                                                   \
+    hipLaunchKernelGGL((blend_forward_combine_kernel<AUX, STATE>), grid, dim3(SMALL_THREADS), 0, s, bin_start, bin_end, \
+                       width, height, tile_row_begin, tile_row_step, image, depth, acc_alpha, last_effective,         \
+                       valid_count, tile_order, tile_work, boundary, final_error, split, parts)
 #define GS_FWD_SMALL2(AUX, STATE) do { if (dbg) GS_FWD_SMALL(AUX, STATE, true); else GS_FWD_SMALL(AUX, STATE, false); } while (0)
 #define GS_FWD(STAGED, AUX, STATE)                                                                                  \
     launch_forward<STAGED, AUX, STATE>(dbg, grid, s, bin_start, bin_end, payload, a4, width, height, tile_row_begin, \
@@ -2136,7 +2392,15 @@ int gs_blend_forward_with_boundaries(const int32_t *bin_start, const int32_t *bi
         else if (aux) GS_FWD_SMALL2(true, false);
         else if (state) GS_FWD_SMALL2(false, true);
         else GS_FWD_SMALL2(false, false);
+        if (split > 1) {
+            GS_CHECK_LAUNCH();
+            if (aux && state) GS_FWD_COMBINE(true, true);
+            else if (aux) GS_FWD_COMBINE(true, false);
+            else if (state) GS_FWD_COMBINE(false, true);
+            else GS_FWD_COMBINE(false, false);
+        }
     } else if (staged) GS_FWD2(true); else GS_FWD2(false);
+#undef GS_FWD_COMBINE
 #undef GS_FWD_SMALL2
 #undef GS_FWD_SMALL
 #undef GS_FWD2

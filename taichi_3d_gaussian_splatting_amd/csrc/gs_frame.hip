@@ -138,11 +138,11 @@ static int frame_forward_stages(GsFrame *f, uint32_t stages, void *stream, bool 
                                           f->bin_ranges + f->n_bins, f->n_bins, (stages & GS_FWD_SORT) ? 1 : 0, stream));
     GS_JOIN_COLOURS();
     if (stages & GS_FWD_BLEND)
-        GS_STAGE(gs_blend_forward_with_boundaries(
+        GS_STAGE(gs_blend_forward_split(
             f->bin_ranges, f->bin_ranges + f->n_bins, payload_sorted, attrs, f->width, f->height, f->tile_row_begin,
             f->tile_row_step, f->tile_row_end, f->bin_shift, filter, f->image, f->depth, f->acc_alpha, f->last_effective,
             f->valid_count, f->blend_flags, nullptr, f->tile_order, f->tile_work, f->walked_list, f->walked_start,
-            f->boundary_states, f->n_keys_capacity, stream));
+            f->boundary_states, f->n_keys_capacity, f->forward_split_workspace, stream));
     return 0;
 }
 #undef GS_JOIN_COLOURS

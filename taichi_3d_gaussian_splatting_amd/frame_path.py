@@ -180,6 +180,8 @@ def forward(outer, xyz, features, invalid, obj, intrinsics, q_pc, t_pc, camera_i
     f.walked_list, f.walked_start = slab.ptr("walked_list"), slab.ptr("walked_start")
     f.boundary_states = slab.ptr("boundary")
     f.split_workspace = hip_ops.split_workspace(ws, width, height, dev).data_ptr() if split else 0
+    fsplit = hip_ops.forward_split_workspace(ws, width, height, layout, dev) if getattr(outer, "split_small_grid_forward", False) else None
+    f.forward_split_workspace = 0 if fsplit is None else fsplit.data_ptr()
     f.filter_workspace = _ws_bytes(ws, "f_filter", lib.gs_filter_workspace_bytes(n), dev)
     f.sort_workspace = _ws_bytes(ws, "f_sort", lib.gs_sort_workspace_bytes(cap), dev)
     stages = FORWARD_STAGES

@@ -417,11 +417,24 @@ def split_workspace(ws: Workspaces, width: int, height: int, device) -> torch.Te
                   device, zeroed=True)
 
 
+def forward_split_bytes(width: int, height: int, layout: ListLayout) -> int:
+    """Bytes of scratch with which gs_blend_forward_split gives a tile several workgroups (include/gsplat_hip.h "List
+    splitting": per-tile lists taken as they are on a grid of at most 1024 rendered tiles), or 0: the forward is not split."""
+    if layout.bin_shift != 0 or layout.filter != 0 or num_owned_tiles(width, height, layout) > SPLIT_GRID_TILES:
+        return 0
+    return int(_lib.load().gs_blend_forward_split_workspace_bytes(int(width), int(height)))
+
+
+def forward_split_workspace(ws: Optional[Workspaces], width: int, height: int, layout: ListLayout, device) -> Optional[torch.Tensor]:
+    nbytes = forward_split_bytes(width, height, layout)
+    return _scratch(ws, "split_forward", nbytes, torch.uint8, device) if nbytes else None
+
+
 def blend_forward(bin_start, bin_end, payload, attrs, width, height, layout: ListLayout = ListLayout(),
                   out=None, rgb_only=False, need_state=True, debug_hits=False, gathered_rows: int = 0,
                   ordered: bool = False, tile_work: Optional[torch.Tensor] = None, arm: Optional[str] = None,
                   ws: Optional[Workspaces] = None, emit_walked_lists: bool = False,
-                  boundary: Optional[torch.Tensor] = None):
+                  boundary: Optional[torch.Tensor] = None, split: bool = False):
     """-> (image, depth, acc_alpha, last_effective, count).  rgb_only: depth and count are not computed (returned
     as None); need_state=False: acc_alpha / last_effective are not computed (None) -- the inference path.
     debug_hits=True appends a uint32-as-int32 [H,W,2] tensor {blended count, hash of blended payloads} per pixel.
@@ -429,7 +442,9 @@ def blend_forward(bin_start, bin_end, payload, attrs, width, height, layout: Lis
     tiles], needs the state): receives the walk lengths the backward pass will see (blend_backward_partials).
     emit_walked_lists (binned layouts with state): appends (walked_start i32[tiles], walked_list i32[K << 2 bin_shift]) --
     every tile's own list as far as it was walked; last_effective then refers to positions in walked_list and the
-    backward pass is run on (walked_start, walked_list) with ``walked_layout(layout)``."""
+    backward pass is run on (walked_start, walked_list) with ``walked_layout(layout)``.
+    split: small grids with per-tile lists give a tile several workgroups (gs_blend_forward_split): every decision as the
+    un-split pass takes it, values equal to rounding."""
     dev = bin_start.device
     flags = (BLEND_RGB_ONLY if rgb_only else 0) | (0 if need_state else BLEND_NO_STATE) | BLEND_ARMS[arm]
     if out is None:
@@ -459,10 +474,11 @@ def blend_forward(bin_start, bin_end, payload, attrs, width, height, layout: Lis
         walked_list = torch.empty(max(payload.shape[0], 1) << (2 * layout.bin_shift), dtype=torch.int32, device=dev)
         walked_start = torch.empty((width // TILE_WIDTH) * (height // TILE_HEIGHT), dtype=torch.int32, device=dev)
     # boundary (uint8 buffer of boundary_states_bytes(...), optional): the forward leaves its boundary states there
-    call("gs_blend_forward_with_boundaries", ptr(bin_start), ptr(bin_end), ptr(payload), ptr(attrs), int(width), int(height),
+    split_ws = forward_split_workspace(ws, width, height, layout, dev) if split else None
+    call("gs_blend_forward_split", ptr(bin_start), ptr(bin_end), ptr(payload), ptr(attrs), int(width), int(height),
          layout.row_begin, layout.row_step, layout.row_end, layout.bin_shift, layout.filter, ptr(image), ptr(depth),
          ptr(acc_alpha), ptr(last_eff), ptr(count), flags, ptr(dbg), ptr(order), ptr(tile_work), ptr(walked_list),
-         ptr(walked_start), ptr(boundary), int(payload.shape[0]), current_stream(dev))
+         ptr(walked_start), ptr(boundary), int(payload.shape[0]), ptr(split_ws), current_stream(dev))
     if emit_walked_lists:
         out = out + (walked_start, walked_list)
     return out + (dbg,) if debug_hits else out

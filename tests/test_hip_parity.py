@@ -584,7 +584,7 @@ def test_point_backward_sh_band_clearing(ops, scene, ofwd, obwd, band, keep):
 
 
 # ------------------------------------------------------------------------------- whole operator
-def _run_operator(scene, grad_image, band=3, hook=None, row=(0, 1), op=None, row_end=None, bin_shift=None):
+def _run_operator(scene, grad_image, band=3, hook=None, row=(0, 1), op=None, row_end=None, bin_shift=None, split_forward=None):
     from taichi_3d_gaussian_splatting_amd import CameraInfo, GaussianPointCloudRasterisation as Op
     s = scene.to("cuda")
     xyz = s.point_cloud.clone().requires_grad_(True)
@@ -598,6 +598,8 @@ def _run_operator(scene, grad_image, band=3, hook=None, row=(0, 1), op=None, row
             op.tile_row_end = row_end
         if bin_shift is not None:
             op.bin_shift = bin_shift
+        if split_forward is not None:
+            op.split_small_grid_forward = split_forward
     inp = Op.GaussianPointCloudRasterisationInput(
         point_cloud=xyz, point_cloud_features=feat, point_object_id=s.point_object_id,
         point_invalid_mask=s.point_invalid_mask,
@@ -1050,6 +1052,77 @@ def test_split_backward_on_small_grids(ops, size, n, bin_shift):
     assert worst < 5e-6 and rel < 2e-6 and mag < 1e-5
 
 
+@pytest.mark.parametrize("size,n,state,rgb_only", [(256, 10_000, True, False), (512, 60_000, True, False), (128, 6_000, True, False),
+                                                   (400, 2_000, True, False), (256, 10_000, False, False), (256, 10_000, False, True),
+                                                   (192, 30_000, True, False)])
+def test_split_forward_on_small_grids(ops, size, n, state, rgb_only):
+    """Forward list splitting (include/gsplat_hip.h, round 6): on grids of at most 1,024 tiles with per-tile lists a tile gets
+    four (<= 512 tiles) or two workgroups forward -- probe, blend from the product of the segments in front, combine.  Against
+    the un-split forward on the same lists: the SAME (pixel, Gaussian) pairs blended on every pixel (count + hash), the same
+    per-pixel count and last effective position, image / depth / transmittance equal to rounding; two split runs give the
+    same bits; and the split backward pass, started from the boundary states the split forward leaves, gives the un-split
+    backward's pairs and its sums to rounding.  Lists of 200-600 entries (every segment holds batches), of a dozen (one
+    batch: the other segments are empty), and -- 192 x 192 with 30,000 Gaussians -- lists that run into the T' < 1e-4 stop
+    in the first segments, so that later ones start dead."""
+    from taichi_3d_gaussian_splatting_amd.synthetic import make_grad_image, make_scene
+    kw = dict(s_min=0.03, s_max=0.12) if n == 30_000 else dict(s_min=0.01, s_max=0.08)
+    s = make_scene(n=n, height=size, width=size, seed=size + 7, **kw).to("cuda")
+    layout = ops.ListLayout(bin_shift=0)
+    st = _stages_to_ranges(ops, s, layout)
+    assert ops.forward_split_bytes(size, size, layout) > 0
+    common = dict(rgb_only=rgb_only, need_state=state, debug_hits=True)
+    boundary = {}
+    if state:
+        nbytes = ops.boundary_states_bytes(st["payload"].shape[0], size, size, layout, False)
+        boundary = {k: torch.full((nbytes,), 0x7f, dtype=torch.uint8, device="cuda") for k in ("plain", "split")}
+    work = {k: torch.empty(ops.num_owned_tiles(size, size, layout), dtype=torch.int32, device="cuda") for k in ("plain", "split")}
+    run = lambda key, split, ws=None: ops.blend_forward(   # noqa: E731
+        st["start"], st["end"], st["payload"], st["attrs"], size, size, layout, ordered=True,
+        tile_work=work[key] if state else None, boundary=boundary.get(key), split=split, ws=ws, **common)
+    plain = run("plain", False)
+    ws = ops.Workspaces()
+    first = [None if t is None else t.clone() for t in run("split", True, ws)]
+    again = run("split", True, ws)
+    for a, b in zip(first, again):                                               # bitwise reproducible
+        assert (a is None and b is None) or torch.equal(a, b)
+    image, depth, acc_alpha, last_eff, count, hits = first
+    assert torch.equal(hits, plain[5])                                           # the same pairs on every pixel
+    stopped = int((plain[2] > 1 - 1.05e-4).sum()) if state else -1
+    if not rgb_only:
+        assert torch.equal(count, plain[4])
+        ok = count > 0
+        d = (depth - plain[1]).abs()[ok] / plain[1][ok].abs().clamp_min(1e-6)
+        assert float(d.max()) < 1e-5
+    worst = float((image - plain[0]).abs().max())
+    report("split_forward", size=size, n=n, tiles=(size // 16) ** 2, image_linf=worst, pixels_at_the_stop=stopped)
+    assert worst < 2e-6
+    if state:
+        assert torch.equal(last_eff, plain[3])
+        assert torch.equal(work["split"], work["plain"])
+        assert float((acc_alpha - plain[2]).abs().max()) < 1e-6
+        if n == 30_000:
+            assert stopped > 1000   # the case is there for the pixels that stop
+        # the split backward pass from the split forward's boundary states, against the un-split backward of the un-split forward
+        g = make_grad_image(size, size).cuda()
+        base = ops.blend_backward_partials(st["start"], st["payload"], st["attrs"], g, plain[2], plain[3], st["slot_offsets"],
+                                           st["n_slots"], size, size, layout, tile_work=work["plain"], debug_hits=True)
+        p0, f0, m0, d0 = [t.clone() for t in base]
+        p1, f1, m1, d1 = ops.blend_backward_partials(st["start"], st["payload"], st["attrs"], g, acc_alpha, last_eff,
+                                                     st["slot_offsets"], st["n_slots"], size, size, layout, tile_work=work["split"],
+                                                     debug_hits=True, ws=ws, image=image, boundary=boundary["split"])
+        assert torch.equal(d1, d0) and torch.equal(f1, f0)
+        a0 = ops.reduce_partials(st["slot_offsets"], st["ntiles"], f0, p0)
+        a1 = ops.reduce_partials(st["slot_offsets"], st["ntiles"], f1, p1)
+        scale = a0[:, :10].abs().amax(dim=0).clamp_min(1e-30)
+        worst_b = float(((a1[:, :10] - a0[:, :10]).abs() / scale).max())
+        rel = float((a1[:, :10] - a0[:, :10]).norm() / a0[:, :10].norm())
+        report("split_forward.backward", size=size, max_scaled_difference_of_sums=worst_b, rel_l2_of_sums=rel)
+        # (looser than test_split_backward_on_small_grids' 5e-6 / 2e-6: a segment's transmittance starts from the product of
+        #  the probes in front of it, which is the chain's own value to ~sqrt(hits) roundings only -- one common factor
+        #  1 +- ~5e-7 on everything behind a cut, where the un-split chain's roundings are independent per entry)
+        assert worst_b < 5e-5 and rel < 5e-6
+
+
 def test_ordered_dispatch_on_a_4k_grid(ops):
     """Longest-first dispatch on a grid of 32,400 tiles (3840 x 2160: more tiles than the ordering kernel keeps in
     registers, and not a multiple of its eight lists' length): every tile is still rendered exactly once -- outputs
@@ -1475,22 +1548,28 @@ def test_hook_feature_gradients_can_be_switched_off(scene):
 def test_operator_tile_row_sharding_matches_single(scene, split, bin_shift):
     """Image-space sharding: rendering two sets of tile rows separately -- rows {0,2,4,..} / {1,3,5,..}, or the bands
     [0,7) / [7,16) whose boundary cuts through the 2x2- and 4x4-tile bins -- and merging equals the un-sharded render
-    bit-for-bit, with per-tile keys and with binned lists; partial gradients add up."""
+    bit-for-bit, with per-tile keys and with binned lists; partial gradients add up.  (Bit-for-bit between forward passes
+    that do not split their lists: the split form -- the default on grids this small with per-tile keys -- takes the same
+    decisions and agrees to rounding, which the last lines check.)"""
     from taichi_3d_gaussian_splatting_amd.synthetic import make_grad_image
     g = make_grad_image(scene.height, scene.width)
-    image, depth, count, xyz, feat = _run_operator(scene, g, bin_shift=0)
+    image, depth, count, xyz, feat = _run_operator(scene, g, bin_shift=0, split_forward=False)
     rows = torch.arange(scene.height, device="cuda") // 16
     if split == "interleaved":
-        parts = [_run_operator(scene, g, row=(r, 2), bin_shift=bin_shift) for r in range(2)]
+        parts = [_run_operator(scene, g, row=(r, 2), bin_shift=bin_shift, split_forward=False) for r in range(2)]
         first = rows % 2 == 0
     else:
-        parts = [_run_operator(scene, g, row=(0, 1), row_end=7, bin_shift=bin_shift),
-                 _run_operator(scene, g, row=(7, 1), bin_shift=bin_shift)]
+        parts = [_run_operator(scene, g, row=(0, 1), row_end=7, bin_shift=bin_shift, split_forward=False),
+                 _run_operator(scene, g, row=(7, 1), bin_shift=bin_shift, split_forward=False)]
         first = rows < 7
     merged = torch.where(first[:, None, None], parts[0][0], parts[1][0])
     assert torch.equal(merged, image)
     merged_count = torch.where(first[:, None], parts[0][2], parts[1][2])
     assert torch.equal(merged_count, count)
+    if bin_shift == 0:
+        image_s, depth_s, count_s, xyz_s, feat_s = _run_operator(scene, g, bin_shift=0, split_forward=True)
+        assert torch.equal(count_s, count) and float((image_s - image).abs().max()) < 2e-6
+        assert rel_l2(feat_s.grad.cpu().numpy(), feat.grad.cpu().numpy()) < 1e-5
     gsum = parts[0][4].grad + parts[1][4].grad
     assert rel_l2(gsum.cpu().numpy(), feat.grad.cpu().numpy()) < 1e-4
     gx = parts[0][3].grad + parts[1][3].grad
