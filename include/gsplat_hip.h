@@ -292,6 +292,8 @@ int gs_read_counters_async(const int32_t *counters, int32_t *host_counters_pinne
                                    LDS) whenever the lists are per-tile lists taken as they are.  Default (no flag): larger grids
                                    than the four-wave form's.  Decisions, the |grad uv| image and debug hashes are bit-identical
                                    to the two-wave kernel's; slot sums add the same per-pixel terms in another order. */
+#define GS_BLEND_SPLIT_FORWARD 32   /* gs_blend_forward_split with a workspace: GS_MAX_FORWARD_SPLIT workgroups per tile whatever the
+                                   grid size (tests, measurements; implies the four-wave form on per-tile lists) */
 int gs_blend_forward(const int32_t *bin_start, const int32_t *bin_end, const int32_t *payload,
                      const float *attrs, int width, int height, int tile_row_begin,
                      int tile_row_step, int tile_row_end, int bin_shift, int filter, float *image,
@@ -331,7 +333,8 @@ int gs_blend_backward(const int32_t *bin_start, const int32_t *payload, const fl
  * counters zero again.  Slot records stay bitwise reproducible; they differ from the un-split ones in rounding only.
  * With boundary_states / image / split_workspace NULL these are gs_blend_forward / gs_blend_backward. */
 #define GS_MAX_BACKWARD_SPLIT 4
-/* The forward pass of such a grid is split too (round 6: gs_blend_forward_split; at most 1024 rendered tiles, per-tile lists):
+/* The forward pass of a still smaller grid is split too (round 6: gs_blend_forward_split; at most GS_FORWARD_SPLIT_TILES
+ * rendered tiles, per-tile lists taken as they are):
  * a probe launch leaves, per pixel and list segment, the product of (1 - alpha) over the segment's hits; every segment then
  * blends its share of the list starting from the product of the segments in front of it, with the stop rule (RAS:458-460)
  * applied against that transmittance -- every 1/255 and 1e-4 decision is still taken as the reference takes it, colours,
@@ -339,6 +342,7 @@ int gs_blend_backward(const int32_t *bin_start, const int32_t *payload, const fl
  * forward_split_workspace: gs_blend_forward_split_workspace_bytes(width, height) bytes of scratch, dead when the call's
  * work has completed; NULL = un-split.  debug_pixel_hits must be ZERO on entry when the forward is split. */
 #define GS_MAX_FORWARD_SPLIT 4
+#define GS_FORWARD_SPLIT_TILES 320   /* grids of at most this many rendered tiles are split (four workgroups per tile) */
 size_t gs_blend_forward_split_workspace_bytes(int width, int height);
 size_t gs_blend_boundary_bytes(int64_t list_length, int width, int height);
 /* Path statistics of the two-waves-per-tile blend kernels: counted only in a tuning build (-DGS_STATS=1, tools/blend_stats.py);

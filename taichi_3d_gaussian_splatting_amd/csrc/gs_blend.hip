@@ -2314,7 +2314,11 @@ size_t gs_blend_forward_split_workspace_bytes(int width, int height) {
 static int forward_split_for(int tiles) {
     static const int forced = getenv("GS_FWD_SPLIT") ? atoi(getenv("GS_FWD_SPLIT")) : 0;   // tuning knob
     if (forced > 0) return forced > GS_MAX_FORWARD_SPLIT ? GS_MAX_FORWARD_SPLIT : forced;
-    return tiles <= 512 ? 4 : (tiles <= 1024 ? 2 : 1);
+    // A tile's chain becomes (probe + blend) / split long, plus two launches: two workgroups per tile buy nothing, four halve
+    // it -- and pay only while the un-split launch is far from filling the chip.  Measured (tools/small_frame_bench.py,
+    // operator forward + backward back to back, un-split -> four workgroups): 256 tiles 0.29-0.32 -> 0.21 ms, 400 tiles
+    // 0.245-0.27 -> 0.27, 576 tiles 0.25-0.28 -> 0.29, 1,024 tiles 0.29 -> 0.37-0.42 (two workgroups: slower at every size)
+    return tiles <= GS_FORWARD_SPLIT_TILES ? GS_MAX_FORWARD_SPLIT : 1;
 }
 
 int gs_blend_forward_split(const int32_t *bin_start, const int32_t *bin_end, const int32_t *payload,
@@ -2354,9 +2358,10 @@ int gs_blend_forward_split(const int32_t *bin_start, const int32_t *bin_end, con
         GS_CHECK_LAUNCH();
     }
     const bool four_waves = !staged && !(flags & GS_BLEND_TWO_WAVES) &&
-                            ((flags & GS_BLEND_FOUR_WAVES) || tw * rows <= GS_SMALL_GRID_TILES);
+                            ((flags & (GS_BLEND_FOUR_WAVES | GS_BLEND_SPLIT_FORWARD)) || tw * rows <= GS_SMALL_GRID_TILES);
     // several workgroups per tile on a grid that cannot fill the chip (see blend_forward_small_kernel): probe, blend, combine
-    const int split = four_waves && forward_split_workspace != nullptr ? forward_split_for(tw * rows) : 1;
+    const int split = !(four_waves && forward_split_workspace != nullptr) ? 1
+                      : (flags & GS_BLEND_SPLIT_FORWARD) ? GS_MAX_FORWARD_SPLIT : forward_split_for(tw * rows);
     const size_t n_pixels = (size_t)width * height;
     float4 *probe = reinterpret_cast<float4 *>(forward_split_workspace);
     float4 *parts = probe == nullptr ? nullptr : probe + (GS_MAX_FORWARD_SPLIT - 1) * n_pixels;

@@ -395,6 +395,7 @@ BLEND_ARMS = {None: 0, "two_waves": 4, "four_waves": 8, "one_wave": 16}   # GS_B
 
 
 SPLIT_GRID_TILES = 1024          # csrc/gs_blend.hip backward_split_for: grids up to this many tiles get a split backward
+FORWARD_SPLIT_GRID_TILES = 320   # include/gsplat_hip.h GS_FORWARD_SPLIT_TILES: ... a split forward
 MAX_BOUNDARY_BYTES = 256 << 20   # above this the backward pass is not split (boundary states cost 4 KB per 128 list entries)
 
 
@@ -417,16 +418,22 @@ def split_workspace(ws: Workspaces, width: int, height: int, device) -> torch.Te
                   device, zeroed=True)
 
 
-def forward_split_bytes(width: int, height: int, layout: ListLayout) -> int:
+BLEND_SPLIT_FORWARD = 32   # GS_BLEND_SPLIT_FORWARD
+
+
+def forward_split_bytes(width: int, height: int, layout: ListLayout, force: bool = False) -> int:
     """Bytes of scratch with which gs_blend_forward_split gives a tile several workgroups (include/gsplat_hip.h "List
-    splitting": per-tile lists taken as they are on a grid of at most 1024 rendered tiles), or 0: the forward is not split."""
-    if layout.bin_shift != 0 or layout.filter != 0 or num_owned_tiles(width, height, layout) > SPLIT_GRID_TILES:
+    splitting": per-tile lists taken as they are on a grid of at most 320 rendered tiles), or 0: the forward is not split."""
+    if layout.bin_shift != 0 or layout.filter != 0:
+        return 0
+    if not force and num_owned_tiles(width, height, layout) > FORWARD_SPLIT_GRID_TILES:
         return 0
     return int(_lib.load().gs_blend_forward_split_workspace_bytes(int(width), int(height)))
 
 
-def forward_split_workspace(ws: Optional[Workspaces], width: int, height: int, layout: ListLayout, device) -> Optional[torch.Tensor]:
-    nbytes = forward_split_bytes(width, height, layout)
+def forward_split_workspace(ws: Optional[Workspaces], width: int, height: int, layout: ListLayout, device,
+                            force: bool = False) -> Optional[torch.Tensor]:
+    nbytes = forward_split_bytes(width, height, layout, force)
     return _scratch(ws, "split_forward", nbytes, torch.uint8, device) if nbytes else None
 
 
@@ -444,7 +451,7 @@ def blend_forward(bin_start, bin_end, payload, attrs, width, height, layout: Lis
     every tile's own list as far as it was walked; last_effective then refers to positions in walked_list and the
     backward pass is run on (walked_start, walked_list) with ``walked_layout(layout)``.
     split: small grids with per-tile lists give a tile several workgroups (gs_blend_forward_split): every decision as the
-    un-split pass takes it, values equal to rounding."""
+    un-split pass takes it, values equal to rounding; split="force": whatever the grid size (tests, measurements)."""
     dev = bin_start.device
     flags = (BLEND_RGB_ONLY if rgb_only else 0) | (0 if need_state else BLEND_NO_STATE) | BLEND_ARMS[arm]
     if out is None:
@@ -474,7 +481,9 @@ def blend_forward(bin_start, bin_end, payload, attrs, width, height, layout: Lis
         walked_list = torch.empty(max(payload.shape[0], 1) << (2 * layout.bin_shift), dtype=torch.int32, device=dev)
         walked_start = torch.empty((width // TILE_WIDTH) * (height // TILE_HEIGHT), dtype=torch.int32, device=dev)
     # boundary (uint8 buffer of boundary_states_bytes(...), optional): the forward leaves its boundary states there
-    split_ws = forward_split_workspace(ws, width, height, layout, dev) if split else None
+    split_ws = forward_split_workspace(ws, width, height, layout, dev, force=split == "force") if split else None
+    if split == "force" and split_ws is not None:
+        flags |= BLEND_SPLIT_FORWARD
     call("gs_blend_forward_split", ptr(bin_start), ptr(bin_end), ptr(payload), ptr(attrs), int(width), int(height),
          layout.row_begin, layout.row_step, layout.row_end, layout.bin_shift, layout.filter, ptr(image), ptr(depth),
          ptr(acc_alpha), ptr(last_eff), ptr(count), flags, ptr(dbg), ptr(order), ptr(tile_work), ptr(walked_list),

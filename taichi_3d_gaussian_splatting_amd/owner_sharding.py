@@ -84,6 +84,7 @@ class OwnerShardedRasteriser:
         self.always_store_normalised_rotation = False
         self.speculative_sizes = True
         self.split_small_grid_backward = True   # the band's backward pass gives a tile up to four workgroups (list splitting)
+        self.split_small_grid_forward = True    # ... and so does its forward pass when the band walks per-tile lists
         # per-tile-row weights that place the bands' boundaries (distributed.band_boundaries: band g ends where the running
         # weight reaches (g + 1) / world of the total) -- THE SAME list on every rank.  None: equal bands.  A trained
         # scene crowds its Gaussians into some rows: with equal bands the slowest of eight ranks took twice the fastest
@@ -318,6 +319,9 @@ class OwnerShardedRasteriser:
         b.boundary_states = slab.ptr("boundary")
         if need_state and self.split_small_grid_backward:
             b.split_workspace = hip_ops.split_workspace(self._scratch, width, height, dev).data_ptr()
+        if self.split_small_grid_forward:
+            fsplit = hip_ops.forward_split_workspace(self._scratch, width, height, layout, dev)
+            b.forward_split_workspace = 0 if fsplit is None else fsplit.data_ptr()
         S = _lib.STAGES
         stages = S["GS_FWD_COUNT_KEYS"] | S["GS_FWD_SCAN"] | S["GS_FWD_READ_SIZES"]
         if guess:   # the list stages and the blend, speculatively, behind the size read
@@ -382,7 +386,8 @@ class OwnerShardedRasteriser:
             b.n_keys_capacity = int(payload.shape[0])   # (the list length the boundary buffer's layout is derived from)
             blended = hip_ops.blend_forward(start, end, payload, records, width, height, layout, out=out,
                                             rgb_only=rgb_only, need_state=need_state, ordered=ordered, tile_work=work,
-                                            ws=self._scratch, emit_walked_lists=emit, boundary=boundary)
+                                            ws=self._scratch, emit_walked_lists=emit, boundary=boundary,
+                                            split=self.split_small_grid_forward)
             if emit:
                 start, payload = blended[5], blended[6]
             fr.keep += [start, payload, slot_offsets]

@@ -1056,8 +1056,9 @@ def test_split_backward_on_small_grids(ops, size, n, bin_shift):
                                                    (400, 2_000, True, False), (256, 10_000, False, False), (256, 10_000, False, True),
                                                    (192, 30_000, True, False)])
 def test_split_forward_on_small_grids(ops, size, n, state, rgb_only):
-    """Forward list splitting (include/gsplat_hip.h, round 6): on grids of at most 1,024 tiles with per-tile lists a tile gets
-    four (<= 512 tiles) or two workgroups forward -- probe, blend from the product of the segments in front, combine.  Against
+    """Forward list splitting (include/gsplat_hip.h, round 6): on grids of at most 320 tiles with per-tile lists a tile gets
+    four workgroups forward -- probe, blend from the product of the segments in front, combine (forced here on the larger
+    grids too, where it does not pay and is not the default).  Against
     the un-split forward on the same lists: the SAME (pixel, Gaussian) pairs blended on every pixel (count + hash), the same
     per-pixel count and last effective position, image / depth / transmittance equal to rounding; two split runs give the
     same bits; and the split backward pass, started from the boundary states the split forward leaves, gives the un-split
@@ -1069,7 +1070,8 @@ def test_split_forward_on_small_grids(ops, size, n, state, rgb_only):
     s = make_scene(n=n, height=size, width=size, seed=size + 7, **kw).to("cuda")
     layout = ops.ListLayout(bin_shift=0)
     st = _stages_to_ranges(ops, s, layout)
-    assert ops.forward_split_bytes(size, size, layout) > 0
+    assert ops.forward_split_bytes(size, size, layout, force=True) > 0
+    assert (ops.forward_split_bytes(size, size, layout) > 0) == ((size // 16) ** 2 <= 320)
     common = dict(rgb_only=rgb_only, need_state=state, debug_hits=True)
     boundary = {}
     if state:
@@ -1081,8 +1083,8 @@ def test_split_forward_on_small_grids(ops, size, n, state, rgb_only):
         tile_work=work[key] if state else None, boundary=boundary.get(key), split=split, ws=ws, **common)
     plain = run("plain", False)
     ws = ops.Workspaces()
-    first = [None if t is None else t.clone() for t in run("split", True, ws)]
-    again = run("split", True, ws)
+    first = [None if t is None else t.clone() for t in run("split", "force", ws)]
+    again = run("split", "force", ws)
     for a, b in zip(first, again):                                               # bitwise reproducible
         assert (a is None and b is None) or torch.equal(a, b)
     image, depth, acc_alpha, last_eff, count, hits = first

@@ -61,6 +61,7 @@ def _sharded(s, g, world, bin_shift=None, frames=1, row_weights=None):
     for c in cores:
         c.bin_shift = bin_shift
         c.row_weights = row_weights
+        c.split_small_grid_forward = False   # (bit-for-bit against the un-split baseline: see _unsharded)
     blocks = [owned_point_rows(n, r, world) for r in range(world)]
     for _ in range(frames):
         inputs = [_inputs(s, blocks[r], requires_grad=False) for r in range(world)]
@@ -149,6 +150,7 @@ def test_owner_sharded_bands_follow_the_work():
     cores = [OwnerShardedRasteriser(_config(s), r, world) for r in range(world)]
     for c in cores:
         c.bin_shift = 0   # (per-tile lists: a tile's walk length is then a property of the tile alone)
+        c.split_small_grid_forward = False   # (bit-for-bit against the un-split baseline: see _unsharded)
     blocks = [owned_point_rows(s.point_cloud.shape[0], r, world) for r in range(world)]
     work = []
     for _ in range(2):
@@ -230,6 +232,7 @@ def _worker(rank, world, port, height):
         base = _unsharded(s, g)
         hooks = []
         op = OwnerShardedRasterisation(_config(s), backward_valid_point_hook=hooks.append)
+        op.core.split_small_grid_forward = False   # (bit-for-bit against the un-split baseline: see _unsharded)
         rows = owned_point_rows(s.point_cloud.shape[0], rank, world)
         for _ in range(2):
             inp = _inputs(s, rows)
