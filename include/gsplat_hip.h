@@ -69,7 +69,7 @@ extern "C" {
 
 /* ABI version of this header.  A TUNING build of the library (measurement arms compiled in: -DGS_TUNING_BUILD=1,
  * tools/build_variants.sh) reports GS_ABI_VERSION + GS_ABI_TUNING_OFFSET, which the product loader refuses. */
-#define GS_ABI_VERSION 35
+#define GS_ABI_VERSION 36
 #define GS_ABI_TUNING_OFFSET 1000
 
 const char *gs_last_error(void);

@@ -17,7 +17,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # GS_LIB_PATH: development knob (tuning sweeps load differently built variants of the library); default = in-tree build
 LIB_PATH = os.environ.get("GS_LIB_PATH") or os.path.join(_HERE, "libgsplat_hip.so")
-ABI_VERSION = 35
+ABI_VERSION = 36
 ABI_TUNING_OFFSET = 1000   # a tuning build of the library (measurement arms compiled in) reports ABI_VERSION + this
 
 _c = ctypes

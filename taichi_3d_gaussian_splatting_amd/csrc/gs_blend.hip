@@ -2352,16 +2352,19 @@ int gs_blend_forward_split(const int32_t *bin_start, const int32_t *bin_end, con
     GS_REQUIRE(tile_work == nullptr || state, "tile_work is the backward's walk length: it needs the state outputs");
     GS_REQUIRE((walked_list == nullptr) == (walked_start == nullptr), "walked_list and walked_start go together");
     GS_REQUIRE(walked_list == nullptr || (staged && state), "walked lists are emitted by the filtering (binned) forward with state");
-    if (tile_order != nullptr) {   // longest lists first
-        hipLaunchKernelGGL(tile_order_kernel, dim3(ORDER_WGS), dim3(ORDER_THREADS), 0, s, (const int32_t *)nullptr, bin_start,
-                           bin_end, tw * rows, tw, tile_row_begin, tile_row_step, bin_shift, tile_order, (uint4 *)nullptr, 0LL);
-        GS_CHECK_LAUNCH();
-    }
     const bool four_waves = !staged && !(flags & GS_BLEND_TWO_WAVES) &&
                             ((flags & (GS_BLEND_FOUR_WAVES | GS_BLEND_SPLIT_FORWARD)) || tw * rows <= GS_SMALL_GRID_TILES);
     // several workgroups per tile on a grid that cannot fill the chip (see blend_forward_small_kernel): probe, blend, combine
     const int split = !(four_waves && forward_split_workspace != nullptr) ? 1
                       : (flags & GS_BLEND_SPLIT_FORWARD) ? GS_MAX_FORWARD_SPLIT : forward_split_for(tw * rows);
+    // A launch whose workgroups are all resident at once (four-wave kernels: at least four per CU) has no dispatch order to
+    // speak of: the ordering launch (5 us, a quarter of what is left of a 256-tile frame's forward pass) is left out
+    if (four_waves && tw * rows * split <= 1024) tile_order = nullptr;
+    if (tile_order != nullptr) {   // longest lists first
+        hipLaunchKernelGGL(tile_order_kernel, dim3(ORDER_WGS), dim3(ORDER_THREADS), 0, s, (const int32_t *)nullptr, bin_start,
+                           bin_end, tw * rows, tw, tile_row_begin, tile_row_step, bin_shift, tile_order, (uint4 *)nullptr, 0LL);
+        GS_CHECK_LAUNCH();
+    }
     const size_t n_pixels = (size_t)width * height;
     float4 *probe = reinterpret_cast<float4 *>(forward_split_workspace);
     float4 *parts = probe == nullptr ? nullptr : probe + (GS_MAX_FORWARD_SPLIT - 1) * n_pixels;
