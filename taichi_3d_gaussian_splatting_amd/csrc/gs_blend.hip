@@ -54,6 +54,11 @@ constexpr float STOP_T = 0.0001f;                  // RAS:458
 #ifndef GS_GROUP_FWD
 #define GS_GROUP_FWD 4
 #endif
+#ifndef GS_FWD_WHOLE_Q
+#define GS_FWD_WHOLE_Q 0   // 1: (amp, depth) arrive with (B, e_lo) in front of the hit test and wait in registers instead of being read
+                           // on the hit path.  Measured slower (forward stage 0.260 -> 0.268 ms in groups of four -- 36 B of scratch --
+                           // and 0.270 in groups of two, same box, alternating runs)
+#endif
 #ifndef GS_FWD_UPFRONT
 #define GS_FWD_UPFRONT 0   // 1: the four exponents of a group are pinned in front of the first hit test.  Measured slower (forward
                            // stage 0.260 -> 0.269 ms, same box, alternating runs; GS_GROUP_FWD = 2: 0.269 either way): left alone the
@@ -680,9 +685,17 @@ __global__ __launch_bounds__(BLEND_THREADS, GS_FWD_MIN_WAVES) void blend_forward
             if ((alive0 | alive1) == 0ull) break;  // every pixel of this wave is saturated
             v2f ex[GROUP_FWD];
             float elo[GROUP_FWD];
+#if GS_FWD_WHOLE_Q
+            float2 azs[GROUP_FWD];
+#endif
 #pragma unroll
             for (int i = 0; i < GROUP_FWD; ++i) {
+#if GS_FWD_WHOLE_Q
+                const float4 q = s_q[k + i];
+                azs[i] = make_float2(q.z, q.w);
+#else
                 const float2 q = *reinterpret_cast<const float2 *>(&s_q[k + i]);   // (B, e_lo)
+#endif
                 ex[i] = gs_pair_exponent_forward(s_p[k + i], q.x, px, py);
                 elo[i] = q.y;
             }
@@ -707,7 +720,11 @@ __global__ __launch_bounds__(BLEND_THREADS, GS_FWD_MIN_WAVES) void blend_forward
                 GS_STAT(GS_STAT_FWD_HIT_LANES, __popcll(mok0 | mok1));
                 GS_STAT(GS_STAT_FWD_HIT_BLOCKS, (((mok0 | mok1) & 0x0f0f0f0f0f0f0f0full) != 0ull) + (((mok0 | mok1) & 0xf0f0f0f0f0f0f0f0ull) != 0ull));
                 const float4 c = s_c[k + i];
+#if GS_FWD_WHOLE_Q
+                const float2 az = azs[i];
+#else
                 const float2 az = reinterpret_cast<const float2 *>(&s_q[k + i])[1];   // (amp, depth)
+#endif
                 const v2f a = gs_weight_from_exponent(ex[i], az.x);
                 {
                     const unsigned long long mhi0 = gs_ballot(a.x >= EPS_HI) & mok0, mhi1 = gs_ballot(a.y >= EPS_HI) & mok1;
