@@ -881,6 +881,9 @@ __global__ __launch_bounds__(BLEND_THREADS, GS_BWD_MIN_WAVES) void blend_backwar
     // (REDUCE 3) lane 4 n + p reads floats [16 p, 16 p + 16) of row n; lanes 44.. read row 10 again and add nothing
     const int tr_read = min(lane >> 2, GS_TR_ROWS - 1) * GS_TR_STRIDE + 16 * (lane & 3);
     const bool tr_owner = (lane & 3) == 0 && lane < 4 * GS_TR_ROWS;
+    // (REDUCE 6) lane 4 v + p reads floats [8 p, 8 p + 8) of value v's half row; lanes 44.. read value 10's again and add nothing
+    const int tr_v = min(lane >> 2, GS_TR_ROWS - 1);
+    const int tr_read_half = (tr_v >> 1) * GS_TR_STRIDE + (tr_v & 1) * 32 + 8 * (lane & 3);
     // (REDUCE 4) sixteen fetched values -> this lane's quarter of row n -> the wave's total of value n -> the entry's row
     auto tr_sum = [&](const float4 a, const float4 b, const float4 c4, const float4 d, int entry, bool live) {
         float t = (((a.x + a.y) + (a.z + a.w)) + ((b.x + b.y) + (b.z + b.w))) +
@@ -1136,6 +1139,60 @@ __global__ __launch_bounds__(BLEND_THREADS, GS_BWD_MIN_WAVES) void blend_backwar
                     t += gs_dpp<0xb1, 0xf, 0xf>(t);   // quad_perm [1,0,3,2]
                     t += gs_dpp<0x4e, 0xf, 0xf>(t);   // quad_perm [2,3,0,1]
                     __builtin_amdgcn_wave_barrier();   // (the next entry's stores stay below these reads)
+                    if (tr_owner) atomicAdd(&s_acc[k + i][lane >> 2], t);
+                } else if constexpr (REDUCE == 5) {
+                    // REDUCE 3 with the read-back confined to the 44 lanes that have a row to read (the other twenty re-read row 10
+                    // and threw it away: a third of the read-back's LDS cycles)
+                    float x[12];
+                    partials_of_entry(x);
+                    float *rows = &s_tr[tid >> 6][0];
+#pragma unroll
+                    for (int n = 0; n < GS_TR_ROWS; ++n) rows[n * GS_TR_STRIDE + lane] = x[n];
+                    __builtin_amdgcn_wave_barrier();
+                    float t = 0.f;
+                    if (lane < 4 * GS_TR_ROWS) {
+                        const float4 *src = reinterpret_cast<const float4 *>(rows + tr_read);
+                        const float4 a = src[0], b = src[1], c4 = src[2], d = src[3];
+                        t = (((a.x + a.y) + (a.z + a.w)) + ((b.x + b.y) + (b.z + b.w))) +
+                            (((c4.x + c4.y) + (c4.z + c4.w)) + ((d.x + d.y) + (d.z + d.w)));
+                    }
+                    t += gs_dpp<0xb1, 0xf, 0xf>(t);   // quad_perm [1,0,3,2]
+                    t += gs_dpp<0x4e, 0xf, 0xf>(t);   // quad_perm [2,3,0,1]
+                    __builtin_amdgcn_wave_barrier();
+                    if (tr_owner) atomicAdd(&s_acc[k + i][lane >> 2], t);
+                } else if constexpr (REDUCE == 6) {
+                    // Half the LDS traffic of REDUCE 3: one v_permlane32_swap + one add per PAIR of values leaves the pair's 2 x 32
+                    // half-wave sums in one register (lanes 0-31: value 2n, lanes 32-63: value 2n + 1) -- six stores of 64 instead
+                    // of eleven, and lane 4 v + p reads 8 floats (two 16-byte reads) of value v's 32 instead of 16 of its 64
+                    float x[12];
+                    partials_of_entry(x);
+                    float *rows = &s_tr[tid >> 6][0];
+                    // (one asm block, as gs_wave_reduce12: the hazard recogniser does not look inside -- the leading s_nop covers
+                    //  "VALU write -> permlane read", every add is six instructions behind the swap that feeds it)
+                    asm("s_nop 1\n\t"
+                        "v_permlane32_swap_b32 %0, %1\n\t"
+                        "v_permlane32_swap_b32 %2, %3\n\t"
+                        "v_permlane32_swap_b32 %4, %5\n\t"
+                        "v_permlane32_swap_b32 %6, %7\n\t"
+                        "v_permlane32_swap_b32 %8, %9\n\t"
+                        "v_permlane32_swap_b32 %10, %11\n\t"
+                        "v_add_f32 %0, %0, %1\n\t"
+                        "v_add_f32 %2, %2, %3\n\t"
+                        "v_add_f32 %4, %4, %5\n\t"
+                        "v_add_f32 %6, %6, %7\n\t"
+                        "v_add_f32 %8, %8, %9\n\t"
+                        "v_add_f32 %10, %10, %11"
+                        : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "+v"(x[7]), "+v"(x[8]),
+                          "+v"(x[9]), "+v"(x[10]), "+v"(x[11]));
+#pragma unroll
+                    for (int n = 0; n < 6; ++n) rows[n * GS_TR_STRIDE + lane] = x[2 * n];   // [value 2n: 32 sums | value 2n + 1: 32 sums]
+                    __builtin_amdgcn_wave_barrier();
+                    const float4 *src = reinterpret_cast<const float4 *>(rows + tr_read_half);
+                    const float4 a = src[0], b = src[1];
+                    float t = ((a.x + a.y) + (a.z + a.w)) + ((b.x + b.y) + (b.z + b.w));
+                    t += gs_dpp<0xb1, 0xf, 0xf>(t);   // quad_perm [1,0,3,2]
+                    t += gs_dpp<0x4e, 0xf, 0xf>(t);   // quad_perm [2,3,0,1]
+                    __builtin_amdgcn_wave_barrier();
                     if (tr_owner) atomicAdd(&s_acc[k + i][lane >> 2], t);
                 } else if constexpr (REDUCE == 4) {
                     // REDUCE 3 with the LDS round trip taken off the wave's critical path: an entry's rows are stored here and read
