@@ -837,7 +837,7 @@ __global__ __launch_bounds__(BLEND_THREADS, GS_BWD_MIN_WAVES) void blend_backwar
     __shared__ float s_acc[BATCH][GS_ACC_STRIDE];  // [entry][value]; value 10 = pixel count (as a float)
     constexpr int REDUCE_ = STAGED ? GS_BWD_REDUCE_STAGED : GS_BWD_REDUCE_DIRECT;
     // REDUCE 3: the cross-lane sums go THROUGH LDS (gs_lds_reduce11 below): per wave eleven rows of 64 partials, 68 floats apart
-    __shared__ __attribute__((aligned(16))) float s_tr[REDUCE_ >= 3 ? BLEND_THREADS / GS_WAVE : 1][REDUCE_ >= 3 ? GS_TR_ROWS * GS_TR_STRIDE : 4];
+    __shared__ __attribute__((aligned(16))) float s_tr[REDUCE_ >= 3 ? BLEND_THREADS / GS_WAVE : 1][REDUCE_ == 6 ? 6 * GS_TR_STRIDE : REDUCE_ >= 3 ? GS_TR_ROWS * GS_TR_STRIDE : 4];
     __shared__ int s_max[BLEND_THREADS / GS_WAVE];
     __shared__ int s_cnt[2 * FILL_PER_THREAD], s_next[1];
     const int tw = width / GS_TILE_WIDTH, th = height / GS_TILE_HEIGHT;
