@@ -66,7 +66,7 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 # VALU issue ceiling: 256 CUs x 4 SIMD-32, one wave64 fp32 instruction per 2 cycles per SIMD at 2.4 GHz
 VALU_PEAK_WAVE_INSTR_PER_S = 256 * 4 * 2.4e9 / 2.0
-PROFILE_TAG = "r05"
+PROFILE_TAG = "r06"
 # Warm-up floor (ms of continuous load before the timed region; profiles/r05_clock_ramp.txt): the W warm-up steps are
 # followed by untimed steps until the GPU has been under this load that long.  0 = exactly W steps.
 WARMUP_FLOOR_MS = float(os.environ.get("GS_BENCH_WARMUP_FLOOR_MS", "40"))

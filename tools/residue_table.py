@@ -1,0 +1,59 @@
+#!/usr/bin/env python
+"""(Re)writes the "arithmetic residue" section of tests/golden/README.md from tests/golden/arithmetic_residue.json
+(tests/golden/make_arithmetic_residue.py: build container only, hours).  usage: python tools/residue_table.py"""
+import json
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+readme = os.path.join(ROOT, "tests", "golden", "README.md")
+table = json.load(open(os.path.join(ROOT, "tests", "golden", "arithmetic_residue.json")))
+names = {"fma_contraction": "FMA contraction (every `a*b + c` fused)", "division_by_reciprocal": "division as reciprocal-multiply",
+         "fma_and_reciprocal": "both", "numpy_fp32_exp": "NumPy's fp32 `exp` instead of the correctly rounded one"}
+rows = []
+for scene in sorted(table):
+    for tag in ("fma_contraction", "division_by_reciprocal", "fma_and_reciprocal", "numpy_fp32_exp"):
+        r = table[scene].get(tag)
+        if r is None:
+            rows.append(f"| `{scene.split('_')[0]}` | {names[tag]} | (run not finished) | | | | |")
+            continue
+        rows.append(f"| `{scene.split('_')[0]}` | {names[tag]} | **{r['pixels_with_another_count']}** of {r['pixels']:,} | "
+                    f"{r.get('gaussians_with_another_affected_pixel_count', 'n/a')} of {r.get('gaussians', 0):,} | "
+                    f"{r.get('gaussians_with_another_tile_count', 'n/a')} | {r['image_linf']:.1e} / {r['image_linf_on_pixels_with_the_same_count']:.1e} | "
+                    f"{r['grad_xyz_rel_l2']:.1e} / {r['grad_feat_rel_l2']:.1e} |")
+section = """## Arithmetic residue: how far the REFERENCE moves when its own arithmetic is varied (round 6)
+
+Every "identical to the reference" statement in this repository is relative to ONE arithmetic: the reference's unmodified
+sources under IEEE fp32 without contraction and with the correctly rounded `exp` (above).  Real Taichi compiles the same
+sources with `fast_math=True` (no `ti.init` in `/root/reference` turns it off: `GaussianPointTrainer.py:119`,
+`gaussian_point_render.py:132`) and a device `expf`: FMA contraction, division by reciprocal-multiply and a not correctly
+rounded exponential are all within what its compiler may do — and cannot be observed here (Taichi is absent).  What CAN be
+measured is how much of the reference's output depends on such liberties.  `taichi_emulation.py` has two switches for it —
+`GS_EMU_FMA=1` rewrites every `a*b + c` / `a*b - c` of the reference's kernels (AST rewrite of its own source) into one fused
+operation, `GS_EMU_RCP_DIV=1` evaluates `a / b` as `a * fl(1/b)` — and `make_arithmetic_residue.py` re-runs vectors `j` (6,000
+Gaussians, deep lists, 42 % of the pixels at the T' < 1e-4 stop), `k` (BASELINE configs[0] as stated) and `p` (truck
+parameters) with one liberty taken everywhere it syntactically can be, against the committed IEEE run of the same scene
+(`arithmetic_residue.json`):
+
+| scene | the reference's arithmetic, varied | pixels whose blended set changes | Gaussians with another affected-pixel count | Gaussians with another tile count | image L-inf: all pixels / pixels with the same count | gradient rel-L2: xyz / features |
+|---|---|---|---|---|---|---|
+ROWS
+
+Reading.  (1) The reference's **discrete decisions are not a property of its source alone**: contraction or reciprocal
+division move the 1/255 skip or the 1e-4 stop of a few pixels per 100,000 (a whole Gaussian blended or not: 2e-5 ... 1.5e-3 on
+those pixels), i.e. a real `fast_math` run of the reference would itself fail the "zero pixels with another blended set" gate
+that the HIP kernels pass against the IEEE run — by about as many pixels as the HIP kernels of rounds 1-4 did (1-10 per
+2 M-pixel frame).  The exactness round 5 bought (3.5 % of the frame, since reduced by the exponent-domain hit test of round
+6) is exactness relative to the emulation's arithmetic: it removes this repository's own contribution to that residue, it
+does not make the result equal to a run nobody can perform here.  (2) Tile counts — the integer chain radius -> tile box ->
+keys — do not move under any of the liberties on these scenes.  (3) On pixels whose decisions agree the image moves by
+<= 4e-6 and the gradients by 1e-5 ... 4e-5 relative L2: the same order as the distance between this repository's fp32 paths
+and the reference run (2e-7 ... 2e-5, `tests/test_reference_operator.py`), and below the 1e-4 north-star bar.  (4) The `exp`
+definition alone (NumPy's fp32 `exp` against the correctly rounded one) flips nothing on these scenes and moves the gradients
+by <= 1e-5; it mattered on needle scenes (above).
+"""
+section = section.replace("ROWS", "\n".join(rows))
+text = open(readme).read()
+text = re.sub(r"\n## Arithmetic residue:.*", "", text, flags=re.S).rstrip("\n") + "\n\n" + section
+open(readme, "w").write(text)
+print("\n".join(rows))
