@@ -292,6 +292,10 @@ int gs_read_counters_async(const int32_t *counters, int32_t *host_counters_pinne
                                    LDS) whenever the lists are per-tile lists taken as they are.  Default (no flag): larger grids
                                    than the four-wave form's.  Decisions, the |grad uv| image and debug hashes are bit-identical
                                    to the two-wave kernel's; slot sums add the same per-pixel terms in another order. */
+#define GS_BLEND_SKEWED_WALKS 64    /* backward pass, two-wave kernel: the walk lengths of this frame are skewed (a few tiles walk many
+                                   times the mean: trained scenes) -- the form of the kernel with the shorter dependent chain per hit
+                                   entry (cross-lane sums in registers) instead of the one with the higher throughput (through LDS).
+                                   Same decisions, sums equal to rounding; a hint, never needed for correctness */
 #define GS_BLEND_SPLIT_FORWARD 32   /* gs_blend_forward_split with a workspace: GS_MAX_FORWARD_SPLIT workgroups per tile whatever the
                                    grid size (tests, measurements; implies the four-wave form on per-tile lists) */
 int gs_blend_forward(const int32_t *bin_start, const int32_t *bin_end, const int32_t *payload,

@@ -89,6 +89,16 @@ constexpr float STOP_T = 0.0001f;                  // RAS:458
 #ifndef GS_BWD_REDUCE_DIRECT
 #define GS_BWD_REDUCE_DIRECT 3
 #endif
+// The form for frames whose walk lengths are SKEWED (flag GS_BLEND_SKEWED_WALKS of gs_blend_backward: the caller's call -- the
+// operator samples the walk lengths the forward pass records every few frames).  A trained scene -- mean 125, max 1,316 list
+// positions walked per tile -- ends in a tail of a few long tiles, and what counts there is the dependent chain per hit
+// entry, not the SIMD's throughput: the register reduce-scatter (2) finishes the trained 1920 x 1072 scene's backward blend
+// in 0.398 ms where the LDS form (3) needs 0.448, while on evenly loaded frames (headline: mean 292, max 749; cfg 3, cfg 4)
+// the LDS form is 5-7 % faster (profiles/r06_backward_arms.md).  (Both forms in ONE kernel behind a wave-uniform branch:
+// 125 VGPRs with scratch, slower than either; two launches with a device-side mark: 5 us for the launch that does nothing.)
+#ifndef GS_BWD_REDUCE_SKEWED
+#define GS_BWD_REDUCE_SKEWED 2
+#endif
 #ifdef GS_BWD_REDUCE_ARM      // (one switch for both kernels: tools/build_variants.sh)
 #undef GS_BWD_REDUCE_STAGED
 #undef GS_BWD_REDUCE_DIRECT
@@ -823,7 +833,8 @@ __global__ __launch_bounds__(BLEND_THREADS, GS_FWD_MIN_WAVES) void blend_forward
 // UTL:343), and the twelve-value reduce-scatter carries the pixel count as a float (exact below 2^24).  Per round of up
 // to 128 staged entries the two waves combine their partial sums in LDS (ds_add_f32), then thread k stores entry k's
 // 48-B record into its (Gaussian, tile) slot (plain stores).
-template <bool STAGED, bool DEBUG>
+// REDUCE_ARM: how a hit entry's partial sums cross the lanes (GS_BWD_REDUCE_* above)
+template <bool STAGED, bool DEBUG, int REDUCE_ARM>
 __global__ __launch_bounds__(BLEND_THREADS, GS_BWD_MIN_WAVES) void blend_backward_kernel(
     const int32_t *__restrict__ bin_start, const int32_t *__restrict__ payload,
     const float4 *__restrict__ attrs, const float *__restrict__ grad_image, const float *__restrict__ acc_alpha,
@@ -835,7 +846,7 @@ __global__ __launch_bounds__(BLEND_THREADS, GS_BWD_MIN_WAVES) void blend_backwar
     __shared__ __attribute__((aligned(16))) int s_j[BATCH];
     __shared__ int s_o[BATCH];
     __shared__ float s_acc[BATCH][GS_ACC_STRIDE];  // [entry][value]; value 10 = pixel count (as a float)
-    constexpr int REDUCE_ = STAGED ? GS_BWD_REDUCE_STAGED : GS_BWD_REDUCE_DIRECT;
+    constexpr int REDUCE_ = REDUCE_ARM;
     // REDUCE 3: the cross-lane sums go THROUGH LDS (gs_lds_reduce11 below): per wave eleven rows of 64 partials, 68 floats apart
     __shared__ __attribute__((aligned(16))) float s_tr[REDUCE_ >= 3 ? BLEND_THREADS / GS_WAVE : 1][REDUCE_ == 6 ? 6 * GS_TR_STRIDE : REDUCE_ >= 3 ? GS_TR_ROWS * GS_TR_STRIDE : 4];
     __shared__ int s_max[BLEND_THREADS / GS_WAVE];
@@ -874,7 +885,7 @@ __global__ __launch_bounds__(BLEND_THREADS, GS_BWD_MIN_WAVES) void blend_backwar
     const int row = lane >> 4;
     const int slot = ((row & 1) << 1) | (row >> 1);  // rows (0,1,2,3) -> values (0,2,1,3) of each result register
     const bool row_tail = (lane & 15) == 15;
-    constexpr int REDUCE = STAGED ? GS_BWD_REDUCE_STAGED : GS_BWD_REDUCE_DIRECT;
+    constexpr int REDUCE = REDUCE_ARM;
     // destination of this lane's pair-reduce results (gs_wave_reduce12_pair): lanes 7 and 15 of each row
     const bool pair_tail = (lane & 7) == 7, pair_b_sel = (row >> 1) != 0;
     const int pair_vi = 2 * ((lane >> 3) & 1) + (row & 1);
@@ -2296,15 +2307,18 @@ static void launch_backward(bool debug, dim3 grid, hipStream_t s, const int32_t 
                             const float4 *attrs, const float *grad_image, const float *acc_alpha,
                             const int32_t *last_effective, int width, int height, int rb, int rs, int bin_shift,
                             int filter, const int32_t *slot_offsets, float4 *partials, uint8_t *slot_flags,
-                            float *magnitude_image, uint32_t *debug_hits, const int32_t *tile_order) {
-    if (debug)
-        hipLaunchKernelGGL((blend_backward_kernel<STAGED, true>), grid, dim3(BLEND_THREADS), 0, s, bin_start, payload,
-                           attrs, grad_image, acc_alpha, last_effective, width, height, rb, rs, bin_shift, filter,
-                           slot_offsets, partials, slot_flags, magnitude_image, debug_hits, tile_order);
-    else
-        hipLaunchKernelGGL((blend_backward_kernel<STAGED, false>), grid, dim3(BLEND_THREADS), 0, s, bin_start, payload,
-                           attrs, grad_image, acc_alpha, last_effective, width, height, rb, rs, bin_shift, filter,
-                           slot_offsets, partials, slot_flags, magnitude_image, debug_hits, tile_order);
+                            float *magnitude_image, uint32_t *debug_hits, const int32_t *tile_order, bool skewed) {
+    constexpr int ARM = STAGED ? GS_BWD_REDUCE_STAGED : GS_BWD_REDUCE_DIRECT;
+#define GS_BWD_LAUNCH(DBG, REDUCE)                                                                                   \
+    hipLaunchKernelGGL((blend_backward_kernel<STAGED, DBG, REDUCE>), grid, dim3(BLEND_THREADS), 0, s, bin_start,       \
+                       payload, attrs, grad_image, acc_alpha, last_effective, width, height, rb, rs, bin_shift, filter, \
+                       slot_offsets, partials, slot_flags, magnitude_image, debug_hits, tile_order)
+    if (skewed && GS_BWD_REDUCE_SKEWED != ARM) {   // (GS_BLEND_SKEWED_WALKS: see GS_BWD_REDUCE_SKEWED)
+        if (debug) GS_BWD_LAUNCH(true, GS_BWD_REDUCE_SKEWED); else GS_BWD_LAUNCH(false, GS_BWD_REDUCE_SKEWED);
+    } else {
+        if (debug) GS_BWD_LAUNCH(true, ARM); else GS_BWD_LAUNCH(false, ARM);
+    }
+#undef GS_BWD_LAUNCH
 }
 
 }  // namespace
@@ -2579,11 +2593,13 @@ int gs_blend_backward_split(const int32_t *bin_start, const int32_t *payload, co
     } else if (staged)
         launch_backward<true>(debug_pixel_hits != nullptr, grid, s, bin_start, payload, a4, grad_image, acc_alpha,
                               last_effective, width, height, tile_row_begin, tile_row_step, bin_shift, filter,
-                              slot_offsets, p4, slot_flags, magnitude_image, debug_pixel_hits, tile_order);
+                              slot_offsets, p4, slot_flags, magnitude_image, debug_pixel_hits, tile_order,
+                              (flags & GS_BLEND_SKEWED_WALKS) != 0);
     else
         launch_backward<false>(debug_pixel_hits != nullptr, grid, s, bin_start, payload, a4, grad_image, acc_alpha,
                                last_effective, width, height, tile_row_begin, tile_row_step, bin_shift, filter,
-                               slot_offsets, p4, slot_flags, magnitude_image, debug_pixel_hits, tile_order);
+                               slot_offsets, p4, slot_flags, magnitude_image, debug_pixel_hits, tile_order,
+                               (flags & GS_BLEND_SKEWED_WALKS) != 0);
     GS_CHECK_LAUNCH();
     return 0;
 }

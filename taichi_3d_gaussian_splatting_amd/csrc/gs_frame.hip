@@ -170,7 +170,7 @@ int gs_frame_backward(GsFrame *f, uint32_t stages, void *stream) {
             f->list_start, f->list_payload, attrs, f->grad_image, f->acc_alpha, f->last_effective, f->slot_offsets, f->n_slots,
             f->width, f->height, f->tile_row_begin, f->tile_row_step, f->tile_row_end, f->backward_bin_shift,
             f->backward_filter, f->partials, f->slot_flags, f->magnitude_image, nullptr,
-            f->blend_flags & (GS_BLEND_TWO_WAVES | GS_BLEND_FOUR_WAVES | GS_BLEND_ONE_WAVE), f->tile_work, f->tile_order_backward,
+            f->blend_flags & (GS_BLEND_TWO_WAVES | GS_BLEND_FOUR_WAVES | GS_BLEND_ONE_WAVE | GS_BLEND_SKEWED_WALKS), f->tile_work, f->tile_order_backward,
             f->boundary_states != nullptr ? f->image : nullptr, f->boundary_states, f->n_keys_capacity, f->split_workspace,
             stream));
     if (stages & GS_BWD_REDUCE)

@@ -201,6 +201,37 @@ def forward(outer, xyz, features, invalid, obj, intrinsics, q_pc, t_pc, camera_i
     return image, depth, count, state, host
 
 
+SKEW_PROBE_EVERY = 16   # frames of one image size between two looks at the walk lengths
+SKEW_RATIO = 5.0        # longest walk / mean walk above which a frame counts as skewed (headline scene 2.6, trained scene 10.4)
+
+
+def walk_skew(outer, slab, layout, width: int, height: int, device) -> bool:
+    """Are this image size's walk lengths skewed?  Every SKEW_PROBE_EVERY-th frame (max, sum) of the forward's tile_work goes
+    to pinned host memory with an asynchronous copy; the answer in force is the last one that has ARRIVED (an event query,
+    never a wait): a frame or two late, which is fine for a property of the scene.  Until the first answer: not skewed."""
+    if getattr(outer, "backward_form_by_walk_skew", True) is False:
+        return False
+    probes = outer.__dict__.setdefault("_walk_skew", {})
+    p = probes.get((width, height, device))
+    if p is None:
+        p = probes[(width, height, device)] = {"frames": 0, "skewed": False, "pending": None,
+                                               "host": torch.empty(2, dtype=torch.int64, pin_memory=True),
+                                               "event": torch.cuda.Event()}
+    if p["pending"] is not None and p["event"].query():
+        mx, total, tiles = int(p["host"][0]), int(p["host"][1]), p["pending"]
+        p["skewed"] = bool(total > 0 and mx * tiles > SKEW_RATIO * total)
+        p["pending"] = None
+    if p["frames"] % SKEW_PROBE_EVERY == 0 and p["pending"] is None:
+        tiles = hip_ops.num_owned_tiles(width, height, layout)
+        if tiles > 0:
+            work = slab.tensor("tile_work", torch.int32, (tiles,))
+            p["host"].copy_(torch.stack((work.max().to(torch.int64), work.sum(dtype=torch.int64))), non_blocking=True)
+            p["event"].record(torch.cuda.current_stream(device))
+            p["pending"] = tiles
+    p["frames"] += 1
+    return p["skewed"]
+
+
 def backward(outer, state: FrameState, grad_image: torch.Tensor, hook, hook_input_type, want_feature_copy: bool):
     """-> (grad_point_cloud, grad_point_cloud_features); calls the hook (RAS:1127-1142)."""
     f, slab = state.frame, state.slab
@@ -245,6 +276,11 @@ def backward(outer, state: FrameState, grad_image: torch.Tensor, hook, hook_inpu
                       point_uv_in_camera=compact[5 * m:7 * m].view(m, 2))
     stream = _lib.current_stream(dev)
     S_ = _lib.STAGES
+    # the form of the two-wave backward kernel: skewed walk lengths (a few tiles walk many times the mean: trained scenes) want
+    # the one with the shorter chain per hit entry (include/gsplat_hip.h GS_BLEND_SKEWED_WALKS) -- decided from the walk
+    # lengths the forward pass recorded, sampled every few frames (walk_skew below: no host wait, ever)
+    skewed = walk_skew(outer, slab, state.layout, width, height, dev) if f.tile_work else False
+    f.blend_flags = (f.blend_flags & ~hip_ops.BLEND_SKEWED_WALKS) | (hip_ops.BLEND_SKEWED_WALKS if skewed else 0)
     reduce_hook = outer.grad_accumulator_reduce
     if reduce_hook is None:
         f.acc = _ws_bytes(ws, "f_acc", 48 * max(m, 1), dev)

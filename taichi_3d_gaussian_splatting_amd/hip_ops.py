@@ -391,7 +391,8 @@ def tile_ranges(keys_sorted: torch.Tensor, num_tiles: int, key_depth_bits: int =
 
 BLEND_RGB_ONLY = 1      # include/gsplat_hip.h GS_BLEND_RGB_ONLY: no depth / per-pixel count (RAS:464-469,478-484)
 BLEND_NO_STATE = 2      # GS_BLEND_NO_STATE: no acc_alpha / last_effective (nothing will be back-propagated)
-BLEND_ARMS = {None: 0, "two_waves": 4, "four_waves": 8, "one_wave": 16}   # GS_BLEND_TWO_WAVES / _FOUR_WAVES / _ONE_WAVE (None: by tile count)
+BLEND_ARMS = {None: 0, "two_waves": 4, "four_waves": 8, "one_wave": 16,   # GS_BLEND_TWO_WAVES / _FOUR_WAVES / _ONE_WAVE (None: by tile count)
+              "two_waves_skewed": 4 | 64}                                 # ... | GS_BLEND_SKEWED_WALKS (backward: sums in registers)
 
 
 SPLIT_GRID_TILES = 1024          # csrc/gs_blend.hip backward_split_for: grids up to this many tiles get a split backward
@@ -419,6 +420,7 @@ def split_workspace(ws: Workspaces, width: int, height: int, device) -> torch.Te
 
 
 BLEND_SPLIT_FORWARD = 32   # GS_BLEND_SPLIT_FORWARD
+BLEND_SKEWED_WALKS = 64    # GS_BLEND_SKEWED_WALKS
 
 
 def forward_split_bytes(width: int, height: int, layout: ListLayout, force: bool = False) -> int:

@@ -975,7 +975,7 @@ def test_one_wave_per_tile_backward(ops, workload):
     g = make_grad_image(s.height, s.width).cuda()
     fwd = ops.blend_forward(st["start"], st["end"], st["payload"], st["attrs"], s.width, s.height, st["layout"], arm="two_waves")
     part = {}
-    for arm in ("two_waves", "one_wave", "one_wave_again", None):
+    for arm in ("two_waves", "one_wave", "one_wave_again", None, "two_waves_skewed"):
         part[arm] = ops.blend_backward_partials(st["start"], st["payload"], st["attrs"], g, fwd[2], fwd[3], st["slot_offsets"],
                                                 st["n_slots"], s.width, s.height, st["layout"], debug_hits=True,
                                                 arm=None if arm is None else arm.replace("_again", ""))
@@ -992,6 +992,15 @@ def test_one_wave_per_tile_backward(ops, workload):
     report(f"one_wave.{workload}", tiles=(s.width // 16) * (s.height // 16), max_scaled_difference_of_sums=worst)
     assert worst < 2e-6
     assert torch.equal(part[None][2], m1) and torch.equal(part[None][1], f1)
+    # GS_BLEND_SKEWED_WALKS: the two-wave kernel with its cross-lane sums in registers (what the operator picks for frames with
+    # skewed walk lengths): the same pairs, flags, counts and |grad uv| image, sums equal to rounding
+    ps, fs, ms, ds = part["two_waves_skewed"]
+    assert torch.equal(ds, d2) and torch.equal(fs, f2) and torch.equal(ms, m2)
+    assert torch.equal(ps[raised][:, 10].contiguous().view(torch.int32), p2[raised][:, 10].contiguous().view(torch.int32))
+    a_s = ops.reduce_partials(st["slot_offsets"], st["ntiles"], fs, ps)
+    worst_s = float(((a_s[:, :10] - a2[:, :10]).abs() / scale).max())
+    report(f"two_waves_skewed.{workload}", max_scaled_difference_of_sums=worst_s)
+    assert worst_s < 2e-6
 
 
 @pytest.mark.parametrize("size,n,bin_shift", [(256, 10_000, 0), (512, 60_000, 0), (128, 6_000, 0), (400, 2_000, 0)])
