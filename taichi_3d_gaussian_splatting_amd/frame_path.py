@@ -15,6 +15,7 @@ an event while the GPU works): a frame that does not fit is redone by the stage-
 from __future__ import annotations
 
 import ctypes
+import os
 from typing import Optional
 
 import torch
@@ -221,6 +222,8 @@ def walk_skew(outer, slab, layout, width: int, height: int, device) -> bool:
         mx, total, tiles = int(p["host"][0]), int(p["host"][1]), p["pending"]
         p["skewed"] = bool(total > 0 and mx * tiles > SKEW_RATIO * total)
         p["pending"] = None
+        if os.environ.get("GS_DEBUG_SKEW"):
+            print(f"[walk_skew] frame {p['frames']} {width}x{height}: max {mx} sum {total} tiles {tiles} -> {p['skewed']}", flush=True)
     if p["frames"] % SKEW_PROBE_EVERY == 0 and p["pending"] is None:
         tiles = hip_ops.num_owned_tiles(width, height, layout)
         if tiles > 0:
