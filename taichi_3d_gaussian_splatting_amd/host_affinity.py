@@ -126,23 +126,25 @@ def pin_host_threads(device_index: int = 0, slot: Optional[int] = None) -> Optio
 
 
 def _stable_device_slot(device_index: int) -> int:
-    """A slot for a process that was given no LOCAL_RANK: the device index -- unless the devices were narrowed with
-    HIP_VISIBLE_DEVICES / CUDA_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES (then every process sees "device 0" and all of them would
-    take the same complex): in that case the PHYSICAL device's position, read from the visibility list or, failing that, from
-    its PCI bus id."""
+    """A slot for a process that was given no LOCAL_RANK: the PHYSICAL device's identity, not its index in this process.
+    Devices are narrowed with HIP_VISIBLE_DEVICES / CUDA_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES, or by a container that shows
+    every pod its one GPU as "0" (round 6: four pods of one host, each with HIP_VISIBLE_DEVICES=0 in its own device namespace,
+    all took the first complex of the same socket -- CPUs 0-7 -- and stalled one another's host threads for milliseconds at
+    a time): so the device's PCI bus number first -- what the hardware says --, then the position the visibility list names,
+    then the index."""
+    try:
+        import torch
+        bus = getattr(torch.cuda.get_device_properties(device_index), "pci_bus_id", None)
+        if bus is not None:
+            return int(bus)
+    except Exception:
+        pass
     for var in ("HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES"):
         text = os.environ.get(var, "")
         if text:
             entries = [e.strip() for e in text.split(",") if e.strip()]
             if 0 <= device_index < len(entries) and entries[device_index].isdigit():
                 return int(entries[device_index])
-            try:
-                import torch
-                bus = getattr(torch.cuda.get_device_properties(device_index), "pci_bus_id", None)
-                if bus is not None:
-                    return int(bus)
-            except Exception:
-                pass
             break
     return int(device_index)
 

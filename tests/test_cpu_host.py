@@ -214,5 +214,15 @@ def test_host_affinity_picks_one_l3_complex_per_local_rank(monkeypatch):
         assert calls == [(101, set(range(32))), (102, set(range(32)))] and torch.get_num_threads() == before
         monkeypatch.setenv("GS_PIN_HOST_THREADS", "0")
         assert h.pin_host_threads(0) is None
+        # a pod that shows its one GPU as "0" (HIP_VISIBLE_DEVICES=0 in every container of the host): the slot is the
+        # device's PCI bus number, not the list's "0" -- two pods of one socket do not share a complex
+        monkeypatch.delenv("GS_PIN_HOST_THREADS")
+        monkeypatch.setenv("HIP_VISIBLE_DEVICES", "0")
+        import types
+        monkeypatch.setattr(torch.cuda, "get_device_properties", lambda i: types.SimpleNamespace(pci_bus_id=0x0B))
+        assert h._stable_device_slot(0) == 0x0B
+        assert h.pin_host_threads(0) == chosen                       # 11 % 2 complexes of the GPU's socket = the second one
+        monkeypatch.setattr(torch.cuda, "get_device_properties", lambda i: types.SimpleNamespace())
+        assert h._stable_device_slot(0) == 0                         # no bus number: the visibility list's entry
     finally:
         torch.set_num_threads(before)
