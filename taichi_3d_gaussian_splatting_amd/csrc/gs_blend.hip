@@ -1955,6 +1955,10 @@ __global__ __launch_bounds__(SMALL_THREADS) void blend_forward_combine_kernel(
                 float4 *st = boundary + ((size_t)(pos >> 7) * 256 + tid) * 2;
                 float4 a = st[0], b = st[1];
                 float sum;
+                // a pixel the reference stopped in an earlier segment: the state behind its stop is its FINAL transmittance (what
+                // the un-split walk keeps, and what a backward segment whose upper cut lies behind the pixel's last blended entry
+                // starts it from) -- this segment only knew the product of the probes, stopping factor included
+                if (r2.w == 0.f) a.x = T;
                 b.x += E[0] + gs_two_sum(C[0], a.y, sum); a.y = sum;
                 b.y += E[1] + gs_two_sum(C[1], a.z, sum); a.z = sum;
                 b.z += E[2] + gs_two_sum(C[2], a.w, sum); a.w = sum;

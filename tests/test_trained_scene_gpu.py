@@ -84,3 +84,44 @@ def test_trained_scene_against_the_oracle(trained):
     h = hooks[-1]
     assert np.array_equal(h.point_id_in_camera_list.cpu().numpy(), f["ids"])
     assert np.array_equal(h.num_overlap_tiles.cpu().numpy(), f["num_overlap_tiles"])
+
+
+def test_the_operator_picks_the_backward_form_by_the_walk_lengths(trained):
+    """frame_path.walk_skew: on the trained scene (a few tiles walk ten times the mean) the operator's sample of the forward's
+    recorded walk lengths arrives within a few frames and selects the register form of the two-wave backward kernel
+    (GS_BLEND_SKEWED_WALKS); on the evenly loaded headline-like scene it does not.  The two forms take the same decisions
+    and agree to rounding: the gradients of a frame rendered before and after the switch are the same to 1e-6."""
+    from taichi_3d_gaussian_splatting_amd import CameraInfo, GaussianPointCloudRasterisation as Op
+    from taichi_3d_gaussian_splatting_amd.synthetic import make_grad_image, make_scene
+
+    def run(scene, frames, by_skew=True):
+        s = scene.to("cuda")
+        g = make_grad_image(s.height, s.width).cuda()
+        op = Op(Op.GaussianPointCloudRasterisationConfig(near_plane=s.near_plane, far_plane=s.far_plane,
+                                                         depth_to_sort_key_scale=s.depth_to_sort_key_scale))
+        op.backward_form_by_walk_skew = by_skew
+        grads = []
+        for _ in range(frames):
+            xyz = s.point_cloud.clone().requires_grad_(True)
+            feat = s.point_cloud_features.clone().requires_grad_(True)
+            inp = Op.GaussianPointCloudRasterisationInput(
+                point_cloud=xyz, point_cloud_features=feat, point_object_id=s.point_object_id,
+                point_invalid_mask=s.point_invalid_mask, camera_info=CameraInfo(s.camera_intrinsics, s.height, s.width, 0),
+                q_pointcloud_camera=s.q_pointcloud_camera, t_pointcloud_camera=s.t_pointcloud_camera, color_max_sh_band=3)
+            image, _, _ = op(inp)
+            (image * g).sum().backward()
+            torch.cuda.synchronize()
+            grads.append(feat.grad.clone())
+        probes = op.__dict__.get("_walk_skew", {})
+        return grads, [p["skewed"] for p in probes.values()]
+
+    grads, skewed = run(trained["scene"], 5)
+    assert skewed == [True]
+    plain, none = run(trained["scene"], 2, by_skew=False)
+    assert none == []                                            # (switched off: no probe at all)
+    rel = rel_l2(grads[-1].cpu().numpy(), plain[-1].cpu().numpy())
+    report("trained_scene.backward_forms", rel_l2_of_feature_gradients=rel)
+    assert rel < 1e-6
+    even = make_scene(n=200_000, height=1072, width=1920, s_min=0.004, s_max=0.02, seed=11)
+    _, skewed = run(even, 4)
+    assert skewed == [False]
