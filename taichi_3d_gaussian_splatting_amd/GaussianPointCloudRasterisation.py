@@ -179,10 +179,11 @@ class GaussianPointCloudRasterisation(torch.nn.Module):
         # above 3,840 tiles; below, the per-tile lists let the backward take the four-waves-per-tile form, whose slot sums
         # add the same per-pixel terms in another order)
         self.backward_on_walked_lists = True
-        # per-pass entry points: the two-wave backward blend in the form that suits the frame's walk lengths -- sums through LDS
-        # (throughput) on evenly loaded frames, in registers (shorter chain per hit entry) when a few tiles walk many times
-        # the mean (trained scenes: -11 % of the kernel); the walk lengths are sampled every 16th frame without a host wait
-        # (frame_path.walk_skew).  Same decisions either way, sums equal to rounding
+        # per-pass entry points: the blend kernels in the forms that suit the frame's walk lengths.  Evenly loaded frames: two
+        # waves per tile, the backward's sums through LDS (throughput).  Frames where a few tiles walk many times the mean
+        # (trained scenes) last as long as those tiles' chains: the forward pass with four waves per tile (-14 % of the
+        # kernel; bit-identical outputs), the backward's sums in registers (-11 %).  The walk lengths are sampled every 16th
+        # frame without a host wait (frame_path.walk_skew).  Same decisions either way, sums equal to rounding
         self.backward_form_by_walk_skew = os.environ.get("GS_BWD_FORM_BY_SKEW", "1") != "0"   # (the switch: A/B measurements)
         # the forward writes a normalised quaternion back only when the stored one differs (RAS:196-205: same memory
         # contents).  True = always write: what a training iteration pays -- the optimiser has just moved q -- for
