@@ -84,3 +84,50 @@ def test_alpha_bound_between_kernel_and_reference():
         worst = float((d / bound).max())
         print(f"[parity] alpha_bound.{name}: largest distance / proven bound = {worst:.3f} over {int(ok.sum())} pairs")
         assert worst <= 1.0, (name, worst)
+
+
+def test_the_exponent_bound_of_the_hit_test_is_on_the_safe_side():
+    """Round 6 (csrc/gs_common.h, "the 1/255 decision in the exponent's domain"): the blend kernels skip a (pixel, Gaussian) pair
+    whose exponent is below ``e_lo = L~ - h``, ``L~ = -logf(255 amp)``, ``h = 4/3 u (6 + 4 |L~|)``, BEFORE evaluating any
+    exponential.  That is only right if the reference never blends such a pair.  For random (opacity, rescale) the exact
+    threshold e* of the reference's decision -- the smallest fp32 exponent with fl(fl(exp_cr(e) rescale) opacity) >= fl(1/255),
+    found by bisection over the fp32 numbers, the reference's alpha being monotone in e -- must lie at or above e_lo, and not
+    far above it (the uncertain zone [e_lo, e*) is what costs exact re-evaluations: a few 1e-6 wide).  NumPy's float32 log
+    stands in for the device's logf (both within an ulp or two of the true value: the bound charges two)."""
+    rng = np.random.default_rng(3)
+    n = 200_000
+    opacity = rng.uniform(1e-3, 1.0, n).astype(f32)
+    rescale = np.concatenate([rng.uniform(0.05, 1.0, n // 2), np.exp(rng.uniform(np.log(1e-6), 0.0, n - n // 2))]).astype(f32)
+    amp = (opacity * rescale).astype(f32)
+    L = (-np.log((f32(255.0) * amp).astype(f32))).astype(f32)
+    e_lo = (L - f32(4.0 / 3.0) * f32(U) * (f32(6.0) + f32(4.0) * np.abs(L))).astype(f32)
+    eps = f32(1.0 / 255.0)
+
+    def reference_hits(e):   # UTL:284 then RAS:447, exp correctly rounded (double exp rounded once)
+        return ((np.exp(e.astype(np.float64)).astype(f32) * rescale).astype(f32) * opacity).astype(f32) >= eps
+
+    # bisection on the ordered integers behind the fp32 values of [-30, 30]
+    def to_ord(x):
+        i = x.view(np.int32).astype(np.int64)
+        return np.where(i < 0, np.int64(-(2 ** 31)) - i - 1 + 0, i)
+
+    def from_ord(o):
+        i = np.where(o < 0, np.int64(-(2 ** 31)) - o - 1, o).astype(np.int32)
+        return i.view(f32)
+    lo, hi = to_ord(np.full(n, -30.0, f32)), to_ord(np.full(n, 30.0, f32))
+    assert not reference_hits(from_ord(lo)).any() and reference_hits(from_ord(hi)).all()
+    while (hi - lo > 1).any():
+        mid = (lo + hi) // 2
+        hit = reference_hits(from_ord(mid))
+        hi = np.where(hit, mid, hi)
+        lo = np.where(hit, lo, mid)
+    e_star = from_ord(hi)                        # the smallest exponent the reference blends
+    assert reference_hits(e_star).all() and not reference_hits(from_ord(hi - 1)).any()
+    assert (e_lo <= e_star).all(), float((e_lo - e_star).max())
+    zone = (e_star.astype(np.float64) - e_lo.astype(np.float64))
+    print(f"[parity] hit_exponent_bound: uncertain zone below the reference's threshold: max {zone.max():.2e}, mean {zone.mean():.2e} "
+          f"(|L| up to {float(np.abs(L).max()):.1f})")
+    assert zone.max() < 4e-5 and zone.mean() < 1e-5
+    # and the margin actually left (in units of the bound h): the proof charges 6 u + 4 u |L|, the model needs far less
+    h = f32(4.0 / 3.0) * U * (6.0 + 4.0 * np.abs(L.astype(np.float64)))
+    assert ((e_star.astype(np.float64) - e_lo) / h).min() > 0.05
