@@ -178,6 +178,8 @@ def test_random_scene_against_the_oracle(case):
                                    camera_width=s.width, camera_id=0),
             q_pointcloud_camera=s.q_pointcloud_camera, t_pointcloud_camera=s.t_pointcloud_camera,
             color_max_sh_band=band)
+        # (the list layout this frame runs with: the pinned one, or what the operator learnt from the frame before)
+        shift_used = opt["bin_shift"] if opt["bin_shift"] is not None else op._auto_bin_shift
         image, depth, count = op(inp)
         (image * torch.from_numpy(g).cuda()).sum().backward()
         tag = f"case {case} frame {frame} ({scene.width}x{scene.height}, n={xyz.shape[0]}, M={len(f['ids'])}, band {band}, " \
@@ -209,8 +211,12 @@ def test_random_scene_against_the_oracle(case):
             assert np.array_equal(h.point_uv_in_camera.cpu().numpy(), ho["point_uv_in_camera"]), tag
             npix = h.num_affected_pixels.cpu().numpy()
             assert np.array_equal(npix, ho["num_affected_pixels"]), tag
-    # inference paths: no backward state (torch.no_grad), and rgb_only -- the same image, bit for bit
+    # inference paths: no backward state (torch.no_grad), and rgb_only -- the same image, bit for bit, ON THE SAME LIST LAYOUT
+    # (per-tile lists on a grid of at most 320 tiles take the split forward pass, whose image is the un-split one to rounding,
+    # not to the bit: an automatic layout that moved to bins for the second frame -- three of the 1,500 draws 14000-15499 --
+    # must not be compared with a fresh operator's per-tile first frame)
     # (fresh copies of the features: the in-place normalisation of an already normalised quaternion may move its last bit)
+    op.bin_shift = shift_used
     inp.point_cloud_features = s.point_cloud_features.clone()
     with torch.no_grad():
         image_ng, depth_ng, count_ng = op(inp)
@@ -218,7 +224,7 @@ def test_random_scene_against_the_oracle(case):
     assert torch.equal(image_ng, image) and torch.equal(depth_ng, depth) and torch.equal(count_ng, count), f"case {case}: no_grad"
     op_rgb = Op(Op.GaussianPointCloudRasterisationConfig(near_plane=s.near_plane, far_plane=s.far_plane,
                                                          depth_to_sort_key_scale=s.depth_to_sort_key_scale, rgb_only=True))
-    op_rgb.bin_shift, op_rgb.exact_tile_cull = opt["bin_shift"], opt["exact_tile_cull"]
+    op_rgb.bin_shift, op_rgb.exact_tile_cull = shift_used, opt["exact_tile_cull"]
     with torch.no_grad():
         image_rgb, depth_rgb, count_rgb = op_rgb(inp)
     assert torch.equal(image_rgb, image) and not depth_rgb.any() and not count_rgb.any(), f"case {case}: rgb_only"
