@@ -411,6 +411,25 @@ __device__ __forceinline__ void gs_view_colour(const float W[9], const float t[3
     }
 }
 
+// ------------------------------------------------------------------ streaming accesses
+// The non-temporal hint for the two big streams of a frame that nothing on the device reads again: the 192 B of SH
+// coefficients per Gaussian the projection reads (gs_wave_view_colours) and the dense + compact gradient rows the per-point
+// backward writes (gs_rows_lds_to_global: 428 MB at the headline size).  Without it they evict what IS read again -- the
+// records, the next frame's rows -- from L2 and the memory-side cache.  Measured (round 6, same box, rocprofv3 averages):
+// preprocess_kernel 113 -> 94-97 us, point_backward_kernel 130 -> 119-126 us, frame 1.077-1.082 -> 1.050-1.058 ms.
+// NOT for data the next kernel reads: the slot records with the hint made reduce_partials_kernel 52 -> 67 us (they come
+// back out of the memory-side cache otherwise); accumulator rows, record rows and the per-pixel outputs: no gain or a loss
+// (profiles/r06_streaming_hints.md).
+typedef float gs_f4_native __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void gs_store_stream(float4 *p, const float4 v) {
+    const gs_f4_native nv = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(nv, reinterpret_cast<gs_f4_native *>(p));
+}
+__device__ __forceinline__ float4 gs_load_stream(const float4 *p) {
+    const gs_f4_native nv = __builtin_nontemporal_load(reinterpret_cast<const gs_f4_native *>(p));
+    return make_float4(nv.x, nv.y, nv.z, nv.w);
+}
+
 // ------------------------------------------------------------------ coalesced access to 224-B feature rows
 // The feature matrix is AoS (56 floats = 14 x 16 B per Gaussian, owned by the caller).  A lane writing its own
 // row with 16-B stores makes every store instruction touch 64 different cache lines.  Instead the wave moves its
@@ -428,7 +447,7 @@ __device__ __forceinline__ void gs_rows_lds_to_global(float4 *__restrict__ base,
     for (int it = 0; it < 16; ++it) {
         const int rr = it * 4 + sub;
         const int rid = __shfl(my_row_id, rr & 63, GS_WAVE);
-        if (lane < 56 && rid >= 0) base[(size_t)rid * 14 + c] = rows[rr * GS_ROW_F4 + c];
+        if (lane < 56 && rid >= 0) gs_store_stream(base + (size_t)rid * 14 + c, rows[rr * GS_ROW_F4 + c]);
     }
 }
 

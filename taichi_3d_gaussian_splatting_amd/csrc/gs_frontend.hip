@@ -449,7 +449,7 @@ __device__ __forceinline__ void gs_wave_view_colours(bool wants, int id, const f
             const int g = (it0 + k) * 4 + (lane >> 4);                 // the Gaussian (lane of this wave) served
             const int gid = __shfl(id, g, GS_WAVE);
             const bool on = ((need >> g) & 1ull) != 0ull && sub < 12;
-            c4[k] = on ? reinterpret_cast<const float4 *>(feat + (size_t)GS_FEATURE_DIM * gid)[2 + sub]
+            c4[k] = on ? gs_load_stream(reinterpret_cast<const float4 *>(feat + (size_t)GS_FEATURE_DIM * gid) + 2 + sub)
                        : make_float4(0.f, 0.f, 0.f, 0.f);
         }
 #pragma unroll
