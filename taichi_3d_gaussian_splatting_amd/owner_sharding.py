@@ -406,18 +406,20 @@ class OwnerShardedRasteriser:
         fr.n_slots, fr.n_keys = int(n_slots), int(n_keys)
         fr.layout_bwd = hip_ops.walked_layout(layout) if fr.walked else layout
         fr.outputs = (image, depth, count)
-        # next frame's list layout: the single-GPU operator's rule on this band's key count scaled to the whole image
+        # next frame's list layout: the single-GPU operator's rule -- its absolute thresholds on this band's key count scaled
+        # to the whole image, its keys-per-Gaussian thresholds on the band's own keys and records (both are the band's: scaling
+        # one of them made an ordinary G = 8 band of the headline frame, 2.1 keys per record, look like the stress distribution)
         owned = max(len(layout.owned_rows(height)), 1)
         k_frame = n_keys * (height // TILE) / owned
         m = max(n_rec, 1)
         used = layout.bin_shift
         if n_keys > 0:
             if used == 0:
-                self._auto_bin_shift = 2 if k_frame >= 64 * m else (1 if k_frame >= 2_000_000 else 0)
+                self._auto_bin_shift = 2 if n_keys >= 64 * m else (1 if k_frame >= 2_000_000 else 0)
             elif used == 1:
-                self._auto_bin_shift = 2 if k_frame >= 16 * m else (0 if k_frame < 700_000 else 1)
+                self._auto_bin_shift = 2 if n_keys >= 16 * m else (0 if k_frame < 700_000 else 1)
             else:
-                self._auto_bin_shift = 1 if k_frame < 3 * m else used
+                self._auto_bin_shift = 1 if n_keys < 3 * m else used
         fr.stats.update(records_received=n_rec, keys=fr.n_keys, slots=fr.n_slots, bin_shift=used,
                         speculative=bool(guess), fits=fits)
         return fr.outputs

@@ -28,7 +28,8 @@ FIRST = int(os.environ.get("GS_FUZZ_FIRST", "0"))
 # fp32 oracle) 2.8e-5 / 2.1e-5 on ordinary scenes, 4.1e-5 / 5.8e-5 on ill-conditioned ones.  (Round 3, before the decisions
 # were exact: one flipped pixel per ~600 draws, ill-conditioned scenes 4.6e-4 / 2.4e-3 / 5.5e-4 from the fp32 oracle.)
 # Sharded vs un-sharded gradients 4.2e-5.  Round 6 (exponent-domain hit test, split forward on grids of at most 320 tiles): 2,100
-# more draws (12000-12299, 13000-13299, 14000-15499): counts equal everywhere, image 6.6e-7, depth 3.6e-6
+# more draws (12000-12299, 13000-13299, 14000-15499), then 1,900 on the last library (17000-17399, 18000-19499): counts equal
+# everywhere, image 8.3e-7, depth 4.5e-6, sharded vs un-sharded gradients 7.2e-5
 # (profiles/r06_fuzz_14000_15500.md).
 PIXEL_TOL = 1e-4            # north star, every pixel (observed round 5: 4.2e-7 over 240 draws)
 GRAD_TOL = 1e-4             # rel-L2 of the dense gradients (ordinary scenes: upstream gradient on every pixel)
