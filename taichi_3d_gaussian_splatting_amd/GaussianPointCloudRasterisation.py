@@ -518,14 +518,8 @@ class GaussianPointCloudRasterisation(torch.nn.Module):
         owned = len(layout.owned_rows(height))
         k_frame = n_keys * ((height // TILE_HEIGHT) / owned if owned else 1.0)
         used = layout.bin_shift
-        if m == 0:
-            choice = used       # nothing on screen: no information
-        elif used == 0:
-            choice = 2 if k_frame >= 64 * m else (1 if k_frame >= 2_000_000 else 0)
-        elif used == 1:
-            choice = 2 if k_frame >= 16 * m else (0 if k_frame < 700_000 else 1)
-        else:
-            choice = 1 if k_frame < 3 * m else used
+        # (the replicated cloud's M is the whole frame's: it goes with the key count scaled to the whole frame)
+        choice = hip_ops.next_bin_shift(used, k_frame, k_frame, m)
         outer._auto_bin_shift = choice
         if len(outer._auto_bin_shift_by_size) >= 64 and (width, height) not in outer._auto_bin_shift_by_size:
             outer._auto_bin_shift_by_size.pop(next(iter(outer._auto_bin_shift_by_size)))   # bounded

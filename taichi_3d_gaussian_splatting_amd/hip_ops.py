@@ -106,6 +106,23 @@ class Workspaces:
 WALKED_LIST_MAX_BYTES = 512 << 20   # above this a binned frame keeps the staged (re-filtering) backward
 
 
+def next_bin_shift(used: int, keys_whole_image: float, keys: float, gaussians: int) -> int:
+    """The automatic list layout of the NEXT frame from this frame's key count, with hysteresis (one rule for the operator
+    and for a band of the owner mode).  `keys_whole_image`: the emitted (bin, Gaussian) keys in the layout `used`, scaled to
+    the whole image when only some tile rows were rendered -- the absolute thresholds: per-tile keys -> 2 x 2-tile bins from
+    2e6 keys on (key generation + radix passes then cost more than the blend kernels pay for filtering), back below 0.7e6
+    bin keys.  `keys` / `gaussians`: keys and the Gaussians that emitted them, BOTH of the same region (the frame, or the
+    band) -- the keys-per-Gaussian thresholds: 4 x 4-tile bins once a Gaussian emits >= 64 tile keys / >= 16 bin keys on
+    average (lists dominated by pairs that are never blended: the reference's stress distribution), back below 3."""
+    if gaussians <= 0:
+        return used       # nothing on screen: no information
+    if used == 0:
+        return 2 if keys >= 64 * gaussians else (1 if keys_whole_image >= 2_000_000 else 0)
+    if used == 1:
+        return 2 if keys >= 16 * gaussians else (0 if keys_whole_image < 700_000 else 1)
+    return 1 if keys < 3 * gaussians else used
+
+
 def can_emit_walked_lists(n_keys: int, bin_shift: int) -> bool:
     """Whether a binned forward pass may write out its per-tile lists for the backward pass: the buffer holds
     (n_keys << 2 bin_shift) int32 -- the key capacity amplified by the tiles per bin -- and lives until the backward pass;

@@ -414,12 +414,7 @@ class OwnerShardedRasteriser:
         m = max(n_rec, 1)
         used = layout.bin_shift
         if n_keys > 0:
-            if used == 0:
-                self._auto_bin_shift = 2 if n_keys >= 64 * m else (1 if k_frame >= 2_000_000 else 0)
-            elif used == 1:
-                self._auto_bin_shift = 2 if n_keys >= 16 * m else (0 if k_frame < 700_000 else 1)
-            else:
-                self._auto_bin_shift = 1 if n_keys < 3 * m else used
+            self._auto_bin_shift = hip_ops.next_bin_shift(used, k_frame, n_keys, m)
         fr.stats.update(records_received=n_rec, keys=fr.n_keys, slots=fr.n_slots, bin_shift=used,
                         speculative=bool(guess), fits=fits)
         return fr.outputs

@@ -172,6 +172,28 @@ def test_list_layout_object():
     assert list(ListLayout(row_begin=60, row_end=100).owned_rows(1072)) == list(range(60, 67))
 
 
+def test_automatic_list_layout_rule():
+    """hip_ops.next_bin_shift: the one rule behind the operator's and the owner mode's automatic layout (thresholds of
+    GaussianPointCloudRasterisation._sizes_arrived's comment), with its hysteresis -- and the case that went wrong in round 6:
+    a G = 8 band of the headline frame (300k keys of 140k-178k record slots: about two keys per record) must not look like
+    the stress distribution because its key count was scaled to the whole image and its record count was not."""
+    from taichi_3d_gaussian_splatting_amd.hip_ops import next_bin_shift as nxt
+    m = 1_000_000
+    assert nxt(0, 1_900_000, 1_900_000, m) == 0 and nxt(0, 2_000_000, 2_000_000, m) == 1     # per tile -> 2 x 2 from 2e6 keys
+    assert nxt(1, 700_000, 700_000, m) == 1 and nxt(1, 699_999, 699_999, m) == 0             # ... back below 0.7e6 bin keys
+    assert nxt(0, 64 * 20_000, 64 * 20_000, 20_000) == 2 and nxt(1, 16 * 20_000, 16 * 20_000, 20_000) == 2   # stress distribution
+    assert nxt(2, 3 * 20_000 - 1, 3 * 20_000 - 1, 20_000) == 1 and nxt(2, 3 * 20_000, 3 * 20_000, 20_000) == 2
+    assert nxt(1, 5e6, 5e6, 0) == 1 and nxt(2, 0, 0, 0) == 2                                  # nothing on screen: keep
+    # the headline frame on one GPU (5.65e6 tile keys / 2.88e6 bin keys of 977,848 Gaussians) settles on 2 x 2 bins
+    assert nxt(0, 5_652_545, 5_652_545, 977_848) == 1 and nxt(1, 2_877_171, 2_877_171, 977_848) == 1
+    # one of eight bands of it in the owner mode: 301,626 keys of 178,696 record slots, 67 / 9 tile rows
+    band_keys, band_records = 301_626, 178_696
+    assert nxt(1, band_keys * 67 / 9, band_keys, band_records) == 1
+    # (with the scaled count on both sides the 16-keys-per-Gaussian threshold trips at 16 * 9 / 67 = 2.1 keys per record:
+    #  the same band with the 140,000 record slots of a smaller chunk capacity went to 4 x 4-tile bins)
+    assert nxt(1, band_keys * 67 / 9, band_keys * 67 / 9, 140_000) == 2 and nxt(1, band_keys * 67 / 9, band_keys, 140_000) == 1
+
+
 def test_host_affinity_picks_one_l3_complex_per_local_rank(monkeypatch):
     """host_affinity on a made-up two-socket box (no real affinity call): rank r's threads go to the r-th L3 complex of the
     GPU's NUMA node, PyTorch's intra-op pool is cut to its cores, unpin restores both."""
